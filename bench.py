@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Benchmark of the NeFeS render-and-refine hot path on MI355X (BASELINE.json metric).
+
+One "step" = one full render() forward + backward to the 3x4 camera pose over one synthetic frame:
+640x480 rays, 64 coarse + 128 importance samples, 8x256 MLP with a 16-channel feature head, random
+(seed-0) weights, loss = mean(feat^2) + mean(rgb^2)  (SURVEY.md §8d).  With N GPUs the frame's rows
+are sharded across ranks (strong scaling) and the only collective is the 48-byte pose-gradient
+all-reduce.  Prints ONE JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic MACs per sample (frozen weights => backward = dX only = forward MACs)
+def macs_sigma(W):
+    return 63 * W + 3 * W * W + (W + 63) * W + 3 * W * W + W
+
+
+def macs_full(W, C):
+    h = W // 2
+    return macs_sigma(W) + W * W + (W + 27) * h + h * (3 + C) + (W + 27) * h + 2 * h * h + 5 * h
+
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def cpu_baseline(Wd, C, Nc, Ni, n_rows, W, focal):
+    """The CPU oracle (same torch op sequence as the reference) on a bounded slice of the same workload."""
+    from oracle import ref_cpu as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    pc, pf = O.make_field_params("coarse", Wd, C), O.make_field_params("fine", Wd, C)
+    cfg = O.RenderCfg(N_samples=Nc, N_importance=Ni)
+
+    def once():
+        c2w = O.bench_pose().requires_grad_()
+        # rows [0, n_rows) of the 480x640 frame: same geometry as the GPU workload
+        rays_o, rays_d = O.ray_bundle(480, W, focal, c2w)
+        rgb, _, _, ex = O.render(480, W, focal, pc, pf, cfg, rays=(rays_o[:n_rows], rays_d[:n_rows]), near=0., far=4.)
+        O.bench_loss(rgb, ex["feat_map"]).backward()
+        return c2w.grad
+
+    once()                                   # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    once()
+    dt = time.perf_counter() - t0
+    n = n_rows * W
+    return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n} rays (first {n_rows} rows of the 480x640 frame), fwd+bwd to pose, {Nc}+{Ni} samples, "
+                      f"8x{Wd} MLP, C={C}, torch {torch.__version__} CPU, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--cpu-rows", type=int, default=4, help="rows of the frame timed on the host cores (0 = skip)")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from nefes_amd import dist as D
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    from nefes_amd.render import render
+    from oracle import ref_cpu as O        # bench_pose()/bench_loss() definitions only; the CPU leg is cpu_baseline()
+
+    Wd, C, Nc, Ni = 256, 16, 64, 128
+    H, W = a.height, a.width
+    focal = 525.505 * W / 640.
+    coarse = NeRFH_NFF('coarse', W=Wd, f_dim=C).requires_grad_(False).to(dev)
+    fine = NeRFH_NFF('fine', W=Wd, f_dim=C, encode_appearance=True, encode_transient=True).requires_grad_(False).to(dev)
+    args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True, netchunk=1 << 21)
+    kw = dict(network_query_fn=None, perturb=False, N_importance=Ni, N_samples=Nc, network_fn=coarse, network_fine=fine,
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=True, args=args, ndc=False, lindisp=False)
+    pose = O.bench_pose().to(dev)
+    row0, nrows = D.row_shard(H, rank, world)
+    n_total = H * W
+
+    def step():
+        c2w = pose.clone().requires_grad_()
+        rgb, disp, acc, ex = render(H, W, focal, c2w=D.replicate_pose(c2w), near=0., far=4., row_range=(row0, nrows), **kw)
+        feat = ex["feat_map"]
+        loss = (feat ** 2).sum() / (n_total * C) + (rgb ** 2).sum() / (n_total * 3)   # = mean over the full frame
+        loss.backward()                                                               # pose all-reduce happens here
+        return c2w.grad
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    ops.TIMERS = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        g = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timers, ops.TIMERS = ops.TIMERS, None
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        value = n_total * a.steps / dt
+        kern = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in timers.items()}   # ms per launch, rank 0
+        rays_local = nrows * W
+        # dominant kernel: the fused fine-field forward (FULL mode); algorithmic FLOPs per launch / launch time
+        flop_fwd = 2.0 * macs_full(Wd, C) * rays_local * (Nc + Ni)
+        ach = flop_fwd / (kern["field_fwd[full]"] * 1e-3) / 1e12
+        flop_frame = 2.0 * (Nc * macs_sigma(Wd) + 2 * (Nc + Ni) * macs_full(Wd, C)) * n_total
+        out = {
+            "metric": "rays/s (fwd+bwd) at 640x480x(64+128) samples, 8x256 MLP", "value": value, "unit": "rays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: 7-Scenes-stairs geometry {W}x{H}, 64+128 samples, 8x256 MLP + "
+                                   f"16-ch feature head, random seed-0 weights, fwd + bwd to the 3x4 pose",
+                       "rays_per_step": n_total, "samples_per_ray": [Nc, Ni], "parallelism": f"rows/{world}"},
+            "roofline": {"bound": "mfma", "kernel": "field_fwd_kernel<256,1,FULL>", "achieved": ach,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None,
+                         "end_to_end_frac": value * (flop_frame / n_total) / (PEAK_F32_MFMA_TFLOPS * 1e12 * world)},
+            "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items())},
+            "pose_grad_abs_max": float(g.abs().max()),
+        }
+        if world == 1 and a.cpu_rows > 0:
+            out["cpu_baseline"] = cpu_baseline(Wd, C, Nc, Ni, a.cpu_rows, W, focal)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/* nefes_hip.h -- C ABI of libnefes_hip.so: the MI355X (gfx950) implementation of the NeFeS
+ * volumetric render-and-refine hot path.
+ *
+ * The reference (ActiveVisionLab/NeFeS) has no native/FFI boundary: its seam is the Python call
+ * surface of script/models/{ray_utils,rendering,nerfh_nff}.py.  Each entry point below replaces the
+ * torch op sequence of the reference function cited next to it (paths relative to the reference
+ * root).  The Python side (nefes_amd/) binds these with ctypes and wraps them in
+ * torch.autograd.Function; see INTEGRATION.md for the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - every pointer marked "dev" is device memory owned by the caller (e.g. tensor.data_ptr());
+ *    the library never allocates, frees or retains device memory and keeps no global state;
+ *  - all kernels are asynchronous on `stream` (a hipStream_t passed as void*); no host sync inside;
+ *  - return value: 0 on success, a positive hipError_t from the launch, or a negative NEFES_E_*
+ *    argument error; never aborts, never throws;
+ *  - fp32 everywhere; "raw_t" is the per-sample field output stored channel-major per ray,
+ *    raw_t[N][R][S]  (the reference's raw[N][S][R] is raw_t.permute(0,2,1));
+ *  - N rays, S samples per ray, M = N*S samples, C feature channels, Wd MLP width.
+ */
+#ifndef NEFES_HIP_H
+#define NEFES_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEFES_ABI_VERSION 1
+
+#define NEFES_E_BADARG (-1)     /* null pointer / non-positive size */
+#define NEFES_E_UNSUPPORTED (-2) /* width / feat_dim / sample count outside the compiled set */
+#define NEFES_E_BADBLOB (-3)
+
+/* field network description: NeRFH_NFF ctor arguments (script/models/nerfh_nff.py:421-427).
+ * depth is fixed at 8 with the skip at layer 5 (skips=[4]), encodings at L=10 / L=4. */
+typedef struct NefesNetDesc {
+    int32_t width;         /* Wd: 128 or 256 */
+    int32_t feat_dim;      /* C: f_dim (16 or 128 compiled; 3+C <= 160) */
+    int32_t has_transient; /* 1 for the 'fine' net (encode_transient), 0 for 'coarse' */
+    int32_t reserved;
+} NefesNetDesc;
+
+/* where each weight stream lives inside a packed blob (all offsets in bytes from the blob start) */
+typedef struct NefesStreamInfo {
+    uint64_t slab_off;   /* first slab */
+    uint32_t n_slabs;    /* 16 KiB each */
+    uint32_t bias_floats;
+    uint64_t bias_off;   /* bias block (fp32, natural row order per layer); 0 if none */
+} NefesStreamInfo;
+
+typedef struct NefesBlobInfo {
+    uint64_t total_bytes;
+    NefesStreamInfo stream[4]; /* indexed by NEFES_STREAM_* in csrc/layout.h; n_slabs == 0 if absent */
+} NefesBlobInfo;
+
+/* compositing variants of raw2outputs_NeRFH_NFF (script/models/nerfh_nff.py:25-166) */
+#define NEFES_COMP_TRANSIENT 1u   /* raw carries the 5 transient channels (output_transient=True) */
+#define NEFES_COMP_STATIC_ONLY 2u /* variant B: test_time and not transient_at_test (:92-117) */
+#define NEFES_COMP_SIGMA_ONLY 4u  /* variant D: coarse net at test time, raw = sigma only (:33-35,83-89) */
+#define NEFES_COMP_WHITE_BKGD 8u  /* :126-127 */
+
+/* field forward modes (run_network_NeRFH_NFF branches, script/models/nerfh_nff.py:192-231) */
+#define NEFES_FIELD_SIGMA 0  /* coarse + test_time: sigma only, R = 1 */
+#define NEFES_FIELD_STATIC 1 /* output_transient=False: R = 3+C+1 */
+#define NEFES_FIELD_FULL 2   /* output_transient=True:  R = 3+C+6 */
+
+int nefes_version(void);
+
+/* ---- weights ------------------------------------------------------------------------------- */
+/* Blob geometry for a network description. */
+int nefes_blob_info(const NefesNetDesc* desc, NefesBlobInfo* info);
+/* Host-side layout transform of a NeRFH_NFF state_dict into the MFMA fragment streams the kernels
+ * consume.  `tensors` = host fp32 pointers, (weight, bias) per layer in the reference's construction
+ * order (nerfh_nff.py:452-505): xyz_encoding_1..8, xyz_encoding_final, dir_encoding.0,
+ * static_sigma.0, static_rgb.0 [, transient_encoding.0/.2/.4, transient_sigma.0, transient_rgb.0,
+ * transient_beta.0]; torch layout [out, in] row-major.  `blob` = host buffer of info.total_bytes. */
+int nefes_pack_weights(const NefesNetDesc* desc, const float* const* tensors, int n_tensors, void* blob,
+                       size_t blob_bytes);
+
+/* ---- rays (script/models/ray_utils.py) ------------------------------------------------------- */
+/* get_rays (:5-16) + viewdirs = d/|d| (rendering.py:217) for image rows [row0, row0+nrows).
+ * c2w: dev, 12 floats row-major 3x4.  Outputs dev [nrows*W, 3]. */
+int nefes_raygen_fwd(int H, int W, float focal, const float* c2w, int row0, int nrows, float* rays_o, float* rays_d,
+                     float* viewdirs, void* stream);
+/* backward of the above: g_c2w[12] (dev) = sum over rays.  g_* may be NULL (treated as zero).
+ * workspace: dev, >= nefes_raygen_bwd_workspace(nrows*W) bytes. */
+size_t nefes_raygen_bwd_workspace(int n_rays);
+int nefes_raygen_bwd(int H, int W, float focal, const float* c2w, int row0, int nrows, const float* g_rays_o,
+                     const float* g_rays_d, const float* g_viewdirs, void* workspace, float* g_c2w, void* stream);
+/* ndc_rays (:27-44) and its backward to (rays_o, rays_d). */
+int nefes_ndc_fwd(int H, int W, float focal, float near, int n, const float* rays_o, const float* rays_d, float* out_o,
+                  float* out_d, void* stream);
+int nefes_ndc_bwd(int H, int W, float focal, float near, int n, const float* rays_o, const float* rays_d,
+                  const float* g_out_o, const float* g_out_d, float* g_rays_o, float* g_rays_d, void* stream);
+/* coarse depths: z = near*(1-t)+far*t or the lindisp form, optional stratified jitter with a
+ * caller-supplied t_rand[N,Nc] (rendering.py:96-112).  t: dev [Nc] = torch.linspace(0,1,Nc). */
+int nefes_coarse_depths(int N, int Nc, float near, float far, int lindisp, const float* t, const float* t_rand,
+                        float* z, void* stream);
+
+/* ---- field MLP (nerfh_nff.py:168-231 run_network + :234-270 Embedder + :525-576 forward) ------- */
+/* Either (rays_o, rays_d, z) are given and pts = o + d*z is formed in-kernel (rendering.py:114,142),
+ * or pts[M,3] is given (run_network call surface).  viewdirs [N,3] is ignored in SIGMA mode.
+ * raw_t: dev [N][R][S].  masks: dev uint32 [ceil(M/32)][mask_words][64] or NULL (FULL mode only;
+ * needed by nefes_field_bwd).  packed: dev blob from nefes_pack_weights. */
+size_t nefes_field_mask_bytes(const NefesNetDesc* desc, int64_t M);
+int nefes_field_fwd(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                    const float* rays_d, const float* z, const float* pts, const float* viewdirs, float* raw_t,
+                    uint32_t* masks, void* stream);
+/* backward to the inputs (frozen weights, no dW): g_pts [M,3], g_viewdirs_s [M,3] (per sample). */
+int nefes_field_bwd(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+                    const float* rays_d, const float* z, const float* pts, const float* viewdirs, const float* raw_t,
+                    const float* g_raw_t, const uint32_t* masks, float* g_pts, float* g_viewdirs_s, void* stream);
+/* per-ray reduction of the above: g_o = sum_s g_pts, g_d = sum_s z*g_pts, g_v = sum_s g_viewdirs_s. */
+int nefes_ray_grad_reduce(int N, int S, const float* z, const float* g_pts, const float* g_viewdirs_s, float* g_rays_o,
+                          float* g_rays_d, float* g_viewdirs, void* stream);
+
+/* ---- compositing (nerfh_nff.py:25-166) -------------------------------------------------------- */
+/* Outputs may be NULL when not wanted.  weights: [N,S] (variant B: the static-only weights). */
+int nefes_composite_fwd(int N, int S, int C, uint32_t flags, float beta_min, const float* raw_t, const float* z,
+                        float* rgb, float* feat, float* disp, float* acc, float* depth, float* weights, float* beta,
+                        void* stream);
+/* g_* upstream gradients may be NULL (zero).  g_raw_t: dev [N][R][S], fully written. */
+int nefes_composite_bwd(int N, int S, int C, uint32_t flags, const float* raw_t, const float* z, const float* g_rgb,
+                        const float* g_feat, const float* g_disp, const float* g_acc, const float* g_depth,
+                        const float* g_weights, const float* g_beta, float* g_raw_t, void* stream);
+
+/* ---- hierarchical sampling (rendering.py:23-66 sample_pdf, :132-141 z_mid / sort) -------------- */
+/* layout 0 (render_rays): z_coarse [N,Nc] coarse depths and weights [N,Nc] coarse compositing weights;
+ *   bins = z_mid and the weights[...,1:-1] slice are formed inside (rendering.py:132-134).
+ * layout 1 (sample_pdf call surface): z_coarse = bins [N,Nc-1], weights = [N,Nc-2] exactly as the
+ *   reference function receives them; z_fine must be NULL.
+ * u: dev [Ni] (u_per_ray = 0, e.g. torch.linspace(0,1,Ni)) or [N,Ni] (u_per_ray = 1).  cdf_in (optional,
+ * [N,Nc-1]) overrides the internally built CDF (stage test: indices bit-exact on identical CDFs).
+ * Outputs: z_fine [N,Nc+Ni] ascending (or NULL), z_samples [N,Ni], inds int32 [N,Ni], cdf_out [N,Nc-1]. */
+int nefes_sample_pdf_merge(int N, int Nc, int Ni, int layout, const float* z_coarse, const float* weights,
+                           const float* u, int u_per_ray, const float* cdf_in, float* z_fine, float* z_samples,
+                           int32_t* inds, float* cdf_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEFES_HIP_H */

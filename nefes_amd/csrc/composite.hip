@@ -1,0 +1,344 @@
+// Alpha compositing of RGB + C-channel feature maps and its backward: one wavefront per ray.
+// Restates raw2outputs_NeRFH_NFF (script/models/nerfh_nff.py:25-166), variants A/B/C/D of SURVEY.md §8 a9.
+//
+// Roofline: HBM-bound.  Algorithmic bytes per ray: forward S*R*4 + S*4 read + (3+C+3)*4 write
+// (20.1 KB at S=192, R=25); backward 2*S*R*4 + small (38.5 KB).  raw_t is channel-major per ray
+// ([N][R][S]) so that lane <-> sample gives 256-byte coalesced rows per channel.
+//
+// Numerics follow the CPU reference: transmittance = exclusive cumprod accumulated in f64 and rounded
+// to f32 per element (torch CPU cumprod semantics); per-ray sums accumulate in f64.
+// The backward is division-free (exact for alpha == 1 saturation; SURVEY.md §7 hard part 5).
+#include "../../include/nefes_hip.h"
+#include "wave.h"
+
+struct CompArgs {
+    int N, S, C, R;
+    uint32_t flags;
+    float beta_min;
+    const float* raw_t;
+    const float* z;
+    // forward outputs (nullable)
+    float *rgb, *feat, *disp, *acc, *depth, *weights, *beta;
+    // backward inputs (nullable) and output
+    const float *g_rgb, *g_feat, *g_disp, *g_acc, *g_depth, *g_weights, *g_beta;
+    float* g_raw_t;
+};
+
+// torch.max(1e-10, x) propagates NaN
+__device__ __forceinline__ float max_nan(float lo, float x) { return (x != x) ? x : (x > lo ? x : lo); }
+
+template <int Q>
+struct RayState {
+    float zz[Q], dl[Q], a_c[Q], a_s[Q], a_t[Q], T[Q], Ts[Q], e_c[Q], e_s[Q], e_t[Q];
+    bool in[Q];
+};
+
+template <int Q>
+__device__ __forceinline__ void ray_forward(const CompArgs& p, const float* raw, const float* zr, int lane, RayState<Q>& r) {
+    const bool transient = p.flags & NEFES_COMP_TRANSIENT, sigma_only = p.flags & NEFES_COMP_SIGMA_ONLY;
+    const bool static_only = p.flags & NEFES_COMP_STATIC_ONLY;
+    const int S = p.S, C3 = 3 + p.C;
+    const int chS = sigma_only ? 0 : C3, chT = C3 + 4;
+    double carry = 1.0, carry_s = 1.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int s = lane + 64 * q;
+        r.in[q] = s < S;
+        const int sc = r.in[q] ? s : S - 1;
+        const float z0 = zr[sc];
+        const float z1 = zr[sc + 1 < S ? sc + 1 : sc];
+        r.zz[q] = z0;
+        r.dl[q] = (sc == S - 1) ? 1e2f : (z1 - z0);                     // :55-60, last delta = 1e2, no |d| scaling
+        const float ss = raw[(size_t)chS * S + sc];
+        const float st = transient ? raw[(size_t)chT * S + sc] : 0.f;
+        r.e_c[q] = expf(-(r.dl[q] * (ss + st)));
+        r.a_c[q] = r.in[q] ? 1.f - r.e_c[q] : 0.f;                      // :62-68
+        if (transient) {
+            r.e_s[q] = expf(-(r.dl[q] * ss));
+            r.e_t[q] = expf(-(r.dl[q] * st));
+            r.a_s[q] = r.in[q] ? 1.f - r.e_s[q] : 0.f;
+            r.a_t[q] = r.in[q] ? 1.f - r.e_t[q] : 0.f;
+        } else {
+            r.e_s[q] = r.e_c[q]; r.e_t[q] = 1.f; r.a_s[q] = r.a_c[q]; r.a_t[q] = 0.f;
+        }
+        // exclusive cumprod of (1 - alpha), f64 accumulate, rounded to f32 per element (:71-72)
+        const double om = r.in[q] ? (double)(1.f - r.a_c[q]) : 1.0;
+        const double inc = wave_incl_prod(om, lane);
+        const double prev = __shfl_up(inc, 1);
+        r.T[q] = (float)(carry * (lane == 0 ? 1.0 : prev));
+        carry *= lane_bcast(inc, 63);
+        if (static_only) {                                              // variant B second chain (:95-98)
+            const double oms = r.in[q] ? (double)(1.f - r.a_s[q]) : 1.0;
+            const double incs = wave_incl_prod(oms, lane);
+            const double prevs = __shfl_up(incs, 1);
+            r.Ts[q] = (float)(carry_s * (lane == 0 ? 1.0 : prevs));
+            carry_s *= lane_bcast(incs, 63);
+        } else {
+            r.Ts[q] = r.T[q];
+        }
+    }
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= p.N) return;
+    const int S = p.S, C = p.C, C3 = 3 + C;
+    const float* raw = p.raw_t + (size_t)ray * p.R * S;
+    const float* zr = p.z + (size_t)ray * S;
+    const bool transient = p.flags & NEFES_COMP_TRANSIENT, sigma_only = p.flags & NEFES_COMP_SIGMA_ONLY;
+    const bool static_only = p.flags & NEFES_COMP_STATIC_ONLY;
+    RayState<Q> r;
+    ray_forward<Q>(p, raw, zr, lane, r);
+
+    float w[Q], ws[Q], wt[Q], wo[Q];   // combined, static, transient, and the "reported" weights
+    double s_acc = 0, s_dep = 0, s_wo = 0, s_beta = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        w[q] = r.a_c[q] * r.T[q];
+        ws[q] = static_only ? r.a_s[q] * r.Ts[q] : (transient ? r.a_s[q] * r.T[q] : w[q]);
+        wt[q] = (transient && !static_only) ? r.a_t[q] * r.T[q] : 0.f;
+        wo[q] = static_only ? ws[q] : w[q];
+        if (r.in[q]) {
+            s_acc += w[q];
+            s_wo += wo[q];
+            s_dep += (double)(wo[q] * r.zz[q]);
+            if (p.weights) p.weights[(size_t)ray * S + lane + 64 * q] = wo[q];
+        }
+    }
+    const float acc = (float)wave_sum(s_acc);
+    if (lane == 0 && p.acc) p.acc[ray] = acc;
+    if (sigma_only) return;                                              // variant D: weights + acc only (:83-89)
+    const float depth = (float)wave_sum(s_dep);
+    const float sum_wo = static_only ? (float)wave_sum(s_wo) : acc;
+    if (lane == 0) {
+        if (p.depth) p.depth[ray] = depth;
+        if (p.disp) p.disp[ray] = 1.f / max_nan(1e-10f, depth / sum_wo);   // :115,165
+    }
+    // rgb = sum w_s * c_s (+ sum w_t * c_t) (:119-131,149 / :101-105 / :153-154)
+    float rgb_keep = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (r.in[q]) {
+                const int s = lane + 64 * q;
+                a += (double)(ws[q] * raw[(size_t)c * S + s]);
+                if (transient && !static_only) b += (double)(wt[q] * raw[(size_t)(C3 + 1 + c) * S + s]);
+            }
+        float v = (float)wave_sum(a);
+        if ((p.flags & NEFES_COMP_WHITE_BKGD) && transient && !static_only) v = v + (1.f - acc);
+        if (transient && !static_only) v = v + (float)wave_sum(b);
+        if (lane == c) rgb_keep = v;
+    }
+    if (lane < 3 && p.rgb) p.rgb[(size_t)ray * 3 + lane] = rgb_keep;
+    // features use the same (static) weights, detached (:108-111,122-125,155-157)
+    if (p.feat) {
+        for (int c0 = 0; c0 < C; c0 += 64) {
+            float keep = 0.f;
+            const int nc = (C - c0) < 64 ? (C - c0) : 64;
+            for (int c = 0; c < nc; ++c) {
+                double a = 0;
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+                    if (r.in[q]) a += (double)(ws[q] * raw[(size_t)(3 + c0 + c) * S + lane + 64 * q]);
+                const float v = (float)wave_sum(a);
+                if (lane == c) keep = v;
+            }
+            if (lane < nc) p.feat[(size_t)ray * C + c0 + lane] = keep;
+        }
+    }
+    if (p.beta) {
+        float bv = 0.f;
+        if (transient && !static_only) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (r.in[q]) s_beta += (double)(wt[q] * raw[(size_t)(C3 + 5) * S + lane + 64 * q]);
+            bv = (float)wave_sum(s_beta) + p.beta_min;                   // :133-137
+        }
+        if (lane == 0) p.beta[ray] = bv;
+    }
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= p.N) return;
+    const int S = p.S, C = p.C, C3 = 3 + C;
+    const float* raw = p.raw_t + (size_t)ray * p.R * S;
+    float* graw = p.g_raw_t + (size_t)ray * p.R * S;
+    const float* zr = p.z + (size_t)ray * S;
+    const bool transient = p.flags & NEFES_COMP_TRANSIENT, sigma_only = p.flags & NEFES_COMP_SIGMA_ONLY;
+    const bool static_only = p.flags & NEFES_COMP_STATIC_ONLY;
+    const bool both = transient && !static_only;   // variant A
+    RayState<Q> r;
+    ray_forward<Q>(p, raw, zr, lane, r);
+
+    float w[Q], ws[Q], wt[Q], wo[Q];
+    double s_acc = 0, s_dep = 0, s_wo = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        w[q] = r.a_c[q] * r.T[q];
+        ws[q] = static_only ? r.a_s[q] * r.Ts[q] : (transient ? r.a_s[q] * r.T[q] : w[q]);
+        wt[q] = both ? r.a_t[q] * r.T[q] : 0.f;
+        wo[q] = static_only ? ws[q] : w[q];
+        if (r.in[q]) { s_acc += w[q]; s_wo += wo[q]; s_dep += (double)(wo[q] * r.zz[q]); }
+    }
+    const float acc = (float)wave_sum(s_acc);
+    const float depth = (float)wave_sum(s_dep);
+    const float sum_wo = static_only ? (float)wave_sum(s_wo) : acc;
+
+    // upstream scalars
+    float g_rgb[3] = {0.f, 0.f, 0.f};
+    if (p.g_rgb && !sigma_only)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g_rgb[c] = p.g_rgb[(size_t)ray * 3 + c];
+    float g_acc = p.g_acc ? p.g_acc[ray] : 0.f;
+    float g_dep = (p.g_depth && !sigma_only) ? p.g_depth[ray] : 0.f;
+    const float g_beta = (p.g_beta && both) ? p.g_beta[ray] : 0.f;
+    float g_sumwo = 0.f;   // gradient w.r.t. the disparity denominator
+    if (p.g_disp && !sigma_only) {
+        const float gd = p.g_disp[ray];
+        const float ratio = depth / sum_wo;
+        if (ratio > 1e-10f || ratio != ratio) {           // torch.max passes the gradient to the larger operand
+            const float disp = 1.f / ratio;
+            const float g_ratio = -gd * disp * disp;
+            g_dep += g_ratio / sum_wo;
+            g_sumwo += -g_ratio * ratio / sum_wo;
+        }
+    }
+    if ((p.flags & NEFES_COMP_WHITE_BKGD) && both) g_acc -= (g_rgb[0] + g_rgb[1] + g_rgb[2]);
+    if (!static_only) { g_acc += g_sumwo; g_sumwo = 0.f; }   // same tensor (sum of combined weights) in A/C
+
+    // per-sample gradient w.r.t. the weights, then w.r.t. the transmittance
+    float Gs[Q], Gt[Q], Gc[Q], G1[Q];
+    double X[Q], X1[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int s = lane + 64 * q;
+        Gs[q] = Gt[q] = Gc[q] = G1[q] = 0.f;
+        if (r.in[q]) {
+            const float gw = p.g_weights ? p.g_weights[(size_t)ray * S + s] : 0.f;
+            float col_s = 0.f, col_t = 0.f;
+            if (!sigma_only) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    col_s += g_rgb[c] * raw[(size_t)c * S + s];
+                    if (both) col_t += g_rgb[c] * raw[(size_t)(C3 + 1 + c) * S + s];
+                }
+            }
+            if (both) {                     // variant A
+                Gs[q] = col_s;
+                Gt[q] = col_t + g_beta * raw[(size_t)(C3 + 5) * S + s];
+                Gc[q] = g_acc + g_dep * r.zz[q] + gw;
+            } else if (static_only) {       // variant B
+                G1[q] = col_s + g_dep * r.zz[q] + g_sumwo + gw;
+                Gc[q] = g_acc;
+            } else {                        // variants C / D
+                Gc[q] = col_s + g_acc + g_dep * r.zz[q] + gw;
+            }
+        }
+    }
+    // X_i = A_i + (1-alpha_i) X_{i+1}: reverse affine scan; B_i = X_{i+1}
+    double carry = 0.0, carry1 = 0.0;
+    double Bc[Q], B1[Q];
+#pragma unroll
+    for (int q = Q - 1; q >= 0; --q) {
+        {
+            double m = r.in[q] ? (double)(1.f - r.a_c[q]) : 1.0;
+            double a = r.in[q] ? (double)Gs[q] * r.a_s[q] * (both ? 1.0 : 0.0) + (double)Gt[q] * r.a_t[q] + (double)Gc[q] * r.a_c[q] : 0.0;
+            wave_rev_affine(m, a, lane);
+            X[q] = a + m * carry;
+            const double nxt = __shfl_down(X[q], 1);
+            Bc[q] = (lane < 63) ? nxt : carry;
+            carry = lane_bcast(X[q], 0);
+        }
+        if (static_only) {
+            double m = r.in[q] ? (double)(1.f - r.a_s[q]) : 1.0;
+            double a = r.in[q] ? (double)G1[q] * r.a_s[q] : 0.0;
+            wave_rev_affine(m, a, lane);
+            X1[q] = a + m * carry1;
+            const double nxt = __shfl_down(X1[q], 1);
+            B1[q] = (lane < 63) ? nxt : carry1;
+            carry1 = lane_bcast(X1[q], 0);
+        } else {
+            B1[q] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (!r.in[q]) continue;
+        const int s = lane + 64 * q;
+        const double T = r.T[q], Ts = r.Ts[q];
+        const double d_ac = (double)Gc[q] * T - T * Bc[q];                       // d L / d alpha (combined)
+        double d_as = 0.0, d_at = 0.0;
+        if (both) { d_as = (double)Gs[q] * T; d_at = (double)Gt[q] * T; }
+        if (static_only) d_as = (double)G1[q] * Ts - Ts * B1[q];
+        const double dl = r.dl[q];
+        const float g_ss = (float)(transient ? d_as * dl * r.e_s[q] + d_ac * dl * r.e_c[q] : d_ac * dl * r.e_c[q]);
+        if (sigma_only) { graw[s] = g_ss; continue; }
+        graw[(size_t)C3 * S + s] = g_ss;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) graw[(size_t)c * S + s] = ws[q] * g_rgb[c];
+        for (int c = 0; c < C; ++c)
+            graw[(size_t)(3 + c) * S + s] = p.g_feat ? ws[q] * p.g_feat[(size_t)ray * C + c] : 0.f;
+        if (transient) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) graw[(size_t)(C3 + 1 + c) * S + s] = wt[q] * g_rgb[c];
+            graw[(size_t)(C3 + 4) * S + s] = (float)(d_at * dl * r.e_t[q] + d_ac * dl * r.e_c[q]);
+            graw[(size_t)(C3 + 5) * S + s] = wt[q] * g_beta;
+        }
+    }
+}
+
+static int comp_args(CompArgs& a, int N, int S, int C, uint32_t flags) {
+    if (N <= 0 || S <= 1 || C < 0) return NEFES_E_BADARG;
+    if (S > 256) return NEFES_E_UNSUPPORTED;
+    a.N = N; a.S = S; a.C = C; a.flags = flags;
+    a.R = (flags & NEFES_COMP_SIGMA_ONLY) ? 1 : ((flags & NEFES_COMP_TRANSIENT) ? 3 + C + 6 : 3 + C + 1);
+    return 0;
+}
+
+extern "C" int nefes_composite_fwd(int N, int S, int C, uint32_t flags, float beta_min, const float* raw_t,
+                                   const float* z, float* rgb, float* feat, float* disp, float* acc, float* depth,
+                                   float* weights, float* beta, void* stream) {
+    CompArgs a = {};
+    int rc = comp_args(a, N, S, C, flags);
+    if (rc) return rc;
+    if (!raw_t || !z) return NEFES_E_BADARG;
+    a.beta_min = beta_min; a.raw_t = raw_t; a.z = z;
+    a.rgb = rgb; a.feat = feat; a.disp = disp; a.acc = acc; a.depth = depth; a.weights = weights; a.beta = beta;
+    const dim3 grid((N + 3) / 4), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch ((S + 63) / 64) {
+        case 1: hipLaunchKernelGGL(composite_fwd_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(composite_fwd_kernel<2>, grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(composite_fwd_kernel<3>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(composite_fwd_kernel<4>, grid, block, 0, st, a); break;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_composite_bwd(int N, int S, int C, uint32_t flags, const float* raw_t, const float* z,
+                                   const float* g_rgb, const float* g_feat, const float* g_disp, const float* g_acc,
+                                   const float* g_depth, const float* g_weights, const float* g_beta, float* g_raw_t,
+                                   void* stream) {
+    CompArgs a = {};
+    int rc = comp_args(a, N, S, C, flags);
+    if (rc) return rc;
+    if (!raw_t || !z || !g_raw_t) return NEFES_E_BADARG;
+    a.raw_t = raw_t; a.z = z; a.g_rgb = g_rgb; a.g_feat = g_feat; a.g_disp = g_disp; a.g_acc = g_acc;
+    a.g_depth = g_depth; a.g_weights = g_weights; a.g_beta = g_beta; a.g_raw_t = g_raw_t;
+    const dim3 grid((N + 3) / 4), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch ((S + 63) / 64) {
+        case 1: hipLaunchKernelGGL(composite_bwd_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(composite_bwd_kernel<2>, grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(composite_bwd_kernel<3>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(composite_bwd_kernel<4>, grid, block, 0, st, a); break;
+    }
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,188 @@
+// Device-side building blocks of the fused field kernels (gfx950 only).
+//   - WeightRing: 8 x 16 KiB LDS ring filled by LDS-DMA (global_load_lds_dwordx4), one barrier per slab
+//   - mma_segment: one (activation vector) x (weight block) product on v_mfma_f32_32x32x2_f32
+//   - accumulator <-> activation-vector moves, bias init, ReLU + mask
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "layout.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// exact reference arithmetic where the reference uses separate mul/add (no FMA contraction)
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+
+// torch.nn.Softplus(beta=1, threshold=20)
+__device__ __forceinline__ float softplus_ref(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_ref(float x) { return 1.f / (1.f + expf(-x)); }
+
+// One 1 KiB LDS-DMA piece: every lane supplies its own 16-byte source address, the destination is
+// M0 (wave-uniform LDS byte address) + lane*16.  The asm statement saves/restores M0 (compiler-owned).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+// Weight stream ring.  All four waves of the workgroup walk the same slab sequence; each wave moves
+// four of the sixteen 1 KiB pieces of every slab.  Protocol per consumed slab i:
+//     s_waitcnt vmcnt(4*(SLOTS-2))   my pieces of slab i have landed (only younger slabs in flight)
+//     s_barrier                      everyone's pieces landed; everyone is done reading slab i-1
+//     issue slab i+SLOTS-1 into the slot slab i-1 occupied
+// Compiler-issued loads/stores interleaved with the DMA only make the counted wait stricter.
+struct WeightRing {
+    const char* src;     // per-lane source: stream base + wave*1024 + lane*16
+    uint32_t lds_wave;   // ring base + wave*1024 (wave-uniform)
+    uint32_t n_slabs;    // slabs in the stream (wraps)
+    uint32_t g_next;     // next slab of the stream to issue
+    uint32_t p_slot;     // slot that slab goes to
+    uint32_t c_slot;     // slot consumed next
+
+    __device__ __forceinline__ void init(const char* stream, uint32_t nslabs, uint32_t ring_lds_base, int wave, int lane) {
+        src = stream + wave * 1024 + lane * 16;
+        lds_wave = ring_lds_base + wave * 1024;
+        n_slabs = nslabs;
+        g_next = 0; p_slot = 0; c_slot = 0;
+#pragma unroll 1
+        for (int i = 0; i < NEFES_RING_SLOTS - 1; ++i) issue();
+    }
+    __device__ __forceinline__ void issue() {
+        const char* s = src + (size_t)g_next * NEFES_SLAB_BYTES;
+        const uint32_t d = lds_wave + p_slot * NEFES_SLAB_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lds_dma16(s + q * 4096, d + q * 4096);
+        g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
+        p_slot = (p_slot + 1 == NEFES_RING_SLOTS) ? 0 : p_slot + 1;
+    }
+    // returns the LDS byte offset (relative to the ring base) of the slab to consume
+    __device__ __forceinline__ uint32_t acquire() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NEFES_RING_SLOTS - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue();
+        const uint32_t off = c_slot * NEFES_SLAB_BYTES;
+        c_slot = (c_slot + 1 == NEFES_RING_SLOTS) ? 0 : c_slot + 1;
+        return off;
+    }
+    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+// acc[t] += W-block * in   for NT accumulator tiles over KS k-steps (fully unrolled; `in` and `acc`
+// are register arrays, every index below is a compile-time constant after unrolling).
+// ring_lane = LDS pointer of the ring base + lane*16.
+template <int NT, int KS>
+__device__ __forceinline__ void mma_segment(WeightRing& ring, const char* ring_lane, const float (&in)[KS],
+                                            f32x16 (&acc)[NT]) {
+    constexpr int SPS = NEFES_SLAB_FRAGS / NT;
+    constexpr int NSLAB = (KS + SPS - 1) / SPS;
+#pragma unroll
+    for (int sl = 0; sl < NSLAB; ++sl) {
+        const char* p = ring_lane + ring.acquire();
+        const int steps = (KS - sl * SPS) < SPS ? (KS - sl * SPS) : SPS;
+        const int nf = steps * NT;
+#pragma unroll
+        for (int g = 0; g < NEFES_SLAB_FRAGS / 4; ++g) {
+            if (g * 4 < nf) {
+                const f32x4 a = *(const f32x4*)(p + g * 1024);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f = g * 4 + q;
+                    if (f < nf) {
+                        const int s = sl * SPS + f / NT, t = f % NT;
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], in[s], acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// acc rows <- bias (natural row order in LDS).  bias_half = bias block + 16*h bytes.
+template <int NT>
+__device__ __forceinline__ void bias_init(f32x16 (&acc)[NT], const char* bias_half) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *(const f32x4*)(bias_half + (t * 32 + 8 * q) * 4);
+            acc[t][4 * q + 0] = b[0]; acc[t][4 * q + 1] = b[1]; acc[t][4 * q + 2] = b[2]; acc[t][4 * q + 3] = b[3];
+        }
+}
+template <int NT>
+__device__ __forceinline__ void zero_init(f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+}
+
+// dst[16*t + r] = max(acc[t][r], floor);  mask bit (16*t + r) = acc > 0.   floor = 0 (ReLU) or -inf (identity)
+template <int NT, int NOUT>
+__device__ __forceinline__ void act_store(float (&dst)[NOUT], const f32x16 (&acc)[NT], float floor_v,
+                                          uint32_t (&bits)[(NT + 1) / 2]) {
+    static_assert(NOUT >= NT * 16, "destination vector too small");
+#pragma unroll
+    for (int w = 0; w < (NT + 1) / 2; ++w) bits[w] = 0u;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[t][r];
+            bits[t >> 1] |= (v > 0.f ? 1u : 0u) << ((t & 1) * 16 + r);
+            dst[t * 16 + r] = fmaxf(v, floor_v);
+        }
+}
+// backward: dst[16*t + r] = bit ? acc[T0 + t][r] : 0
+template <int NT, int T0, int NACC, int NOUT>
+__device__ __forceinline__ void mask_store(float (&dst)[NOUT], const f32x16 (&acc)[NACC], const uint32_t (&bits)[(NT + 1) / 2]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            dst[t * 16 + r] = ((bits[t >> 1] >> ((t & 1) * 16 + r)) & 1u) ? acc[T0 + t][r] : 0.f;
+}
+
+// frequency embedding of a 3-vector into slot order (layout.h nefes_emb_slot); L frequencies.
+// half-0 lanes keep sin, half-1 lanes keep cos.  torch: sin(x * 2^k), cos(x * 2^k); x*2^k is exact.
+template <int L, int NS>
+__device__ __forceinline__ void embed_slots(float (&e)[NS], const float (&x)[3], int h) {
+    static_assert(NS >= 3 * L + 2, "embedding vector too small");
+#pragma unroll
+    for (int k = 0; k < L; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float sn, cs;
+            sincosf(x[a] * (float)(1 << k), &sn, &cs);
+            e[3 * k + a] = h ? cs : sn;
+        }
+    e[3 * L] = h ? x[1] : x[0];
+    e[3 * L + 1] = h ? 0.f : x[2];
+#pragma unroll
+    for (int s = 3 * L + 2; s < NS; ++s) e[s] = 0.f;
+}
+// backward of embed_slots: g[s] holds d/d(slot (s, h)); returns this lane-half's partial d/dx
+// (the caller adds the other half's).   d sin(fx)/dx = f cos(fx),  d cos(fx)/dx = -f sin(fx).
+template <int L, int NS>
+__device__ __forceinline__ void embed_slots_bwd(float (&gx)[3], const float (&g)[NS], const float (&x)[3], int h) {
+    gx[0] = gx[1] = gx[2] = 0.f;
+#pragma unroll
+    for (int k = 0; k < L; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float sn, cs;
+            const float f = (float)(1 << k);
+            sincosf(x[a] * f, &sn, &cs);
+            gx[a] += g[3 * k + a] * (h ? -(f * sn) : (f * cs));
+        }
+    if (h) { gx[1] += g[3 * L]; } else { gx[0] += g[3 * L]; gx[2] += g[3 * L + 1]; }
+}

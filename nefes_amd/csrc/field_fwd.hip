@@ -1,0 +1,250 @@
+// Fused field forward: pts = o + d*z -> frequency embedding -> 8-layer skip MLP -> heads, one launch.
+// Replaces run_network_NeRFH_NFF + Embedder.embed + NeRFH_NFF.forward
+// (script/models/nerfh_nff.py:168-231, :234-270, :525-576) and rendering.py:114,142 (pts).
+//
+// Roofline: MFMA-bound (fp32 32x32x2 at 157.3 TFLOP/s); algorithmic work per sample = 2 * MACs of
+// SURVEY.md §8d (491 264 sigma-only / 665 088 full at Wd=256,C=16).  Weights: LDS-DMA ring, read once
+// per 128-sample workgroup tile from L2 (2.7 MB stream, resident).  Activations never leave registers.
+#include "field_common.h"
+#include "../../include/nefes_hip.h"
+
+struct FieldFwdArgs {
+    const char* stream;      // weight slabs
+    const float* bias;       // bias block (floats)
+    uint32_t n_slabs, bias_floats;
+    const float* rays_o;     // [N,3] or null
+    const float* rays_d;
+    const float* z;          // [N,S]
+    const float* pts;        // [M,3] or null
+    const float* viewdirs;   // [N,3]
+    float* raw_t;            // [N][R][S]
+    uint32_t* masks;         // [tiles32][MW][64] or null
+    int N, S, R, C;
+    long long M;
+    int n_tiles;             // 128-sample workgroup tiles
+};
+
+// MODE: NEFES_FIELD_SIGMA / STATIC / FULL.  W: MLP width.  NTR: tiles of the rgb+feature head.
+template <int W, int NTR, int MODE>
+__global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
+    constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;   // tiles / k-steps
+    constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring_base = smem;
+    float* bias_lds = (float*)(smem + NEFES_RING_SLOTS * NEFES_SLAB_BYTES);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    for (uint32_t i = threadIdx.x; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
+    WeightRing ring;
+    ring.init(a.stream, a.n_slabs, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_base, wave, lane);
+    __syncthreads();
+    const char* ring_lane = ring_base + lane * 16;
+    const char* bias_half = (const char*)bias_lds + 16 * h;
+
+    // bias block offsets (floats), in stream order: L1..L8, SIG, FINAL, DIR, RGB, T0, T1, T2, TH
+    constexpr int B_SIG = 8 * W, B_FINAL = B_SIG + 32, B_DIR = B_FINAL + W, B_RGB = B_DIR + W / 2,
+                  B_T0 = B_RGB + 32 * NTR, B_T1 = B_T0 + W / 2, B_T2 = B_T1 + W / 2, B_TH = B_T2 + W / 2;
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const long long m_raw = (long long)tile * 128 + wave * 32 + j;
+        const bool valid = m_raw < a.M;
+        const long long m = valid ? m_raw : a.M - 1;
+        const int ray = (int)(m / a.S);
+        const int smp = (int)(m - (long long)ray * a.S);
+        float x[3];
+        if (a.pts) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[c] = a.pts[m * 3 + c];
+        } else {
+            const float zz = a.z[m];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[c] = add_rn(a.rays_o[ray * 3 + c], mul_rn(a.rays_d[ray * 3 + c], zz));
+        }
+        float E[NEFES_E_STEPS];
+        embed_slots<NEFES_N_FREQ_XYZ>(E, x, h);
+        float Dv[NEFES_D_STEPS];
+        if (MODE != NEFES_FIELD_SIGMA) {
+            float v[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[ray * 3 + c];
+            embed_slots<NEFES_N_FREQ_DIR>(Dv, v, h);
+        }
+        uint32_t* mask_out = (MODE == NEFES_FIELD_FULL && a.masks && valid)
+                                 ? a.masks + ((size_t)(m_raw >> 5) * MW) * 64 + lane
+                                 : nullptr;
+        // NOTE: m_raw>>5 == global 32-sample tile index (tile*4 + wave) because 128 | tile base.
+
+        float H[HS];
+        f32x16 acc[NTW];
+        uint32_t bits[(NTW + 1) / 2];
+        // ---- layer 1: 63 -> W ----
+        bias_init<NTW>(acc, bias_half);
+        mma_segment<NTW, NEFES_E_STEPS>(ring, ring_lane, E, acc);
+        act_store<NTW>(H, acc, 0.f, bits);
+        if (mask_out) {
+#pragma unroll
+            for (int w = 0; w < (NTW + 1) / 2; ++w) mask_out[w * 64] = bits[w];
+        }
+        // ---- layers 2..8, then (STATIC/FULL) xyz_encoding_final as "layer 9"; the static sigma head reads h8 ----
+        auto sigma_head = [&]() {
+            // static_sigma on h8 (nerfh_nff.py:485,555): one tile, row 0 = (half 0, register 0)
+            f32x16 sg[1];
+            bias_init<1>(sg, bias_half + B_SIG * 4);
+            mma_segment<1, HS>(ring, ring_lane, H, sg);
+            if (valid && h == 0) {
+                const int ch = (MODE == NEFES_FIELD_SIGMA) ? 0 : 3 + a.C;
+                a.raw_t[((size_t)ray * a.R + ch) * a.S + smp] = softplus_ref(sg[0][0]);
+            }
+        };
+        constexpr int LEND = (MODE == NEFES_FIELD_SIGMA) ? 8 : 9;
+#pragma unroll 1
+        for (int l = 2; l <= LEND; ++l) {
+            if constexpr (MODE != NEFES_FIELD_SIGMA) {
+                if (l == 9) sigma_head();
+            }
+            const int boff = (l <= 8) ? (l - 1) * W : B_FINAL;
+            bias_init<NTW>(acc, bias_half + boff * 4);
+            if (l == 5) mma_segment<NTW, NEFES_E_STEPS>(ring, ring_lane, E, acc);   // skip: cat[xyz, h] (:551-552)
+            mma_segment<NTW, HS>(ring, ring_lane, H, acc);
+            act_store<NTW>(H, acc, l == 9 ? -__builtin_inff() : 0.f, bits);
+            if (mask_out && l <= 8) {
+#pragma unroll
+                for (int w = 0; w < (NTW + 1) / 2; ++w) mask_out[((l - 1) * ((NTW + 1) / 2) + w) * 64] = bits[w];
+            }
+        }
+        if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head();
+        if (MODE != NEFES_FIELD_SIGMA) {
+            // H now holds xyz_encoding_final (no activation, :559)
+            float G[GS];
+            f32x16 acc2[NTH];
+            uint32_t bits2[(NTH + 1) / 2];
+            constexpr int MW_TRUNK = 8 * ((NTW + 1) / 2);
+            // ---- dir_encoding: cat[final, dir-emb] -> W/2, ReLU ----
+            bias_init<NTH>(acc2, bias_half + B_DIR * 4);
+            mma_segment<NTH, HS>(ring, ring_lane, H, acc2);
+            mma_segment<NTH, NEFES_D_STEPS>(ring, ring_lane, Dv, acc2);
+            act_store<NTH>(G, acc2, 0.f, bits2);
+            if (mask_out) {
+#pragma unroll
+                for (int w = 0; w < (NTH + 1) / 2; ++w) mask_out[(MW_TRUNK + w) * 64] = bits2[w];
+            }
+            // ---- static_rgb: W/2 -> 3+C, no activation (:487-490) ----
+            {
+                f32x16 ar[NTR];
+                bias_init<NTR>(ar, bias_half + B_RGB * 4);
+                mma_segment<NTR, GS>(ring, ring_lane, G, ar);
+                if (valid) {
+#pragma unroll
+                    for (int t = 0; t < NTR; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ch = 32 * t + nefes_rho(h, r);
+                            if (ch < 3 + a.C) a.raw_t[((size_t)ray * a.R + ch) * a.S + smp] = ar[t][r];
+                        }
+                }
+            }
+            if (MODE == NEFES_FIELD_FULL) {
+                // ---- transient_encoding.{0,2,4} ----
+                bias_init<NTH>(acc2, bias_half + B_T0 * 4);
+                mma_segment<NTH, HS>(ring, ring_lane, H, acc2);
+                mma_segment<NTH, NEFES_D_STEPS>(ring, ring_lane, Dv, acc2);
+                act_store<NTH>(G, acc2, 0.f, bits2);
+                if (mask_out) {
+#pragma unroll
+                    for (int w = 0; w < (NTH + 1) / 2; ++w) mask_out[(MW_TRUNK + (NTH + 1) / 2 + w) * 64] = bits2[w];
+                }
+#pragma unroll 1
+                for (int tl = 1; tl <= 2; ++tl) {
+                    bias_init<NTH>(acc2, bias_half + (tl == 1 ? B_T1 : B_T2) * 4);
+                    mma_segment<NTH, GS>(ring, ring_lane, G, acc2);
+                    act_store<NTH>(G, acc2, 0.f, bits2);
+                    if (mask_out) {
+#pragma unroll
+                        for (int w = 0; w < (NTH + 1) / 2; ++w)
+                            mask_out[(MW_TRUNK + (1 + tl) * ((NTH + 1) / 2) + w) * 64] = bits2[w];
+                    }
+                }
+                // ---- transient heads: rows 0..2 rgb (sigmoid), 3 sigma (softplus), 4 beta (softplus) ----
+                f32x16 th[1];
+                bias_init<1>(th, bias_half + B_TH * 4);
+                mma_segment<1, GS>(ring, ring_lane, G, th);
+                if (valid) {
+                    float* o = a.raw_t + ((size_t)ray * a.R + 3 + a.C + 1) * a.S + smp;
+                    if (h == 0) {
+                        o[0] = sigmoid_ref(th[0][0]);
+                        o[(size_t)a.S] = sigmoid_ref(th[0][1]);
+                        o[(size_t)2 * a.S] = sigmoid_ref(th[0][2]);
+                        o[(size_t)3 * a.S] = softplus_ref(th[0][3]);
+                    } else {
+                        o[(size_t)4 * a.S] = softplus_ref(th[0][0]);
+                    }
+                }
+            }
+        }
+    }
+    ring.drain();
+}
+
+template <int W, int NTR, int MODE>
+static int launch_fwd(const FieldFwdArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)NEFES_RING_SLOTS * NEFES_SLAB_BYTES + ((a.bias_floats * 4 + 255) / 256) * 256;
+    auto k = field_fwd_kernel<W, NTR, MODE>;
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int grid = a.n_tiles < cus ? a.n_tiles : cus;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t nefes_field_mask_bytes(const NefesNetDesc* desc, int64_t M) {
+    if (!desc || M <= 0) return 0;
+    const int64_t tiles32 = ((M + 127) / 128) * 4;
+    return (size_t)tiles32 * nefes_mask_words(desc->width) * 64 * 4;
+}
+
+extern "C" int nefes_field_fwd(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                               const float* rays_d, const float* z, const float* pts, const float* viewdirs,
+                               float* raw_t, uint32_t* masks, void* stream) {
+    if (!desc || !packed || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
+    if (!pts && !(rays_o && rays_d && z)) return NEFES_E_BADARG;
+    if (mode != NEFES_FIELD_SIGMA && !viewdirs) return NEFES_E_BADARG;
+    if (mode == NEFES_FIELD_FULL && !desc->has_transient) return NEFES_E_BADARG;
+    NefesBlobInfo info;
+    int rc = nefes_blob_info(desc, &info);
+    if (rc) return rc;
+    const int sk = mode == NEFES_FIELD_SIGMA ? NEFES_STREAM_FWD_SIGMA
+                 : mode == NEFES_FIELD_STATIC ? NEFES_STREAM_FWD_STATIC : NEFES_STREAM_FWD_FULL;
+    const NefesStreamInfo& si = info.stream[sk];
+    if (si.n_slabs == 0) return NEFES_E_UNSUPPORTED;
+    FieldFwdArgs a;
+    a.stream = (const char*)packed + si.slab_off;
+    a.bias = (const float*)((const char*)packed + si.bias_off);
+    a.n_slabs = si.n_slabs; a.bias_floats = si.bias_floats;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.viewdirs = viewdirs;
+    a.raw_t = raw_t; a.masks = masks;
+    a.N = N; a.S = S; a.C = desc->feat_dim;
+    a.R = mode == NEFES_FIELD_SIGMA ? 1 : (mode == NEFES_FIELD_STATIC ? 3 + a.C + 1 : 3 + a.C + 6);
+    a.M = (long long)N * S;
+    a.n_tiles = (int)((a.M + 127) / 128);
+    hipStream_t st = (hipStream_t)stream;
+    const int W = desc->width, C = desc->feat_dim;
+    const int ntr = (3 + C + 31) / 32;
+#define NEFES_DISPATCH(WW, NN)                                                          \
+    if (W == WW && ntr == NN) {                                                         \
+        if (mode == NEFES_FIELD_SIGMA) return launch_fwd<WW, NN, NEFES_FIELD_SIGMA>(a, st);   \
+        if (mode == NEFES_FIELD_STATIC) return launch_fwd<WW, NN, NEFES_FIELD_STATIC>(a, st); \
+        return launch_fwd<WW, NN, NEFES_FIELD_FULL>(a, st);                             \
+    }
+    NEFES_DISPATCH(256, 1)   /* BASELINE metric shape: Wd=256, C=16 */
+    NEFES_DISPATCH(128, 5)   /* reference defaults:    Wd=128, C=128 */
+#undef NEFES_DISPATCH
+    return NEFES_E_UNSUPPORTED;
+}

@@ -1,0 +1,69 @@
+// Register/stream layout shared by the host-side weight packer (pack.cpp) and the
+// fused field kernels (field_fwd.hip / field_bwd.hip).
+//
+// The field MLP (reference: script/models/nerfh_nff.py:421-576) is evaluated
+// TRANSPOSED:  H'^T[out, sample] = W[out, in] * H^T[in, sample]  with
+// v_mfma_f32_32x32x2_f32 (A = weights, B = activations).  With that orientation the
+// 32x32 accumulator tile of one layer (lane = sample column, registers = feature
+// rows) is, register for register, the B operand of the next layer, so
+// activations never leave the register file.  Per wave: 32 samples.
+//
+// Vocabulary
+//   slot (s, h)  : register index s of an activation vector, lane half h = lane>>5.
+//                  One MFMA k-step consumes register s: half 0 supplies k = slot(s,0),
+//                  half 1 supplies k = slot(s,1).
+//   tile (t, i)  : accumulator tile t, row i (0..31).  Row i lives in register
+//                  r = (i&3) + 4*(i>>3) of lane half h = (i>>2)&1   [CDNA C/D map].
+//   fragment     : 64 lanes x 1 float = 256 B; the A operand of one MFMA.
+//   slab         : 16 KiB = up to 64 fragments in consumption order; the unit of
+//                  the LDS-DMA weight ring.  A slab never spans two segments.
+//   segment      : one (activation vector) x (weight block) product accumulated into
+//                  NT tiles over KS k-steps.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIP__)
+#define NEFES_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define NEFES_HD inline
+#endif
+
+#define NEFES_SLAB_BYTES 16384
+#define NEFES_SLAB_FRAGS 64
+#define NEFES_RING_SLOTS 8
+#define NEFES_N_FREQ_XYZ 10
+#define NEFES_N_FREQ_DIR 4
+#define NEFES_E_STEPS 32   /* 63 xyz-embedding features + 1 pad, two per k-step */
+#define NEFES_D_STEPS 14   /* 27 dir-embedding features + 1 pad */
+
+// accumulator row of (register r, lane half h)
+NEFES_HD int nefes_rho(int h, int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// inverse: row i -> register / half
+NEFES_HD int nefes_row_reg(int i) { return (i & 3) + 4 * (i >> 3); }
+NEFES_HD int nefes_row_half(int i) { return (i >> 2) & 1; }
+// natural hidden-vector slot -> feature index
+NEFES_HD int nefes_nat_slot(int s, int h) { return 32 * (s >> 4) + nefes_rho(h, s & 15); }
+// frequency-embedding slot -> index in the reference's embedding order
+//   reference order (nerfh_nff.py:257-267): [x(3), sin(2^0 x)(3), cos(2^0 x)(3), sin(2^1 x)(3), ...]
+//   ours: step s < 3L holds (sin | cos) of frequency s/3, axis s%3 in (half 0 | half 1);
+//         step 3L holds (x0 | x1); step 3L+1 holds (x2 | pad).   -1 = pad.
+NEFES_HD int nefes_emb_slot(int L, int s, int h) {
+    if (s < 3 * L) return 3 + 6 * (s / 3) + 3 * h + (s % 3);
+    if (s == 3 * L) return h;
+    if (s == 3 * L + 1) return h == 0 ? 2 : -1;
+    return -1;
+}
+// k-steps per slab for a segment with NT accumulator tiles
+NEFES_HD int nefes_steps_per_slab(int nt) { return NEFES_SLAB_FRAGS / nt; }
+NEFES_HD int nefes_segment_slabs(int nt, int ks) {
+    const int sps = NEFES_SLAB_FRAGS / nt;
+    return (ks + sps - 1) / sps;
+}
+
+// stream kinds inside a packed blob
+enum { NEFES_STREAM_FWD_SIGMA = 0, NEFES_STREAM_FWD_STATIC = 1, NEFES_STREAM_FWD_FULL = 2, NEFES_STREAM_BWD_FULL = 3,
+       NEFES_N_STREAMS = 4 };
+
+// ReLU-mask words (32 bit) written per lane per 32-sample tile by the full forward pass:
+// 8 trunk layers (W/64 words each) + dir + 3 transient layers (W/128 words each)
+NEFES_HD int nefes_mask_words(int W) { return 8 * (W / 64) + 4 * (W / 128); }

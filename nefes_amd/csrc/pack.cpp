@@ -1,0 +1,285 @@
+// Host-side weight packer: NeRFH_NFF state_dict (torch [out,in] fp32) -> MFMA fragment streams.
+// See layout.h for the vocabulary.  Reference tensors: script/models/nerfh_nff.py:452-505.
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/nefes_hip.h"
+#include "layout.h"
+
+namespace {
+
+enum { L_XYZ1 = 0, L_FINAL = 8, L_DIR = 9, L_SIGMA = 10, L_RGB = 11, L_T0 = 12, L_T1 = 13, L_T2 = 14, L_TSIGMA = 15,
+       L_TRGB = 16, L_TBETA = 17 };
+
+struct Seg {
+    int nt = 0, ks = 0;
+    std::vector<int> kidx;  // [ks][2]  column of W (row if transposed) per slot, -1 = pad
+    std::vector<int> ridx;  // [nt][32] row of W (column if transposed) per accumulator row, -1 = pad
+    const float* W = nullptr;
+    int ld = 0;
+    bool transposed = false;
+    float at(int s, int t, int lane) const {
+        const int i = lane & 31, h = lane >> 5;
+        const int r = ridx[t * 32 + i], k = kidx[s * 2 + h];
+        if (r < 0 || k < 0) return 0.f;
+        return transposed ? W[(size_t)k * ld + r] : W[(size_t)r * ld + k];
+    }
+    int slabs() const { return nefes_segment_slabs(nt, ks); }
+};
+
+struct BiasBlk {
+    const float* b;
+    std::vector<int> ridx;  // [nt*32] index into b or -1
+};
+
+struct Stream {
+    std::vector<Seg> segs;
+    std::vector<BiasBlk> bias;
+    int n_slabs() const {
+        int n = 0;
+        for (auto& s : segs) n += s.slabs();
+        return n;
+    }
+    int bias_floats() const {
+        int n = 0;
+        for (auto& b : bias) n += (int)b.ridx.size();
+        return n;
+    }
+};
+
+std::vector<int> rows_natural(int nt, int limit) {
+    std::vector<int> r(nt * 32);
+    for (int i = 0; i < nt * 32; ++i) r[i] = i < limit ? i : -1;
+    return r;
+}
+std::vector<int> k_natural(int ks, int base) {
+    std::vector<int> k(ks * 2);
+    for (int s = 0; s < ks; ++s)
+        for (int h = 0; h < 2; ++h) k[s * 2 + h] = base + nefes_nat_slot(s, h);
+    return k;
+}
+std::vector<int> k_emb(int L, int ks, int base) {
+    std::vector<int> k(ks * 2);
+    for (int s = 0; s < ks; ++s)
+        for (int h = 0; h < 2; ++h) {
+            const int e = nefes_emb_slot(L, s, h);
+            k[s * 2 + h] = e < 0 ? -1 : base + e;
+        }
+    return k;
+}
+std::vector<int> k_compact(int ks, int limit) {
+    std::vector<int> k(ks * 2);
+    for (int i = 0; i < ks * 2; ++i) k[i] = i < limit ? i : -1;
+    return k;
+}
+// accumulator rows of embedding tiles (backward): row i of tile tau <-> slot (16*tau + reg(i), half(i))
+std::vector<int> rows_emb(int L, int ntiles, int base) {
+    std::vector<int> r(ntiles * 32);
+    for (int t = 0; t < ntiles; ++t)
+        for (int i = 0; i < 32; ++i) {
+            const int e = nefes_emb_slot(L, 16 * t + nefes_row_reg(i), nefes_row_half(i));
+            r[t * 32 + i] = e < 0 ? -1 : base + e;
+        }
+    return r;
+}
+std::vector<int> concat(std::vector<int> a, const std::vector<int>& b) {
+    a.insert(a.end(), b.begin(), b.end());
+    return a;
+}
+
+struct Net {
+    int W, W2, C, NTW, NTH, NTR;
+    bool transient;
+    const float* const* t;
+    std::vector<float> th_w, th_b;  // virtual transient-head matrix [5][W2]: rgb(3), sigma, beta
+    const float* w(int l) const { return t[2 * l]; }
+    const float* b(int l) const { return t[2 * l + 1]; }
+};
+
+Seg seg(int nt, int ks, std::vector<int> kidx, std::vector<int> ridx, const float* W, int ld, bool tr = false) {
+    Seg s;
+    s.nt = nt; s.ks = ks; s.kidx = std::move(kidx); s.ridx = std::move(ridx); s.W = W; s.ld = ld; s.transposed = tr;
+    return s;
+}
+
+void add_trunk(const Net& n, Stream& st) {
+    const int W = n.W, NT = n.NTW;
+    for (int l = 0; l < 8; ++l) {
+        if (l == 0) {
+            st.segs.push_back(seg(NT, NEFES_E_STEPS, k_emb(10, NEFES_E_STEPS, 0), rows_natural(NT, W), n.w(0), 63));
+        } else if (l == 4) {  // skip layer: columns [xyz(63), h(W)]  (nerfh_nff.py:472-473,551-552)
+            st.segs.push_back(seg(NT, NEFES_E_STEPS, k_emb(10, NEFES_E_STEPS, 0), rows_natural(NT, W), n.w(4), 63 + W));
+            st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, 63), rows_natural(NT, W), n.w(4), 63 + W));
+        } else {
+            st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, 0), rows_natural(NT, W), n.w(l), W));
+        }
+        st.bias.push_back({n.b(l), rows_natural(NT, W)});
+    }
+    // static sigma head: one tile, row 0
+    st.segs.push_back(seg(1, W / 2, k_natural(W / 2, 0), rows_natural(1, 1), n.w(L_SIGMA), W));
+    st.bias.push_back({n.b(L_SIGMA), rows_natural(1, 1)});
+}
+
+void add_static_head(const Net& n, Stream& st) {
+    const int W = n.W, W2 = n.W2;
+    st.segs.push_back(seg(n.NTW, W / 2, k_natural(W / 2, 0), rows_natural(n.NTW, W), n.w(L_FINAL), W));
+    st.bias.push_back({n.b(L_FINAL), rows_natural(n.NTW, W)});
+    st.segs.push_back(seg(n.NTH, W / 2, k_natural(W / 2, 0), rows_natural(n.NTH, W2), n.w(L_DIR), W + 27));
+    st.segs.push_back(seg(n.NTH, NEFES_D_STEPS, k_emb(4, NEFES_D_STEPS, W), rows_natural(n.NTH, W2), n.w(L_DIR), W + 27));
+    st.bias.push_back({n.b(L_DIR), rows_natural(n.NTH, W2)});
+    st.segs.push_back(seg(n.NTR, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTR, 3 + n.C), n.w(L_RGB), W2));
+    st.bias.push_back({n.b(L_RGB), rows_natural(n.NTR, 3 + n.C)});
+}
+
+void add_transient_head(const Net& n, Stream& st) {
+    const int W = n.W, W2 = n.W2;
+    st.segs.push_back(seg(n.NTH, W / 2, k_natural(W / 2, 0), rows_natural(n.NTH, W2), n.w(L_T0), W + 27));
+    st.segs.push_back(seg(n.NTH, NEFES_D_STEPS, k_emb(4, NEFES_D_STEPS, W), rows_natural(n.NTH, W2), n.w(L_T0), W + 27));
+    st.bias.push_back({n.b(L_T0), rows_natural(n.NTH, W2)});
+    for (int l = L_T1; l <= L_T2; ++l) {
+        st.segs.push_back(seg(n.NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTH, W2), n.w(l), W2));
+        st.bias.push_back({n.b(l), rows_natural(n.NTH, W2)});
+    }
+    st.segs.push_back(seg(1, W2 / 2, k_natural(W2 / 2, 0), rows_natural(1, 5), n.th_w.data(), W2));
+    st.bias.push_back({n.th_b.data(), rows_natural(1, 5)});
+}
+
+// backward-to-inputs stream: A operand = W^T, B operand = upstream gradient vector
+void add_backward(const Net& n, Stream& st) {
+    const int W = n.W, W2 = n.W2, NTW = n.NTW, NTH = n.NTH;
+    // transient heads^T: in = 5 pre-activation grads (compact slots), out = d t2
+    st.segs.push_back(seg(NTH, 3, k_compact(3, 5), rows_natural(NTH, W2), n.th_w.data(), W2, true));
+    st.segs.push_back(seg(NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(NTH, W2), n.w(L_T2), W2, true));
+    st.segs.push_back(seg(NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(NTH, W2), n.w(L_T1), W2, true));
+    // static rgb/feature head^T: in = 3+C grads (compact), out = d g
+    const int kr = (3 + n.C + 1) / 2;
+    st.segs.push_back(seg(NTH, kr, k_compact(kr, 3 + n.C), rows_natural(NTH, W2), n.w(L_RGB), W2, true));
+    // [transient_encoding.0 ; dir_encoding]^T: out rows = final features (NTW tiles) + dir-embedding slots (1 tile)
+    std::vector<int> rows_fd = concat(rows_natural(NTW, W), rows_emb(4, 1, W));
+    st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_T0), W + 27, true));
+    st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_DIR), W + 27, true));
+    // xyz_encoding_final^T, plus the static-sigma head as one extra k-step
+    st.segs.push_back(seg(NTW, W / 2, k_natural(W / 2, 0), rows_natural(NTW, W), n.w(L_FINAL), W, true));
+    st.segs.push_back(seg(NTW, 1, k_compact(1, 1), rows_natural(NTW, W), n.w(L_SIGMA), W, true));
+    for (int l = 7; l >= 0; --l) {
+        if (l == 4) {
+            std::vector<int> rows = concat(rows_emb(10, 2, 0), rows_natural(NTW, W));
+            for (int i = 64; i < (int)rows.size(); ++i) rows[i] += 63;
+            st.segs.push_back(seg(NTW + 2, W / 2, k_natural(W / 2, 0), rows, n.w(4), 63 + W, true));
+        } else if (l == 0) {
+            st.segs.push_back(seg(2, W / 2, k_natural(W / 2, 0), rows_emb(10, 2, 0), n.w(0), 63, true));
+        } else {
+            st.segs.push_back(seg(NTW, W / 2, k_natural(W / 2, 0), rows_natural(NTW, W), n.w(l), W, true));
+        }
+    }
+}
+
+bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&st)[NEFES_N_STREAMS]) {
+    if (!d) return false;
+    if (d->width != 128 && d->width != 256) return false;
+    if (d->feat_dim < 0 || 3 + d->feat_dim > 160) return false;
+    n.W = d->width; n.W2 = n.W / 2; n.C = d->feat_dim;
+    n.NTW = n.W / 32; n.NTH = n.W2 / 32; n.NTR = (3 + n.C + 31) / 32;
+    n.transient = d->has_transient != 0;
+    n.t = tensors;
+    if (tensors && n.transient) {
+        n.th_w.assign((size_t)5 * n.W2, 0.f);
+        n.th_b.assign(5, 0.f);
+        memcpy(&n.th_w[0], n.w(L_TRGB), sizeof(float) * 3 * n.W2);
+        memcpy(&n.th_w[(size_t)3 * n.W2], n.w(L_TSIGMA), sizeof(float) * n.W2);
+        memcpy(&n.th_w[(size_t)4 * n.W2], n.w(L_TBETA), sizeof(float) * n.W2);
+        memcpy(&n.th_b[0], n.b(L_TRGB), sizeof(float) * 3);
+        n.th_b[3] = n.b(L_TSIGMA)[0];
+        n.th_b[4] = n.b(L_TBETA)[0];
+    } else {
+        n.th_w.assign((size_t)5 * n.W2, 0.f);
+        n.th_b.assign(5, 0.f);
+    }
+    // a null `tensors` is allowed for geometry queries: substitute a dummy table
+    static const float* dummy[36] = {nullptr};
+    if (!tensors) n.t = dummy;
+    add_trunk(n, st[NEFES_STREAM_FWD_SIGMA]);
+    add_trunk(n, st[NEFES_STREAM_FWD_STATIC]);
+    add_static_head(n, st[NEFES_STREAM_FWD_STATIC]);
+    if (n.transient) {
+        add_trunk(n, st[NEFES_STREAM_FWD_FULL]);
+        add_static_head(n, st[NEFES_STREAM_FWD_FULL]);
+        add_transient_head(n, st[NEFES_STREAM_FWD_FULL]);
+        add_backward(n, st[NEFES_STREAM_BWD_FULL]);
+    }
+    return true;
+}
+
+const uint64_t kHeaderBytes = 256;
+uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+void fill_info(const Stream (&st)[NEFES_N_STREAMS], NefesBlobInfo* info) {
+    uint64_t off = kHeaderBytes;
+    for (int k = 0; k < NEFES_N_STREAMS; ++k) {
+        NefesStreamInfo& si = info->stream[k];
+        si.n_slabs = (uint32_t)st[k].n_slabs();
+        si.bias_floats = (uint32_t)st[k].bias_floats();
+        if (si.n_slabs == 0) { si.slab_off = si.bias_off = 0; si.bias_floats = 0; continue; }
+        si.bias_off = off;
+        off = align_up(off + 4ull * si.bias_floats, 256);
+        si.slab_off = off;
+        off += (uint64_t)si.n_slabs * NEFES_SLAB_BYTES;
+    }
+    info->total_bytes = off;
+}
+
+}  // namespace
+
+extern "C" int nefes_version(void) { return NEFES_ABI_VERSION; }
+
+extern "C" int nefes_blob_info(const NefesNetDesc* desc, NefesBlobInfo* info) {
+    if (!desc || !info) return NEFES_E_BADARG;
+    Net n;
+    Stream st[NEFES_N_STREAMS];
+    if (!build(desc, nullptr, n, st)) return NEFES_E_UNSUPPORTED;
+    fill_info(st, info);
+    return 0;
+}
+
+extern "C" int nefes_pack_weights(const NefesNetDesc* desc, const float* const* tensors, int n_tensors, void* blob,
+                                  size_t blob_bytes) {
+    if (!desc || !tensors || !blob) return NEFES_E_BADARG;
+    const int need = desc->has_transient ? 36 : 24;
+    if (n_tensors < need) return NEFES_E_BADARG;
+    for (int i = 0; i < need; ++i)
+        if (!tensors[i]) return NEFES_E_BADARG;
+    Net n;
+    Stream st[NEFES_N_STREAMS];
+    if (!build(desc, tensors, n, st)) return NEFES_E_UNSUPPORTED;
+    NefesBlobInfo info;
+    fill_info(st, &info);
+    if (blob_bytes < info.total_bytes) return NEFES_E_BADBLOB;
+    char* base = (char*)blob;
+    memset(base, 0, info.total_bytes);
+    uint32_t* hdr = (uint32_t*)base;
+    hdr[0] = 0x5346454eu;  // 'NEFS'
+    hdr[1] = NEFES_ABI_VERSION;
+    memcpy(hdr + 2, desc, sizeof(*desc));
+    memcpy(hdr + 8, &info, sizeof(info));
+    for (int k = 0; k < NEFES_N_STREAMS; ++k) {
+        const NefesStreamInfo& si = info.stream[k];
+        if (si.n_slabs == 0) continue;
+        float* bias = (float*)(base + si.bias_off);
+        for (auto& bb : st[k].bias)
+            for (int r : bb.ridx) *bias++ = r < 0 ? 0.f : bb.b[r];
+        float* slab = (float*)(base + si.slab_off);
+        for (auto& sg : st[k].segs) {
+            const int sps = nefes_steps_per_slab(sg.nt);
+            for (int sl = 0; sl < sg.slabs(); ++sl, slab += NEFES_SLAB_BYTES / 4) {
+                const int steps = (sg.ks - sl * sps) < sps ? (sg.ks - sl * sps) : sps;
+                for (int f = 0; f < steps * sg.nt; ++f) {
+                    const int s = sl * sps + f / sg.nt, t = f % sg.nt;
+                    float* dst = slab + (f >> 2) * 256 + (f & 3);   // b128 group f/4, component f%4
+                    for (int lane = 0; lane < 64; ++lane) dst[lane * 4] = sg.at(s, t, lane);
+                }
+            }
+        }
+    }
+    return 0;
+}

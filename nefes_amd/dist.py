@@ -1,0 +1,75 @@
+"""Ray-batch data parallelism for the render-and-refine path: one process per GPU, rays sharded by
+image rows, weights replicated (2.7 MB), and exactly one collective per backward: an all-reduce (SUM)
+of the 3x4 pose gradient (48 bytes) over RCCL/xGMI.  The reference has no distributed code at all
+(`--multi_gpu` is nn.DataParallel, nerfh_nff.py:647-648); this is new functionality.
+
+No data-path collective exists in the forward pass: every rank generates its own rays from the
+(replicated) pose.  If a whole-image loss follows (FusionNet), use `gather_maps`.
+"""
+import torch
+import torch.distributed as dist
+
+
+def row_shard(H: int, rank: int, world: int):
+    """Contiguous block of image rows for `rank`: (row0, nrows).  Remainder rows go to the first ranks."""
+    base, rem = divmod(H, world)
+    nrows = base + (1 if rank < rem else 0)
+    row0 = rank * base + min(rank, rem)
+    return row0, nrows
+
+
+class _PoseGradAllReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c2w, group):
+        ctx.group = group
+        return c2w.view_as(c2w)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(ctx.group) > 1:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)      # the single collective: 12 floats
+        return g, None
+
+
+def replicate_pose(c2w: torch.Tensor, group=None) -> torch.Tensor:
+    """Identity in forward; all-reduces the pose gradient in backward.  Wrap the pose once per iteration,
+    render this rank's rows from the result, and every rank ends up with the full d loss / d c2w."""
+    return _PoseGradAllReduce.apply(c2w, group)
+
+
+def render_sharded(render_fn, H, W, focal, c2w, rank=None, world=None, group=None, **kw):
+    """render() restricted to this rank's rows, with the pose-gradient all-reduce attached."""
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    row0, nrows = row_shard(H, rank, world)
+    return render_fn(H, W, focal, c2w=replicate_pose(c2w, group), row_range=(row0, nrows), **kw)
+
+
+def gather_maps(local: torch.Tensor, H: int, group=None) -> torch.Tensor:
+    """all_gather of per-rank [rows*W, C] maps into the full image order (for whole-image losses).
+    Differentiable: the backward hands each rank the slice of the gradient that belongs to its rows."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    return _GatherRows.apply(local, H, group)
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, local, H, group):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        per_row = local.shape[0] // row_shard(H, rank, world)[1]
+        sizes = [row_shard(H, r, world)[1] * per_row for r in range(world)]
+        bufs = [local.new_empty((s,) + tuple(local.shape[1:])) for s in sizes]
+        dist.all_gather(bufs, local.contiguous(), group=group) if len(set(sizes)) == 1 else \
+            [dist.broadcast(b if r != rank else b.copy_(local), src=dist.get_global_rank(group, r) if group else r, group=group)
+             for r, b in enumerate(bufs)]
+        ctx.slice = (sum(sizes[:rank]), sizes[rank])
+        return torch.cat(bufs, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        off, n = ctx.slice
+        return g[off:off + n].contiguous(), None, None

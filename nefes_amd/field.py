@@ -1,0 +1,209 @@
+"""Field network: host-side mirror of the reference's NeRFH_NFF module and its query function.
+
+Mirrors script/models/nerfh_nff.py (reference): class NeRFH_NFF (:421-626), FusionNet (:356-418),
+get_embedder/Embedder (:234-354), run_network_NeRFH_NFF (:168-231).  Parameter names and
+construction order are identical, so reference checkpoints load with load_state_dict and
+`torch.manual_seed(0)` random init is bit-identical (checked in tests against stored checksums).
+
+The per-sample evaluation on the render path is NOT torch: `run_network_NeRFH_NFF` and
+`render()` hand the module to the fused HIP kernels through `module.packed()`.
+`NeRFH_NFF.forward` (pre-embedded inputs, the nn.Module API) is kept in torch only so that code
+which calls the module directly keeps working; nothing on the render path calls it.
+"""
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from . import ops
+
+FEATURE_DIM = 128        # nerfh_nff.py:21
+
+
+class FusionNet(nn.Module):
+    """4-layer conv 'fusion' CNN on the rendered (rgb || feature) image (nerfh_nff.py:356-418).
+    Runs once per image after the path; plain torch (MIOpen) by design."""
+    mean = [0.485, 0.456, 0.406]
+    std = [0.229, 0.224, 0.225]
+
+    def __init__(self, f_dim, fusion_residule=False, no_BN=False):
+        super().__init__()
+        self.fusion_residule, self.no_BN = fusion_residule, no_BN
+        layers = [nn.Conv2d(3 + f_dim, 64, 3, 1, 1), nn.ReLU(), nn.Conv2d(64, 64, 3, 1, 1), nn.ReLU(),
+                  nn.Conv2d(64, 64, 3, 1, 1), nn.ReLU(), nn.Conv2d(64, f_dim, 5, 1, 2)]
+        if not no_BN:
+            layers.append(nn.BatchNorm2d(f_dim))
+        self.net = nn.Sequential(*layers)
+
+    def forward(self, x):
+        mean, std = x.new_tensor(self.mean), x.new_tensor(self.std)
+        x[:, :3] = (x[:, :3] - mean[:, None, None]) / std[:, None, None]     # in place, as the reference does
+        out = self.net(x)
+        return x[:, 3:] + out if self.fusion_residule else out
+
+
+class ExposureMLP(nn.Module):
+    """tcnn-free stand-in for tcnn.Network(10 -> 12, FullyFusedMLP, 32 neurons, 3 hidden layers, ReLU, no bias)
+    (nerfh_nff.py:511-522).  Keeps the flat `params` vector of the checkpoints: matrices stored back to back,
+    each [out, in] row-major with the input padded 10->16 and the output padded 12->16 (tiny-cuda-nn's published
+    FullyFusedMLP layout; parity UNPINNED -- tiny-cuda-nn is not vendored by the reference)."""
+    SHAPES = [(32, 16), (32, 32), (32, 32), (16, 32)]
+
+    def __init__(self, n_input_dims=10, n_output_dims=12):
+        super().__init__()
+        self.n_in, self.n_out = n_input_dims, n_output_dims
+        n = sum(o * i for o, i in self.SHAPES)
+        self.params = nn.Parameter(torch.empty(n).uniform_(-0.2, 0.2))
+
+    def forward(self, x):
+        h = torch.nn.functional.pad(x.float(), (0, 16 - self.n_in))
+        off = 0
+        for k, (o, i) in enumerate(self.SHAPES):
+            w = self.params[off:off + o * i].view(o, i)
+            off += o * i
+            h = h @ w.t()
+            if k + 1 < len(self.SHAPES):
+                h = torch.relu(h)
+        return h[:, :self.n_out]
+
+
+class NeRFH_NFF(nn.Module):
+    """Same constructor, attributes and parameter names as the reference (nerfh_nff.py:421-522)."""
+
+    def __init__(self, typ, D=8, W=256, skips=[4], in_channels_xyz=63, in_channels_dir=27, encode_appearance=False,
+                 in_channels_a=48, encode_transient=False, in_channels_t=16, beta_min=0.1, out_ch_size=3,
+                 f_dim=FEATURE_DIM, fusion_residule=False, no_BN=False):
+        super().__init__()
+        torch.manual_seed(0)                                         # reference side effect (:446)
+        self.typ, self.D, self.W, self.skips = typ, D, W, list(skips)
+        self.in_channels_xyz, self.in_channels_dir = in_channels_xyz, in_channels_dir
+        self.encode_appearance = False if typ == 'coarse' else encode_appearance
+        self.encode_transient = False if typ == 'coarse' else encode_transient
+        self.beta_min = beta_min
+        self.W_features = f_dim
+        self.out_ch_size = out_ch_size + f_dim
+        self.fusion_residule, self.no_BN = fusion_residule, no_BN
+        for i in range(D):
+            n_in = in_channels_xyz if i == 0 else (W + in_channels_xyz if i in self.skips else W)
+            setattr(self, f"xyz_encoding_{i + 1}", nn.Sequential(nn.Linear(n_in, W), nn.ReLU(True)))
+        self.xyz_encoding_final = nn.Linear(W, W)
+        self.dir_encoding = nn.Sequential(nn.Linear(W + in_channels_dir, W // 2), nn.ReLU(True))
+        self.static_sigma = nn.Sequential(nn.Linear(W, 1), nn.Softplus())
+        if self.out_ch_size == 3:
+            self.static_rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Sigmoid())
+        else:
+            self.static_rgb = nn.Sequential(nn.Linear(W // 2, self.out_ch_size))
+        if self.encode_transient:
+            self.transient_encoding = nn.Sequential(nn.Linear(W + in_channels_dir, W // 2), nn.ReLU(True),
+                                                    nn.Linear(W // 2, W // 2), nn.ReLU(True),
+                                                    nn.Linear(W // 2, W // 2), nn.ReLU(True))
+            self.transient_sigma = nn.Sequential(nn.Linear(W // 2, 1), nn.Softplus())
+            if out_ch_size == 3:
+                self.transient_rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Sigmoid())
+            else:
+                self.transient_rgb = nn.Sequential(nn.Linear(W // 2, self.out_ch_size))
+            self.transient_beta = nn.Sequential(nn.Linear(W // 2, 1), nn.Softplus())
+        if typ == 'coarse':
+            self.fusion_net = FusionNet(self.W_features, fusion_residule, no_BN)
+            self.exposure_embedding = ExposureMLP(10, 12)
+            self.sigmoid = nn.Sigmoid()
+        self._pk = None
+        self._pk_key = None
+
+    # -- the HIP path ---------------------------------------------------------------------------
+    def _supported(self):
+        return (self.D == 8 and self.skips == [4] and self.in_channels_xyz == 63 and self.in_channels_dir == 27
+                and self.W in (128, 256) and self.out_ch_size != 3)
+
+    def packed(self) -> ops.PackedField:
+        """Fragment streams for the fused kernels; re-packed when any path parameter changes."""
+        if not self._supported():
+            raise RuntimeError("nefes_amd: the HIP field kernels are built for D=8, skips=[4], 63/27 encodings, "
+                               "W in {128,256} and a feature head (f_dim>0); got an unsupported NeRFH_NFF configuration")
+        names = ops.PackedField.LAYERS_FINE if self.encode_transient else ops.PackedField.LAYERS_COARSE
+        sd = dict(self.named_parameters())
+        prm = [sd[n + s] for n in names for s in (".weight", ".bias")]
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in prm)
+        if self._pk is None or key != self._pk_key:
+            dev = prm[0].device if prm[0].is_cuda else torch.device("cuda")
+            self._pk = ops.PackedField({n: p for n, p in sd.items()}, self.W, self.W_features, self.encode_transient, dev)
+            self._pk_key = key
+        return self._pk
+
+    # -- nn.Module API on pre-embedded inputs (not on the render path) ---------------------------
+    def forward(self, x, sigma_only=False, output_transient=True):
+        if sigma_only:
+            input_xyz = x
+        else:
+            input_xyz, input_dir_a = torch.split(x, [self.in_channels_xyz, self.in_channels_dir], dim=-1)
+        h = input_xyz
+        for i in range(self.D):
+            if i in self.skips:
+                h = torch.cat([input_xyz, h], 1)
+            h = getattr(self, f"xyz_encoding_{i + 1}")(h)
+        static_sigma = self.static_sigma(h)
+        if sigma_only:
+            return static_sigma
+        final = self.xyz_encoding_final(h)
+        head_in = torch.cat([final, input_dir_a], 1)
+        static = torch.cat([self.static_rgb(self.dir_encoding(head_in)), static_sigma], 1)
+        if not output_transient:
+            return static
+        t = self.transient_encoding(head_in)
+        return torch.cat([static, self.transient_rgb(t), self.transient_sigma(t), self.transient_beta(t)], 1)
+
+    # -- post-render helpers used by the refinement loop (nerfh_nff.py:578-626) ----------------------
+    def run_fusion_net(self, rgb, feature, H, W, B):
+        render_rgb = rgb.reshape(B, H, W, 3).permute(0, 3, 1, 2)
+        render_feature = feature.reshape(B, H, W, self.W_features).permute(0, 3, 1, 2)
+        fused = self.fusion_net(torch.cat([render_rgb, render_feature], dim=1))
+        return render_rgb, render_feature, fused
+
+    def affine_color_transform(self, args, rgb, hist, batch_size):
+        assert args.encode_hist and self.typ == 'coarse'
+        self.a_embedded = self.exposure_embedding(hist.long()).float()
+        kernel = self.a_embedded[:, :9].reshape(-1, 3, 3)
+        bias = self.a_embedded[:, 9:].reshape(-1, 3, 1)
+        rgb = rgb.reshape(batch_size, -1, 3)
+        rgb = torch.bmm(kernel, rgb.transpose(1, 2)) + bias
+        return self.sigmoid(rgb.transpose(1, 2).reshape(-1, 3))
+
+
+def run_network_NeRFH_NFF(inputs, viewdirs, ts, fn, embed_fn=None, embeddirs_fn=None, typ='coarse', output_transient=False,
+                          netchunk=1024 * 64, test_time=False, store_rgb=False):
+    """Reference signature (nerfh_nff.py:168-170).  inputs [N,S,3], viewdirs [N,3] -> raw [N,S,R].
+    The embedders and `netchunk` are accepted for compatibility; the fused kernel embeds in-register and
+    tiles internally.  The result is a permuted view of the kernel's channel-major raw_t [N,R,S]."""
+    pk = fn.packed()
+    if typ == 'coarse' and test_time:
+        mode = L.FIELD_SIGMA
+    elif typ == 'coarse' or not output_transient:
+        mode = L.FIELD_STATIC
+    else:
+        mode = L.FIELD_FULL
+    dev = pk.blob.device
+    raw_t = ops.FieldFromPoints.apply(inputs.to(dev), None if viewdirs is None else viewdirs.to(dev), pk, mode)
+    return raw_t.permute(0, 2, 1)
+
+
+class _Embedder:
+    """Embedder (nerfh_nff.py:234-270), kept because create_nerf returns embed fns inside the query lambda."""
+
+    def __init__(self, multires, include_input=True):
+        self.N_freqs, self.out_dim = multires, 3 * (1 + 2 * multires)
+        self.freq_bands = 2. ** torch.linspace(0., multires - 1, steps=multires) if multires > 0 else torch.zeros(0)
+
+    def embed(self, x):
+        parts = [x]
+        for f in self.freq_bands:
+            parts += [torch.sin(x * f), torch.cos(x * f)]
+        return torch.cat(parts, -1)
+
+
+def get_embedder(multires, i=0, reduce_mode=-1, epochToMaxFreq=-1):
+    """nerfh_nff.py:303-354.  Only the paper-default encoding (reduce_mode=-1) is built into the kernels."""
+    if i == -1:
+        return nn.Identity(), 3
+    if reduce_mode not in (-1,):
+        raise NotImplementedError("nefes_amd: reduce_embedding modes 0/1/2 are not built into the HIP field kernels")
+    eo = _Embedder(multires)
+    return (lambda x, eo=eo: eo.embed(x)), eo.out_dim, eo

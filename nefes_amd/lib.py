@@ -1,0 +1,82 @@
+"""ctypes binding of libnefes_hip.so (C ABI: include/nefes_hip.h).
+
+There is no CPU fallback: if the library cannot be loaded the product path raises.
+`import torch` happens first so that the HIP runtime already mapped by PyTorch-ROCm
+(same SONAME libamdhip64.so.7) is the one the kernels launch on, which makes
+`torch.cuda.current_stream().cuda_stream` a valid hipStream_t for every call.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede dlopen of libnefes_hip.so, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnefes_hip.so")
+
+
+class NefesNetDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("feat_dim", C.c_int32), ("has_transient", C.c_int32), ("reserved", C.c_int32)]
+
+
+class NefesStreamInfo(C.Structure):
+    _fields_ = [("slab_off", C.c_uint64), ("n_slabs", C.c_uint32), ("bias_floats", C.c_uint32), ("bias_off", C.c_uint64)]
+
+
+class NefesBlobInfo(C.Structure):
+    _fields_ = [("total_bytes", C.c_uint64), ("stream", NefesStreamInfo * 4)]
+
+
+STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL = 0, 1, 2, 3
+FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
+COMP_TRANSIENT, COMP_STATIC_ONLY, COMP_SIGMA_ONLY, COMP_WHITE_BKGD = 1, 2, 4, 8
+
+_p, _i, _f, _u32, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t
+_desc = C.POINTER(NefesNetDesc)
+
+# name -> (restype, argtypes); mirrors include/nefes_hip.h declaration by declaration
+SIGNATURES = {
+    "nefes_version": (_i, []),
+    "nefes_blob_info": (_i, [_desc, C.POINTER(NefesBlobInfo)]),
+    "nefes_pack_weights": (_i, [_desc, C.POINTER(_p), _i, _p, _sz]),
+    "nefes_raygen_fwd": (_i, [_i, _i, _f, _p, _i, _i, _p, _p, _p, _p]),
+    "nefes_raygen_bwd_workspace": (_sz, [_i]),
+    "nefes_raygen_bwd": (_i, [_i, _i, _f, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "nefes_ndc_fwd": (_i, [_i, _i, _f, _f, _i, _p, _p, _p, _p, _p]),
+    "nefes_ndc_bwd": (_i, [_i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_coarse_depths": (_i, [_i, _i, _f, _f, _i, _p, _p, _p, _p]),
+    "nefes_field_mask_bytes": (_sz, [_desc, C.c_int64]),
+    "nefes_field_fwd": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_field_bwd": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_ray_grad_reduce": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_composite_fwd": (_i, [_i, _i, _i, _u32, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_composite_bwd": (_i, [_i, _i, _i, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_sample_pdf_merge": (_i, [_i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Return the loaded library; raise RuntimeError (never fall back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C nefes_amd/csrc`. nefes_amd has no CPU or PyTorch fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = ABI mismatch; let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nefes_version() != 1:
+        raise RuntimeError("libnefes_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "unsupported configuration", -3: "bad weight blob"}.get(rc, f"hipError {rc}")
+        raise RuntimeError(f"{what} failed: {kind}")

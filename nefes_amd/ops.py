@@ -1,0 +1,348 @@
+"""torch-facing wrappers of the C ABI (include/nefes_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation on the hot
+path is a HIP kernel in libnefes_hip.so.  All tensors are fp32 CUDA(=HIP) tensors; wrappers
+check dtype/contiguity/device and raise rather than silently converting on a different path.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# Optional per-kernel timing (bench.py): when TIMERS is a dict, every C-ABI launch is bracketed by HIP events
+# recorded on the launch stream (torch's current stream is the stream the kernels are launched on).
+TIMERS = None
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TIMERS is not None:
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t1 = torch.cuda.Event(enable_timing=True)
+            self.t0.record()
+
+    def __exit__(self, *exc):
+        if TIMERS is not None:
+            self.t1.record()
+            TIMERS.setdefault(self.name, []).append((self.t0, self.t1))
+        return False
+
+
+def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"nefes_amd: `{name}` must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"nefes_amd: `{name}` must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError(f"nefes_amd: `{name}` must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# rays
+# ---------------------------------------------------------------------------------------------
+def raygen_fwd(H, W, focal, c2w, row0=0, nrows=None):
+    nrows = H - row0 if nrows is None else nrows
+    c2w = _f32(c2w[:3, :4])
+    n = nrows * W
+    o = torch.empty(n, 3, device=c2w.device)
+    d = torch.empty_like(o)
+    v = torch.empty_like(o)
+    L.check(L.load().nefes_raygen_fwd(H, W, float(focal), _chk(c2w, "c2w"), row0, nrows, _chk(o, "o"), _chk(d, "d"),
+                                      _chk(v, "v"), _stream()), "nefes_raygen_fwd")
+    return o, d, v
+
+
+def raygen_bwd(H, W, focal, c2w, row0, nrows, g_o, g_d, g_v):
+    lib = L.load()
+    c2w = _f32(c2w[:3, :4])
+    n = nrows * W
+    ws = torch.empty(lib.nefes_raygen_bwd_workspace(n), dtype=torch.uint8, device=c2w.device)
+    g = torch.empty(3, 4, device=c2w.device)
+    fix = lambda t: None if t is None else _f32(t)
+    g_o, g_d, g_v = fix(g_o), fix(g_d), fix(g_v)
+    L.check(lib.nefes_raygen_bwd(H, W, float(focal), _chk(c2w, "c2w"), row0, nrows, _chk(g_o, "g_o"), _chk(g_d, "g_d"),
+                                 _chk(g_v, "g_v"), _chk(ws, "ws", torch.uint8), _chk(g, "g_c2w"), _stream()),
+            "nefes_raygen_bwd")
+    return g
+
+
+class RayGen(torch.autograd.Function):
+    """get_rays + viewdirs (ray_utils.py:5-16, rendering.py:217) with the backward to the pose."""
+
+    @staticmethod
+    def forward(ctx, c2w, H, W, focal, row0, nrows):
+        o, d, v = raygen_fwd(H, W, focal, c2w, row0, nrows)
+        ctx.save_for_backward(c2w)
+        ctx.geom = (H, W, focal, row0, nrows)
+        return o, d, v
+
+    @staticmethod
+    def backward(ctx, g_o, g_d, g_v):
+        (c2w,) = ctx.saved_tensors
+        H, W, focal, row0, nrows = ctx.geom
+        g = raygen_bwd(H, W, focal, c2w, row0, nrows, g_o, g_d, g_v)
+        out = torch.zeros_like(c2w)
+        out[:3, :4] = g
+        return out, None, None, None, None, None
+
+
+class NdcRays(torch.autograd.Function):
+    """ndc_rays (ray_utils.py:27-44)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, H, W, focal, near):
+        o, d = _f32(rays_o).reshape(-1, 3), _f32(rays_d).reshape(-1, 3)
+        oo, od = torch.empty_like(o), torch.empty_like(d)
+        L.check(L.load().nefes_ndc_fwd(H, W, float(focal), float(near), o.shape[0], _chk(o, "o"), _chk(d, "d"),
+                                       _chk(oo, "oo"), _chk(od, "od"), _stream()), "nefes_ndc_fwd")
+        ctx.save_for_backward(o, d)
+        ctx.geom = (H, W, focal, near, rays_o.shape)
+        return oo.reshape(rays_o.shape), od.reshape(rays_d.shape)
+
+    @staticmethod
+    def backward(ctx, g_oo, g_od):
+        o, d = ctx.saved_tensors
+        H, W, focal, near, shape = ctx.geom
+        go, gd = torch.empty_like(o), torch.empty_like(d)
+        g_oo = None if g_oo is None else _f32(g_oo).reshape(-1, 3)
+        g_od = None if g_od is None else _f32(g_od).reshape(-1, 3)
+        L.check(L.load().nefes_ndc_bwd(H, W, float(focal), float(near), o.shape[0], _chk(o, "o"), _chk(d, "d"),
+                                       _chk(g_oo, "g_oo"), _chk(g_od, "g_od"), _chk(go, "go"), _chk(gd, "gd"), _stream()),
+                "nefes_ndc_bwd")
+        return go.reshape(shape), gd.reshape(shape), None, None, None, None
+
+
+def coarse_depths(N, Nc, near, far, lindisp=False, t_rand=None, device="cuda"):
+    t = torch.linspace(0., 1., steps=Nc, device=device)            # rendering.py:95 (torch's own two-sided formula)
+    z = torch.empty(N, Nc, device=device)
+    t_rand = None if t_rand is None else _f32(t_rand)
+    L.check(L.load().nefes_coarse_depths(N, Nc, float(near), float(far), int(bool(lindisp)), _chk(t, "t"),
+                                         _chk(t_rand, "t_rand"), _chk(z, "z"), _stream()), "nefes_coarse_depths")
+    return z
+
+
+# ---------------------------------------------------------------------------------------------
+# field MLP
+# ---------------------------------------------------------------------------------------------
+class PackedField:
+    """Device-resident fragment streams of one NeRFH_NFF network (nefes_pack_weights)."""
+
+    LAYERS_COARSE = [f"xyz_encoding_{i}.0" for i in range(1, 9)] + ["xyz_encoding_final", "dir_encoding.0",
+                                                                    "static_sigma.0", "static_rgb.0"]
+    LAYERS_FINE = LAYERS_COARSE + ["transient_encoding.0", "transient_encoding.2", "transient_encoding.4",
+                                   "transient_sigma.0", "transient_rgb.0", "transient_beta.0"]
+
+    def __init__(self, state_dict, width, feat_dim, has_transient, device):
+        lib = L.load()
+        self.desc = L.NefesNetDesc(int(width), int(feat_dim), 1 if has_transient else 0, 0)
+        self.width, self.feat_dim, self.has_transient = int(width), int(feat_dim), bool(has_transient)
+        info = L.NefesBlobInfo()
+        L.check(lib.nefes_blob_info(self.desc, info), "nefes_blob_info")
+        names = self.LAYERS_FINE if has_transient else self.LAYERS_COARSE
+        host = []
+        for n in names:
+            host.append(state_dict[n + ".weight"].detach().to("cpu", torch.float32).contiguous())
+            host.append(state_dict[n + ".bias"].detach().to("cpu", torch.float32).contiguous())
+        ptrs = (C.c_void_p * len(host))(*[t.data_ptr() for t in host])
+        blob = torch.zeros(info.total_bytes, dtype=torch.uint8)
+        L.check(lib.nefes_pack_weights(self.desc, ptrs, len(host), C.c_void_p(blob.data_ptr()), blob.numel()),
+                "nefes_pack_weights")
+        self.blob = blob.to(device)
+        self.info = info
+
+    def mask_bytes(self, M):
+        return L.load().nefes_field_mask_bytes(self.desc, M)
+
+    def n_raw(self, mode):
+        return 1 if mode == L.FIELD_SIGMA else (3 + self.feat_dim + (1 if mode == L.FIELD_STATIC else 6))
+
+
+def field_fwd(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, pts=None, viewdirs=None, want_masks=False):
+    dev = pk.blob.device
+    raw_t = torch.empty(N, pk.n_raw(mode), S, device=dev)
+    masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=dev) if want_masks else None
+    with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]}]"):
+      L.check(L.load().nefes_field_fwd(pk.desc, _chk(pk.blob, "blob", torch.uint8), mode, N, S, _chk(rays_o, "rays_o"),
+                                     _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),
+                                     _chk(raw_t, "raw_t"), _chk(masks, "masks", torch.int32), _stream()), "nefes_field_fwd")
+    return raw_t, masks
+
+
+def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=None, z=None, pts=None, viewdirs=None):
+    dev = pk.blob.device
+    g_pts = torch.empty(N * S, 3, device=dev)
+    g_vs = torch.empty(N * S, 3, device=dev)
+    with _timed("field_bwd"):
+      L.check(L.load().nefes_field_bwd(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
+                                     _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),
+                                     _chk(raw_t, "raw_t"), _chk(g_raw_t, "g_raw_t"), _chk(masks, "masks", torch.int32),
+                                     _chk(g_pts, "g_pts"), _chk(g_vs, "g_vs"), _stream()), "nefes_field_bwd")
+    return g_pts, g_vs
+
+
+def ray_grad_reduce(N, S, z, g_pts, g_vs):
+    dev = g_pts.device
+    g_o, g_d, g_v = (torch.empty(N, 3, device=dev) for _ in range(3))
+    with _timed("ray_grad_reduce"):
+      L.check(L.load().nefes_ray_grad_reduce(N, S, _chk(z, "z"), _chk(g_pts, "g_pts"), _chk(g_vs, "g_vs"), _chk(g_o, "g_o"),
+                                           _chk(g_d, "g_d"), _chk(g_v, "g_v"), _stream()), "nefes_ray_grad_reduce")
+    return g_o, g_d, g_v
+
+
+class FieldFromRays(torch.autograd.Function):
+    """Fused pts = o + d*z -> embed -> MLP (rendering.py:142 + nerfh_nff.py:217-231, :525-576).
+    Returns raw_t [N, R, S].  Differentiable w.r.t. rays_o, rays_d, viewdirs in FULL mode (frozen weights)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, viewdirs, z, pk, mode):
+        rays_o, rays_d, viewdirs, z = _f32(rays_o), _f32(rays_d), _f32(viewdirs), _f32(z)
+        N, S = z.shape
+        need = mode == L.FIELD_FULL and any(ctx.needs_input_grad[:3])
+        raw_t, masks = field_fwd(pk, mode, N, S, rays_o=rays_o, rays_d=rays_d, z=z, viewdirs=viewdirs, want_masks=need)
+        ctx.pk, ctx.mode, ctx.have = pk, mode, need
+        if need:
+            ctx.save_for_backward(rays_o, rays_d, viewdirs, z, raw_t, masks)
+        return raw_t
+
+    @staticmethod
+    def backward(ctx, g_raw_t):
+        if not ctx.have:
+            raise NotImplementedError("nefes_amd: backward through the field is built for the FULL (fine, test-time) "
+                                      "mode only; the train-mode dW/coarse backward kernels are a later row of SURVEY §8f")
+        rays_o, rays_d, viewdirs, z, raw_t, masks = ctx.saved_tensors
+        N, S = z.shape
+        g_pts, g_vs = field_bwd(ctx.pk, N, S, raw_t, _f32(g_raw_t), masks, rays_o=rays_o, rays_d=rays_d, z=z,
+                                viewdirs=viewdirs)
+        g_o, g_d, g_v = ray_grad_reduce(N, S, z, g_pts, g_vs)
+        return g_o, g_d, g_v, None, None, None
+
+
+class FieldFromPoints(torch.autograd.Function):
+    """run_network_NeRFH_NFF call surface: explicit pts [N,S,3] (+ viewdirs [N,3]) -> raw_t [N,R,S]."""
+
+    @staticmethod
+    def forward(ctx, pts, viewdirs, pk, mode):
+        pts = _f32(pts)
+        N, S = pts.shape[0], pts.shape[1]
+        if viewdirs is None:
+            viewdirs = torch.zeros(N, 3, device=pts.device)
+        viewdirs = _f32(viewdirs)
+        need = mode == L.FIELD_FULL and any(ctx.needs_input_grad[:2])
+        raw_t, masks = field_fwd(pk, mode, N, S, pts=pts.reshape(-1, 3), viewdirs=viewdirs, want_masks=need)
+        ctx.pk, ctx.mode, ctx.have = pk, mode, need
+        if need:
+            ctx.save_for_backward(pts, viewdirs, raw_t, masks)
+        return raw_t
+
+    @staticmethod
+    def backward(ctx, g_raw_t):
+        if not ctx.have:
+            raise NotImplementedError("nefes_amd: field backward is built for the FULL (fine) mode only")
+        pts, viewdirs, raw_t, masks = ctx.saved_tensors
+        N, S = pts.shape[0], pts.shape[1]
+        g_pts, g_vs = field_bwd(ctx.pk, N, S, raw_t, _f32(g_raw_t), masks, pts=pts.reshape(-1, 3), viewdirs=viewdirs)
+        zeros = torch.zeros(N, S, device=pts.device)
+        _, _, g_v = ray_grad_reduce(N, S, zeros, g_pts, g_vs)
+        return g_pts.reshape(N, S, 3), g_v, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# compositing
+# ---------------------------------------------------------------------------------------------
+def composite_fwd(raw_t, z, C_feat, flags, beta_min=0.1):
+    N, _, S = raw_t.shape
+    dev = raw_t.device
+    sigma_only = bool(flags & L.COMP_SIGMA_ONLY)
+    acc = torch.empty(N, device=dev)
+    weights = torch.empty(N, S, device=dev)
+    if sigma_only:
+        rgb = feat = disp = depth = beta = None
+    else:
+        rgb, feat = torch.empty(N, 3, device=dev), torch.empty(N, C_feat, device=dev)
+        disp, depth, beta = torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)
+    with _timed("composite_fwd[D]" if sigma_only else "composite_fwd"):
+      L.check(L.load().nefes_composite_fwd(N, S, C_feat, flags, float(beta_min), _chk(raw_t, "raw_t"), _chk(z, "z"),
+                                         _chk(rgb, "rgb"), _chk(feat, "feat"), _chk(disp, "disp"), _chk(acc, "acc"),
+                                         _chk(depth, "depth"), _chk(weights, "weights"), _chk(beta, "beta"), _stream()),
+            "nefes_composite_fwd")
+    return rgb, feat, disp, acc, depth, weights, beta
+
+
+class Composite(torch.autograd.Function):
+    """raw2outputs_NeRFH_NFF (nerfh_nff.py:25-166) on raw_t [N,R,S]; z carries no gradient (detached in the reference)."""
+
+    @staticmethod
+    def forward(ctx, raw_t, z, C_feat, flags, beta_min):
+        raw_t, z = _f32(raw_t), _f32(z)
+        outs = composite_fwd(raw_t, z, C_feat, flags, beta_min)
+        ctx.save_for_backward(raw_t, z)
+        ctx.cfg = (C_feat, flags)
+        if flags & L.COMP_SIGMA_ONLY:
+            _, _, _, acc, _, weights, _ = outs
+            dummy = raw_t.new_zeros(0)
+            return dummy, dummy, dummy, acc, dummy, weights, dummy
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_feat, g_disp, g_acc, g_depth, g_weights, g_beta):
+        raw_t, z = ctx.saved_tensors
+        C_feat, flags = ctx.cfg
+        N, R, S = raw_t.shape
+        g_raw_t = torch.empty_like(raw_t)
+        so = bool(flags & L.COMP_SIGMA_ONLY)
+        fix = lambda g, ok=True: None if (g is None or not ok or g.numel() == 0) else _f32(g)
+        g_rgb, g_feat, g_disp, g_depth, g_beta = (fix(g, not so) for g in (g_rgb, g_feat, g_disp, g_depth, g_beta))
+        g_acc, g_weights = fix(g_acc), fix(g_weights)
+        with _timed("composite_bwd"):
+          L.check(L.load().nefes_composite_bwd(N, S, C_feat, flags, _chk(raw_t, "raw_t"), _chk(z, "z"), _chk(g_rgb, "g_rgb"),
+                                             _chk(g_feat, "g_feat"), _chk(g_disp, "g_disp"), _chk(g_acc, "g_acc"),
+                                             _chk(g_depth, "g_depth"), _chk(g_weights, "g_weights"), _chk(g_beta, "g_beta"),
+                                             _chk(g_raw_t, "g_raw_t"), _stream()), "nefes_composite_bwd")
+        return g_raw_t, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# hierarchical sampling
+# ---------------------------------------------------------------------------------------------
+def sample_pdf_merge(z_coarse, weights, Ni, u=None, cdf=None, want_debug=False, bins_layout=False):
+    """sample_pdf + sort(cat) (rendering.py:23-66,132-141).  u=None -> deterministic linspace(0,1,Ni).
+    bins_layout=True: (z_coarse, weights) are the reference's (bins, weights) arguments; no merge."""
+    z_coarse, weights = _f32(z_coarse), _f32(weights)
+    N, Nc = z_coarse.shape
+    if bins_layout:
+        Nc += 1
+    dev = z_coarse.device
+    if u is None:
+        u = torch.linspace(0., 1., steps=Ni, device=dev)             # rendering.py:33 bits
+    u = _f32(u)
+    per_ray = 1 if u.dim() == 2 else 0
+    z_fine = None if bins_layout else torch.empty(N, Nc + Ni, device=dev)
+    z_samples = torch.empty(N, Ni, device=dev)
+    inds = torch.empty(N, Ni, dtype=torch.int32, device=dev) if want_debug else None
+    cdf_out = torch.empty(N, Nc - 1, device=dev) if want_debug else None
+    cdf = None if cdf is None else _f32(cdf)
+    with _timed("sample_pdf_merge"):
+      L.check(L.load().nefes_sample_pdf_merge(N, Nc, Ni, 1 if bins_layout else 0, _chk(z_coarse, "z_coarse"), _chk(weights, "weights"), _chk(u, "u"),
+                                            per_ray, _chk(cdf, "cdf"), _chk(z_fine, "z_fine"), _chk(z_samples, "z_samples"),
+                                            _chk(inds, "inds", torch.int32), _chk(cdf_out, "cdf_out"), _stream()),
+            "nefes_sample_pdf_merge")
+    if want_debug:
+        return z_fine, z_samples, inds, cdf_out
+    return z_fine, z_samples

@@ -1,0 +1,168 @@
+"""render()/render_rays()/batchify_rays()/sample_pdf() with the reference's signatures
+(script/models/rendering.py:23-243), executed by the HIP kernels of libnefes_hip.so.
+
+Kernel sequence of one render() at test time (perturb=0, test_time=True):
+    RayGen (get_rays + viewdirs)                 -> rays_o, rays_d, viewdirs          [grad -> c2w]
+    coarse_depths                                -> z_coarse [N,Nc]
+    field_fwd SIGMA (coarse net, no grad)        -> sigma [N,1,Nc]
+    composite_fwd variant D                      -> weights [N,Nc]
+    sample_pdf_merge                             -> z_fine [N,Nc+Ni]
+    FieldFromRays FULL (fine net, masks saved)   -> raw_t [N,R,S]                      [grad -> rays]
+    Composite variant A/B                        -> rgb, feat, disp, acc               [grad -> raw_t]
+The ray batch is processed in one launch per kernel (no Python chunk loop; `chunk`/`netchunk`
+are accepted and only bound the internal batch when memory would not allow one launch).
+"""
+import types
+
+import torch
+
+from . import lib as L
+from . import ops
+
+_DEV = "cuda"
+MAX_RAYS_PER_LAUNCH = 1 << 22
+
+
+def _cfg(kwargs):
+    a = kwargs.get("args", None)
+    g = lambda name, default: getattr(a, name, default) if a is not None else default
+    return types.SimpleNamespace(
+        N_samples=int(kwargs["N_samples"]), N_importance=int(kwargs.get("N_importance", 0)),
+        perturb=float(kwargs.get("perturb", 0.)), lindisp=bool(kwargs.get("lindisp", False)),
+        white_bkgd=bool(kwargs.get("white_bkgd", False)), raw_noise_std=float(kwargs.get("raw_noise_std", 0.)),
+        test_time=bool(kwargs.get("test_time", False)), nerfh_nff=bool(g("nerfh_nff", True)),
+        use_fine_only=bool(g("use_fine_only", False)), NeRFW=bool(g("NeRFW", True)),
+        transient_at_test=bool(g("transient_at_test", False)))
+
+
+def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, cfg):
+    """rendering.py:88-180 for n rays already on the GPU.  Returns the reference's `ret` dict."""
+    N = rays_o.shape[0]
+    dev = rays_o.device
+    Nc, Ni = cfg.N_samples, cfg.N_importance
+    if torch.is_grad_enabled():
+        for net in (network_fn, network_fine):
+            if net is not None and any(p.requires_grad for n, p in net.named_parameters()
+                                       if not n.startswith(("fusion_net", "exposure_embedding"))):
+                raise NotImplementedError(
+                    "nefes_amd: the HIP field kernels differentiate w.r.t. the rays/pose only (frozen weights, as in "
+                    "the refinement loop: DFM_APR_refine.py:192-193). Call requires_grad_(False) on the NeRF modules; "
+                    "the dW (training) kernels are a later row of SURVEY.md §8f.")
+    t_rand = torch.rand(N, Nc, device=dev) if cfg.perturb > 0. else None            # :110 (RNG stays in torch)
+    z = ops.coarse_depths(N, Nc, near, far, cfg.lindisp, t_rand, device=dev)
+    store_rgb = (Ni == 0)
+    pk_c = network_fn.packed()
+    C = pk_c.feat_dim
+    if cfg.test_time:
+        # coarse + test_time: sigma-only branch, nothing differentiable (nerfh_nff.py:192-202)
+        with torch.no_grad():
+            raw_c, _ = ops.field_fwd(pk_c, L.FIELD_SIGMA, N, Nc, rays_o=rays_o.detach(), rays_d=rays_d.detach(), z=z)
+            if cfg.raw_noise_std > 0.:
+                raw_c = raw_c + torch.randn_like(raw_c) * cfg.raw_noise_std
+            _, _, _, acc0, _, w0, _ = ops.composite_fwd(raw_c, z, C, L.COMP_SIGMA_ONLY)
+        rgb0 = feat0 = disp0 = None
+    else:
+        raw_c = ops.FieldFromRays.apply(rays_o, rays_d, viewdirs, z, pk_c, L.FIELD_STATIC)
+        if cfg.raw_noise_std > 0.:
+            noise = torch.zeros_like(raw_c)
+            noise[:, 3 + C] = torch.randn(N, Nc, device=dev) * cfg.raw_noise_std
+            raw_c = raw_c + noise
+        rgb0, feat0, disp0, acc0, _, w0, _ = ops.Composite.apply(raw_c, z, C, 0, 0.1)
+    if Ni == 0:
+        if cfg.test_time:
+            raise NotImplementedError("nefes_amd: N_importance == 0 at test time renders nothing in the reference "
+                                      "either (sigma-only coarse branch, rendering.py:116-125)")
+        ret = {"rgb_map": rgb0, "disp_map": disp0, "acc_map": acc0}
+        if cfg.nerfh_nff:
+            ret["feat_map"] = feat0
+        return ret
+    # hierarchical sampling (:132-141); z_samples are detached in the reference
+    u = None if cfg.perturb == 0. else torch.rand(N, Ni, device=dev)
+    z_fine, z_samples = ops.sample_pdf_merge(z, w0.detach(), Ni, u=u)
+    z_f = z_samples if cfg.use_fine_only else z_fine
+    pk_f = network_fine.packed()
+    mode = L.FIELD_FULL if cfg.NeRFW else L.FIELD_STATIC
+    raw_f = ops.FieldFromRays.apply(rays_o, rays_d, viewdirs, z_f, pk_f, mode)
+    flags = 0
+    if cfg.NeRFW:
+        flags |= L.COMP_TRANSIENT
+        if cfg.test_time and not cfg.transient_at_test:
+            flags |= L.COMP_STATIC_ONLY
+    if cfg.white_bkgd:
+        flags |= L.COMP_WHITE_BKGD
+    rgb, feat, disp, acc, depth, weights, beta = ops.Composite.apply(raw_f, z_f, C, flags, float(network_fine.beta_min))
+    ret = {"rgb_map": rgb, "disp_map": disp, "acc_map": acc}
+    if cfg.nerfh_nff:
+        ret["feat_map"] = feat
+    if not cfg.test_time:                                                            # :160-173
+        ret["rgb0"], ret["disp0"], ret["acc0"] = rgb0, disp0, acc0
+        ret["z_std"] = torch.std(z_samples, dim=-1, unbiased=False)
+        if cfg.NeRFW:
+            ret["transient_sigmas"] = raw_f[:, 3 + C + 4, :]
+            ret["beta"] = beta
+        if cfg.nerfh_nff and feat0 is not None:
+            ret["feat0"] = feat0
+    return ret
+
+
+def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retraw=False, lindisp=False, perturb=0.,
+                N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False,
+                i_epoch=-1, embedding_a=None, embedding_t=None, test_time=False, args=None, volume=None):
+    """Reference signature (rendering.py:68-86) on a packed [n, 8+3(+hist)] ray batch."""
+    ray_batch = ray_batch.to(_DEV)
+    rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
+    viewdirs = ray_batch[:, 8:11].contiguous()
+    near, far = float(ray_batch[0, 6]), float(ray_batch[0, 7])     # constant columns (rendering.py:227)
+    cfg = _cfg(dict(N_samples=N_samples, N_importance=N_importance, perturb=perturb, lindisp=lindisp,
+                    white_bkgd=white_bkgd, raw_noise_std=raw_noise_std, test_time=test_time, args=args))
+    return _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, cfg)
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    """Reference signature (rendering.py:182-195).  One launch unless the batch exceeds MAX_RAYS_PER_LAUNCH."""
+    step = max(int(chunk), MAX_RAYS_PER_LAUNCH)
+    parts = {}
+    for i in range(0, rays_flat.shape[0], step):
+        for k, v in render_rays(rays_flat[i:i + step], **kwargs).items():
+            parts.setdefault(k, []).append(v)
+    return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in parts.items()}
+
+
+def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, img_idx=torch.Tensor(0), row_range=None, **kwargs):
+    """Reference signature (rendering.py:197-200) + `row_range=(row0, nrows)` for ray-batch sharding.
+    Returns [rgb_map [N,3], disp_map [N], acc_map [N], extras dict]."""
+    if not use_viewdirs:
+        raise NotImplementedError("nefes_amd: the NeFeS field always uses view directions (use_viewdirs=True)")
+    cfg = _cfg(kwargs)
+    network_fn, network_fine = kwargs["network_fn"], kwargs.get("network_fine", None)
+    if c2w is not None:
+        c2w = c2w.to(_DEV)
+        row0, nrows = (0, H) if row_range is None else row_range
+        rays_o, rays_d, viewdirs = ops.RayGen.apply(c2w, H, W, float(focal), row0, nrows)
+        if c2w_staticcam is not None:
+            rays_o, rays_d, _ = ops.RayGen.apply(c2w_staticcam.to(_DEV), H, W, float(focal), row0, nrows)
+    else:
+        rays_o, rays_d = rays
+        rays_o, rays_d = rays_o.to(_DEV).reshape(-1, 3).float(), rays_d.to(_DEV).reshape(-1, 3).float()
+        viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)             # caller-supplied rays: torch glue
+        if c2w_staticcam is not None:
+            rays_o, rays_d, _ = ops.RayGen.apply(c2w_staticcam.to(_DEV), H, W, float(focal), 0, H)
+    if ndc:
+        rays_o, rays_d = ops.NdcRays.apply(rays_o, rays_d, H, W, float(focal), 1.)
+    N = rays_o.shape[0]
+    outs = []
+    for i in range(0, N, MAX_RAYS_PER_LAUNCH):
+        sl = slice(i, min(N, i + MAX_RAYS_PER_LAUNCH))
+        outs.append(_render_core(rays_o[sl], rays_d[sl], viewdirs[sl], float(near), float(far), network_fn, network_fine, cfg))
+    all_ret = outs[0] if len(outs) == 1 else {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+    k_extract = ["rgb_map", "disp_map", "acc_map"]
+    return [all_ret[k] for k in k_extract] + [{k: v for k, v in all_ret.items() if k not in k_extract}]
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    """Reference signature (rendering.py:23).  bins [n, B], weights [n, B-1] -> samples [n, N_samples]."""
+    dev = _DEV
+    u = None if det else torch.rand(bins.shape[0], N_samples, device=dev)
+    _, samples = ops.sample_pdf_merge(bins.to(dev), weights.to(dev), N_samples, u=u, bins_layout=True)
+    return samples

@@ -1,0 +1,357 @@
+"""GPU parity tests (run with `-m gpu` on the MI355X box): every HIP stage through the C ABI against
+(a) the golden vectors captured from the reference and (b) the CPU oracle on seeded inputs.
+Tolerances: integer/index results bit-exact; fp32 maps and gradients 1e-4 relative (north star)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nefes_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def L():
+    from nefes_amd import lib as _L
+    _L.load()
+    return _L
+
+
+def test_native_library_is_loaded(L):
+    maps = open("/proc/self/maps").read()
+    assert "libnefes_hip.so" in maps
+
+
+# ---- a1/a2/a5 rays --------------------------------------------------------------------------------
+def test_raygen_matches_reference(golden, ops):
+    g = golden("raygen")
+    for k in range(3):
+        H, W, f = g[f"hwf{k}"]
+        o, d, v = ops.raygen_fwd(int(H), int(W), float(f), T(g[f"c2w{k}"]).to(DEV))
+        assert np.array_equal(o.cpu().numpy().reshape(int(H), int(W), 3), g[f"rays_o{k}"])
+        np.testing.assert_allclose(d.cpu().numpy().reshape(int(H), int(W), 3), g[f"rays_d{k}"], rtol=3e-7, atol=1e-7)
+        np.testing.assert_allclose(v.cpu().numpy().reshape(int(H), int(W), 3), g[f"viewdirs{k}"], rtol=3e-7, atol=1e-7)
+
+
+def test_raygen_backward_and_row_shards(ops):
+    H, W, f = 10, 7, 9.1
+    c2w = O.bench_pose()
+    gen = torch.Generator().manual_seed(3)
+    go, gd, gv = (torch.randn(H * W, 3, generator=gen) for _ in range(3))
+    c = c2w.clone().double().requires_grad_()
+    o, d = O.ray_bundle(H, W, f, c)
+    v = d / torch.norm(d, dim=-1, keepdim=True)
+    ((o.reshape(-1, 3) * go.double()).sum() + (d.reshape(-1, 3) * gd.double()).sum() + (v.reshape(-1, 3) * gv.double()).sum()).backward()
+    g_full = ops.raygen_bwd(H, W, f, c2w.to(DEV), 0, H, go.to(DEV), gd.to(DEV), gv.to(DEV))
+    assert rel(g_full, c.grad) < 1e-5
+    # sharded rows sum to the unsharded gradient (the data-parallel contract of SURVEY.md §8e)
+    acc = torch.zeros(3, 4, dtype=torch.float64)
+    for row0, n in [(0, 3), (3, 3), (6, 4)]:
+        sl = slice(row0 * W, (row0 + n) * W)
+        acc += ops.raygen_bwd(H, W, f, c2w.to(DEV), row0, n, go[sl].to(DEV), gd[sl].to(DEV), gv[sl].to(DEV)).cpu().double()
+        o_s, d_s, _ = ops.raygen_fwd(H, W, f, c2w.to(DEV), row0, n)
+        assert torch.equal(d_s.cpu(), ops.raygen_fwd(H, W, f, c2w.to(DEV))[1].cpu()[sl])
+    assert rel(acc, c.grad) < 1e-5
+
+
+def test_ndc_and_depths(golden, ops):
+    g, gd = golden("raygen"), golden("depths")
+    o, d, _ = ops.raygen_fwd(6, 8, 7.3, T(g["c2w0"]).to(DEV))
+    oo, od = ops.NdcRays.apply(o, d, 6, 8, 7.3, 1.)
+    np.testing.assert_allclose(oo.cpu().numpy().reshape(6, 8, 3), g["ndc_o"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(od.cpu().numpy().reshape(6, 8, 3), g["ndc_d"], rtol=2e-5, atol=2e-6)
+    # backward against autograd of the oracle
+    oc, dc = o.cpu().double().requires_grad_(), d.cpu().double().requires_grad_()
+    o2, d2 = O.ndc_warp(6, 8, 7.3, 1., oc, dc)
+    gen = torch.Generator().manual_seed(1)
+    ga, gb = torch.randn(48, 3, generator=gen), torch.randn(48, 3, generator=gen)
+    ((o2 * ga.double()).sum() + (d2 * gb.double()).sum()).backward()
+    oh, dh = o.clone().requires_grad_(), d.clone().requires_grad_()
+    o3, d3 = ops.NdcRays.apply(oh, dh, 6, 8, 7.3, 1.)
+    ((o3 * ga.to(DEV)).sum() + (d3 * gb.to(DEV)).sum()).backward()
+    assert rel(oh.grad, oc.grad) < 1e-4 and rel(dh.grad, dc.grad) < 1e-4
+    assert np.array_equal(ops.coarse_depths(5, 16, 0.5, 6.0, False).cpu().numpy(), gd["z_lin"])
+    np.testing.assert_allclose(ops.coarse_depths(5, 16, 0.5, 6.0, True).cpu().numpy(), gd["z_disp"], rtol=2e-7)
+    tr = torch.rand(5, 16, generator=gen)
+    ref = O.coarse_depths(torch.full((5, 1), 0.5), torch.full((5, 1), 6.0), 16, False, tr)
+    np.testing.assert_allclose(ops.coarse_depths(5, 16, 0.5, 6.0, False, tr.to(DEV)).cpu().numpy(), ref.numpy(), rtol=2e-7)
+
+
+# ---- a9 compositing -----------------------------------------------------------------------------------
+VARIANTS = {"A": (1, True), "Atrain": (1, True), "B": (1 | 2, True), "C": (0, False), "D": (4, False)}
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_composite_matches_reference(golden, ops, tag):
+    g = golden("composite")
+    C = g["g_feat"].shape[1]
+    flags, _ = VARIANTS[tag]
+    raw = T(g["raw"])
+    if tag == "C":
+        raw = raw[..., :3 + C + 1]
+    if tag == "D":
+        raw = raw[..., 3 + C:3 + C + 1]
+    raw_t = raw.permute(0, 2, 1).contiguous().to(DEV).requires_grad_()
+    z = T(g["z"]).to(DEV)
+    rgb, feat, disp, acc, depth, w, beta = ops.Composite.apply(raw_t, z, C, flags, 0.1)
+    ok = np.arange(raw.shape[0]) != 0          # row 0: sigma == 0 -> the reference itself gives disp = NaN
+    np.testing.assert_allclose(acc.detach().cpu().numpy(), g[f"{tag}.acc"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(w.detach().cpu().numpy(), g[f"{tag}.weights"], rtol=1e-5, atol=1e-7)
+    loss = (acc * T(g["g_acc"]).to(DEV)).sum() + (w * T(g["g_w"]).to(DEV)).sum()
+    if tag != "D":
+        np.testing.assert_allclose(rgb.detach().cpu().numpy(), g[f"{tag}.rgb"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(feat.detach().cpu().numpy(), g[f"{tag}.feat"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(depth.detach().cpu().numpy(), g[f"{tag}.depth"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(disp.detach().cpu().numpy()[ok], g[f"{tag}.disp"][ok], rtol=1e-5)
+        assert np.isnan(disp.detach().cpu().numpy()[0]) and np.isnan(g[f"{tag}.disp"][0])
+        np.testing.assert_allclose(beta.detach().cpu().numpy(), g[f"{tag}.beta"], rtol=1e-5, atol=1e-6)
+        # keep the NaN row out of the scalar loss so the other rows' gradients stay comparable
+        gd = T(g["g_disp"]).to(DEV).clone()
+        loss = loss + (rgb * T(g["g_rgb"]).to(DEV)).sum() + (feat * T(g["g_feat"]).to(DEV)).sum() \
+            + (disp * gd).sum() + (depth * T(g["g_depth"]).to(DEV)).sum()
+        if tag in ("A", "Atrain"):
+            loss = loss + (beta * T(g["g_beta"]).to(DEV)).sum()
+    loss.backward()
+    got = raw_t.grad.permute(0, 2, 1).cpu().numpy()
+    want = g[f"{tag}.g_raw"]
+    fin = np.isfinite(want)
+    assert np.isfinite(got[1:]).all()                       # alpha == 1 saturation rows stay finite
+    scale = np.abs(want[fin]).max()
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_composite_rejects_cpu_tensors(ops):
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.composite_fwd(torch.zeros(2, 1, 8), torch.zeros(2, 8), 0, 4)
+
+
+# ---- a10/a11 hierarchical sampling -----------------------------------------------------------------------
+@pytest.mark.parametrize("tag,det,Ni", [("det128", True, 128), ("det64", True, 64), ("rand128", False, 128)])
+def test_sample_pdf_indices_bit_exact(golden, ops, tag, det, Ni):
+    g = golden("sample_pdf")
+    z, w = T(g[f"{tag}.z"]).to(DEV), T(g["w"]).to(DEV)
+    u = None if det else T(g[f"{tag}.u"]).to(DEV)
+    # stage test on the reference's own CDF: indices, samples and merged depths must be bit-exact
+    zf, zs, inds, cdf = ops.sample_pdf_merge(z, w, Ni, u=u, cdf=T(g[f"{tag}.cdf"]).to(DEV), want_debug=True)
+    assert np.array_equal(inds.cpu().numpy().astype(np.int64), g[f"{tag}.inds"])
+    assert np.array_equal(zs.cpu().numpy(), g[f"{tag}.samples"])
+    assert np.array_equal(zf.cpu().numpy(), g[f"{tag}.merged"])
+    # end to end (CDF built in-kernel): torch.sum's cascade order is not reproducible, so the CDF may differ by an
+    # ulp; report the index mismatch rate and require every mismatch to be an ulp-level tie, samples continuous.
+    zf2, zs2, inds2, cdf2 = ops.sample_pdf_merge(z, w, Ni, u=u, want_debug=True)
+    np.testing.assert_allclose(cdf2.cpu().numpy(), g[f"{tag}.cdf"], rtol=0, atol=2.4e-7)
+    bad = inds2.cpu().numpy().astype(np.int64) != g[f"{tag}.inds"]
+    print(f"[{tag}] index mismatch rate with in-kernel CDF: {bad.mean():.4%}")
+    if bad.any():
+        uu = np.broadcast_to(g[f"{tag}.u"], bad.shape)
+        cg = g[f"{tag}.cdf"]
+        rows, cols = np.nonzero(bad)
+        k = np.minimum(inds2.cpu().numpy()[rows, cols], g[f"{tag}.inds"][rows, cols])
+        assert (np.abs(uu[rows, cols] - cg[rows, np.minimum(k, cg.shape[1] - 1)]) <= 2.4e-7).all()
+    np.testing.assert_allclose(zs2.cpu().numpy(), g[f"{tag}.samples"], rtol=0, atol=2e-5)
+    assert (np.diff(zf2.cpu().numpy(), axis=-1) >= 0).all()
+    # reference call surface: sample_pdf(bins, weights[...,1:-1], N, det)
+    mid = .5 * (z[..., 1:] + z[..., :-1])
+    _, zs3 = ops.sample_pdf_merge(mid, w[..., 1:-1].contiguous(), Ni, u=u, bins_layout=True)
+    np.testing.assert_allclose(zs3.cpu().numpy(), g[f"{tag}.samples"], rtol=0, atol=2e-5)
+
+
+# ---- a6/a7/a8 field MLP ---------------------------------------------------------------------------------------
+def _modules(Wd, C, sigma_scale=1.0):
+    from nefes_amd.field import NeRFH_NFF
+    coarse = NeRFH_NFF('coarse', D=8, W=Wd, skips=[4], f_dim=C)
+    fine = NeRFH_NFF('fine', D=8, W=Wd, skips=[4], encode_appearance=True, encode_transient=True,
+                     in_channels_a=50, in_channels_t=20, f_dim=C)
+    with torch.no_grad():
+        for m in (coarse, fine):
+            m.static_sigma[0].weight.mul_(sigma_scale)
+            m.static_sigma[0].bias.mul_(sigma_scale)
+    for m in (coarse, fine):
+        m.requires_grad_(False)
+    return coarse.to(DEV), fine.to(DEV)
+
+
+@pytest.mark.parametrize("Wd,C", [(256, 16), (128, 128)])
+def test_module_init_matches_reference_checksums(golden, Wd, C):
+    g = golden("mlp")
+    coarse, fine = _modules(Wd, C)
+    for typ, m in (("coarse", coarse), ("fine", fine)):
+        for k, v in m.state_dict().items():
+            key = f"w{Wd}c{C}.{typ}.{k}"
+            if key in g:
+                v = v.cpu()
+                got = np.array([v.double().sum().item(), v.double().abs().sum().item(), float(v.flatten()[0])])
+                np.testing.assert_allclose(got, g[key], rtol=0, atol=0, err_msg=key)
+
+
+@pytest.mark.parametrize("Wd,C", [(256, 16), (128, 128)])
+def test_field_forward_backward_vs_reference(golden, ops, L, Wd, C):
+    g = golden("mlp")
+    tag = f"w{Wd}c{C}"
+    coarse, fine = _modules(Wd, C)
+    pts = T(g[f"{tag}.pts"]).to(DEV)              # 48 points: treat as N=2 rays x S=24 samples
+    dirs = T(g[f"{tag}.dirs"])
+    N, S = 2, 24
+    # the golden used one direction per point; run_network expands one direction per ray, so check per ray
+    from nefes_amd.field import run_network_NeRFH_NFF
+    for r in range(N):
+        for s0 in range(0, S, 8):
+            idx = r * S + s0
+            p1 = pts[idx:idx + 1].reshape(1, 1, 3).clone().requires_grad_()
+            v1 = dirs[idx:idx + 1].to(DEV).clone().requires_grad_()
+            raw = run_network_NeRFH_NFF(p1, v1, None, fine, typ='fine', output_transient=True, test_time=True)
+            np.testing.assert_allclose(raw.detach().cpu().numpy()[0, 0], g[f"{tag}.raw_full"][idx], rtol=1e-4, atol=2e-6)
+            raw.backward(T(g[f"{tag}.g_raw"][idx]).to(DEV).reshape(1, 1, -1))
+            # reference gradient w.r.t. the embedded input -> chain through the embedding on the oracle side
+            pe = T(g[f"{tag}.pts"][idx:idx + 1]).double().requires_grad_()
+            de = dirs[idx:idx + 1].double().requires_grad_()
+            emb = torch.cat([O.freq_encode(pe, 10), O.freq_encode(de, 4)], 1)
+            emb.backward(T(g[f"{tag}.g_emb"][idx:idx + 1]).double())
+            assert rel(p1.grad.reshape(1, 3), pe.grad) < 2e-4, (idx, p1.grad, pe.grad)
+            assert rel(v1.grad, de.grad) < 2e-4
+    # all 48 points at once, sigma-only and static branches of the coarse net (random dirs per RAY here)
+    p3 = pts.reshape(N, S, 3)
+    vv = dirs[:N].to(DEV)
+    pc = O.make_field_params("coarse", Wd, C)
+    sig = run_network_NeRFH_NFF(p3, vv, None, coarse, typ='coarse', output_transient=False, test_time=True)
+    np.testing.assert_allclose(sig.cpu().numpy().reshape(-1), g[f"{tag}.sigma"].reshape(-1), rtol=1e-4, atol=2e-6)
+    st = run_network_NeRFH_NFF(p3, vv, None, coarse, typ='coarse', output_transient=False, test_time=False)
+    ref = O.query_field(pc, p3.cpu(), vv.cpu(), "coarse", False, False)
+    np.testing.assert_allclose(st.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("Wd,C,S", [(256, 16, 192), (128, 128, 128), (256, 16, 40)])
+def test_field_from_rays_vs_oracle(ops, L, Wd, C, S):
+    """Seeded rays (N not a multiple of the 128-sample tile): forward maps and d(rays) against the oracle."""
+    coarse, fine = _modules(Wd, C)
+    pf = O.make_field_params("fine", Wd, C)
+    gen = torch.Generator().manual_seed(11)
+    N = 7
+    o = (torch.rand(N, 3, generator=gen) - .5)
+    d = torch.randn(N, 3, generator=gen)
+    v = d / d.norm(dim=-1, keepdim=True)
+    z = torch.sort(torch.rand(N, S, generator=gen) * 4, -1)[0]
+    g_raw = torch.randn(N, S, 3 + C + 6, generator=gen)
+    # oracle (f64 ground truth and fp32 reference behaviour)
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        oo, dd, vv = (t.to(dt).clone().requires_grad_() for t in (o, d, v))
+        pts = oo[:, None, :] + dd[:, None, :] * z.to(dt)[..., None]
+        raw = O.query_field({k: w.to(dt) for k, w in pf.items()}, pts, vv, "fine", True, True)
+        raw.backward(g_raw.to(dt))
+        res[dt] = (raw.detach(), oo.grad, dd.grad, vv.grad)
+    oh, dh, vh = (t.to(DEV).clone().requires_grad_() for t in (o, d, v))
+    raw_t = ops.FieldFromRays.apply(oh, dh, vh, z.to(DEV), fine.packed(), L.FIELD_FULL)
+    raw_t.backward(g_raw.permute(0, 2, 1).contiguous().to(DEV))
+    assert rel(raw_t.permute(0, 2, 1), res[torch.float32][0]) < 1e-4
+    for name, got, i in (("rays_o", oh.grad, 1), ("rays_d", dh.grad, 2), ("viewdirs", vh.grad, 3)):
+        truth, ref32 = res[torch.float64][i], res[torch.float32][i]
+        e_hip, e_ref = rel(got, truth), rel(ref32, truth)
+        print(f"[{Wd},{C},{S}] d {name}: hip-vs-f64 {e_hip:.2e}  ref32-vs-f64 {e_ref:.2e}  hip-vs-ref32 {rel(got, ref32):.2e}")
+        assert e_hip <= max(1e-4, 3 * e_ref)
+
+
+# ---- end to end through the drop-in module path ------------------------------------------------------------------
+def _dropin():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = os.path.join(root, "nefes_amd", "dropin")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import models.rendering as R
+    import models.nerfh_nff as M
+    return R, M
+
+
+def _kwargs(M, coarse, fine, Ni, tat):
+    args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=tat, netchunk=1 << 21)
+    q = lambda inputs, viewdirs, ts, network_fn, typ, output_transient, test_time, store_rgb: \
+        M.run_network_NeRFH_NFF(inputs, viewdirs, ts, network_fn, typ=typ, output_transient=output_transient,
+                                netchunk=args.netchunk, test_time=test_time, store_rgb=store_rgb)
+    return dict(network_query_fn=q, perturb=False, N_importance=Ni, N_samples=64, network_fn=coarse, network_fine=fine,
+                use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=True, args=args, ndc=False, lindisp=False)
+
+
+@pytest.mark.parametrize("tag", ["ref_default", "metric", "metric_B", "surface", "ref_default_B"])
+def test_render_end_to_end_vs_reference(golden, tag):
+    R, M = _dropin()
+    g = golden("end_to_end")
+    Wd, C, Ni, tat, sscale, H, W, focal = g[f"{tag}.cfg"]
+    Wd, C, Ni, H, W = int(Wd), int(C), int(Ni), int(H), int(W)
+    coarse, fine = _modules(Wd, C, float(sscale))
+    kw = _kwargs(M, coarse, fine, Ni, bool(tat))
+    c2w = T(g[f"{tag}.c2w"]).to(DEV).clone().requires_grad_()
+    rgb, disp, acc, ex = R.render(H, W, float(focal), chunk=32768, c2w=c2w, near=0., far=4.,
+                                  img_idx=torch.full((1, 10), 10.), **kw)
+    feat = ex["feat_map"]
+    assert rel(rgb, g[f"{tag}.rgb"]) < 1e-4 and rel(feat, g[f"{tag}.feat"]) < 1e-4
+    assert rel(disp, g[f"{tag}.disp"]) < 1e-4 and rel(acc, g[f"{tag}.acc"]) < 1e-4
+    (g1,) = torch.autograd.grad(O.bench_loss(rgb, feat), c2w, retain_graph=True)
+    (g2,) = torch.autograd.grad((rgb * T(g[f"{tag}.g_rgb"]).to(DEV)).sum() + (feat * T(g[f"{tag}.g_feat"]).to(DEV)).sum(), c2w)
+    # ground truth for the pose gradient: the oracle evaluated in float64 (SURVEY.md §7 hard part 10)
+    pc, pf = O.make_field_params("coarse", Wd, C, dtype=torch.float64), O.make_field_params("fine", Wd, C, dtype=torch.float64)
+    for p in (pc, pf):
+        p["static_sigma.0.weight"] = p["static_sigma.0.weight"] * float(sscale)
+        p["static_sigma.0.bias"] = p["static_sigma.0.bias"] * float(sscale)
+    c64 = T(g[f"{tag}.c2w"]).double().requires_grad_()
+    cfg = O.RenderCfg(N_samples=64, N_importance=Ni, transient_at_test=bool(tat))
+    r64, _, _, e64 = O.render(H, W, float(focal), pc, pf, cfg, c2w=c64, near=0., far=4.)
+    (t1,) = torch.autograd.grad(O.bench_loss(r64, e64["feat_map"]), c64, retain_graph=True)
+    (t2,) = torch.autograd.grad((r64 * T(g[f"{tag}.g_rgb"]).double()).sum() + (e64["feat_map"] * T(g[f"{tag}.g_feat"]).double()).sum(), c64)
+    for name, got, ref32, truth in (("loss", g1, g[f"{tag}.g_c2w_loss"], t1), ("linear", g2, g[f"{tag}.g_c2w_lin"], t2)):
+        e_hip, e_ref, direct = rel(got, truth), rel(ref32, truth), rel(got, ref32)
+        print(f"[{tag}/{name}] d c2w: hip-vs-f64 {e_hip:.2e}  reference-fp32-vs-f64 {e_ref:.2e}  hip-vs-reference {direct:.2e}")
+        assert e_hip <= max(1e-4, 3 * e_ref), (name, e_hip, e_ref)
+        assert direct <= max(1e-4, 4 * e_ref)
+
+
+def test_render_requires_frozen_weights():
+    R, M = _dropin()
+    coarse, fine = _modules(128, 128)
+    fine.requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="frozen weights"):
+        R.render(4, 4, 3.0, c2w=O.bench_pose().to(DEV), near=0., far=4., **_kwargs(M, coarse, fine, 64, True))
+
+
+def test_full_size_properties(ops, L):
+    """BASELINE shape per ray (64+128 samples, 8x256, C=16) on a few thousand rays: size-independent properties."""
+    R, M = _dropin()
+    coarse, fine = _modules(256, 16)
+    kw = _kwargs(M, coarse, fine, 128, True)
+    H, W = 48, 64
+    c2w = O.bench_pose().to(DEV).requires_grad_()
+    rgb, disp, acc, ex = R.render(H, W, 525.505 * W / 640., c2w=c2w, near=0., far=4., **kw)
+    feat = ex["feat_map"]
+    assert torch.isfinite(rgb).all() and torch.isfinite(feat).all() and torch.isfinite(disp).all()
+    assert (acc > 0).all() and (acc <= 1 + 1e-5).all()             # weights form a sub-probability
+    (g_full,) = torch.autograd.grad(O.bench_loss(rgb, feat), c2w)
+    # determinism: a second run is bit-identical
+    rgb2, _, _, ex2 = R.render(H, W, 525.505 * W / 640., c2w=c2w, near=0., far=4., **kw)
+    assert torch.equal(rgb, rgb2) and torch.equal(feat, ex2["feat_map"])
+    # linearity of the sharded pose gradient: sum over row shards == unsharded (loss normalised by the full size)
+    from nefes_amd import dist as D
+    acc_g = torch.zeros_like(g_full)
+    for rank in range(4):
+        row0, n = D.row_shard(H, rank, 4)
+        r, _, _, e = R.render(H, W, 525.505 * W / 640., c2w=c2w, near=0., far=4., row_range=(row0, n), **kw)
+        assert torch.equal(r, rgb[row0 * W:(row0 + n) * W])
+        part = (e["feat_map"] ** 2).sum() / feat.numel() + (r ** 2).sum() / rgb.numel()
+        acc_g += torch.autograd.grad(part, c2w)[0]
+    assert rel(acc_g, g_full) < 1e-5

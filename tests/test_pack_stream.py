@@ -1,0 +1,288 @@
+"""Host-side checks that need no GPU:
+ * libnefes_hip.so loads and exports every symbol include/nefes_hip.h declares;
+ * the packed weight streams, consumed in the exact order the kernels consume them
+   (numpy emulation of the 32x32x2 MFMA lane maps, slabs, slots and tiles of
+   nefes_amd/csrc/layout.h), reproduce the oracle's MLP forward and its backward-to-inputs.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from nefes_amd import lib as L
+from oracle import ref_cpu as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_match_header():
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "nefes_hip.h")).read()
+    declared = set(re.findall(r"\b(nefes_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.nefes_version() == 1
+
+
+def test_missing_library_is_loud(monkeypatch):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libnefes_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        L.load()
+
+
+# ---- layout.h restated ------------------------------------------------------------------------
+def rho(h, r):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def emb_slot(Lf, s, h):
+    if s < 3 * Lf:
+        return 3 + 6 * (s // 3) + 3 * h + (s % 3)
+    if s == 3 * Lf:
+        return h
+    if s == 3 * Lf + 1:
+        return 2 if h == 0 else -1
+    return -1
+
+
+def emb_vector(e, Lf, steps):
+    """[n, 3+6L] embedding in reference order -> slot vector [steps, 2, n]."""
+    out = np.zeros((steps, 2, e.shape[0]), np.float32)
+    for s in range(steps):
+        for h in range(2):
+            k = emb_slot(Lf, s, h)
+            if k >= 0:
+                out[s, h] = e[:, k]
+    return out
+
+
+def emb_vector_T(g, Lf, n_ref):
+    """slot vector [steps,2,n] -> [n, n_ref] in reference order (transpose of emb_vector)."""
+    out = np.zeros((g.shape[2], n_ref), np.float32)
+    for s in range(g.shape[0]):
+        for h in range(2):
+            k = emb_slot(Lf, s, h)
+            if k >= 0:
+                out[:, k] = g[s, h]
+    return out
+
+
+def acc_to_vec(acc, t0=0, nt=None):
+    nt = acc.shape[0] - t0 if nt is None else nt
+    v = np.zeros((nt * 16, 2, acc.shape[2]), np.float32)
+    for t in range(nt):
+        for r in range(16):
+            for h in range(2):
+                v[t * 16 + r, h] = acc[t0 + t, rho(h, r)]
+    return v
+
+
+class Stream:
+    def __init__(self, blob, si):
+        self.slabs = np.frombuffer(blob, np.float32, count=si.n_slabs * 4096, offset=si.slab_off).reshape(si.n_slabs, 16, 64, 4)
+        self.bias = np.frombuffer(blob, np.float32, count=si.bias_floats, offset=si.bias_off) if si.bias_floats else None
+        self.pos = 0
+        self.bpos = 0
+
+    def bias_tiles(self, nt, n):
+        b = self.bias[self.bpos:self.bpos + nt * 32].reshape(nt, 32)
+        self.bpos += nt * 32
+        return np.repeat(b[:, :, None], n, 2).astype(np.float32).copy()
+
+    def mma(self, nt, vec, acc):
+        ks = vec.shape[0]
+        sps = 64 // nt
+        for sl in range((ks + sps - 1) // sps):
+            slab = self.slabs[self.pos]
+            self.pos += 1
+            steps = min(sps, ks - sl * sps)
+            for f in range(steps * nt):
+                s, t = sl * sps + f // nt, f % nt
+                a = slab[f // 4, :, f % 4]                       # fragment: lane = i + 32*h
+                acc[t] += a[:32, None] * vec[s, 0][None, :]       # k = slot(s,0)
+                acc[t] += a[32:, None] * vec[s, 1][None, :]       # k = slot(s,1)
+
+
+def pack(Wd, Cf, typ):
+    lib = L.load()
+    p = O.make_field_params(typ, Wd, Cf)
+    d = L.NefesNetDesc(Wd, Cf, 1 if typ == "fine" else 0, 0)
+    info = L.NefesBlobInfo()
+    assert lib.nefes_blob_info(d, info) == 0
+    names = [n for n, _, _ in O.field_param_shapes(typ, Wd, Cf)]
+    arrs = []
+    for n in names:
+        arrs += [np.ascontiguousarray(p[n + ".weight"].numpy()), np.ascontiguousarray(p[n + ".bias"].numpy())]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    blob = np.zeros(info.total_bytes, np.uint8)
+    assert lib.nefes_pack_weights(d, ptrs, len(arrs), blob.ctypes.data, blob.nbytes) == 0
+    return p, info, blob.tobytes()
+
+
+def softplus(x):
+    return np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, 20))))
+
+
+def emulate_forward(info, blob, Wd, Cf, e63, e27, mode):
+    """Mirrors field_fwd_kernel<W,NTR,MODE> (csrc/field_fwd.hip) segment by segment."""
+    n = e63.shape[0]
+    NTW, NTH, NTR = Wd // 32, Wd // 64, (3 + Cf + 31) // 32
+    st = Stream(blob, info.stream[{0: L.STREAM_FWD_SIGMA, 1: L.STREAM_FWD_STATIC, 2: L.STREAM_FWD_FULL}[mode]])
+    E, D = emb_vector(e63, 10, 32), emb_vector(e27, 4, 14)
+    masks = {}
+    acc = st.bias_tiles(NTW, n)
+    st.mma(NTW, E, acc)
+    masks["L1"] = acc > 0
+    H = acc_to_vec(np.maximum(acc, 0))
+    biases = [st.bias_tiles(NTW, n) for _ in range(7)]          # L2..L8 (bias block order)
+    b_sig = st.bias_tiles(1, n)
+    out = {}
+
+    def sigma_head():
+        sg = b_sig.copy()
+        st.mma(1, H, sg)
+        out["sigma"] = softplus(sg[0, 0])
+
+    last = 8 if mode == 0 else 9
+    b_final = st.bias_tiles(NTW, n) if mode != 0 else None
+    for l in range(2, last + 1):
+        if mode != 0 and l == 9:
+            sigma_head()
+        acc = biases[l - 2].copy() if l <= 8 else b_final.copy()
+        if l == 5:
+            st.mma(NTW, E, acc)
+        st.mma(NTW, H, acc)
+        if l <= 8:
+            masks[f"L{l}"] = acc > 0
+            acc = np.maximum(acc, 0)
+        H = acc_to_vec(acc)
+    if mode == 0:
+        sigma_head()
+        assert st.pos == st.slabs.shape[0]
+        return out, masks
+    a2 = st.bias_tiles(NTH, n)
+    st.mma(NTH, H, a2)
+    st.mma(NTH, D, a2)
+    masks["DIR"] = a2 > 0
+    G = acc_to_vec(np.maximum(a2, 0))
+    ar = st.bias_tiles(NTR, n)
+    st.mma(NTR, G, ar)
+    out["rgbfeat"] = ar.reshape(NTR * 32, n)[:3 + Cf].T
+    if mode == 2:
+        a2 = st.bias_tiles(NTH, n)
+        st.mma(NTH, H, a2)
+        st.mma(NTH, D, a2)
+        masks["T0"] = a2 > 0
+        G = acc_to_vec(np.maximum(a2, 0))
+        for tl in (1, 2):
+            a2 = st.bias_tiles(NTH, n)
+            st.mma(NTH, G, a2)
+            masks[f"T{tl}"] = a2 > 0
+            G = acc_to_vec(np.maximum(a2, 0))
+        th = st.bias_tiles(1, n)
+        st.mma(1, G, th)
+        sig = lambda x: 1 / (1 + np.exp(-x))
+        out["t_rgb"] = sig(th[0, :3]).T
+        out["t_sigma"] = softplus(th[0, 3])
+        out["t_beta"] = softplus(th[0, 4])
+    assert st.pos == st.slabs.shape[0]
+    return out, masks
+
+
+def compact(vals, steps):
+    """list of per-sample arrays -> compact slot vector (slot index 2s+h)."""
+    n = vals[0].shape[0]
+    v = np.zeros((steps, 2, n), np.float32)
+    for k, a in enumerate(vals):
+        v[k // 2, k % 2] = a
+    return v
+
+
+def emulate_backward(info, blob, Wd, Cf, masks, d_pre):
+    """Mirrors field_bwd_kernel (csrc/field_bwd.hip).  d_pre: pre-activation head gradients."""
+    n = d_pre["sigma"].shape[0]
+    NTW, NTH = Wd // 32, Wd // 64
+    st = Stream(blob, info.stream[L.STREAM_BWD_FULL])
+    Z = lambda nt: np.zeros((nt, 32, n), np.float32)
+    a2 = Z(NTH)
+    st.mma(NTH, compact([d_pre["t_rgb"][:, 0], d_pre["t_rgb"][:, 1], d_pre["t_rgb"][:, 2], d_pre["t_sigma"], d_pre["t_beta"]], 3), a2)
+    Tv = acc_to_vec(a2 * masks["T2"])
+    for tl in (2, 1):
+        a2 = Z(NTH)
+        st.mma(NTH, Tv, a2)
+        Tv = acc_to_vec(a2 * masks[f"T{tl - 1}"])
+    a2 = Z(NTH)
+    C3 = 3 + Cf
+    st.mma(NTH, compact([d_pre["rgbfeat"][:, k] for k in range(C3)], (C3 + 1) // 2), a2)
+    Gv = acc_to_vec(a2 * masks["DIR"])
+    a9 = Z(NTW + 1)
+    st.mma(NTW + 1, Tv, a9)
+    st.mma(NTW + 1, Gv, a9)
+    H = acc_to_vec(a9, 0, NTW)
+    dD = acc_to_vec(a9, NTW, 1)
+    acc = Z(NTW)
+    st.mma(NTW, H, acc)
+    st.mma(NTW, compact([d_pre["sigma"]], 1), acc)
+    H = acc_to_vec(acc * masks["L8"])
+    accE = Z(2)
+    for l in range(8, 1, -1):
+        if l == 5:
+            a10 = Z(NTW + 2)
+            st.mma(NTW + 2, H, a10)
+            accE = a10[:2].copy()
+            H = acc_to_vec(a10[2:] * masks["L4"])
+        else:
+            acc = Z(NTW)
+            st.mma(NTW, H, acc)
+            H = acc_to_vec(acc * masks[f"L{l - 1}"])
+    st.mma(2, H, accE)
+    assert st.pos == st.slabs.shape[0]
+    return emb_vector_T(acc_to_vec(accE), 10, 63), emb_vector_T(dD[:14], 4, 27)
+
+
+@pytest.mark.parametrize("Wd,Cf", [(256, 16), (128, 128)])
+def test_packed_streams_reproduce_the_mlp(Wd, Cf):
+    n = 8
+    g = torch.Generator().manual_seed(5)
+    pts = (torch.rand(n, 3, generator=g) - .5) * 5
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    e63, e27 = O.freq_encode(pts, 10), O.freq_encode(dirs, 4)
+
+    # coarse net: sigma-only and static streams
+    pc, info_c, blob_c = pack(Wd, Cf, "coarse")
+    out, _ = emulate_forward(info_c, blob_c, Wd, Cf, e63.numpy(), e27.numpy(), 0)
+    ref = O.field_forward(pc, e63, sigma_only=True)[:, 0].numpy()
+    np.testing.assert_allclose(out["sigma"], ref, rtol=2e-5, atol=2e-6)
+    out, _ = emulate_forward(info_c, blob_c, Wd, Cf, e63.numpy(), e27.numpy(), 1)
+    ref = O.field_forward(pc, torch.cat([e63, e27], 1), output_transient=False).numpy()
+    np.testing.assert_allclose(out["rgbfeat"], ref[:, :3 + Cf], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out["sigma"], ref[:, 3 + Cf], rtol=2e-5, atol=2e-6)
+
+    # fine net: full forward, then backward-to-inputs against autograd
+    pf, info_f, blob_f = pack(Wd, Cf, "fine")
+    out, masks = emulate_forward(info_f, blob_f, Wd, Cf, e63.numpy(), e27.numpy(), 2)
+    emb = torch.cat([e63, e27], 1).requires_grad_()
+    raw = O.field_forward(pf, emb, output_transient=True)
+    r = raw.detach().numpy()
+    C3 = 3 + Cf
+    np.testing.assert_allclose(out["rgbfeat"], r[:, :C3], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out["sigma"], r[:, C3], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out["t_rgb"], r[:, C3 + 1:C3 + 4], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out["t_sigma"], r[:, C3 + 4], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out["t_beta"], r[:, C3 + 5], rtol=2e-5, atol=2e-6)
+
+    g_raw = torch.randn(raw.shape, generator=g)
+    (g_emb,) = torch.autograd.grad(raw, emb, g_raw)
+    gr = g_raw.numpy()
+    d_pre = {"rgbfeat": gr[:, :C3], "sigma": gr[:, C3] * (1 - np.exp(-r[:, C3])),
+             "t_rgb": gr[:, C3 + 1:C3 + 4] * r[:, C3 + 1:C3 + 4] * (1 - r[:, C3 + 1:C3 + 4]),
+             "t_sigma": gr[:, C3 + 4] * (1 - np.exp(-r[:, C3 + 4])), "t_beta": gr[:, C3 + 5] * (1 - np.exp(-r[:, C3 + 5]))}
+    g63, g27 = emulate_backward(info_f, blob_f, Wd, Cf, masks, d_pre)
+    scale = np.abs(g_emb.numpy()).max()
+    np.testing.assert_allclose(g63, g_emb.numpy()[:, :63], rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(g27, g_emb.numpy()[:, 63:], rtol=1e-4, atol=2e-5 * scale)
