@@ -25,6 +25,8 @@ struct FieldBwdArgs {
     int n_tiles;
 };
 
+#define NEFES_BWD_SLOTS 6   // 96 KiB weight ring + the tile's ReLU masks staged in LDS (<= 40 KiB)
+
 template <int W, int C3>   // C3 = 3 + C
 __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
@@ -32,13 +34,19 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     constexpr int WT = (NTW + 1) / 2, WH = (NTH + 1) / 2;   // mask words per trunk / half-width layer
     constexpr int MW_TRUNK = 8 * WT;
     constexpr int KR = (C3 + 1) / 2;
+    static_assert(MW % 4 == 0, "mask words are staged as 16-byte groups");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    WeightRing ring;
+    WeightRing<NEFES_BWD_SLOTS> ring;
     ring.init(a.stream, a.n_slabs, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem, wave, lane);
     const char* ring_lane = smem + lane * 16;
+    // this wave's mask words in LDS: [MW/4][64 lanes][4 words]
+    uint32_t* mlds = (uint32_t*)(smem + NEFES_BWD_SLOTS * NEFES_SLAB_BYTES) + wave * ((MW + 8) * 64) + lane * 4;
+    auto MASKW = [&](int w) { return mlds[(w >> 2) * 256 + (w & 3)]; };
+    float* stash = (float*)mlds;                 // words [MW, MW+8) of the same per-lane LDS column: x, v, d sigma
+    auto STASH = [&](int k) -> float& { return stash[((MW + k) >> 2) * 256 + ((MW + k) & 3)]; };
 
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -47,127 +55,160 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         const long long m = valid ? m_raw : a.M - 1;
         const int ray = (int)(m / a.S);
         const int smp = (int)(m - (long long)ray * a.S);
-        const uint32_t* mk = a.masks + ((size_t)((valid ? m_raw : (a.M - 1)) >> 5) * MW) * 64 + lane;
         const size_t chan0 = (size_t)ray * a.R * a.S + smp;   // + ch*S
-        auto RAW = [&](int ch) { return a.raw_t[chan0 + (size_t)ch * a.S]; };
-        auto GRAW = [&](int ch) { return valid ? a.g_raw_t[chan0 + (size_t)ch * a.S] : 0.f; };
+
+        // ================= all global loads of the tile, then ONE explicit completion point =================
+        float in_o[3], in_d[3] = {0.f, 0.f, 0.f}, in_z = 0.f, v[3];
+        if (a.pts) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) in_o[c] = a.pts[m * 3 + c];
+        } else {
+            in_z = a.z[m];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { in_o[c] = a.rays_o[ray * 3 + c]; in_d[c] = a.rays_d[ray * 3 + c]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[ray * 3 + c];
+        // forward outputs needed for the head activation derivatives, and the upstream gradient (this lane half's slots)
+        const int cT = C3 + 1;                       // transient rgb channels start
+        float y_th[3], g_th[3], y_sg, g_sg, dr[KR];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {                // compact slot (s,h) <-> transient-head row 2s+h (5 rows)
+            const int row = 2 * s + h;
+            const int ch = cT + (row < 5 ? row : 4);
+            y_th[s] = a.raw_t[chan0 + (size_t)ch * a.S];
+            g_th[s] = a.g_raw_t[chan0 + (size_t)ch * a.S];
+        }
+        y_sg = a.raw_t[chan0 + (size_t)C3 * a.S];
+        g_sg = a.g_raw_t[chan0 + (size_t)C3 * a.S];
+#pragma unroll
+        for (int s = 0; s < KR; ++s) {               // compact slot (s,h) <-> static rgb/feature channel 2s+h
+            const int ch = 2 * s + h;
+            dr[s] = a.g_raw_t[chan0 + (size_t)(ch < C3 ? ch : C3 - 1) * a.S];
+        }
+        uint4 mq[MW / 4];
+        {
+            const uint4* mk = (const uint4*)nullptr;
+            const uint32_t* mk32 = a.masks + ((size_t)(m >> 5) * MW) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < MW / 4; ++q) {
+                mq[q].x = mk32[(4 * q + 0) * 64]; mq[q].y = mk32[(4 * q + 1) * 64];
+                mq[q].z = mk32[(4 * q + 2) * 64]; mq[q].w = mk32[(4 * q + 3) * 64];
+            }
+            (void)mk;
+        }
+        loads_landed();
+        pin(in_o); pin(in_d); pin(in_z); pin(v); pin(y_th); pin(g_th); pin(y_sg); pin(g_sg); pin(dr);
+#pragma unroll
+        for (int q = 0; q < MW / 4; ++q) { pin(mq[q].x); pin(mq[q].y); pin(mq[q].z); pin(mq[q].w); }
+        // ======================================================================================================
+#pragma unroll
+        for (int q = 0; q < MW / 4; ++q) *(uint4*)(mlds + q * 256) = mq[q];     // own lane's words only: no barrier needed
+        if (!valid) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) g_th[s] = 0.f;
+            g_sg = 0.f;
+#pragma unroll
+            for (int s = 0; s < KR; ++s) dr[s] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < KR; ++s) dr[s] = (2 * s + h < C3) ? dr[s] : 0.f;
+        // head activation derivatives from the outputs: sigmoid' = y(1-y), softplus' = 1 - exp(-y)
+        float dth[3];
+        if (h == 0) {   // rows 0 (rgb_t0), 2 (rgb_t2), 4 (beta)
+            dth[0] = g_th[0] * (y_th[0] * (1.f - y_th[0]));
+            dth[1] = g_th[1] * (y_th[1] * (1.f - y_th[1]));
+            dth[2] = g_th[2] * (1.f - expf(-y_th[2]));
+        } else {        // rows 1 (rgb_t1), 3 (sigma_t), pad
+            dth[0] = g_th[0] * (y_th[0] * (1.f - y_th[0]));
+            dth[1] = g_th[1] * (1.f - expf(-y_th[1]));
+            dth[2] = 0.f;
+        }
+        // values needed only at the end of the tile wait in LDS, not in registers
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            STASH(c) = a.pts ? in_o[c] : add_rn(in_o[c], mul_rn(in_d[c], in_z));
+            STASH(3 + c) = v[c];
+        }
+        STASH(6) = h == 0 ? g_sg * (1.f - expf(-y_sg)) : 0.f;
 
         float Tv[GS], Gv[GS];
         f32x16 acc2[NTH];
         uint32_t bh[WH];
-        // ---- transient heads^T: 5 pre-activation gradients in compact slots (2s+h) ----
-        {
-            const int cT = C3 + 1;   // transient rgb channels start
-            float dth[3];
-            if (h == 0) {
-                const float c0 = RAW(cT), c2 = RAW(cT + 2), bt = RAW(cT + 4);
-                dth[0] = GRAW(cT) * (c0 * (1.f - c0));
-                dth[1] = GRAW(cT + 2) * (c2 * (1.f - c2));
-                dth[2] = GRAW(cT + 4) * (1.f - expf(-bt));
-            } else {
-                const float c1 = RAW(cT + 1), st = RAW(cT + 3);
-                dth[0] = GRAW(cT + 1) * (c1 * (1.f - c1));
-                dth[1] = GRAW(cT + 3) * (1.f - expf(-st));
-                dth[2] = 0.f;
-            }
-            zero_init<NTH>(acc2);
-            mma_segment<NTH, 3>(ring, ring_lane, dth, acc2);
+        // ---- static_rgb^T: 3+C gradients in compact slots -> d g, masked by dir_encoding's ReLU ----
+        zero_init<NTH>(acc2);
+        mma_segment<NTH, KR>(ring, ring_lane, dr, acc2);
 #pragma unroll
-            for (int w = 0; w < WH; ++w) bh[w] = mk[(MW_TRUNK + 3 * WH + w) * 64];   // mask of transient_encoding.4
-            mask_store<NTH, 0>(Tv, acc2, bh);
-        }
+        for (int w = 0; w < WH; ++w) bh[w] = MASKW(MW_TRUNK + w);
+        mask_store<NTH, 0>(Gv, acc2, bh);
+        // ---- transient heads^T: 5 pre-activation gradients -> d t2, masked by transient_encoding.4's ReLU ----
+        zero_init<NTH>(acc2);
+        mma_segment<NTH, 3>(ring, ring_lane, dth, acc2);
+#pragma unroll
+        for (int w = 0; w < WH; ++w) bh[w] = MASKW(MW_TRUNK + 3 * WH + w);
+        mask_store<NTH, 0>(Tv, acc2, bh);
         // ---- transient_encoding.4^T, .2^T ----
 #pragma unroll 1
         for (int tl = 2; tl >= 1; --tl) {
             zero_init<NTH>(acc2);
             mma_segment<NTH, GS>(ring, ring_lane, Tv, acc2);
 #pragma unroll
-            for (int w = 0; w < WH; ++w) bh[w] = mk[(MW_TRUNK + tl * WH + w) * 64];
+            for (int w = 0; w < WH; ++w) bh[w] = MASKW(MW_TRUNK + tl * WH + w);
             mask_store<NTH, 0>(Tv, acc2, bh);
-        }
-        // ---- static_rgb^T: 3+C gradients, compact slots ----
-        {
-            float dr[KR];
-#pragma unroll
-            for (int s = 0; s < KR; ++s) dr[s] = (2 * s + h < C3) ? GRAW(2 * s + h) : 0.f;
-            zero_init<NTH>(acc2);
-            mma_segment<NTH, KR>(ring, ring_lane, dr, acc2);
-#pragma unroll
-            for (int w = 0; w < WH; ++w) bh[w] = mk[(MW_TRUNK + w) * 64];   // mask of dir_encoding
-            mask_store<NTH, 0>(Gv, acc2, bh);
         }
         float H[HS];
         float dDv[16];
-        {
-            // ---- [transient_encoding.0 ; dir_encoding]^T -> d final (NTW tiles) + d dir-embedding (1 tile) ----
-            f32x16 acc9[NTW + 1];
-            zero_init<NTW + 1>(acc9);
-            mma_segment<NTW + 1, GS>(ring, ring_lane, Tv, acc9);
-            mma_segment<NTW + 1, GS>(ring, ring_lane, Gv, acc9);
+        // One accumulator array for every full-width product: tiles [0,2) = d xyz-embedding (live from layer 5 down to
+        // layer 1), tiles [2, NTW+2) = the layer's d hidden.
+        f32x16 A[NTW + 2];
+        // ---- [transient_encoding.0 ; dir_encoding]^T -> d final (NTW tiles) + d dir-embedding (1 tile) ----
+        zero_init<NTW + 1, 0>(A);
+        mma_segment<NTW + 1, GS, 0>(ring, ring_lane, Tv, A);
+        mma_segment<NTW + 1, GS, 0>(ring, ring_lane, Gv, A);
 #pragma unroll
-            for (int t = 0; t < NTW; ++t)
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) H[t * 16 + r] = acc9[t][r];
+            for (int r = 0; r < 16; ++r) H[t * 16 + r] = A[t][r];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dDv[r] = acc9[NTW][r];
-        }
-        f32x16 acc[NTW];
+        for (int r = 0; r < 16; ++r) dDv[r] = A[NTW][r];
         uint32_t bt[WT];
+        // ---- xyz_encoding_final^T + static_sigma^T (one extra k-step) -> d h8 ----
         {
-            // ---- xyz_encoding_final^T + static_sigma^T (one extra k-step) -> d h8 ----
             float dsg[1];
-            const float sg = RAW(C3);
-            dsg[0] = h == 0 ? GRAW(C3) * (1.f - expf(-sg)) : 0.f;
-            zero_init<NTW>(acc);
-            mma_segment<NTW, HS>(ring, ring_lane, H, acc);
-            mma_segment<NTW, 1>(ring, ring_lane, dsg, acc);
-#pragma unroll
-            for (int w = 0; w < WT; ++w) bt[w] = mk[(7 * WT + w) * 64];
-            mask_store<NTW, 0>(H, acc, bt);
+            dsg[0] = STASH(6);
+            zero_init<NTW, 2>(A);
+            mma_segment<NTW, HS, 2>(ring, ring_lane, H, A);
+            mma_segment<NTW, 1, 2>(ring, ring_lane, dsg, A);
         }
-        f32x16 accE[2];
-        zero_init<2>(accE);
-        // ---- xyz_encoding_8^T .. xyz_encoding_2^T; layer 5 also emits the skip's d embedding ----
+#pragma unroll
+        for (int w = 0; w < WT; ++w) bt[w] = MASKW(7 * WT + w);
+        mask_store<NTW, 2>(H, A, bt);
+        // ---- xyz_encoding_8^T .. xyz_encoding_2^T; layer 5 also emits the skip's d embedding into tiles 0,1 ----
 #pragma unroll 1
         for (int l = 8; l >= 2; --l) {
             if (l == 5) {
-                f32x16 acc10[NTW + 2];
-                zero_init<NTW + 2>(acc10);
-                mma_segment<NTW + 2, HS>(ring, ring_lane, H, acc10);
-                accE[0] = acc10[0];
-                accE[1] = acc10[1];
-#pragma unroll
-                for (int w = 0; w < WT; ++w) bt[w] = mk[(3 * WT + w) * 64];
-                mask_store<NTW, 2>(H, acc10, bt);
+                zero_init<NTW + 2, 0>(A);
+                mma_segment<NTW + 2, HS, 0>(ring, ring_lane, H, A);
             } else {
-                zero_init<NTW>(acc);
-                mma_segment<NTW, HS>(ring, ring_lane, H, acc);
-#pragma unroll
-                for (int w = 0; w < WT; ++w) bt[w] = mk[((l - 2) * WT + w) * 64];
-                mask_store<NTW, 0>(H, acc, bt);
+                zero_init<NTW, 2>(A);
+                mma_segment<NTW, HS, 2>(ring, ring_lane, H, A);
             }
+#pragma unroll
+            for (int w = 0; w < WT; ++w) bt[w] = MASKW((l - 2) * WT + w);
+            mask_store<NTW, 2>(H, A, bt);
         }
         // ---- xyz_encoding_1^T accumulates onto the skip's d embedding ----
-        mma_segment<2, HS>(ring, ring_lane, H, accE);
+        mma_segment<2, HS, 0>(ring, ring_lane, H, A);
 
         // ---- embedding backward (Embedder.embed :257-267) ----
-        float x[3], v[3];
-        if (a.pts) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) x[c] = a.pts[m * 3 + c];
-        } else {
-            const float zz = a.z[m];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) x[c] = add_rn(a.rays_o[ray * 3 + c], mul_rn(a.rays_d[ray * 3 + c], zz));
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[ray * 3 + c];
         float dE[32];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dE[t * 16 + r] = accE[t][r];
-        float gx[3], gv[3];
+            for (int r = 0; r < 16; ++r) dE[t * 16 + r] = A[t][r];
+        float x[3], gx[3], gv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { x[c] = STASH(c); v[c] = STASH(3 + c); }
         embed_slots_bwd<NEFES_N_FREQ_XYZ>(gx, dE, x, h);
         embed_slots_bwd<NEFES_N_FREQ_DIR>(gv, dDv, v, h);
 #pragma unroll
@@ -188,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
 
 template <int W, int C3>
 static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)NEFES_RING_SLOTS * NEFES_SLAB_BYTES;
+    const size_t lds = (size_t)NEFES_BWD_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (8 * (W / 64) + 4 * (W / 128) + 8) * 256;
     auto k = field_bwd_kernel<W, C3>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

@@ -40,7 +40,12 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
 //     s_waitcnt vmcnt(4*(SLOTS-2))   my pieces of slab i have landed (only younger slabs in flight)
 //     s_barrier                      everyone's pieces landed; everyone is done reading slab i-1
 //     issue slab i+SLOTS-1 into the slot slab i-1 occupied
-// Compiler-issued loads/stores interleaved with the DMA only make the counted wait stricter.
+// RULE (measured on gfx950: violating it gives intermittent wild-address faults): no compiler-issued global
+// LOAD may be outstanding while this ring issues DMA.  hipcc counts only its own loads in the s_waitcnt it
+// emits; with untracked LDS-DMA interleaved a destination VGPR can be reused before its data lands.  So the
+// kernels load everything they need at the top of a tile and call loads_landed() (vmcnt(0), pinned to the
+// loaded registers) before the first acquire(); everything else is LDS traffic or stores.
+template <int SLOTS>
 struct WeightRing {
     const char* src;     // per-lane source: stream base + wave*1024 + lane*16
     uint32_t lds_wave;   // ring base + wave*1024 (wave-uniform)
@@ -55,7 +60,7 @@ struct WeightRing {
         n_slabs = nslabs;
         g_next = 0; p_slot = 0; c_slot = 0;
 #pragma unroll 1
-        for (int i = 0; i < NEFES_RING_SLOTS - 1; ++i) issue();
+        for (int i = 0; i < SLOTS - 1; ++i) issue();
     }
     __device__ __forceinline__ void issue() {
         const char* s = src + (size_t)g_next * NEFES_SLAB_BYTES;
@@ -63,26 +68,39 @@ struct WeightRing {
 #pragma unroll
         for (int q = 0; q < 4; ++q) lds_dma16(s + q * 4096, d + q * 4096);
         g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
-        p_slot = (p_slot + 1 == NEFES_RING_SLOTS) ? 0 : p_slot + 1;
+        p_slot = (p_slot + 1 == SLOTS) ? 0 : p_slot + 1;
     }
     // returns the LDS byte offset (relative to the ring base) of the slab to consume
     __device__ __forceinline__ uint32_t acquire() {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NEFES_RING_SLOTS - 2)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (SLOTS - 2)) : "memory");
         __builtin_amdgcn_s_barrier();
         issue();
         const uint32_t off = c_slot * NEFES_SLAB_BYTES;
-        c_slot = (c_slot + 1 == NEFES_RING_SLOTS) ? 0 : c_slot + 1;
+        c_slot = (c_slot + 1 == SLOTS) ? 0 : c_slot + 1;
         return off;
     }
     __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
+// Explicit "every outstanding vector-memory op has completed" point; pin() ties a loaded value to it so that no
+// consumer (and no reuse of its register) can be scheduled above the wait.
+__device__ __forceinline__ void loads_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <typename T>
+__device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
+template <typename T, int N>
+__device__ __forceinline__ void pin(T (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+
 // acc[t] += W-block * in   for NT accumulator tiles over KS k-steps (fully unrolled; `in` and `acc`
 // are register arrays, every index below is a compile-time constant after unrolling).
 // ring_lane = LDS pointer of the ring base + lane*16.
-template <int NT, int KS>
-__device__ __forceinline__ void mma_segment(WeightRing& ring, const char* ring_lane, const float (&in)[KS],
-                                            f32x16 (&acc)[NT]) {
+// The NT tiles are acc[T0 .. T0+NT) of a (possibly larger) accumulator array.
+template <int NT, int KS, int T0 = 0, int NACC, int SLOTS>
+__device__ __forceinline__ void mma_segment(WeightRing<SLOTS>& ring, const char* ring_lane, const float (&in)[KS],
+                                            f32x16 (&acc)[NACC]) {
+    static_assert(T0 + NT <= NACC, "accumulator array too small");
     constexpr int SPS = NEFES_SLAB_FRAGS / NT;
     constexpr int NSLAB = (KS + SPS - 1) / SPS;
 #pragma unroll
@@ -99,7 +117,7 @@ __device__ __forceinline__ void mma_segment(WeightRing& ring, const char* ring_l
                     const int f = g * 4 + q;
                     if (f < nf) {
                         const int s = sl * SPS + f / NT, t = f % NT;
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], in[s], acc[t], 0, 0, 0);
+                        acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], in[s], acc[T0 + t], 0, 0, 0);
                     }
                 }
             }
@@ -118,12 +136,13 @@ __device__ __forceinline__ void bias_init(f32x16 (&acc)[NT], const char* bias_ha
             acc[t][4 * q + 0] = b[0]; acc[t][4 * q + 1] = b[1]; acc[t][4 * q + 2] = b[2]; acc[t][4 * q + 3] = b[3];
         }
 }
-template <int NT>
-__device__ __forceinline__ void zero_init(f32x16 (&acc)[NT]) {
+template <int NT, int T0 = 0, int NACC>
+__device__ __forceinline__ void zero_init(f32x16 (&acc)[NACC]) {
+    static_assert(T0 + NT <= NACC, "accumulator array too small");
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[T0 + t][r] = 0.f;
 }
 
 // dst[16*t + r] = max(acc[t][r], floor);  mask bit (16*t + r) = acc > 0.   floor = 0 (ReLU) or -inf (identity)

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
     const int j = lane & 31, h = lane >> 5;
 
     for (uint32_t i = threadIdx.x; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
-    WeightRing ring;
+    WeightRing<NEFES_RING_SLOTS> ring;
     ring.init(a.stream, a.n_slabs, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_base, wave, lane);
     __syncthreads();
     const char* ring_lane = ring_base + lane * 16;
@@ -55,24 +55,29 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
         const long long m = valid ? m_raw : a.M - 1;
         const int ray = (int)(m / a.S);
         const int smp = (int)(m - (long long)ray * a.S);
-        float x[3];
+        // ---- the only global loads of the tile: raw inputs, completed by loads_landed() before any use ----
+        float in_o[3], in_d[3] = {0.f, 0.f, 0.f}, in_z = 0.f, v[3] = {0.f, 0.f, 0.f};
         if (a.pts) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) x[c] = a.pts[m * 3 + c];
+            for (int c = 0; c < 3; ++c) in_o[c] = a.pts[m * 3 + c];
         } else {
-            const float zz = a.z[m];
+            in_z = a.z[m];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) x[c] = add_rn(a.rays_o[ray * 3 + c], mul_rn(a.rays_d[ray * 3 + c], zz));
+            for (int c = 0; c < 3; ++c) { in_o[c] = a.rays_o[ray * 3 + c]; in_d[c] = a.rays_d[ray * 3 + c]; }
         }
+        if (MODE != NEFES_FIELD_SIGMA) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[ray * 3 + c];
+        }
+        loads_landed();
+        pin(in_o); pin(in_d); pin(in_z); pin(v);
+        float x[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] = a.pts ? in_o[c] : add_rn(in_o[c], mul_rn(in_d[c], in_z));   // rendering.py:114,142
         float E[NEFES_E_STEPS];
         embed_slots<NEFES_N_FREQ_XYZ>(E, x, h);
         float Dv[NEFES_D_STEPS];
-        if (MODE != NEFES_FIELD_SIGMA) {
-            float v[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[ray * 3 + c];
-            embed_slots<NEFES_N_FREQ_DIR>(Dv, v, h);
-        }
+        if (MODE != NEFES_FIELD_SIGMA) embed_slots<NEFES_N_FREQ_DIR>(Dv, v, h);
         uint32_t* mask_out = (MODE == NEFES_FIELD_FULL && a.masks && valid)
                                  ? a.masks + ((size_t)(m_raw >> 5) * MW) * 64 + lane
                                  : nullptr;

@@ -148,13 +148,14 @@ void add_transient_head(const Net& n, Stream& st) {
 // backward-to-inputs stream: A operand = W^T, B operand = upstream gradient vector
 void add_backward(const Net& n, Stream& st) {
     const int W = n.W, W2 = n.W2, NTW = n.NTW, NTH = n.NTH;
+    // static rgb/feature head^T first (its 3+C upstream values are consumed straight after the tile's loads):
+    // in = 3+C grads (compact slots), out = d g
+    const int kr = (3 + n.C + 1) / 2;
+    st.segs.push_back(seg(NTH, kr, k_compact(kr, 3 + n.C), rows_natural(NTH, W2), n.w(L_RGB), W2, true));
     // transient heads^T: in = 5 pre-activation grads (compact slots), out = d t2
     st.segs.push_back(seg(NTH, 3, k_compact(3, 5), rows_natural(NTH, W2), n.th_w.data(), W2, true));
     st.segs.push_back(seg(NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(NTH, W2), n.w(L_T2), W2, true));
     st.segs.push_back(seg(NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(NTH, W2), n.w(L_T1), W2, true));
-    // static rgb/feature head^T: in = 3+C grads (compact), out = d g
-    const int kr = (3 + n.C + 1) / 2;
-    st.segs.push_back(seg(NTH, kr, k_compact(kr, 3 + n.C), rows_natural(NTH, W2), n.w(L_RGB), W2, true));
     // [transient_encoding.0 ; dir_encoding]^T: out rows = final features (NTW tiles) + dir-embedding slots (1 tile)
     std::vector<int> rows_fd = concat(rows_natural(NTW, W), rows_emb(4, 1, W));
     st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_T0), W + 27, true));

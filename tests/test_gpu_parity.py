@@ -166,12 +166,14 @@ def test_sample_pdf_indices_bit_exact(golden, ops, tag, det, Ni):
         rows, cols = np.nonzero(bad)
         k = np.minimum(inds2.cpu().numpy()[rows, cols], g[f"{tag}.inds"][rows, cols])
         assert (np.abs(uu[rows, cols] - cg[rows, np.minimum(k, cg.shape[1] - 1)]) <= 2.4e-7).all()
-    np.testing.assert_allclose(zs2.cpu().numpy(), g[f"{tag}.samples"], rtol=0, atol=2e-5)
+    # where the index agrees the sample is continuous in the CDF; at an ulp tie (u == cdf[k], notably u = 1.0 against
+    # cdf[-1] = 1 +- 1ulp, SURVEY.md §7 hard part 1) the reference's own result flips with the last bit of its cumsum
+    np.testing.assert_allclose(zs2.cpu().numpy()[~bad], g[f"{tag}.samples"][~bad], rtol=0, atol=2e-5)
     assert (np.diff(zf2.cpu().numpy(), axis=-1) >= 0).all()
     # reference call surface: sample_pdf(bins, weights[...,1:-1], N, det)
     mid = .5 * (z[..., 1:] + z[..., :-1])
     _, zs3 = ops.sample_pdf_merge(mid, w[..., 1:-1].contiguous(), Ni, u=u, bins_layout=True)
-    np.testing.assert_allclose(zs3.cpu().numpy(), g[f"{tag}.samples"], rtol=0, atol=2e-5)
+    assert np.array_equal(zs3.cpu().numpy(), zs2.cpu().numpy())
 
 
 # ---- a6/a7/a8 field MLP ---------------------------------------------------------------------------------------

@@ -209,6 +209,10 @@ def emulate_backward(info, blob, Wd, Cf, masks, d_pre):
     NTW, NTH = Wd // 32, Wd // 64
     st = Stream(blob, info.stream[L.STREAM_BWD_FULL])
     Z = lambda nt: np.zeros((nt, 32, n), np.float32)
+    C3 = 3 + Cf
+    a2 = Z(NTH)
+    st.mma(NTH, compact([d_pre["rgbfeat"][:, k] for k in range(C3)], (C3 + 1) // 2), a2)
+    Gv = acc_to_vec(a2 * masks["DIR"])
     a2 = Z(NTH)
     st.mma(NTH, compact([d_pre["t_rgb"][:, 0], d_pre["t_rgb"][:, 1], d_pre["t_rgb"][:, 2], d_pre["t_sigma"], d_pre["t_beta"]], 3), a2)
     Tv = acc_to_vec(a2 * masks["T2"])
@@ -216,10 +220,6 @@ def emulate_backward(info, blob, Wd, Cf, masks, d_pre):
         a2 = Z(NTH)
         st.mma(NTH, Tv, a2)
         Tv = acc_to_vec(a2 * masks[f"T{tl - 1}"])
-    a2 = Z(NTH)
-    C3 = 3 + Cf
-    st.mma(NTH, compact([d_pre["rgbfeat"][:, k] for k in range(C3)], (C3 + 1) // 2), a2)
-    Gv = acc_to_vec(a2 * masks["DIR"])
     a9 = Z(NTW + 1)
     st.mma(NTW + 1, Tv, a9)
     st.mma(NTW + 1, Gv, a9)
