@@ -152,6 +152,16 @@ def main():
         flop_fwd = 2.0 * macs_full(Wd, C) * rays_local * (Nc + Ni)
         ach = flop_fwd / (kern["field_fwd[full]"] * 1e-3) / 1e12
         flop_frame = 2.0 * (Nc * macs_sigma(Wd) + 2 * (Nc + Ni) * macs_full(Wd, C)) * n_total
+        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure
+        # comes from the committed rocprofv3 passes of this same command (profiles/, 2*FETCH_SIZE + WRITE_SIZE in KiB,
+        # gfx950 correction of MI355X_MICROARCH.md) and is quoted only for the workload it was measured on.
+        traffic = None
+        try:
+            if (H, W, world) == (480, 640, 1):
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_per_launch.json")))["field_fwd_kernel<256, 1, 2>"]
+                traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+        except Exception:
+            traffic = None
         out = {
             "metric": "rays/s (fwd+bwd) at 640x480x(64+128) samples, 8x256 MLP", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -161,7 +171,7 @@ def main():
                        "rays_per_step": n_total, "samples_per_ray": [Nc, Ni], "parallelism": f"rows/{world}"},
             "roofline": {"bound": "mfma", "kernel": "field_fwd_kernel<256,1,FULL>", "achieved": ach,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_unit": "bytes/launch (HBM side, from profiles/r01 PMC passes)",
                          "end_to_end_frac": value * (flop_frame / n_total) / (PEAK_F32_MFMA_TFLOPS * 1e12 * world)},
             "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items())},
             "pose_grad_abs_max": float(g.abs().max()),

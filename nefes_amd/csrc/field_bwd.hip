@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     WeightRing<NEFES_BWD_SLOTS> ring;
     ring.init(a.stream, a.n_slabs, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem, wave, lane);
     const char* ring_lane = smem + lane * 16;
+    ring.prime(ring_lane);
     // this wave's mask words in LDS: [MW/4][64 lanes][4 words]
     uint32_t* mlds = (uint32_t*)(smem + NEFES_BWD_SLOTS * NEFES_SLAB_BYTES) + wave * ((MW + 8) * 64) + lane * 4;
     auto MASKW = [&](int w) { return mlds[(w >> 2) * 256 + (w & 3)]; };

@@ -53,6 +53,8 @@ struct WeightRing {
     uint32_t g_next;     // next slab of the stream to issue
     uint32_t p_slot;     // slot that slab goes to
     uint32_t c_slot;     // slot consumed next
+    uint32_t cur_off;    // LDS offset of the slab being consumed (already acquired)
+    f32x4 pf;            // its first fragment group, prefetched
 
     __device__ __forceinline__ void init(const char* stream, uint32_t nslabs, uint32_t ring_lds_base, int wave, int lane) {
         src = stream + wave * 1024 + lane * 16;
@@ -70,14 +72,44 @@ struct WeightRing {
         g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
         p_slot = (p_slot + 1 == SLOTS) ? 0 : p_slot + 1;
     }
-    // returns the LDS byte offset (relative to the ring base) of the slab to consume
+    // One 1 KiB piece (q = 0..3) of the slab that refills the slot freed by the latest acquire().  The four
+    // pieces are issued one at a time behind MFMAs of the slab being consumed (mma_segment), never as a burst:
+    // an LDS-DMA issue costs ~60 cycles of the wave's issue slot, which one 64-cycle MFMA in flight covers.
+    __device__ __forceinline__ void issue_piece(int q) {
+        lds_dma16(src + (size_t)g_next * NEFES_SLAB_BYTES + q * 4096, lds_wave + p_slot * NEFES_SLAB_BYTES + q * 4096);
+        if (q == 3) {
+            g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
+            p_slot = (p_slot + 1 == SLOTS) ? 0 : p_slot + 1;
+        }
+    }
+    // Synchronisation point before consuming the next slab; returns its LDS byte offset (relative to the ring base).
+    // After it the slot of the slab consumed before is free: its refill = the 4 issue_piece() calls that follow.
+#ifdef NEFES_STAMP   // diagnostic build only: cycles parked in the counted wait and in the barrier
+    unsigned long long dbg_wait = 0, dbg_barrier = 0;
+    static __device__ __forceinline__ unsigned long long now() {
+        unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+#endif
     __device__ __forceinline__ uint32_t acquire() {
+#ifdef NEFES_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t0 = now();
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (SLOTS - 2)) : "memory");
+        const unsigned long long t1 = now();
         __builtin_amdgcn_s_barrier();
-        issue();
+        const unsigned long long t2 = now();
+        dbg_wait += t1 - t0; dbg_barrier += t2 - t1;
+#else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (SLOTS - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+#endif
         const uint32_t off = c_slot * NEFES_SLAB_BYTES;
         c_slot = (c_slot + 1 == SLOTS) ? 0 : c_slot + 1;
         return off;
+    }
+    // acquire the first slab and request its first fragment group (once, before the tile loop)
+    __device__ __forceinline__ void prime(const char* ring_lane) {
+        cur_off = acquire();
+        pf = *(const f32x4*)(ring_lane + cur_off);
     }
     __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
@@ -103,15 +135,35 @@ __device__ __forceinline__ void mma_segment(WeightRing<SLOTS>& ring, const char*
     static_assert(T0 + NT <= NACC, "accumulator array too small");
     constexpr int SPS = NEFES_SLAB_FRAGS / NT;
     constexpr int NSLAB = (KS + SPS - 1) / SPS;
+    // Software pipeline: the 16-byte fragment group of the NEXT 4 MFMAs is always in flight behind the current 4.
+    // At the last group of a slab the next slab (of this or of the following segment: the stream is one sequence)
+    // is acquired and its first group requested BEFORE the last 4 MFMAs issue, so the barrier and the LDS latency
+    // sit in the shadow of the matrix pipe.  ring.pf / ring.cur_off carry that state between segments.
 #pragma unroll
     for (int sl = 0; sl < NSLAB; ++sl) {
-        const char* p = ring_lane + ring.acquire();
+        const char* p = ring_lane + ring.cur_off;
         const int steps = (KS - sl * SPS) < SPS ? (KS - sl * SPS) : SPS;
         const int nf = steps * NT;
+        const int ng = (nf + 3) / 4;
+        f32x4 a = ring.pf;
 #pragma unroll
         for (int g = 0; g < NEFES_SLAB_FRAGS / 4; ++g) {
-            if (g * 4 < nf) {
-                const f32x4 a = *(const f32x4*)(p + g * 1024);
+            if (g < ng) {
+                // refill pieces scheduled in this group: piece q goes behind the first MFMA of group (q*ng)/4; in the
+                // last group of the slab they go first, because all four must be issued before the next acquire()
+                if (g == ng - 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((q * ng) / 4 == g) ring.issue_piece(q);
+                }
+                f32x4 a_next;
+                if (g + 1 < ng) {
+                    a_next = *(const f32x4*)(p + (g + 1) * 1024);
+                } else {
+                    ring.cur_off = ring.acquire();          // waits lgkmcnt(0): every read of this slab is in registers
+                    a_next = *(const f32x4*)(ring_lane + ring.cur_off);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int f = g * 4 + q;
@@ -119,9 +171,20 @@ __device__ __forceinline__ void mma_segment(WeightRing<SLOTS>& ring, const char*
                         const int s = sl * SPS + f / NT, t = f % NT;
                         acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], in[s], acc[T0 + t], 0, 0, 0);
                     }
+                    if (q == 0 && g != ng - 1) {
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq)
+                            if ((qq * ng) / 4 == g) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                ring.issue_piece(qq);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                    }
                 }
+                a = a_next;
             }
         }
+        ring.pf = a;
     }
 }
 

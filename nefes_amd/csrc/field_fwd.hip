@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
     __syncthreads();
     const char* ring_lane = ring_base + lane * 16;
     const char* bias_half = (const char*)bias_lds + 16 * h;
+    ring.prime(ring_lane);
 
     // bias block offsets (floats), in stream order: L1..L8, SIG, FINAL, DIR, RGB, T0, T1, T2, TH
     constexpr int B_SIG = 8 * W, B_FINAL = B_SIG + 32, B_DIR = B_FINAL + W, B_RGB = B_DIR + W / 2,
