@@ -133,80 +133,64 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         }
         STASH(6) = h == 0 ? g_sg * (1.f - expf(-y_sg)) : 0.f;
 
-        float Tv[GS], Gv[GS];
-        f32x16 acc2[NTH];
-        uint32_t bh[WH];
-        // ---- static_rgb^T: 3+C gradients in compact slots -> d g, masked by dir_encoding's ReLU ----
-        zero_init<NTH>(acc2);
-        mma_segment<NTH, KR>(ring, ring_lane, dr, acc2);
-#pragma unroll
-        for (int w = 0; w < WH; ++w) bh[w] = MASKW(MW_TRUNK + w);
-        mask_store<NTH, 0>(Gv, acc2, bh);
-        // ---- transient heads^T: 5 pre-activation gradients -> d t2, masked by transient_encoding.4's ReLU ----
-        zero_init<NTH>(acc2);
-        mma_segment<NTH, 3>(ring, ring_lane, dth, acc2);
-#pragma unroll
-        for (int w = 0; w < WH; ++w) bh[w] = MASKW(MW_TRUNK + 3 * WH + w);
-        mask_store<NTH, 0>(Tv, acc2, bh);
+        // Consumer-side masking (see field_common.h): every product reads its upstream gradient straight out of the
+        // producer's accumulators and applies that layer's ReLU mask on the way in; nothing is copied between layers.
+        auto load_bits = [&](uint32_t* b, int word0, int n) {
+            for (int w = 0; w < n; ++w) b[w] = MASKW(word0 + w);
+        };
+        uint32_t bh[WH], bt[WT];
+        f32x16 G2[NTH], T3[NTH], T4[NTH];
+        // ---- static_rgb^T: 3+C gradients in compact slots -> d(dir_encoding output) ----
+        mma_run<NTH, KR, 0, true>(ring, ring_lane, ArrayIn<KR>{dr}, ZeroInit{}, G2);
+        // ---- transient heads^T: 5 pre-activation gradients -> d(transient_encoding.4 output) ----
+        mma_run<NTH, 3, 0, true>(ring, ring_lane, ArrayIn<3>{dth}, ZeroInit{}, T3);
         // ---- transient_encoding.4^T, .2^T ----
-#pragma unroll 1
-        for (int tl = 2; tl >= 1; --tl) {
-            zero_init<NTH>(acc2);
-            mma_segment<NTH, GS>(ring, ring_lane, Tv, acc2);
-#pragma unroll
-            for (int w = 0; w < WH; ++w) bh[w] = MASKW(MW_TRUNK + tl * WH + w);
-            mask_store<NTH, 0>(Tv, acc2, bh);
-        }
-        float H[HS];
-        float dDv[16];
-        // One accumulator array for every full-width product: tiles [0,2) = d xyz-embedding (live from layer 5 down to
-        // layer 1), tiles [2, NTW+2) = the layer's d hidden.
-        f32x16 A[NTW + 2];
-        // ---- [transient_encoding.0 ; dir_encoding]^T -> d final (NTW tiles) + d dir-embedding (1 tile) ----
-        zero_init<NTW + 1, 0>(A);
-        mma_segment<NTW + 1, GS, 0>(ring, ring_lane, Tv, A);
-        mma_segment<NTW + 1, GS, 0>(ring, ring_lane, Gv, A);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) H[t * 16 + r] = A[t][r];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dDv[r] = A[NTW][r];
-        uint32_t bt[WT];
-        // ---- xyz_encoding_final^T + static_sigma^T (one extra k-step) -> d h8 ----
+        load_bits(bh, MW_TRUNK + 3 * WH, WH);
+        mma_run<NTH, GS, 0, true>(ring, ring_lane, MaskedIn<NTH, WH>{T3, bh}, ZeroInit{}, T4);
+        load_bits(bh, MW_TRUNK + 2 * WH, WH);
+        mma_run<NTH, GS, 0, true>(ring, ring_lane, MaskedIn<NTH, WH>{T4, bh}, ZeroInit{}, T3);
+        // Full-width accumulators, ping-pong.  Tiles [2, NTW+2) hold a layer's d hidden; XA tile 1 = d dir-embedding;
+        // XB tiles 0,1 = d xyz-embedding (written by layer 5, accumulated by layer 1).
+        f32x16 XA[NTW + 2], XB[NTW + 2];
+        // ---- [transient_encoding.0 ; dir_encoding]^T -> d dir-embedding (tile 1) + d final (tiles 2..) ----
+        load_bits(bh, MW_TRUNK + WH, WH);
+        mma_run<NTW + 1, GS, 1, true>(ring, ring_lane, MaskedIn<NTH, WH>{T3, bh}, ZeroInit{}, XA);
+        load_bits(bh, MW_TRUNK, WH);
+        mma_run<NTW + 1, GS, 1, false>(ring, ring_lane, MaskedIn<NTH, WH>{G2, bh}, ZeroInit{}, XA);
+        // ---- xyz_encoding_final^T (no ReLU on its output) + static_sigma^T (one extra k-step) -> d h8 ----
         {
             float dsg[1];
             dsg[0] = STASH(6);
-            zero_init<NTW, 2>(A);
-            mma_segment<NTW, HS, 2>(ring, ring_lane, H, A);
-            mma_segment<NTW, 1, 2>(ring, ring_lane, dsg, A);
+            mma_run<NTW, HS, 2, true>(ring, ring_lane, IdentIn<NTW + 2, 2>{XA}, ZeroInit{}, XB);
+            mma_run<NTW, 1, 2, false>(ring, ring_lane, ArrayIn<1>{dsg}, ZeroInit{}, XB);
         }
-#pragma unroll
-        for (int w = 0; w < WT; ++w) bt[w] = MASKW(7 * WT + w);
-        mask_store<NTW, 2>(H, A, bt);
-        // ---- xyz_encoding_8^T .. xyz_encoding_2^T; layer 5 also emits the skip's d embedding into tiles 0,1 ----
-#pragma unroll 1
-        for (int l = 8; l >= 2; --l) {
-            if (l == 5) {
-                zero_init<NTW + 2, 0>(A);
-                mma_segment<NTW + 2, HS, 0>(ring, ring_lane, H, A);
-            } else {
-                zero_init<NTW, 2>(A);
-                mma_segment<NTW, HS, 2>(ring, ring_lane, H, A);
-            }
-#pragma unroll
-            for (int w = 0; w < WT; ++w) bt[w] = MASKW((l - 2) * WT + w);
-            mask_store<NTW, 2>(H, A, bt);
-        }
+        // ---- xyz_encoding_8^T .. xyz_encoding_2^T, straight-line (XB -> XA -> XB ...): a runtime loop over the ping-pong
+        //      pair makes the register allocator shuffle and spill whole accumulator tiles at the back-edge.
+        //      Layer 5 also emits the skip's d xyz-embedding into XB tiles 0,1. ----
+#define NEFES_BWD_LAYER(L, SRC, DST, NTILES, T0)                                                            \
+        load_bits(bt, ((L) - 1) * WT, WT);                                                              \
+        mma_run<NTILES, HS, T0, true>(ring, ring_lane, MaskedIn<NTW + 2, WT, 2>{SRC, bt}, ZeroInit{}, DST);
+        NEFES_BWD_LAYER(8, XB, XA, NTW, 2)
+        NEFES_BWD_LAYER(7, XA, XB, NTW, 2)
+        NEFES_BWD_LAYER(6, XB, XA, NTW, 2)
+        NEFES_BWD_LAYER(5, XA, XB, NTW + 2, 0)
+        NEFES_BWD_LAYER(4, XB, XA, NTW, 2)
+        NEFES_BWD_LAYER(3, XA, XB, NTW, 2)
+        NEFES_BWD_LAYER(2, XB, XA, NTW, 2)
+#undef NEFES_BWD_LAYER
         // ---- xyz_encoding_1^T accumulates onto the skip's d embedding ----
-        mma_segment<2, HS, 0>(ring, ring_lane, H, A);
+        load_bits(bt, 0, WT);
+        mma_run<2, HS, 0, false>(ring, ring_lane, MaskedIn<NTW + 2, WT, 2>{XA, bt}, ZeroInit{}, XB);
+        float dDv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dDv[r] = XA[1][r];
 
         // ---- embedding backward (Embedder.embed :257-267) ----
         float dE[32];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dE[t * 16 + r] = A[t][r];
+            for (int r = 0; r < 16; ++r) dE[t * 16 + r] = XB[t][r];
         float x[3], gx[3], gv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { x[c] = STASH(c); v[c] = STASH(3 + c); }

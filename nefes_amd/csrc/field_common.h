@@ -22,17 +22,53 @@ __device__ __forceinline__ float sigmoid_ref(float x) { return 1.f / (1.f + expf
 
 // One 1 KiB LDS-DMA piece: every lane supplies its own 16-byte source address, the destination is
 // M0 (wave-uniform LDS byte address) + lane*16.  The asm statement saves/restores M0 (compiler-owned).
-__device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
+// Source address = wave-uniform 64-bit base (SGPR pair, advanced by scalar ALU) + a constant 32-bit per-lane offset:
+// the refill costs no vector ALU instruction (VALU ops are never hidden behind an fp32 MFMA of the same wave).
+__device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, uint32_t lds_dst) {
     uint32_t keep;
+#ifdef NEFES_DBG_OLD_DMA
+    const char* gsrc = (const char*)gbase + lane_off;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#else
+    // s_nop 4 first: the SGPR base may have just been written by a VALU instruction (v_readlane restoring a spilled
+    // SGPR, v_readfirstlane) and a VMEM instruction reading such an SGPR needs 5 wait states the compiler does not
+    // insert for inline asm.
     asm volatile(
+        "s_nop 4\n\t"
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
+        : "v"(lane_off), "s"(gbase), "s"(lds_dst)
         : "memory");
+#endif
+}
+// 1-instruction ReLU (fmaxf() costs a canonicalising v_max in front of the real one)
+__device__ __forceinline__ float relu1(float v) {
+#ifdef NEFES_DBG_OLD_RELU
+    return fmaxf(v, 0.f);
+#else
+    float r;
+    // trailing s_nop 1: the result usually feeds an MFMA as srcB straight away, and a VALU write -> MFMA operand read
+    // needs 2 wait states that the compiler does not pad for values defined inside inline asm (measured: without it
+    // the MFMA consumes the previous k-step's operand).
+    asm("v_max_f32 %0, 0, %1\n\ts_nop 1" : "=v"(r) : "v"(v));
+    return r;
+#endif
+}
+// ReLU-mask words are built by shifting: forward shifts (v > 0) in from the right (v_cmp + v_addc), backward shifts
+// the bits out from the left (v_add_co + v_cndmask).  Both walk a layer's activations in the same order, 32 per word,
+// so the first activation of a word travels to bit 31 and is the first to come back out.
+__device__ __forceinline__ void mask_shift_in(uint32_t& bits, float v) {
+    asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v) : "vcc");
+}
+__device__ __forceinline__ float mask_shift_out(uint32_t& bits, float v) {
+    float r;
+    asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %2, vcc\n\ts_nop 1" : "+v"(bits), "=v"(r) : "v"(v) : "vcc");
+    return r;
 }
 
 // Weight stream ring.  All four waves of the workgroup walk the same slab sequence; each wave moves
@@ -47,7 +83,8 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
 // loaded registers) before the first acquire(); everything else is LDS traffic or stores.
 template <int SLOTS>
 struct WeightRing {
-    const char* src;     // per-lane source: stream base + wave*1024 + lane*16
+    const char* src;     // stream base (wave-uniform)
+    uint32_t lane_off;   // wave*1024 + lane*16
     uint32_t lds_wave;   // ring base + wave*1024 (wave-uniform)
     uint32_t n_slabs;    // slabs in the stream (wraps)
     uint32_t g_next;     // next slab of the stream to issue
@@ -57,7 +94,8 @@ struct WeightRing {
     f32x4 pf;            // its first fragment group, prefetched
 
     __device__ __forceinline__ void init(const char* stream, uint32_t nslabs, uint32_t ring_lds_base, int wave, int lane) {
-        src = stream + wave * 1024 + lane * 16;
+        src = stream;
+        lane_off = (uint32_t)(wave * 1024 + lane * 16);
         lds_wave = ring_lds_base + wave * 1024;
         n_slabs = nslabs;
         g_next = 0; p_slot = 0; c_slot = 0;
@@ -68,7 +106,7 @@ struct WeightRing {
         const char* s = src + (size_t)g_next * NEFES_SLAB_BYTES;
         const uint32_t d = lds_wave + p_slot * NEFES_SLAB_BYTES;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) lds_dma16(s + q * 4096, d + q * 4096);
+        for (int q = 0; q < 4; ++q) lds_dma16(s + q * 4096, lane_off, d + q * 4096);
         g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
         p_slot = (p_slot + 1 == SLOTS) ? 0 : p_slot + 1;
     }
@@ -76,7 +114,7 @@ struct WeightRing {
     // pieces are issued one at a time behind MFMAs of the slab being consumed (mma_segment), never as a burst:
     // an LDS-DMA issue costs ~60 cycles of the wave's issue slot, which one 64-cycle MFMA in flight covers.
     __device__ __forceinline__ void issue_piece(int q) {
-        lds_dma16(src + (size_t)g_next * NEFES_SLAB_BYTES + q * 4096, lds_wave + p_slot * NEFES_SLAB_BYTES + q * 4096);
+        lds_dma16(src + (size_t)g_next * NEFES_SLAB_BYTES + q * 4096, lane_off, lds_wave + p_slot * NEFES_SLAB_BYTES + q * 4096);
         if (q == 3) {
             g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
             p_slot = (p_slot + 1 == SLOTS) ? 0 : p_slot + 1;
@@ -125,13 +163,69 @@ __device__ __forceinline__ void pin(T (&v)[N]) {
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
 }
 
-// acc[t] += W-block * in   for NT accumulator tiles over KS k-steps (fully unrolled; `in` and `acc`
-// are register arrays, every index below is a compile-time constant after unrolling).
-// ring_lane = LDS pointer of the ring base + lane*16.
-// The NT tiles are acc[T0 .. T0+NT) of a (possibly larger) accumulator array.
-template <int NT, int KS, int T0 = 0, int NACC, int SLOTS>
-__device__ __forceinline__ void mma_segment(WeightRing<SLOTS>& ring, const char* ring_lane, const float (&in)[KS],
-                                            f32x16 (&acc)[NACC]) {
+// ---- B-operand producers (one float per k-step and lane) and C-operand initialisers (one tile at a time) ----------
+// Consumer-side activation: a layer never materialises its activated output.  The NEXT layer's product reads the
+// producer's accumulators register by register (k-step s <-> accumulator tile s/16, register s%16), applies the
+// activation on the way in and, in the forward pass, records the 1-bit ReLU mask.  The two or three VALU ops per k-step
+// issue in the shadow of that k-step's NT MFMAs instead of as a serial epilogue between layers.
+template <int NX, int NW>
+struct ReluCapture {            // forward: relu(X) and mask bit s
+    const f32x16 (&X)[NX];
+    uint32_t (&bits)[NW];
+    __device__ __forceinline__ float operator()(int s) const {
+        const float v = X[s >> 4][s & 15];
+        mask_shift_in(bits[s >> 5], v);
+        return relu1(v);
+    }
+};
+template <int NX>
+struct ReluIn {                 // forward: relu(X), no mask
+    const f32x16 (&X)[NX];
+    __device__ __forceinline__ float operator()(int s) const { return relu1(X[s >> 4][s & 15]); }
+};
+template <int NX, int T0 = 0>
+struct IdentIn {                // X as is (tiles T0..)
+    const f32x16 (&X)[NX];
+    __device__ __forceinline__ float operator()(int s) const { return X[T0 + (s >> 4)][s & 15]; }
+};
+template <int NX, int NW, int T0 = 0>
+struct MaskedIn {               // backward: mask bit of activation s ? X : 0   (consumes the word by shifting)
+    const f32x16 (&X)[NX];
+    uint32_t (&bits)[NW];
+    __device__ __forceinline__ float operator()(int s) const { return mask_shift_out(bits[s >> 5], X[T0 + (s >> 4)][s & 15]); }
+};
+template <int N>
+struct ArrayIn {
+    const float (&v)[N];
+    __device__ __forceinline__ float operator()(int s) const { return v[s]; }
+};
+struct ZeroInit {               // C operand of the first k-step = 0
+    __device__ __forceinline__ f32x16 operator()(int) const {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        return z;
+    }
+};
+struct BiasInit {               // C operand of the first k-step = bias rows of tile t (natural order in LDS)
+    const char* p;              // bias block of the layer + 16*h bytes
+    __device__ __forceinline__ f32x16 operator()(int t) const {
+        f32x16 c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *(const f32x4*)(p + (t * 32 + 8 * q) * 4);
+            c[4 * q + 0] = b[0]; c[4 * q + 1] = b[1]; c[4 * q + 2] = b[2]; c[4 * q + 3] = b[3];
+        }
+        return c;
+    }
+};
+
+// acc[T0 .. T0+NT) (+)= W-block * in   over KS k-steps, fully unrolled: every register index below is a compile-time
+// constant after unrolling.  FIRST: the first k-step takes its C operand from init(t) (bias or zero) instead of acc,
+// so accumulators need no initialisation pass.  ring_lane = LDS pointer of the ring base + lane*16.
+template <int NT, int KS, int T0, bool FIRST, class InFn, class InitFn, int NACC, int SLOTS>
+__device__ __forceinline__ void mma_run(WeightRing<SLOTS>& ring, const char* ring_lane, const InFn& in, const InitFn& init,
+                                        f32x16 (&acc)[NACC]) {
     static_assert(T0 + NT <= NACC, "accumulator array too small");
     constexpr int SPS = NEFES_SLAB_FRAGS / NT;
     constexpr int NSLAB = (KS + SPS - 1) / SPS;
@@ -139,6 +233,12 @@ __device__ __forceinline__ void mma_segment(WeightRing<SLOTS>& ring, const char*
     // At the last group of a slab the next slab (of this or of the following segment: the stream is one sequence)
     // is acquired and its first group requested BEFORE the last 4 MFMAs issue, so the barrier and the LDS latency
     // sit in the shadow of the matrix pipe.  ring.pf / ring.cur_off carry that state between segments.
+    f32x16 c0, c1;              // C operands of the first k-step, fetched two tiles ahead
+    if (FIRST) {
+        c0 = init(0);
+        if (NT > 1) c1 = init(1);
+    }
+    float b = 0.f;
 #pragma unroll
     for (int sl = 0; sl < NSLAB; ++sl) {
         const char* p = ring_lane + ring.cur_off;
@@ -169,7 +269,14 @@ __device__ __forceinline__ void mma_segment(WeightRing<SLOTS>& ring, const char*
                     const int f = g * 4 + q;
                     if (f < nf) {
                         const int s = sl * SPS + f / NT, t = f % NT;
-                        acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], in[s], acc[T0 + t], 0, 0, 0);
+                        if (t == 0) b = in(s);
+                        if (FIRST && s == 0) {
+                            acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, c0, 0, 0, 0);
+                            c0 = c1;
+                            if (t + 2 < NT) c1 = init(t + 2);
+                        } else {
+                            acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, acc[T0 + t], 0, 0, 0);
+                        }
                     }
                     if (q == 0 && g != ng - 1) {
 #pragma unroll
@@ -186,6 +293,12 @@ __device__ __forceinline__ void mma_segment(WeightRing<SLOTS>& ring, const char*
         }
         ring.pf = a;
     }
+}
+// array-input, accumulate-into-acc form (callers initialise acc themselves)
+template <int NT, int KS, int T0 = 0, int NACC, int SLOTS>
+__device__ __forceinline__ void mma_segment(WeightRing<SLOTS>& ring, const char* ring_lane, const float (&in)[KS],
+                                            f32x16 (&acc)[NACC]) {
+    mma_run<NT, KS, T0, false>(ring, ring_lane, ArrayIn<KS>{in}, ZeroInit{}, acc);
 }
 
 // acc rows <- bias (natural row order in LDS).  bias_half = bias block + 16*h bytes.
@@ -224,14 +337,37 @@ __device__ __forceinline__ void act_store(float (&dst)[NOUT], const f32x16 (&acc
             dst[t * 16 + r] = fmaxf(v, floor_v);
         }
 }
-// backward: dst[16*t + r] = bit ? acc[T0 + t][r] : 0
+// backward: dst[s] = (mask bit of activation s) ? acc[T0 + s/16][s%16] : 0, words consumed in shift order (see mask_shift_in)
 template <int NT, int T0, int NACC, int NOUT>
 __device__ __forceinline__ void mask_store(float (&dst)[NOUT], const f32x16 (&acc)[NACC], const uint32_t (&bits)[(NT + 1) / 2]) {
+    uint32_t w[(NT + 1) / 2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int k = 0; k < (NT + 1) / 2; ++k) w[k] = bits[k];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            dst[t * 16 + r] = ((bits[t >> 1] >> ((t & 1) * 16 + r)) & 1u) ? acc[T0 + t][r] : 0.f;
+    for (int s = 0; s < NT * 16; ++s) dst[s] = mask_shift_out(w[s >> 5], acc[T0 + (s >> 4)][s & 15]);
+}
+
+// sin/cos of x*2^k for the frequency embedding.  x*2^k is exact in fp32 (the reference computes sin(x * 2^k)), so the
+// argument reduction can be done exactly in turns: t = x/(2 pi) in f64 (|error| < 1e-13 turns at |x*2^k| = 2048),
+// frac(t*2^k) by an exponent shift and a round; then a quadrant split and the classic fp32 minimax polynomials on
+// [-pi/4, pi/4] (abs error ~1e-7, like a 1-2 ulp libm).  ~26 instructions instead of the ~120 of ocml sincosf, which
+// carries a Payne-Hanek path.  VALU count matters: nothing overlaps with an fp32 MFMA of the same wave.
+__device__ __forceinline__ void sincos_turns(double t, int k, float& sn, float& cs) {
+#ifdef NEFES_DBG_OLD_SINCOS
+    sincosf((float)(t * 6.283185307179586) * (float)(1 << k), &sn, &cs);
+    return;
+#endif
+    const double tk = __builtin_ldexp(t, k);
+    const float r = (float)(tk - __builtin_rint(tk));          // [-0.5, 0.5] turns, exact difference
+    const float q = __builtin_rintf(r * 4.f);                  // quadrant -2..2
+    const float th = __builtin_fmaf(-0.25f, q, r) * 6.28318530717958647692f;   // [-pi/4, pi/4]
+    const float z = th * th;
+    const float ps = th + th * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+    const float pc = 1.f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+    const int qi = (int)q & 3;
+    const float s0 = (qi & 1) ? pc : ps, c0 = (qi & 1) ? ps : pc;
+    sn = (qi & 2) ? -s0 : s0;
+    cs = ((qi + 1) & 2) ? -c0 : c0;
 }
 
 // frequency embedding of a 3-vector into slot order (layout.h nefes_emb_slot); L frequencies.
@@ -239,12 +375,15 @@ __device__ __forceinline__ void mask_store(float (&dst)[NOUT], const f32x16 (&ac
 template <int L, int NS>
 __device__ __forceinline__ void embed_slots(float (&e)[NS], const float (&x)[3], int h) {
     static_assert(NS >= 3 * L + 2, "embedding vector too small");
+    double t[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) t[a] = (double)x[a] * 0.15915494309189533577;
 #pragma unroll
     for (int k = 0; k < L; ++k)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             float sn, cs;
-            sincosf(x[a] * (float)(1 << k), &sn, &cs);
+            sincos_turns(t[a], k, sn, cs);
             e[3 * k + a] = h ? cs : sn;
         }
     e[3 * L] = h ? x[1] : x[0];
@@ -257,13 +396,16 @@ __device__ __forceinline__ void embed_slots(float (&e)[NS], const float (&x)[3],
 template <int L, int NS>
 __device__ __forceinline__ void embed_slots_bwd(float (&gx)[3], const float (&g)[NS], const float (&x)[3], int h) {
     gx[0] = gx[1] = gx[2] = 0.f;
+    double t[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) t[a] = (double)x[a] * 0.15915494309189533577;
 #pragma unroll
     for (int k = 0; k < L; ++k)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             float sn, cs;
             const float f = (float)(1 << k);
-            sincosf(x[a] * f, &sn, &cs);
+            sincos_turns(t[a], k, sn, cs);
             gx[a] += g[3 * k + a] * (h ? -(f * sn) : (f * cs));
         }
     if (h) { gx[1] += g[3 * L]; } else { gx[0] += g[3 * L]; gx[2] += g[3 * L + 1]; }

@@ -79,107 +79,117 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
         embed_slots<NEFES_N_FREQ_XYZ>(E, x, h);
         float Dv[NEFES_D_STEPS];
         if (MODE != NEFES_FIELD_SIGMA) embed_slots<NEFES_N_FREQ_DIR>(Dv, v, h);
-        uint32_t* mask_out = (MODE == NEFES_FIELD_FULL && a.masks && valid)
-                                 ? a.masks + ((size_t)(m_raw >> 5) * MW) * 64 + lane
-                                 : nullptr;
-        // NOTE: m_raw>>5 == global 32-sample tile index (tile*4 + wave) because 128 | tile base.
-
-        float H[HS];
-        f32x16 acc[NTW];
-        uint32_t bits[(NTW + 1) / 2];
-        // ---- layer 1: 63 -> W ----
-        bias_init<NTW>(acc, bias_half);
-        mma_segment<NTW, NEFES_E_STEPS>(ring, ring_lane, E, acc);
-        act_store<NTW>(H, acc, 0.f, bits);
-        if (mask_out) {
-#pragma unroll
-            for (int w = 0; w < (NTW + 1) / 2; ++w) mask_out[w * 64] = bits[w];
-        }
-        // ---- layers 2..8, then (STATIC/FULL) xyz_encoding_final as "layer 9"; the static sigma head reads h8 ----
-        auto sigma_head = [&]() {
-            // static_sigma on h8 (nerfh_nff.py:485,555): one tile, row 0 = (half 0, register 0)
-            f32x16 sg[1];
-            bias_init<1>(sg, bias_half + B_SIG * 4);
-            mma_segment<1, HS>(ring, ring_lane, H, sg);
-            if (valid && h == 0) {
-                const int ch = (MODE == NEFES_FIELD_SIGMA) ? 0 : 3 + a.C;
-                a.raw_t[((size_t)ray * a.R + ch) * a.S + smp] = softplus_ref(sg[0][0]);
+        // ReLU masks are lane-private words of whole 32-sample tiles (the buffer is padded to whole tiles), so they are
+        // written unconditionally: no per-lane predicate on the store path.
+        // Mask words: wave-uniform tile base (SGPRs) + a uniform running word counter; the only per-lane part is `lane`.
+        // Words are emitted in layout order (layers 1..8, dir, transient 0,2,4).  Lane-private words of whole 32-sample
+        // tiles (the buffer is padded to whole tiles) => stored unconditionally, no per-lane predicate.
+        uint32_t* mask_tile = (MODE == NEFES_FIELD_FULL && a.masks)
+                                  ? a.masks + ((size_t)((long long)tile * 4 + wave) * MW) * 64
+                                  : nullptr;
+        int mask_word = 0;
+        constexpr int WT = (NTW + 1) / 2, WH = (NTH + 1) / 2;
+        auto put_masks = [&](const uint32_t* bits, int n) {
+            if (mask_tile) {
+                for (int w = 0; w < n; ++w) mask_tile[(mask_word + w) * 64 + lane] = bits[w];
+                mask_word += n;
             }
         };
-        constexpr int LEND = (MODE == NEFES_FIELD_SIGMA) ? 8 : 9;
+        // per-lane base of this sample's column in raw_t; channel c lives at + c*S.  Re-materialised (pinned) right before
+        // each group of stores so the compiler does not keep 25 precomputed 64-bit addresses alive across the MLP.
+        const size_t raw_off = (size_t)ray * a.R * a.S + smp;
+        auto raw_col = [&]() {
+            float* pcol = a.raw_t + raw_off;
+            asm volatile("" : "+v"(pcol));
+            return pcol;
+        };
+        auto bias_at = [&](int off_floats) { return BiasInit{bias_half + off_floats * 4}; };
+        const ArrayIn<NEFES_E_STEPS> in_E{E};
+        const ArrayIn<NEFES_D_STEPS> in_D{Dv};
+
+        // Ping-pong accumulators: a layer reads its input straight out of the other array (consumer-side ReLU).
+        f32x16 A[NTW], B[NTW];
+        uint32_t bits[WT];
+        auto clear_bits = [&]() {
+#pragma unroll
+            for (int w = 0; w < WT; ++w) bits[w] = 0u;
+        };
+        auto sigma_head = [&](const f32x16 (&X)[NTW]) {
+            // static_sigma on h8 = relu(X) (nerfh_nff.py:485,555): one tile, row 0 = (half 0, register 0)
+            f32x16 sg[1];
+            mma_run<1, HS, 0, true>(ring, ring_lane, ReluIn<NTW>{X}, bias_at(B_SIG), sg);
+            if (valid && h == 0) {
+                const int ch = (MODE == NEFES_FIELD_SIGMA) ? 0 : 3 + a.C;
+                raw_col()[(size_t)ch * a.S] = softplus_ref(sg[0][0]);
+            }
+        };
+        // ---- layer 1: 63 -> W (its bias rides on the first k-step as the C operand) ----
+        mma_run<NTW, NEFES_E_STEPS, 0, true>(ring, ring_lane, in_E, bias_at(0), A);
+        // ---- layers 2..8 (+ xyz_encoding_final as layer 9 in STATIC/FULL), two per iteration: A -> B -> A ----
 #pragma unroll 1
-        for (int l = 2; l <= LEND; ++l) {
-            if constexpr (MODE != NEFES_FIELD_SIGMA) {
-                if (l == 9) sigma_head();
+        for (int p = 0; p < 4; ++p) {
+            const int l1 = 2 + 2 * p, l2 = l1 + 1;
+            clear_bits();
+            mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluCapture<NTW, WT>{A, bits}, bias_at((l1 - 1) * W), B);
+            put_masks(bits, WT);                                      // mask of layer l1-1 (the producer of A)
+            if (p == 3) {
+                if (MODE == NEFES_FIELD_SIGMA) break;                 // layer 8 is the last; B holds its pre-activation
+                sigma_head(B);
             }
-            const int boff = (l <= 8) ? (l - 1) * W : B_FINAL;
-            bias_init<NTW>(acc, bias_half + boff * 4);
-            if (l == 5) mma_segment<NTW, NEFES_E_STEPS>(ring, ring_lane, E, acc);   // skip: cat[xyz, h] (:551-552)
-            mma_segment<NTW, HS>(ring, ring_lane, H, acc);
-            act_store<NTW>(H, acc, l == 9 ? -__builtin_inff() : 0.f, bits);
-            if (mask_out && l <= 8) {
-#pragma unroll
-                for (int w = 0; w < (NTW + 1) / 2; ++w) mask_out[((l - 1) * ((NTW + 1) / 2) + w) * 64] = bits[w];
-            }
+            clear_bits();
+            mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluCapture<NTW, WT>{B, bits},
+                                      bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);
+            if (p == 1) mma_run<NTW, NEFES_E_STEPS, 0, false>(ring, ring_lane, in_E, ZeroInit{}, A);   // skip: + W5[:, :63] e
+            put_masks(bits, WT);                                      // mask of layer l1 (the producer of B)
         }
-        if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head();
-        if (MODE != NEFES_FIELD_SIGMA) {
-            // H now holds xyz_encoding_final (no activation, :559)
-            float G[GS];
-            f32x16 acc2[NTH];
-            uint32_t bits2[(NTH + 1) / 2];
-            constexpr int MW_TRUNK = 8 * ((NTW + 1) / 2);
-            // ---- dir_encoding: cat[final, dir-emb] -> W/2, ReLU ----
-            bias_init<NTH>(acc2, bias_half + B_DIR * 4);
-            mma_segment<NTH, HS>(ring, ring_lane, H, acc2);
-            mma_segment<NTH, NEFES_D_STEPS>(ring, ring_lane, Dv, acc2);
-            act_store<NTH>(G, acc2, 0.f, bits2);
-            if (mask_out) {
+        if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head(B);
+        if constexpr (MODE != NEFES_FIELD_SIGMA) {
+            // A holds xyz_encoding_final (no activation, :559)
+            f32x16 acc2[NTH], acc3[NTH];
+            uint32_t bits2[WH];
+            auto clear2 = [&]() {
 #pragma unroll
-                for (int w = 0; w < (NTH + 1) / 2; ++w) mask_out[(MW_TRUNK + w) * 64] = bits2[w];
-            }
-            // ---- static_rgb: W/2 -> 3+C, no activation (:487-490) ----
+                for (int w = 0; w < WH; ++w) bits2[w] = 0u;
+            };
+            // ---- dir_encoding: cat[final, dir-emb] -> W/2 ----
+            mma_run<NTH, HS, 0, true>(ring, ring_lane, IdentIn<NTW>{A}, bias_at(B_DIR), acc2);
+            mma_run<NTH, NEFES_D_STEPS, 0, false>(ring, ring_lane, in_D, ZeroInit{}, acc2);
+            // ---- static_rgb on relu(dir): W/2 -> 3+C, no activation (:487-490) ----
             {
                 f32x16 ar[NTR];
-                bias_init<NTR>(ar, bias_half + B_RGB * 4);
-                mma_segment<NTR, GS>(ring, ring_lane, G, ar);
+                clear2();
+                mma_run<NTR, GS, 0, true>(ring, ring_lane, ReluCapture<NTH, WH>{acc2, bits2}, bias_at(B_RGB), ar);
+                put_masks(bits2, WH);                                 // dir_encoding
                 if (valid) {
+                    // channel of (tile t, register r, half h) = 32t + rho(0,r) + 4h: per-lane part folded into the base,
+                    // the rest is a wave-uniform offset
+                    float* ph = raw_col() + (size_t)(4 * h) * a.S;
 #pragma unroll
                     for (int t = 0; t < NTR; ++t)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int ch = 32 * t + nefes_rho(h, r);
-                            if (ch < 3 + a.C) a.raw_t[((size_t)ray * a.R + ch) * a.S + smp] = ar[t][r];
+                            const int cu = 32 * t + nefes_rho(0, r);
+                            if (cu + 4 * h < 3 + a.C) ph[(size_t)cu * a.S] = ar[t][r];
                         }
                 }
             }
-            if (MODE == NEFES_FIELD_FULL) {
+            if constexpr (MODE == NEFES_FIELD_FULL) {
                 // ---- transient_encoding.{0,2,4} ----
-                bias_init<NTH>(acc2, bias_half + B_T0 * 4);
-                mma_segment<NTH, HS>(ring, ring_lane, H, acc2);
-                mma_segment<NTH, NEFES_D_STEPS>(ring, ring_lane, Dv, acc2);
-                act_store<NTH>(G, acc2, 0.f, bits2);
-                if (mask_out) {
-#pragma unroll
-                    for (int w = 0; w < (NTH + 1) / 2; ++w) mask_out[(MW_TRUNK + (NTH + 1) / 2 + w) * 64] = bits2[w];
-                }
-#pragma unroll 1
-                for (int tl = 1; tl <= 2; ++tl) {
-                    bias_init<NTH>(acc2, bias_half + (tl == 1 ? B_T1 : B_T2) * 4);
-                    mma_segment<NTH, GS>(ring, ring_lane, G, acc2);
-                    act_store<NTH>(G, acc2, 0.f, bits2);
-                    if (mask_out) {
-#pragma unroll
-                        for (int w = 0; w < (NTH + 1) / 2; ++w)
-                            mask_out[(MW_TRUNK + (1 + tl) * ((NTH + 1) / 2) + w) * 64] = bits2[w];
-                    }
-                }
+                mma_run<NTH, HS, 0, true>(ring, ring_lane, IdentIn<NTW>{A}, bias_at(B_T0), acc2);
+                mma_run<NTH, NEFES_D_STEPS, 0, false>(ring, ring_lane, in_D, ZeroInit{}, acc2);
+                clear2();
+                mma_run<NTH, GS, 0, true>(ring, ring_lane, ReluCapture<NTH, WH>{acc2, bits2}, bias_at(B_T1), acc3);
+                put_masks(bits2, WH);                                 // transient_encoding.0
+                clear2();
+                mma_run<NTH, GS, 0, true>(ring, ring_lane, ReluCapture<NTH, WH>{acc3, bits2}, bias_at(B_T2), acc2);
+                put_masks(bits2, WH);                                 // transient_encoding.2
                 // ---- transient heads: rows 0..2 rgb (sigmoid), 3 sigma (softplus), 4 beta (softplus) ----
                 f32x16 th[1];
-                bias_init<1>(th, bias_half + B_TH * 4);
-                mma_segment<1, GS>(ring, ring_lane, G, th);
+                clear2();
+                mma_run<1, GS, 0, true>(ring, ring_lane, ReluCapture<NTH, WH>{acc2, bits2}, bias_at(B_TH), th);
+                put_masks(bits2, WH);                                 // transient_encoding.4
                 if (valid) {
-                    float* o = a.raw_t + ((size_t)ray * a.R + 3 + a.C + 1) * a.S + smp;
+                    float* o = raw_col() + (size_t)(3 + a.C + 1) * a.S;
                     if (h == 0) {
                         o[0] = sigmoid_ref(th[0][0]);
                         o[(size_t)a.S] = sigmoid_ref(th[0][1]);

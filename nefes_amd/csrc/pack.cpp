@@ -109,8 +109,9 @@ void add_trunk(const Net& n, Stream& st) {
         if (l == 0) {
             st.segs.push_back(seg(NT, NEFES_E_STEPS, k_emb(10, NEFES_E_STEPS, 0), rows_natural(NT, W), n.w(0), 63));
         } else if (l == 4) {  // skip layer: columns [xyz(63), h(W)]  (nerfh_nff.py:472-473,551-552)
-            st.segs.push_back(seg(NT, NEFES_E_STEPS, k_emb(10, NEFES_E_STEPS, 0), rows_natural(NT, W), n.w(4), 63 + W));
+            // the kernels accumulate the hidden part first (its first k-step carries the bias), then the xyz part
             st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, 63), rows_natural(NT, W), n.w(4), 63 + W));
+            st.segs.push_back(seg(NT, NEFES_E_STEPS, k_emb(10, NEFES_E_STEPS, 0), rows_natural(NT, W), n.w(4), 63 + W));
         } else {
             st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, 0), rows_natural(NT, W), n.w(l), W));
         }
@@ -156,8 +157,8 @@ void add_backward(const Net& n, Stream& st) {
     st.segs.push_back(seg(NTH, 3, k_compact(3, 5), rows_natural(NTH, W2), n.th_w.data(), W2, true));
     st.segs.push_back(seg(NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(NTH, W2), n.w(L_T2), W2, true));
     st.segs.push_back(seg(NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(NTH, W2), n.w(L_T1), W2, true));
-    // [transient_encoding.0 ; dir_encoding]^T: out rows = final features (NTW tiles) + dir-embedding slots (1 tile)
-    std::vector<int> rows_fd = concat(rows_natural(NTW, W), rows_emb(4, 1, W));
+    // [transient_encoding.0 ; dir_encoding]^T: out rows = dir-embedding slots (1 tile) then final features (NTW tiles)
+    std::vector<int> rows_fd = concat(rows_emb(4, 1, W), rows_natural(NTW, W));
     st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_T0), W + 27, true));
     st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_DIR), W + 27, true));
     // xyz_encoding_final^T, plus the static-sigma head as one extra k-step

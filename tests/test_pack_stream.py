@@ -154,9 +154,9 @@ def emulate_forward(info, blob, Wd, Cf, e63, e27, mode):
         if mode != 0 and l == 9:
             sigma_head()
         acc = biases[l - 2].copy() if l <= 8 else b_final.copy()
-        if l == 5:
-            st.mma(NTW, E, acc)
         st.mma(NTW, H, acc)
+        if l == 5:
+            st.mma(NTW, E, acc)           # skip layer: hidden part first, then the xyz-embedding part
         if l <= 8:
             masks[f"L{l}"] = acc > 0
             acc = np.maximum(acc, 0)
@@ -223,8 +223,8 @@ def emulate_backward(info, blob, Wd, Cf, masks, d_pre):
     a9 = Z(NTW + 1)
     st.mma(NTW + 1, Tv, a9)
     st.mma(NTW + 1, Gv, a9)
-    H = acc_to_vec(a9, 0, NTW)
-    dD = acc_to_vec(a9, NTW, 1)
+    dD = acc_to_vec(a9, 0, 1)             # tile 0 = d dir-embedding, tiles 1.. = d final
+    H = acc_to_vec(a9, 1, NTW)
     acc = Z(NTW)
     st.mma(NTW, H, acc)
     st.mma(NTW, compact([d_pre["sigma"]], 1), acc)
