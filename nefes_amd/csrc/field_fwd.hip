@@ -130,15 +130,22 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
         for (int p = 0; p < 4; ++p) {
             const int l1 = 2 + 2 * p, l2 = l1 + 1;
             clear_bits();
-            mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluCapture<NTW, WT>{A, bits}, bias_at((l1 - 1) * W), B);
+            // masks are recorded only when a backward pass can follow (FULL); the other modes save 2 VALU ops per k-step
+            if constexpr (MODE == NEFES_FIELD_FULL)
+                mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluCapture<NTW, WT>{A, bits}, bias_at((l1 - 1) * W), B);
+            else
+                mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluIn<NTW>{A}, bias_at((l1 - 1) * W), B);
             put_masks(bits, WT);                                      // mask of layer l1-1 (the producer of A)
             if (p == 3) {
                 if (MODE == NEFES_FIELD_SIGMA) break;                 // layer 8 is the last; B holds its pre-activation
                 sigma_head(B);
             }
             clear_bits();
-            mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluCapture<NTW, WT>{B, bits},
-                                      bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);
+            if constexpr (MODE == NEFES_FIELD_FULL)
+                mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluCapture<NTW, WT>{B, bits},
+                                          bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);
+            else
+                mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluIn<NTW>{B}, bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);
             if (p == 1) mma_run<NTW, NEFES_E_STEPS, 0, false>(ring, ring_lane, in_E, ZeroInit{}, A);   // skip: + W5[:, :63] e
             put_masks(bits, WT);                                      // mask of layer l1 (the producer of B)
         }

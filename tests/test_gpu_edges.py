@@ -1,0 +1,183 @@
+"""GPU edge cases and the rest of the reference's call surface (run with -m gpu):
+single ray, ragged tiles, unsupported sizes, train-mode forward extras, white background, explicit `rays=`,
+NDC, stratified jitter, the drop-in `raw2outputs_NeRFH_NFF` / `sample_pdf` / `render_path` / `create_nerf`
+entry points, and re-packing after a weight update."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), (b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(b).double())
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def dropin():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = os.path.join(root, "nefes_amd", "dropin")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import models.rendering as R
+    import models.nerfh_nff as M
+    import models.ray_utils as RU
+    return R, M, RU
+
+
+def nets(Wd=128, C=128):
+    from nefes_amd.field import NeRFH_NFF
+    coarse = NeRFH_NFF('coarse', W=Wd, f_dim=C).requires_grad_(False).to(DEV)
+    fine = NeRFH_NFF('fine', W=Wd, f_dim=C, encode_appearance=True, encode_transient=True).requires_grad_(False).to(DEV)
+    return coarse, fine
+
+
+def kwargs(coarse, fine, Ni=64, test_time=True, tat=True, perturb=0., white=False, Nc=64):
+    args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=tat, netchunk=1 << 21)
+    return dict(network_query_fn=None, perturb=perturb, N_importance=Ni, N_samples=Nc, network_fn=coarse, network_fine=fine,
+                use_viewdirs=True, white_bkgd=white, raw_noise_std=0., test_time=test_time, args=args, ndc=False, lindisp=False)
+
+
+def oracle_params(Wd=128, C=128):
+    return O.make_field_params("coarse", Wd, C), O.make_field_params("fine", Wd, C)
+
+
+def test_single_ray_and_ragged_tiles():
+    R, M, RU = dropin()
+    coarse, fine = nets()
+    pc, pf = oracle_params()
+    for H, W in [(1, 1), (1, 3), (3, 5)]:          # 1, 3, 15 rays: every tile is partial
+        c2w = O.bench_pose().to(DEV).requires_grad_()
+        rgb, disp, acc, ex = R.render(H, W, 2.5, c2w=c2w, near=0., far=4., **kwargs(coarse, fine))
+        c_ref = O.bench_pose().requires_grad_()
+        r_rgb, r_disp, r_acc, r_ex = O.render(H, W, 2.5, pc, pf, O.RenderCfg(N_samples=64, N_importance=64), c2w=c_ref, near=0., far=4.)
+        assert rgb.shape == (H * W, 3) and ex["feat_map"].shape == (H * W, 128)
+        assert rel(rgb, r_rgb) < 1e-4 and rel(ex["feat_map"], r_ex["feat_map"]) < 1e-4 and rel(disp, r_disp) < 1e-4
+        O.bench_loss(rgb, ex["feat_map"]).backward()
+        O.bench_loss(r_rgb, r_ex["feat_map"]).backward()
+        assert rel(c2w.grad, c_ref.grad) < 2e-3
+
+
+def test_unsupported_sizes_fail_loudly():
+    from nefes_amd import ops, lib as L
+    with pytest.raises(RuntimeError, match="unsupported"):
+        ops.composite_fwd(torch.zeros(2, 1, 300, device=DEV), torch.zeros(2, 300, device=DEV), 0, L.COMP_SIGMA_ONLY)
+    from nefes_amd.field import NeRFH_NFF
+    odd = NeRFH_NFF('coarse', W=64, f_dim=16).requires_grad_(False).to(DEV)
+    with pytest.raises(RuntimeError, match="unsupported NeRFH_NFF configuration"):
+        odd.packed()
+    with pytest.raises(RuntimeError, match="bad argument"):
+        ops.sample_pdf_merge(torch.zeros(2, 2, device=DEV), torch.zeros(2, 2, device=DEV), 4)     # Nc < 3
+
+
+def test_train_mode_forward_extras_and_white_background():
+    """test_time=False (frozen weights, no jitter): coarse net runs its full static head (variant C) and render() returns
+    the training extras (rendering.py:160-173)."""
+    R, M, RU = dropin()
+    coarse, fine = nets(256, 16)
+    pc, pf = oracle_params(256, 16)
+    H, W = 3, 4
+    for white in (False, True):
+        with torch.no_grad():
+            rgb, disp, acc, ex = R.render(H, W, 3.0, c2w=O.bench_pose().to(DEV), near=0., far=4.,
+                                          **kwargs(coarse, fine, Ni=128, test_time=False, tat=False, white=white))
+        cfg = O.RenderCfg(N_samples=64, N_importance=128, test_time=False, transient_at_test=False, white_bkgd=white)
+        r_rgb, r_disp, r_acc, r_ex = O.render(H, W, 3.0, pc, pf, cfg, c2w=O.bench_pose(), near=0., far=4.)
+        assert set(ex) == set(r_ex) == {"feat_map", "rgb0", "disp0", "acc0", "z_std", "transient_sigmas", "beta", "feat0"}
+        assert rel(rgb, r_rgb) < 1e-4 and rel(disp, r_disp) < 1e-4 and rel(acc, r_acc) < 1e-4
+        for k in r_ex:
+            assert rel(ex[k], r_ex[k]) < 1e-4, k
+
+
+def test_explicit_rays_and_ndc():
+    R, M, RU = dropin()
+    coarse, fine = nets()
+    pc, pf = oracle_params()
+    H, W, f = 4, 5, 4.0
+    o_ref, d_ref = O.ray_bundle(H, W, f, O.bench_pose())
+    o_ref = (o_ref.reshape(-1, 3) + torch.tensor([0., 0., 3.])).clone()          # keep z away from the NDC singularity
+    d_ref = d_ref.reshape(-1, 3).clone()
+    for ndc in (False, True):
+        oh, dh = o_ref.to(DEV).requires_grad_(), d_ref.to(DEV).requires_grad_()
+        kw = kwargs(coarse, fine)
+        kw["ndc"] = ndc
+        rgb, disp, acc, ex = R.render(H, W, f, rays=(oh, dh), near=0., far=1. if ndc else 4., **kw)
+        oc, dc = o_ref.clone().requires_grad_(), d_ref.clone().requires_grad_()
+        r_rgb, _, _, r_ex = O.render(H, W, f, pc, pf, O.RenderCfg(N_samples=64, N_importance=64), rays=(oc, dc), ndc=ndc,
+                                     near=0., far=1. if ndc else 4.)
+        assert rel(rgb, r_rgb) < 1e-4 and rel(ex["feat_map"], r_ex["feat_map"]) < 1e-4
+        O.bench_loss(rgb, ex["feat_map"]).backward()
+        O.bench_loss(r_rgb, r_ex["feat_map"]).backward()
+        assert rel(oh.grad, oc.grad) < 5e-3 and rel(dh.grad, dc.grad) < 5e-3
+
+
+def test_stratified_jitter_path_runs_and_is_sorted():
+    from nefes_amd import ops
+    R, M, RU = dropin()
+    coarse, fine = nets()
+    torch.manual_seed(0)
+    rgb, disp, acc, ex = R.render(4, 4, 3.0, c2w=O.bench_pose().to(DEV), near=0., far=4., **kwargs(coarse, fine, perturb=1.))
+    assert torch.isfinite(rgb).all() and torch.isfinite(ex["feat_map"]).all()
+    z = ops.coarse_depths(16, 64, 0., 4., False, torch.rand(16, 64, device=DEV))
+    assert (z[:, 1:] >= z[:, :-1]).all() and z.min() >= 0 and z.max() <= 4
+
+
+def test_dropin_raw2outputs_sample_pdf_render_path(golden):
+    R, M, RU = dropin()
+    g = golden("composite")
+    C = g["g_feat"].shape[1]
+    raw, z = T(g["raw"]).to(DEV), T(g["z"]).to(DEV)
+    rgb, feat, disp, acc, w, depth, t_sig, beta = M.raw2outputs_NeRFH_NFF(raw, z, output_transient=True, test_time=True,
+                                                                          typ="fine", transient_at_test=True)
+    np.testing.assert_allclose(rgb.cpu().numpy(), g["A.rgb"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(w.cpu().numpy(), g["A.weights"], rtol=1e-5, atol=1e-7)
+    assert torch.equal(t_sig, raw[..., 3 + C + 4])
+    out = M.raw2outputs_NeRFH_NFF(raw[..., 3 + C:3 + C + 1], z, test_time=True, typ="coarse")
+    assert out[0] is None and out[2] is None
+    np.testing.assert_allclose(out[4].cpu().numpy(), g["D.weights"], rtol=1e-5, atol=1e-7)
+    gs = golden("sample_pdf")
+    zc, wts = T(gs["det128.z"]).to(DEV), T(gs["w"]).to(DEV)
+    s = R.sample_pdf(.5 * (zc[..., 1:] + zc[..., :-1]), wts[..., 1:-1].contiguous(), 128, det=True)
+    np.testing.assert_allclose(s.cpu().numpy()[:, 1:-1], gs["det128.samples"][:, 1:-1], rtol=0, atol=2e-5)
+    coarse, fine = nets()
+    poses = torch.stack([O.bench_pose(), O.bench_pose()]).to(DEV)
+    rgbs, disps = R.render_path(None, poses, (4, 6, 3.0), 32768, dict(kwargs(coarse, fine), near=0., far=4.),
+                                gt_imgs=np.zeros((2, 4, 6, 3), np.float32))
+    assert rgbs.shape == (2, 4, 6, 3) and disps.shape == (2, 4, 6) and np.array_equal(rgbs[0], rgbs[1])
+
+
+def test_create_nerf_checkpoint_roundtrip_and_repack(tmp_path):
+    R, M, RU = dropin()
+    args = types.SimpleNamespace(multires=10, multires_views=4, i_embed=0, reduce_embedding=-1, use_viewdirs=True, netdepth=8,
+                                 netwidth=128, N_importance=64, N_samples=64, netchunk=1 << 21, no_grad_update=True,
+                                 basedir=str(tmp_path), expname="exp", ft_path=None, no_reload=False, perturb=1.,
+                                 white_bkgd=False, raw_noise_std=0., dataset_type="7Scenes", no_ndc=True, lindisp=False,
+                                 nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True, lrate=5e-4)
+    os.makedirs(tmp_path / "exp")
+    train_kw, test_kw, start, grad_vars, opt = M.create_nerf(args)
+    assert start == 0 and grad_vars is None and test_kw["test_time"] is True and test_kw["perturb"] is False
+    for net in (test_kw["network_fn"], test_kw["network_fine"]):
+        net.requires_grad_(False)
+    c2w = O.bench_pose().to(DEV)
+    rgb0, _, _, _ = R.render(3, 3, 2.0, c2w=c2w, near=0., far=4., **test_kw)
+    # perturb the fine net, save a reference-format checkpoint, reload through create_nerf
+    with torch.no_grad():
+        test_kw["network_fine"].static_rgb[0].bias.add_(0.25)
+    rgb1, _, _, _ = R.render(3, 3, 2.0, c2w=c2w, near=0., far=4., **test_kw)            # same modules, in-place update
+    assert (rgb1 - rgb0).abs().max() > 0.05                                             # the packed weights were refreshed
+    torch.save({"global_step": 7, "network_fn_state_dict": test_kw["network_fn"].state_dict(),
+                "network_fine_state_dict": test_kw["network_fine"].state_dict()}, tmp_path / "exp" / "000007.tar")
+    _, test_kw2, start2, _, _ = M.create_nerf(args)
+    assert start2 == 7
+    for net in (test_kw2["network_fn"], test_kw2["network_fine"]):
+        net.requires_grad_(False)
+    rgb2, _, _, _ = R.render(3, 3, 2.0, c2w=c2w, near=0., far=4., **test_kw2)
+    assert torch.equal(rgb1, rgb2)
