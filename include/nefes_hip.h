@@ -137,6 +137,25 @@ int nefes_sample_pdf_merge(int N, int Nc, int Ni, int layout, const float* z_coa
                            const float* u, int u_per_ray, const float* cdf_in, float* z_fine, float* z_samples,
                            int32_t* inds, float* cdf_out, void* stream);
 
+/* ---- multiresolution hash-grid encoding (script/models/nerfh_tcnn.py:60-75,151-156; tiny-cuda-nn semantics) ---- */
+/* PARITY UNPINNED: the reference delegates this to tiny-cuda-nn (not vendored, not version-pinned) and its own model
+ * using it is orphaned; checked only against oracle/hashgrid_ref.py's restatement of the published algorithm. */
+typedef struct NefesHashGridDesc {
+    int32_t n_levels;          /* 16 */
+    int32_t n_features;        /* 2 (only value built) */
+    int32_t log2_hashmap_size; /* 19 */
+    int32_t base_resolution;   /* 16 */
+    float per_level_scale;     /* exp(ln(2048/16)/15) */
+    float bound;               /* scene bound: x01 = (x+bound)/(2 bound) */
+} NefesHashGridDesc;
+size_t nefes_hashgrid_table_entries(const NefesHashGridDesc* desc);   /* entries of n_features floats; 0 = unsupported */
+/* x [M,3] -> enc [M, n_levels*n_features]; table: dev fp32 [entries][n_features]. */
+int nefes_hashgrid_fwd(const NefesHashGridDesc* desc, const float* table, int64_t M, const float* x, float* enc,
+                       void* stream);
+/* backward to the positions (frozen table): g_x [M,3]. */
+int nefes_hashgrid_bwd_x(const NefesHashGridDesc* desc, const float* table, int64_t M, const float* x, const float* g_enc,
+                         float* g_x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

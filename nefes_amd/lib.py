@@ -26,6 +26,11 @@ class NefesBlobInfo(C.Structure):
     _fields_ = [("total_bytes", C.c_uint64), ("stream", NefesStreamInfo * 4)]
 
 
+class NefesHashGridDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("n_features", C.c_int32), ("log2_hashmap_size", C.c_int32),
+                ("base_resolution", C.c_int32), ("per_level_scale", C.c_float), ("bound", C.c_float)]
+
+
 STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL = 0, 1, 2, 3
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
 COMP_TRANSIENT, COMP_STATIC_ONLY, COMP_SIGMA_ONLY, COMP_WHITE_BKGD = 1, 2, 4, 8
@@ -50,6 +55,9 @@ SIGNATURES = {
     "nefes_ray_grad_reduce": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_composite_fwd": (_i, [_i, _i, _i, _u32, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_composite_bwd": (_i, [_i, _i, _i, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_hashgrid_table_entries": (_sz, [C.POINTER(NefesHashGridDesc)]),
+    "nefes_hashgrid_fwd": (_i, [C.POINTER(NefesHashGridDesc), _p, C.c_int64, _p, _p, _p]),
+    "nefes_hashgrid_bwd_x": (_i, [C.POINTER(NefesHashGridDesc), _p, C.c_int64, _p, _p, _p, _p]),
     "nefes_sample_pdf_merge": (_i, [_i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
 }
 

@@ -346,3 +346,53 @@ def sample_pdf_merge(z_coarse, weights, Ni, u=None, cdf=None, want_debug=False, 
     if want_debug:
         return z_fine, z_samples, inds, cdf_out
     return z_fine, z_samples
+
+
+# ---------------------------------------------------------------------------------------------
+# hash-grid encoding (BASELINE config 4; parity unpinned, see oracle/hashgrid_ref.py)
+# ---------------------------------------------------------------------------------------------
+class HashGrid:
+    """Table + geometry of a tiny-cuda-nn style multiresolution hash grid (nerfh_tcnn.py:60-75)."""
+
+    def __init__(self, bound, table=None, n_levels=16, log2_hashmap_size=19, base_resolution=16, max_resolution=2048,
+                 device="cuda"):
+        import math
+        self.desc = L.NefesHashGridDesc(n_levels, 2, log2_hashmap_size, base_resolution,
+                                        math.exp(math.log(max_resolution / base_resolution) / (n_levels - 1)), float(bound))
+        self.n_out = 2 * n_levels
+        n = L.load().nefes_hashgrid_table_entries(self.desc)
+        if n == 0:
+            raise RuntimeError("nefes_amd: unsupported hash-grid configuration")
+        if table is None:
+            g = torch.Generator().manual_seed(0)
+            table = (torch.rand(n, 2, generator=g) * 2 - 1) * 1e-4
+        if tuple(table.shape) != (n, 2):
+            raise RuntimeError(f"nefes_amd: hash-grid table must be [{n}, 2]")
+        self.table = table.to(device, torch.float32).contiguous()
+
+    def __call__(self, x):
+        return HashGridEncode.apply(x, self)
+
+
+class HashGridEncode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, grid):
+        shape = x.shape
+        xf = _f32(x).reshape(-1, 3)
+        enc = torch.empty(xf.shape[0], grid.n_out, device=xf.device)
+        with _timed("hashgrid_fwd"):
+            L.check(L.load().nefes_hashgrid_fwd(grid.desc, _chk(grid.table, "table"), xf.shape[0], _chk(xf, "x"),
+                                                _chk(enc, "enc"), _stream()), "nefes_hashgrid_fwd")
+        ctx.save_for_backward(xf)
+        ctx.grid, ctx.shape = grid, shape
+        return enc.reshape(*shape[:-1], grid.n_out)
+
+    @staticmethod
+    def backward(ctx, g_enc):
+        (xf,) = ctx.saved_tensors
+        g = _f32(g_enc).reshape(-1, ctx.grid.n_out)
+        g_x = torch.empty_like(xf)
+        with _timed("hashgrid_bwd_x"):
+            L.check(L.load().nefes_hashgrid_bwd_x(ctx.grid.desc, _chk(ctx.grid.table, "table"), xf.shape[0], _chk(xf, "x"),
+                                                  _chk(g, "g_enc"), _chk(g_x, "g_x"), _stream()), "nefes_hashgrid_bwd_x")
+        return g_x.reshape(ctx.shape), None
