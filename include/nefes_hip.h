@@ -38,8 +38,11 @@ typedef struct NefesNetDesc {
     int32_t width;         /* Wd: 128 or 256 */
     int32_t feat_dim;      /* C: f_dim (16 or 128 compiled; 3+C <= 160) */
     int32_t has_transient; /* 1 for the 'fine' net (encode_transient), 0 for 'coarse' */
-    int32_t reserved;
+    int32_t xyz_encoding;  /* NEFES_XYZ_FREQ10: 63 frequency features computed in-kernel from the sample position;
+                            * NEFES_XYZ_EXTERNAL32: 32 features supplied per sample (xyz_enc), e.g. nefes_hashgrid_fwd */
 } NefesNetDesc;
+#define NEFES_XYZ_FREQ10 0
+#define NEFES_XYZ_EXTERNAL32 1
 
 /* where each weight stream lives inside a packed blob (all offsets in bytes from the blob start) */
 typedef struct NefesStreamInfo {
@@ -100,17 +103,20 @@ int nefes_coarse_depths(int N, int Nc, float near, float far, int lindisp, const
 
 /* ---- field MLP (nerfh_nff.py:168-231 run_network + :234-270 Embedder + :525-576 forward) ------- */
 /* Either (rays_o, rays_d, z) are given and pts = o + d*z is formed in-kernel (rendering.py:114,142),
- * or pts[M,3] is given (run_network call surface).  viewdirs [N,3] is ignored in SIGMA mode.
+ * or pts[M,3] is given (run_network call surface), or (NEFES_XYZ_EXTERNAL32) xyz_enc[M,32] is given.
+ * viewdirs [N,3] is ignored in SIGMA mode.
  * raw_t: dev [N][R][S].  masks: dev uint32 [ceil(M/32)][mask_words][64] or NULL (FULL mode only;
  * needed by nefes_field_bwd).  packed: dev blob from nefes_pack_weights. */
 size_t nefes_field_mask_bytes(const NefesNetDesc* desc, int64_t M);
 int nefes_field_fwd(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
-                    const float* rays_d, const float* z, const float* pts, const float* viewdirs, float* raw_t,
-                    uint32_t* masks, void* stream);
-/* backward to the inputs (frozen weights, no dW): g_pts [M,3], g_viewdirs_s [M,3] (per sample). */
+                    const float* rays_d, const float* z, const float* pts, const float* xyz_enc, const float* viewdirs,
+                    float* raw_t, uint32_t* masks, void* stream);
+/* backward to the inputs (frozen weights, no dW): g_pts [M,3] (NEFES_XYZ_FREQ10) or g_xyz_enc [M,32]
+ * (NEFES_XYZ_EXTERNAL32; positions are then not needed), and g_viewdirs_s [M,3] (per sample). */
 int nefes_field_bwd(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
                     const float* rays_d, const float* z, const float* pts, const float* viewdirs, const float* raw_t,
-                    const float* g_raw_t, const uint32_t* masks, float* g_pts, float* g_viewdirs_s, void* stream);
+                    const float* g_raw_t, const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s,
+                    void* stream);
 /* per-ray reduction of the above: g_o = sum_s g_pts, g_d = sum_s z*g_pts, g_v = sum_s g_viewdirs_s. */
 int nefes_ray_grad_reduce(int N, int S, const float* z, const float* g_pts, const float* g_viewdirs_s, float* g_rays_o,
                           float* g_rays_d, float* g_viewdirs, void* stream);

@@ -18,7 +18,8 @@ struct FieldBwdArgs {
     const float* raw_t;     // [N][R][S] forward output
     const float* g_raw_t;   // [N][R][S] upstream gradient
     const uint32_t* masks;  // [tiles32][MW][64]
-    float* g_pts;           // [M,3]
+    float* g_pts;           // [M,3] (NEFES_XYZ_FREQ10)
+    float* g_enc;           // [M,32] (NEFES_XYZ_EXTERNAL32)
     float* g_vs;            // [M,3] per-sample d viewdirs
     int N, S, R, C;
     long long M;
@@ -27,7 +28,7 @@ struct FieldBwdArgs {
 
 #define NEFES_BWD_SLOTS 6   // 96 KiB weight ring + the tile's ReLU masks staged in LDS (<= 40 KiB)
 
-template <int W, int C3>   // C3 = 3 + C
+template <int W, int C3, int ENC>   // C3 = 3 + C; ENC = NEFES_XYZ_*
 __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
@@ -59,8 +60,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         const size_t chan0 = (size_t)ray * a.R * a.S + smp;   // + ch*S
 
         // ================= all global loads of the tile, then ONE explicit completion point =================
-        float in_o[3], in_d[3] = {0.f, 0.f, 0.f}, in_z = 0.f, v[3];
-        if (a.pts) {
+        float in_o[3] = {0.f, 0.f, 0.f}, in_d[3] = {0.f, 0.f, 0.f}, in_z = 0.f, v[3];
+        if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+            // the gradient w.r.t. the supplied embedding does not depend on the sample position
+        } else if (a.pts) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) in_o[c] = a.pts[m * 3 + c];
         } else {
@@ -186,15 +189,27 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         for (int r = 0; r < 16; ++r) dDv[r] = XA[1][r];
 
         // ---- embedding backward (Embedder.embed :257-267) ----
-        float dE[32];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dE[t * 16 + r] = XB[t][r];
-        float x[3], gx[3], gv[3];
+        float x[3], gx[3] = {0.f, 0.f, 0.f}, gv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { x[c] = STASH(c); v[c] = STASH(3 + c); }
-        embed_slots_bwd<NEFES_N_FREQ_XYZ>(gx, dE, x, h);
+        if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+            // tile 0, compact slots (feature 2s+h; tile 1 is padding); copied out with constant indices before the stores
+            float ge[NEFES_X_STEPS];
+#pragma unroll
+            for (int s = 0; s < NEFES_X_STEPS; ++s) ge[s] = XB[0][s];
+            if (valid) {
+                float* gp = a.g_enc + m * 32 + h;
+#pragma unroll
+                for (int s = 0; s < NEFES_X_STEPS; ++s) gp[2 * s] = ge[s];
+            }
+        } else {
+            float dE[32];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dE[t * 16 + r] = XB[t][r];
+            embed_slots_bwd<NEFES_N_FREQ_XYZ>(gx, dE, x, h);
+        }
         embed_slots_bwd<NEFES_N_FREQ_DIR>(gv, dDv, v, h);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         if (valid && h == 0) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                a.g_pts[m * 3 + c] = gx[c];
+                if (ENC != NEFES_XYZ_EXTERNAL32) a.g_pts[m * 3 + c] = gx[c];
                 a.g_vs[m * 3 + c] = gv[c];
             }
         }
@@ -212,10 +227,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     ring.drain();
 }
 
-template <int W, int C3>
+template <int W, int C3, int ENC>
 static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_BWD_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (8 * (W / 64) + 4 * (W / 128) + 8) * 256;
-    auto k = field_bwd_kernel<W, C3>;
+    auto k = field_bwd_kernel<W, C3, ENC>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -230,10 +245,11 @@ static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
 extern "C" int nefes_field_bwd(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
                                const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
-                               float* g_viewdirs_s, void* stream) {
-    if (!desc || !packed || !viewdirs || !raw_t || !g_raw_t || !masks || !g_pts || !g_viewdirs_s || N <= 0 || S <= 0)
+                               float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
+    if (!desc || !packed || !viewdirs || !raw_t || !g_raw_t || !masks || !g_viewdirs_s || N <= 0 || S <= 0)
         return NEFES_E_BADARG;
-    if (!pts && !(rays_o && rays_d && z)) return NEFES_E_BADARG;
+    const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
+    if (ext ? !g_xyz_enc : (!g_pts || (!pts && !(rays_o && rays_d && z)))) return NEFES_E_BADARG;
     if (!desc->has_transient) return NEFES_E_UNSUPPORTED;
     NefesBlobInfo info;
     int rc = nefes_blob_info(desc, &info);
@@ -244,12 +260,13 @@ extern "C" int nefes_field_bwd(const NefesNetDesc* desc, const void* packed, int
     a.stream = (const char*)packed + si.slab_off;
     a.n_slabs = si.n_slabs;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.viewdirs = viewdirs;
-    a.raw_t = raw_t; a.g_raw_t = g_raw_t; a.masks = masks; a.g_pts = g_pts; a.g_vs = g_viewdirs_s;
+    a.raw_t = raw_t; a.g_raw_t = g_raw_t; a.masks = masks; a.g_pts = g_pts; a.g_enc = g_xyz_enc; a.g_vs = g_viewdirs_s;
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + 6;
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
-    if (desc->width == 256 && desc->feat_dim == 16) return launch_bwd<256, 19>(a, st);
-    if (desc->width == 128 && desc->feat_dim == 128) return launch_bwd<128, 131>(a, st);
+    if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10>(a, st);
+    if (desc->width == 128 && desc->feat_dim == 128 && !ext) return launch_bwd<128, 131, NEFES_XYZ_FREQ10>(a, st);
+    if (desc->width == 256 && desc->feat_dim == 16 && ext) return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32>(a, st);
     return NEFES_E_UNSUPPORTED;
 }

@@ -16,6 +16,7 @@ struct FieldFwdArgs {
     const float* rays_d;
     const float* z;          // [N,S]
     const float* pts;        // [M,3] or null
+    const float* xyz_enc;    // [M,32] (NEFES_XYZ_EXTERNAL32) or null
     const float* viewdirs;   // [N,3]
     float* raw_t;            // [N][R][S]
     uint32_t* masks;         // [tiles32][MW][64] or null
@@ -25,10 +26,12 @@ struct FieldFwdArgs {
 };
 
 // MODE: NEFES_FIELD_SIGMA / STATIC / FULL.  W: MLP width.  NTR: tiles of the rgb+feature head.
-template <int W, int NTR, int MODE>
+// ENC: NEFES_XYZ_FREQ10 (embedding computed here) / NEFES_XYZ_EXTERNAL32 (32 features per sample read from xyz_enc).
+template <int W, int NTR, int MODE, int ENC>
 __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;   // tiles / k-steps
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
+    constexpr int ES = ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : NEFES_E_STEPS;   // k-steps of the xyz embedding
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring_base = smem;
     float* bias_lds = (float*)(smem + NEFES_RING_SLOTS * NEFES_SLAB_BYTES);
@@ -57,8 +60,12 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
         const int ray = (int)(m / a.S);
         const int smp = (int)(m - (long long)ray * a.S);
         // ---- the only global loads of the tile: raw inputs, completed by loads_landed() before any use ----
-        float in_o[3], in_d[3] = {0.f, 0.f, 0.f}, in_z = 0.f, v[3] = {0.f, 0.f, 0.f};
-        if (a.pts) {
+        float in_o[3] = {0.f, 0.f, 0.f}, in_d[3] = {0.f, 0.f, 0.f}, in_z = 0.f, v[3] = {0.f, 0.f, 0.f};
+        float E[ES];
+        if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+#pragma unroll
+            for (int s = 0; s < ES; ++s) E[s] = a.xyz_enc[m * 32 + 2 * s + h];    // compact slots: feature 2s+h
+        } else if (a.pts) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) in_o[c] = a.pts[m * 3 + c];
         } else {
@@ -72,11 +79,14 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
         }
         loads_landed();
         pin(in_o); pin(in_d); pin(in_z); pin(v);
-        float x[3];
+        if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+            pin(E);
+        } else {
+            float x[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) x[c] = a.pts ? in_o[c] : add_rn(in_o[c], mul_rn(in_d[c], in_z));   // rendering.py:114,142
-        float E[NEFES_E_STEPS];
-        embed_slots<NEFES_N_FREQ_XYZ>(E, x, h);
+            for (int c = 0; c < 3; ++c) x[c] = a.pts ? in_o[c] : add_rn(in_o[c], mul_rn(in_d[c], in_z));   // rendering.py:114,142
+            embed_slots<NEFES_N_FREQ_XYZ>(E, x, h);
+        }
         float Dv[NEFES_D_STEPS];
         if (MODE != NEFES_FIELD_SIGMA) embed_slots<NEFES_N_FREQ_DIR>(Dv, v, h);
         // ReLU masks are lane-private words of whole 32-sample tiles (the buffer is padded to whole tiles), so they are
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
             return pcol;
         };
         auto bias_at = [&](int off_floats) { return BiasInit{bias_half + off_floats * 4}; };
-        const ArrayIn<NEFES_E_STEPS> in_E{E};
+        const ArrayIn<ES> in_E{E};
         const ArrayIn<NEFES_D_STEPS> in_D{Dv};
 
         // Ping-pong accumulators: a layer reads its input straight out of the other array (consumer-side ReLU).
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
             }
         };
         // ---- layer 1: 63 -> W (its bias rides on the first k-step as the C operand) ----
-        mma_run<NTW, NEFES_E_STEPS, 0, true>(ring, ring_lane, in_E, bias_at(0), A);
+        mma_run<NTW, ES, 0, true>(ring, ring_lane, in_E, bias_at(0), A);
         // ---- layers 2..8 (+ xyz_encoding_final as layer 9 in STATIC/FULL), two per iteration: A -> B -> A ----
 #pragma unroll 1
         for (int p = 0; p < 4; ++p) {
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
                                           bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);
             else
                 mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluIn<NTW>{B}, bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);
-            if (p == 1) mma_run<NTW, NEFES_E_STEPS, 0, false>(ring, ring_lane, in_E, ZeroInit{}, A);   // skip: + W5[:, :63] e
+            if (p == 1) mma_run<NTW, ES, 0, false>(ring, ring_lane, in_E, ZeroInit{}, A);   // skip: + W5[:, :63] e
             put_masks(bits, WT);                                      // mask of layer l1 (the producer of B)
         }
         if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head(B);
@@ -212,10 +222,10 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
     ring.drain();
 }
 
-template <int W, int NTR, int MODE>
+template <int W, int NTR, int MODE, int ENC>
 static int launch_fwd(const FieldFwdArgs& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_RING_SLOTS * NEFES_SLAB_BYTES + ((a.bias_floats * 4 + 255) / 256) * 256;
-    auto k = field_fwd_kernel<W, NTR, MODE>;
+    auto k = field_fwd_kernel<W, NTR, MODE, ENC>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -234,10 +244,11 @@ extern "C" size_t nefes_field_mask_bytes(const NefesNetDesc* desc, int64_t M) {
 }
 
 extern "C" int nefes_field_fwd(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
-                               const float* rays_d, const float* z, const float* pts, const float* viewdirs,
-                               float* raw_t, uint32_t* masks, void* stream) {
+                               const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
+                               const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
     if (!desc || !packed || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
-    if (!pts && !(rays_o && rays_d && z)) return NEFES_E_BADARG;
+    const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
+    if (ext ? !xyz_enc : (!pts && !(rays_o && rays_d && z))) return NEFES_E_BADARG;
     if (mode != NEFES_FIELD_SIGMA && !viewdirs) return NEFES_E_BADARG;
     if (mode == NEFES_FIELD_FULL && !desc->has_transient) return NEFES_E_BADARG;
     NefesBlobInfo info;
@@ -251,7 +262,7 @@ extern "C" int nefes_field_fwd(const NefesNetDesc* desc, const void* packed, int
     a.stream = (const char*)packed + si.slab_off;
     a.bias = (const float*)((const char*)packed + si.bias_off);
     a.n_slabs = si.n_slabs; a.bias_floats = si.bias_floats;
-    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.viewdirs = viewdirs;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.xyz_enc = xyz_enc; a.viewdirs = viewdirs;
     a.raw_t = raw_t; a.masks = masks;
     a.N = N; a.S = S; a.C = desc->feat_dim;
     a.R = mode == NEFES_FIELD_SIGMA ? 1 : (mode == NEFES_FIELD_STATIC ? 3 + a.C + 1 : 3 + a.C + 6);
@@ -260,14 +271,15 @@ extern "C" int nefes_field_fwd(const NefesNetDesc* desc, const void* packed, int
     hipStream_t st = (hipStream_t)stream;
     const int W = desc->width, C = desc->feat_dim;
     const int ntr = (3 + C + 31) / 32;
-#define NEFES_DISPATCH(WW, NN)                                                          \
-    if (W == WW && ntr == NN) {                                                         \
-        if (mode == NEFES_FIELD_SIGMA) return launch_fwd<WW, NN, NEFES_FIELD_SIGMA>(a, st);   \
-        if (mode == NEFES_FIELD_STATIC) return launch_fwd<WW, NN, NEFES_FIELD_STATIC>(a, st); \
-        return launch_fwd<WW, NN, NEFES_FIELD_FULL>(a, st);                             \
+#define NEFES_DISPATCH(WW, NN, EE)                                                              \
+    if (W == WW && ntr == NN && desc->xyz_encoding == EE) {                                         \
+        if (mode == NEFES_FIELD_SIGMA) return launch_fwd<WW, NN, NEFES_FIELD_SIGMA, EE>(a, st);   \
+        if (mode == NEFES_FIELD_STATIC) return launch_fwd<WW, NN, NEFES_FIELD_STATIC, EE>(a, st); \
+        return launch_fwd<WW, NN, NEFES_FIELD_FULL, EE>(a, st);                                   \
     }
-    NEFES_DISPATCH(256, 1)   /* BASELINE metric shape: Wd=256, C=16 */
-    NEFES_DISPATCH(128, 5)   /* reference defaults:    Wd=128, C=128 */
+    NEFES_DISPATCH(256, 1, NEFES_XYZ_FREQ10)       /* BASELINE metric shape: Wd=256, C=16 */
+    NEFES_DISPATCH(128, 5, NEFES_XYZ_FREQ10)       /* reference defaults:    Wd=128, C=128 */
+    NEFES_DISPATCH(256, 1, NEFES_XYZ_EXTERNAL32)   /* BASELINE config 4: hash-grid embedding in front of the same MLP */
 #undef NEFES_DISPATCH
     return NEFES_E_UNSUPPORTED;
 }

@@ -35,6 +35,7 @@
 #define NEFES_N_FREQ_DIR 4
 #define NEFES_E_STEPS 32   /* 63 xyz-embedding features + 1 pad, two per k-step */
 #define NEFES_D_STEPS 14   /* 27 dir-embedding features + 1 pad */
+#define NEFES_X_STEPS 16   /* 32 features of an externally supplied xyz embedding (hash grid), compact slots 2s+h */
 
 // accumulator row of (register r, lane half h)
 NEFES_HD int nefes_rho(int h, int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

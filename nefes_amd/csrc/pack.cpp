@@ -91,6 +91,8 @@ std::vector<int> concat(std::vector<int> a, const std::vector<int>& b) {
 struct Net {
     int W, W2, C, NTW, NTH, NTR;
     bool transient;
+    bool ext;        // xyz embedding supplied by the caller (32 features, e.g. the hash grid) instead of the 63 frequency features
+    int in_xyz, e_steps;
     const float* const* t;
     std::vector<float> th_w, th_b;  // virtual transient-head matrix [5][W2]: rgb(3), sigma, beta
     const float* w(int l) const { return t[2 * l]; }
@@ -103,15 +105,29 @@ Seg seg(int nt, int ks, std::vector<int> kidx, std::vector<int> ridx, const floa
     return s;
 }
 
+// k-steps / accumulator rows of the xyz embedding: frequency slots (layout.h nefes_emb_slot) or, for an external
+// 32-feature embedding, compact slots (feature 2s+h)
+std::vector<int> k_xyz(const Net& n, int base) {
+    return n.ext ? [&] { auto k = k_compact(n.e_steps, n.in_xyz); for (auto& v : k) if (v >= 0) v += base; return k; }()
+                 : k_emb(10, n.e_steps, base);
+}
+std::vector<int> rows_xyz(const Net& n, int base) {
+    if (!n.ext) return rows_emb(10, 2, base);
+    // two tiles like the frequency embedding (same kernel shapes): tile 0 = the 32 features, tile 1 = padding
+    std::vector<int> r(64, -1);
+    for (int i = 0; i < 32; ++i) r[i] = base + 2 * nefes_row_reg(i) + nefes_row_half(i);
+    return r;
+}
+
 void add_trunk(const Net& n, Stream& st) {
     const int W = n.W, NT = n.NTW;
     for (int l = 0; l < 8; ++l) {
         if (l == 0) {
-            st.segs.push_back(seg(NT, NEFES_E_STEPS, k_emb(10, NEFES_E_STEPS, 0), rows_natural(NT, W), n.w(0), 63));
+            st.segs.push_back(seg(NT, n.e_steps, k_xyz(n, 0), rows_natural(NT, W), n.w(0), n.in_xyz));
         } else if (l == 4) {  // skip layer: columns [xyz(63), h(W)]  (nerfh_nff.py:472-473,551-552)
             // the kernels accumulate the hidden part first (its first k-step carries the bias), then the xyz part
-            st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, 63), rows_natural(NT, W), n.w(4), 63 + W));
-            st.segs.push_back(seg(NT, NEFES_E_STEPS, k_emb(10, NEFES_E_STEPS, 0), rows_natural(NT, W), n.w(4), 63 + W));
+            st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, n.in_xyz), rows_natural(NT, W), n.w(4), n.in_xyz + W));
+            st.segs.push_back(seg(NT, n.e_steps, k_xyz(n, 0), rows_natural(NT, W), n.w(4), n.in_xyz + W));
         } else {
             st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, 0), rows_natural(NT, W), n.w(l), W));
         }
@@ -166,11 +182,14 @@ void add_backward(const Net& n, Stream& st) {
     st.segs.push_back(seg(NTW, 1, k_compact(1, 1), rows_natural(NTW, W), n.w(L_SIGMA), W, true));
     for (int l = 7; l >= 0; --l) {
         if (l == 4) {
-            std::vector<int> rows = concat(rows_emb(10, 2, 0), rows_natural(NTW, W));
-            for (int i = 64; i < (int)rows.size(); ++i) rows[i] += 63;
-            st.segs.push_back(seg(NTW + 2, W / 2, k_natural(W / 2, 0), rows, n.w(4), 63 + W, true));
+            // d xyz-embedding tiles first (2 tiles of frequency slots, or 1 tile for an external embedding), then d hidden
+            const std::vector<int> re = rows_xyz(n, 0);
+            std::vector<int> rows = concat(re, rows_natural(NTW, W));
+            for (int i = (int)re.size(); i < (int)rows.size(); ++i) rows[i] += n.in_xyz;
+            st.segs.push_back(seg(NTW + (int)re.size() / 32, W / 2, k_natural(W / 2, 0), rows, n.w(4), n.in_xyz + W, true));
         } else if (l == 0) {
-            st.segs.push_back(seg(2, W / 2, k_natural(W / 2, 0), rows_emb(10, 2, 0), n.w(0), 63, true));
+            const std::vector<int> re = rows_xyz(n, 0);
+            st.segs.push_back(seg((int)re.size() / 32, W / 2, k_natural(W / 2, 0), re, n.w(0), n.in_xyz, true));
         } else {
             st.segs.push_back(seg(NTW, W / 2, k_natural(W / 2, 0), rows_natural(NTW, W), n.w(l), W, true));
         }
@@ -184,6 +203,10 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
     n.W = d->width; n.W2 = n.W / 2; n.C = d->feat_dim;
     n.NTW = n.W / 32; n.NTH = n.W2 / 32; n.NTR = (3 + n.C + 31) / 32;
     n.transient = d->has_transient != 0;
+    n.ext = d->xyz_encoding == NEFES_XYZ_EXTERNAL32;
+    if (d->xyz_encoding != NEFES_XYZ_FREQ10 && !n.ext) return false;
+    n.in_xyz = n.ext ? 32 : 63;
+    n.e_steps = n.ext ? NEFES_X_STEPS : NEFES_E_STEPS;
     n.t = tensors;
     if (tensors && n.transient) {
         n.th_w.assign((size_t)5 * n.W2, 0.f);

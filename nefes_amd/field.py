@@ -111,7 +111,7 @@ class NeRFH_NFF(nn.Module):
 
     # -- the HIP path ---------------------------------------------------------------------------
     def _supported(self):
-        return (self.D == 8 and self.skips == [4] and self.in_channels_xyz == 63 and self.in_channels_dir == 27
+        return (self.D == 8 and self.skips == [4] and self.in_channels_xyz in (63, 32) and self.in_channels_dir == 27
                 and self.W in (128, 256) and self.out_ch_size != 3)
 
     def packed(self) -> ops.PackedField:
@@ -125,7 +125,8 @@ class NeRFH_NFF(nn.Module):
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in prm)
         if self._pk is None or key != self._pk_key:
             dev = prm[0].device if prm[0].is_cuda else torch.device("cuda")
-            self._pk = ops.PackedField({n: p for n, p in sd.items()}, self.W, self.W_features, self.encode_transient, dev)
+            enc = L.XYZ_EXTERNAL32 if self.in_channels_xyz == 32 else L.XYZ_FREQ10      # 32 = externally encoded (hash grid)
+            self._pk = ops.PackedField({n: p for n, p in sd.items()}, self.W, self.W_features, self.encode_transient, dev, enc)
             self._pk_key = key
         return self._pk
 

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("NEFES_HIP_LIB", os.path.join(_HERE, "libnefes_hip.so"
 
 
 class NefesNetDesc(C.Structure):
-    _fields_ = [("width", C.c_int32), ("feat_dim", C.c_int32), ("has_transient", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("width", C.c_int32), ("feat_dim", C.c_int32), ("has_transient", C.c_int32), ("xyz_encoding", C.c_int32)]
 
 
 class NefesStreamInfo(C.Structure):
@@ -33,6 +33,7 @@ class NefesHashGridDesc(C.Structure):
 
 STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL = 0, 1, 2, 3
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
+XYZ_FREQ10, XYZ_EXTERNAL32 = 0, 1
 COMP_TRANSIENT, COMP_STATIC_ONLY, COMP_SIGMA_ONLY, COMP_WHITE_BKGD = 1, 2, 4, 8
 
 _p, _i, _f, _u32, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t
@@ -50,8 +51,8 @@ SIGNATURES = {
     "nefes_ndc_bwd": (_i, [_i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_coarse_depths": (_i, [_i, _i, _f, _f, _i, _p, _p, _p, _p]),
     "nefes_field_mask_bytes": (_sz, [_desc, C.c_int64]),
-    "nefes_field_fwd": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "nefes_field_bwd": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_field_fwd": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_field_bwd": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_ray_grad_reduce": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_composite_fwd": (_i, [_i, _i, _i, _u32, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_composite_bwd": (_i, [_i, _i, _i, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -149,9 +149,10 @@ class PackedField:
     LAYERS_FINE = LAYERS_COARSE + ["transient_encoding.0", "transient_encoding.2", "transient_encoding.4",
                                    "transient_sigma.0", "transient_rgb.0", "transient_beta.0"]
 
-    def __init__(self, state_dict, width, feat_dim, has_transient, device):
+    def __init__(self, state_dict, width, feat_dim, has_transient, device, xyz_encoding=0):
         lib = L.load()
-        self.desc = L.NefesNetDesc(int(width), int(feat_dim), 1 if has_transient else 0, 0)
+        self.desc = L.NefesNetDesc(int(width), int(feat_dim), 1 if has_transient else 0, int(xyz_encoding))
+        self.xyz_encoding = int(xyz_encoding)
         self.width, self.feat_dim, self.has_transient = int(width), int(feat_dim), bool(has_transient)
         info = L.NefesBlobInfo()
         L.check(lib.nefes_blob_info(self.desc, info), "nefes_blob_info")
@@ -174,27 +175,32 @@ class PackedField:
         return 1 if mode == L.FIELD_SIGMA else (3 + self.feat_dim + (1 if mode == L.FIELD_STATIC else 6))
 
 
-def field_fwd(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, pts=None, viewdirs=None, want_masks=False):
+def field_fwd(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, pts=None, viewdirs=None, want_masks=False,
+              xyz_enc=None):
     dev = pk.blob.device
     raw_t = torch.empty(N, pk.n_raw(mode), S, device=dev)
     masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=dev) if want_masks else None
     with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]}]"):
       L.check(L.load().nefes_field_fwd(pk.desc, _chk(pk.blob, "blob", torch.uint8), mode, N, S, _chk(rays_o, "rays_o"),
-                                     _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),
-                                     _chk(raw_t, "raw_t"), _chk(masks, "masks", torch.int32), _stream()), "nefes_field_fwd")
+                                     _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(xyz_enc, "xyz_enc"),
+                                     _chk(viewdirs, "viewdirs"), _chk(raw_t, "raw_t"), _chk(masks, "masks", torch.int32),
+                                     _stream()), "nefes_field_fwd")
     return raw_t, masks
 
 
 def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=None, z=None, pts=None, viewdirs=None):
     dev = pk.blob.device
-    g_pts = torch.empty(N * S, 3, device=dev)
+    ext = pk.xyz_encoding == L.XYZ_EXTERNAL32
+    g_pts = None if ext else torch.empty(N * S, 3, device=dev)
+    g_enc = torch.empty(N * S, 32, device=dev) if ext else None
     g_vs = torch.empty(N * S, 3, device=dev)
     with _timed("field_bwd"):
       L.check(L.load().nefes_field_bwd(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
                                      _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),
                                      _chk(raw_t, "raw_t"), _chk(g_raw_t, "g_raw_t"), _chk(masks, "masks", torch.int32),
-                                     _chk(g_pts, "g_pts"), _chk(g_vs, "g_vs"), _stream()), "nefes_field_bwd")
-    return g_pts, g_vs
+                                     _chk(g_pts, "g_pts"), _chk(g_enc, "g_enc"), _chk(g_vs, "g_vs"), _stream()),
+              "nefes_field_bwd")
+    return (g_enc if ext else g_pts), g_vs
 
 
 def ray_grad_reduce(N, S, z, g_pts, g_vs):
@@ -261,6 +267,35 @@ class FieldFromPoints(torch.autograd.Function):
         zeros = torch.zeros(N, S, device=pts.device)
         _, _, g_v = ray_grad_reduce(N, S, zeros, g_pts, g_vs)
         return g_pts.reshape(N, S, 3), g_v, None, None
+
+
+class FieldFromEncoding(torch.autograd.Function):
+    """Field MLP on a caller-supplied 32-feature xyz embedding (hash grid, BASELINE config 4): enc [N,S,32], viewdirs [N,3]
+    -> raw_t [N,R,S]; backward to enc and viewdirs."""
+
+    @staticmethod
+    def forward(ctx, enc, viewdirs, pk, mode):
+        enc = _f32(enc)
+        N, S = enc.shape[0], enc.shape[1]
+        viewdirs = torch.zeros(N, 3, device=enc.device) if viewdirs is None else _f32(viewdirs)
+        need = mode == L.FIELD_FULL and any(ctx.needs_input_grad[:2])
+        raw_t, masks = field_fwd(pk, mode, N, S, xyz_enc=enc.reshape(-1, 32), viewdirs=viewdirs, want_masks=need)
+        ctx.pk, ctx.have = pk, need
+        if need:
+            ctx.save_for_backward(viewdirs, raw_t, masks)
+            ctx.shape = (N, S)
+        return raw_t
+
+    @staticmethod
+    def backward(ctx, g_raw_t):
+        if not ctx.have:
+            raise NotImplementedError("nefes_amd: field backward is built for the FULL (fine) mode only")
+        viewdirs, raw_t, masks = ctx.saved_tensors
+        N, S = ctx.shape
+        g_enc, g_vs = field_bwd(ctx.pk, N, S, raw_t, _f32(g_raw_t), masks, viewdirs=viewdirs)
+        zeros = torch.zeros(N, S, device=raw_t.device)
+        _, _, g_v = ray_grad_reduce(N, S, zeros, g_vs, g_vs)
+        return g_enc.reshape(N, S, 32), g_v, None, None
 
 
 # ---------------------------------------------------------------------------------------------

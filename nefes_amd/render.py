@@ -32,7 +32,17 @@ def _cfg(kwargs):
         white_bkgd=bool(kwargs.get("white_bkgd", False)), raw_noise_std=float(kwargs.get("raw_noise_std", 0.)),
         test_time=bool(kwargs.get("test_time", False)), nerfh_nff=bool(g("nerfh_nff", True)),
         use_fine_only=bool(g("use_fine_only", False)), NeRFW=bool(g("NeRFW", True)),
-        transient_at_test=bool(g("transient_at_test", False)))
+        transient_at_test=bool(g("transient_at_test", False)),
+        # BASELINE config 4: a hash-grid (ops.HashGrid) in front of the same MLP instead of the frequency embedding
+        xyz_encoder=kwargs.get("xyz_encoder", None))
+
+
+def _field(pk, mode, rays_o, rays_d, viewdirs, z, xyz_encoder):
+    """raw_t [N,R,S] for samples z along the rays; differentiable w.r.t. rays_o, rays_d, viewdirs in FULL mode."""
+    if xyz_encoder is None:
+        return ops.FieldFromRays.apply(rays_o, rays_d, viewdirs, z, pk, mode)
+    pts = rays_o[:, None, :] + rays_d[:, None, :] * z[..., None]                    # rendering.py:114,142 (torch glue)
+    return ops.FieldFromEncoding.apply(xyz_encoder(pts), viewdirs, pk, mode)
 
 
 def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, cfg):
@@ -56,13 +66,13 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
     if cfg.test_time:
         # coarse + test_time: sigma-only branch, nothing differentiable (nerfh_nff.py:192-202)
         with torch.no_grad():
-            raw_c, _ = ops.field_fwd(pk_c, L.FIELD_SIGMA, N, Nc, rays_o=rays_o.detach(), rays_d=rays_d.detach(), z=z)
+            raw_c = _field(pk_c, L.FIELD_SIGMA, rays_o.detach(), rays_d.detach(), viewdirs.detach(), z, cfg.xyz_encoder)
             if cfg.raw_noise_std > 0.:
                 raw_c = raw_c + torch.randn_like(raw_c) * cfg.raw_noise_std
             _, _, _, acc0, _, w0, _ = ops.composite_fwd(raw_c, z, C, L.COMP_SIGMA_ONLY)
         rgb0 = feat0 = disp0 = None
     else:
-        raw_c = ops.FieldFromRays.apply(rays_o, rays_d, viewdirs, z, pk_c, L.FIELD_STATIC)
+        raw_c = _field(pk_c, L.FIELD_STATIC, rays_o, rays_d, viewdirs, z, cfg.xyz_encoder)
         if cfg.raw_noise_std > 0.:
             noise = torch.zeros_like(raw_c)
             noise[:, 3 + C] = torch.randn(N, Nc, device=dev) * cfg.raw_noise_std
@@ -82,7 +92,7 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
     z_f = z_samples if cfg.use_fine_only else z_fine
     pk_f = network_fine.packed()
     mode = L.FIELD_FULL if cfg.NeRFW else L.FIELD_STATIC
-    raw_f = ops.FieldFromRays.apply(rays_o, rays_d, viewdirs, z_f, pk_f, mode)
+    raw_f = _field(pk_f, mode, rays_o, rays_d, viewdirs, z_f, cfg.xyz_encoder)
     flags = 0
     if cfg.NeRFW:
         flags |= L.COMP_TRANSIENT

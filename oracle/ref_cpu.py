@@ -103,13 +103,13 @@ def field_param_shapes(typ: str, Wd: int, C: int, in_xyz: int = 63, in_dir: int 
     return spec
 
 
-def make_field_params(typ: str, Wd: int = 256, C: int = 16, seed: int = 0, dtype=torch.float32) -> Dict[str, Tensor]:
+def make_field_params(typ: str, Wd: int = 256, C: int = 16, seed: int = 0, dtype=torch.float32, in_xyz: int = 63) -> Dict[str, Tensor]:
     """Random-init parameters with the reference's key names.  Like the ctor
     (nerfh_nff.py:446) this reseeds the global generator, then draws each
     nn.Linear in construction order (default kaiming-uniform init)."""
     torch.manual_seed(seed)
     out: Dict[str, Tensor] = {}
-    for name, n_out, n_in in field_param_shapes(typ, Wd, C):
+    for name, n_out, n_in in field_param_shapes(typ, Wd, C, in_xyz=in_xyz):
         lin = torch.nn.Linear(n_in, n_out)
         out[name + ".weight"] = lin.weight.detach().to(dtype).clone()
         out[name + ".bias"] = lin.bias.detach().to(dtype).clone()

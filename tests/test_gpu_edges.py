@@ -210,3 +210,56 @@ def test_hashgrid_encoding_vs_oracle():
     HG.encode(x32, table, bound).backward(gen)
     assert rel(xh.grad, x32.grad) < 2e-4
     assert rel(xh.grad, xc.grad) < 1.5 * rel(x32.grad, xc.grad) + 1e-4
+
+
+def test_hashgrid_in_front_of_the_field_mlp():
+    """BASELINE config 4 shape of the path: hash-grid embedding (32 features) feeding the same 8x256 MLP, forward maps and
+    the pose gradient against the oracle composed the same way (hash-grid arithmetic itself: parity unpinned)."""
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    from nefes_amd.render import render
+    from oracle import hashgrid_ref as HG
+    Wd, C, bound = 256, 16, 8.0
+    coarse = NeRFH_NFF('coarse', W=Wd, f_dim=C, in_channels_xyz=32).requires_grad_(False).to(DEV)
+    fine = NeRFH_NFF('fine', W=Wd, f_dim=C, in_channels_xyz=32, encode_appearance=True, encode_transient=True).requires_grad_(False).to(DEV)
+    table = HG.make_table(0) * 3e3                        # O(0.3) features so the MLP actually sees the position
+    grid = ops.HashGrid(bound, table=table)
+    kw = kwargs(coarse, fine, Ni=128)
+    kw["xyz_encoder"] = grid
+    H, W, f = 3, 4, 3.0
+    c2w = O.bench_pose().to(DEV).requires_grad_()
+    rgb, disp, acc, ex = render(H, W, f, c2w=c2w, near=0., far=4., **kw)
+    O.bench_loss(rgb, ex["feat_map"]).backward()
+    # oracle: same composition on CPU
+    pc = O.make_field_params("coarse", Wd, C, in_xyz=32)
+    pf = O.make_field_params("fine", Wd, C, in_xyz=32)
+
+    def field(p, pts, v, sigma_only, dt):
+        e = HG.encode(pts.reshape(-1, 3), table.to(dt), bound)
+        if sigma_only:
+            return O.field_forward(p, e, sigma_only=True, in_xyz=32).reshape(pts.shape[0], pts.shape[1], 1)
+        ed = O.freq_encode(v[:, None].expand(pts.shape).reshape(-1, 3), 4)
+        return O.field_forward(p, torch.cat([e, ed], 1), in_xyz=32).reshape(pts.shape[0], pts.shape[1], -1)
+
+    def oracle(dt):
+        c = O.bench_pose(dt).requires_grad_()
+        o, d = O.ray_bundle(H, W, f, c)
+        o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+        v = d / torch.norm(d, dim=-1, keepdim=True)
+        near, far = torch.zeros(o.shape[0], 1, dtype=dt), torch.full((o.shape[0], 1), 4., dtype=dt)
+        z = O.coarse_depths(near, far, 64, False)
+        cast = lambda p: {k: t.to(dt) for k, t in p.items()}
+        w0 = O.composite(field(cast(pc), o[:, None] + d[:, None] * z[..., None], v, True, dt), z, test_time=True, typ="coarse").weights
+        zs = O.inverse_cdf_samples(.5 * (z[..., 1:] + z[..., :-1]), w0[..., 1:-1], 128, det=True).detach()
+        zf = torch.sort(torch.cat([z, zs], -1), -1)[0]
+        out = O.composite(field(cast(pf), o[:, None] + d[:, None] * zf[..., None], v, False, dt), zf, output_transient=True,
+                          test_time=True, typ="fine", transient_at_test=True)
+        O.bench_loss(out.rgb, out.feat).backward()
+        return out, c.grad
+
+    out32, g32 = oracle(torch.float32)
+    out64, g64 = oracle(torch.float64)
+    assert rel(rgb, out32.rgb) < 1e-4 and rel(ex["feat_map"], out32.feat) < 1e-4 and rel(disp, out32.disp) < 1e-4
+    e_hip, e_ref = rel(c2w.grad, g64), rel(g32, g64)
+    print(f"[hashgrid] d c2w: hip-vs-f64 {e_hip:.2e}  fp32-oracle-vs-f64 {e_ref:.2e}  hip-vs-fp32-oracle {rel(c2w.grad, g32):.2e}")
+    assert e_hip <= max(1e-4, 3 * e_ref)
