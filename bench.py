@@ -23,13 +23,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic MACs per sample (frozen weights => backward = dX only = forward MACs)
-def macs_sigma(W):
-    return 63 * W + 3 * W * W + (W + 63) * W + 3 * W * W + W
+def macs_sigma(W, in_xyz=63):
+    return in_xyz * W + 3 * W * W + (W + in_xyz) * W + 3 * W * W + W
 
 
-def macs_full(W, C):
+def macs_full(W, C, in_xyz=63):
     h = W // 2
-    return macs_sigma(W) + W * W + (W + 27) * h + h * (3 + C) + (W + 27) * h + 2 * h * h + 5 * h
+    return macs_sigma(W, in_xyz) + W * W + (W + 27) * h + h * (3 + C) + (W + 27) * h + 2 * h * h + 5 * h
+
+
+# workloads: "metric" is the BASELINE.json headline (configs[1]); the others are secondary lines, never the default
+WORKLOADS = {
+    "metric": dict(H=480, W=640, focal=525.505, near=0., far=4., Wd=256, C=16, Nc=64, Ni=128, hashgrid=False,
+                   name="BASELINE configs[1]: 7-Scenes-stairs geometry, 64+128 samples, 8x256 MLP + 16-ch feature head"),
+    "cam": dict(H=480, W=854, focal=744., near=0., far=20., Wd=256, C=16, Nc=64, Ni=128, hashgrid=True,
+                name="BASELINE configs[3]: Cambridge ShopFacade geometry 854x480, hash-grid (L=16,F=2,T=2^19, bound 25) in "
+                     "front of the 8x256 MLP + 16-ch feature head (hash-grid arithmetic: parity unpinned)"),
+    "ref": dict(H=60, W=80, focal=262.75 / 4, near=0., far=4., Wd=128, C=128, Nc=64, Ni=64, hashgrid=False,
+                name="refinement-loop frame the reference actually renders (DFM_APR_refine.py:107): 80x60, 64+64 samples, "
+                     "8x128 MLP + 128-ch feature head (reference defaults)"),
+}
 
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -80,9 +93,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=0, help="override the workload's frame height (debugging)")
+    ap.add_argument("--width", type=int, default=0, help="override the workload's frame width (debugging)")
     ap.add_argument("--cpu-rows", type=int, default=4, help="rows of the frame timed on the host cores (0 = skip)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="metric")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -103,21 +117,29 @@ def main():
     from nefes_amd.render import render
     from oracle import ref_cpu as O        # bench_pose()/bench_loss() definitions only; the CPU leg is cpu_baseline()
 
-    Wd, C, Nc, Ni = 256, 16, 64, 128
-    H, W = a.height, a.width
-    focal = 525.505 * W / 640.
-    coarse = NeRFH_NFF('coarse', W=Wd, f_dim=C).requires_grad_(False).to(dev)
-    fine = NeRFH_NFF('fine', W=Wd, f_dim=C, encode_appearance=True, encode_transient=True).requires_grad_(False).to(dev)
+    wl = WORKLOADS[a.workload]
+    Wd, C, Nc, Ni = wl["Wd"], wl["C"], wl["Nc"], wl["Ni"]
+    H, W = a.height or wl["H"], a.width or wl["W"]
+    focal = wl["focal"] * W / wl["W"]
+    near, far = wl["near"], wl["far"]
+    in_xyz = 32 if wl["hashgrid"] else 63
+    coarse = NeRFH_NFF('coarse', W=Wd, f_dim=C, in_channels_xyz=in_xyz).requires_grad_(False).to(dev)
+    fine = NeRFH_NFF('fine', W=Wd, f_dim=C, in_channels_xyz=in_xyz, encode_appearance=True,
+                     encode_transient=True).requires_grad_(False).to(dev)
     args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True, netchunk=1 << 21)
     kw = dict(network_query_fn=None, perturb=False, N_importance=Ni, N_samples=Nc, network_fn=coarse, network_fine=fine,
               use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=True, args=args, ndc=False, lindisp=False)
+    if wl["hashgrid"]:
+        # table scaled to O(0.3) so that the MLP sees the position (tiny-cuda-nn's 1e-4 init would feed it ~zeros)
+        kw["xyz_encoder"] = ops.HashGrid(25.0, device=dev)
+        kw["xyz_encoder"].table.mul_(3e3)
     pose = O.bench_pose().to(dev)
     row0, nrows = D.row_shard(H, rank, world)
     n_total = H * W
 
     def step():
         c2w = pose.clone().requires_grad_()
-        rgb, disp, acc, ex = render(H, W, focal, c2w=D.replicate_pose(c2w), near=0., far=4., row_range=(row0, nrows), **kw)
+        rgb, disp, acc, ex = render(H, W, focal, c2w=D.replicate_pose(c2w), near=near, far=far, row_range=(row0, nrows), **kw)
         feat = ex["feat_map"]
         loss = (feat ** 2).sum() / (n_total * C) + (rgb ** 2).sum() / (n_total * 3)   # = mean over the full frame
         loss.backward()                                                               # pose all-reduce happens here
@@ -149,34 +171,34 @@ def main():
         kern = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in timers.items()}   # ms per launch, rank 0
         rays_local = nrows * W
         # dominant kernel: the fused fine-field forward (FULL mode); algorithmic FLOPs per launch / launch time
-        flop_fwd = 2.0 * macs_full(Wd, C) * rays_local * (Nc + Ni)
+        flop_fwd = 2.0 * macs_full(Wd, C, in_xyz) * rays_local * (Nc + Ni)
         ach = flop_fwd / (kern["field_fwd[full]"] * 1e-3) / 1e12
-        flop_frame = 2.0 * (Nc * macs_sigma(Wd) + 2 * (Nc + Ni) * macs_full(Wd, C)) * n_total
+        flop_frame = 2.0 * (Nc * macs_sigma(Wd, in_xyz) + 2 * (Nc + Ni) * macs_full(Wd, C, in_xyz)) * n_total
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure
         # comes from the committed rocprofv3 passes of this same command (profiles/, 2*FETCH_SIZE + WRITE_SIZE in KiB,
         # gfx950 correction of MI355X_MICROARCH.md) and is quoted only for the workload it was measured on.
         traffic = None
         try:
-            if (H, W, world) == (480, 640, 1):
+            if (a.workload, H, W, world) == ("metric", 480, 640, 1):
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_per_launch.json")))["field_fwd_kernel<256, 1, 2>"]
                 traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
         except Exception:
             traffic = None
         out = {
-            "metric": "rays/s (fwd+bwd) at 640x480x(64+128) samples, 8x256 MLP", "value": value, "unit": "rays/s",
+            "metric": "rays/s (fwd+bwd) at 640x480x(64+128) samples, 8x256 MLP" if a.workload == "metric"
+                      else f"rays/s (fwd+bwd), secondary workload '{a.workload}'", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: 7-Scenes-stairs geometry {W}x{H}, 64+128 samples, 8x256 MLP + "
-                                   f"16-ch feature head, random seed-0 weights, fwd + bwd to the 3x4 pose",
+            "config": {"workload": f"{wl['name']}; {W}x{H}, random seed-0 weights, fwd + bwd to the 3x4 pose",
                        "rays_per_step": n_total, "samples_per_ray": [Nc, Ni], "parallelism": f"rows/{world}"},
-            "roofline": {"bound": "mfma", "kernel": "field_fwd_kernel<256,1,FULL>", "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{int(wl['hashgrid'])}>", "achieved": ach,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes/launch (HBM side, from profiles/r01 PMC passes)",
                          "end_to_end_frac": value * (flop_frame / n_total) / (PEAK_F32_MFMA_TFLOPS * 1e12 * world)},
             "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items())},
             "pose_grad_abs_max": float(g.abs().max()),
         }
-        if world == 1 and a.cpu_rows > 0:
+        if world == 1 and a.cpu_rows > 0 and a.workload == "metric":
             out["cpu_baseline"] = cpu_baseline(Wd, C, Nc, Ni, a.cpu_rows, W, focal)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
