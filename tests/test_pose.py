@@ -40,3 +40,17 @@ def test_learnpose_parameters_and_gradients():
         (c[:3, :4] * torch.arange(12.).reshape(3, 4)).sum().backward()
         assert m.r.grad is not None and m.t.grad is not None and m.r.grad[0].abs().sum() == 0 and m.t.grad[1].abs().sum() > 0
         assert m(torch.tensor([0, 2])).shape == (2, 4, 4)
+
+
+def test_fusion_net_matches_reference(golden):
+    """FusionNet + run_fusion_net (nerfh_nff.py:356-418,578-603) against the reference module: same seed-0 init
+    (checksums), same output in the never-.eval()'ed train mode the refinement loop really uses."""
+    import numpy as np
+    from nefes_amd.field import NeRFH_NFF
+    g = golden("fusion")
+    net = NeRFH_NFF('coarse', W=128, f_dim=16)
+    for k, v in net.fusion_net.state_dict().items():
+        np.testing.assert_allclose([v.double().sum().item(), v.double().abs().sum().item()], g["sd." + k], rtol=0, atol=0)
+    r_rgb, r_feat, fused = net.run_fusion_net(torch.from_numpy(g["rgb"]).clone(), torch.from_numpy(g["feat"]).clone(), 6, 8, 1)
+    np.testing.assert_allclose(fused.detach().numpy(), g["fused"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r_feat.detach().numpy(), g["render_feat"], rtol=0, atol=0)

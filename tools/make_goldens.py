@@ -234,6 +234,16 @@ def main():
     d["z_disp"] = npy((1. / (1. / near * (1. - t) + 1. / far * t)).expand(5, 16))
     np.savez_compressed(os.path.join(OUT, "depths.npz"), **d)
 
+    # ---- FusionNet (post-render CNN) -------------------------------------
+    d = {}
+    coarse, _ = build_nets(M, 128, 16)
+    for k, v in coarse.fusion_net.state_dict().items():
+        d["sd." + k] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+    rgb_in, feat_in = rnd(48, 3), rndn(48, 16)
+    r_rgb, r_feat, fused = coarse.run_fusion_net(rgb_in.clone(), feat_in.clone(), 6, 8, 1)      # modules stay in train() mode
+    d.update(rgb=npy(rgb_in), feat=npy(feat_in), render_rgb=npy(r_rgb), render_feat=npy(r_feat), fused=npy(fused))
+    np.savez_compressed(os.path.join(OUT, "fusion.npz"), **d)
+
     # ---- end to end ----------------------------------------------------------------------
     d = {}
     hist = torch.full((1, 10), 10.)
