@@ -238,7 +238,8 @@ def main():
         traffic = None
         try:
             if (a.workload, H, W, world) == ("metric", 480, 640, 1):
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_per_launch.json")))["field_fwd_kernel<256, 1, 2>"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_per_launch.json")))
+                pm = next(v for k, v in pm.items() if k.replace(" ", "").startswith("field_fwd_kernel<256,1,2"))
                 traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
         except Exception:
             traffic = None
