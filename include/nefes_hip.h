@@ -162,6 +162,14 @@ int nefes_hashgrid_fwd(const NefesHashGridDesc* desc, const float* table, int64_
 int nefes_hashgrid_bwd_x(const NefesHashGridDesc* desc, const float* table, int64_t M, const float* x, const float* g_enc,
                          float* g_x, void* stream);
 
+/* ---- bicubic up-sampling of the fused feature image (script/dm/DFM_APR_refine.py:114,118: torch.nn.Upsample(size,
+ *      mode='bicubic'), align_corners=False, A=-0.75) ---- */
+/* in [planes,h,w] -> out [planes,OH,OW] (planes = batch*channels, contiguous NCHW). */
+int nefes_bicubic_up_fwd(int64_t planes, int h, int w, int OH, int OW, const float* in, float* out, void* stream);
+/* g_out [planes,OH,OW] -> g_in [planes,h,w]; separable gather (no atomics, deterministic); tmp: [planes,h,OW] scratch. */
+int nefes_bicubic_up_bwd(int64_t planes, int h, int w, int OH, int OW, const float* g_out, float* tmp, float* g_in,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,9 +33,13 @@ class FusionNet(nn.Module):
         if not no_BN:
             layers.append(nn.BatchNorm2d(f_dim))
         self.net = nn.Sequential(*layers)
+        self._norm = {}                                             # (device, dtype) -> (mean, std); not in the state_dict
 
     def forward(self, x):
-        mean, std = x.new_tensor(self.mean), x.new_tensor(self.std)
+        key = (x.device, x.dtype)
+        if key not in self._norm:                                   # one host->device copy per device, outside any graph capture
+            self._norm[key] = (x.new_tensor(self.mean), x.new_tensor(self.std))
+        mean, std = self._norm[key]
         x[:, :3] = (x[:, :3] - mean[:, None, None]) / std[:, None, None]     # in place, as the reference does
         out = self.net(x)
         return x[:, 3:] + out if self.fusion_residule else out

@@ -59,6 +59,8 @@ SIGNATURES = {
     "nefes_hashgrid_table_entries": (_sz, [C.POINTER(NefesHashGridDesc)]),
     "nefes_hashgrid_fwd": (_i, [C.POINTER(NefesHashGridDesc), _p, C.c_int64, _p, _p, _p]),
     "nefes_hashgrid_bwd_x": (_i, [C.POINTER(NefesHashGridDesc), _p, C.c_int64, _p, _p, _p, _p]),
+    "nefes_bicubic_up_fwd": (_i, [C.c_int64, _i, _i, _i, _i, _p, _p, _p]),
+    "nefes_bicubic_up_bwd": (_i, [C.c_int64, _i, _i, _i, _i, _p, _p, _p, _p]),
     "nefes_sample_pdf_merge": (_i, [_i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
 }
 

@@ -431,3 +431,34 @@ class HashGridEncode(torch.autograd.Function):
             L.check(L.load().nefes_hashgrid_bwd_x(ctx.grid.desc, _chk(ctx.grid.table, "table"), xf.shape[0], _chk(xf, "x"),
                                                   _chk(g, "g_enc"), _chk(g_x, "g_x"), _stream()), "nefes_hashgrid_bwd_x")
         return g_x.reshape(ctx.shape), None
+
+
+class BicubicUpsample(torch.autograd.Function):
+    """torch.nn.Upsample(size=(OH, OW), mode='bicubic') on a contiguous [B,C,h,w] image (DFM_APR_refine.py:114,118);
+    the backward is a separable gather instead of the library's atomic scatter."""
+
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        B, Cc, h, w = x.shape
+        xf = _f32(x)
+        out = torch.empty(B, Cc, OH, OW, device=xf.device)
+        with _timed("bicubic_up_fwd"):
+            L.check(L.load().nefes_bicubic_up_fwd(B * Cc, h, w, OH, OW, _chk(xf, "x"), _chk(out, "out"), _stream()),
+                    "nefes_bicubic_up_fwd")
+        ctx.dims = (B, Cc, h, w, OH, OW)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        B, Cc, h, w, OH, OW = ctx.dims
+        g = _f32(g_out)
+        tmp = torch.empty(B * Cc, h, OW, device=g.device)
+        g_in = torch.empty(B, Cc, h, w, device=g.device)
+        with _timed("bicubic_up_bwd"):
+            L.check(L.load().nefes_bicubic_up_bwd(B * Cc, h, w, OH, OW, _chk(g, "g_out"), _chk(tmp, "tmp"), _chk(g_in, "g_in"),
+                                                  _stream()), "nefes_bicubic_up_bwd")
+        return g_in, None, None
+
+
+def bicubic_upsample(x, size):
+    return BicubicUpsample.apply(x, int(size[0]), int(size[1]))

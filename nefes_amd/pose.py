@@ -17,6 +17,12 @@ def _skew(v):
                         torch.stack([-v[..., 1], v[..., 0], z], -1)], -2)
 
 
+def _bottom_row(like, shape):
+    """[0,0,0,1] built by fill kernels on the device (no host->device copy, so the pose chain is graph-capturable)."""
+    row = torch.cat([torch.zeros(3, dtype=like.dtype, device=like.device), torch.ones(1, dtype=like.dtype, device=like.device)])
+    return row.expand(*shape, 1, 4)
+
+
 def so3_exp(r):
     """Rodrigues, same expression as lie_group_helper.Exp (:60-69): eps only guards the division."""
     K = _skew(r)
@@ -29,7 +35,7 @@ def make_c2w(r, t):
     """lie_group_helper.make_c2w (:72-81): [Exp(r) | t] as 4x4 (batched over leading dims)."""
     R = so3_exp(r)
     top = torch.cat([R, t[..., None]], -1)
-    bottom = torch.tensor([0., 0., 0., 1.], dtype=r.dtype, device=r.device).expand(*top.shape[:-2], 1, 4)
+    bottom = _bottom_row(r, top.shape[:-2])
     return torch.cat([top, bottom], -2)
 
 
@@ -49,7 +55,7 @@ def se3_exp(tau_phi):
     V = eye + b * K + c * (K @ K)
     t = (V @ tau[..., None])[..., 0]
     top = torch.cat([R, t[..., None]], -1)
-    bottom = torch.tensor([0., 0., 0., 1.], dtype=phi.dtype, device=phi.device).expand(*top.shape[:-2], 1, 4)
+    bottom = _bottom_row(phi, top.shape[:-2])
     return torch.cat([top, bottom], -2)
 
 

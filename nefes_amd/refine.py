@@ -1,0 +1,142 @@
+"""Per-image pose refinement loop around the HIP render path.
+
+Mirrors the inner loop of script/dm/DFM_pose_refine.py:290-348 (`DFM_optimization_NFF`, `--pose_only 3`) and of
+script/dm/DFM_APR_refine.py:84-156 (`train_on_batch`):
+
+    LearnPose(cam) -> fix_coord_supp -> render(H/ts, W/ts, focal/ts, c2w) -> affine_color_transform(hist)
+        -> run_fusion_net -> [bicubic upsample + 10 px crop] -> 1 - mean cosine similarity -> backward -> Adam
+
+The reference runs the 50 iterations of one image as 50 eager Python passes (~150 launches each).  `PoseRefiner`
+captures ONE iteration -- forward, backward and the Adam update -- into a HIP graph on first use and replays it, so the
+loop's cost is the kernels' and not the host's; per-image state (pose delta, Adam moments, target features, histogram)
+lives in static device buffers that are reset in place.  The bicubic up-sampling runs on ops.BicubicUpsample (gather
+backward; the library's atomic scatter backward was 40 % of an iteration).  No CPU fallback anywhere on the path.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .pose import LearnPose
+from .render import render
+
+
+def fix_coord_supp(pose, world_setup_dict, device=None):
+    """dm/direct_pose_model.py:210-232: APR/COLMAP translation -> NeRF scale, `t' = (t*sc + move)*sc2`.
+    Out of place (the reference mutates a clone), constants as device scalars so the chain is graph-capturable."""
+    sc, sc2 = float(world_setup_dict['pose_scale']), float(world_setup_dict['pose_scale2'])
+    mv = [float(v) * sc2 for v in world_setup_dict['move_all_cam_vec']]
+    t = pose[..., :3, 3] * (sc * sc2)
+    t = torch.stack([t[..., 0] + mv[0], t[..., 1] + mv[1], t[..., 2] + mv[2]], -1)
+    return torch.cat([pose[..., :3, :3], t[..., None]], -1)
+
+
+def feature_loss(feature_rgb, feature_target, img_in=True, per_pixel=False):
+    """dm/DFM_pose_refine.py:211-233: 1 - mean cosine similarity (per channel over pixels, or per pixel over channels)."""
+    if img_in:
+        C = feature_rgb.shape[0]
+        feature_rgb, feature_target = feature_rgb.reshape(C, -1), feature_target.reshape(C, -1)
+    cos = nn.CosineSimilarity(dim=0 if per_pixel else 1, eps=1e-6)
+    return 1 - cos(feature_rgb, feature_target).mean()
+
+
+class FeatureLoss(nn.Module):
+    """dm/DFM_pose_refine.py:236-255."""
+
+    def __init__(self, img_in=True, per_pixel=False):
+        super().__init__()
+        self.img_in, self.per_pixel = img_in, per_pixel
+
+    def forward(self, feature_rgb, feature_target):
+        return feature_loss(feature_rgb, feature_target, self.img_in, self.per_pixel)
+
+
+class PoseRefiner:
+    """One query image at a time: `refine(init_c2w, feature_target, hist, iters)` -> (refined 4x4 c2w, losses [iters]).
+
+    hwf: full-resolution (H, W, focal); the render runs at 1/tinyscale.  `upsample=True` is the APR variant (bicubic
+    upsample of the fused features to (H, W) and a 10-pixel crop; `feature_target` is [C, H, W]); False is the
+    DFM_pose_refine variant (`feature_target` is [C, H/ts, W/ts]).  `world_setup` = dict(pose_scale, pose_scale2,
+    move_all_cam_vec) or None.  `graph=True` replays one captured HIP graph per iteration."""
+
+    def __init__(self, render_kwargs, args, hwf, near, far, tinyscale=4, lr_r=0.01, lr_t=0.1, lietorch=False,
+                 upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda"):
+        self.kw, self.args = dict(render_kwargs), args
+        H, W, focal = hwf
+        self.H, self.W = int(H), int(W)
+        self.h, self.w, self.focal = int(H // tinyscale), int(W // tinyscale), float(focal) / tinyscale
+        self.near, self.far = float(near), float(far)
+        self.upsample, self.per_pixel, self.world_setup = upsample, per_pixel, world_setup
+        self.coarse = self.kw["network_fn"]
+        self.C = self.coarse.W_features
+        self.dev = torch.device(device)
+        self.model = LearnPose(1, True, True, init_c2w=torch.eye(4)[None].clone(), lietorch=lietorch).to(self.dev)
+        self.opt = torch.optim.Adam([{"params": [self.model.r], "lr": lr_r}, {"params": [self.model.t], "lr": lr_t}],
+                                    capturable=bool(graph))
+        th, tw = (self.H - 20, self.W - 20) if upsample else (self.h, self.w)
+        self.target = torch.zeros(self.C, th, tw, device=self.dev)
+        self.hist = torch.zeros(1, 10, device=self.dev)
+        self.loss = torch.zeros((), device=self.dev)
+        self.use_graph, self.graph = bool(graph), None
+
+    # one iteration on the static buffers -------------------------------------------------------------------------
+    def _iteration(self):
+        c2w = self.model(0)[None, :3, :4]
+        if self.world_setup is not None:
+            c2w = fix_coord_supp(c2w, self.world_setup)
+        rgb, _, _, ex = render(self.h, self.w, self.focal, c2w=c2w[0], near=self.near, far=self.far, img_idx=self.hist,
+                               **self.kw)
+        if getattr(self.args, "encode_hist", False):
+            rgb = self.coarse.affine_color_transform(self.args, rgb, self.hist, 1)
+        _, _, fused = self.coarse.run_fusion_net(rgb, ex["feat_map"], self.h, self.w, 1)
+        if self.upsample:
+            fused = ops.bicubic_upsample(fused, (self.H, self.W))[:, :, 10:-10, 10:-10]
+        loss = feature_loss(fused[0], self.target, per_pixel=self.per_pixel)
+        loss.backward()
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=False)
+        self.loss.copy_(loss.detach())
+
+    def _reset(self, init_c2w, feature_target, hist):
+        with torch.no_grad():
+            self.model.r.zero_()
+            self.model.t.zero_()
+            self.model.init_c2w.copy_(init_c2w.reshape(1, 4, 4))
+            self.target.copy_(feature_target.reshape(self.target.shape))
+            self.hist.copy_(hist.reshape(1, 10))
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            for p in (self.model.r, self.model.t):
+                if p.grad is not None:
+                    p.grad.zero_()
+
+    def _capture(self):
+        """Warm up on a side stream (allocator, MIOpen plans, Adam state), then capture one iteration."""
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._iteration()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._iteration()
+        self.graph = g
+
+    def refine(self, init_c2w, feature_target, hist, iters=50):
+        init_c2w, feature_target, hist = init_c2w.to(self.dev), feature_target.to(self.dev), hist.to(self.dev)
+        self._reset(init_c2w, feature_target, hist)
+        if self.use_graph and self.graph is None:
+            self._capture()
+            self._reset(init_c2w, feature_target, hist)
+        losses = torch.empty(iters, device=self.dev)
+        for i in range(iters):
+            if self.use_graph:
+                self.graph.replay()
+            else:
+                self._iteration()
+            losses[i] = self.loss
+        with torch.no_grad():
+            return self.model(0).detach().clone(), losses

@@ -295,3 +295,59 @@ def test_pose_refinement_loop_reduces_pose_error():
     # random seed-0 weights give a low-contrast 'fog' scene (loss ~1e-8, rotation can trade against translation):
     # require that the HIP pose gradients drive the photometric+feature loss down and the pose does not drift away
     assert losses[-1] < 0.5 * losses[0] and err1 < err0
+
+
+@pytest.mark.gpu
+def test_pose_refiner_graph_matches_eager():
+    """one captured HIP graph per refinement iteration gives the same trajectory as the eager loop."""
+    import types
+    from nefes_amd.field import NeRFH_NFF
+    from nefes_amd.refine import PoseRefiner
+    dev = torch.device("cuda")
+    H, W, focal, C = 12, 16, 26.0, 16
+    coarse = NeRFH_NFF('coarse', W=256, f_dim=C).requires_grad_(False).to(dev)
+    fine = NeRFH_NFF('fine', W=256, f_dim=C, encode_appearance=True, encode_transient=True).requires_grad_(False).to(dev)
+    args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True, encode_hist=True)
+    kw = dict(network_query_fn=None, perturb=False, N_importance=32, N_samples=32, network_fn=coarse, network_fine=fine,
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=True, args=args, ndc=False, lindisp=False)
+    init = torch.eye(4, device=dev)
+    init[:3, :4] = O.bench_pose().to(dev)
+    hist = torch.full((1, 10), 10., device=dev)
+    true = init.clone()
+    true[:3, 3] += torch.tensor([0.03, -0.02, 0.04], device=dev)
+    with torch.no_grad():                                            # target = fused features rendered at the true pose
+        from nefes_amd.render import render
+        rgb, _, _, ex = render(H, W, focal, c2w=true[:3, :4], near=0., far=4., img_idx=hist, **kw)
+        rgb = coarse.affine_color_transform(args, rgb, hist, 1)
+        target = coarse.run_fusion_net(rgb, ex["feat_map"], H, W, 1)[2][0].clone()
+    ws = dict(pose_scale=1.0, pose_scale2=1.0, move_all_cam_vec=[0.0, 0.0, 0.0])
+    outs = []
+    for graph in (False, True):
+        bn = coarse.fusion_net.net[-1]
+        bn.reset_running_stats()
+        r = PoseRefiner(kw, args, (4 * H, 4 * W, 4 * focal), 0., 4., tinyscale=4, lr_t=0.01, world_setup=ws, graph=graph, device=dev)
+        r.refine(init, target, hist, 2)                              # second call below re-uses the captured graph
+        outs.append(r.refine(init, target, hist, 4))
+    (p0, l0), (p1, l1) = outs
+    assert torch.isfinite(l0).all()
+    assert torch.allclose(l0, l1, rtol=1e-2, atol=1e-6), (l0, l1)
+    assert torch.allclose(p0, p1, rtol=0, atol=2e-3), (p0 - p1).abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,size", [((1, 16, 60, 80), (240, 320)), ((2, 3, 7, 5), (19, 23)), ((1, 4, 9, 9), (9, 9))])
+def test_bicubic_upsample_matches_torch(shape, size):
+    """nefes_bicubic_up_fwd/bwd against torch.nn.Upsample(size, mode='bicubic') (DFM_APR_refine.py:114) computed by
+    torch on the CPU in float64; the gather backward must equal autograd's scatter backward."""
+    from nefes_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(*shape, generator=g)
+    go = torch.randn(shape[0], shape[1], *size, generator=g)
+    xr = x.double().requires_grad_()
+    yr = torch.nn.Upsample(size=size, mode='bicubic')(xr)
+    yr.backward(go.double())
+    xg = x.cuda().requires_grad_()
+    y = ops.bicubic_upsample(xg, size)
+    y.backward(go.cuda())
+    assert torch.allclose(y.detach().cpu().double(), yr.detach(), rtol=0, atol=2e-6 * float(yr.detach().abs().max()))
+    assert torch.allclose(xg.grad.cpu().double(), xr.grad, rtol=0, atol=2e-6 * float(xr.grad.abs().max()))
