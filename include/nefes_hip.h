@@ -162,6 +162,28 @@ int nefes_hashgrid_fwd(const NefesHashGridDesc* desc, const float* table, int64_
 int nefes_hashgrid_bwd_x(const NefesHashGridDesc* desc, const float* table, int64_t M, const float* x, const float* g_enc,
                          float* g_x, void* stream);
 
+/* ---- train mode: weight gradients (script/run_nefes.py:42-108 `loss.backward()` through models/nerfh_nff.py:525-576) ----
+ * Buffers `acts` / `dacts`: fp32 [n_tiles = ceil(N*S/128)][rows][128 samples], rows = nefes_train_rows(desc); row blocks
+ * NEFES_TB_* (nefes_amd/csrc/layout.h): E, DV (embeddings, slot order), L1..L8, FINAL, DIR, T0..T2 (natural feature
+ * order), RGB, SIG, TH (head gradients, padded to 32 rows).  `acts` holds PRE-activations, `dacts` their gradients. */
+size_t nefes_train_rows(const NefesNetDesc* desc);
+int nefes_train_row_offset(const NefesNetDesc* desc, int block);      /* block 0..18 (18 = rows per tile) */
+/* nefes_field_fwd (mode STATIC or FULL, frequency embedding) that also writes `acts`. */
+int nefes_field_fwd_train(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                          const float* rays_d, const float* z, const float* pts, const float* viewdirs, float* raw_t,
+                          float* acts, void* stream);
+/* d raw_t [N][R][S] -> head pre-activation gradients in dacts blocks RGB, SIG (, TH); samples beyond N*S are zeroed. */
+int nefes_train_head_grad(const NefesNetDesc* desc, int mode, int N, int S, const float* raw_t, const float* g_raw_t,
+                          float* dacts, void* stream);
+/* dacts_out[dst_row0 + i][s] (+)= sum_{o < n_out} wt[i][o] * dacts_in[g_row0 + o][s],  i < n_in (64, 128 or 256);
+ * wt = TRANSPOSED weights [n_in][ldw] (n_out % 8 == 0, zero padded); mask: multiply by [acts[dst_row0 + i][s] > 0]. */
+int nefes_train_dx(int64_t n_tiles, int rows, const float* dacts_in, int g_row0, int n_out, const float* wt, int ldw,
+                   int n_in, const float* acts, int dst_row0, int accumulate, int mask, float* dacts_out, void* stream);
+/* partial[sp][o][i] = sum over the sp-th share of the sample tiles of dacts[g_row0 + o][s] * f(acts[x_row0 + i][s]),
+ * f = ReLU if x_relu else identity; n_out, n_in multiples of 32; the caller sums the `splits` partials. */
+int nefes_train_dw(int64_t n_tiles, int rows, const float* dacts, int g_row0, int n_out, const float* acts, int x_row0,
+                   int n_in, int x_relu, int splits, float* partial, void* stream);
+
 /* ---- bicubic up-sampling of the fused feature image (script/dm/DFM_APR_refine.py:114,118: torch.nn.Upsample(size,
  *      mode='bicubic'), align_corners=False, A=-0.75) ---- */
 /* in [planes,h,w] -> out [planes,OH,OW] (planes = batch*channels, contiguous NCHW). */

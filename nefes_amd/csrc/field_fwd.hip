@@ -23,11 +23,25 @@ struct FieldFwdArgs {
     int N, S, R, C;
     long long M;
     int n_tiles;             // 128-sample workgroup tiles
+    float* acts;             // TRAIN instances: [n_tiles][rows][128] pre-activations + embeddings (layout.h row map)
+    int rows;
 };
+
+// TRAIN: dump a layer's accumulators (pre-activation, bias included) as rows [row0, row0 + 32 NT) of this tile.
+// One accumulator register = two 128-byte row segments (lane halves hold rows rho and rho + 4): full-rate stores.
+template <int NT>
+__device__ __forceinline__ void train_save(float* tile_base, uint32_t voff, int row0, const f32x16 (&X)[NT]) {
+    float* p = tile_base + (size_t)row0 * 128 + voff;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[(32 * t + nefes_rho(0, r)) * 128] = X[t][r];
+}
 
 // MODE: NEFES_FIELD_SIGMA / STATIC / FULL.  W: MLP width.  NTR: tiles of the rgb+feature head.
 // ENC: NEFES_XYZ_FREQ10 (embedding computed here) / NEFES_XYZ_EXTERNAL32 (32 features per sample read from xyz_enc).
-template <int W, int NTR, int MODE, int ENC>
+// TRAIN: additionally write every hidden layer's pre-activation and both embeddings to a.acts (weight-gradient pass).
+template <int W, int NTR, int MODE, int ENC, bool TRAIN = false>
 __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;   // tiles / k-steps
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
@@ -116,6 +130,25 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
         auto bias_at = [&](int off_floats) { return BiasInit{bias_half + off_floats * 4}; };
         const ArrayIn<ES> in_E{E};
         const ArrayIn<NEFES_D_STEPS> in_D{Dv};
+        float* act_tile = nullptr;                                    // wave-uniform
+        const uint32_t act_voff = (uint32_t)(4 * h * 128 + wave * 32 + j);
+        if constexpr (TRAIN) {
+            act_tile = a.acts + (size_t)tile * a.rows * 128;
+            float* pe = act_tile + (size_t)nefes_train_row(W, 0, NEFES_TB_E) * 128 + (h * 128 + wave * 32 + j);
+#pragma unroll
+            for (int s = 0; s < ES; ++s) pe[2 * s * 128] = E[s];     // slot (s,h) -> row 2s+h
+            if (MODE != NEFES_FIELD_SIGMA) {
+                float* pd = act_tile + (size_t)nefes_train_row(W, 0, NEFES_TB_DV) * 128 + (h * 128 + wave * 32 + j);
+#pragma unroll
+                for (int s = 0; s < NEFES_D_STEPS; ++s) pd[2 * s * 128] = Dv[s];
+            }
+        }
+        auto save_trunk = [&](int layer, const f32x16 (&X)[NTW]) {   // layer 1..9 (9 = xyz_encoding_final)
+            if constexpr (TRAIN) train_save<NTW>(act_tile, act_voff, nefes_train_row(W, 0, NEFES_TB_L1) + (layer - 1) * W, X);
+        };
+        auto save_half = [&](int block, const f32x16 (&X)[NTH]) {
+            if constexpr (TRAIN) train_save<NTH>(act_tile, act_voff, nefes_train_row(W, 0, block), X);
+        };
 
         // Ping-pong accumulators: a layer reads its input straight out of the other array (consumer-side ReLU).
         f32x16 A[NTW], B[NTW];
@@ -135,6 +168,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
         };
         // ---- layer 1: 63 -> W (its bias rides on the first k-step as the C operand) ----
         mma_run<NTW, ES, 0, true>(ring, ring_lane, in_E, bias_at(0), A);
+        save_trunk(1, A);
         // ---- layers 2..8 (+ xyz_encoding_final as layer 9 in STATIC/FULL), two per iteration: A -> B -> A ----
 #pragma unroll 1
         for (int p = 0; p < 4; ++p) {
@@ -146,6 +180,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
             else
                 mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluIn<NTW>{A}, bias_at((l1 - 1) * W), B);
             put_masks(bits, WT);                                      // mask of layer l1-1 (the producer of A)
+            save_trunk(l1, B);
             if (p == 3) {
                 if (MODE == NEFES_FIELD_SIGMA) break;                 // layer 8 is the last; B holds its pre-activation
                 sigma_head(B);
@@ -158,6 +193,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
                 mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluIn<NTW>{B}, bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);
             if (p == 1) mma_run<NTW, ES, 0, false>(ring, ring_lane, in_E, ZeroInit{}, A);   // skip: + W5[:, :63] e
             put_masks(bits, WT);                                      // mask of layer l1 (the producer of B)
+            save_trunk(l2, A);
         }
         if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head(B);
         if constexpr (MODE != NEFES_FIELD_SIGMA) {
@@ -171,6 +207,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
             // ---- dir_encoding: cat[final, dir-emb] -> W/2 ----
             mma_run<NTH, HS, 0, true>(ring, ring_lane, IdentIn<NTW>{A}, bias_at(B_DIR), acc2);
             mma_run<NTH, NEFES_D_STEPS, 0, false>(ring, ring_lane, in_D, ZeroInit{}, acc2);
+            save_half(NEFES_TB_DIR, acc2);
             // ---- static_rgb on relu(dir): W/2 -> 3+C, no activation (:487-490) ----
             {
                 f32x16 ar[NTR];
@@ -194,12 +231,15 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
                 // ---- transient_encoding.{0,2,4} ----
                 mma_run<NTH, HS, 0, true>(ring, ring_lane, IdentIn<NTW>{A}, bias_at(B_T0), acc2);
                 mma_run<NTH, NEFES_D_STEPS, 0, false>(ring, ring_lane, in_D, ZeroInit{}, acc2);
+                save_half(NEFES_TB_T0, acc2);
                 clear2();
                 mma_run<NTH, GS, 0, true>(ring, ring_lane, ReluCapture<NTH, WH>{acc2, bits2}, bias_at(B_T1), acc3);
                 put_masks(bits2, WH);                                 // transient_encoding.0
+                save_half(NEFES_TB_T1, acc3);
                 clear2();
                 mma_run<NTH, GS, 0, true>(ring, ring_lane, ReluCapture<NTH, WH>{acc3, bits2}, bias_at(B_T2), acc2);
                 put_masks(bits2, WH);                                 // transient_encoding.2
+                save_half(NEFES_TB_T2, acc2);
                 // ---- transient heads: rows 0..2 rgb (sigmoid), 3 sigma (softplus), 4 beta (softplus) ----
                 f32x16 th[1];
                 clear2();
@@ -222,10 +262,10 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
     ring.drain();
 }
 
-template <int W, int NTR, int MODE, int ENC>
+template <int W, int NTR, int MODE, int ENC, bool TRAIN = false>
 static int launch_fwd(const FieldFwdArgs& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_RING_SLOTS * NEFES_SLAB_BYTES + ((a.bias_floats * 4 + 255) / 256) * 256;
-    auto k = field_fwd_kernel<W, NTR, MODE, ENC>;
+    auto k = field_fwd_kernel<W, NTR, MODE, ENC, TRAIN>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -243,9 +283,9 @@ extern "C" size_t nefes_field_mask_bytes(const NefesNetDesc* desc, int64_t M) {
     return (size_t)tiles32 * nefes_mask_words(desc->width) * 64 * 4;
 }
 
-extern "C" int nefes_field_fwd(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
-                               const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
-                               const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
+static int field_fwd_impl(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                          const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
+                          const float* viewdirs, float* raw_t, uint32_t* masks, float* acts, void* stream) {
     if (!desc || !packed || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
     const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
     if (ext ? !xyz_enc : (!pts && !(rays_o && rays_d && z))) return NEFES_E_BADARG;
@@ -263,7 +303,8 @@ extern "C" int nefes_field_fwd(const NefesNetDesc* desc, const void* packed, int
     a.bias = (const float*)((const char*)packed + si.bias_off);
     a.n_slabs = si.n_slabs; a.bias_floats = si.bias_floats;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.xyz_enc = xyz_enc; a.viewdirs = viewdirs;
-    a.raw_t = raw_t; a.masks = masks;
+    a.raw_t = raw_t; a.masks = masks; a.acts = acts;
+    a.rows = nefes_train_row(desc->width, desc->feat_dim, NEFES_TB_END);
     a.N = N; a.S = S; a.C = desc->feat_dim;
     a.R = mode == NEFES_FIELD_SIGMA ? 1 : (mode == NEFES_FIELD_STATIC ? 3 + a.C + 1 : 3 + a.C + 6);
     a.M = (long long)N * S;
@@ -271,6 +312,18 @@ extern "C" int nefes_field_fwd(const NefesNetDesc* desc, const void* packed, int
     hipStream_t st = (hipStream_t)stream;
     const int W = desc->width, C = desc->feat_dim;
     const int ntr = (3 + C + 31) / 32;
+    if (acts) {   // train-mode instances: frequency embedding, heads present
+        if (mode == NEFES_FIELD_SIGMA || desc->xyz_encoding != NEFES_XYZ_FREQ10) return NEFES_E_UNSUPPORTED;
+#define NEFES_DISPATCH_TRAIN(WW, NN)                                                                            \
+    if (W == WW && ntr == NN) {                                                                                 \
+        if (mode == NEFES_FIELD_STATIC) return launch_fwd<WW, NN, NEFES_FIELD_STATIC, NEFES_XYZ_FREQ10, true>(a, st); \
+        return launch_fwd<WW, NN, NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, true>(a, st);                             \
+    }
+        NEFES_DISPATCH_TRAIN(256, 1)
+        NEFES_DISPATCH_TRAIN(128, 5)
+#undef NEFES_DISPATCH_TRAIN
+        return NEFES_E_UNSUPPORTED;
+    }
 #define NEFES_DISPATCH(WW, NN, EE)                                                              \
     if (W == WW && ntr == NN && desc->xyz_encoding == EE) {                                         \
         if (mode == NEFES_FIELD_SIGMA) return launch_fwd<WW, NN, NEFES_FIELD_SIGMA, EE>(a, st);   \
@@ -282,4 +335,26 @@ extern "C" int nefes_field_fwd(const NefesNetDesc* desc, const void* packed, int
     NEFES_DISPATCH(256, 1, NEFES_XYZ_EXTERNAL32)   /* BASELINE config 4: hash-grid embedding in front of the same MLP */
 #undef NEFES_DISPATCH
     return NEFES_E_UNSUPPORTED;
+}
+
+extern "C" int nefes_field_fwd(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                               const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
+                               const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
+    return field_fwd_impl(desc, packed, mode, N, S, rays_o, rays_d, z, pts, xyz_enc, viewdirs, raw_t, masks, nullptr, stream);
+}
+
+extern "C" size_t nefes_train_rows(const NefesNetDesc* desc) {
+    return desc ? (size_t)nefes_train_row(desc->width, desc->feat_dim, NEFES_TB_END) : 0;
+}
+
+extern "C" int nefes_train_row_offset(const NefesNetDesc* desc, int block) {
+    if (!desc || block < 0 || block > NEFES_TB_END) return NEFES_E_BADARG;
+    return nefes_train_row(desc->width, desc->feat_dim, block);
+}
+
+extern "C" int nefes_field_fwd_train(const NefesNetDesc* desc, const void* packed, int mode, int N, int S,
+                                     const float* rays_o, const float* rays_d, const float* z, const float* pts,
+                                     const float* viewdirs, float* raw_t, float* acts, void* stream) {
+    if (!acts) return NEFES_E_BADARG;
+    return field_fwd_impl(desc, packed, mode, N, S, rays_o, rays_d, z, pts, nullptr, viewdirs, raw_t, nullptr, acts, stream);
 }

@@ -68,3 +68,30 @@ enum { NEFES_STREAM_FWD_SIGMA = 0, NEFES_STREAM_FWD_STATIC = 1, NEFES_STREAM_FWD
 // ReLU-mask words (32 bit) written per lane per 32-sample tile by the full forward pass:
 // 8 trunk layers (W/64 words each) + dir + 3 transient layers (W/128 words each)
 NEFES_HD int nefes_mask_words(int W) { return 8 * (W / 64) + 4 * (W / 128); }
+
+// ---- train-mode activation / gradient buffers (field_fwd TRAIN instances, train.hip) ----
+// Tile-major: buf[tile128][row][128 samples] fp32.  One row map for both buffers:
+//   `acts`  (forward):  E, DV = embeddings in slot order (row 2s+h); L1..L8, FINAL, DIR, T0..T2 = PRE-activations
+//   `dacts` (backward): L1..T2 = gradient w.r.t. those pre-activations; RGB, SIG, TH = head pre-activation gradients
+// Hidden blocks are in natural feature order.  Head blocks are padded to whole 32-row tiles.
+enum { NEFES_TB_E = 0, NEFES_TB_DV = 1, NEFES_TB_L1 = 2 /* .. L8 = 9 */, NEFES_TB_FINAL = 10, NEFES_TB_DIR = 11,
+       NEFES_TB_T0 = 12, NEFES_TB_T1 = 13, NEFES_TB_T2 = 14, NEFES_TB_RGB = 15, NEFES_TB_SIG = 16, NEFES_TB_TH = 17,
+       NEFES_TB_END = 18 };
+NEFES_HD int nefes_train_row(int W, int C, int block) {
+    const int ntr = (3 + C + 31) / 32;
+    int r = 0;
+    if (block == NEFES_TB_E) return r;
+    r += 2 * NEFES_E_STEPS;
+    if (block == NEFES_TB_DV) return r;
+    r += 32;
+    if (block >= NEFES_TB_L1 && block <= NEFES_TB_FINAL) return r + (block - NEFES_TB_L1) * W;
+    r += 9 * W;
+    if (block >= NEFES_TB_DIR && block <= NEFES_TB_T2) return r + (block - NEFES_TB_DIR) * (W / 2);
+    r += 4 * (W / 2);
+    if (block == NEFES_TB_RGB) return r;
+    r += 32 * ntr;
+    if (block == NEFES_TB_SIG) return r;
+    r += 32;
+    if (block == NEFES_TB_TH) return r;
+    return r + 32;   // NEFES_TB_END = rows per tile
+}

@@ -34,6 +34,8 @@ class NefesHashGridDesc(C.Structure):
 STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL = 0, 1, 2, 3
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
 XYZ_FREQ10, XYZ_EXTERNAL32 = 0, 1
+(TB_E, TB_DV, TB_L1, TB_FINAL, TB_DIR, TB_T0, TB_T1, TB_T2, TB_RGB, TB_SIG, TB_TH, TB_END) = (0, 1, 2, 10, 11, 12, 13, 14, 15, 16,
+                                                                                              17, 18)
 COMP_TRANSIENT, COMP_STATIC_ONLY, COMP_SIGMA_ONLY, COMP_WHITE_BKGD = 1, 2, 4, 8
 
 _p, _i, _f, _u32, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t
@@ -59,6 +61,12 @@ SIGNATURES = {
     "nefes_hashgrid_table_entries": (_sz, [C.POINTER(NefesHashGridDesc)]),
     "nefes_hashgrid_fwd": (_i, [C.POINTER(NefesHashGridDesc), _p, C.c_int64, _p, _p, _p]),
     "nefes_hashgrid_bwd_x": (_i, [C.POINTER(NefesHashGridDesc), _p, C.c_int64, _p, _p, _p, _p]),
+    "nefes_train_rows": (_sz, [_desc]),
+    "nefes_train_row_offset": (_i, [_desc, _i]),
+    "nefes_field_fwd_train": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_train_head_grad": (_i, [_desc, _i, _i, _i, _p, _p, _p, _p]),
+    "nefes_train_dx": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
+    "nefes_train_dw": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p]),
     "nefes_bicubic_up_fwd": (_i, [C.c_int64, _i, _i, _i, _i, _p, _p, _p]),
     "nefes_bicubic_up_bwd": (_i, [C.c_int64, _i, _i, _i, _i, _p, _p, _p, _p]),
     "nefes_sample_pdf_merge": (_i, [_i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),

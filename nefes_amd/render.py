@@ -50,14 +50,22 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
     N = rays_o.shape[0]
     dev = rays_o.device
     Nc, Ni = cfg.N_samples, cfg.N_importance
-    if torch.is_grad_enabled():
-        for net in (network_fn, network_fine):
-            if net is not None and any(p.requires_grad for n, p in net.named_parameters()
-                                       if not n.startswith(("fusion_net", "exposure_embedding"))):
-                raise NotImplementedError(
-                    "nefes_amd: the HIP field kernels differentiate w.r.t. the rays/pose only (frozen weights, as in "
-                    "the refinement loop: DFM_APR_refine.py:192-193). Call requires_grad_(False) on the NeRF modules; "
-                    "the dW (training) kernels are a later row of SURVEY.md §8f.")
+    # Trainable NeRF weights (run_nefes.py) go through the train-mode instances: forward with saved pre-activations and
+    # the weight-gradient kernels of csrc/train.hip.  Frozen weights (refinement loop, DFM_APR_refine.py:192-193) use the
+    # fused backward-to-rays path.
+    def trainable(net):
+        return (torch.is_grad_enabled() and net is not None
+                and any(p.requires_grad for n, p in net.named_parameters()
+                        if not n.startswith(("fusion_net", "exposure_embedding"))))
+
+    def field(net, pk, mode, z_):
+        if trainable(net) and mode != L.FIELD_SIGMA:
+            if cfg.xyz_encoder is not None:
+                raise NotImplementedError("nefes_amd: train mode is built for the frequency embedding only")
+            from . import train as T
+            return T.field_train(net, mode, rays_o, rays_d, viewdirs, z_)
+        return _field(pk, mode, rays_o, rays_d, viewdirs, z_, cfg.xyz_encoder)
+
     t_rand = torch.rand(N, Nc, device=dev) if cfg.perturb > 0. else None            # :110 (RNG stays in torch)
     z = ops.coarse_depths(N, Nc, near, far, cfg.lindisp, t_rand, device=dev)
     store_rgb = (Ni == 0)
@@ -72,7 +80,7 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
             _, _, _, acc0, _, w0, _ = ops.composite_fwd(raw_c, z, C, L.COMP_SIGMA_ONLY)
         rgb0 = feat0 = disp0 = None
     else:
-        raw_c = _field(pk_c, L.FIELD_STATIC, rays_o, rays_d, viewdirs, z, cfg.xyz_encoder)
+        raw_c = field(network_fn, pk_c, L.FIELD_STATIC, z)
         if cfg.raw_noise_std > 0.:
             noise = torch.zeros_like(raw_c)
             noise[:, 3 + C] = torch.randn(N, Nc, device=dev) * cfg.raw_noise_std
@@ -92,7 +100,7 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
     z_f = z_samples if cfg.use_fine_only else z_fine
     pk_f = network_fine.packed()
     mode = L.FIELD_FULL if cfg.NeRFW else L.FIELD_STATIC
-    raw_f = _field(pk_f, mode, rays_o, rays_d, viewdirs, z_f, cfg.xyz_encoder)
+    raw_f = field(network_fine, pk_f, mode, z_f)
     flags = 0
     if cfg.NeRFW:
         flags |= L.COMP_TRANSIENT

@@ -1,0 +1,213 @@
+"""Train mode of the field MLP: forward with saved pre-activations + weight gradients.
+
+What `loss.backward()` does in script/run_nefes.py:42-108 for the NeRF weights, on the HIP path:
+
+    forward   nefes_field_fwd_train   the fused forward kernel (TRAIN instance) also writes every hidden layer's
+                                      pre-activation and both embeddings to `acts` [tiles][rows][128]
+    backward  nefes_train_head_grad   d raw -> head pre-activation gradients
+              nefes_train_dx          G_{l-1} = relu'(pre_{l-1}) * W_l^T G_l, layer by layer (MFMA)
+              nefes_train_dw          dW_l = G_l act(X_{l-1})^T over all samples (MFMA, split over sample tiles)
+              bias gradients          row sums of `dacts`
+
+The layer graph below is the reference's NeRFH_NFF.forward (models/nerfh_nff.py:525-576): trunk 1..8 with the
+skip `cat([input_xyz, h])` at layer 5, static_sigma on h8, xyz_encoding_final (no activation),
+dir_encoding / transient_encoding.0 on `cat([final, dir_emb])`, static_rgb, transient_encoding.{2,4}, transient heads.
+Gradients w.r.t. the rays are not produced here (training rays are data; the pose-refinement path uses field_bwd).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from . import ops
+
+EMB_XYZ, EMB_DIR = 63, 27
+DEBUG = None          # tests may set this to a dict to receive the acts / dacts buffers of the last backward pass
+
+
+def _emb_slot(n_freq, s, h):
+    """layout.h nefes_emb_slot: embedding slot (s, h) -> index in the reference's embedding order, -1 = padding."""
+    if s < 3 * n_freq:
+        return 3 + 6 * (s // 3) + 3 * h + (s % 3)
+    if s == 3 * n_freq:
+        return h
+    if s == 3 * n_freq + 1:
+        return 2 if h == 0 else -1
+    return -1
+
+
+def _slot_rows(n_freq, n_rows, n_nat, device):
+    """index tensor: natural embedding feature -> row of the slot-ordered block."""
+    idx = [-1] * n_nat
+    for row in range(n_rows):
+        k = _emb_slot(n_freq, row // 2, row % 2)
+        if k >= 0:
+            idx[k] = row
+    assert min(idx) >= 0
+    return torch.tensor(idx, device=device)
+
+
+def _pad_t(w, n_in_pad, k_pad):
+    """[out, in] weight -> transposed, zero-padded [n_in_pad, k_pad] contiguous (A operand of nefes_train_dx)."""
+    out, inn = w.shape
+    wt = torch.zeros(n_in_pad, k_pad, device=w.device, dtype=torch.float32)
+    wt[:inn, :out] = w.detach().t()
+    return wt
+
+
+class _Pass:
+    def __init__(self, net, desc, n_tiles, acts, dacts):
+        self.lib, self.desc, self.n_tiles = L.load(), desc, n_tiles
+        self.acts, self.dacts = acts, dacts
+        self.rows = int(self.lib.nefes_train_rows(C.byref(desc)))
+        self.off = lambda b: int(self.lib.nefes_train_row_offset(C.byref(desc), b))
+        self.stream = ops._stream()
+        self.dev = acts.device
+        want = 8192                                                   # waves per dW launch
+        self.scratch = None
+        self.want = want
+
+    def dx(self, g_block, n_out, w, n_in, dst_block, accumulate, mask, g_rows=None):
+        k = (n_out + 7) // 8 * 8
+        wt = _pad_t(w, n_in, k)
+        L.check(self.lib.nefes_train_dx(self.n_tiles, self.rows, self.dacts.data_ptr(), self.off(g_block), k, wt.data_ptr(), k,
+                                        n_in, self.acts.data_ptr(), self.off(dst_block), int(accumulate), int(mask),
+                                        self.dacts.data_ptr(), self.stream), "nefes_train_dx")
+        return wt                                                     # kept alive by the caller until the stream is done
+
+    def dw(self, g_block, n_out, x_block, n_in, relu):
+        """-> [n_out_pad, n_in_pad] = sum_s G[o][s] f(X[i][s])"""
+        op, ip = (n_out + 31) // 32 * 32, (n_in + 31) // 32 * 32
+        blocks = max(1, (op // 32) * (ip // 32) // 8)
+        splits = max(1, min(self.n_tiles, self.want // blocks))
+        partial = torch.empty(splits, op, ip, device=self.dev)
+        L.check(self.lib.nefes_train_dw(self.n_tiles, self.rows, self.dacts.data_ptr(), self.off(g_block), op,
+                                        self.acts.data_ptr(), self.off(x_block), ip, int(relu), splits, partial.data_ptr(),
+                                        self.stream), "nefes_train_dw")
+        return partial.sum(0)
+
+
+def param_names(net, mode):
+    names = [f"xyz_encoding_{i}.0" for i in range(1, 9)] + ["xyz_encoding_final", "dir_encoding.0", "static_sigma.0",
+                                                             "static_rgb.0"]
+    if mode == L.FIELD_FULL:
+        names += ["transient_encoding.0", "transient_encoding.2", "transient_encoding.4", "transient_sigma.0",
+                  "transient_rgb.0", "transient_beta.0"]
+    return [n + s for n in names for s in (".weight", ".bias")]
+
+
+def weight_grads(net, pk, mode, N, S, raw_t, g_raw_t, acts):
+    """-> dict parameter name -> gradient (fp32, parameter shape) for every parameter on the path of `mode`."""
+    lib, desc = L.load(), pk.desc
+    W, Cf = net.W, net.W_features
+    C3, H2 = 3 + Cf, W // 2
+    full = mode == L.FIELD_FULL
+    n_tiles = acts.shape[0]
+    dacts = torch.empty_like(acts)
+    L.check(lib.nefes_train_head_grad(C.byref(desc), mode, N, S, raw_t.data_ptr(), g_raw_t.data_ptr(), dacts.data_ptr(),
+                                      ops._stream()), "nefes_train_head_grad")
+    P = _Pass(net, desc, n_tiles, acts, dacts)
+    sd = dict(net.named_parameters())
+    w = lambda name: sd[name + ".weight"]
+    keep = []
+    TB = lambda l: L.TB_L1 + (l - 1)
+    # ---- backward through the layers: dacts rows of every hidden block become d loss / d pre-activation ----
+    if full:
+        w_th = torch.cat([w("transient_rgb.0"), w("transient_sigma.0"), w("transient_beta.0")], 0)     # raw channel order
+        keep.append(P.dx(L.TB_TH, 5, w_th, H2, L.TB_T2, False, True))
+        keep.append(P.dx(L.TB_T2, H2, w("transient_encoding.4"), H2, L.TB_T1, False, True))
+        keep.append(P.dx(L.TB_T1, H2, w("transient_encoding.2"), H2, L.TB_T0, False, True))
+    keep.append(P.dx(L.TB_RGB, C3, w("static_rgb.0"), H2, L.TB_DIR, False, True))
+    keep.append(P.dx(L.TB_DIR, H2, w("dir_encoding.0")[:, :W], W, L.TB_FINAL, False, False))
+    if full:
+        keep.append(P.dx(L.TB_T0, H2, w("transient_encoding.0")[:, :W], W, L.TB_FINAL, True, False))
+    keep.append(P.dx(L.TB_FINAL, W, w("xyz_encoding_final"), W, TB(8), False, False))
+    keep.append(P.dx(L.TB_SIG, 1, w("static_sigma.0"), W, TB(8), True, True))
+    for l in range(8, 1, -1):
+        wl = w(f"xyz_encoding_{l}.0")
+        keep.append(P.dx(TB(l), W, wl[:, EMB_XYZ:] if l == 5 else wl, W, TB(l - 1), False, True))
+    # ---- weight gradients ----
+    e_idx = _slot_rows(10, 64, EMB_XYZ, acts.device)
+    d_idx = _slot_rows(4, 28, EMB_DIR, acts.device)
+    g = {}
+    g["xyz_encoding_1.0.weight"] = P.dw(TB(1), W, L.TB_E, 64, False)[:W][:, e_idx]
+    for l in range(2, 9):
+        dh = P.dw(TB(l), W, TB(l - 1), W, True)[:W, :W]
+        if l == 5:
+            dh = torch.cat([P.dw(TB(5), W, L.TB_E, 64, False)[:W][:, e_idx], dh], 1)
+        g[f"xyz_encoding_{l}.0.weight"] = dh
+    g["static_sigma.0.weight"] = P.dw(L.TB_SIG, 1, TB(8), W, True)[:1, :W]
+    g["xyz_encoding_final.weight"] = P.dw(L.TB_FINAL, W, TB(8), W, True)[:W, :W]
+    g["dir_encoding.0.weight"] = torch.cat([P.dw(L.TB_DIR, H2, L.TB_FINAL, W, False)[:H2, :W],
+                                            P.dw(L.TB_DIR, H2, L.TB_DV, 32, False)[:H2][:, d_idx]], 1)
+    g["static_rgb.0.weight"] = P.dw(L.TB_RGB, C3, L.TB_DIR, H2, True)[:C3, :H2]
+    if full:
+        g["transient_encoding.0.weight"] = torch.cat([P.dw(L.TB_T0, H2, L.TB_FINAL, W, False)[:H2, :W],
+                                                      P.dw(L.TB_T0, H2, L.TB_DV, 32, False)[:H2][:, d_idx]], 1)
+        g["transient_encoding.2.weight"] = P.dw(L.TB_T1, H2, L.TB_T0, H2, True)[:H2, :H2]
+        g["transient_encoding.4.weight"] = P.dw(L.TB_T2, H2, L.TB_T1, H2, True)[:H2, :H2]
+        d_th = P.dw(L.TB_TH, 5, L.TB_T2, H2, True)[:5, :H2]
+        g["transient_rgb.0.weight"], g["transient_sigma.0.weight"], g["transient_beta.0.weight"] = d_th[:3], d_th[3:4], d_th[4:5]
+    # ---- bias gradients: row sums over all samples ----
+    lo, hi = P.off(L.TB_L1), P.off(L.TB_END if full else L.TB_TH)
+    db = torch.zeros(P.rows, device=acts.device)
+    db[lo:hi] = dacts[:, lo:hi, :].sum((0, 2))
+    blk = lambda b, n: db[P.off(b):P.off(b) + n]
+    for l in range(1, 9):
+        g[f"xyz_encoding_{l}.0.bias"] = blk(TB(l), W)
+    g["xyz_encoding_final.bias"], g["dir_encoding.0.bias"] = blk(L.TB_FINAL, W), blk(L.TB_DIR, H2)
+    g["static_sigma.0.bias"], g["static_rgb.0.bias"] = blk(L.TB_SIG, 1), blk(L.TB_RGB, C3)
+    if full:
+        g["transient_encoding.0.bias"], g["transient_encoding.2.bias"] = blk(L.TB_T0, H2), blk(L.TB_T1, H2)
+        g["transient_encoding.4.bias"] = blk(L.TB_T2, H2)
+        th = blk(L.TB_TH, 5)
+        g["transient_rgb.0.bias"], g["transient_sigma.0.bias"], g["transient_beta.0.bias"] = th[:3], th[3:4], th[4:5]
+    if DEBUG is not None:
+        DEBUG.update(acts=acts, dacts=dacts, rows=P.rows, off={b: P.off(b) for b in range(19)})
+    del keep
+    return g
+
+
+class FieldTrain(torch.autograd.Function):
+    """raw_t [N,R,S] of the field at samples z along the rays, differentiable w.r.t. the network parameters
+    (passed as *params in `param_names` order so autograd routes their gradients)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, viewdirs, z, net, mode, *params):
+        pk = net.packed()
+        lib = L.load()
+        if mode not in (L.FIELD_STATIC, L.FIELD_FULL):
+            raise ValueError("nefes_amd: train mode evaluates the static or the full head")
+        o, d, v, zz = ops._f32(rays_o), ops._f32(rays_d), ops._f32(viewdirs), ops._f32(z)
+        N, S = zz.shape
+        R = 3 + pk.feat_dim + (1 if mode == L.FIELD_STATIC else 6)
+        n_tiles = (N * S + 127) // 128
+        rows = int(lib.nefes_train_rows(C.byref(pk.desc)))
+        raw_t = torch.empty(N, R, S, device=zz.device)
+        acts = torch.empty(n_tiles, rows, 128, device=zz.device)
+        with ops._timed("field_fwd_train"):
+            L.check(lib.nefes_field_fwd_train(C.byref(pk.desc), pk.blob.data_ptr(), mode, N, S, ops._chk(o, "rays_o"),
+                                              ops._chk(d, "rays_d"), ops._chk(zz, "z"), None, ops._chk(v, "viewdirs"),
+                                              raw_t.data_ptr(), acts.data_ptr(), ops._stream()), "nefes_field_fwd_train")
+        ctx.save_for_backward(raw_t, acts)
+        if DEBUG is not None:
+            DEBUG.update(acts=acts, rows=rows, off={b: int(lib.nefes_train_row_offset(C.byref(pk.desc), b)) for b in range(19)})
+        ctx.net, ctx.pk, ctx.mode, ctx.NS = net, pk, mode, (N, S)
+        return raw_t
+
+    @staticmethod
+    def backward(ctx, g_raw_t):
+        if any(ctx.needs_input_grad[:4]):
+            raise NotImplementedError("nefes_amd: the train-mode pass produces weight gradients only; gradients w.r.t. the "
+                                      "rays come from the refinement path (frozen weights, ops.FieldFromRays)")
+        raw_t, acts = ctx.saved_tensors
+        N, S = ctx.NS
+        with ops._timed("field_bwd_train"):
+            g = weight_grads(ctx.net, ctx.pk, ctx.mode, N, S, raw_t, ops._f32(g_raw_t), acts)
+        names = param_names(ctx.net, ctx.mode)
+        return (None,) * 6 + tuple(g[n].contiguous() for n in names)
+
+
+def field_train(net, mode, rays_o, rays_d, viewdirs, z):
+    sd = dict(net.named_parameters())
+    return FieldTrain.apply(rays_o, rays_d, viewdirs, z, net, mode, *[sd[n] for n in param_names(net, mode)])
