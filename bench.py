@@ -121,6 +121,50 @@ def refinement_loop(dev, iters=50, graph=True):
     return (time.perf_counter() - t0) / n_img, iters * H * W
 
 
+def train_steps(dev, steps=10, warmup=2):
+    """BASELINE configs[0] on the HIP path: stage-1 colour-only training step of script/run_nefes.py:42-108 --
+    200x200 crop (40 000 rays), 64 coarse samples, N_importance=0, reference-default net (8x128, C=128), stratified
+    jitter, img2mse loss, backward to the NeRF weights, Adam step.  Returns (seconds per step, rays per step, kernel ms)."""
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    from nefes_amd.render import render
+    from oracle import ref_cpu as O
+    H = W = 200
+    focal, Wd, C = 525.505 * 200 / 480, 128, 128
+    coarse = NeRFH_NFF('coarse', W=Wd, f_dim=C).to(dev)
+    prm = [p for n, p in coarse.named_parameters() if not n.startswith(("fusion_net", "exposure_embedding"))]
+    opt = torch.optim.Adam(prm, lr=5e-4, betas=(0.9, 0.999))
+    args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True, netchunk=1024)
+    kw = dict(network_query_fn=None, perturb=1., N_importance=0, N_samples=64, network_fn=coarse, network_fine=None,
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=False, args=args, ndc=False, lindisp=False)
+    c2w = O.bench_pose()
+    ro, rd = O.ray_bundle(H, W, focal, c2w)
+    ro, rd = ro.reshape(-1, 3).to(dev), rd.reshape(-1, 3).to(dev)
+    target = torch.rand(H * W, 3, device=dev)
+    losses = []
+
+    def step():
+        rgb, _, _, _ = render(H, W, focal, rays=(ro, rd), near=0., far=4., **kw)
+        loss = ((rgb - target) ** 2).mean()                              # img2mse
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ops.TIMERS = {}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    timers, ops.TIMERS = ops.TIMERS, None
+    kern = {k: round(sum(s.elapsed_time(e) for s, e in v) / len(v), 4) for k, v in timers.items()}
+    return dt, H * W, kern, [float(l) for l in (losses[0], losses[-1])]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +173,7 @@ def main():
     ap.add_argument("--height", type=int, default=0, help="override the workload's frame height (debugging)")
     ap.add_argument("--width", type=int, default=0, help="override the workload's frame width (debugging)")
     ap.add_argument("--cpu-rows", type=int, default=4, help="rows of the frame timed on the host cores (0 = skip)")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["loop50"], default="metric")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["loop50", "train"], default="metric")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -150,6 +194,18 @@ def main():
     from nefes_amd.render import render
     from oracle import ref_cpu as O        # bench_pose()/bench_loss() definitions only; the CPU leg is cpu_baseline()
 
+    if a.workload == "train":
+        sec, rays, kern, ls = train_steps(dev)
+        # weight-gradient training step: forward + dX + dW = 3 x the forward MACs of the static coarse net
+        flop = 3 * 2 * (130944 + 128 * 128 + (128 + 27) * 64 + 64 * 131) * rays * 64
+        print(json.dumps({"metric": "rays/s (training step), secondary workload 'train'", "value": rays / sec, "unit": "rays/s",
+                          "n_gpus": 1, "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+                          "ms_per_step": sec * 1e3, "kernels_ms": kern, "loss_first_last": ls,
+                          "algorithmic_tflops": flop / sec / 1e12,
+                          "config": {"workload": "BASELINE configs[0] on the HIP path: stage-1 colour-only training step, 200x200 "
+                                                 "crop, 64 coarse samples, N_importance=0, 8x128 net with 128-ch feature head, "
+                                                 "perturb=1, img2mse, backward to weights, Adam"}}), flush=True)
+        return
     if a.workload == "loop50":
         sec_e, rays = refinement_loop(dev, graph=False)
         sec, rays = refinement_loop(dev, graph=True)

@@ -119,28 +119,33 @@ __global__ __launch_bounds__(64) void train_dw_kernel(int n_tiles, int rows, con
     for (int tile = t_lo; tile < t_hi; ++tile) {
         const float* g = gbuf + (size_t)tile * rows * 128 + go;
         const float* x = xbuf + (size_t)tile * rows * 128 + xo;
-#pragma unroll 4
-        for (int q = 0; q < 16; ++q) {
-            float4 a[NTO], b[NTI];
-#pragma unroll
-            for (int to = 0; to < NTO; ++to) a[to] = *(const float4*)(g + (size_t)32 * to * 128 + 8 * q);
-#pragma unroll
-            for (int ti = 0; ti < NTI; ++ti) {
-                b[ti] = *(const float4*)(x + (size_t)32 * ti * 128 + 8 * q);
-                if (x_relu) {
-                    b[ti].x = fmaxf(b[ti].x, 0.f); b[ti].y = fmaxf(b[ti].y, 0.f);
-                    b[ti].z = fmaxf(b[ti].z, 0.f); b[ti].w = fmaxf(b[ti].w, 0.f);
-                }
-            }
+        // one 128-byte line of every row per step (4 x 16 bytes per lane issued together, so each line is fetched once)
+#pragma unroll 1
+        for (int line = 0; line < 4; ++line) {
+            float4 a[NTO][4], b[NTI][4];
 #pragma unroll
             for (int to = 0; to < NTO; ++to)
 #pragma unroll
-                for (int ti = 0; ti < NTI; ++ti) {
-                    acc[to][ti] = mfma2(a[to].x, b[ti].x, acc[to][ti]);
-                    acc[to][ti] = mfma2(a[to].y, b[ti].y, acc[to][ti]);
-                    acc[to][ti] = mfma2(a[to].z, b[ti].z, acc[to][ti]);
-                    acc[to][ti] = mfma2(a[to].w, b[ti].w, acc[to][ti]);
+                for (int u = 0; u < 4; ++u) a[to][u] = *(const float4*)(g + (size_t)32 * to * 128 + 32 * line + 8 * u);
+#pragma unroll
+            for (int ti = 0; ti < NTI; ++ti)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float4 v = *(const float4*)(x + (size_t)32 * ti * 128 + 32 * line + 8 * u);
+                    if (x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    b[ti][u] = v;
                 }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int to = 0; to < NTO; ++to)
+#pragma unroll
+                    for (int ti = 0; ti < NTI; ++ti) {
+                        acc[to][ti] = mfma2(a[to][u].x, b[ti][u].x, acc[to][ti]);
+                        acc[to][ti] = mfma2(a[to][u].y, b[ti][u].y, acc[to][ti]);
+                        acc[to][ti] = mfma2(a[to][u].z, b[ti][u].z, acc[to][ti]);
+                        acc[to][ti] = mfma2(a[to][u].w, b[ti][u].w, acc[to][ti]);
+                    }
         }
     }
     float* out = partial + (size_t)sp * n_out_pad * n_in_pad + (size_t)(32 * NTO * ob + 4 * kh) * n_in_pad + 32 * NTI * ib + m;

@@ -60,12 +60,13 @@ class _Pass:
         self.lib, self.desc, self.n_tiles = L.load(), desc, n_tiles
         self.acts, self.dacts = acts, dacts
         self.rows = int(self.lib.nefes_train_rows(C.byref(desc)))
-        self.off = lambda b: int(self.lib.nefes_train_row_offset(C.byref(desc), b))
+        self.offsets = [int(self.lib.nefes_train_row_offset(C.byref(desc), b)) for b in range(L.TB_END + 1)]
         self.stream = ops._stream()
         self.dev = acts.device
-        want = 8192                                                   # waves per dW launch
-        self.scratch = None
-        self.want = want
+        self.want = 8192                                              # waves per dW launch
+
+    def off(self, block):                                             # (a method, not a closure: no reference cycle
+        return self.offsets[block]                                    #  may keep the multi-GB buffers alive)
 
     def dx(self, g_block, n_out, w, n_in, dst_block, accumulate, mask, g_rows=None):
         k = (n_out + 7) // 8 * 8
