@@ -162,7 +162,23 @@ def train_steps(dev, steps=10, warmup=2):
     dt = (time.perf_counter() - t0) / steps
     timers, ops.TIMERS = ops.TIMERS, None
     kern = {k: round(sum(s.elapsed_time(e) for s, e in v) / len(v), 4) for k, v in timers.items()}
-    return dt, H * W, kern, [float(l) for l in (losses[0], losses[-1])]
+    # CPU oracle on a bounded slice of the same step (reference settings: netchunk=1024 slices, autograd to the weights)
+    th = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(th)
+    pc = {k: v.requires_grad_() for k, v in O.make_field_params("coarse", Wd, C).items()}
+    cfg = O.RenderCfg(N_samples=64, N_importance=0, perturb=1., test_time=False, netchunk=1024)
+    n_cpu = 20 * W
+    copt = torch.optim.Adam(list(pc.values()), lr=5e-4)
+    roc, rdc, tc = ro[:n_cpu].cpu(), rd[:n_cpu].cpu(), target[:n_cpu].cpu()
+    t0 = time.perf_counter()
+    rgb, _, _, _ = O.render(H, W, focal, pc, None, cfg, rays=(roc, rdc), near=0., far=4.)
+    copt.zero_grad()
+    ((rgb - tc) ** 2).mean().backward()
+    copt.step()
+    dtc = time.perf_counter() - t0
+    cpu = {"value": n_cpu / dtc, "unit": "rays/s", "cores": th, "kind": "port",
+           "sample": f"{n_cpu} rays of the same step (netchunk=1024), torch {torch.__version__} CPU, {dtc:.1f} s"}
+    return dt, H * W, kern, [float(l) for l in (losses[0], losses[-1])], cpu
 
 
 def main():
@@ -195,13 +211,13 @@ def main():
     from oracle import ref_cpu as O        # bench_pose()/bench_loss() definitions only; the CPU leg is cpu_baseline()
 
     if a.workload == "train":
-        sec, rays, kern, ls = train_steps(dev)
+        sec, rays, kern, ls, cpu = train_steps(dev)
         # weight-gradient training step: forward + dX + dW = 3 x the forward MACs of the static coarse net
         flop = 3 * 2 * (130944 + 128 * 128 + (128 + 27) * 64 + 64 * 131) * rays * 64
         print(json.dumps({"metric": "rays/s (training step), secondary workload 'train'", "value": rays / sec, "unit": "rays/s",
                           "n_gpus": 1, "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
                           "ms_per_step": sec * 1e3, "kernels_ms": kern, "loss_first_last": ls,
-                          "algorithmic_tflops": flop / sec / 1e12,
+                          "algorithmic_tflops": flop / sec / 1e12, "cpu_baseline": cpu,
                           "config": {"workload": "BASELINE configs[0] on the HIP path: stage-1 colour-only training step, 200x200 "
                                                  "crop, 64 coarse samples, N_importance=0, 8x128 net with 128-ch feature head, "
                                                  "perturb=1, img2mse, backward to weights, Adam"}}), flush=True)

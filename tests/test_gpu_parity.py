@@ -324,12 +324,16 @@ def test_render_end_to_end_vs_reference(golden, tag):
         assert direct <= max(1e-4, 4 * e_ref)
 
 
-def test_render_requires_frozen_weights():
+def test_joint_pose_and_weight_gradients_fail_loudly():
+    """Trainable weights take the train-mode path (weight gradients, tests/test_gpu_train.py); asking for the pose
+    gradient through it as well is not built and must raise instead of silently returning no gradient."""
     R, M = _dropin()
     coarse, fine = _modules(128, 128)
     fine.requires_grad_(True)
-    with pytest.raises(NotImplementedError, match="frozen weights"):
-        R.render(4, 4, 3.0, c2w=O.bench_pose().to(DEV), near=0., far=4., **_kwargs(M, coarse, fine, 64, True))
+    c2w = O.bench_pose().to(DEV).requires_grad_()
+    rgb, _, _, _ = R.render(4, 4, 3.0, c2w=c2w, near=0., far=4., **_kwargs(M, coarse, fine, 64, True))
+    with pytest.raises(NotImplementedError, match="weight gradients only"):
+        rgb.sum().backward()
 
 
 def test_full_size_properties(ops, L):

@@ -135,3 +135,28 @@ def test_render_train_mode_weight_grads(Wd, C, Ni):
                 assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.9995, n
                 checked += 1
     assert checked >= 24
+
+
+def test_training_steps_reduce_loss():
+    """A few Adam steps of the stage-1 colour loss through render() (run_nefes.py:42-108): the packed weight streams are
+    rebuilt after every optimiser step (NeRFH_NFF.packed() keys on the parameters' versions) and the loss goes down."""
+    from nefes_amd.render import render
+    H, W, focal = 16, 16, 24.0
+    coarse = _net("coarse", 128, 128)
+    prm = [p for n, p in coarse.named_parameters() if not n.startswith(("fusion_net", "exposure_embedding"))]
+    opt = torch.optim.Adam(prm, lr=5e-4)
+    args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True)
+    kw = dict(network_query_fn=None, perturb=1., N_importance=0, N_samples=32, network_fn=coarse, network_fine=None,
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=False, args=args, ndc=False, lindisp=False)
+    ro, rd = O.ray_bundle(H, W, focal, O.bench_pose())
+    ro, rd = ro.reshape(-1, 3).to(DEV), rd.reshape(-1, 3).to(DEV)
+    target = torch.rand(H * W, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    losses = []
+    for _ in range(8):
+        rgb, _, _, ex = render(H, W, focal, rays=(ro, rd), near=0., far=4., **kw)
+        loss = ((rgb - target) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.9 * losses[0], losses
