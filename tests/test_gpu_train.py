@@ -160,3 +160,43 @@ def test_training_steps_reduce_loss():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.9 * losses[0], losses
+
+
+@pytest.mark.parametrize("tag", ["stage1", "full"])
+def test_train_mode_vs_reference_golden(golden, tag):
+    """The HIP train path against tensors captured from the reference itself (tools/make_goldens.py, train.npz):
+    maps and train extras within 2e-5; weight gradients with the kink-tolerant bound (see above)."""
+    import numpy as np
+    from nefes_amd.render import render
+    g = golden("train")
+    Wd, C, Nc, Ni, H, W, focal = g[f"{tag}.cfg"]
+    Wd, C, Nc, Ni, H, W = int(Wd), int(C), int(Nc), int(Ni), int(H), int(W)
+    coarse, fine = _net("coarse", Wd, C), _net("fine", Wd, C)
+    args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True)
+    kw = dict(network_query_fn=None, perturb=0., N_importance=Ni, N_samples=Nc, network_fn=coarse, network_fine=fine,
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=False, args=args, ndc=False, lindisp=False)
+    rays_o, rays_d = O.ray_bundle(H, W, float(focal), torch.from_numpy(g[f"{tag}.c2w"])[:3, :4])
+    rgb, disp, acc, ex = render(H, W, float(focal), rays=(rays_o.to(DEV), rays_d.to(DEV)), near=0., far=4., **kw)
+    rel = lambda a, b: float(np.abs(a.detach().cpu().numpy() - b).max() / max(np.abs(b).max(), 1e-12))
+    assert rel(rgb, g[f"{tag}.rgb"]) < 2e-5 and rel(acc, g[f"{tag}.acc"]) < 2e-5
+    for k in [k for k in g if k.startswith(f"{tag}.ex.")]:
+        assert rel(ex[k.split(".ex.")[1]], g[k]) < 5e-5, k
+    t_rgb, t_feat = torch.from_numpy(g[f"{tag}.t_rgb"]).to(DEV), torch.from_numpy(g[f"{tag}.t_feat"]).to(DEV)
+    loss = ((rgb - t_rgb) ** 2).mean() + ((ex["feat_map"] - t_feat) ** 2).mean()
+    if Ni > 0:
+        loss = loss + ((ex["rgb0"] - t_rgb) ** 2).mean()
+    assert abs(float(loss.detach()) - float(g[f"{tag}.loss"])) < 1e-5 * float(g[f"{tag}.loss"])
+    loss.backward()
+    n = 0
+    for k in [k for k in g if k.startswith(f"{tag}.grad.")]:
+        _, _, net, name = k.split(".", 3)
+        got = dict((coarse if net == "coarse" else fine).named_parameters())[name].grad
+        assert got is not None, k
+        a, b = got.detach().cpu().double().reshape(-1), torch.from_numpy(g[k]).double().reshape(-1)
+        if float(b.abs().max()) == 0.:                                # e.g. transient_beta: beta is not in this loss
+            assert float(a.abs().max()) == 0., k
+            continue
+        assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) < 3e-2, k
+        assert float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30)) > 0.9995, k
+        n += 1
+    assert n >= 19

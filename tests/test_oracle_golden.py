@@ -144,3 +144,36 @@ def test_end_to_end(golden, tag):
     sc1, sc2 = np.abs(g[f"{tag}.g_c2w_loss"]).max(), np.abs(g[f"{tag}.g_c2w_lin"]).max()
     assert np.abs(g1.numpy() - g[f"{tag}.g_c2w_loss"]).max() <= 2e-5 * sc1
     assert np.abs(g2.numpy() - g[f"{tag}.g_c2w_lin"]).max() <= 2e-5 * sc2
+
+
+@pytest.mark.parametrize("tag", ["stage1", "full"])
+def test_train_mode(golden, tag):
+    """Train mode of the reference (test_time=False, perturb=0, trainable weights): maps, train extras
+    (rendering.py:160-173) and loss.backward() to the NeRF parameters (run_nefes.py:42-108)."""
+    g = golden("train")
+    Wd, C, Nc, Ni, H, W, focal = g[f"{tag}.cfg"]
+    Wd, C, Nc, Ni, H, W = int(Wd), int(C), int(Nc), int(Ni), int(H), int(W)
+    pc = {k: v.requires_grad_() for k, v in O.make_field_params("coarse", Wd, C).items()}
+    pf = {k: v.requires_grad_() for k, v in O.make_field_params("fine", Wd, C).items()}
+    cfg = O.RenderCfg(N_samples=Nc, N_importance=Ni, perturb=0., test_time=False, transient_at_test=True)
+    rays_o, rays_d = O.ray_bundle(H, W, float(focal), T(g[f"{tag}.c2w"])[:3, :4])
+    rgb, disp, acc, ex = O.render(H, W, float(focal), pc, pf, cfg, rays=(rays_o, rays_d), near=0., far=4.,
+                                  hist=torch.full((1, 10), 10.))
+    close(rgb, g[f"{tag}.rgb"], rtol=1e-5, atol=1e-6)
+    close(acc, g[f"{tag}.acc"], rtol=1e-5)
+    for k in [k for k in g if k.startswith(f"{tag}.ex.")]:
+        close(ex[k.split(".ex.")[1]], g[k], rtol=2e-5, atol=2e-6)
+    t_rgb, t_feat = T(g[f"{tag}.t_rgb"]), T(g[f"{tag}.t_feat"])
+    loss = ((rgb - t_rgb) ** 2).mean() + ((ex["feat_map"] - t_feat) ** 2).mean()
+    if Ni > 0:
+        loss = loss + ((ex["rgb0"] - t_rgb) ** 2).mean()
+    assert abs(float(loss) - float(g[f"{tag}.loss"])) < 1e-6 * float(g[f"{tag}.loss"])
+    loss.backward()
+    n = 0
+    for k in [k for k in g if k.startswith(f"{tag}.grad.")]:
+        _, _, net, name = k.split(".", 3)
+        got = (pc if net == "coarse" else pf)[name].grad
+        assert got is not None, k
+        assert np.abs(got.numpy() - g[k]).max() <= 2e-5 * max(np.abs(g[k]).max(), 1e-12), k
+        n += 1
+    assert n >= 19

@@ -270,6 +270,34 @@ def main():
                   f"{tag}.g_c2w_lin": npy(g2)})
         print(tag, "loss", float(loss), "|g|", float(g1.abs().max()))
     np.savez_compressed(os.path.join(OUT, "end_to_end.npz"), **d)
+
+    # ---- train mode: test_time=False, trainable weights, loss.backward() to the NeRF parameters (run_nefes.py:42-108) ----
+    d = {}
+    KEEP = ("xyz_encoding_1.0.weight", "xyz_encoding_5.0.weight", "xyz_encoding_8.0.weight", "static_sigma.0.weight",
+            "static_rgb.0.weight", "dir_encoding.0.weight", "xyz_encoding_final.weight", "transient_encoding.0.weight",
+            "transient_encoding.4.weight", "transient_rgb.0.weight", "transient_sigma.0.weight", "transient_beta.0.weight")
+    for tag, Wd, C, Nc, Ni, (H, W) in [("stage1", 128, 128, 32, 0, (4, 6)), ("full", 128, 128, 32, 32, (4, 6))]:
+        coarse, fine = build_nets(M, Wd, C)
+        kw = make_kwargs(M, coarse, fine, Nc, Ni, True, test_time=False, perturb=0.)
+        focal = 525.505 * W / 640.
+        rays_o, rays_d = RU.get_rays(H, W, focal, poses[0][:3, :4])
+        rgb, disp, acc, ex = R.render(H, W, focal, chunk=32768, rays=(rays_o, rays_d), near=0., far=4., img_idx=hist, **kw)
+        t_rgb, t_feat = torch.rand(H * W, 3), rndn(H * W, C)
+        loss = ((rgb - t_rgb) ** 2).mean() + ((ex["feat_map"] - t_feat) ** 2).mean()
+        if "rgb0" in ex:
+            loss = loss + ((ex["rgb0"] - t_rgb) ** 2).mean()
+        loss.backward()
+        d.update({f"{tag}.cfg": np.array([Wd, C, Nc, Ni, H, W, focal]), f"{tag}.c2w": npy(poses[0]), f"{tag}.t_rgb": npy(t_rgb),
+                  f"{tag}.t_feat": npy(t_feat), f"{tag}.loss": np.array(float(loss)), f"{tag}.rgb": npy(rgb),
+                  f"{tag}.disp": npy(disp), f"{tag}.acc": npy(acc)})
+        for k, v in ex.items():
+            d[f"{tag}.ex.{k}"] = npy(v)
+        for name, net in (("coarse", coarse), ("fine", fine)):
+            for k, prm in net.named_parameters():
+                if prm.grad is not None and (k in KEEP or k.endswith(".bias")) and not k.startswith(("fusion", "exposure")):
+                    d[f"{tag}.grad.{name}.{k}"] = npy(prm.grad)
+        print(tag, "loss", float(loss), "extras", sorted(ex.keys()))
+    np.savez_compressed(os.path.join(OUT, "train.npz"), **d)
     print("wrote", sorted(os.listdir(OUT)))
 
 
