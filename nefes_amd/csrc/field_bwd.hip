@@ -26,7 +26,6 @@ struct FieldBwdArgs {
     int n_tiles;
 };
 
-#define NEFES_BWD_SLOTS 6   // 96 KiB weight ring + the tile's ReLU masks staged in LDS (<= 40 KiB)
 
 template <int W, int C3, int ENC>   // C3 = 3 + C; ENC = NEFES_XYZ_*
 __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {

@@ -59,15 +59,18 @@ __device__ __forceinline__ float relu1(float v) {
     return r;
 #endif
 }
-// ReLU-mask words are built by shifting: forward shifts (v > 0) in from the right (v_cmp + v_addc), backward shifts
-// the bits out from the left (v_add_co + v_cndmask).  Both walk a layer's activations in the same order, 32 per word,
-// so the first activation of a word travels to bit 31 and is the first to come back out.
+// ReLU-mask words are built by shifting, one VALU instruction per activation on either side of a word's life:
+// forward shifts the SIGN bit of the pre-activation in from the right (v_alignbit_b32: {word, v} >> 31 = word<<1 | sign),
+// backward shifts the bits out from the left (v_add_co -> carry) and zeroes the gradient where the sign was set
+// (v_cndmask).  Bit = 1 means "pre-activation negative" (relu' = 0).  Both sides walk a layer's activations in the same
+// order, 32 per word, so the first activation of a word travels to bit 31 and is the first to come back out.
+// (A pre-activation of exactly +0.0 passes the gradient where torch's relu' gives 0; -0.0 does not.)
 __device__ __forceinline__ void mask_shift_in(uint32_t& bits, float v) {
-    asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v) : "vcc");
+    asm("v_alignbit_b32 %0, %0, %1, 31" : "+v"(bits) : "v"(v));
 }
 __device__ __forceinline__ float mask_shift_out(uint32_t& bits, float v) {
     float r;
-    asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, 0, %2, vcc\n\ts_nop 1" : "+v"(bits), "=v"(r) : "v"(v) : "vcc");
+    asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, %2, 0, vcc\n\ts_nop 1" : "+v"(bits), "=v"(r) : "v"(v) : "vcc");
     return r;
 }
 
@@ -106,7 +109,7 @@ struct WeightRing {
         const char* s = src + (size_t)g_next * NEFES_SLAB_BYTES;
         const uint32_t d = lds_wave + p_slot * NEFES_SLAB_BYTES;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) lds_dma16(s + q * 4096, lane_off, d + q * 4096);
+        for (int q = 0; q < NEFES_SLAB_PIECES; ++q) lds_dma16(s + q * 4096, lane_off, d + q * 4096);
         g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
         p_slot = (p_slot + 1 == SLOTS) ? 0 : p_slot + 1;
     }
@@ -115,7 +118,7 @@ struct WeightRing {
     // an LDS-DMA issue costs ~60 cycles of the wave's issue slot, which one 64-cycle MFMA in flight covers.
     __device__ __forceinline__ void issue_piece(int q) {
         lds_dma16(src + (size_t)g_next * NEFES_SLAB_BYTES + q * 4096, lane_off, lds_wave + p_slot * NEFES_SLAB_BYTES + q * 4096);
-        if (q == 3) {
+        if (q == NEFES_SLAB_PIECES - 1) {
             g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
             p_slot = (p_slot + 1 == SLOTS) ? 0 : p_slot + 1;
         }
@@ -131,13 +134,13 @@ struct WeightRing {
 #ifdef NEFES_STAMP
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long t0 = now();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (SLOTS - 2)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEFES_SLAB_PIECES * (SLOTS - 2)) : "memory");
         const unsigned long long t1 = now();
         __builtin_amdgcn_s_barrier();
         const unsigned long long t2 = now();
         dbg_wait += t1 - t0; dbg_barrier += t2 - t1;
 #else
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (SLOTS - 2)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEFES_SLAB_PIECES * (SLOTS - 2)) : "memory");
         __builtin_amdgcn_s_barrier();
 #endif
         const uint32_t off = c_slot * NEFES_SLAB_BYTES;
@@ -253,8 +256,8 @@ __device__ __forceinline__ void mma_run(WeightRing<SLOTS>& ring, const char* rin
                 // last group of the slab they go first, because all four must be issued before the next acquire()
                 if (g == ng - 1) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if ((q * ng) / 4 == g) ring.issue_piece(q);
+                    for (int q = 0; q < NEFES_SLAB_PIECES; ++q)
+                        if ((q * ng) / NEFES_SLAB_PIECES == g) ring.issue_piece(q);
                 }
                 f32x4 a_next;
                 if (g + 1 < ng) {
@@ -280,8 +283,8 @@ __device__ __forceinline__ void mma_run(WeightRing<SLOTS>& ring, const char* rin
                     }
                     if (q == 0 && g != ng - 1) {
 #pragma unroll
-                        for (int qq = 0; qq < 4; ++qq)
-                            if ((qq * ng) / 4 == g) {
+                        for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
+                            if ((qq * ng) / NEFES_SLAB_PIECES == g) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 ring.issue_piece(qq);
                                 __builtin_amdgcn_sched_barrier(0);

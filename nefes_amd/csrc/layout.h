@@ -28,9 +28,15 @@
 #define NEFES_HD inline
 #endif
 
-#define NEFES_SLAB_BYTES 16384
-#define NEFES_SLAB_FRAGS 64
-#define NEFES_RING_SLOTS 8
+#ifndef NEFES_SLAB_KIB
+#define NEFES_SLAB_KIB 16           /* slab size: 16 or 32 KiB (one workgroup barrier per slab; 32 measured +0.7 % forward, but the
+                                       backward kernel then no longer unrolls without scratch) */
+#endif
+#define NEFES_SLAB_BYTES (NEFES_SLAB_KIB * 1024)
+#define NEFES_SLAB_FRAGS (NEFES_SLAB_BYTES / 256)
+#define NEFES_SLAB_PIECES (NEFES_SLAB_BYTES / 4096)   /* 1 KiB LDS-DMA pieces per wave and slab */
+#define NEFES_RING_SLOTS (128 / NEFES_SLAB_KIB)       /* forward ring: 128 KiB */
+#define NEFES_BWD_SLOTS (96 / NEFES_SLAB_KIB)         /* backward ring: 96 KiB (+ the tile's ReLU masks, <= 40 KiB) */
 #define NEFES_N_FREQ_XYZ 10
 #define NEFES_N_FREQ_DIR 4
 #define NEFES_E_STEPS 32   /* 63 xyz-embedding features + 1 pad, two per k-step */

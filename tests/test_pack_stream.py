@@ -82,9 +82,19 @@ def acc_to_vec(acc, t0=0, nt=None):
     return v
 
 
+def _slab_frags():
+    """NEFES_SLAB_FRAGS of nefes_amd/csrc/layout.h (slab bytes / 256)."""
+    import re
+    txt = open(os.path.join(os.path.dirname(__file__), '..', 'nefes_amd', 'csrc', 'layout.h')).read()
+    return int(re.search(r'#define NEFES_SLAB_KIB (\d+)', txt).group(1)) * 4
+
+
+SLAB_FRAGS = _slab_frags()
+
+
 class Stream:
     def __init__(self, blob, si):
-        self.slabs = np.frombuffer(blob, np.float32, count=si.n_slabs * 4096, offset=si.slab_off).reshape(si.n_slabs, 16, 64, 4)
+        self.slabs = np.frombuffer(blob, np.float32, count=si.n_slabs * SLAB_FRAGS * 64, offset=si.slab_off).reshape(si.n_slabs, SLAB_FRAGS // 4, 64, 4)
         self.bias = np.frombuffer(blob, np.float32, count=si.bias_floats, offset=si.bias_off) if si.bias_floats else None
         self.pos = 0
         self.bpos = 0
@@ -96,7 +106,7 @@ class Stream:
 
     def mma(self, nt, vec, acc):
         ks = vec.shape[0]
-        sps = 64 // nt
+        sps = SLAB_FRAGS // nt
         for sl in range((ks + sps - 1) // sps):
             slab = self.slabs[self.pos]
             self.pos += 1
