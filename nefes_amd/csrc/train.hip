@@ -69,13 +69,22 @@ __global__ __launch_bounds__(256, 2) void train_dx_kernel(int rows, const float*
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    for (int q = 0; q < n_out / 8; ++q) {
-        float4 a[NT];
+    // operands of step q+1 are requested before the MFMAs of step q issue (the G rows come from HBM)
+    const int nq = n_out / 8;
+    float4 a[NT];
+    float b[4];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) a[t] = *(const float4*)(wrow + (size_t)32 * t * ldw + 8 * q);
-        float b[4];
+    for (int t = 0; t < NT; ++t) a[t] = *(const float4*)(wrow + (size_t)32 * t * ldw);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) b[c] = g[(size_t)(8 * q + 4 * kh + c) * 128];
+    for (int c = 0; c < 4; ++c) b[c] = g[(size_t)(4 * kh + c) * 128];
+    for (int q = 0; q < nq; ++q) {
+        float4 an[NT];
+        float bn[4];
+        const int qn = q + 1 < nq ? q + 1 : q;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) an[t] = *(const float4*)(wrow + (size_t)32 * t * ldw + 8 * qn);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bn[c] = g[(size_t)(8 * qn + 4 * kh + c) * 128];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             acc[t] = mfma2(a[t].x, b[0], acc[t]);
@@ -83,6 +92,10 @@ __global__ __launch_bounds__(256, 2) void train_dx_kernel(int rows, const float*
             acc[t] = mfma2(a[t].z, b[2], acc[t]);
             acc[t] = mfma2(a[t].w, b[3], acc[t]);
         }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = an[t];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[c] = bn[c];
     }
     const size_t o0 = tile_off + (size_t)(dst_row0 + 4 * kh) * 128 + wave * 32 + j;
 #pragma unroll

@@ -63,7 +63,7 @@ class _Pass:
         self.offsets = [int(self.lib.nefes_train_row_offset(C.byref(desc), b)) for b in range(L.TB_END + 1)]
         self.stream = ops._stream()
         self.dev = acts.device
-        self.want = 8192                                              # waves per dW launch
+        self.want = 2048                                              # waves per dW launch (1024 SIMDs x 2-3 resident)
 
     def off(self, block):                                             # (a method, not a closure: no reference cycle
         return self.offsets[block]                                    #  may keep the multi-GB buffers alive)
