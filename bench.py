@@ -48,6 +48,13 @@ WORKLOADS = {
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
+def bench_pose():
+    """SURVEY.md §8d pose: c2w = [Exp(r) | t], r = (0.10, -0.20, 0.05), t = (0.10, 0.20, 0.30) (nefes_amd.pose, fp64 -> fp32)."""
+    from nefes_amd.pose import make_c2w
+    return make_c2w(torch.tensor([0.10, -0.20, 0.05], dtype=torch.float64),
+                    torch.tensor([0.10, 0.20, 0.30], dtype=torch.float64))[:3, :4].float()
+
+
 def cpu_baseline(Wd, C, Nc, Ni, n_rows, W, focal):
     """The CPU oracle (same torch op sequence as the reference) on a bounded slice of the same workload."""
     from oracle import ref_cpu as O
@@ -96,7 +103,6 @@ def refinement_loop(dev, iters=50, graph=True):
     Returns (seconds per image, rays rendered per image)."""
     from nefes_amd.field import NeRFH_NFF
     from nefes_amd.refine import PoseRefiner
-    from oracle import ref_cpu as O
     wl = WORKLOADS["ref"]
     H, W, focal, Wd, C = wl["H"], wl["W"], wl["focal"], wl["Wd"], wl["C"]
     coarse = NeRFH_NFF('coarse', W=Wd, f_dim=C).requires_grad_(False).to(dev)
@@ -107,7 +113,7 @@ def refinement_loop(dev, iters=50, graph=True):
               network_fine=fine, use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=True, args=args, ndc=False,
               lindisp=False)
     init = torch.eye(4, device=dev)
-    init[:3, :4] = O.bench_pose().to(dev)
+    init[:3, :4] = bench_pose().to(dev)
     hist = torch.full((1, 10), 10., device=dev)
     target = torch.nn.functional.normalize(torch.randn(C, 4 * H - 20, 4 * W - 20, device=dev), dim=0)
     ref = PoseRefiner(kw, args, (4 * H, 4 * W, 4 * focal), 0., 4., tinyscale=4, upsample=True, graph=graph, device=dev)
@@ -128,7 +134,6 @@ def train_steps(dev, steps=10, warmup=2):
     from nefes_amd import ops
     from nefes_amd.field import NeRFH_NFF
     from nefes_amd.render import render
-    from oracle import ref_cpu as O
     H = W = 200
     focal, Wd, C = 525.505 * 200 / 480, 128, 128
     coarse = NeRFH_NFF('coarse', W=Wd, f_dim=C).to(dev)
@@ -137,9 +142,7 @@ def train_steps(dev, steps=10, warmup=2):
     args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True, netchunk=1024)
     kw = dict(network_query_fn=None, perturb=1., N_importance=0, N_samples=64, network_fn=coarse, network_fine=None,
               use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=False, args=args, ndc=False, lindisp=False)
-    c2w = O.bench_pose()
-    ro, rd = O.ray_bundle(H, W, focal, c2w)
-    ro, rd = ro.reshape(-1, 3).to(dev), rd.reshape(-1, 3).to(dev)
+    ro, rd, _ = ops.raygen_fwd(H, W, focal, bench_pose().to(dev))                    # get_rays on the GPU
     target = torch.rand(H * W, 3, device=dev)
     losses = []
 
@@ -163,6 +166,7 @@ def train_steps(dev, steps=10, warmup=2):
     timers, ops.TIMERS = ops.TIMERS, None
     kern = {k: round(sum(s.elapsed_time(e) for s, e in v) / len(v), 4) for k, v in timers.items()}
     # CPU oracle on a bounded slice of the same step (reference settings: netchunk=1024 slices, autograd to the weights)
+    from oracle import ref_cpu as O
     th = min(32, os.cpu_count() or 1)
     torch.set_num_threads(th)
     pc = {k: v.requires_grad_() for k, v in O.make_field_params("coarse", Wd, C).items()}
@@ -208,7 +212,6 @@ def main():
     from nefes_amd import ops
     from nefes_amd.field import NeRFH_NFF
     from nefes_amd.render import render
-    from oracle import ref_cpu as O        # bench_pose()/bench_loss() definitions only; the CPU leg is cpu_baseline()
 
     if a.workload == "train":
         sec, rays, kern, ls, cpu = train_steps(dev)
@@ -248,7 +251,7 @@ def main():
         # table scaled to O(0.3) so that the MLP sees the position (tiny-cuda-nn's 1e-4 init would feed it ~zeros)
         kw["xyz_encoder"] = ops.HashGrid(25.0, device=dev)
         kw["xyz_encoder"].table.mul_(3e3)
-    pose = O.bench_pose().to(dev)
+    pose = bench_pose().to(dev)
     row0, nrows = D.row_shard(H, rank, world)
     n_total = H * W
 
