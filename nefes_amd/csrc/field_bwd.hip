@@ -4,6 +4,7 @@
 // on v_mfma_f32_32x32x2_f32: A operand = W^T fragments (LDS-DMA ring), B operand = the upstream
 // gradient vector held in registers, ReLU derivative from the 1-bit masks the forward pass stored.
 // Head activation derivatives are recovered from the raw outputs (softplus' = 1 - exp(-y), sigmoid' = y(1-y)).
+#define NEFES_SLAB_KIB NEFES_BWD_SLAB_KIB
 #include "field_common.h"
 #include "../../include/nefes_hip.h"
 

@@ -5,6 +5,7 @@
 // Roofline: MFMA-bound (fp32 32x32x2 at 157.3 TFLOP/s); algorithmic work per sample = 2 * MACs of
 // SURVEY.md §8d (491 264 sigma-only / 665 088 full at Wd=256,C=16).  Weights: LDS-DMA ring, read once
 // per 128-sample workgroup tile from L2 (2.7 MB stream, resident).  Activations never leave registers.
+#define NEFES_SLAB_KIB NEFES_FWD_SLAB_KIB
 #include "field_common.h"
 #include "../../include/nefes_hip.h"
 

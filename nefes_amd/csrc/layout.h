@@ -28,15 +28,17 @@
 #define NEFES_HD inline
 #endif
 
-#ifndef NEFES_SLAB_KIB
-#define NEFES_SLAB_KIB 16           /* slab size: 16 or 32 KiB (one workgroup barrier per slab; 32 measured +0.7 % forward, but the
-                                       backward kernel then no longer unrolls without scratch) */
-#endif
-#define NEFES_SLAB_BYTES (NEFES_SLAB_KIB * 1024)
-#define NEFES_SLAB_FRAGS (NEFES_SLAB_BYTES / 256)
-#define NEFES_SLAB_PIECES (NEFES_SLAB_BYTES / 4096)   /* 1 KiB LDS-DMA pieces per wave and slab */
-#define NEFES_RING_SLOTS (128 / NEFES_SLAB_KIB)       /* forward ring: 128 KiB */
-#define NEFES_BWD_SLOTS (96 / NEFES_SLAB_KIB)         /* backward ring: 96 KiB (+ the tile's ReLU masks, <= 40 KiB) */
+// Slab sizes (one workgroup barrier per slab).  Forward streams use 32 KiB slabs (half the barriers: +0.7 % measured);
+// the backward kernel stops unrolling without scratch at 32 KiB, so its stream keeps 16 KiB slabs.  A kernel translation
+// unit defines NEFES_SLAB_KIB (to one of the two) before including field_common.h; the packer knows both.
+#define NEFES_FWD_SLAB_KIB 32
+#define NEFES_BWD_SLAB_KIB 16
+#define NEFES_FRAGS_OF_KIB(kib) ((kib) * 4)               /* 256-byte fragments per slab */
+#define NEFES_SLAB_BYTES (NEFES_SLAB_KIB * 1024)          /* (expand where used: the kernel TU's NEFES_SLAB_KIB) */
+#define NEFES_SLAB_FRAGS NEFES_FRAGS_OF_KIB(NEFES_SLAB_KIB)
+#define NEFES_SLAB_PIECES (NEFES_SLAB_BYTES / 4096)       /* 1 KiB LDS-DMA pieces per wave and slab */
+#define NEFES_RING_SLOTS (128 / NEFES_FWD_SLAB_KIB)       /* forward ring: 128 KiB */
+#define NEFES_BWD_SLOTS (96 / NEFES_BWD_SLAB_KIB)         /* backward ring: 96 KiB (+ the tile's ReLU masks, <= 40 KiB) */
 #define NEFES_N_FREQ_XYZ 10
 #define NEFES_N_FREQ_DIR 4
 #define NEFES_E_STEPS 32   /* 63 xyz-embedding features + 1 pad, two per k-step */
@@ -61,15 +63,16 @@ NEFES_HD int nefes_emb_slot(int L, int s, int h) {
     return -1;
 }
 // k-steps per slab for a segment with NT accumulator tiles
-NEFES_HD int nefes_steps_per_slab(int nt) { return NEFES_SLAB_FRAGS / nt; }
-NEFES_HD int nefes_segment_slabs(int nt, int ks) {
-    const int sps = NEFES_SLAB_FRAGS / nt;
+NEFES_HD int nefes_steps_per_slab(int nt, int slab_frags) { return slab_frags / nt; }
+NEFES_HD int nefes_segment_slabs(int nt, int ks, int slab_frags) {
+    const int sps = slab_frags / nt;
     return (ks + sps - 1) / sps;
 }
 
 // stream kinds inside a packed blob
 enum { NEFES_STREAM_FWD_SIGMA = 0, NEFES_STREAM_FWD_STATIC = 1, NEFES_STREAM_FWD_FULL = 2, NEFES_STREAM_BWD_FULL = 3,
        NEFES_N_STREAMS = 4 };
+NEFES_HD int nefes_stream_slab_kib(int stream) { return stream == NEFES_STREAM_BWD_FULL ? NEFES_BWD_SLAB_KIB : NEFES_FWD_SLAB_KIB; }
 
 // ReLU-mask words (32 bit) written per lane per 32-sample tile by the full forward pass:
 // 8 trunk layers (W/64 words each) + dir + 3 transient layers (W/128 words each)

@@ -25,7 +25,7 @@ struct Seg {
         if (r < 0 || k < 0) return 0.f;
         return transposed ? W[(size_t)k * ld + r] : W[(size_t)r * ld + k];
     }
-    int slabs() const { return nefes_segment_slabs(nt, ks); }
+    int slabs(int slab_frags) const { return nefes_segment_slabs(nt, ks, slab_frags); }
 };
 
 struct BiasBlk {
@@ -36,9 +36,9 @@ struct BiasBlk {
 struct Stream {
     std::vector<Seg> segs;
     std::vector<BiasBlk> bias;
-    int n_slabs() const {
+    int n_slabs(int slab_frags) const {
         int n = 0;
-        for (auto& s : segs) n += s.slabs();
+        for (auto& s : segs) n += s.slabs(slab_frags);
         return n;
     }
     int bias_floats() const {
@@ -243,13 +243,14 @@ void fill_info(const Stream (&st)[NEFES_N_STREAMS], NefesBlobInfo* info) {
     uint64_t off = kHeaderBytes;
     for (int k = 0; k < NEFES_N_STREAMS; ++k) {
         NefesStreamInfo& si = info->stream[k];
-        si.n_slabs = (uint32_t)st[k].n_slabs();
+        const int kib = nefes_stream_slab_kib(k);
+        si.n_slabs = (uint32_t)st[k].n_slabs(NEFES_FRAGS_OF_KIB(kib));
         si.bias_floats = (uint32_t)st[k].bias_floats();
         if (si.n_slabs == 0) { si.slab_off = si.bias_off = 0; si.bias_floats = 0; continue; }
         si.bias_off = off;
         off = align_up(off + 4ull * si.bias_floats, 256);
         si.slab_off = off;
-        off += (uint64_t)si.n_slabs * NEFES_SLAB_BYTES;
+        off += (uint64_t)si.n_slabs * kib * 1024;
     }
     info->total_bytes = off;
 }
@@ -295,8 +296,9 @@ extern "C" int nefes_pack_weights(const NefesNetDesc* desc, const float* const* 
             for (int r : bb.ridx) *bias++ = r < 0 ? 0.f : bb.b[r];
         float* slab = (float*)(base + si.slab_off);
         for (auto& sg : st[k].segs) {
-            const int sps = nefes_steps_per_slab(sg.nt);
-            for (int sl = 0; sl < sg.slabs(); ++sl, slab += NEFES_SLAB_BYTES / 4) {
+            const int frags = NEFES_FRAGS_OF_KIB(nefes_stream_slab_kib(k));
+            const int sps = nefes_steps_per_slab(sg.nt, frags);
+            for (int sl = 0; sl < sg.slabs(frags); ++sl, slab += frags * 64) {
                 const int steps = (sg.ks - sl * sps) < sps ? (sg.ks - sl * sps) : sps;
                 for (int f = 0; f < steps * sg.nt; ++f) {
                     const int s = sl * sps + f / sg.nt, t = f % sg.nt;

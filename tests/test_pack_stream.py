@@ -82,18 +82,15 @@ def acc_to_vec(acc, t0=0, nt=None):
     return v
 
 
-def _slab_frags():
-    """NEFES_SLAB_FRAGS of nefes_amd/csrc/layout.h (slab bytes / 256)."""
-    import re
+def _slab_frags(which):
+    """256-byte fragments per slab of the forward ('FWD') or backward ('BWD') streams (nefes_amd/csrc/layout.h)."""
     txt = open(os.path.join(os.path.dirname(__file__), '..', 'nefes_amd', 'csrc', 'layout.h')).read()
-    return int(re.search(r'#define NEFES_SLAB_KIB (\d+)', txt).group(1)) * 4
-
-
-SLAB_FRAGS = _slab_frags()
+    return int(re.search(r'#define NEFES_%s_SLAB_KIB (\d+)' % which, txt).group(1)) * 4
 
 
 class Stream:
-    def __init__(self, blob, si):
+    def __init__(self, blob, si, which="FWD"):
+        SLAB_FRAGS = self.frags = _slab_frags(which)
         self.slabs = np.frombuffer(blob, np.float32, count=si.n_slabs * SLAB_FRAGS * 64, offset=si.slab_off).reshape(si.n_slabs, SLAB_FRAGS // 4, 64, 4)
         self.bias = np.frombuffer(blob, np.float32, count=si.bias_floats, offset=si.bias_off) if si.bias_floats else None
         self.pos = 0
@@ -106,7 +103,7 @@ class Stream:
 
     def mma(self, nt, vec, acc):
         ks = vec.shape[0]
-        sps = SLAB_FRAGS // nt
+        sps = self.frags // nt
         for sl in range((ks + sps - 1) // sps):
             slab = self.slabs[self.pos]
             self.pos += 1
@@ -217,7 +214,7 @@ def emulate_backward(info, blob, Wd, Cf, masks, d_pre):
     """Mirrors field_bwd_kernel (csrc/field_bwd.hip).  d_pre: pre-activation head gradients."""
     n = d_pre["sigma"].shape[0]
     NTW, NTH = Wd // 32, Wd // 64
-    st = Stream(blob, info.stream[L.STREAM_BWD_FULL])
+    st = Stream(blob, info.stream[L.STREAM_BWD_FULL], "BWD")
     Z = lambda nt: np.zeros((nt, 32, n), np.float32)
     C3 = 3 + Cf
     a2 = Z(NTH)
