@@ -28,11 +28,15 @@
 #define NEFES_HD inline
 #endif
 
-// Slab sizes (one workgroup barrier per slab).  Forward streams use 32 KiB slabs (half the barriers: +0.7 % measured);
-// the backward kernel stops unrolling without scratch at 32 KiB, so its stream keeps 16 KiB slabs.  A kernel translation
-// unit defines NEFES_SLAB_KIB (to one of the two) before including field_common.h; the packer knows both.
+// Slab sizes (one workgroup barrier per slab): 32 KiB measured +0.7..1 % over 16 KiB (half the barriers).  Forward and
+// backward streams are sized separately; a kernel translation unit defines NEFES_SLAB_KIB (to one of the two) before
+// including field_common.h; the packer knows both.
+#ifndef NEFES_FWD_SLAB_KIB
 #define NEFES_FWD_SLAB_KIB 32
-#define NEFES_BWD_SLAB_KIB 16
+#endif
+#ifndef NEFES_BWD_SLAB_KIB
+#define NEFES_BWD_SLAB_KIB 32
+#endif
 #define NEFES_FRAGS_OF_KIB(kib) ((kib) * 4)               /* 256-byte fragments per slab */
 #define NEFES_SLAB_BYTES (NEFES_SLAB_KIB * 1024)          /* (expand where used: the kernel TU's NEFES_SLAB_KIB) */
 #define NEFES_SLAB_FRAGS NEFES_FRAGS_OF_KIB(NEFES_SLAB_KIB)
