@@ -47,15 +47,18 @@ __device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, 
 #endif
 }
 // 1-instruction ReLU (fmaxf() costs a canonicalising v_max in front of the real one)
+// NOP = true: the result feeds an MFMA as srcB straight away.  A VALU write -> MFMA operand read needs 2 wait states that
+// the compiler does not pad for values defined inside inline asm (measured: without them the MFMA consumes the previous
+// k-step's operand), hence the trailing s_nop 1 (8 cycles of issue).  NOP = false: the caller guarantees at least one
+// MFMA issues between this instruction and the consumer (mma_run computes the operand one k-step ahead).
+template <bool NOP = true>
 __device__ __forceinline__ float relu1(float v) {
 #ifdef NEFES_DBG_OLD_RELU
     return fmaxf(v, 0.f);
 #else
     float r;
-    // trailing s_nop 1: the result usually feeds an MFMA as srcB straight away, and a VALU write -> MFMA operand read
-    // needs 2 wait states that the compiler does not pad for values defined inside inline asm (measured: without it
-    // the MFMA consumes the previous k-step's operand).
-    asm("v_max_f32 %0, 0, %1\n\ts_nop 1" : "=v"(r) : "v"(v));
+    if (NOP) asm volatile("v_max_f32 %0, 0, %1\n\ts_nop 1" : "=v"(r) : "v"(v));
+    else asm volatile("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
     return r;
 #endif
 }
@@ -66,11 +69,13 @@ __device__ __forceinline__ float relu1(float v) {
 // order, 32 per word, so the first activation of a word travels to bit 31 and is the first to come back out.
 // (A pre-activation of exactly +0.0 passes the gradient where torch's relu' gives 0; -0.0 does not.)
 __device__ __forceinline__ void mask_shift_in(uint32_t& bits, float v) {
-    asm("v_alignbit_b32 %0, %0, %1, 31" : "+v"(bits) : "v"(v));
+    asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(bits) : "v"(v));
 }
+template <bool NOP = true>
 __device__ __forceinline__ float mask_shift_out(uint32_t& bits, float v) {
     float r;
-    asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, %2, 0, vcc\n\ts_nop 1" : "+v"(bits), "=v"(r) : "v"(v) : "vcc");
+    if (NOP) asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, %2, 0, vcc\n\ts_nop 1" : "+v"(bits), "=v"(r) : "v"(v) : "vcc");
+    else asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, %2, 0, vcc" : "+v"(bits), "=v"(r) : "v"(v) : "vcc");
     return r;
 }
 
@@ -175,32 +180,37 @@ template <int NX, int NW>
 struct ReluCapture {            // forward: relu(X) and mask bit s
     const f32x16 (&X)[NX];
     uint32_t (&bits)[NW];
-    __device__ __forceinline__ float operator()(int s) const {
+    template <bool NOP>
+    __device__ __forceinline__ float get(int s) const {
         const float v = X[s >> 4][s & 15];
         mask_shift_in(bits[s >> 5], v);
-        return relu1(v);
+        return relu1<NOP>(v);
     }
 };
 template <int NX>
 struct ReluIn {                 // forward: relu(X), no mask
     const f32x16 (&X)[NX];
-    __device__ __forceinline__ float operator()(int s) const { return relu1(X[s >> 4][s & 15]); }
+    template <bool NOP>
+    __device__ __forceinline__ float get(int s) const { return relu1<NOP>(X[s >> 4][s & 15]); }
 };
 template <int NX, int T0 = 0>
 struct IdentIn {                // X as is (tiles T0..)
     const f32x16 (&X)[NX];
-    __device__ __forceinline__ float operator()(int s) const { return X[T0 + (s >> 4)][s & 15]; }
+    template <bool NOP>
+    __device__ __forceinline__ float get(int s) const { return X[T0 + (s >> 4)][s & 15]; }
 };
 template <int NX, int NW, int T0 = 0>
 struct MaskedIn {               // backward: mask bit of activation s ? X : 0   (consumes the word by shifting)
     const f32x16 (&X)[NX];
     uint32_t (&bits)[NW];
-    __device__ __forceinline__ float operator()(int s) const { return mask_shift_out(bits[s >> 5], X[T0 + (s >> 4)][s & 15]); }
+    template <bool NOP>
+    __device__ __forceinline__ float get(int s) const { return mask_shift_out<NOP>(bits[s >> 5], X[T0 + (s >> 4)][s & 15]); }
 };
 template <int N>
 struct ArrayIn {
     const float (&v)[N];
-    __device__ __forceinline__ float operator()(int s) const { return v[s]; }
+    template <bool NOP>
+    __device__ __forceinline__ float get(int s) const { return v[s]; }
 };
 struct ZeroInit {               // C operand of the first k-step = 0
     __device__ __forceinline__ f32x16 operator()(int) const {
@@ -241,7 +251,12 @@ __device__ __forceinline__ void mma_run(WeightRing<SLOTS>& ring, const char* rin
         c0 = init(0);
         if (NT > 1) c1 = init(1);
     }
-    float b = 0.f;
+    // B operand of k-step s+1 is produced in front of the last TWO MFMAs of k-step s (NT >= 3): its VALU instructions then
+    // need no wait-state padding in front of their consumer (2 wait states = 2 issued instructions; with only one MFMA in
+    // between the parity tests fail).  (Right behind the FIRST MFMA measured 2.5 % slower:
+    // a VALU instruction waits for the fp32 MFMA in flight, which pushed the LDS-DMA issue that follows out of its shadow.)
+    constexpr bool AHEAD = NT >= 3;
+    float b = 0.f, b_next = 0.f;
 #pragma unroll
     for (int sl = 0; sl < NSLAB; ++sl) {
         const char* p = ring_lane + ring.cur_off;
@@ -272,13 +287,27 @@ __device__ __forceinline__ void mma_run(WeightRing<SLOTS>& ring, const char* rin
                     const int f = g * 4 + q;
                     if (f < nf) {
                         const int s = sl * SPS + f / NT, t = f % NT;
-                        if (t == 0) b = in(s);
+                        if (t == 0) {
+                            if (AHEAD && s > 0) {
+                                // keep the two MFMAs issued since b_next was produced in front of its consumer (the
+                                // scheduler may otherwise hoist this MFMA: seen with NT = 9, where k-steps straddle groups)
+                                __builtin_amdgcn_sched_barrier(0);
+                                b = b_next;
+                            } else {
+                                b = in.template get<true>(s);
+                            }
+                        }
                         if (FIRST && s == 0) {
                             acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, c0, 0, 0, 0);
                             c0 = c1;
                             if (t + 2 < NT) c1 = init(t + 2);
                         } else {
                             acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, acc[T0 + t], 0, 0, 0);
+                        }
+                        if (AHEAD && t == NT - 3 && s + 1 < KS) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            b_next = in.template get<false>(s + 1);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                     if (q == 0 && g != ng - 1) {
