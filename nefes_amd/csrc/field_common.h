@@ -33,7 +33,7 @@ __device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, 
 #else
     // s_nop 4 first: the SGPR base may have just been written by a VALU instruction (v_readlane restoring a spilled
     // SGPR, v_readfirstlane) and a VMEM instruction reading such an SGPR needs 5 wait states the compiler does not
-    // insert for inline asm.
+    // insert for inline asm.  (Measured without it: +0.3 % forward -- not worth the exposure.)
     asm volatile(
         "s_nop 4\n\t"
         "s_mov_b32 %0, m0\n\t"
