@@ -47,7 +47,7 @@ typedef struct NefesNetDesc {
 /* where each weight stream lives inside a packed blob (all offsets in bytes from the blob start) */
 typedef struct NefesStreamInfo {
     uint64_t slab_off;   /* first slab */
-    uint32_t n_slabs;    /* 16 KiB each */
+    uint32_t n_slabs;    /* 32 KiB each (nefes_amd/csrc/layout.h: NEFES_FWD_SLAB_KIB / NEFES_BWD_SLAB_KIB) */
     uint32_t bias_floats;
     uint64_t bias_off;   /* bias block (fp32, natural row order per layer); 0 if none */
 } NefesStreamInfo;

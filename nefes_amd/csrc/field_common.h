@@ -1,5 +1,6 @@
 // Device-side building blocks of the fused field kernels (gfx950 only).
-//   - WeightRing: 8 x 16 KiB LDS ring filled by LDS-DMA (global_load_lds_dwordx4), one barrier per slab
+//   - WeightRing: LDS ring of NEFES_SLAB_KIB-KiB slabs (4 x 32 forward, 3 x 32 backward) filled by LDS-DMA
+//     (global_load_lds_dwordx4), one barrier per slab
 //   - mma_segment: one (activation vector) x (weight block) product on v_mfma_f32_32x32x2_f32
 //   - accumulator <-> activation-vector moves, bias init, ReLU + mask
 #pragma once

@@ -15,7 +15,7 @@
 //   tile (t, i)  : accumulator tile t, row i (0..31).  Row i lives in register
 //                  r = (i&3) + 4*(i>>3) of lane half h = (i>>2)&1   [CDNA C/D map].
 //   fragment     : 64 lanes x 1 float = 256 B; the A operand of one MFMA.
-//   slab         : 16 KiB = up to 64 fragments in consumption order; the unit of
+//   slab         : 32 KiB = up to 128 fragments in consumption order; the unit of
 //                  the LDS-DMA weight ring.  A slab never spans two segments.
 //   segment      : one (activation vector) x (weight block) product accumulated into
 //                  NT tiles over KS k-steps.
