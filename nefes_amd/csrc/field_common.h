@@ -4,6 +4,12 @@
 //   - mma_segment: one (activation vector) x (weight block) product on v_mfma_f32_32x32x2_f32
 //   - accumulator <-> activation-vector moves, bias init, ReLU + mask
 #pragma once
+#ifndef NEFES_B_BATCH
+#define NEFES_B_BATCH 4      /* k-steps whose B operands are produced in one VALU gap (mma_run) */
+#endif
+#ifndef NEFES_B_BATCH_NT8
+#define NEFES_B_BATCH_NT8 NEFES_B_BATCH   /* same, for 8-tile (Wd = 256 trunk) segments; a kernel TU may raise it */
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -252,12 +258,24 @@ __device__ __forceinline__ void mma_run(WeightRing<SLOTS>& ring, const char* rin
         c0 = init(0);
         if (NT > 1) c1 = init(1);
     }
-    // B operand of k-step s+1 is produced in front of the last TWO MFMAs of k-step s (NT >= 3): its VALU instructions then
-    // need no wait-state padding in front of their consumer (2 wait states = 2 issued instructions; with only one MFMA in
-    // between the parity tests fail).  (Right behind the FIRST MFMA measured 2.5 % slower:
-    // a VALU instruction waits for the fp32 MFMA in flight, which pushed the LDS-DMA issue that follows out of its shadow.)
-    constexpr bool AHEAD = NT >= 3;
-    float b = 0.f, b_next = 0.f;
+    // B operands are produced AHEAD of their consumer, at least two MFMAs earlier: the VALU instructions then need no
+    // wait-state padding (2 wait states = 2 issued instructions; with only one MFMA in between the parity tests fail).
+    // NT >= 3: in front of the last two MFMAs of the previous k-step (right behind its FIRST MFMA measured 2.5 % slower: a
+    // VALU instruction waits for the fp32 MFMA in flight, which pushed the LDS-DMA issue that follows out of its shadow);
+    // NT = 2: two k-steps earlier; NT = 1: three.  And in BATCHES of NEFES_B_BATCH k-steps: the first VALU instruction
+    // after an MFMA costs ~21 cycles, each further one 4 (tools/probe/overlap_probe.hip), so one VALU gap per batch.
+    constexpr int BATCH = (NT == 8) ? NEFES_B_BATCH_NT8 : NEFES_B_BATCH;
+    constexpr int LA = NT >= 3 ? 1 : (NT == 2 ? 2 : 3);      // look-ahead in k-steps
+    constexpr int PROD_T = NT >= 3 ? NT - 3 : 0;              // tile index behind whose MFMA a batch is produced
+    constexpr int QD = 2 * BATCH;                             // queue depth: a batch is consumed before it is overwritten
+    static_assert(LA <= BATCH, "look-ahead must not exceed the batch size");
+    float b = 0.f, bq[QD];
+#pragma unroll
+    for (int i = 0; i < QD; ++i) bq[i] = 0.f;
+    // the first LA operands up front, in k order (the mask-capturing producers shift bits in call order)
+#pragma unroll
+    for (int i = 0; i < LA; ++i)
+        if (i < KS) bq[i] = in.template get<true>(i);
 #pragma unroll
     for (int sl = 0; sl < NSLAB; ++sl) {
         const char* p = ring_lane + ring.cur_off;
@@ -289,14 +307,10 @@ __device__ __forceinline__ void mma_run(WeightRing<SLOTS>& ring, const char* rin
                     if (f < nf) {
                         const int s = sl * SPS + f / NT, t = f % NT;
                         if (t == 0) {
-                            if (AHEAD && s > 0) {
-                                // keep the two MFMAs issued since b_next was produced in front of its consumer (the
-                                // scheduler may otherwise hoist this MFMA: seen with NT = 9, where k-steps straddle groups)
-                                __builtin_amdgcn_sched_barrier(0);
-                                b = b_next;
-                            } else {
-                                b = in.template get<true>(s);
-                            }
+                            // keep the MFMAs issued since the operand was produced in front of its consumer (the
+                            // scheduler may otherwise hoist this MFMA: seen with NT = 9, where k-steps straddle groups)
+                            __builtin_amdgcn_sched_barrier(0);
+                            b = bq[s % QD];
                         }
                         if (FIRST && s == 0) {
                             acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, c0, 0, 0, 0);
@@ -305,9 +319,11 @@ __device__ __forceinline__ void mma_run(WeightRing<SLOTS>& ring, const char* rin
                         } else {
                             acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, acc[T0 + t], 0, 0, 0);
                         }
-                        if (AHEAD && t == NT - 3 && s + 1 < KS) {
+                        if (t == PROD_T && s % BATCH == 0 && s + LA < KS) {
                             __builtin_amdgcn_sched_barrier(0);
-                            b_next = in.template get<false>(s + 1);
+#pragma unroll
+                            for (int i = 0; i < BATCH; ++i)
+                                if (s + LA + i < KS) bq[(s + LA + i) % QD] = in.template get<false>(s + LA + i);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
