@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEFES_ABI_VERSION 1
+#define NEFES_ABI_VERSION 2
 
 #define NEFES_E_BADARG (-1)     /* null pointer / non-positive size */
 #define NEFES_E_UNSUPPORTED (-2) /* width / feat_dim / sample count outside the compiled set */
@@ -54,7 +54,7 @@ typedef struct NefesStreamInfo {
 
 typedef struct NefesBlobInfo {
     uint64_t total_bytes;
-    NefesStreamInfo stream[4]; /* indexed by NEFES_STREAM_* in csrc/layout.h; n_slabs == 0 if absent */
+    NefesStreamInfo stream[6]; /* indexed by NEFES_STREAM_* in csrc/layout.h; n_slabs == 0 if absent */
 } NefesBlobInfo;
 
 /* compositing variants of raw2outputs_NeRFH_NFF (script/models/nerfh_nff.py:25-166) */
@@ -161,6 +161,11 @@ int nefes_hashgrid_fwd(const NefesHashGridDesc* desc, const float* table, int64_
 /* backward to the positions (frozen table): g_x [M,3]. */
 int nefes_hashgrid_bwd_x(const NefesHashGridDesc* desc, const float* table, int64_t M, const float* x, const float* g_enc,
                          float* g_x, void* stream);
+
+/* nefes_field_fwd(mode = NEFES_FIELD_SIGMA) with the hidden 256x256 products as bf16x6 split products on
+ * v_mfma_f32_32x32x16_bf16 (fp32-level accuracy, see nefes_amd/csrc/field_fwd_x6.hip); width 256, frequency embedding. */
+int nefes_field_fwd_sigma_x6(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+                             const float* rays_d, const float* z, const float* pts, float* raw_t, void* stream);
 
 /* ---- train mode: weight gradients (script/run_nefes.py:42-108 `loss.backward()` through models/nerfh_nff.py:525-576) ----
  * Buffers `acts` / `dacts`: fp32 [n_tiles = ceil(N*S/128)][rows][128 samples], rows = nefes_train_rows(desc); row blocks

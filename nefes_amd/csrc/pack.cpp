@@ -19,14 +19,41 @@ struct Seg {
     const float* W = nullptr;
     int ld = 0;
     bool transposed = false;
+    bool x6 = false;        // bf16x6 segment: fragments are bf16 triples (hi, mid, lo) for v_mfma_f32_32x32x16_bf16
     float at(int s, int t, int lane) const {
         const int i = lane & 31, h = lane >> 5;
         const int r = ridx[t * 32 + i], k = kidx[s * 2 + h];
         if (r < 0 || k < 0) return 0.f;
         return transposed ? W[(size_t)k * ld + r] : W[(size_t)r * ld + k];
     }
-    int slabs(int slab_frags) const { return nefes_segment_slabs(nt, ks, slab_frags); }
+    // x6: element (k16-step q, lane group g, i) of the A operand = k-step 8q+i, half g of the fp32 ordering
+    float at16(int q, int i, int t, int lane) const {
+        const int m = lane & 31, g = lane >> 5;
+        const int r = ridx[t * 32 + m], k = kidx[(8 * q + i) * 2 + g];
+        if (r < 0 || k < 0) return 0.f;
+        return transposed ? W[(size_t)k * ld + r] : W[(size_t)r * ld + k];
+    }
+    int units() const { return (ks / 8) * nt; }                       // x6: one unit = (k16-step, tile) = 3 KiB
+    int slabs(int slab_frags) const {
+        if (!x6) return nefes_segment_slabs(nt, ks, slab_frags);
+        const int ups = (slab_frags / 4) / 3;
+        return (units() + ups - 1) / ups;
+    }
 };
+
+// w = hi + mid + lo exactly, each a bf16 (truncation split: 24 mantissa bits = 3 x 8)
+static void split_bf16x3(float w, uint16_t (&part)[3]) {
+    float r = w;
+    for (int p = 0; p < 3; ++p) {
+        uint32_t b;
+        memcpy(&b, &r, 4);
+        b &= 0xffff0000u;
+        float f;
+        memcpy(&f, &b, 4);
+        part[p] = (uint16_t)(b >> 16);
+        r -= f;
+    }
+}
 
 struct BiasBlk {
     const float* b;
@@ -119,7 +146,7 @@ std::vector<int> rows_xyz(const Net& n, int base) {
     return r;
 }
 
-void add_trunk(const Net& n, Stream& st) {
+void add_trunk(const Net& n, Stream& st, bool x6 = false) {
     const int W = n.W, NT = n.NTW;
     for (int l = 0; l < 8; ++l) {
         if (l == 0) {
@@ -127,9 +154,11 @@ void add_trunk(const Net& n, Stream& st) {
         } else if (l == 4) {  // skip layer: columns [xyz(63), h(W)]  (nerfh_nff.py:472-473,551-552)
             // the kernels accumulate the hidden part first (its first k-step carries the bias), then the xyz part
             st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, n.in_xyz), rows_natural(NT, W), n.w(4), n.in_xyz + W));
+            st.segs.back().x6 = x6;
             st.segs.push_back(seg(NT, n.e_steps, k_xyz(n, 0), rows_natural(NT, W), n.w(4), n.in_xyz + W));
         } else {
             st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, 0), rows_natural(NT, W), n.w(l), W));
+            st.segs.back().x6 = x6;
         }
         st.bias.push_back({n.b(l), rows_natural(NT, W)});
     }
@@ -233,6 +262,7 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
         add_transient_head(n, st[NEFES_STREAM_FWD_FULL]);
         add_backward(n, st[NEFES_STREAM_BWD_FULL]);
     }
+    if (n.W == 256 && !n.ext) add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_X6], true);   // bf16x6 trunk (layout.h)
     return true;
 }
 
@@ -297,6 +327,22 @@ extern "C" int nefes_pack_weights(const NefesNetDesc* desc, const float* const* 
         float* slab = (float*)(base + si.slab_off);
         for (auto& sg : st[k].segs) {
             const int frags = NEFES_FRAGS_OF_KIB(nefes_stream_slab_kib(k));
+            if (sg.x6) {   // units of three 1 KiB groups (hi, mid, lo): lane = 8 bf16 = A operand of one 32x32x16 MFMA
+                const int ups = (frags / 4) / 3;
+                for (int sl = 0; sl < sg.slabs(frags); ++sl, slab += frags * 64) {
+                    for (int uu = 0; uu < ups && sl * ups + uu < sg.units(); ++uu) {
+                        const int u = sl * ups + uu, q = u / sg.nt, t = u % sg.nt;
+                        uint16_t* grp = (uint16_t*)(slab + uu * 3 * 256);
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int i = 0; i < 8; ++i) {
+                                uint16_t part[3];
+                                split_bf16x3(sg.at16(q, i, t, lane), part);
+                                for (int pp = 0; pp < 3; ++pp) grp[pp * 512 + lane * 8 + i] = part[pp];
+                            }
+                    }
+                }
+                continue;
+            }
             const int sps = nefes_steps_per_slab(sg.nt, frags);
             for (int sl = 0; sl < sg.slabs(frags); ++sl, slab += frags * 64) {
                 const int steps = (sg.ks - sl * sps) < sps ? (sg.ks - sl * sps) : sps;

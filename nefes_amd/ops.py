@@ -188,6 +188,16 @@ def field_fwd(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, pts
     return raw_t, masks
 
 
+def field_fwd_sigma_x6(pk: PackedField, N, S, rays_o, rays_d, z):
+    """sigma-only forward (coarse pass) with the hidden layers as bf16x6 split products (width 256 only)."""
+    raw_t = torch.empty(N, 1, S, device=pk.blob.device)
+    with _timed("field_fwd[sigma,x6]"):
+        L.check(L.load().nefes_field_fwd_sigma_x6(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
+                                                  _chk(rays_d, "rays_d"), _chk(z, "z"), None, _chk(raw_t, "raw_t"), _stream()),
+                "nefes_field_fwd_sigma_x6")
+    return raw_t
+
+
 def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=None, z=None, pts=None, viewdirs=None):
     dev = pk.blob.device
     ext = pk.xyz_encoding == L.XYZ_EXTERNAL32

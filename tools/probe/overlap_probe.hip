@@ -86,6 +86,77 @@ static void run_il(const char* name, float* d_out, unsigned long long* d_cyc) {
     printf("%-14s same wave, %d VALU per MFMA: %.1f cycles per MFMA\n", name, NV, (double)h / n);
 }
 
+// bf16x6 feasibility: per "slab" 96 bf16 MFMAs (16 units x 6), 48 ds_read_b128 (3 per unit), P LDS-DMA pieces per wave
+// (1 KiB each, from an L2-resident blob), one counted wait + workgroup barrier.  4 waves, one per SIMD.
+__device__ __forceinline__ void dma16(const void* gbase, unsigned lane_off, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+}
+template <int P, int NV>
+__global__ __launch_bounds__(256, 1) void dma_mix(const char* blob, float* out, unsigned long long* cyc, int n_slabs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    f32x16 acc[8];
+    for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = out[threadIdx.x] + i;
+    bf16x8 bh;
+    for (int i = 0; i < 8; ++i) bh[i] = (__bf16)v[i];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned lane_off = wave * 1024 + lane * 16;
+    const char* rd = smem + lane * 16;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int sl = 0; sl < n_slabs; ++sl) {
+        const int slot = sl % 3;
+        const char* src = blob + (size_t)(sl & 63) * 49152;
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            f32x4 fa = *(const f32x4*)(rd + slot * 49152 + (3 * u) * 1024);
+            f32x4 fb = *(const f32x4*)(rd + slot * 49152 + (3 * u + 1) * 1024);
+            f32x4 fc = *(const f32x4*)(rd + slot * 49152 + (3 * u + 2) * 1024);
+            bf16x8 a0, a1, a2;
+            __builtin_memcpy(&a0, &fa, 16); __builtin_memcpy(&a1, &fb, 16); __builtin_memcpy(&a2, &fc, 16);
+            acc[u & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[u & 7], 0, 0, 0);
+            if (u * P / 16 != (u + 1) * P / 16) {
+                __builtin_amdgcn_sched_barrier(0);
+                for (int q = u * P / 16; q < (u + 1) * P / 16; ++q)
+                    dma16(src + q * 4096, lane_off, lds0 + ((slot + 2) % 3) * 49152 + wave * 1024 + q * 4096);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc[u & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[u & 7], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[i & 7]) : "v"(v[(i + 1) & 7]));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[u & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[u & 7], 0, 0, 0);
+            acc[u & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bh, acc[u & 7], 0, 0, 0);
+            acc[u & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bh, acc[u & 7], 0, 0, 0);
+            acc[u & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bh, acc[u & 7], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(P) : "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int t = 0; t < 8; ++t) s += acc[t][0];
+    for (int i = 0; i < 8; ++i) s += v[i];
+    out[threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int P, int NV>
+static void run_mix(float* d_out, unsigned long long* d_cyc, const char* blob) {
+    unsigned long long h;
+    const int n = 200;
+    hipFuncSetAttribute((const void*)dma_mix<P, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((dma_mix<P, NV>), dim3(256), dim3(256), 3 * 49152, 0, blob, d_out, d_cyc, n);
+    hipDeviceSynchronize();
+    hipMemcpy(&h, d_cyc, sizeof(h), hipMemcpyDeviceToHost);
+    printf("bf16x6 mix: %2d DMA pieces + 48 ds_read_b128 + %2d VALU/unit per 96 MFMAs: %.1f cycles per MFMA (floor 32)\n", P, NV, (double)h / (n * 96.0));
+}
+
 template <int KIND>
 static void run(const char* name, float* d_out, unsigned long long* d_cyc, int n_mfma, int n_valu) {
     unsigned long long h[16];
@@ -111,5 +182,8 @@ int main() {
     run_il<0, 4>("fp32 32x32x2", d_out, d_cyc); run_il<0, 8>("fp32 32x32x2", d_out, d_cyc);
     run_il<1, 0>("bf16 32x32x16", d_out, d_cyc); run_il<1, 1>("bf16 32x32x16", d_out, d_cyc); run_il<1, 2>("bf16 32x32x16", d_out, d_cyc);
     run_il<1, 4>("bf16 32x32x16", d_out, d_cyc); run_il<1, 6>("bf16 32x32x16", d_out, d_cyc); run_il<1, 8>("bf16 32x32x16", d_out, d_cyc);
+    char* blob; hipMalloc(&blob, 64 * 49152); hipMemset(blob, 0, 64 * 49152);
+    run_mix<0, 0>(d_out, d_cyc, blob); run_mix<12, 0>(d_out, d_cyc, blob); run_mix<12, 8>(d_out, d_cyc, blob); run_mix<12, 16>(d_out, d_cyc, blob);
+    run_mix<6, 8>(d_out, d_cyc, blob);
     return 0;
 }
