@@ -288,9 +288,16 @@ def main():
         value = n_total * a.steps / dt
         kern = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in timers.items()}   # ms per launch, rank 0
         rays_local = nrows * W
-        # dominant kernel: the fused fine-field forward (FULL mode); algorithmic FLOPs per launch / launch time
+        # Dominant kernel = the longest-running launch of the step.  Fine-field forward (FULL mode) and backward-to-inputs
+        # do the same algorithmic MACs per sample; algorithmic FLOPs per launch / launch time, against the fp32-MFMA peak.
         flop_fwd = 2.0 * macs_full(Wd, C, in_xyz) * rays_local * (Nc + Ni)
-        ach = flop_fwd / (kern["field_fwd[full]"] * 1e-3) / 1e12
+        fwd_key = next(k for k in kern if k.startswith("field_fwd[full"))
+        x6 = fwd_key.endswith(",x6]")
+        dom_key = max((fwd_key, "field_bwd"), key=lambda k: kern[k])
+        ach = flop_fwd / (kern[dom_key] * 1e-3) / 1e12
+        enc = int(wl['hashgrid'])
+        dom_name = (f"field_bwd_kernel<{Wd},{3 + C},{enc}>" if dom_key == "field_bwd"
+                    else (f"field_fwd_x6_kernel<FULL>" if x6 else f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{enc}>"))
         flop_frame = 2.0 * (Nc * macs_sigma(Wd, in_xyz) + 2 * (Nc + Ni) * macs_full(Wd, C, in_xyz)) * n_total
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure
         # comes from the committed rocprofv3 passes of this same command (profiles/, 2*FETCH_SIZE + WRITE_SIZE in KiB,
@@ -299,10 +306,20 @@ def main():
         try:
             if (a.workload, H, W, world) == ("metric", 480, 640, 1):
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_per_launch.json")))
-                pm = next(v for k, v in pm.items() if k.replace(" ", "").startswith("field_fwd_kernel<256,1,2"))
+                pref = dom_name.split("<")[0]
+                pm = next(v for k, v in pm.items() if k.startswith(pref) and ("256" in k or "x6" in k) and (dom_key == "field_bwd" or ", 2" in k or "<2" in k))
                 traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
         except Exception:
             traffic = None
+        fwd_info = None
+        if x6:   # forward passes on bf16x6: algorithmic fp32 FLOPs per second, and executed bf16 MFMA FLOPs against the bf16 peak
+            t_f = kern[fwd_key] * 1e-3
+            exec_bf16 = 6 * 2.0 * 8 * Wd * Wd * rays_local * (Nc + Ni)
+            fwd_info = {"kernel": "field_fwd_x6_kernel<FULL>", "ms": round(kern[fwd_key], 4),
+                        "algorithmic_tflops": flop_fwd / t_f / 1e12,
+                        "frac_of_fp32_mfma_peak": flop_fwd / t_f / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                        "executed_bf16_tflops": exec_bf16 / t_f / 1e12, "bf16_mfma_peak": 2500.0,
+                        "note": "hidden 256x256 layers as bf16x6 split products (6 bf16 MFMA FLOPs per algorithmic FLOP), fp32-level accuracy"}
         out = {
             "metric": "rays/s (fwd+bwd) at 640x480x(64+128) samples, 8x256 MLP" if a.workload == "metric"
                       else f"rays/s (fwd+bwd), secondary workload '{a.workload}'", "value": value, "unit": "rays/s",
@@ -310,13 +327,15 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl['name']}; {W}x{H}, random seed-0 weights, fwd + bwd to the 3x4 pose",
                        "rays_per_step": n_total, "samples_per_ray": [Nc, Ni], "parallelism": f"rows/{world}"},
-            "roofline": {"bound": "mfma", "kernel": f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{int(wl['hashgrid'])}>", "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": ach,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes/launch (HBM side, from profiles/r01 PMC passes)",
                          "end_to_end_frac": value * (flop_frame / n_total) / (PEAK_F32_MFMA_TFLOPS * 1e12 * world)},
             "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items())},
             "pose_grad_abs_max": float(g.abs().max()),
         }
+        if fwd_info:
+            out["forward_x6"] = fwd_info
         if world == 1 and a.cpu_rows > 0 and a.workload == "metric":
             out["cpu_baseline"] = cpu_baseline(Wd, C, Nc, Ni, a.cpu_rows, W, focal)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

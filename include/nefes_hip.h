@@ -162,10 +162,13 @@ int nefes_hashgrid_fwd(const NefesHashGridDesc* desc, const float* table, int64_
 int nefes_hashgrid_bwd_x(const NefesHashGridDesc* desc, const float* table, int64_t M, const float* x, const float* g_enc,
                          float* g_x, void* stream);
 
-/* nefes_field_fwd(mode = NEFES_FIELD_SIGMA) with the hidden 256x256 products as bf16x6 split products on
- * v_mfma_f32_32x32x16_bf16 (fp32-level accuracy, see nefes_amd/csrc/field_fwd_x6.hip); width 256, frequency embedding. */
-int nefes_field_fwd_sigma_x6(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
-                             const float* rays_d, const float* z, const float* pts, float* raw_t, void* stream);
+/* nefes_field_fwd(mode = NEFES_FIELD_SIGMA or NEFES_FIELD_FULL) with the hidden 256x256 products (layers 2..8 and
+ * xyz_encoding_final) as bf16x6 split products on v_mfma_f32_32x32x16_bf16 -- exact hi/mid/lo bf16 triples, six cross terms,
+ * fp32 accumulation: fp32-level accuracy (nefes_amd/csrc/field_fwd_x6.hip).  Width 256, C = 16, frequency embedding;
+ * same outputs and the same ReLU-mask words as nefes_field_fwd, so nefes_field_bwd follows unchanged. */
+int nefes_field_fwd_x6(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                       const float* rays_d, const float* z, const float* pts, const float* viewdirs, float* raw_t,
+                       uint32_t* masks, void* stream);
 
 /* ---- train mode: weight gradients (script/run_nefes.py:42-108 `loss.backward()` through models/nerfh_nff.py:525-576) ----
  * Buffers `acts` / `dacts`: fp32 [n_tiles = ceil(N*S/128)][rows][128 samples], rows = nefes_train_rows(desc); row blocks

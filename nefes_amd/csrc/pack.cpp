@@ -167,9 +167,10 @@ void add_trunk(const Net& n, Stream& st, bool x6 = false) {
     st.bias.push_back({n.b(L_SIGMA), rows_natural(1, 1)});
 }
 
-void add_static_head(const Net& n, Stream& st) {
+void add_static_head(const Net& n, Stream& st, bool x6 = false) {
     const int W = n.W, W2 = n.W2;
     st.segs.push_back(seg(n.NTW, W / 2, k_natural(W / 2, 0), rows_natural(n.NTW, W), n.w(L_FINAL), W));
+    st.segs.back().x6 = x6;                                            // xyz_encoding_final: a 256x256 product like the trunk
     st.bias.push_back({n.b(L_FINAL), rows_natural(n.NTW, W)});
     st.segs.push_back(seg(n.NTH, W / 2, k_natural(W / 2, 0), rows_natural(n.NTH, W2), n.w(L_DIR), W + 27));
     st.segs.push_back(seg(n.NTH, NEFES_D_STEPS, k_emb(4, NEFES_D_STEPS, W), rows_natural(n.NTH, W2), n.w(L_DIR), W + 27));
@@ -262,7 +263,14 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
         add_transient_head(n, st[NEFES_STREAM_FWD_FULL]);
         add_backward(n, st[NEFES_STREAM_BWD_FULL]);
     }
-    if (n.W == 256 && !n.ext) add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_X6], true);   // bf16x6 trunk (layout.h)
+    if (n.W == 256 && !n.ext) {                                         // bf16x6 hidden products (layout.h)
+        add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_X6], true);
+        if (n.transient && n.C == 16) {
+            add_trunk(n, st[NEFES_STREAM_FWD_FULL_X6], true);
+            add_static_head(n, st[NEFES_STREAM_FWD_FULL_X6], true);
+            add_transient_head(n, st[NEFES_STREAM_FWD_FULL_X6]);
+        }
+    }
     return true;
 }
 

@@ -7,6 +7,8 @@ check dtype/contiguity/device and raise rather than silently converting on a dif
 import ctypes as C
 from typing import Optional
 
+import os
+
 import torch
 
 from . import lib as L
@@ -188,14 +190,29 @@ def field_fwd(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, pts
     return raw_t, masks
 
 
-def field_fwd_sigma_x6(pk: PackedField, N, S, rays_o, rays_d, z):
-    """sigma-only forward (coarse pass) with the hidden layers as bf16x6 split products (width 256 only)."""
-    raw_t = torch.empty(N, 1, S, device=pk.blob.device)
-    with _timed("field_fwd[sigma,x6]"):
-        L.check(L.load().nefes_field_fwd_sigma_x6(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
-                                                  _chk(rays_d, "rays_d"), _chk(z, "z"), None, _chk(raw_t, "raw_t"), _stream()),
-                "nefes_field_fwd_sigma_x6")
-    return raw_t
+# Forward passes at the headline shape (width 256, C = 16) run the hidden 256x256 products as bf16x6 split products on
+# v_mfma_f32_32x32x16_bf16 (csrc/field_fwd_x6.hip: fp32-level accuracy, checked against the float64 oracle in
+# tests/test_gpu_x6.py).  Set False (or NEFES_X6=0) for the plain fp32-MFMA kernels.
+USE_X6 = os.environ.get("NEFES_X6", "1") != "0"
+
+
+def x6_supported(pk: PackedField, mode):
+    """bf16x6 instances exist for the headline shape: width 256, C = 16, frequency embedding, sigma-only or full mode."""
+    return (pk.width == 256 and pk.feat_dim == 16 and pk.xyz_encoding == L.XYZ_FREQ10
+            and (mode == L.FIELD_SIGMA or (mode == L.FIELD_FULL and pk.has_transient)))
+
+
+def field_fwd_x6(pk: PackedField, mode, N, S, rays_o, rays_d, z, viewdirs=None, want_masks=False):
+    """field_fwd with the hidden 256x256 layers as bf16x6 split products (same outputs, same mask words)."""
+    dev = pk.blob.device
+    raw_t = torch.empty(N, pk.n_raw(mode), S, device=dev)
+    masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=dev) if want_masks else None
+    with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]},x6]"):
+        L.check(L.load().nefes_field_fwd_x6(pk.desc, _chk(pk.blob, "blob", torch.uint8), mode, N, S, _chk(rays_o, "rays_o"),
+                                            _chk(rays_d, "rays_d"), _chk(z, "z"), None, _chk(viewdirs, "viewdirs"),
+                                            _chk(raw_t, "raw_t"), _chk(masks, "masks", torch.int32), _stream()),
+                "nefes_field_fwd_x6")
+    return raw_t, masks
 
 
 def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=None, z=None, pts=None, viewdirs=None):
@@ -231,7 +248,10 @@ class FieldFromRays(torch.autograd.Function):
         rays_o, rays_d, viewdirs, z = _f32(rays_o), _f32(rays_d), _f32(viewdirs), _f32(z)
         N, S = z.shape
         need = mode == L.FIELD_FULL and any(ctx.needs_input_grad[:3])
-        raw_t, masks = field_fwd(pk, mode, N, S, rays_o=rays_o, rays_d=rays_d, z=z, viewdirs=viewdirs, want_masks=need)
+        if USE_X6 and x6_supported(pk, mode):
+            raw_t, masks = field_fwd_x6(pk, mode, N, S, rays_o, rays_d, z, viewdirs=viewdirs, want_masks=need)
+        else:
+            raw_t, masks = field_fwd(pk, mode, N, S, rays_o=rays_o, rays_d=rays_d, z=z, viewdirs=viewdirs, want_masks=need)
         ctx.pk, ctx.mode, ctx.have = pk, mode, need
         if need:
             ctx.save_for_backward(rays_o, rays_d, viewdirs, z, raw_t, masks)

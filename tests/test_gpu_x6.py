@@ -26,7 +26,7 @@ def test_sigma_x6_matches_fp32_kernel_and_oracle(N, S):
     o = torch.randn(N, 3, generator=g) * 0.3
     d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
     z = torch.sort(torch.rand(N, S, generator=g) * 3.8 + 0.1, -1)[0]
-    x6 = ops.field_fwd_sigma_x6(pk, N, S, o.to(DEV), d.to(DEV), z.to(DEV))
+    x6, _ = ops.field_fwd_x6(pk, L.FIELD_SIGMA, N, S, o.to(DEV), d.to(DEV), z.to(DEV))
     f32, _ = ops.field_fwd(pk, L.FIELD_SIGMA, N, S, rays_o=o.to(DEV), rays_d=d.to(DEV), z=z.to(DEV))
     p = {k: v.detach().cpu().double() for k, v in net.named_parameters() if not k.startswith(("fusion", "exposure"))}
     pts = (o[:, None, :] + d[:, None, :] * z[..., None])            # fp32 positions, as both kernels compute them
@@ -39,3 +39,78 @@ def test_sigma_x6_matches_fp32_kernel_and_oracle(N, S):
     e_ref = float((ref32.double() - ref).abs().max()) / sc
     print(f"[x6] sigma vs float64: bf16x6 {e_x6:.2e}  fp32-MFMA {e_f32:.2e}  torch fp32 {e_ref:.2e}")
     assert e_x6 <= max(2e-6, 3 * e_ref)
+
+
+@pytest.mark.parametrize("N,S", [(41, 24), (300, 64)])
+def test_full_x6_outputs_and_masks(N, S):
+    """FULL mode: all 25 raw channels against the float64 oracle, and the ReLU-mask words against the fp32 kernel's
+    (identical up to pre-activations within rounding of zero), so the unchanged backward kernel follows either forward."""
+    from nefes_amd import lib as L
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    net = NeRFH_NFF('fine', W=256, f_dim=16, encode_appearance=True, encode_transient=True).requires_grad_(False).to(DEV)
+    pk = net.packed()
+    g = torch.Generator().manual_seed(9)
+    o = torch.randn(N, 3, generator=g) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    z = torch.sort(torch.rand(N, S, generator=g) * 3.8 + 0.1, -1)[0]
+    od, dd, zd = o.to(DEV), d.to(DEV), z.to(DEV)
+    x6, m6 = ops.field_fwd_x6(pk, L.FIELD_FULL, N, S, od, dd, zd, viewdirs=dd, want_masks=True)
+    f32, m32 = ops.field_fwd(pk, L.FIELD_FULL, N, S, rays_o=od, rays_d=dd, z=zd, viewdirs=dd, want_masks=True)
+    p = {k: v.detach().cpu().double() for k, v in net.named_parameters()}
+    pts = o[:, None, :] + d[:, None, :] * z[..., None]
+    ref = O.query_field(p, pts.double(), d.double(), "fine", True, True)               # [N,S,25] float64
+    ref32 = O.query_field({k: v.float() for k, v in p.items()}, pts, d, "fine", True, True)
+    sc = ref.abs().amax((0, 1)).clamp_min(1e-30)                                         # per channel
+    e_x6 = float(((x6.permute(0, 2, 1).cpu().double() - ref).abs().amax((0, 1)) / sc).max())
+    e_f32 = float(((f32.permute(0, 2, 1).cpu().double() - ref).abs().amax((0, 1)) / sc).max())
+    e_ref = float(((ref32.double() - ref).abs().amax((0, 1)) / sc).max())
+    print(f"[x6] raw (25 ch) vs float64: bf16x6 {e_x6:.2e}  fp32-MFMA {e_f32:.2e}  torch fp32 {e_ref:.2e}")
+    assert e_x6 <= max(3e-6, 3 * e_ref)
+    n_tiles32 = ((N * S + 127) // 128) * 4
+    a = m6.view(n_tiles32, -1, 64)[: (N * S) // 32]                                     # whole 32-sample tiles only
+    b = m32.view(n_tiles32, -1, 64)[: (N * S) // 32]
+    diff_bits = int(sum(bin(int(v) & 0xffffffff).count("1") for v in (a ^ b).flatten().cpu().tolist() if v))
+    total_bits = a.numel() * 32
+    print(f"[x6] ReLU-mask bits differing from the fp32 kernel: {diff_bits} of {total_bits}")
+    assert diff_bits <= max(4, total_bits // 100000)
+
+
+def test_render_with_x6_forward_matches_oracle_gradient():
+    """End to end at the headline shape per ray: render() with the bf16x6 forward kernels (ops.USE_X6) and the unchanged
+    backward against the float64 oracle's pose gradient -- same bar as tests/test_gpu_parity.py."""
+    import types
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    from nefes_amd.render import render
+    coarse = NeRFH_NFF('coarse', W=256, f_dim=16).requires_grad_(False).to(DEV)
+    fine = NeRFH_NFF('fine', W=256, f_dim=16, encode_appearance=True, encode_transient=True).requires_grad_(False).to(DEV)
+    args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True)
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, N_samples=64, network_fn=coarse, network_fine=fine,
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=True, args=args, ndc=False, lindisp=False)
+    H, W, f = 6, 8, 525.505 * 8 / 640.
+    res = {}
+    for use in (False, True):
+        old, ops.USE_X6 = ops.USE_X6, use
+        try:
+            c2w = O.bench_pose().to(DEV).requires_grad_()
+            rgb, disp, acc, ex = render(H, W, f, c2w=c2w, near=0., far=4., **kw)
+            O.bench_loss(rgb, ex["feat_map"]).backward()
+            res[use] = (rgb.detach().cpu(), ex["feat_map"].detach().cpu(), c2w.grad.cpu())
+        finally:
+            ops.USE_X6 = old
+
+    def oracle(dt):
+        pc = {k: v.detach().cpu().to(dt) for k, v in coarse.named_parameters() if not k.startswith(("fusion", "exposure"))}
+        pf = {k: v.detach().cpu().to(dt) for k, v in fine.named_parameters()}
+        c = O.bench_pose(dt).requires_grad_()
+        rgb, _, _, ex = O.render(H, W, f, pc, pf, O.RenderCfg(N_samples=64, N_importance=128), c2w=c, near=0., far=4.)
+        O.bench_loss(rgb, ex["feat_map"]).backward()
+        return rgb.detach(), ex["feat_map"].detach(), c.grad
+
+    r64, r32 = oracle(torch.float64), oracle(torch.float32)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    assert rel(res[True][0], r64[0]) < 1e-4 and rel(res[True][1], r64[1]) < 1e-4
+    e_x6, e_f32, e_ref = rel(res[True][2], r64[2]), rel(res[False][2], r64[2]), rel(r32[2], r64[2])
+    print(f"[x6] d c2w vs float64: bf16x6 forward {e_x6:.2e}  fp32-MFMA forward {e_f32:.2e}  torch fp32 {e_ref:.2e}")
+    assert e_x6 <= max(1e-4, 3 * e_ref)
