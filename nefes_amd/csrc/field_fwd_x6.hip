@@ -14,8 +14,7 @@
 #include "field_common.h"
 #include "../../include/nefes_hip.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#include "field_x6.h"
 #define NEFES_X6_SLOTS 3   // 144 KiB ring
 
 struct FieldFwdX6Args {
@@ -33,120 +32,6 @@ struct FieldFwdX6Args {
     long long M;
     int n_tiles;
 };
-
-struct Split3 {
-    u32x4 h, m, l;           // 8 bf16 each: element i in the low/high half of dword i/2
-};
-
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
-    bf16x8 r;
-    __builtin_memcpy(&r, &v, 16);
-    return r;
-}
-__device__ __forceinline__ bf16x8 as_bf16x8(f32x4 v) {
-    bf16x8 r;
-    __builtin_memcpy(&r, &v, 16);
-    return r;
-}
-
-// relu(X[8j .. 8j+7] of tile T) -> three packed bf16 vectors (hi, mid, lo), x = hi + mid + lo exactly.
-// CAPTURE: also shift the sign bit of each pre-activation into the layer's ReLU-mask words, in the same order as the fp32
-// kernel (activation 8*s16 + i <-> k-step 16T + r there), so field_bwd_kernel reads identical words.
-template <bool CAPTURE, int NX, int NWORDS>
-__device__ __forceinline__ Split3 split_relu(const f32x16 (&X)[NX], int s16, uint32_t (&bits)[NWORDS]) {
-    const int T = s16 >> 1, r0 = (s16 & 1) * 8;
-    Split3 o;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const float v0 = X[T][r0 + 2 * p], v1 = X[T][r0 + 2 * p + 1];
-        if (CAPTURE) {
-            mask_shift_in(bits[(8 * s16 + 2 * p) >> 5], v0);
-            mask_shift_in(bits[(8 * s16 + 2 * p + 1) >> 5], v1);
-        }
-        const float x0 = fmaxf(v0, 0.f), x1 = fmaxf(v1, 0.f);
-        const uint32_t b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
-        const float e0 = x0 - __uint_as_float(b0 & 0xffff0000u), e1 = x1 - __uint_as_float(b1 & 0xffff0000u);   // exact
-        const uint32_t c0 = __float_as_uint(e0), c1 = __float_as_uint(e1);
-        const float f0 = e0 - __uint_as_float(c0 & 0xffff0000u), f1 = e1 - __uint_as_float(c1 & 0xffff0000u);   // exact, <= 8 bits
-        // v_perm_b32: bytes {src0 = element 1, src1 = element 0}; take the upper halves -> (hi16(x1) << 16) | hi16(x0)
-        o.h[p] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-        o.m[p] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
-        o.l[p] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
-    }
-    return o;
-}
-
-// acc[0..NT) = W * relu(X) over KS16 steps of 16 k-values, bias as the C operand of each tile's first MFMA.
-// Stream order: for k16-step q, for tile t: [A_hi | A_mid | A_lo] (3 KiB unit); 16 units per 48 KiB slab.
-template <int NT, int KS16, bool CAPTURE, class InitFn, int NX, int NWORDS, int SLOTS>
-__device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* ring_lane, const f32x16 (&X)[NX],
-                                           uint32_t (&bits)[NWORDS], const InitFn& init, f32x16 (&acc)[NT]) {
-    constexpr int UPS = (NEFES_SLAB_FRAGS / 4) / 3;       // units per slab
-    constexpr int NU = KS16 * NT;
-    constexpr int NSLAB = (NU + UPS - 1) / UPS;
-    Split3 B = split_relu<CAPTURE>(X, 0, bits), Bn = B;
-    f32x16 c0 = init(0);                                   // bias tile of the next first-step unit, fetched one unit ahead
-    const char* p = ring_lane + ring.cur_off;
-    f32x4 ah = ring.pf, am = *(const f32x4*)(p + 1024), al = *(const f32x4*)(p + 2048);
-#pragma unroll
-    for (int sl = 0; sl < NSLAB; ++sl) {
-        const int nu = (NU - sl * UPS) < UPS ? (NU - sl * UPS) : UPS;
-#pragma unroll
-        for (int uu = 0; uu < UPS; ++uu) {
-            if (uu < nu) {
-                const int u = sl * UPS + uu, q = u / NT, t = u % NT;
-                // A operands of the next unit (of this slab, or of the slab acquired here: the stream is one sequence)
-                f32x4 nh, nm, nl;
-                if (uu + 1 < nu) {
-                    nh = *(const f32x4*)(p + (3 * uu + 3) * 1024);
-                    nm = *(const f32x4*)(p + (3 * uu + 4) * 1024);
-                    nl = *(const f32x4*)(p + (3 * uu + 5) * 1024);
-                } else {
-#pragma unroll
-                    for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
-                        if ((qq * nu) / NEFES_SLAB_PIECES >= uu) ring.issue_piece(qq);   // everything still owed to this slab
-                    ring.cur_off = ring.acquire();
-                    p = ring_lane + ring.cur_off;
-                    nh = *(const f32x4*)(p);
-                    nm = *(const f32x4*)(p + 1024);
-                    nl = *(const f32x4*)(p + 2048);
-                }
-                if (t == 0 && q > 0) B = Bn;
-                __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 Ah = as_bf16x8(ah), Am = as_bf16x8(am), Al = as_bf16x8(al);
-                const bf16x8 Bh = as_bf16x8(B.h), Bm = as_bf16x8(B.m), Bl = as_bf16x8(B.l);
-                f32x16 c;
-                if (q == 0) {
-                    c = c0;
-                    if (t + 1 < NT) c0 = init(t + 1);
-                } else {
-                    c = acc[t];
-                }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, c, 0, 0, 0);      // small terms first
-                if (uu + 1 < nu) {
-#pragma unroll
-                    for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
-                        if ((qq * nu) / NEFES_SLAB_PIECES == uu) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            ring.issue_piece(qq);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, c, 0, 0, 0);
-                acc[t] = c;
-                // the next k16-step's operand: split in the gaps of this step's MFMAs (one eighth per tile would be finer;
-                // one block in the middle of the step is what the probe measured as hidden)
-                if (t == NT / 2 && q + 1 < KS16) Bn = split_relu<CAPTURE>(X, q + 1, bits);
-                ah = nh; am = nm; al = nl;
-            }
-        }
-    }
-    ring.pf = ah;
-}
 
 template <int MODE>   // NEFES_FIELD_SIGMA or NEFES_FIELD_FULL; Wd = 256, C = 16, frequency embedding
 __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) {
@@ -235,14 +120,14 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
         for (int p = 0; p < 4; ++p) {
             const int l1 = 2 + 2 * p, l2 = l1 + 1;
             clear_bits();
-            mma_run_x6<NTW, W / 16, CAP>(ring, ring_lane, A, bits, bias_at((l1 - 1) * W), B);         // layers 2, 4, 6, 8
+            mma_run_x6<NTW, W / 16, 0>(ring, ring_lane, ReluSplit<CAP, NTW, WT>{A, bits}, bias_at((l1 - 1) * W), B);   // layers 2, 4, 6, 8
             put_masks(bits, WT);                                                                      // mask of layer l1-1
             if (p == 3) {
                 if (MODE == NEFES_FIELD_SIGMA) break;
                 sigma_head(B);
             }
             clear_bits();
-            mma_run_x6<NTW, W / 16, CAP>(ring, ring_lane, B, bits, bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);   // 3, 5, 7, final
+            mma_run_x6<NTW, W / 16, 0>(ring, ring_lane, ReluSplit<CAP, NTW, WT>{B, bits}, bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);   // 3, 5, 7, final
             if (p == 1) mma_run<NTW, ES, 0, false>(ring, ring_lane, in_E, ZeroInit{}, A);            // skip: + W5[:, :63] e
             put_masks(bits, WT);                                                                      // mask of layer l1
         }
