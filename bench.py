@@ -293,10 +293,11 @@ def main():
         flop_fwd = 2.0 * macs_full(Wd, C, in_xyz) * rays_local * (Nc + Ni)
         fwd_key = next(k for k in kern if k.startswith("field_fwd[full"))
         x6 = fwd_key.endswith(",x6]")
-        dom_key = max((fwd_key, "field_bwd"), key=lambda k: kern[k])
+        bwd_key = next(k for k in kern if k.startswith("field_bwd"))
+        dom_key = max((fwd_key, bwd_key), key=lambda k: kern[k])
         ach = flop_fwd / (kern[dom_key] * 1e-3) / 1e12
         enc = int(wl['hashgrid'])
-        dom_name = (f"field_bwd_kernel<{Wd},{3 + C},{enc}>" if dom_key == "field_bwd"
+        dom_name = (f"field_bwd_kernel<{Wd},{3 + C},{enc}{',X6' if bwd_key.endswith('x6]') else ''}>" if dom_key == bwd_key
                     else (f"field_fwd_x6_kernel<FULL>" if x6 else f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{enc}>"))
         flop_frame = 2.0 * (Nc * macs_sigma(Wd, in_xyz) + 2 * (Nc + Ni) * macs_full(Wd, C, in_xyz)) * n_total
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure
@@ -307,7 +308,7 @@ def main():
             if (a.workload, H, W, world) == ("metric", 480, 640, 1):
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_per_launch.json")))
                 pref = dom_name.split("<")[0]
-                pm = next(v for k, v in pm.items() if k.startswith(pref) and ("256" in k or "x6" in k) and (dom_key == "field_bwd" or ", 2" in k or "<2" in k))
+                pm = next(v for k, v in pm.items() if k.startswith(pref) and ("256" in k or "x6" in k) and (dom_key == bwd_key or ", 2" in k or "<2" in k))
                 traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
         except Exception:
             traffic = None

@@ -6,6 +6,7 @@
 // Head activation derivatives are recovered from the raw outputs (softplus' = 1 - exp(-y), sigmoid' = y(1-y)).
 #define NEFES_SLAB_KIB NEFES_BWD_SLAB_KIB
 #include "field_common.h"
+#include "field_x6.h"
 #include "../../include/nefes_hip.h"
 
 struct FieldBwdArgs {
@@ -28,7 +29,9 @@ struct FieldBwdArgs {
 };
 
 
-template <int W, int C3, int ENC>   // C3 = 3 + C; ENC = NEFES_XYZ_*
+// X6: the eight 256x256 transposed products (xyz_encoding_final^T, layers 8..2) as bf16x6 split products (field_x6.h);
+// the stream then is NEFES_STREAM_BWD_FULL_X6.  Same mask words, same outputs.
+template <int W, int C3, int ENC, bool X6 = false>   // C3 = 3 + C; ENC = NEFES_XYZ_*
 __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
@@ -164,7 +167,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         {
             float dsg[1];
             dsg[0] = STASH(6);
-            mma_run<NTW, HS, 2, true>(ring, ring_lane, IdentIn<NTW + 2, 2>{XA}, ZeroInit{}, XB);
+            if constexpr (X6) mma_run_x6<NTW, W / 16, 2>(ring, ring_lane, IdentSplit<NTW + 2, 2>{XA}, ZeroInit{}, XB);
+            else mma_run<NTW, HS, 2, true>(ring, ring_lane, IdentIn<NTW + 2, 2>{XA}, ZeroInit{}, XB);
             mma_run<NTW, 1, 2, false>(ring, ring_lane, ArrayIn<1>{dsg}, ZeroInit{}, XB);
         }
         // ---- xyz_encoding_8^T .. xyz_encoding_2^T, straight-line (XB -> XA -> XB ...): a runtime loop over the ping-pong
@@ -172,7 +176,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         //      Layer 5 also emits the skip's d xyz-embedding into XB tiles 0,1. ----
 #define NEFES_BWD_LAYER(L, SRC, DST, NTILES, T0)                                                            \
         load_bits(bt, ((L) - 1) * WT, WT);                                                              \
-        mma_run<NTILES, HS, T0, true>(ring, ring_lane, MaskedIn<NTW + 2, WT, 2>{SRC, bt}, ZeroInit{}, DST);
+        if constexpr (X6) mma_run_x6<NTILES, W / 16, T0>(ring, ring_lane, MaskedSplit<NTW + 2, WT, 2>{SRC, bt}, ZeroInit{}, DST); \
+        else mma_run<NTILES, HS, T0, true>(ring, ring_lane, MaskedIn<NTW + 2, WT, 2>{SRC, bt}, ZeroInit{}, DST);
         NEFES_BWD_LAYER(8, XB, XA, NTW, 2)
         NEFES_BWD_LAYER(7, XA, XB, NTW, 2)
         NEFES_BWD_LAYER(6, XB, XA, NTW, 2)
@@ -227,10 +232,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     ring.drain();
 }
 
-template <int W, int C3, int ENC>
+template <int W, int C3, int ENC, bool X6 = false>
 static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_BWD_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (8 * (W / 64) + 4 * (W / 128) + 8) * 256;
-    auto k = field_bwd_kernel<W, C3, ENC>;
+    auto k = field_bwd_kernel<W, C3, ENC, X6>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -242,10 +247,10 @@ static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-extern "C" int nefes_field_bwd(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
-                               const float* rays_d, const float* z, const float* pts, const float* viewdirs,
-                               const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
-                               float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
+static int field_bwd_impl(bool x6, const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+                          const float* rays_d, const float* z, const float* pts, const float* viewdirs,
+                          const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
+                          float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
     if (!desc || !packed || !viewdirs || !raw_t || !g_raw_t || !masks || !g_viewdirs_s || N <= 0 || S <= 0)
         return NEFES_E_BADARG;
     const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
@@ -254,7 +259,7 @@ extern "C" int nefes_field_bwd(const NefesNetDesc* desc, const void* packed, int
     NefesBlobInfo info;
     int rc = nefes_blob_info(desc, &info);
     if (rc) return rc;
-    const NefesStreamInfo& si = info.stream[NEFES_STREAM_BWD_FULL];
+    const NefesStreamInfo& si = info.stream[x6 ? NEFES_STREAM_BWD_FULL_X6 : NEFES_STREAM_BWD_FULL];
     if (si.n_slabs == 0) return NEFES_E_UNSUPPORTED;
     FieldBwdArgs a;
     a.stream = (const char*)packed + si.slab_off;
@@ -265,8 +270,28 @@ extern "C" int nefes_field_bwd(const NefesNetDesc* desc, const void* packed, int
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
+    if (x6) {
+        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, true>(a, st);
+        return NEFES_E_UNSUPPORTED;
+    }
     if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10>(a, st);
     if (desc->width == 128 && desc->feat_dim == 128 && !ext) return launch_bwd<128, 131, NEFES_XYZ_FREQ10>(a, st);
     if (desc->width == 256 && desc->feat_dim == 16 && ext) return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32>(a, st);
     return NEFES_E_UNSUPPORTED;
+}
+
+extern "C" int nefes_field_bwd(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+                               const float* rays_d, const float* z, const float* pts, const float* viewdirs,
+                               const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
+                               float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
+    return field_bwd_impl(false, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
+                          g_viewdirs_s, stream);
+}
+
+extern "C" int nefes_field_bwd_x6(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+                                  const float* rays_d, const float* z, const float* pts, const float* viewdirs,
+                                  const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
+                                  float* g_viewdirs_s, void* stream) {
+    return field_bwd_impl(true, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr,
+                          g_viewdirs_s, stream);
 }

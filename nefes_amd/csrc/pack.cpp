@@ -193,7 +193,7 @@ void add_transient_head(const Net& n, Stream& st) {
 }
 
 // backward-to-inputs stream: A operand = W^T, B operand = upstream gradient vector
-void add_backward(const Net& n, Stream& st) {
+void add_backward(const Net& n, Stream& st, bool x6 = false) {
     const int W = n.W, W2 = n.W2, NTW = n.NTW, NTH = n.NTH;
     // static rgb/feature head^T first (its 3+C upstream values are consumed straight after the tile's loads):
     // in = 3+C grads (compact slots), out = d g
@@ -209,6 +209,7 @@ void add_backward(const Net& n, Stream& st) {
     st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_DIR), W + 27, true));
     // xyz_encoding_final^T, plus the static-sigma head as one extra k-step
     st.segs.push_back(seg(NTW, W / 2, k_natural(W / 2, 0), rows_natural(NTW, W), n.w(L_FINAL), W, true));
+    st.segs.back().x6 = x6;
     st.segs.push_back(seg(NTW, 1, k_compact(1, 1), rows_natural(NTW, W), n.w(L_SIGMA), W, true));
     for (int l = 7; l >= 0; --l) {
         if (l == 4) {
@@ -217,11 +218,13 @@ void add_backward(const Net& n, Stream& st) {
             std::vector<int> rows = concat(re, rows_natural(NTW, W));
             for (int i = (int)re.size(); i < (int)rows.size(); ++i) rows[i] += n.in_xyz;
             st.segs.push_back(seg(NTW + (int)re.size() / 32, W / 2, k_natural(W / 2, 0), rows, n.w(4), n.in_xyz + W, true));
+            st.segs.back().x6 = x6;
         } else if (l == 0) {
             const std::vector<int> re = rows_xyz(n, 0);
             st.segs.push_back(seg((int)re.size() / 32, W / 2, k_natural(W / 2, 0), re, n.w(0), n.in_xyz, true));
         } else {
             st.segs.push_back(seg(NTW, W / 2, k_natural(W / 2, 0), rows_natural(NTW, W), n.w(l), W, true));
+            st.segs.back().x6 = x6;
         }
     }
 }
@@ -269,6 +272,7 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
             add_trunk(n, st[NEFES_STREAM_FWD_FULL_X6], true);
             add_static_head(n, st[NEFES_STREAM_FWD_FULL_X6], true);
             add_transient_head(n, st[NEFES_STREAM_FWD_FULL_X6]);
+            add_backward(n, st[NEFES_STREAM_BWD_FULL_X6], true);
         }
     }
     return true;

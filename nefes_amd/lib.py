@@ -23,7 +23,7 @@ class NefesStreamInfo(C.Structure):
 
 
 class NefesBlobInfo(C.Structure):
-    _fields_ = [("total_bytes", C.c_uint64), ("stream", NefesStreamInfo * 6)]
+    _fields_ = [("total_bytes", C.c_uint64), ("stream", NefesStreamInfo * 7)]
 
 
 class NefesHashGridDesc(C.Structure):
@@ -61,6 +61,7 @@ SIGNATURES = {
     "nefes_hashgrid_table_entries": (_sz, [C.POINTER(NefesHashGridDesc)]),
     "nefes_hashgrid_fwd": (_i, [C.POINTER(NefesHashGridDesc), _p, C.c_int64, _p, _p, _p]),
     "nefes_hashgrid_bwd_x": (_i, [C.POINTER(NefesHashGridDesc), _p, C.c_int64, _p, _p, _p, _p]),
+    "nefes_field_bwd_x6": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_fwd_x6": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_train_rows": (_sz, [_desc]),
     "nefes_train_row_offset": (_i, [_desc, _i]),
@@ -90,7 +91,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError here = ABI mismatch; let it propagate
         fn.restype = res
         fn.argtypes = args
-    if lib.nefes_version() != 2:
+    if lib.nefes_version() != 3:
         raise RuntimeError("libnefes_hip.so ABI version mismatch")
     _lib = lib
     return lib

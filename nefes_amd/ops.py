@@ -221,6 +221,13 @@ def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=
     g_pts = None if ext else torch.empty(N * S, 3, device=dev)
     g_enc = torch.empty(N * S, 32, device=dev) if ext else None
     g_vs = torch.empty(N * S, 3, device=dev)
+    if USE_X6 and not ext and x6_supported(pk, L.FIELD_FULL):
+        with _timed("field_bwd[x6]"):
+            L.check(L.load().nefes_field_bwd_x6(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
+                                                _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),
+                                                _chk(raw_t, "raw_t"), _chk(g_raw_t, "g_raw_t"), _chk(masks, "masks", torch.int32),
+                                                _chk(g_pts, "g_pts"), _chk(g_vs, "g_vs"), _stream()), "nefes_field_bwd_x6")
+        return g_pts, g_vs
     with _timed("field_bwd"):
       L.check(L.load().nefes_field_bwd(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
                                      _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),

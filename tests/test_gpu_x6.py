@@ -114,3 +114,30 @@ def test_render_with_x6_forward_matches_oracle_gradient():
     e_x6, e_f32, e_ref = rel(res[True][2], r64[2]), rel(res[False][2], r64[2]), rel(r32[2], r64[2])
     print(f"[x6] d c2w vs float64: bf16x6 forward {e_x6:.2e}  fp32-MFMA forward {e_f32:.2e}  torch fp32 {e_ref:.2e}")
     assert e_x6 <= max(1e-4, 3 * e_ref)
+
+
+def test_backward_x6_matches_fp32_backward():
+    """nefes_field_bwd_x6 against nefes_field_bwd on identical forward outputs, masks and upstream gradients."""
+    from nefes_amd import lib as L
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    N, S = 53, 40
+    net = NeRFH_NFF('fine', W=256, f_dim=16, encode_appearance=True, encode_transient=True).requires_grad_(False).to(DEV)
+    pk = net.packed()
+    g = torch.Generator().manual_seed(13)
+    o = (torch.randn(N, 3, generator=g) * 0.3).to(DEV)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).to(DEV)
+    z = torch.sort(torch.rand(N, S, generator=g) * 3.8 + 0.1, -1)[0].to(DEV)
+    G = torch.randn(N, 25, S, generator=g).to(DEV)
+    raw_t, masks = ops.field_fwd(pk, L.FIELD_FULL, N, S, rays_o=o, rays_d=d, z=z, viewdirs=d, want_masks=True)
+    out = {}
+    for use in (False, True):
+        old, ops.USE_X6 = ops.USE_X6, use
+        try:
+            out[use] = ops.field_bwd(pk, N, S, raw_t, G, masks, rays_o=o, rays_d=d, z=z, viewdirs=d)
+        finally:
+            ops.USE_X6 = old
+    for a, b, name in ((out[True][0], out[False][0], "g_pts"), (out[True][1], out[False][1], "g_viewdirs")):
+        e = float((a - b).abs().max() / b.abs().max())
+        print(f"[x6] backward {name}: bf16x6 vs fp32-MFMA {e:.2e}")
+        assert e < 2e-5, name
