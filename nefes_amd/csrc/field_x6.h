@@ -48,43 +48,30 @@ template <bool CAPTURE, int NX, int NWORDS>
 struct ReluSplit {              // forward: relu(X) (+ mask capture)
     const f32x16 (&X)[NX];
     uint32_t (&bits)[NWORDS];
-    __device__ __forceinline__ Split3 get(int q) const {
-        Split3 o;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const float v0 = X[q >> 1][(q & 1) * 8 + 2 * p], v1 = X[q >> 1][(q & 1) * 8 + 2 * p + 1];
-            if (CAPTURE) {
-                mask_shift_in(bits[(8 * q + 2 * p) >> 5], v0);
-                mask_shift_in(bits[(8 * q + 2 * p + 1) >> 5], v1);
-            }
-            split_pair(o, p, fmaxf(v0, 0.f), fmaxf(v1, 0.f));
+    __device__ __forceinline__ void pair(Split3& o, int q, int p) const {      // values 2p, 2p+1 of k16-step q
+        const float v0 = X[q >> 1][(q & 1) * 8 + 2 * p], v1 = X[q >> 1][(q & 1) * 8 + 2 * p + 1];
+        if (CAPTURE) {
+            mask_shift_in(bits[(8 * q + 2 * p) >> 5], v0);
+            mask_shift_in(bits[(8 * q + 2 * p + 1) >> 5], v1);
         }
-        return o;
+        split_pair(o, p, relu1<false>(v0), relu1<false>(v1));                  // one v_max each (fmaxf canonicalises first)
     }
 };
 template <int NX, int NWORDS, int T0>
 struct MaskedSplit {            // backward: mask bit ? X : 0
     const f32x16 (&X)[NX];
     uint32_t (&bits)[NWORDS];
-    __device__ __forceinline__ Split3 get(int q) const {
-        Split3 o;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const float v0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
-            const float v1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
-            split_pair(o, p, v0, v1);
-        }
-        return o;
+    __device__ __forceinline__ void pair(Split3& o, int q, int p) const {
+        const float v0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
+        const float v1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
+        split_pair(o, p, v0, v1);
     }
 };
 template <int NX, int T0>
 struct IdentSplit {             // X as is
     const f32x16 (&X)[NX];
-    __device__ __forceinline__ Split3 get(int q) const {
-        Split3 o;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) split_pair(o, p, X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
-        return o;
+    __device__ __forceinline__ void pair(Split3& o, int q, int p) const {
+        split_pair(o, p, X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
     }
 };
 
@@ -97,7 +84,12 @@ __device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* 
     constexpr int UPS = (NEFES_SLAB_FRAGS / 4) / 3;       // units per slab
     constexpr int NU = KS16 * NT;
     constexpr int NSLAB = (NU + UPS - 1) / UPS;
-    Split3 B = src.get(0), Bn = B;
+    // the operand of k16-step q+1 is produced during step q, one pair of values per tile (every second tile for NT >= 8),
+    // so that pair's ~17 VALU instructions sit in the gaps of one unit's six MFMAs (3-4 per gap)
+    Split3 B, Bn;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) src.pair(B, 0, pp);
+    Bn = B;
     f32x16 c0 = init(0);                                   // bias tile of the next first-step unit, fetched one unit ahead
     const char* p = ring_lane + ring.cur_off;
     f32x4 ah = ring.pf, am = *(const f32x4*)(p + 1024), al = *(const f32x4*)(p + 2048);
@@ -151,9 +143,20 @@ __device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* 
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, c, 0, 0, 0);
                 acc[T0 + t] = c;
-                // the next k16-step's operand: split in the gaps of this step's MFMAs (one eighth per tile would be finer;
-                // one block in the middle of the step is what the probe measured as hidden)
-                if (t == NT / 2 && q + 1 < KS16) Bn = src.get(q + 1);
+                if (q + 1 < KS16) {
+                    constexpr int STRIDE = NT >= 8 ? 2 : 1;                   // tiles between two pairs
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp)
+                        if (t == pp * STRIDE + STRIDE - 1) {
+                            src.pair(Bn, q + 1, pp);
+                            // interleave: one MFMA, then up to four VALU instructions, five times
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            }
+                        }
+                }
                 ah = nh; am = nm; al = nl;
             }
         }
