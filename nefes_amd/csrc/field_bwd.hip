@@ -152,17 +152,21 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         mma_run<NTH, 3, 0, true>(ring, ring_lane, ArrayIn<3>{dth}, ZeroInit{}, T3);
         // ---- transient_encoding.4^T, .2^T ----
         load_bits(bh, MW_TRUNK + 3 * WH, WH);
-        mma_run<NTH, GS, 0, true>(ring, ring_lane, MaskedIn<NTH, WH>{T3, bh}, ZeroInit{}, T4);
+        if constexpr (X6) mma_run_x6<NTH, GS / 8, 0>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{T3, bh}, ZeroInit{}, T4);
+        else mma_run<NTH, GS, 0, true>(ring, ring_lane, MaskedIn<NTH, WH>{T3, bh}, ZeroInit{}, T4);
         load_bits(bh, MW_TRUNK + 2 * WH, WH);
-        mma_run<NTH, GS, 0, true>(ring, ring_lane, MaskedIn<NTH, WH>{T4, bh}, ZeroInit{}, T3);
+        if constexpr (X6) mma_run_x6<NTH, GS / 8, 0>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{T4, bh}, ZeroInit{}, T3);
+        else mma_run<NTH, GS, 0, true>(ring, ring_lane, MaskedIn<NTH, WH>{T4, bh}, ZeroInit{}, T3);
         // Full-width accumulators, ping-pong.  Tiles [2, NTW+2) hold a layer's d hidden; XA tile 1 = d dir-embedding;
         // XB tiles 0,1 = d xyz-embedding (written by layer 5, accumulated by layer 1).
         f32x16 XA[NTW + 2], XB[NTW + 2];
         // ---- [transient_encoding.0 ; dir_encoding]^T -> d dir-embedding (tile 1) + d final (tiles 2..) ----
         load_bits(bh, MW_TRUNK + WH, WH);
-        mma_run<NTW + 1, GS, 1, true>(ring, ring_lane, MaskedIn<NTH, WH>{T3, bh}, ZeroInit{}, XA);
+        if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{T3, bh}, ZeroInit{}, XA);
+        else mma_run<NTW + 1, GS, 1, true>(ring, ring_lane, MaskedIn<NTH, WH>{T3, bh}, ZeroInit{}, XA);
         load_bits(bh, MW_TRUNK, WH);
-        mma_run<NTW + 1, GS, 1, false>(ring, ring_lane, MaskedIn<NTH, WH>{G2, bh}, ZeroInit{}, XA);
+        if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1, false>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{G2, bh}, ZeroInit{}, XA);
+        else mma_run<NTW + 1, GS, 1, false>(ring, ring_lane, MaskedIn<NTH, WH>{G2, bh}, ZeroInit{}, XA);
         // ---- xyz_encoding_final^T (no ReLU on its output) + static_sigma^T (one extra k-step) -> d h8 ----
         {
             float dsg[1];
@@ -188,7 +192,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
 #undef NEFES_BWD_LAYER
         // ---- xyz_encoding_1^T accumulates onto the skip's d embedding ----
         load_bits(bt, 0, WT);
-        mma_run<2, HS, 0, false>(ring, ring_lane, MaskedIn<NTW + 2, WT, 2>{XA, bt}, ZeroInit{}, XB);
+        if constexpr (X6) mma_run_x6<2, W / 16, 0, false>(ring, ring_lane, MaskedSplit<NTW + 2, WT, 2>{XA, bt}, ZeroInit{}, XB);
+        else mma_run<2, HS, 0, false>(ring, ring_lane, MaskedIn<NTW + 2, WT, 2>{XA, bt}, ZeroInit{}, XB);
         float dDv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dDv[r] = XA[1][r];

@@ -1,7 +1,7 @@
 // Fused field forward with the trunk layers 2..8 as bf16x6 split products (sigma-only coarse pass, Wd = 256).
 // Same function as field_fwd_kernel<256,1,SIGMA,FREQ10> (script/models/nerfh_nff.py:192-202,525-555 + rendering.py:114):
-// pts = o + d*z -> frequency embedding -> 8-layer skip MLP -> static_sigma.  Layer 1, the skip's embedding part and the
-// sigma head stay on v_mfma_f32_32x32x2_f32; the seven 256x256 hidden products run on v_mfma_f32_32x32x16_bf16:
+// pts = o + d*z -> frequency embedding -> 8-layer skip MLP -> heads.  The one-tile heads (sigma, rgb+feature, transient)
+// and the 27-feature direction parts stay on v_mfma_f32_32x32x2_f32; every other product runs on v_mfma_f32_32x32x16_bf16:
 //     x = xh + xm + xl, w = wh + wm + wl exactly (three bf16 each: 24 = 3 x 8 mantissa bits, truncation split)
 //     w x ~= wh xh + wh xm + wm xh + wh xl + wl xh + wm xm        (dropped terms: relative size 2^-24)
 // accumulated in fp32 by the matrix core: fp32-level accuracy (tools/bf16x6_accuracy.py: 2.5e-7 of the output scale
@@ -47,6 +47,9 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
     WeightRing<NEFES_X6_SLOTS> ring;
     ring.init(a.stream, a.n_slabs, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_base, wave, lane);
     __syncthreads();
+#ifdef NEFES_STAMP
+    const unsigned long long stamp_t0 = ring.now();
+#endif
     const char* ring_lane = ring_base + lane * 16;
     const char* bias_half = (const char*)bias_lds + 16 * h;
     ring.prime(ring_lane);
@@ -79,8 +82,6 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
 #pragma unroll
         for (int c = 0; c < 3; ++c) x[c] = a.pts ? in_o[c] : add_rn(in_o[c], mul_rn(in_d[c], in_z));   // rendering.py:114,142
         embed_slots<NEFES_N_FREQ_XYZ>(E, x, h);
-        float Dv[NEFES_D_STEPS];
-        if (MODE != NEFES_FIELD_SIGMA) embed_slots<NEFES_N_FREQ_DIR>(Dv, v, h);
         uint32_t* mask_tile = (MODE == NEFES_FIELD_FULL && a.masks)
                                   ? a.masks + ((size_t)((long long)tile * 4 + wave) * MW) * 64
                                   : nullptr;
@@ -99,7 +100,6 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
         };
         auto bias_at = [&](int off_floats) { return BiasInit{bias_half + off_floats * 4}; };
         const ArrayIn<ES> in_E{E};
-        const ArrayIn<NEFES_D_STEPS> in_D{Dv};
         f32x16 A[NTW], B[NTW];
         uint32_t bits[WT];
         auto clear_bits = [&]() {
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
                 raw_col()[(size_t)ch * a.S] = softplus_ref(sg[0][0]);
             }
         };
-        mma_run<NTW, ES, 0, true>(ring, ring_lane, in_E, bias_at(0), A);                              // layer 1 (fp32)
+        mma_run_x6<NTW, ES / 8, 0>(ring, ring_lane, ArraySplit<ES>{E}, bias_at(0), A);               // layer 1
 #pragma unroll 1
         for (int p = 0; p < 4; ++p) {
             const int l1 = 2 + 2 * p, l2 = l1 + 1;
@@ -128,19 +128,23 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
             }
             clear_bits();
             mma_run_x6<NTW, W / 16, 0>(ring, ring_lane, ReluSplit<CAP, NTW, WT>{B, bits}, bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);   // 3, 5, 7, final
-            if (p == 1) mma_run<NTW, ES, 0, false>(ring, ring_lane, in_E, ZeroInit{}, A);            // skip: + W5[:, :63] e
+            if (p == 1) mma_run_x6<NTW, ES / 8, 0, false>(ring, ring_lane, ArraySplit<ES>{E}, ZeroInit{}, A);   // skip: + W5[:, :63] e
             put_masks(bits, WT);                                                                      // mask of layer l1
         }
         if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head(B);
         if constexpr (MODE == NEFES_FIELD_FULL) {
-            // the heads run on the fp32 path exactly as in field_fwd_kernel (21 % of the MACs)
+            // dir / transient encodings on bf16x6 too; their 27-feature direction parts and the three 1-tile heads stay fp32
+            // the direction embedding is computed here, not at the top of the tile: 3 live registers instead of 14
+            float Dv[NEFES_D_STEPS];
+            embed_slots<NEFES_N_FREQ_DIR>(Dv, v, h);
+            const ArrayIn<NEFES_D_STEPS> in_D{Dv};
             f32x16 acc2[NTH], acc3[NTH];
             uint32_t bits2[WH];
             auto clear2 = [&]() {
 #pragma unroll
                 for (int w = 0; w < WH; ++w) bits2[w] = 0u;
             };
-            mma_run<NTH, HS, 0, true>(ring, ring_lane, IdentIn<NTW>{A}, bias_at(B_DIR), acc2);
+            mma_run_x6<NTH, W / 16, 0>(ring, ring_lane, IdentSplit<NTW, 0>{A}, bias_at(B_DIR), acc2);
             mma_run<NTH, NEFES_D_STEPS, 0, false>(ring, ring_lane, in_D, ZeroInit{}, acc2);
             {
                 f32x16 ar[NTR];
@@ -159,10 +163,10 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
             mma_run<NTH, HS, 0, true>(ring, ring_lane, IdentIn<NTW>{A}, bias_at(B_T0), acc2);
             mma_run<NTH, NEFES_D_STEPS, 0, false>(ring, ring_lane, in_D, ZeroInit{}, acc2);
             clear2();
-            mma_run<NTH, GS, 0, true>(ring, ring_lane, ReluCapture<NTH, WH>{acc2, bits2}, bias_at(B_T1), acc3);
+            mma_run_x6<NTH, W / 32, 0>(ring, ring_lane, ReluSplit<true, NTH, WH>{acc2, bits2}, bias_at(B_T1), acc3);
             put_masks(bits2, WH);
             clear2();
-            mma_run<NTH, GS, 0, true>(ring, ring_lane, ReluCapture<NTH, WH>{acc3, bits2}, bias_at(B_T2), acc2);
+            mma_run_x6<NTH, W / 32, 0>(ring, ring_lane, ReluSplit<true, NTH, WH>{acc3, bits2}, bias_at(B_T2), acc2);
             put_masks(bits2, WH);
             f32x16 th[1];
             clear2();
@@ -182,6 +186,13 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
         }
     }
     ring.drain();
+#ifdef NEFES_STAMP   // diagnostic build: per workgroup [cycles in counted waits, cycles in barriers, total cycles, tiles] of wave 0
+    if (a.masks && MODE != NEFES_FIELD_FULL && threadIdx.x == 0) {
+        unsigned long long* o = (unsigned long long*)a.masks + (size_t)blockIdx.x * 4;
+        o[0] = ring.dbg_wait; o[1] = ring.dbg_barrier; o[2] = ring.now() - stamp_t0;
+        o[3] = (a.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    }
+#endif
 }
 
 template <int MODE>

@@ -77,7 +77,14 @@ struct IdentSplit {             // X as is
 
 // acc[T0 .. T0+NT) = W-block * src over KS16 steps of 16 k-values; init(t) (bias or zero) is the C operand of each tile's
 // first MFMA.  Stream order: for k16-step q, for tile t: [A_hi | A_mid | A_lo] (3 KiB unit); floor(slab KiB / 3) units per slab.
-template <int NT, int KS16, int T0, class SrcFn, class InitFn, int NACC, int SLOTS>
+template <int N>
+struct ArraySplit {             // per-lane values v[8q + i] (embedding slots) as they are
+    const float (&v)[N];
+    __device__ __forceinline__ void pair(Split3& o, int q, int p) const { split_pair(o, p, v[8 * q + 2 * p], v[8 * q + 2 * p + 1]); }
+};
+
+// FIRST = false: accumulate onto acc (init unused).
+template <int NT, int KS16, int T0, bool FIRST = true, class SrcFn, class InitFn, int NACC, int SLOTS>
 __device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* ring_lane, const SrcFn& src,
                                            const InitFn& init, f32x16 (&acc)[NACC]) {
     static_assert(T0 + NT <= NACC, "accumulator array too small");
@@ -90,7 +97,8 @@ __device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* 
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) src.pair(B, 0, pp);
     Bn = B;
-    f32x16 c0 = init(0);                                   // bias tile of the next first-step unit, fetched one unit ahead
+    f32x16 c0;                                             // bias tile of the next first-step unit, fetched one unit ahead
+    if (FIRST) c0 = init(0);
     const char* p = ring_lane + ring.cur_off;
     f32x4 ah = ring.pf, am = *(const f32x4*)(p + 1024), al = *(const f32x4*)(p + 2048);
 #pragma unroll
@@ -121,7 +129,7 @@ __device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* 
                 const bf16x8 Ah = as_bf16x8(ah), Am = as_bf16x8(am), Al = as_bf16x8(al);
                 const bf16x8 Bh = as_bf16x8(B.h), Bm = as_bf16x8(B.m), Bl = as_bf16x8(B.l);
                 f32x16 c;
-                if (q == 0) {
+                if (FIRST && q == 0) {
                     c = c0;
                     if (t + 1 < NT) c0 = init(t + 1);
                 } else {
@@ -147,7 +155,7 @@ __device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* 
                     constexpr int STRIDE = NT >= 8 ? 2 : 1;                   // tiles between two pairs
 #pragma unroll
                     for (int pp = 0; pp < 4; ++pp)
-                        if (t == pp * STRIDE + STRIDE - 1) {
+                        if (NT >= 4 ? (t == pp * STRIDE + STRIDE - 1) : (t == (pp * NT) / 4)) {
                             src.pair(Bn, q + 1, pp);
                             // interleave: one MFMA, then up to four VALU instructions, five times
 #pragma unroll

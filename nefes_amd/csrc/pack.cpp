@@ -151,11 +151,13 @@ void add_trunk(const Net& n, Stream& st, bool x6 = false) {
     for (int l = 0; l < 8; ++l) {
         if (l == 0) {
             st.segs.push_back(seg(NT, n.e_steps, k_xyz(n, 0), rows_natural(NT, W), n.w(0), n.in_xyz));
+            st.segs.back().x6 = x6;
         } else if (l == 4) {  // skip layer: columns [xyz(63), h(W)]  (nerfh_nff.py:472-473,551-552)
             // the kernels accumulate the hidden part first (its first k-step carries the bias), then the xyz part
             st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, n.in_xyz), rows_natural(NT, W), n.w(4), n.in_xyz + W));
             st.segs.back().x6 = x6;
             st.segs.push_back(seg(NT, n.e_steps, k_xyz(n, 0), rows_natural(NT, W), n.w(4), n.in_xyz + W));
+            st.segs.back().x6 = x6;
         } else {
             st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, 0), rows_natural(NT, W), n.w(l), W));
             st.segs.back().x6 = x6;
@@ -173,19 +175,22 @@ void add_static_head(const Net& n, Stream& st, bool x6 = false) {
     st.segs.back().x6 = x6;                                            // xyz_encoding_final: a 256x256 product like the trunk
     st.bias.push_back({n.b(L_FINAL), rows_natural(n.NTW, W)});
     st.segs.push_back(seg(n.NTH, W / 2, k_natural(W / 2, 0), rows_natural(n.NTH, W2), n.w(L_DIR), W + 27));
+    st.segs.back().x6 = x6;
     st.segs.push_back(seg(n.NTH, NEFES_D_STEPS, k_emb(4, NEFES_D_STEPS, W), rows_natural(n.NTH, W2), n.w(L_DIR), W + 27));
     st.bias.push_back({n.b(L_DIR), rows_natural(n.NTH, W2)});
     st.segs.push_back(seg(n.NTR, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTR, 3 + n.C), n.w(L_RGB), W2));
     st.bias.push_back({n.b(L_RGB), rows_natural(n.NTR, 3 + n.C)});
 }
 
-void add_transient_head(const Net& n, Stream& st) {
+void add_transient_head(const Net& n, Stream& st, bool x6 = false) {
     const int W = n.W, W2 = n.W2;
+    // (transient_encoding.0 stays fp32: with both it and dir_encoding on bf16x6 the forward kernel spills registers)
     st.segs.push_back(seg(n.NTH, W / 2, k_natural(W / 2, 0), rows_natural(n.NTH, W2), n.w(L_T0), W + 27));
     st.segs.push_back(seg(n.NTH, NEFES_D_STEPS, k_emb(4, NEFES_D_STEPS, W), rows_natural(n.NTH, W2), n.w(L_T0), W + 27));
     st.bias.push_back({n.b(L_T0), rows_natural(n.NTH, W2)});
     for (int l = L_T1; l <= L_T2; ++l) {
         st.segs.push_back(seg(n.NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTH, W2), n.w(l), W2));
+        st.segs.back().x6 = x6;
         st.bias.push_back({n.b(l), rows_natural(n.NTH, W2)});
     }
     st.segs.push_back(seg(1, W2 / 2, k_natural(W2 / 2, 0), rows_natural(1, 5), n.th_w.data(), W2));
@@ -202,11 +207,15 @@ void add_backward(const Net& n, Stream& st, bool x6 = false) {
     // transient heads^T: in = 5 pre-activation grads (compact slots), out = d t2
     st.segs.push_back(seg(NTH, 3, k_compact(3, 5), rows_natural(NTH, W2), n.th_w.data(), W2, true));
     st.segs.push_back(seg(NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(NTH, W2), n.w(L_T2), W2, true));
+    st.segs.back().x6 = x6;
     st.segs.push_back(seg(NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(NTH, W2), n.w(L_T1), W2, true));
+    st.segs.back().x6 = x6;
     // [transient_encoding.0 ; dir_encoding]^T: out rows = dir-embedding slots (1 tile) then final features (NTW tiles)
     std::vector<int> rows_fd = concat(rows_emb(4, 1, W), rows_natural(NTW, W));
     st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_T0), W + 27, true));
+    st.segs.back().x6 = x6;
     st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_DIR), W + 27, true));
+    st.segs.back().x6 = x6;
     // xyz_encoding_final^T, plus the static-sigma head as one extra k-step
     st.segs.push_back(seg(NTW, W / 2, k_natural(W / 2, 0), rows_natural(NTW, W), n.w(L_FINAL), W, true));
     st.segs.back().x6 = x6;
@@ -222,6 +231,7 @@ void add_backward(const Net& n, Stream& st, bool x6 = false) {
         } else if (l == 0) {
             const std::vector<int> re = rows_xyz(n, 0);
             st.segs.push_back(seg((int)re.size() / 32, W / 2, k_natural(W / 2, 0), re, n.w(0), n.in_xyz, true));
+            st.segs.back().x6 = x6;
         } else {
             st.segs.push_back(seg(NTW, W / 2, k_natural(W / 2, 0), rows_natural(NTW, W), n.w(l), W, true));
             st.segs.back().x6 = x6;
@@ -271,7 +281,7 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
         if (n.transient && n.C == 16) {
             add_trunk(n, st[NEFES_STREAM_FWD_FULL_X6], true);
             add_static_head(n, st[NEFES_STREAM_FWD_FULL_X6], true);
-            add_transient_head(n, st[NEFES_STREAM_FWD_FULL_X6]);
+            add_transient_head(n, st[NEFES_STREAM_FWD_FULL_X6], true);
             add_backward(n, st[NEFES_STREAM_BWD_FULL_X6], true);
         }
     }

@@ -21,3 +21,13 @@ for mode, name in ((L.FIELD_SIGMA, 'sigma'), (L.FIELD_STATIC, 'static')):
     st = stats.view(256, 4).double()
     tot = st[:, 2].sum()
     print(name, "wait %.2f%%  barrier %.2f%%  cycles/tile %.0f (memtime ticks)" % (100 * st[:, 0].sum() / tot, 100 * st[:, 1].sum() / tot, float(tot / st[:, 3].sum())))
+
+# bf16x6 sigma kernel (NEFES_STAMP build of field_fwd_x6.hip)
+raw = torch.empty(N, 1, S, device=dev)
+stats = torch.zeros(256 * 4, dtype=torch.int64, device=dev)
+L.check(L.load().nefes_field_fwd_x6(pk.desc, pk.blob.data_ptr(), L.FIELD_SIGMA, N, S, o.data_ptr(), d.data_ptr(), z.data_ptr(), None,
+                                    None, raw.data_ptr(), stats.data_ptr(), ops._stream()), "fwd_x6")
+torch.cuda.synchronize()
+st = stats.view(256, 4).double()
+tot = st[:, 2].sum()
+print("sigma x6", "wait %.2f%%  barrier %.2f%%  cycles/tile %.0f" % (100 * st[:, 0].sum() / tot, 100 * st[:, 1].sum() / tot, float(tot / st[:, 3].sum())))
