@@ -45,6 +45,7 @@ WORKLOADS = {
 }
 
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
@@ -289,16 +290,21 @@ def main():
         kern = {k: sum(s.elapsed_time(e) for s, e in v) / len(v) for k, v in timers.items()}   # ms per launch, rank 0
         rays_local = nrows * W
         # Dominant kernel = the longest-running launch of the step.  Fine-field forward (FULL mode) and backward-to-inputs
-        # do the same algorithmic MACs per sample; algorithmic FLOPs per launch / launch time, against the fp32-MFMA peak.
+        # do the same algorithmic MACs per sample.  roofline.achieved = algorithmic fp32 FLOPs per launch / launch time.
+        # Peak: a plain fp32-MFMA kernel is bounded by 157.3 TFLOP/s; a bf16x6 kernel executes six bf16 MFMA FLOPs per
+        # algorithmic FLOP, so its bound is the dense bf16 MFMA peak / 6 = 416.7 TFLOP/s of algorithmic work.
         flop_fwd = 2.0 * macs_full(Wd, C, in_xyz) * rays_local * (Nc + Ni)
         fwd_key = next(k for k in kern if k.startswith("field_fwd[full"))
-        x6 = fwd_key.endswith(",x6]")
         bwd_key = next(k for k in kern if k.startswith("field_bwd"))
         dom_key = max((fwd_key, bwd_key), key=lambda k: kern[k])
+        x6 = dom_key.endswith("x6]")
         ach = flop_fwd / (kern[dom_key] * 1e-3) / 1e12
         enc = int(wl['hashgrid'])
-        dom_name = (f"field_bwd_kernel<{Wd},{3 + C},{enc}{',X6' if bwd_key.endswith('x6]') else ''}>" if dom_key == bwd_key
-                    else (f"field_fwd_x6_kernel<FULL>" if x6 else f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{enc}>"))
+        if dom_key == bwd_key:
+            dom_name = f"field_bwd_kernel<{Wd},{3 + C},{enc}{',X6' if x6 else ''}>"
+        else:
+            dom_name = "field_fwd_x6_kernel<FULL>" if x6 else f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{enc}>"
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x6 else PEAK_F32_MFMA_TFLOPS
         flop_frame = 2.0 * (Nc * macs_sigma(Wd, in_xyz) + 2 * (Nc + Ni) * macs_full(Wd, C, in_xyz)) * n_total
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure
         # comes from the committed rocprofv3 passes of this same command (profiles/, 2*FETCH_SIZE + WRITE_SIZE in KiB,
@@ -307,20 +313,14 @@ def main():
         try:
             if (a.workload, H, W, world) == ("metric", 480, 640, 1):
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_per_launch.json")))
-                pref = dom_name.split("<")[0]
-                pm = next(v for k, v in pm.items() if k.startswith(pref) and ("256" in k or "x6" in k) and (dom_key == bwd_key or ", 2" in k or "<2" in k))
+                if dom_key == bwd_key:
+                    want = "field_bwd_kernel<256,19,0,true>" if x6 else "field_bwd_kernel<256,19,0"
+                else:
+                    want = "field_fwd_x6_kernel<2>" if x6 else "field_fwd_kernel<256,1,2"
+                pm = next(v for k, v in pm.items() if k.replace(" ", "").startswith(want))
                 traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
         except Exception:
             traffic = None
-        fwd_info = None
-        if x6:   # forward passes on bf16x6: algorithmic fp32 FLOPs per second, and executed bf16 MFMA FLOPs against the bf16 peak
-            t_f = kern[fwd_key] * 1e-3
-            exec_bf16 = 6 * 2.0 * 8 * Wd * Wd * rays_local * (Nc + Ni)
-            fwd_info = {"kernel": "field_fwd_x6_kernel<FULL>", "ms": round(kern[fwd_key], 4),
-                        "algorithmic_tflops": flop_fwd / t_f / 1e12,
-                        "frac_of_fp32_mfma_peak": flop_fwd / t_f / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                        "executed_bf16_tflops": exec_bf16 / t_f / 1e12, "bf16_mfma_peak": 2500.0,
-                        "note": "hidden 256x256 layers as bf16x6 split products (6 bf16 MFMA FLOPs per algorithmic FLOP), fp32-level accuracy"}
         out = {
             "metric": "rays/s (fwd+bwd) at 640x480x(64+128) samples, 8x256 MLP" if a.workload == "metric"
                       else f"rays/s (fwd+bwd), secondary workload '{a.workload}'", "value": value, "unit": "rays/s",
@@ -329,14 +329,15 @@ def main():
             "config": {"workload": f"{wl['name']}; {W}x{H}, random seed-0 weights, fwd + bwd to the 3x4 pose",
                        "rays_per_step": n_total, "samples_per_ray": [Nc, Ni], "parallelism": f"rows/{world}"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": ach,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         "peak_basis": ("dense bf16 MFMA peak 2500 / 6: bf16x6 split products, fp32-level accuracy" if x6
+                                        else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                         "vs_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes/launch (HBM side, from profiles/r01 PMC passes)",
                          "end_to_end_frac": value * (flop_frame / n_total) / (PEAK_F32_MFMA_TFLOPS * 1e12 * world)},
             "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items())},
             "pose_grad_abs_max": float(g.abs().max()),
         }
-        if fwd_info:
-            out["forward_x6"] = fwd_info
         if world == 1 and a.cpu_rows > 0 and a.workload == "metric":
             out["cpu_baseline"] = cpu_baseline(Wd, C, Nc, Ni, a.cpu_rows, W, focal)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
