@@ -38,17 +38,19 @@ __device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 #else
-    // s_nop 4 first: the SGPR base may have just been written by a VALU instruction (v_readlane restoring a spilled
-    // SGPR, v_readfirstlane) and a VMEM instruction reading such an SGPR needs 5 wait states the compiler does not
-    // insert for inline asm.  (Measured without it: +0.3 % forward -- not worth the exposure.)
+    // The SGPR base may have just been written by a VALU instruction (v_readlane restoring a spilled SGPR,
+    // v_readfirstlane), and a VMEM instruction reading such an SGPR needs 5 wait states the compiler does not insert for
+    // inline asm.  Instead of padding (s_nop 4 = 20 cycles, a large part of a 32-cycle bf16 MFMA gap) the base is copied
+    // by the scalar ALU into a fresh pair that the DMA reads: SALU-written SGPRs carry no such hazard.
+    uint64_t base2;
     asm volatile(
-        "s_nop 4\n\t"
+        "s_mov_b64 %1, %3\n\t"
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
+        "s_mov_b32 m0, %4\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %2, %1\n\t"
         "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        : "=&s"(keep), "=&s"(base2)
         : "v"(lane_off), "s"(gbase), "s"(lds_dst)
         : "memory");
 #endif

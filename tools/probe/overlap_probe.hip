@@ -93,7 +93,7 @@ __device__ __forceinline__ void dma16(const void* gbase, unsigned lane_off, unsi
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
 }
-template <int P, int NV>
+template <int P, int NV, int IL = 0>
 __global__ __launch_bounds__(256, 1) void dma_mix(const char* blob, float* out, unsigned long long* cyc, int n_slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -118,22 +118,23 @@ __global__ __launch_bounds__(256, 1) void dma_mix(const char* blob, float* out, 
             f32x4 fc = *(const f32x4*)(rd + slot * 49152 + (3 * u + 2) * 1024);
             bf16x8 a0, a1, a2;
             __builtin_memcpy(&a0, &fa, 16); __builtin_memcpy(&a1, &fb, 16); __builtin_memcpy(&a2, &fc, 16);
-            acc[u & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[u & 7], 0, 0, 0);
+            const int x0 = u & 7, x1 = IL ? ((u + 4) & 7) : (u & 7);     // IL: alternate between two accumulators
+            acc[x0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[x0], 0, 0, 0);
             if (u * P / 16 != (u + 1) * P / 16) {
                 __builtin_amdgcn_sched_barrier(0);
                 for (int q = u * P / 16; q < (u + 1) * P / 16; ++q)
                     dma16(src + q * 4096, lane_off, lds0 + ((slot + 2) % 3) * 49152 + wave * 1024 + q * 4096);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            acc[u & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[u & 7], 0, 0, 0);
+            acc[x1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[x1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NV; ++i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[i & 7]) : "v"(v[(i + 1) & 7]));
             __builtin_amdgcn_sched_barrier(0);
-            acc[u & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[u & 7], 0, 0, 0);
-            acc[u & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bh, acc[u & 7], 0, 0, 0);
-            acc[u & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bh, acc[u & 7], 0, 0, 0);
-            acc[u & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bh, acc[u & 7], 0, 0, 0);
+            acc[x0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[x0], 0, 0, 0);
+            acc[x1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bh, acc[x1], 0, 0, 0);
+            acc[x0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bh, acc[x0], 0, 0, 0);
+            acc[x1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bh, acc[x1], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(P) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -146,15 +147,15 @@ __global__ __launch_bounds__(256, 1) void dma_mix(const char* blob, float* out, 
     out[threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
-template <int P, int NV>
+template <int P, int NV, int IL = 0>
 static void run_mix(float* d_out, unsigned long long* d_cyc, const char* blob) {
     unsigned long long h;
     const int n = 200;
-    hipFuncSetAttribute((const void*)dma_mix<P, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((dma_mix<P, NV>), dim3(256), dim3(256), 3 * 49152, 0, blob, d_out, d_cyc, n);
+    hipFuncSetAttribute((const void*)dma_mix<P, NV, IL>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((dma_mix<P, NV, IL>), dim3(256), dim3(256), 3 * 49152, 0, blob, d_out, d_cyc, n);
     hipDeviceSynchronize();
     hipMemcpy(&h, d_cyc, sizeof(h), hipMemcpyDeviceToHost);
-    printf("bf16x6 mix: %2d DMA pieces + 48 ds_read_b128 + %2d VALU/unit per 96 MFMAs: %.1f cycles per MFMA (floor 32)\n", P, NV, (double)h / (n * 96.0));
+    printf("%s", IL ? "[two accumulators alternating] " : ""); printf("bf16x6 mix: %2d DMA pieces + 48 ds_read_b128 + %2d VALU/unit per 96 MFMAs: %.1f cycles per MFMA (floor 32)\n", P, NV, (double)h / (n * 96.0));
 }
 
 template <int KIND>
@@ -185,5 +186,6 @@ int main() {
     char* blob; hipMalloc(&blob, 64 * 49152); hipMemset(blob, 0, 64 * 49152);
     run_mix<0, 0>(d_out, d_cyc, blob); run_mix<12, 0>(d_out, d_cyc, blob); run_mix<12, 8>(d_out, d_cyc, blob); run_mix<12, 16>(d_out, d_cyc, blob);
     run_mix<6, 8>(d_out, d_cyc, blob);
+    run_mix<0, 0, 1>(d_out, d_cyc, blob); run_mix<12, 8, 1>(d_out, d_cyc, blob);
     return 0;
 }
