@@ -164,17 +164,17 @@ int nefes_hashgrid_bwd_x(const NefesHashGridDesc* desc, const float* table, int6
 
 /* nefes_field_fwd(mode = NEFES_FIELD_SIGMA or NEFES_FIELD_FULL) with the hidden 256x256 products (layers 2..8 and
  * xyz_encoding_final) as bf16x6 split products on v_mfma_f32_32x32x16_bf16 -- exact hi/mid/lo bf16 triples, six cross terms,
- * fp32 accumulation: fp32-level accuracy (nefes_amd/csrc/field_fwd_x6.hip).  Width 256, C = 16, frequency embedding;
+ * fp32 accumulation: fp32-level accuracy (nefes_amd/csrc/field_fwd_x6.hip).  Width 256, C = 16, either xyz encoding;
  * same outputs and the same ReLU-mask words as nefes_field_fwd, so nefes_field_bwd follows unchanged. */
 int nefes_field_fwd_x6(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
-                       const float* rays_d, const float* z, const float* pts, const float* viewdirs, float* raw_t,
-                       uint32_t* masks, void* stream);
+                       const float* rays_d, const float* z, const float* pts, const float* xyz_enc, const float* viewdirs,
+                       float* raw_t, uint32_t* masks, void* stream);
 
-/* nefes_field_bwd (width 256, C = 16, frequency embedding) with the eight 256x256 transposed products as bf16x6 split
+/* nefes_field_bwd (width 256, C = 16) with the transposed products as bf16x6 split
  * products; consumes the mask words of either forward kernel. */
 int nefes_field_bwd_x6(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
                        const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
-                       const uint32_t* masks, float* g_pts, float* g_viewdirs_s, void* stream);
+                       const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);
 
 /* ---- train mode: weight gradients (script/run_nefes.py:42-108 `loss.backward()` through models/nerfh_nff.py:525-576) ----
  * Buffers `acts` / `dacts`: fp32 [n_tiles = ceil(N*S/128)][rows][128 samples], rows = nefes_train_rows(desc); row blocks

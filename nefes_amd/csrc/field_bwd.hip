@@ -277,6 +277,7 @@ static int field_bwd_impl(bool x6, const NefesNetDesc* desc, const void* packed,
     hipStream_t st = (hipStream_t)stream;
     if (x6) {
         if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, true>(a, st);
+        if (desc->width == 256 && desc->feat_dim == 16 && ext) return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32, true>(a, st);
         return NEFES_E_UNSUPPORTED;
     }
     if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10>(a, st);
@@ -296,7 +297,7 @@ extern "C" int nefes_field_bwd(const NefesNetDesc* desc, const void* packed, int
 extern "C" int nefes_field_bwd_x6(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
                                   const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                   const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
-                                  float* g_viewdirs_s, void* stream) {
-    return field_bwd_impl(true, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr,
+                                  float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
+    return field_bwd_impl(true, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
                           g_viewdirs_s, stream);
 }

@@ -25,6 +25,7 @@ struct FieldFwdX6Args {
     const float* rays_d;
     const float* z;
     const float* pts;
+    const float* xyz_enc;    // [M,32] (NEFES_XYZ_EXTERNAL32) or null
     const float* viewdirs;   // [N,3] (FULL)
     float* raw_t;            // [N][R][S]
     uint32_t* masks;         // [tiles32][MW][64] or null (FULL)
@@ -33,9 +34,11 @@ struct FieldFwdX6Args {
     int n_tiles;
 };
 
-template <int MODE>   // NEFES_FIELD_SIGMA or NEFES_FIELD_FULL; Wd = 256, C = 16, frequency embedding
+// MODE: NEFES_FIELD_SIGMA or NEFES_FIELD_FULL; ENC: NEFES_XYZ_FREQ10 or NEFES_XYZ_EXTERNAL32 (hash grid); Wd = 256, C = 16
+template <int MODE, int ENC>
 __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) {
-    constexpr int W = 256, NTW = 8, NTH = 4, NTR = 1, HS = W / 2, GS = W / 4, ES = NEFES_E_STEPS;
+    constexpr int W = 256, NTW = 8, NTH = 4, NTR = 1, HS = W / 2, GS = W / 4;
+    constexpr int ES = ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : NEFES_E_STEPS;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128), WT = 4, WH = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring_base = smem;
@@ -64,7 +67,11 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
         const int ray = (int)(m / a.S);
         const int smp = (int)(m - (long long)ray * a.S);
         float in_o[3] = {0.f, 0.f, 0.f}, in_d[3] = {0.f, 0.f, 0.f}, in_z = 0.f, v[3] = {0.f, 0.f, 0.f};
-        if (a.pts) {
+        float E[ES];
+        if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+#pragma unroll
+            for (int s = 0; s < ES; ++s) E[s] = a.xyz_enc[m * 32 + 2 * s + h];    // compact slots: feature 2s+h
+        } else if (a.pts) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) in_o[c] = a.pts[m * 3 + c];
         } else {
@@ -78,10 +85,14 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
         }
         loads_landed();
         pin(in_o); pin(in_d); pin(in_z); pin(v);
-        float E[ES], x[3];
+        if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+            pin(E);
+        } else {
+            float x[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) x[c] = a.pts ? in_o[c] : add_rn(in_o[c], mul_rn(in_d[c], in_z));   // rendering.py:114,142
-        embed_slots<NEFES_N_FREQ_XYZ>(E, x, h);
+            for (int c = 0; c < 3; ++c) x[c] = a.pts ? in_o[c] : add_rn(in_o[c], mul_rn(in_d[c], in_z));   // rendering.py:114,142
+            embed_slots<NEFES_N_FREQ_XYZ>(E, x, h);
+        }
         uint32_t* mask_tile = (MODE == NEFES_FIELD_FULL && a.masks)
                                   ? a.masks + ((size_t)((long long)tile * 4 + wave) * MW) * 64
                                   : nullptr;
@@ -195,10 +206,10 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
 #endif
 }
 
-template <int MODE>
+template <int MODE, int ENC>
 static int launch_x6(const FieldFwdX6Args& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_X6_SLOTS * NEFES_SLAB_BYTES + ((a.bias_floats * 4 + 255) / 256) * 256;
-    auto k = field_fwd_x6_kernel<MODE>;
+    auto k = field_fwd_x6_kernel<MODE, ENC>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -210,13 +221,14 @@ static int launch_x6(const FieldFwdX6Args& a, hipStream_t st) {
 }
 
 extern "C" int nefes_field_fwd_x6(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
-                                  const float* rays_d, const float* z, const float* pts, const float* viewdirs, float* raw_t,
-                                  uint32_t* masks, void* stream) {
+                                  const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
+                                  const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
     if (!desc || !packed || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
-    if (!pts && !(rays_o && rays_d && z)) return NEFES_E_BADARG;
+    const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
+    if (ext ? !xyz_enc : (!pts && !(rays_o && rays_d && z))) return NEFES_E_BADARG;
     if (mode != NEFES_FIELD_SIGMA && mode != NEFES_FIELD_FULL) return NEFES_E_UNSUPPORTED;
     if (mode == NEFES_FIELD_FULL && (!viewdirs || !desc->has_transient)) return NEFES_E_BADARG;
-    if (desc->width != 256 || desc->feat_dim != 16 || desc->xyz_encoding != NEFES_XYZ_FREQ10) return NEFES_E_UNSUPPORTED;
+    if (desc->width != 256 || desc->feat_dim != 16 || (desc->xyz_encoding != NEFES_XYZ_FREQ10 && !ext)) return NEFES_E_UNSUPPORTED;
     NefesBlobInfo info;
     int rc = nefes_blob_info(desc, &info);
     if (rc) return rc;
@@ -226,10 +238,15 @@ extern "C" int nefes_field_fwd_x6(const NefesNetDesc* desc, const void* packed, 
     a.stream = (const char*)packed + si.slab_off;
     a.bias = (const float*)((const char*)packed + si.bias_off);
     a.n_slabs = si.n_slabs; a.bias_floats = si.bias_floats;
-    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.viewdirs = viewdirs; a.raw_t = raw_t; a.masks = masks;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.xyz_enc = xyz_enc; a.viewdirs = viewdirs; a.raw_t = raw_t; a.masks = masks;
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = mode == NEFES_FIELD_SIGMA ? 1 : 3 + a.C + 6;
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
-    if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA>(a, (hipStream_t)stream);
-    return launch_x6<NEFES_FIELD_FULL>(a, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (ext) {
+        if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32>(a, st);
+        return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32>(a, st);
+    }
+    if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10>(a, st);
+    return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10>(a, st);
 }

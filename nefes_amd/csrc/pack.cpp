@@ -276,7 +276,7 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
         add_transient_head(n, st[NEFES_STREAM_FWD_FULL]);
         add_backward(n, st[NEFES_STREAM_BWD_FULL]);
     }
-    if (n.W == 256 && !n.ext) {                                         // bf16x6 hidden products (layout.h)
+    if (n.W == 256) {                                                   // bf16x6 products (layout.h)
         add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_X6], true);
         if (n.transient && n.C == 16) {
             add_trunk(n, st[NEFES_STREAM_FWD_FULL_X6], true);

@@ -61,8 +61,8 @@ SIGNATURES = {
     "nefes_hashgrid_table_entries": (_sz, [C.POINTER(NefesHashGridDesc)]),
     "nefes_hashgrid_fwd": (_i, [C.POINTER(NefesHashGridDesc), _p, C.c_int64, _p, _p, _p]),
     "nefes_hashgrid_bwd_x": (_i, [C.POINTER(NefesHashGridDesc), _p, C.c_int64, _p, _p, _p, _p]),
-    "nefes_field_bwd_x6": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "nefes_field_fwd_x6": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_field_bwd_x6": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_field_fwd_x6": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_train_rows": (_sz, [_desc]),
     "nefes_train_row_offset": (_i, [_desc, _i]),
     "nefes_field_fwd_train": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -198,18 +198,18 @@ USE_X6 = os.environ.get("NEFES_X6", "1") != "0"
 
 def x6_supported(pk: PackedField, mode):
     """bf16x6 instances exist for the headline shape: width 256, C = 16, frequency embedding, sigma-only or full mode."""
-    return (pk.width == 256 and pk.feat_dim == 16 and pk.xyz_encoding == L.XYZ_FREQ10
+    return (pk.width == 256 and pk.feat_dim == 16
             and (mode == L.FIELD_SIGMA or (mode == L.FIELD_FULL and pk.has_transient)))
 
 
-def field_fwd_x6(pk: PackedField, mode, N, S, rays_o, rays_d, z, viewdirs=None, want_masks=False):
+def field_fwd_x6(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, viewdirs=None, want_masks=False, xyz_enc=None):
     """field_fwd with the hidden 256x256 layers as bf16x6 split products (same outputs, same mask words)."""
     dev = pk.blob.device
     raw_t = torch.empty(N, pk.n_raw(mode), S, device=dev)
     masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=dev) if want_masks else None
     with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]},x6]"):
         L.check(L.load().nefes_field_fwd_x6(pk.desc, _chk(pk.blob, "blob", torch.uint8), mode, N, S, _chk(rays_o, "rays_o"),
-                                            _chk(rays_d, "rays_d"), _chk(z, "z"), None, _chk(viewdirs, "viewdirs"),
+                                            _chk(rays_d, "rays_d"), _chk(z, "z"), None, _chk(xyz_enc, "xyz_enc"), _chk(viewdirs, "viewdirs"),
                                             _chk(raw_t, "raw_t"), _chk(masks, "masks", torch.int32), _stream()),
                 "nefes_field_fwd_x6")
     return raw_t, masks
@@ -221,13 +221,14 @@ def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=
     g_pts = None if ext else torch.empty(N * S, 3, device=dev)
     g_enc = torch.empty(N * S, 32, device=dev) if ext else None
     g_vs = torch.empty(N * S, 3, device=dev)
-    if USE_X6 and not ext and x6_supported(pk, L.FIELD_FULL):
+    if USE_X6 and x6_supported(pk, L.FIELD_FULL):
         with _timed("field_bwd[x6]"):
             L.check(L.load().nefes_field_bwd_x6(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
                                                 _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),
                                                 _chk(raw_t, "raw_t"), _chk(g_raw_t, "g_raw_t"), _chk(masks, "masks", torch.int32),
-                                                _chk(g_pts, "g_pts"), _chk(g_vs, "g_vs"), _stream()), "nefes_field_bwd_x6")
-        return g_pts, g_vs
+                                                _chk(g_pts, "g_pts"), _chk(g_enc, "g_enc"), _chk(g_vs, "g_vs"), _stream()),
+                    "nefes_field_bwd_x6")
+        return (g_enc if ext else g_pts), g_vs
     with _timed("field_bwd"):
       L.check(L.load().nefes_field_bwd(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
                                      _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),
@@ -316,7 +317,10 @@ class FieldFromEncoding(torch.autograd.Function):
         N, S = enc.shape[0], enc.shape[1]
         viewdirs = torch.zeros(N, 3, device=enc.device) if viewdirs is None else _f32(viewdirs)
         need = mode == L.FIELD_FULL and any(ctx.needs_input_grad[:2])
-        raw_t, masks = field_fwd(pk, mode, N, S, xyz_enc=enc.reshape(-1, 32), viewdirs=viewdirs, want_masks=need)
+        if USE_X6 and x6_supported(pk, mode):
+            raw_t, masks = field_fwd_x6(pk, mode, N, S, xyz_enc=enc.reshape(-1, 32), viewdirs=viewdirs, want_masks=need)
+        else:
+            raw_t, masks = field_fwd(pk, mode, N, S, xyz_enc=enc.reshape(-1, 32), viewdirs=viewdirs, want_masks=need)
         ctx.pk, ctx.have = pk, need
         if need:
             ctx.save_for_backward(viewdirs, raw_t, masks)
