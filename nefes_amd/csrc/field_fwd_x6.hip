@@ -34,12 +34,13 @@ struct FieldFwdX6Args {
     int n_tiles;
 };
 
-// MODE: NEFES_FIELD_SIGMA or NEFES_FIELD_FULL; ENC: NEFES_XYZ_FREQ10 or NEFES_XYZ_EXTERNAL32 (hash grid); Wd = 256, C = 16
-template <int MODE, int ENC>
+// MODE: NEFES_FIELD_SIGMA or NEFES_FIELD_FULL; ENC: NEFES_XYZ_FREQ10 or NEFES_XYZ_EXTERNAL32 (hash grid);
+// (W, NTR) = (256, 1) [C = 16] or (128, 5) [C = 128: the reference-default shape]
+template <int MODE, int ENC, int W = 256, int NTR = 1>
 __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) {
-    constexpr int W = 256, NTW = 8, NTH = 4, NTR = 1, HS = W / 2, GS = W / 4;
+    constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
     constexpr int ES = ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : NEFES_E_STEPS;
-    constexpr int MW = 8 * (W / 64) + 4 * (W / 128), WT = 4, WH = 2;
+    constexpr int MW = 8 * (W / 64) + 4 * (W / 128), WT = (NTW + 1) / 2, WH = (NTH + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring_base = smem;
     float* bias_lds = (float*)(smem + NEFES_X6_SLOTS * NEFES_SLAB_BYTES);
@@ -165,10 +166,12 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
                 if (valid) {
                     float* ph = raw_col() + (size_t)(4 * h) * a.S;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int cu = nefes_rho(0, r);
-                        if (cu + 4 * h < 3 + a.C) ph[(size_t)cu * a.S] = ar[0][r];
-                    }
+                    for (int t = 0; t < NTR; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int cu = 32 * t + nefes_rho(0, r);
+                            if (cu + 4 * h < 3 + a.C) ph[(size_t)cu * a.S] = ar[t][r];
+                        }
                 }
             }
             mma_run<NTH, HS, 0, true>(ring, ring_lane, IdentIn<NTW>{A}, bias_at(B_T0), acc2);
@@ -206,10 +209,10 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
 #endif
 }
 
-template <int MODE, int ENC>
+template <int MODE, int ENC, int W = 256, int NTR = 1>
 static int launch_x6(const FieldFwdX6Args& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_X6_SLOTS * NEFES_SLAB_BYTES + ((a.bias_floats * 4 + 255) / 256) * 256;
-    auto k = field_fwd_x6_kernel<MODE, ENC>;
+    auto k = field_fwd_x6_kernel<MODE, ENC, W, NTR>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -228,7 +231,8 @@ extern "C" int nefes_field_fwd_x6(const NefesNetDesc* desc, const void* packed, 
     if (ext ? !xyz_enc : (!pts && !(rays_o && rays_d && z))) return NEFES_E_BADARG;
     if (mode != NEFES_FIELD_SIGMA && mode != NEFES_FIELD_FULL) return NEFES_E_UNSUPPORTED;
     if (mode == NEFES_FIELD_FULL && (!viewdirs || !desc->has_transient)) return NEFES_E_BADARG;
-    if (desc->width != 256 || desc->feat_dim != 16 || (desc->xyz_encoding != NEFES_XYZ_FREQ10 && !ext)) return NEFES_E_UNSUPPORTED;
+    const bool big = desc->width == 256 && desc->feat_dim == 16, small = desc->width == 128 && desc->feat_dim == 128 && !ext;
+    if (!(big || small) || (desc->xyz_encoding != NEFES_XYZ_FREQ10 && !ext)) return NEFES_E_UNSUPPORTED;
     NefesBlobInfo info;
     int rc = nefes_blob_info(desc, &info);
     if (rc) return rc;
@@ -243,6 +247,10 @@ extern "C" int nefes_field_fwd_x6(const NefesNetDesc* desc, const void* packed, 
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
+    if (small) {
+        if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5>(a, st);
+        return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5>(a, st);
+    }
     if (ext) {
         if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32>(a, st);
         return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32>(a, st);

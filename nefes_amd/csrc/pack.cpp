@@ -276,13 +276,14 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
         add_transient_head(n, st[NEFES_STREAM_FWD_FULL]);
         add_backward(n, st[NEFES_STREAM_BWD_FULL]);
     }
-    if (n.W == 256) {                                                   // bf16x6 products (layout.h)
+    const bool big = n.W == 256, small = n.W == 128 && n.C == 128 && !n.ext;   // shapes with bf16x6 instances (layout.h)
+    if (big || small) {
         add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_X6], true);
-        if (n.transient && n.C == 16) {
+        if (n.transient && (small || n.C == 16)) {
             add_trunk(n, st[NEFES_STREAM_FWD_FULL_X6], true);
             add_static_head(n, st[NEFES_STREAM_FWD_FULL_X6], true);
             add_transient_head(n, st[NEFES_STREAM_FWD_FULL_X6], true);
-            add_backward(n, st[NEFES_STREAM_BWD_FULL_X6], true);
+            if (big) add_backward(n, st[NEFES_STREAM_BWD_FULL_X6], true);   // (the Wd = 128 backward is at its register limit)
         }
     }
     return true;

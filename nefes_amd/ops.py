@@ -196,10 +196,11 @@ def field_fwd(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, pts
 USE_X6 = os.environ.get("NEFES_X6", "1") != "0"
 
 
-def x6_supported(pk: PackedField, mode):
-    """bf16x6 instances exist for the headline shape: width 256, C = 16, frequency embedding, sigma-only or full mode."""
-    return (pk.width == 256 and pk.feat_dim == 16
-            and (mode == L.FIELD_SIGMA or (mode == L.FIELD_FULL and pk.has_transient)))
+def x6_supported(pk: PackedField, mode, forward=True):
+    """bf16x6 instances: width 256 / C = 16 (forward and backward, either xyz encoding) and the reference-default
+    width 128 / C = 128 (forward only); sigma-only or full mode."""
+    ok = (pk.width == 256 and pk.feat_dim == 16) or (forward and pk.width == 128 and pk.feat_dim == 128 and pk.xyz_encoding == L.XYZ_FREQ10)
+    return ok and (mode == L.FIELD_SIGMA or (mode == L.FIELD_FULL and pk.has_transient))
 
 
 def field_fwd_x6(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, viewdirs=None, want_masks=False, xyz_enc=None):
@@ -221,7 +222,7 @@ def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=
     g_pts = None if ext else torch.empty(N * S, 3, device=dev)
     g_enc = torch.empty(N * S, 32, device=dev) if ext else None
     g_vs = torch.empty(N * S, 3, device=dev)
-    if USE_X6 and x6_supported(pk, L.FIELD_FULL):
+    if USE_X6 and x6_supported(pk, L.FIELD_FULL, forward=False):
         with _timed("field_bwd[x6]"):
             L.check(L.load().nefes_field_bwd_x6(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
                                                 _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),

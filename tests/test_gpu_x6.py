@@ -141,3 +141,36 @@ def test_backward_x6_matches_fp32_backward():
         e = float((a - b).abs().max() / b.abs().max())
         print(f"[x6] backward {name}: bf16x6 vs fp32-MFMA {e:.2e}")
         assert e < 2e-5, name
+
+
+def test_reference_default_shape_x6_forward():
+    """Wd = 128, C = 128 (the reference's default shape): bf16x6 forward instances against the float64 oracle and the fp32
+    kernel's mask words."""
+    from nefes_amd import lib as L
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    N, S = 61, 32
+    fine = NeRFH_NFF('fine', W=128, f_dim=128, encode_appearance=True, encode_transient=True).requires_grad_(False).to(DEV)
+    pk = fine.packed()
+    g = torch.Generator().manual_seed(17)
+    o = torch.randn(N, 3, generator=g) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    z = torch.sort(torch.rand(N, S, generator=g) * 3.8 + 0.1, -1)[0]
+    od, dd, zd = o.to(DEV), d.to(DEV), z.to(DEV)
+    x6, m6 = ops.field_fwd_x6(pk, L.FIELD_FULL, N, S, od, dd, zd, viewdirs=dd, want_masks=True)
+    f32, m32 = ops.field_fwd(pk, L.FIELD_FULL, N, S, rays_o=od, rays_d=dd, z=zd, viewdirs=dd, want_masks=True)
+    s6, _ = ops.field_fwd_x6(pk, L.FIELD_SIGMA, N, S, od, dd, zd)
+    p = {k: v.detach().cpu().double() for k, v in fine.named_parameters()}
+    pts = o[:, None, :] + d[:, None, :] * z[..., None]
+    ref = O.query_field(p, pts.double(), d.double(), "fine", True, True)
+    ref32 = O.query_field({k: v.float() for k, v in p.items()}, pts, d, "fine", True, True)
+    sc = ref.abs().amax((0, 1)).clamp_min(1e-30)
+    e_x6 = float(((x6.permute(0, 2, 1).cpu().double() - ref).abs().amax((0, 1)) / sc).max())
+    e_ref = float(((ref32.double() - ref).abs().amax((0, 1)) / sc).max())
+    e_sig = float((s6[:, 0].cpu().double() - ref[..., 3 + 128]).abs().max() / ref[..., 3 + 128].abs().max())
+    print(f"[x6] Wd=128: raw (137 ch) vs float64: bf16x6 {e_x6:.2e}  torch fp32 {e_ref:.2e};  sigma-only {e_sig:.2e}")
+    assert e_x6 <= max(3e-6, 3 * e_ref) and e_sig <= max(3e-6, 3 * e_ref)
+    n32, words = (N * S) // 32, 8 * (128 // 64) + 4 * (128 // 128)                      # whole 32-sample tiles, mask words
+    a, b = m6.view(-1, words, 64)[:n32], m32.view(-1, words, 64)[:n32]
+    diff = int(sum(bin(int(v) & 0xffffffff).count("1") for v in (a ^ b).flatten().cpu().tolist() if v))
+    assert diff <= 4, diff
