@@ -293,3 +293,31 @@ def test_packed_streams_reproduce_the_mlp(Wd, Cf):
     scale = np.abs(g_emb.numpy()).max()
     np.testing.assert_allclose(g63, g_emb.numpy()[:, :63], rtol=1e-4, atol=2e-5 * scale)
     np.testing.assert_allclose(g27, g_emb.numpy()[:, 63:], rtol=1e-4, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize("Wd,Cf", [(256, 16), (128, 128)])
+def test_x6_stream_decodes_to_the_weights(Wd, Cf):
+    """bf16x6 streams (layout.h, pack.cpp x6 segments): every weight is stored as an exact (hi, mid, lo) bf16 triple in the
+    A-operand order of v_mfma_f32_32x32x16_bf16 -- lane (m, g) of unit (k16-step q, tile t) holds W[32t+m][slot(8q+i, g)].
+    Decodes layer 2 of the sigma-only x6 stream (the first hidden 1:1 layer) back into the weight matrix."""
+    p, info, blob = pack(Wd, Cf, "coarse")
+    si = info.stream[L.STREAM_FWD_SIGMA_X6]
+    assert si.n_slabs > 0
+    slab_bytes, ups = 48 * 1024, 16
+    nt, k16 = Wd // 32, Wd // 16
+    # segment order: layer 1 (embedding part: 4 k16-steps x nt tiles), then layer 2
+    l1_slabs = (4 * nt + ups - 1) // ups
+    raw = np.frombuffer(blob, np.uint16, count=si.n_slabs * slab_bytes // 2, offset=si.slab_off).reshape(si.n_slabs, slab_bytes // 2)
+    Wm = p["xyz_encoding_2.0.weight"].numpy()
+    got = np.zeros_like(Wm)
+    for u in range(k16 * nt):
+        sl, uu = l1_slabs + u // ups, u % ups
+        q, t = u // nt, u % nt
+        unit = raw[sl, uu * 1536:(uu + 1) * 1536].reshape(3, 64, 8).astype(np.uint32)        # [part][lane][i]
+        val = sum((unit[pp] << 16).view(np.float32).astype(np.float64) for pp in range(3))     # hi + mid + lo
+        for lane in range(64):
+            m, g = lane & 31, lane >> 5
+            for i in range(8):
+                s = 8 * q + i
+                got[32 * t + m, 32 * (s >> 4) + rho(g, s & 15)] = val[lane, i]
+    assert np.array_equal(got, Wm)                                                           # exact, not approximately
