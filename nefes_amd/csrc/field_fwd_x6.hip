@@ -145,24 +145,28 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
         }
         if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head(B);
         if constexpr (MODE == NEFES_FIELD_FULL) {
-            // dir / transient encodings on bf16x6 too; their 27-feature direction parts and the three 1-tile heads stay fp32
-            // the direction embedding is computed here, not at the top of the tile: 3 live registers instead of 14
+            // dir_encoding and transient_encoding.0 as ONE stacked 2*NTH-tile product (pack.cpp add_heads_x6): tiles
+            // [0, NTH) = dir, [NTH, 2 NTH) = t0; their 27-feature direction part and the one-tile heads stay fp32
             float Dv[NEFES_D_STEPS];
             embed_slots<NEFES_N_FREQ_DIR>(Dv, v, h);
             const ArrayIn<NEFES_D_STEPS> in_D{Dv};
-            f32x16 acc2[NTH], acc3[NTH];
+            f32x16 dt[2 * NTH], acc3[NTH], acc2[NTH];
             uint32_t bits2[WH];
             auto clear2 = [&]() {
 #pragma unroll
                 for (int w = 0; w < WH; ++w) bits2[w] = 0u;
             };
-            mma_run_x6<NTH, W / 16, 0>(ring, ring_lane, IdentSplit<NTW, 0>{A}, bias_at(B_DIR), acc2);
-            mma_run<NTH, NEFES_D_STEPS, 0, false>(ring, ring_lane, in_D, ZeroInit{}, acc2);
+            struct Bias2 {             // C operands of the stacked product: dir bias tiles, then t0 bias tiles
+                BiasInit a, b;
+                __device__ __forceinline__ f32x16 operator()(int t) const { return t < NTH ? a(t) : b(t - NTH); }
+            };
+            mma_run_x6<2 * NTH, W / 16, 0>(ring, ring_lane, IdentSplit<NTW, 0>{A}, Bias2{bias_at(B_DIR), bias_at(B_T0)}, dt);
+            mma_run<2 * NTH, NEFES_D_STEPS, 0, false>(ring, ring_lane, in_D, ZeroInit{}, dt);
             {
                 f32x16 ar[NTR];
                 clear2();
-                mma_run<NTR, GS, 0, true>(ring, ring_lane, ReluCapture<NTH, WH>{acc2, bits2}, bias_at(B_RGB), ar);
-                put_masks(bits2, WH);
+                mma_run<NTR, GS, 0, true>(ring, ring_lane, ReluCapture<2 * NTH, WH>{dt, bits2}, bias_at(B_RGB), ar);
+                put_masks(bits2, WH);                                 // dir_encoding
                 if (valid) {
                     float* ph = raw_col() + (size_t)(4 * h) * a.S;
 #pragma unroll
@@ -174,14 +178,12 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
                         }
                 }
             }
-            mma_run<NTH, HS, 0, true>(ring, ring_lane, IdentIn<NTW>{A}, bias_at(B_T0), acc2);
-            mma_run<NTH, NEFES_D_STEPS, 0, false>(ring, ring_lane, in_D, ZeroInit{}, acc2);
             clear2();
-            mma_run_x6<NTH, W / 32, 0>(ring, ring_lane, ReluSplit<true, NTH, WH>{acc2, bits2}, bias_at(B_T1), acc3);
-            put_masks(bits2, WH);
+            mma_run_x6<NTH, W / 32, 0>(ring, ring_lane, ReluSplit<true, 2 * NTH, WH, NTH>{dt, bits2}, bias_at(B_T1), acc3);
+            put_masks(bits2, WH);                                     // transient_encoding.0
             clear2();
             mma_run_x6<NTH, W / 32, 0>(ring, ring_lane, ReluSplit<true, NTH, WH>{acc3, bits2}, bias_at(B_T2), acc2);
-            put_masks(bits2, WH);
+            put_masks(bits2, WH);                                     // transient_encoding.2
             f32x16 th[1];
             clear2();
             mma_run<1, GS, 0, true>(ring, ring_lane, ReluCapture<NTH, WH>{acc2, bits2}, bias_at(B_TH), th);

@@ -44,12 +44,12 @@ __device__ __forceinline__ void split_pair(Split3& o, int p, float x0, float x1)
 // B-operand sources: get(q) = the 8 values of k16-step q (source tile T0 + q/2, registers 8(q%2) .. +7), transformed and
 // split.  The mask-touching ones walk the activations in the same order as the fp32 functors (activation 8q + i <-> k-step
 // 16T + r there), so forward and backward kernels of either kind exchange identical ReLU-mask words.
-template <bool CAPTURE, int NX, int NWORDS>
-struct ReluSplit {              // forward: relu(X) (+ mask capture)
+template <bool CAPTURE, int NX, int NWORDS, int T0 = 0>
+struct ReluSplit {              // forward: relu(X) (+ mask capture), source tiles T0..
     const f32x16 (&X)[NX];
     uint32_t (&bits)[NWORDS];
     __device__ __forceinline__ void pair(Split3& o, int q, int p) const {      // values 2p, 2p+1 of k16-step q
-        const float v0 = X[q >> 1][(q & 1) * 8 + 2 * p], v1 = X[q >> 1][(q & 1) * 8 + 2 * p + 1];
+        const float v0 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p], v1 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1];
         if (CAPTURE) {
             mask_shift_in(bits[(8 * q + 2 * p) >> 5], v0);
             mask_shift_in(bits[(8 * q + 2 * p + 1) >> 5], v1);

@@ -122,6 +122,7 @@ struct Net {
     int in_xyz, e_steps;
     const float* const* t;
     std::vector<float> th_w, th_b;  // virtual transient-head matrix [5][W2]: rgb(3), sigma, beta
+    std::vector<float> dt_w;        // virtual stacked [dir_encoding ; transient_encoding.0] matrix [2 W2][W + 27] (x6 streams)
     const float* w(int l) const { return t[2 * l]; }
     const float* b(int l) const { return t[2 * l + 1]; }
 };
@@ -180,6 +181,31 @@ void add_static_head(const Net& n, Stream& st, bool x6 = false) {
     st.bias.push_back({n.b(L_DIR), rows_natural(n.NTH, W2)});
     st.segs.push_back(seg(n.NTR, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTR, 3 + n.C), n.w(L_RGB), W2));
     st.bias.push_back({n.b(L_RGB), rows_natural(n.NTR, 3 + n.C)});
+}
+
+// x6 forward streams: dir_encoding and transient_encoding.0 read the same input (cat[final, dir-emb]), so they run as ONE
+// product with 2*NTH tiles (rows: dir | t0): one operand split instead of two, and the standard 8-tile shape at Wd = 256.
+// Segment order: FINAL, [DIR;T0] hidden part (x6), [DIR;T0] direction part (fp32), RGB, T1, T2, TH; bias blocks keep the
+// order of the fp32 streams (FINAL, DIR, RGB, T0, T1, T2, TH).
+void add_heads_x6(const Net& n, Stream& st) {
+    const int W = n.W, W2 = n.W2;
+    st.segs.push_back(seg(n.NTW, W / 2, k_natural(W / 2, 0), rows_natural(n.NTW, W), n.w(L_FINAL), W));
+    st.segs.back().x6 = true;
+    st.bias.push_back({n.b(L_FINAL), rows_natural(n.NTW, W)});
+    st.segs.push_back(seg(2 * n.NTH, W / 2, k_natural(W / 2, 0), rows_natural(2 * n.NTH, 2 * W2), n.dt_w.data(), W + 27));
+    st.segs.back().x6 = true;
+    st.segs.push_back(seg(2 * n.NTH, NEFES_D_STEPS, k_emb(4, NEFES_D_STEPS, W), rows_natural(2 * n.NTH, 2 * W2), n.dt_w.data(), W + 27));
+    st.bias.push_back({n.b(L_DIR), rows_natural(n.NTH, W2)});
+    st.segs.push_back(seg(n.NTR, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTR, 3 + n.C), n.w(L_RGB), W2));
+    st.bias.push_back({n.b(L_RGB), rows_natural(n.NTR, 3 + n.C)});
+    st.bias.push_back({n.b(L_T0), rows_natural(n.NTH, W2)});
+    for (int l = L_T1; l <= L_T2; ++l) {
+        st.segs.push_back(seg(n.NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTH, W2), n.w(l), W2));
+        st.segs.back().x6 = true;
+        st.bias.push_back({n.b(l), rows_natural(n.NTH, W2)});
+    }
+    st.segs.push_back(seg(1, W2 / 2, k_natural(W2 / 2, 0), rows_natural(1, 5), n.th_w.data(), W2));
+    st.bias.push_back({n.th_b.data(), rows_natural(1, 5)});
 }
 
 void add_transient_head(const Net& n, Stream& st, bool x6 = false) {
@@ -260,7 +286,11 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
         memcpy(&n.th_b[0], n.b(L_TRGB), sizeof(float) * 3);
         n.th_b[3] = n.b(L_TSIGMA)[0];
         n.th_b[4] = n.b(L_TBETA)[0];
+        n.dt_w.resize((size_t)2 * n.W2 * (n.W + 27));
+        memcpy(&n.dt_w[0], n.w(L_DIR), sizeof(float) * n.W2 * (n.W + 27));
+        memcpy(&n.dt_w[(size_t)n.W2 * (n.W + 27)], n.w(L_T0), sizeof(float) * n.W2 * (n.W + 27));
     } else {
+        n.dt_w.assign((size_t)2 * n.W2 * (n.W + 27), 0.f);
         n.th_w.assign((size_t)5 * n.W2, 0.f);
         n.th_b.assign(5, 0.f);
     }
@@ -281,8 +311,7 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
         add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_X6], true);
         if (n.transient && (small || n.C == 16)) {
             add_trunk(n, st[NEFES_STREAM_FWD_FULL_X6], true);
-            add_static_head(n, st[NEFES_STREAM_FWD_FULL_X6], true);
-            add_transient_head(n, st[NEFES_STREAM_FWD_FULL_X6], true);
+            add_heads_x6(n, st[NEFES_STREAM_FWD_FULL_X6]);
             if (big) add_backward(n, st[NEFES_STREAM_BWD_FULL_X6], true);   // (the Wd = 128 backward is at its register limit)
         }
     }
