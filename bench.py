@@ -316,7 +316,7 @@ def main():
                 if dom_key == bwd_key:
                     want = "field_bwd_kernel<256,19,0,true>" if x6 else "field_bwd_kernel<256,19,0"
                 else:
-                    want = "field_fwd_x6_kernel<2>" if x6 else "field_fwd_kernel<256,1,2"
+                    want = "field_fwd_x6_kernel<2," if x6 else "field_fwd_kernel<256,1,2"
                 pm = next(v for k, v in pm.items() if k.replace(" ", "").startswith(want))
                 traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
         except Exception:
