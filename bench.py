@@ -327,7 +327,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl['name']}; {W}x{H}, random seed-0 weights, fwd + bwd to the 3x4 pose",
-                       "rays_per_step": n_total, "samples_per_ray": [Nc, Ni], "parallelism": f"rows/{world}"},
+                       "rays_per_step": n_total, "samples_per_ray": [Nc, Ni], "parallelism": f"rows/{world}",
+                       "arithmetic": ("fp32 in, fp32 out; matrix products as exact bf16x6 split products with fp32 accumulation "
+                                      "(fp32-level accuracy, tests/test_gpu_x6.py); NEFES_X6=0 selects the fp32-MFMA kernels"
+                                      if any(k.endswith("x6]") for k in kern) else "fp32 MFMA")},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "peak_basis": ("dense bf16 MFMA peak 2500 / 6: bf16x6 split products, fp32-level accuracy" if x6
