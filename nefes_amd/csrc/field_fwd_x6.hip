@@ -1,7 +1,6 @@
 // Fused field forward with the trunk layers 2..8 as bf16x6 split products (sigma-only coarse pass, Wd = 256).
 // Same function as field_fwd_kernel<256,1,SIGMA,FREQ10> (script/models/nerfh_nff.py:192-202,525-555 + rendering.py:114):
-// pts = o + d*z -> frequency embedding -> 8-layer skip MLP -> heads.  The one-tile heads (sigma, rgb+feature, transient)
-// and the 27-feature direction parts stay on v_mfma_f32_32x32x2_f32; every other product runs on v_mfma_f32_32x32x16_bf16:
+// pts = o + d*z -> frequency embedding -> 8-layer skip MLP -> heads.  Every product runs on v_mfma_f32_32x32x16_bf16:
 //     x = xh + xm + xl, w = wh + wm + wl exactly (three bf16 each: 24 = 3 x 8 mantissa bits, truncation split)
 //     w x ~= wh xh + wh xm + wm xh + wh xl + wl xh + wm xm        (dropped terms: relative size 2^-24)
 // accumulated in fp32 by the matrix core: fp32-level accuracy (tools/bf16x6_accuracy.py: 2.5e-7 of the output scale
@@ -121,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
         constexpr bool CAP = MODE == NEFES_FIELD_FULL;
         auto sigma_head = [&](const f32x16 (&X)[NTW]) {
             f32x16 sg[1];
-            mma_run<1, HS, 0, true>(ring, ring_lane, ReluIn<NTW>{X}, bias_at(B_SIG), sg);             // static_sigma (fp32)
+            mma_run_x6<1, W / 16, 0>(ring, ring_lane, ReluSplit<false, NTW, WT>{X, bits}, bias_at(B_SIG), sg);   // static_sigma
             if (valid && h == 0) {
                 const int ch = (MODE == NEFES_FIELD_SIGMA) ? 0 : 3 + a.C;
                 raw_col()[(size_t)ch * a.S] = softplus_ref(sg[0][0]);
@@ -146,10 +145,14 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
         if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head(B);
         if constexpr (MODE == NEFES_FIELD_FULL) {
             // dir_encoding and transient_encoding.0 as ONE stacked 2*NTH-tile product (pack.cpp add_heads_x6): tiles
-            // [0, NTH) = dir, [NTH, 2 NTH) = t0; their 27-feature direction part and the one-tile heads stay fp32
-            float Dv[NEFES_D_STEPS];
-            embed_slots<NEFES_N_FREQ_DIR>(Dv, v, h);
-            const ArrayIn<NEFES_D_STEPS> in_D{Dv};
+            // [0, NTH) = dir, [NTH, 2 NTH) = t0
+            float Dv[16];                                              // 14 embedding slots + 2 padding slots (two 16-k steps)
+            {
+                float d14[NEFES_D_STEPS];
+                embed_slots<NEFES_N_FREQ_DIR>(d14, v, h);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) Dv[s] = s < NEFES_D_STEPS ? d14[s] : 0.f;
+            }
             f32x16 dt[2 * NTH], acc3[NTH], acc2[NTH];
             uint32_t bits2[WH];
             auto clear2 = [&]() {
@@ -161,11 +164,11 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
                 __device__ __forceinline__ f32x16 operator()(int t) const { return t < NTH ? a(t) : b(t - NTH); }
             };
             mma_run_x6<2 * NTH, W / 16, 0>(ring, ring_lane, IdentSplit<NTW, 0>{A}, Bias2{bias_at(B_DIR), bias_at(B_T0)}, dt);
-            mma_run<2 * NTH, NEFES_D_STEPS, 0, false>(ring, ring_lane, in_D, ZeroInit{}, dt);
+            mma_run_x6<2 * NTH, 2, 0, false>(ring, ring_lane, ArraySplit<16>{Dv}, ZeroInit{}, dt);
             {
                 f32x16 ar[NTR];
                 clear2();
-                mma_run<NTR, GS, 0, true>(ring, ring_lane, ReluCapture<2 * NTH, WH>{dt, bits2}, bias_at(B_RGB), ar);
+                mma_run_x6<NTR, W / 32, 0>(ring, ring_lane, ReluSplit<true, 2 * NTH, WH>{dt, bits2}, bias_at(B_RGB), ar);
                 put_masks(bits2, WH);                                 // dir_encoding
                 if (valid) {
                     float* ph = raw_col() + (size_t)(4 * h) * a.S;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
             put_masks(bits2, WH);                                     // transient_encoding.2
             f32x16 th[1];
             clear2();
-            mma_run<1, GS, 0, true>(ring, ring_lane, ReluCapture<NTH, WH>{acc2, bits2}, bias_at(B_TH), th);
+            mma_run_x6<1, W / 32, 0>(ring, ring_lane, ReluSplit<true, NTH, WH>{acc2, bits2}, bias_at(B_TH), th);
             put_masks(bits2, WH);
             if (valid) {
                 float* o = raw_col() + (size_t)(3 + a.C + 1) * a.S;

@@ -167,6 +167,7 @@ void add_trunk(const Net& n, Stream& st, bool x6 = false) {
     }
     // static sigma head: one tile, row 0
     st.segs.push_back(seg(1, W / 2, k_natural(W / 2, 0), rows_natural(1, 1), n.w(L_SIGMA), W));
+    st.segs.back().x6 = x6;
     st.bias.push_back({n.b(L_SIGMA), rows_natural(1, 1)});
 }
 
@@ -185,7 +186,7 @@ void add_static_head(const Net& n, Stream& st, bool x6 = false) {
 
 // x6 forward streams: dir_encoding and transient_encoding.0 read the same input (cat[final, dir-emb]), so they run as ONE
 // product with 2*NTH tiles (rows: dir | t0): one operand split instead of two, and the standard 8-tile shape at Wd = 256.
-// Segment order: FINAL, [DIR;T0] hidden part (x6), [DIR;T0] direction part (fp32), RGB, T1, T2, TH; bias blocks keep the
+// Segment order: FINAL, [DIR;T0] hidden part, [DIR;T0] direction part, RGB, T1, T2, TH (all x6); bias blocks keep the
 // order of the fp32 streams (FINAL, DIR, RGB, T0, T1, T2, TH).
 void add_heads_x6(const Net& n, Stream& st) {
     const int W = n.W, W2 = n.W2;
@@ -194,9 +195,12 @@ void add_heads_x6(const Net& n, Stream& st) {
     st.bias.push_back({n.b(L_FINAL), rows_natural(n.NTW, W)});
     st.segs.push_back(seg(2 * n.NTH, W / 2, k_natural(W / 2, 0), rows_natural(2 * n.NTH, 2 * W2), n.dt_w.data(), W + 27));
     st.segs.back().x6 = true;
-    st.segs.push_back(seg(2 * n.NTH, NEFES_D_STEPS, k_emb(4, NEFES_D_STEPS, W), rows_natural(2 * n.NTH, 2 * W2), n.dt_w.data(), W + 27));
+    // direction part: 14 k-steps padded to 16 (= two 16-k steps; slots 14, 15 are padding)
+    st.segs.push_back(seg(2 * n.NTH, 16, k_emb(4, 16, W), rows_natural(2 * n.NTH, 2 * W2), n.dt_w.data(), W + 27));
+    st.segs.back().x6 = true;
     st.bias.push_back({n.b(L_DIR), rows_natural(n.NTH, W2)});
     st.segs.push_back(seg(n.NTR, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTR, 3 + n.C), n.w(L_RGB), W2));
+    st.segs.back().x6 = true;
     st.bias.push_back({n.b(L_RGB), rows_natural(n.NTR, 3 + n.C)});
     st.bias.push_back({n.b(L_T0), rows_natural(n.NTH, W2)});
     for (int l = L_T1; l <= L_T2; ++l) {
@@ -205,6 +209,7 @@ void add_heads_x6(const Net& n, Stream& st) {
         st.bias.push_back({n.b(l), rows_natural(n.NTH, W2)});
     }
     st.segs.push_back(seg(1, W2 / 2, k_natural(W2 / 2, 0), rows_natural(1, 5), n.th_w.data(), W2));
+    st.segs.back().x6 = true;
     st.bias.push_back({n.th_b.data(), rows_natural(1, 5)});
 }
 

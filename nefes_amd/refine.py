@@ -59,7 +59,7 @@ class PoseRefiner:
     move_all_cam_vec) or None.  `graph=True` replays one captured HIP graph per iteration."""
 
     def __init__(self, render_kwargs, args, hwf, near, far, tinyscale=4, lr_r=0.01, lr_t=0.1, lietorch=False,
-                 upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda"):
+                 upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda", adam_capturable=None):
         self.kw, self.args = dict(render_kwargs), args
         H, W, focal = hwf
         self.H, self.W = int(H), int(W)
@@ -71,7 +71,7 @@ class PoseRefiner:
         self.dev = torch.device(device)
         self.model = LearnPose(1, True, True, init_c2w=torch.eye(4)[None].clone(), lietorch=lietorch).to(self.dev)
         self.opt = torch.optim.Adam([{"params": [self.model.r], "lr": lr_r}, {"params": [self.model.t], "lr": lr_t}],
-                                    capturable=bool(graph))
+                                    capturable=bool(graph) if adam_capturable is None else bool(adam_capturable))
         th, tw = (self.H - 20, self.W - 20) if upsample else (self.h, self.w)
         self.target = torch.zeros(self.C, th, tw, device=self.dev)
         self.hist = torch.zeros(1, 10, device=self.dev)
