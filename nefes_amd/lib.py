@@ -31,6 +31,7 @@ class NefesHashGridDesc(C.Structure):
                 ("base_resolution", C.c_int32), ("per_level_scale", C.c_float), ("bound", C.c_float)]
 
 
+ABI_VERSION = 3        # NEFES_ABI_VERSION of include/nefes_hip.h
 STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6 = 0, 1, 2, 3, 4, 5
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
 XYZ_FREQ10, XYZ_EXTERNAL32 = 0, 1
@@ -91,7 +92,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError here = ABI mismatch; let it propagate
         fn.restype = res
         fn.argtypes = args
-    if lib.nefes_version() != 3:
+    if lib.nefes_version() != ABI_VERSION:
         raise RuntimeError("libnefes_hip.so ABI version mismatch")
     _lib = lib
     return lib
