@@ -201,13 +201,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # NEFES_BENCH_ONE_GPU=1 + NEFES_BENCH_BACKEND=gloo: functional test of the N>1 path on a single-GPU box (every rank on
+    # cuda:0, collectives staged through the host); never a measurement.
+    one_gpu = os.environ.get("NEFES_BENCH_ONE_GPU", "0") == "1"
+    dev_index = 0 if (world == 1 or one_gpu) else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        backend = os.environ.get("NEFES_BENCH_BACKEND", "nccl")          # "nccl" = RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
 
     from nefes_amd import dist as D
     from nefes_amd import ops
