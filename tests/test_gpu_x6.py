@@ -174,3 +174,32 @@ def test_reference_default_shape_x6_forward():
     a, b = m6.view(-1, words, 64)[:n32], m32.view(-1, words, 64)[:n32]
     diff = int(sum(bin(int(v) & 0xffffffff).count("1") for v in (a ^ b).flatten().cpu().tolist() if v))
     assert diff <= 4, diff
+
+
+@pytest.mark.parametrize("N,S,seed", [(1, 1, 0), (7, 33, 1), (129, 192, 2), (3, 256, 3), (1000, 5, 4)])
+def test_x6_ragged_shapes_against_fp32_kernel(N, S, seed):
+    """Single sample, ragged last tile, the maximum sample count per ray: bf16x6 outputs equal the fp32 kernel's to fp32
+    rounding (both are within a few 1e-7 of float64, see above); forward FULL and backward."""
+    from nefes_amd import lib as L
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    net = NeRFH_NFF('fine', W=256, f_dim=16, encode_appearance=True, encode_transient=True).requires_grad_(False).to(DEV)
+    pk = net.packed()
+    g = torch.Generator().manual_seed(100 + seed)
+    o = (torch.randn(N, 3, generator=g) * 0.5).to(DEV)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).to(DEV)
+    z = torch.sort(torch.rand(N, S, generator=g) * 6.0, -1)[0].to(DEV)
+    G = torch.randn(N, 25, S, generator=g).to(DEV)
+    x6, m6 = ops.field_fwd_x6(pk, L.FIELD_FULL, N, S, o, d, z, viewdirs=d, want_masks=True)
+    f32, m32 = ops.field_fwd(pk, L.FIELD_FULL, N, S, rays_o=o, rays_d=d, z=z, viewdirs=d, want_masks=True)
+    sc = f32.abs().amax((0, 2), keepdim=True).clamp_min(0.1 * float(f32.abs().max()))   # per channel, floored for tiny batches
+    assert float(((x6 - f32).abs() / sc).max()) < 4e-6
+    outs = {}
+    for use in (False, True):
+        old, ops.USE_X6 = ops.USE_X6, use
+        try:
+            outs[use] = ops.field_bwd(pk, N, S, f32, G, m32, rays_o=o, rays_d=d, z=z, viewdirs=d)
+        finally:
+            ops.USE_X6 = old
+    for a, b in zip(outs[True], outs[False]):
+        assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) < 2e-5
