@@ -361,3 +361,38 @@ def test_full_size_properties(ops, L):
         part = (e["feat_map"] ** 2).sum() / feat.numel() + (r ** 2).sum() / rgb.numel()
         acc_g += torch.autograd.grad(part, c2w)[0]
     assert rel(acc_g, g_full) < 1e-5
+
+
+def test_full_frame_640x480_properties(ops, L):
+    """The BASELINE frame itself (640x480, 64+128 samples, 8x256, C=16: 59 M fine samples, ~33 GB resident): properties that
+    need no oracle -- determinism bit for bit, the maps of a row shard equal the rows of the full frame bit for bit, the pose
+    gradient is linear in the loss and additive over shards, compositing weights form a sub-probability."""
+    R, M = _dropin()
+    coarse, fine = _modules(256, 16)
+    kw = _kwargs(M, coarse, fine, 128, True)
+    H, W, f = 480, 640, 525.505
+    c2w = O.bench_pose().to(DEV).requires_grad_()
+    rgb, disp, acc, ex = R.render(H, W, f, c2w=c2w, near=0., far=4., **kw)
+    feat = ex["feat_map"]
+    assert rgb.shape == (H * W, 3) and feat.shape == (H * W, 16)
+    assert torch.isfinite(rgb).all() and torch.isfinite(feat).all() and torch.isfinite(disp).all()
+    assert (acc > 0).all() and (acc <= 1 + 1e-5).all()
+    loss = O.bench_loss(rgb, feat)
+    (g1,) = torch.autograd.grad(loss, c2w, retain_graph=True)
+    (g3,) = torch.autograd.grad(3.0 * loss, c2w)
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    assert rel(g3, 3.0 * g1) < 1e-6                                  # linear in the upstream gradient
+    chk = (float(rgb.double().sum()), float(feat.double().sum()))
+    del rgb, disp, acc, ex, loss
+    rgb2, _, _, ex2 = R.render(H, W, f, c2w=c2w, near=0., far=4., **kw)
+    assert (float(rgb2.double().sum()), float(ex2["feat_map"].double().sum())) == chk       # bit-identical rerun
+    from nefes_amd import dist as D
+    acc_g = torch.zeros_like(g1)
+    for rank in range(2):
+        row0, n = D.row_shard(H, rank, 2)
+        r, _, _, e = R.render(H, W, f, c2w=c2w, near=0., far=4., row_range=(row0, n), **kw)
+        assert torch.equal(r, rgb2[row0 * W:(row0 + n) * W]) and torch.equal(e["feat_map"], ex2["feat_map"][row0 * W:(row0 + n) * W])
+        part = (e["feat_map"] ** 2).sum() / (H * W * 16) + (r ** 2).sum() / (H * W * 3)
+        acc_g += torch.autograd.grad(part, c2w)[0]
+        del r, e, part
+    assert rel(acc_g, g1) < 1e-5
