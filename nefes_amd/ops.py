@@ -203,14 +203,16 @@ def x6_supported(pk: PackedField, mode, forward=True):
     return ok and (mode == L.FIELD_SIGMA or (mode == L.FIELD_FULL and pk.has_transient))
 
 
-def field_fwd_x6(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, viewdirs=None, want_masks=False, xyz_enc=None):
+def field_fwd_x6(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, viewdirs=None, want_masks=False, xyz_enc=None,
+                 pts=None):
     """field_fwd with the hidden 256x256 layers as bf16x6 split products (same outputs, same mask words)."""
     dev = pk.blob.device
     raw_t = torch.empty(N, pk.n_raw(mode), S, device=dev)
     masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=dev) if want_masks else None
     with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]},x6]"):
         L.check(L.load().nefes_field_fwd_x6(pk.desc, _chk(pk.blob, "blob", torch.uint8), mode, N, S, _chk(rays_o, "rays_o"),
-                                            _chk(rays_d, "rays_d"), _chk(z, "z"), None, _chk(xyz_enc, "xyz_enc"), _chk(viewdirs, "viewdirs"),
+                                            _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(xyz_enc, "xyz_enc"),
+                                            _chk(viewdirs, "viewdirs"),
                                             _chk(raw_t, "raw_t"), _chk(masks, "masks", torch.int32), _stream()),
                 "nefes_field_fwd_x6")
     return raw_t, masks
@@ -290,7 +292,10 @@ class FieldFromPoints(torch.autograd.Function):
             viewdirs = torch.zeros(N, 3, device=pts.device)
         viewdirs = _f32(viewdirs)
         need = mode == L.FIELD_FULL and any(ctx.needs_input_grad[:2])
-        raw_t, masks = field_fwd(pk, mode, N, S, pts=pts.reshape(-1, 3), viewdirs=viewdirs, want_masks=need)
+        if USE_X6 and x6_supported(pk, mode) and pk.xyz_encoding == L.XYZ_FREQ10:
+            raw_t, masks = field_fwd_x6(pk, mode, N, S, pts=pts.reshape(-1, 3), viewdirs=viewdirs, want_masks=need)
+        else:
+            raw_t, masks = field_fwd(pk, mode, N, S, pts=pts.reshape(-1, 3), viewdirs=viewdirs, want_masks=need)
         ctx.pk, ctx.mode, ctx.have = pk, mode, need
         if need:
             ctx.save_for_backward(pts, viewdirs, raw_t, masks)
