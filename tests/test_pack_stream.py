@@ -321,3 +321,113 @@ def test_x6_stream_decodes_to_the_weights(Wd, Cf):
                 s = 8 * q + i
                 got[32 * t + m, 32 * (s >> 4) + rho(g, s & 15)] = val[lane, i]
     assert np.array_equal(got, Wm)                                                           # exact, not approximately
+
+
+class StreamX6:
+    """Consumption of a bf16x6 forward stream (field_x6.h mma_run_x6): units of three 1 KiB groups (hi | mid | lo), 16 units
+    per 48 KiB slab, a segment starts on a slab boundary; lane (m, g) of unit (k16-step q, tile t) multiplies slot (8q+i, g)."""
+
+    def __init__(self, blob, si, slab_kib=48):
+        self.half = slab_kib * 512
+        self.ups = (slab_kib // 3)
+        self.raw = np.frombuffer(blob, np.uint16, count=si.n_slabs * self.half, offset=si.slab_off).reshape(si.n_slabs, self.half)
+        self.bias = np.frombuffer(blob, np.float32, count=si.bias_floats, offset=si.bias_off)
+        self.pos = self.bpos = 0
+
+    def bias_tiles(self, nt, n):
+        b = self.bias[self.bpos:self.bpos + nt * 32].reshape(nt, 32)
+        self.bpos += nt * 32
+        return np.repeat(b[:, :, None], n, 2).astype(np.float64).copy()
+
+    def mma(self, nt, vec, acc):
+        k16 = vec.shape[0] // 8
+        n_units = k16 * nt
+        for u in range(n_units):
+            sl, uu = self.pos + u // self.ups, u % self.ups
+            q, t = u // nt, u % nt
+            unit = self.raw[sl, uu * 1536:(uu + 1) * 1536].reshape(3, 64, 8).astype(np.uint32)
+            w = sum((unit[pp] << 16).view(np.float32).astype(np.float64) for pp in range(3))      # [lane][i], exact weights
+            for g in range(2):
+                acc[t] += w[32 * g:32 * g + 32] @ vec[8 * q:8 * q + 8, g].astype(np.float64)       # [32 rows, 8] @ [8, n]
+        self.pos += (n_units + self.ups - 1) // self.ups
+
+
+@pytest.mark.parametrize("Wd,Cf", [(256, 16), (128, 128)])
+def test_x6_sigma_stream_reproduces_the_mlp(Wd, Cf):
+    """The whole sigma-only bf16x6 stream consumed in kernel order (field_fwd_x6_kernel<SIGMA>): layer 1 on the embedding,
+    layers 2..8 (skip part at layer 5), static_sigma -- against the oracle's forward."""
+    n = 8
+    g = torch.Generator().manual_seed(6)
+    pts = (torch.rand(n, 3, generator=g) - .5) * 5
+    e63 = O.freq_encode(pts, 10)
+    pc, info, blob = pack(Wd, Cf, "coarse")
+    st = StreamX6(blob, info.stream[L.STREAM_FWD_SIGMA_X6])
+    NTW = Wd // 32
+    E = emb_vector(e63.numpy(), 10, 32)
+    b1 = st.bias_tiles(NTW, n)
+    biases = [st.bias_tiles(NTW, n) for _ in range(7)]
+    b_sig = st.bias_tiles(1, n)
+    acc = b1
+    st.mma(NTW, E, acc)
+    H = acc_to_vec(np.maximum(acc, 0))
+    for l in range(2, 9):
+        acc = biases[l - 2]
+        st.mma(NTW, H, acc)
+        if l == 5:
+            st.mma(NTW, E, acc)
+        H = acc_to_vec(np.maximum(acc, 0))
+    sg = b_sig
+    st.mma(1, H, sg)
+    assert st.pos == st.raw.shape[0]
+    ref = O.field_forward(pc, e63, sigma_only=True)[:, 0].numpy()
+    np.testing.assert_allclose(softplus(sg[0, 0]), ref, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("Wd,Cf", [(256, 16), (128, 128)])
+def test_x6_full_stream_reproduces_the_mlp(Wd, Cf):
+    """The FULL bf16x6 forward stream in kernel order (field_fwd_x6_kernel<FULL>): trunk, static_sigma, xyz_encoding_final,
+    the stacked [dir_encoding ; transient_encoding.0] product with its direction part, static_rgb, transient_encoding.2/.4,
+    transient heads -- against the oracle's forward (all 3+C+6 raw channels)."""
+    n = 8
+    g = torch.Generator().manual_seed(7)
+    pts = (torch.rand(n, 3, generator=g) - .5) * 5
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    e63, e27 = O.freq_encode(pts, 10), O.freq_encode(dirs, 4)
+    pf, info, blob = pack(Wd, Cf, "fine")
+    st = StreamX6(blob, info.stream[L.STREAM_FWD_FULL_X6])
+    NTW, NTH, NTR = Wd // 32, Wd // 64, (3 + Cf + 31) // 32
+    E, D = emb_vector(e63.numpy(), 10, 32), emb_vector(e27.numpy(), 4, 16)       # direction part padded to 16 slots
+    b = {"L1": st.bias_tiles(NTW, n)}
+    for l in range(2, 9):
+        b[f"L{l}"] = st.bias_tiles(NTW, n)
+    for name, nt in (("SIG", 1), ("FINAL", NTW), ("DIR", NTH), ("RGB", NTR), ("T0", NTH), ("T1", NTH), ("T2", NTH), ("TH", 1)):
+        b[name] = st.bias_tiles(nt, n)
+    acc = b["L1"]
+    st.mma(NTW, E, acc)
+    H = acc_to_vec(np.maximum(acc, 0))
+    for l in range(2, 9):
+        acc = b[f"L{l}"]
+        st.mma(NTW, H, acc)
+        if l == 5:
+            st.mma(NTW, E, acc)
+        H = acc_to_vec(np.maximum(acc, 0))
+    sg = b["SIG"]
+    st.mma(1, H, sg)
+    fin = b["FINAL"]
+    st.mma(NTW, H, fin)
+    dt = np.concatenate([b["DIR"], b["T0"]], 0)                                      # stacked tiles: dir | t0
+    st.mma(2 * NTH, acc_to_vec(fin), dt)
+    st.mma(2 * NTH, D, dt)
+    ar = b["RGB"]
+    st.mma(NTR, acc_to_vec(np.maximum(dt[:NTH], 0)), ar)
+    t1 = b["T1"]
+    st.mma(NTH, acc_to_vec(np.maximum(dt[NTH:], 0)), t1)
+    t2 = b["T2"]
+    st.mma(NTH, acc_to_vec(np.maximum(t1, 0)), t2)
+    th = b["TH"]
+    st.mma(1, acc_to_vec(np.maximum(t2, 0)), th)
+    assert st.pos == st.raw.shape[0] and st.bpos == st.bias.shape[0]
+    ref = O.field_forward(pf, torch.cat([e63, e27], 1), output_transient=True).numpy()
+    sig = lambda x: 1 / (1 + np.exp(-x))
+    got = np.concatenate([ar.reshape(NTR * 32, n)[:3 + Cf].T, softplus(sg[0, :1]).T, sig(th[0, :3]).T, softplus(th[0, 3:5]).T], 1)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
