@@ -32,7 +32,7 @@ class NefesHashGridDesc(C.Structure):
 
 
 ABI_VERSION = 3        # NEFES_ABI_VERSION of include/nefes_hip.h
-STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6 = 0, 1, 2, 3, 4, 5
+STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6, STREAM_BWD_FULL_X6 = 0, 1, 2, 3, 4, 5, 6
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
 XYZ_FREQ10, XYZ_EXTERNAL32 = 0, 1
 (TB_E, TB_DV, TB_L1, TB_FINAL, TB_DIR, TB_T0, TB_T1, TB_T2, TB_RGB, TB_SIG, TB_TH, TB_END) = (0, 1, 2, 10, 11, 12, 13, 14, 15, 16,

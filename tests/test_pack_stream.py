@@ -82,6 +82,11 @@ def acc_to_vec(acc, t0=0, nt=None):
     return v
 
 
+def _slab_kib(which):
+    txt = open(os.path.join(os.path.dirname(__file__), '..', 'nefes_amd', 'csrc', 'layout.h')).read()
+    return int(re.search(r'#define NEFES_%s_SLAB_KIB (\d+)' % which, txt).group(1))
+
+
 def _slab_frags(which):
     """256-byte fragments per slab of the forward ('FWD') or backward ('BWD') streams (nefes_amd/csrc/layout.h)."""
     txt = open(os.path.join(os.path.dirname(__file__), '..', 'nefes_amd', 'csrc', 'layout.h')).read()
@@ -210,11 +215,42 @@ def compact(vals, steps):
     return v
 
 
-def emulate_backward(info, blob, Wd, Cf, masks, d_pre):
-    """Mirrors field_bwd_kernel (csrc/field_bwd.hip).  d_pre: pre-activation head gradients."""
+class MixedStream:
+    """Backward bf16x6 stream: fp32 segments (fragments of 256 B) and x6 segments (3 KiB units) in one slab sequence."""
+
+    def __init__(self, blob, si, slab_kib):
+        self.f32 = Stream(blob, si, "BWD")
+        self.x6 = StreamX6(blob, si, slab_kib)
+
+    def mma(self, nt, vec, acc):                    # fp32 segment
+        self.f32.pos = self.x6.pos
+        self.f32.mma(nt, vec, acc)
+        self.x6.pos = self.f32.pos
+
+    def mma16(self, nt, vec, acc):                  # bf16x6 segment
+        a64 = acc.astype(np.float64)
+        self.x6.mma(nt, vec, a64)
+        acc[...] = a64
+
+    @property
+    def pos(self):
+        return self.x6.pos
+
+    @property
+    def slabs(self):
+        return self.f32.slabs
+
+
+def emulate_backward(info, blob, Wd, Cf, masks, d_pre, x6=False):
+    """Mirrors field_bwd_kernel (csrc/field_bwd.hip).  d_pre: pre-activation head gradients.  x6: the X6 instance's stream."""
     n = d_pre["sigma"].shape[0]
     NTW, NTH = Wd // 32, Wd // 64
-    st = Stream(blob, info.stream[L.STREAM_BWD_FULL], "BWD")
+    if x6:
+        st = MixedStream(blob, info.stream[L.STREAM_BWD_FULL_X6], _slab_kib("BWD"))
+        big = st.mma16
+    else:
+        st = Stream(blob, info.stream[L.STREAM_BWD_FULL], "BWD")
+        big = st.mma
     Z = lambda nt: np.zeros((nt, 32, n), np.float32)
     C3 = 3 + Cf
     a2 = Z(NTH)
@@ -225,29 +261,29 @@ def emulate_backward(info, blob, Wd, Cf, masks, d_pre):
     Tv = acc_to_vec(a2 * masks["T2"])
     for tl in (2, 1):
         a2 = Z(NTH)
-        st.mma(NTH, Tv, a2)
+        big(NTH, Tv, a2)
         Tv = acc_to_vec(a2 * masks[f"T{tl - 1}"])
     a9 = Z(NTW + 1)
-    st.mma(NTW + 1, Tv, a9)
-    st.mma(NTW + 1, Gv, a9)
+    big(NTW + 1, Tv, a9)
+    big(NTW + 1, Gv, a9)
     dD = acc_to_vec(a9, 0, 1)             # tile 0 = d dir-embedding, tiles 1.. = d final
     H = acc_to_vec(a9, 1, NTW)
     acc = Z(NTW)
-    st.mma(NTW, H, acc)
+    big(NTW, H, acc)
     st.mma(NTW, compact([d_pre["sigma"]], 1), acc)
     H = acc_to_vec(acc * masks["L8"])
     accE = Z(2)
     for l in range(8, 1, -1):
         if l == 5:
             a10 = Z(NTW + 2)
-            st.mma(NTW + 2, H, a10)
+            big(NTW + 2, H, a10)
             accE = a10[:2].copy()
             H = acc_to_vec(a10[2:] * masks["L4"])
         else:
             acc = Z(NTW)
-            st.mma(NTW, H, acc)
+            big(NTW, H, acc)
             H = acc_to_vec(acc * masks[f"L{l - 1}"])
-    st.mma(2, H, accE)
+    big(2, H, accE)
     assert st.pos == st.slabs.shape[0]
     return emb_vector_T(acc_to_vec(accE), 10, 63), emb_vector_T(dD[:14], 4, 27)
 
@@ -289,10 +325,11 @@ def test_packed_streams_reproduce_the_mlp(Wd, Cf):
     d_pre = {"rgbfeat": gr[:, :C3], "sigma": gr[:, C3] * (1 - np.exp(-r[:, C3])),
              "t_rgb": gr[:, C3 + 1:C3 + 4] * r[:, C3 + 1:C3 + 4] * (1 - r[:, C3 + 1:C3 + 4]),
              "t_sigma": gr[:, C3 + 4] * (1 - np.exp(-r[:, C3 + 4])), "t_beta": gr[:, C3 + 5] * (1 - np.exp(-r[:, C3 + 5]))}
-    g63, g27 = emulate_backward(info_f, blob_f, Wd, Cf, masks, d_pre)
     scale = np.abs(g_emb.numpy()).max()
-    np.testing.assert_allclose(g63, g_emb.numpy()[:, :63], rtol=1e-4, atol=2e-5 * scale)
-    np.testing.assert_allclose(g27, g_emb.numpy()[:, 63:], rtol=1e-4, atol=2e-5 * scale)
+    for x6 in ((False, True) if (Wd, Cf) == (256, 16) else (False,)):       # the bf16x6 backward exists for Wd=256, C=16
+        g63, g27 = emulate_backward(info_f, blob_f, Wd, Cf, masks, d_pre, x6=x6)
+        np.testing.assert_allclose(g63, g_emb.numpy()[:, :63], rtol=1e-4, atol=2e-5 * scale)
+        np.testing.assert_allclose(g27, g_emb.numpy()[:, 63:], rtol=1e-4, atol=2e-5 * scale)
 
 
 @pytest.mark.parametrize("Wd,Cf", [(256, 16), (128, 128)])
