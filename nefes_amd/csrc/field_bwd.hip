@@ -5,6 +5,9 @@
 // gradient vector held in registers, ReLU derivative from the 1-bit masks the forward pass stored.
 // Head activation derivatives are recovered from the raw outputs (softplus' = 1 - exp(-y), sigmoid' = y(1-y)).
 #define NEFES_SLAB_KIB NEFES_BWD_SLAB_KIB
+// look-ahead batches of 2 k-steps for the narrow segments: with 4 the Wd = 128 bf16x6 instance spills (316 B scratch)
+#define NEFES_B_BATCH 2
+#define NEFES_B_BATCH_NT8 4
 #include "field_common.h"
 #include "field_x6.h"
 #include "../../include/nefes_hip.h"
@@ -278,6 +281,7 @@ static int field_bwd_impl(bool x6, const NefesNetDesc* desc, const void* packed,
     if (x6) {
         if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, true>(a, st);
         if (desc->width == 256 && desc->feat_dim == 16 && ext) return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32, true>(a, st);
+        if (desc->width == 128 && desc->feat_dim == 128 && !ext) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, true>(a, st);
         return NEFES_E_UNSUPPORTED;
     }
     if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10>(a, st);

@@ -317,7 +317,7 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
         if (n.transient && (small || n.C == 16)) {
             add_trunk(n, st[NEFES_STREAM_FWD_FULL_X6], true);
             add_heads_x6(n, st[NEFES_STREAM_FWD_FULL_X6]);
-            if (big) add_backward(n, st[NEFES_STREAM_BWD_FULL_X6], true);   // (the Wd = 128 backward is at its register limit)
+            add_backward(n, st[NEFES_STREAM_BWD_FULL_X6], true);
         }
     }
     return true;

@@ -197,9 +197,9 @@ USE_X6 = os.environ.get("NEFES_X6", "1") != "0"
 
 
 def x6_supported(pk: PackedField, mode, forward=True):
-    """bf16x6 instances: width 256 / C = 16 (forward and backward, either xyz encoding) and the reference-default
-    width 128 / C = 128 (forward only); sigma-only or full mode."""
-    ok = (pk.width == 256 and pk.feat_dim == 16) or (forward and pk.width == 128 and pk.feat_dim == 128 and pk.xyz_encoding == L.XYZ_FREQ10)
+    """bf16x6 instances: width 256 / C = 16 (either xyz encoding) and the reference-default width 128 / C = 128
+    (frequency embedding); sigma-only or full mode, forward and backward."""
+    ok = (pk.width == 256 and pk.feat_dim == 16) or (pk.width == 128 and pk.feat_dim == 128 and pk.xyz_encoding == L.XYZ_FREQ10)
     return ok and (mode == L.FIELD_SIGMA or (mode == L.FIELD_FULL and pk.has_transient))
 
 
