@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEFES_ABI_VERSION 3
+#define NEFES_ABI_VERSION 4
 
 #define NEFES_E_BADARG (-1)     /* null pointer / non-positive size */
 #define NEFES_E_UNSUPPORTED (-2) /* width / feat_dim / sample count outside the compiled set */
@@ -54,7 +54,7 @@ typedef struct NefesStreamInfo {
 
 typedef struct NefesBlobInfo {
     uint64_t total_bytes;
-    NefesStreamInfo stream[7]; /* indexed by NEFES_STREAM_* in csrc/layout.h; n_slabs == 0 if absent */
+    NefesStreamInfo stream[8]; /* indexed by NEFES_STREAM_* in csrc/layout.h; n_slabs == 0 if absent */
 } NefesBlobInfo;
 
 /* compositing variants of raw2outputs_NeRFH_NFF (script/models/nerfh_nff.py:25-166) */
@@ -169,6 +169,12 @@ int nefes_hashgrid_bwd_x(const NefesHashGridDesc* desc, const float* table, int6
 int nefes_field_fwd_x6(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                        const float* rays_d, const float* z, const float* pts, const float* xyz_enc, const float* viewdirs,
                        float* raw_t, uint32_t* masks, void* stream);
+
+/* nefes_field_bwd for a NEFES_FIELD_STATIC forward (raw channels rgb+feature, sigma; masks from nefes_field_fwd in that mode):
+ * what autograd does for the coarse network in train mode (rendering.py:116-125 with test_time=False). */
+int nefes_field_bwd_static(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+                           const float* rays_d, const float* z, const float* pts, const float* viewdirs, const float* raw_t,
+                           const float* g_raw_t, const uint32_t* masks, float* g_pts, float* g_viewdirs_s, void* stream);
 
 /* nefes_field_bwd (width 256, C = 16) with the transposed products as bf16x6 split
  * products; consumes the mask words of either forward kernel. */

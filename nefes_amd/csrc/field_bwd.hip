@@ -34,7 +34,9 @@ struct FieldBwdArgs {
 
 // X6: the eight 256x256 transposed products (xyz_encoding_final^T, layers 8..2) as bf16x6 split products (field_x6.h);
 // the stream then is NEFES_STREAM_BWD_FULL_X6.  Same mask words, same outputs.
-template <int W, int C3, int ENC, bool X6 = false>   // C3 = 3 + C; ENC = NEFES_XYZ_*
+// HAS_T = false: the static head only (NEFES_FIELD_STATIC forward: raw channels rgb+feature, sigma); the stream then is
+// NEFES_STREAM_BWD_STATIC and the transient segments are skipped.
+template <int W, int C3, int ENC, bool X6 = false, bool HAS_T = true>   // C3 = 3 + C; ENC = NEFES_XYZ_*
 __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
@@ -81,13 +83,15 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[ray * 3 + c];
         // forward outputs needed for the head activation derivatives, and the upstream gradient (this lane half's slots)
         const int cT = C3 + 1;                       // transient rgb channels start
-        float y_th[3], g_th[3], y_sg, g_sg, dr[KR];
+        float y_th[3] = {0.f, 0.f, 0.f}, g_th[3] = {0.f, 0.f, 0.f}, y_sg, g_sg, dr[KR];
+        if constexpr (HAS_T) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {                // compact slot (s,h) <-> transient-head row 2s+h (5 rows)
-            const int row = 2 * s + h;
-            const int ch = cT + (row < 5 ? row : 4);
-            y_th[s] = a.raw_t[chan0 + (size_t)ch * a.S];
-            g_th[s] = a.g_raw_t[chan0 + (size_t)ch * a.S];
+            for (int s = 0; s < 3; ++s) {            // compact slot (s,h) <-> transient-head row 2s+h (5 rows)
+                const int row = 2 * s + h;
+                const int ch = cT + (row < 5 ? row : 4);
+                y_th[s] = a.raw_t[chan0 + (size_t)ch * a.S];
+                g_th[s] = a.g_raw_t[chan0 + (size_t)ch * a.S];
+            }
         }
         y_sg = a.raw_t[chan0 + (size_t)C3 * a.S];
         g_sg = a.g_raw_t[chan0 + (size_t)C3 * a.S];
@@ -151,6 +155,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         f32x16 G2[NTH], T3[NTH], T4[NTH];
         // ---- static_rgb^T: 3+C gradients in compact slots -> d(dir_encoding output) ----
         mma_run<NTH, KR, 0, true>(ring, ring_lane, ArrayIn<KR>{dr}, ZeroInit{}, G2);
+        if constexpr (HAS_T) {
         // ---- transient heads^T: 5 pre-activation gradients -> d(transient_encoding.4 output) ----
         mma_run<NTH, 3, 0, true>(ring, ring_lane, ArrayIn<3>{dth}, ZeroInit{}, T3);
         // ---- transient_encoding.4^T, .2^T ----
@@ -160,16 +165,19 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         load_bits(bh, MW_TRUNK + 2 * WH, WH);
         if constexpr (X6) mma_run_x6<NTH, GS / 8, 0>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{T4, bh}, ZeroInit{}, T3);
         else mma_run<NTH, GS, 0, true>(ring, ring_lane, MaskedIn<NTH, WH>{T4, bh}, ZeroInit{}, T3);
+        }
         // Full-width accumulators, ping-pong.  Tiles [2, NTW+2) hold a layer's d hidden; XA tile 1 = d dir-embedding;
         // XB tiles 0,1 = d xyz-embedding (written by layer 5, accumulated by layer 1).
         f32x16 XA[NTW + 2], XB[NTW + 2];
         // ---- [transient_encoding.0 ; dir_encoding]^T -> d dir-embedding (tile 1) + d final (tiles 2..) ----
-        load_bits(bh, MW_TRUNK + WH, WH);
-        if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{T3, bh}, ZeroInit{}, XA);
-        else mma_run<NTW + 1, GS, 1, true>(ring, ring_lane, MaskedIn<NTH, WH>{T3, bh}, ZeroInit{}, XA);
+        if constexpr (HAS_T) {
+            load_bits(bh, MW_TRUNK + WH, WH);
+            if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{T3, bh}, ZeroInit{}, XA);
+            else mma_run<NTW + 1, GS, 1, true>(ring, ring_lane, MaskedIn<NTH, WH>{T3, bh}, ZeroInit{}, XA);
+        }
         load_bits(bh, MW_TRUNK, WH);
-        if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1, false>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{G2, bh}, ZeroInit{}, XA);
-        else mma_run<NTW + 1, GS, 1, false>(ring, ring_lane, MaskedIn<NTH, WH>{G2, bh}, ZeroInit{}, XA);
+        if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{G2, bh}, ZeroInit{}, XA);
+        else mma_run<NTW + 1, GS, 1, !HAS_T>(ring, ring_lane, MaskedIn<NTH, WH>{G2, bh}, ZeroInit{}, XA);
         // ---- xyz_encoding_final^T (no ReLU on its output) + static_sigma^T (one extra k-step) -> d h8 ----
         {
             float dsg[1];
@@ -240,10 +248,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     ring.drain();
 }
 
-template <int W, int C3, int ENC, bool X6 = false>
+template <int W, int C3, int ENC, bool X6 = false, bool HAS_T = true>
 static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_BWD_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (8 * (W / 64) + 4 * (W / 128) + 8) * 256;
-    auto k = field_bwd_kernel<W, C3, ENC, X6>;
+    auto k = field_bwd_kernel<W, C3, ENC, X6, HAS_T>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -255,7 +263,7 @@ static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-static int field_bwd_impl(bool x6, const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+static int field_bwd_impl(bool x6, bool full, const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
                           const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                           const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                           float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
@@ -263,21 +271,26 @@ static int field_bwd_impl(bool x6, const NefesNetDesc* desc, const void* packed,
         return NEFES_E_BADARG;
     const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
     if (ext ? !g_xyz_enc : (!g_pts || (!pts && !(rays_o && rays_d && z)))) return NEFES_E_BADARG;
-    if (!desc->has_transient) return NEFES_E_UNSUPPORTED;
+    if (full && !desc->has_transient) return NEFES_E_UNSUPPORTED;
     NefesBlobInfo info;
     int rc = nefes_blob_info(desc, &info);
     if (rc) return rc;
-    const NefesStreamInfo& si = info.stream[x6 ? NEFES_STREAM_BWD_FULL_X6 : NEFES_STREAM_BWD_FULL];
+    const NefesStreamInfo& si = info.stream[!full ? NEFES_STREAM_BWD_STATIC : (x6 ? NEFES_STREAM_BWD_FULL_X6 : NEFES_STREAM_BWD_FULL)];
     if (si.n_slabs == 0) return NEFES_E_UNSUPPORTED;
     FieldBwdArgs a;
     a.stream = (const char*)packed + si.slab_off;
     a.n_slabs = si.n_slabs;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.viewdirs = viewdirs;
     a.raw_t = raw_t; a.g_raw_t = g_raw_t; a.masks = masks; a.g_pts = g_pts; a.g_enc = g_xyz_enc; a.g_vs = g_viewdirs_s;
-    a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + 6;
+    a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + (full ? 6 : 1);
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
+    if (!full) {   // static head only (fp32-MFMA instances)
+        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, false, false>(a, st);
+        if (desc->width == 128 && desc->feat_dim == 128 && !ext) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, false, false>(a, st);
+        return NEFES_E_UNSUPPORTED;
+    }
     if (x6) {
         if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, true>(a, st);
         if (desc->width == 256 && desc->feat_dim == 16 && ext) return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32, true>(a, st);
@@ -294,7 +307,7 @@ extern "C" int nefes_field_bwd(const NefesNetDesc* desc, const void* packed, int
                                const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                                float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
-    return field_bwd_impl(false, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
+    return field_bwd_impl(false, true, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
                           g_viewdirs_s, stream);
 }
 
@@ -302,6 +315,14 @@ extern "C" int nefes_field_bwd_x6(const NefesNetDesc* desc, const void* packed, 
                                   const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                   const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                                   float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
-    return field_bwd_impl(true, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
+    return field_bwd_impl(true, true, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
+                          g_viewdirs_s, stream);
+}
+
+extern "C" int nefes_field_bwd_static(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+                                      const float* rays_d, const float* z, const float* pts, const float* viewdirs,
+                                      const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
+                                      float* g_viewdirs_s, void* stream) {
+    return field_bwd_impl(false, false, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr,
                           g_viewdirs_s, stream);
 }

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
         // Mask words: wave-uniform tile base (SGPRs) + a uniform running word counter; the only per-lane part is `lane`.
         // Words are emitted in layout order (layers 1..8, dir, transient 0,2,4).  Lane-private words of whole 32-sample
         // tiles (the buffer is padded to whole tiles) => stored unconditionally, no per-lane predicate.
-        uint32_t* mask_tile = (MODE == NEFES_FIELD_FULL && a.masks)
+        uint32_t* mask_tile = (MODE != NEFES_FIELD_SIGMA && a.masks)
                                   ? a.masks + ((size_t)((long long)tile * 4 + wave) * MW) * 64
                                   : nullptr;
         int mask_word = 0;
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
         for (int p = 0; p < 4; ++p) {
             const int l1 = 2 + 2 * p, l2 = l1 + 1;
             clear_bits();
-            // masks are recorded only when a backward pass can follow (FULL); the other modes save 2 VALU ops per k-step
-            if constexpr (MODE == NEFES_FIELD_FULL)
+            // masks are recorded only when a backward pass can follow (STATIC, FULL); the sigma-only pass saves the VALU op
+            if constexpr (MODE != NEFES_FIELD_SIGMA)
                 mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluCapture<NTW, WT>{A, bits}, bias_at((l1 - 1) * W), B);
             else
                 mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluIn<NTW>{A}, bias_at((l1 - 1) * W), B);
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
                 sigma_head(B);
             }
             clear_bits();
-            if constexpr (MODE == NEFES_FIELD_FULL)
+            if constexpr (MODE != NEFES_FIELD_SIGMA)
                 mma_run<NTW, HS, 0, true>(ring, ring_lane, ReluCapture<NTW, WT>{B, bits},
                                           bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);
             else

@@ -77,10 +77,11 @@ NEFES_HD int nefes_segment_slabs(int nt, int ks, int slab_frags) {
 // _X6 streams: trunk layers 2..8 as bf16x6 split products (v_mfma_f32_32x32x16_bf16 on exact hi/mid/lo bf16 triples, six
 // cross terms: fp32-level accuracy), everything else as in the fp32 stream; 48 KiB slabs = 16 units of 3 KiB.
 enum { NEFES_STREAM_FWD_SIGMA = 0, NEFES_STREAM_FWD_STATIC = 1, NEFES_STREAM_FWD_FULL = 2, NEFES_STREAM_BWD_FULL = 3,
-       NEFES_STREAM_FWD_SIGMA_X6 = 4, NEFES_STREAM_FWD_FULL_X6 = 5, NEFES_STREAM_BWD_FULL_X6 = 6, NEFES_N_STREAMS = 7 };
+       NEFES_STREAM_FWD_SIGMA_X6 = 4, NEFES_STREAM_FWD_FULL_X6 = 5, NEFES_STREAM_BWD_FULL_X6 = 6, NEFES_STREAM_BWD_STATIC = 7,
+       NEFES_N_STREAMS = 8 };
 #define NEFES_X6_SLAB_KIB 48
 NEFES_HD int nefes_stream_slab_kib(int stream) {
-    if (stream == NEFES_STREAM_BWD_FULL || stream == NEFES_STREAM_BWD_FULL_X6) return NEFES_BWD_SLAB_KIB;
+    if (stream == NEFES_STREAM_BWD_FULL || stream == NEFES_STREAM_BWD_FULL_X6 || stream == NEFES_STREAM_BWD_STATIC) return NEFES_BWD_SLAB_KIB;
     return stream >= NEFES_STREAM_FWD_SIGMA_X6 ? NEFES_X6_SLAB_KIB : NEFES_FWD_SLAB_KIB;
 }
 

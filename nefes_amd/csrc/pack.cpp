@@ -229,22 +229,26 @@ void add_transient_head(const Net& n, Stream& st, bool x6 = false) {
 }
 
 // backward-to-inputs stream: A operand = W^T, B operand = upstream gradient vector
-void add_backward(const Net& n, Stream& st, bool x6 = false) {
+void add_backward(const Net& n, Stream& st, bool x6 = false, bool transient = true) {
     const int W = n.W, W2 = n.W2, NTW = n.NTW, NTH = n.NTH;
     // static rgb/feature head^T first (its 3+C upstream values are consumed straight after the tile's loads):
     // in = 3+C grads (compact slots), out = d g
     const int kr = (3 + n.C + 1) / 2;
     st.segs.push_back(seg(NTH, kr, k_compact(kr, 3 + n.C), rows_natural(NTH, W2), n.w(L_RGB), W2, true));
+    if (transient) {
     // transient heads^T: in = 5 pre-activation grads (compact slots), out = d t2
     st.segs.push_back(seg(NTH, 3, k_compact(3, 5), rows_natural(NTH, W2), n.th_w.data(), W2, true));
     st.segs.push_back(seg(NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(NTH, W2), n.w(L_T2), W2, true));
     st.segs.back().x6 = x6;
     st.segs.push_back(seg(NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(NTH, W2), n.w(L_T1), W2, true));
     st.segs.back().x6 = x6;
+    }
     // [transient_encoding.0 ; dir_encoding]^T: out rows = dir-embedding slots (1 tile) then final features (NTW tiles)
     std::vector<int> rows_fd = concat(rows_emb(4, 1, W), rows_natural(NTW, W));
-    st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_T0), W + 27, true));
-    st.segs.back().x6 = x6;
+    if (transient) {
+        st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_T0), W + 27, true));
+        st.segs.back().x6 = x6;
+    }
     st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_DIR), W + 27, true));
     st.segs.back().x6 = x6;
     // xyz_encoding_final^T, plus the static-sigma head as one extra k-step
@@ -305,6 +309,7 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
     add_trunk(n, st[NEFES_STREAM_FWD_SIGMA]);
     add_trunk(n, st[NEFES_STREAM_FWD_STATIC]);
     add_static_head(n, st[NEFES_STREAM_FWD_STATIC]);
+    add_backward(n, st[NEFES_STREAM_BWD_STATIC], false, false);
     if (n.transient) {
         add_trunk(n, st[NEFES_STREAM_FWD_FULL]);
         add_static_head(n, st[NEFES_STREAM_FWD_FULL]);

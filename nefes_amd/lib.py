@@ -23,7 +23,7 @@ class NefesStreamInfo(C.Structure):
 
 
 class NefesBlobInfo(C.Structure):
-    _fields_ = [("total_bytes", C.c_uint64), ("stream", NefesStreamInfo * 7)]
+    _fields_ = [("total_bytes", C.c_uint64), ("stream", NefesStreamInfo * 8)]
 
 
 class NefesHashGridDesc(C.Structure):
@@ -31,8 +31,8 @@ class NefesHashGridDesc(C.Structure):
                 ("base_resolution", C.c_int32), ("per_level_scale", C.c_float), ("bound", C.c_float)]
 
 
-ABI_VERSION = 3        # NEFES_ABI_VERSION of include/nefes_hip.h
-STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6, STREAM_BWD_FULL_X6 = 0, 1, 2, 3, 4, 5, 6
+ABI_VERSION = 4        # NEFES_ABI_VERSION of include/nefes_hip.h
+STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6, STREAM_BWD_FULL_X6, STREAM_BWD_STATIC = 0, 1, 2, 3, 4, 5, 6, 7
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
 XYZ_FREQ10, XYZ_EXTERNAL32 = 0, 1
 (TB_E, TB_DV, TB_L1, TB_FINAL, TB_DIR, TB_T0, TB_T1, TB_T2, TB_RGB, TB_SIG, TB_TH, TB_END) = (0, 1, 2, 10, 11, 12, 13, 14, 15, 16,
@@ -62,6 +62,7 @@ SIGNATURES = {
     "nefes_hashgrid_table_entries": (_sz, [C.POINTER(NefesHashGridDesc)]),
     "nefes_hashgrid_fwd": (_i, [C.POINTER(NefesHashGridDesc), _p, C.c_int64, _p, _p, _p]),
     "nefes_hashgrid_bwd_x": (_i, [C.POINTER(NefesHashGridDesc), _p, C.c_int64, _p, _p, _p, _p]),
+    "nefes_field_bwd_static": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_bwd_x6": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_fwd_x6": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_train_rows": (_sz, [_desc]),

@@ -218,9 +218,18 @@ def field_fwd_x6(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, 
     return raw_t, masks
 
 
-def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=None, z=None, pts=None, viewdirs=None):
+def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=None, z=None, pts=None, viewdirs=None,
+              mode=L.FIELD_FULL):
     dev = pk.blob.device
     ext = pk.xyz_encoding == L.XYZ_EXTERNAL32
+    if mode == L.FIELD_STATIC:                      # static head only (coarse network in train mode)
+        g_pts, g_vs = torch.empty(N * S, 3, device=dev), torch.empty(N * S, 3, device=dev)
+        with _timed("field_bwd[static]"):
+            L.check(L.load().nefes_field_bwd_static(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
+                                                    _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),
+                                                    _chk(raw_t, "raw_t"), _chk(g_raw_t, "g_raw_t"), _chk(masks, "masks", torch.int32),
+                                                    _chk(g_pts, "g_pts"), _chk(g_vs, "g_vs"), _stream()), "nefes_field_bwd_static")
+        return g_pts, g_vs
     g_pts = None if ext else torch.empty(N * S, 3, device=dev)
     g_enc = torch.empty(N * S, 32, device=dev) if ext else None
     g_vs = torch.empty(N * S, 3, device=dev)
@@ -258,7 +267,7 @@ class FieldFromRays(torch.autograd.Function):
     def forward(ctx, rays_o, rays_d, viewdirs, z, pk, mode):
         rays_o, rays_d, viewdirs, z = _f32(rays_o), _f32(rays_d), _f32(viewdirs), _f32(z)
         N, S = z.shape
-        need = mode == L.FIELD_FULL and any(ctx.needs_input_grad[:3])
+        need = mode in (L.FIELD_FULL, L.FIELD_STATIC) and any(ctx.needs_input_grad[:3])
         if USE_X6 and x6_supported(pk, mode):
             raw_t, masks = field_fwd_x6(pk, mode, N, S, rays_o, rays_d, z, viewdirs=viewdirs, want_masks=need)
         else:
@@ -271,12 +280,12 @@ class FieldFromRays(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_raw_t):
         if not ctx.have:
-            raise NotImplementedError("nefes_amd: backward through the field is built for the FULL (fine, test-time) "
-                                      "mode only; the train-mode dW/coarse backward kernels are a later row of SURVEY §8f")
+            raise NotImplementedError("nefes_amd: the sigma-only field pass has no backward (the reference evaluates it "
+                                      "without gradients at test time: nerfh_nff.py:192-202)")
         rays_o, rays_d, viewdirs, z, raw_t, masks = ctx.saved_tensors
         N, S = z.shape
         g_pts, g_vs = field_bwd(ctx.pk, N, S, raw_t, _f32(g_raw_t), masks, rays_o=rays_o, rays_d=rays_d, z=z,
-                                viewdirs=viewdirs)
+                                viewdirs=viewdirs, mode=ctx.mode)
         g_o, g_d, g_v = ray_grad_reduce(N, S, z, g_pts, g_vs)
         return g_o, g_d, g_v, None, None, None
 

@@ -271,6 +271,37 @@ def test_field_from_rays_vs_oracle(ops, L, Wd, C, S):
         assert e_hip <= max(1e-4, 3 * e_ref)
 
 
+@pytest.mark.parametrize("Wd,C,S", [(256, 16, 64), (128, 128, 40)])
+def test_static_mode_field_backward_vs_oracle(ops, L, Wd, C, S):
+    """NEFES_FIELD_STATIC (the coarse network in train mode, rendering.py:116-125 with test_time=False): forward and the
+    gradient w.r.t. the rays through nefes_field_bwd_static against the oracle."""
+    coarse, fine = _modules(Wd, C)
+    pc = O.make_field_params("coarse", Wd, C)
+    gen = torch.Generator().manual_seed(21)
+    N = 9
+    o = (torch.rand(N, 3, generator=gen) - .5)
+    d = torch.randn(N, 3, generator=gen)
+    v = d / d.norm(dim=-1, keepdim=True)
+    z = torch.sort(torch.rand(N, S, generator=gen) * 4, -1)[0]
+    g_raw = torch.randn(N, S, 3 + C + 1, generator=gen)
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        oo, dd, vv = (t.to(dt).clone().requires_grad_() for t in (o, d, v))
+        pts = oo[:, None, :] + dd[:, None, :] * z.to(dt)[..., None]
+        raw = O.query_field({k: w.to(dt) for k, w in pc.items()}, pts, vv, "coarse", False, False)
+        raw.backward(g_raw.to(dt))
+        res[dt] = (raw.detach(), oo.grad, dd.grad, vv.grad)
+    oh, dh, vh = (t.to(DEV).clone().requires_grad_() for t in (o, d, v))
+    raw_t = ops.FieldFromRays.apply(oh, dh, vh, z.to(DEV), coarse.packed(), L.FIELD_STATIC)
+    raw_t.backward(g_raw.permute(0, 2, 1).contiguous().to(DEV))
+    assert rel(raw_t.permute(0, 2, 1), res[torch.float32][0]) < 1e-4
+    for name, got, i in (("rays_o", oh.grad, 1), ("rays_d", dh.grad, 2), ("viewdirs", vh.grad, 3)):
+        truth, ref32 = res[torch.float64][i], res[torch.float32][i]
+        e_hip, e_ref = rel(got, truth), rel(ref32, truth)
+        print(f"[static {Wd},{C},{S}] d {name}: hip-vs-f64 {e_hip:.2e}  ref32-vs-f64 {e_ref:.2e}")
+        assert e_hip <= max(1e-4, 3 * e_ref)
+
+
 # ---- end to end through the drop-in module path ------------------------------------------------------------------
 def _dropin():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
