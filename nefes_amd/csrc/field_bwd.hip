@@ -29,6 +29,8 @@ struct FieldBwdArgs {
     int N, S, R, C;
     long long M;
     int n_tiles;
+    float* dacts;           // TRAIN instances: [n_tiles][rows][128] gradient buffer (layout.h row map)
+    int rows;
 };
 
 
@@ -36,7 +38,10 @@ struct FieldBwdArgs {
 // the stream then is NEFES_STREAM_BWD_FULL_X6.  Same mask words, same outputs.
 // HAS_T = false: the static head only (NEFES_FIELD_STATIC forward: raw channels rgb+feature, sigma); the stream then is
 // NEFES_STREAM_BWD_STATIC and the transient segments are skipped.
-template <int W, int C3, int ENC, bool X6 = false, bool HAS_T = true>   // C3 = 3 + C; ENC = NEFES_XYZ_*
+// TRAIN: every gradient vector a product consumes (= d loss / d pre-activation of a hidden layer, ReLU mask applied) is
+// also written to a.dacts, where the weight-gradient kernel (train.hip) reads it: one fused launch replaces the
+// layer-by-layer nefes_train_dx chain.
+template <int W, int C3, int ENC, bool X6 = false, bool HAS_T = true, bool TRAIN = false>   // C3 = 3 + C; ENC = NEFES_XYZ_*
 __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
@@ -152,6 +157,11 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
             for (int w = 0; w < n; ++w) b[w] = MASKW(word0 + w);
         };
         uint32_t bh[WH], bt[WT];
+        // TRAIN: this lane's column of a hidden block in the gradient buffer (first row + 4 rows for lane half 1)
+        auto gptr = [&](int block) -> float* {
+            if constexpr (!TRAIN) return nullptr;
+            else return a.dacts + ((size_t)tile * a.rows + nefes_train_row(W, 0, block) + 4 * h) * 128 + wave * 32 + j;
+        };
         f32x16 G2[NTH], T3[NTH], T4[NTH];
         // ---- static_rgb^T: 3+C gradients in compact slots -> d(dir_encoding output) ----
         mma_run<NTH, KR, 0, true>(ring, ring_lane, ArrayIn<KR>{dr}, ZeroInit{}, G2);
@@ -160,11 +170,11 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         mma_run<NTH, 3, 0, true>(ring, ring_lane, ArrayIn<3>{dth}, ZeroInit{}, T3);
         // ---- transient_encoding.4^T, .2^T ----
         load_bits(bh, MW_TRUNK + 3 * WH, WH);
-        if constexpr (X6) mma_run_x6<NTH, GS / 8, 0>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{T3, bh}, ZeroInit{}, T4);
-        else mma_run<NTH, GS, 0, true>(ring, ring_lane, MaskedIn<NTH, WH>{T3, bh}, ZeroInit{}, T4);
+        if constexpr (X6) mma_run_x6<NTH, GS / 8, 0>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTH, WH, 0>{T3, bh}, gptr(NEFES_TB_T2)), ZeroInit{}, T4);
+        else mma_run<NTH, GS, 0, true>(ring, ring_lane, wrap_store<TRAIN>(MaskedIn<NTH, WH>{T3, bh}, gptr(NEFES_TB_T2)), ZeroInit{}, T4);
         load_bits(bh, MW_TRUNK + 2 * WH, WH);
-        if constexpr (X6) mma_run_x6<NTH, GS / 8, 0>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{T4, bh}, ZeroInit{}, T3);
-        else mma_run<NTH, GS, 0, true>(ring, ring_lane, MaskedIn<NTH, WH>{T4, bh}, ZeroInit{}, T3);
+        if constexpr (X6) mma_run_x6<NTH, GS / 8, 0>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTH, WH, 0>{T4, bh}, gptr(NEFES_TB_T1)), ZeroInit{}, T3);
+        else mma_run<NTH, GS, 0, true>(ring, ring_lane, wrap_store<TRAIN>(MaskedIn<NTH, WH>{T4, bh}, gptr(NEFES_TB_T1)), ZeroInit{}, T3);
         }
         // Full-width accumulators, ping-pong.  Tiles [2, NTW+2) hold a layer's d hidden; XA tile 1 = d dir-embedding;
         // XB tiles 0,1 = d xyz-embedding (written by layer 5, accumulated by layer 1).
@@ -172,18 +182,18 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         // ---- [transient_encoding.0 ; dir_encoding]^T -> d dir-embedding (tile 1) + d final (tiles 2..) ----
         if constexpr (HAS_T) {
             load_bits(bh, MW_TRUNK + WH, WH);
-            if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{T3, bh}, ZeroInit{}, XA);
-            else mma_run<NTW + 1, GS, 1, true>(ring, ring_lane, MaskedIn<NTH, WH>{T3, bh}, ZeroInit{}, XA);
+            if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTH, WH, 0>{T3, bh}, gptr(NEFES_TB_T0)), ZeroInit{}, XA);
+            else mma_run<NTW + 1, GS, 1, true>(ring, ring_lane, wrap_store<TRAIN>(MaskedIn<NTH, WH>{T3, bh}, gptr(NEFES_TB_T0)), ZeroInit{}, XA);
         }
         load_bits(bh, MW_TRUNK, WH);
-        if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, MaskedSplit<NTH, WH, 0>{G2, bh}, ZeroInit{}, XA);
-        else mma_run<NTW + 1, GS, 1, !HAS_T>(ring, ring_lane, MaskedIn<NTH, WH>{G2, bh}, ZeroInit{}, XA);
+        if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTH, WH, 0>{G2, bh}, gptr(NEFES_TB_DIR)), ZeroInit{}, XA);
+        else mma_run<NTW + 1, GS, 1, !HAS_T>(ring, ring_lane, wrap_store<TRAIN>(MaskedIn<NTH, WH>{G2, bh}, gptr(NEFES_TB_DIR)), ZeroInit{}, XA);
         // ---- xyz_encoding_final^T (no ReLU on its output) + static_sigma^T (one extra k-step) -> d h8 ----
         {
             float dsg[1];
             dsg[0] = STASH(6);
-            if constexpr (X6) mma_run_x6<NTW, W / 16, 2>(ring, ring_lane, IdentSplit<NTW + 2, 2>{XA}, ZeroInit{}, XB);
-            else mma_run<NTW, HS, 2, true>(ring, ring_lane, IdentIn<NTW + 2, 2>{XA}, ZeroInit{}, XB);
+            if constexpr (X6) mma_run_x6<NTW, W / 16, 2>(ring, ring_lane, wrap_store_x6<TRAIN>(IdentSplit<NTW + 2, 2>{XA}, gptr(NEFES_TB_FINAL)), ZeroInit{}, XB);
+            else mma_run<NTW, HS, 2, true>(ring, ring_lane, wrap_store<TRAIN>(IdentIn<NTW + 2, 2>{XA}, gptr(NEFES_TB_FINAL)), ZeroInit{}, XB);
             mma_run<NTW, 1, 2, false>(ring, ring_lane, ArrayIn<1>{dsg}, ZeroInit{}, XB);
         }
         // ---- xyz_encoding_8^T .. xyz_encoding_2^T, straight-line (XB -> XA -> XB ...): a runtime loop over the ping-pong
@@ -191,8 +201,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         //      Layer 5 also emits the skip's d xyz-embedding into XB tiles 0,1. ----
 #define NEFES_BWD_LAYER(L, SRC, DST, NTILES, T0)                                                            \
         load_bits(bt, ((L) - 1) * WT, WT);                                                              \
-        if constexpr (X6) mma_run_x6<NTILES, W / 16, T0>(ring, ring_lane, MaskedSplit<NTW + 2, WT, 2>{SRC, bt}, ZeroInit{}, DST); \
-        else mma_run<NTILES, HS, T0, true>(ring, ring_lane, MaskedIn<NTW + 2, WT, 2>{SRC, bt}, ZeroInit{}, DST);
+        if constexpr (X6) mma_run_x6<NTILES, W / 16, T0>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTW + 2, WT, 2>{SRC, bt}, gptr(NEFES_TB_L1 + (L) - 1)), ZeroInit{}, DST); \
+        else mma_run<NTILES, HS, T0, true>(ring, ring_lane, wrap_store<TRAIN>(MaskedIn<NTW + 2, WT, 2>{SRC, bt}, gptr(NEFES_TB_L1 + (L) - 1)), ZeroInit{}, DST);
         NEFES_BWD_LAYER(8, XB, XA, NTW, 2)
         NEFES_BWD_LAYER(7, XA, XB, NTW, 2)
         NEFES_BWD_LAYER(6, XB, XA, NTW, 2)
@@ -203,8 +213,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
 #undef NEFES_BWD_LAYER
         // ---- xyz_encoding_1^T accumulates onto the skip's d embedding ----
         load_bits(bt, 0, WT);
-        if constexpr (X6) mma_run_x6<2, W / 16, 0, false>(ring, ring_lane, MaskedSplit<NTW + 2, WT, 2>{XA, bt}, ZeroInit{}, XB);
-        else mma_run<2, HS, 0, false>(ring, ring_lane, MaskedIn<NTW + 2, WT, 2>{XA, bt}, ZeroInit{}, XB);
+        if constexpr (X6) mma_run_x6<2, W / 16, 0, false>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTW + 2, WT, 2>{XA, bt}, gptr(NEFES_TB_L1)), ZeroInit{}, XB);
+        else mma_run<2, HS, 0, false>(ring, ring_lane, wrap_store<TRAIN>(MaskedIn<NTW + 2, WT, 2>{XA, bt}, gptr(NEFES_TB_L1)), ZeroInit{}, XB);
         float dDv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dDv[r] = XA[1][r];
@@ -248,10 +258,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     ring.drain();
 }
 
-template <int W, int C3, int ENC, bool X6 = false, bool HAS_T = true>
+template <int W, int C3, int ENC, bool X6 = false, bool HAS_T = true, bool TRAIN = false>
 static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_BWD_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (8 * (W / 64) + 4 * (W / 128) + 8) * 256;
-    auto k = field_bwd_kernel<W, C3, ENC, X6, HAS_T>;
+    auto k = field_bwd_kernel<W, C3, ENC, X6, HAS_T, TRAIN>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -263,7 +273,7 @@ static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-static int field_bwd_impl(bool x6, bool full, const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+static int field_bwd_impl(bool x6, bool full, float* dacts, const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
                           const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                           const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                           float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
@@ -285,7 +295,21 @@ static int field_bwd_impl(bool x6, bool full, const NefesNetDesc* desc, const vo
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + (full ? 6 : 1);
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
+    a.dacts = dacts;
+    a.rows = nefes_train_row(desc->width, desc->feat_dim, NEFES_TB_END);
     hipStream_t st = (hipStream_t)stream;
+    if (dacts) {   // train instances (frequency embedding): fused dX chain that also stores every layer's gradient vector
+        if (ext) return NEFES_E_UNSUPPORTED;
+        if (desc->width == 256 && desc->feat_dim == 16) {
+            if (full) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, true, true, true>(a, st);
+            return launch_bwd<256, 19, NEFES_XYZ_FREQ10, false, false, true>(a, st);
+        }
+        if (desc->width == 128 && desc->feat_dim == 128) {
+            if (full) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, false, true, true>(a, st);
+            return launch_bwd<128, 131, NEFES_XYZ_FREQ10, false, false, true>(a, st);
+        }
+        return NEFES_E_UNSUPPORTED;
+    }
     if (!full) {   // static head only (fp32-MFMA instances)
         if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, false, false>(a, st);
         if (desc->width == 128 && desc->feat_dim == 128 && !ext) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, false, false>(a, st);
@@ -307,7 +331,7 @@ extern "C" int nefes_field_bwd(const NefesNetDesc* desc, const void* packed, int
                                const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                                float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
-    return field_bwd_impl(false, true, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
+    return field_bwd_impl(false, true, nullptr, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
                           g_viewdirs_s, stream);
 }
 
@@ -315,7 +339,7 @@ extern "C" int nefes_field_bwd_x6(const NefesNetDesc* desc, const void* packed, 
                                   const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                   const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                                   float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
-    return field_bwd_impl(true, true, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
+    return field_bwd_impl(true, true, nullptr, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
                           g_viewdirs_s, stream);
 }
 
@@ -323,6 +347,18 @@ extern "C" int nefes_field_bwd_static(const NefesNetDesc* desc, const void* pack
                                       const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                       const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                                       float* g_viewdirs_s, void* stream) {
-    return field_bwd_impl(false, false, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr,
+    return field_bwd_impl(false, false, nullptr, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr,
+                          g_viewdirs_s, stream);
+}
+
+extern "C" int nefes_field_bwd_train(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                                     const float* rays_d, const float* z, const float* viewdirs, const float* raw_t,
+                                     const float* g_raw_t, const uint32_t* masks, float* dacts, float* g_pts,
+                                     float* g_viewdirs_s, void* stream) {
+    if (!dacts || (mode != NEFES_FIELD_STATIC && mode != NEFES_FIELD_FULL)) return NEFES_E_BADARG;
+    const bool full = mode == NEFES_FIELD_FULL;
+    // the FULL instance at width 256 runs on the bf16x6 stream, everything else on the fp32 streams
+    const bool x6 = full && desc && desc->width == 256 && desc->feat_dim == 16;
+    return field_bwd_impl(x6, full, dacts, desc, packed, N, S, rays_o, rays_d, z, nullptr, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr,
                           g_viewdirs_s, stream);
 }

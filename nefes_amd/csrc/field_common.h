@@ -215,6 +215,27 @@ struct MaskedIn {               // backward: mask bit of activation s ? X : 0   
     template <bool NOP>
     __device__ __forceinline__ float get(int s) const { return mask_shift_out<NOP>(bits[s >> 5], X[T0 + (s >> 4)][s & 15]); }
 };
+// TRAIN instances of the backward kernel: the (masked) gradient vector a product consumes is also what the weight-gradient
+// kernels need, so it is stored on the way in -- element s (feature 32*(s/16) + rho_h(s%16)) of this lane's sample goes to
+// row p[...] of the tile-major gradient buffer (layout.h); p already holds the block's first row, the lane half's +4 rows
+// and the sample column.
+template <class Inner>
+struct Storing {
+    Inner in;
+    float* p;
+    template <bool NOP>
+    __device__ __forceinline__ float get(int s) const {
+        const float v = in.template get<NOP>(s);
+        p[(32 * (s >> 4) + nefes_rho(0, s & 15)) * 128] = v;
+        return v;
+    }
+};
+template <bool ON, class Inner>
+__device__ __forceinline__ auto wrap_store(const Inner& in, float* p) {
+    if constexpr (ON) return Storing<Inner>{in, p};
+    else return in;
+}
+
 template <int N>
 struct ArrayIn {
     const float (&v)[N];

@@ -365,7 +365,7 @@ extern "C" int nefes_train_row_offset(const NefesNetDesc* desc, int block) {
 
 extern "C" int nefes_field_fwd_train(const NefesNetDesc* desc, const void* packed, int mode, int N, int S,
                                      const float* rays_o, const float* rays_d, const float* z, const float* pts,
-                                     const float* viewdirs, float* raw_t, float* acts, void* stream) {
+                                     const float* viewdirs, float* raw_t, float* acts, uint32_t* masks, void* stream) {
     if (!acts) return NEFES_E_BADARG;
-    return field_fwd_impl(desc, packed, mode, N, S, rays_o, rays_d, z, pts, nullptr, viewdirs, raw_t, nullptr, acts, stream);
+    return field_fwd_impl(desc, packed, mode, N, S, rays_o, rays_d, z, pts, nullptr, viewdirs, raw_t, masks, acts, stream);
 }

@@ -48,35 +48,57 @@ template <bool CAPTURE, int NX, int NWORDS, int T0 = 0>
 struct ReluSplit {              // forward: relu(X) (+ mask capture), source tiles T0..
     const f32x16 (&X)[NX];
     uint32_t (&bits)[NWORDS];
-    __device__ __forceinline__ void pair(Split3& o, int q, int p) const {      // values 2p, 2p+1 of k16-step q
+    __device__ __forceinline__ void vals(int q, int p, float& x0, float& x1) const {   // values 2p, 2p+1 of k16-step q
         const float v0 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p], v1 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1];
         if (CAPTURE) {
             mask_shift_in(bits[(8 * q + 2 * p) >> 5], v0);
             mask_shift_in(bits[(8 * q + 2 * p + 1) >> 5], v1);
         }
-        split_pair(o, p, relu1<false>(v0), relu1<false>(v1));                  // one v_max each (fmaxf canonicalises first)
+        x0 = relu1<false>(v0); x1 = relu1<false>(v1);                          // one v_max each (fmaxf canonicalises first)
     }
+    __device__ __forceinline__ void pair(Split3& o, int q, int p) const { float x0, x1; vals(q, p, x0, x1); split_pair(o, p, x0, x1); }
 };
 template <int NX, int NWORDS, int T0>
 struct MaskedSplit {            // backward: mask bit ? X : 0
     const f32x16 (&X)[NX];
     uint32_t (&bits)[NWORDS];
-    __device__ __forceinline__ void pair(Split3& o, int q, int p) const {
-        const float v0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
-        const float v1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
-        split_pair(o, p, v0, v1);
+    __device__ __forceinline__ void vals(int q, int p, float& x0, float& x1) const {
+        x0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
+        x1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
     }
+    __device__ __forceinline__ void pair(Split3& o, int q, int p) const { float x0, x1; vals(q, p, x0, x1); split_pair(o, p, x0, x1); }
 };
 template <int NX, int T0>
 struct IdentSplit {             // X as is
     const f32x16 (&X)[NX];
-    __device__ __forceinline__ void pair(Split3& o, int q, int p) const {
-        split_pair(o, p, X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
+    __device__ __forceinline__ void vals(int q, int p, float& x0, float& x1) const {
+        x0 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]; x1 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1];
     }
+    __device__ __forceinline__ void pair(Split3& o, int q, int p) const { float x0, x1; vals(q, p, x0, x1); split_pair(o, p, x0, x1); }
 };
 
 // acc[T0 .. T0+NT) = W-block * src over KS16 steps of 16 k-values; init(t) (bias or zero) is the C operand of each tile's
 // first MFMA.  Stream order: for k16-step q, for tile t: [A_hi | A_mid | A_lo] (3 KiB unit); floor(slab KiB / 3) units per slab.
+// TRAIN instances of the backward kernel: store the consumed gradient values (see Storing in field_common.h)
+template <class Inner>
+struct StoringSplit {
+    Inner in;
+    float* p;
+    __device__ __forceinline__ void pair(Split3& o, int q, int pp) const {
+        float x0, x1;
+        in.vals(q, pp, x0, x1);
+        const int s = 8 * q + 2 * pp;
+        p[(32 * (s >> 4) + nefes_rho(0, s & 15)) * 128] = x0;
+        p[(32 * ((s + 1) >> 4) + nefes_rho(0, (s + 1) & 15)) * 128] = x1;
+        split_pair(o, pp, x0, x1);
+    }
+};
+template <bool ON, class Inner>
+__device__ __forceinline__ auto wrap_store_x6(const Inner& in, float* p) {
+    if constexpr (ON) return StoringSplit<Inner>{in, p};
+    else return in;
+}
+
 template <int N>
 struct ArraySplit {             // per-lane values v[8q + i] (embedding slots) as they are
     const float (&v)[N];

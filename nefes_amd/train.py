@@ -97,8 +97,12 @@ def param_names(net, mode):
     return [n + s for n in names for s in (".weight", ".bias")]
 
 
-def weight_grads(net, pk, mode, N, S, raw_t, g_raw_t, acts):
-    """-> dict parameter name -> gradient (fp32, parameter shape) for every parameter on the path of `mode`."""
+FUSED_DX = True       # one fused backward launch (nefes_field_bwd_train) instead of the layer-by-layer nefes_train_dx chain
+
+
+def weight_grads(net, pk, mode, N, S, raw_t, g_raw_t, acts, fused=None):
+    """-> dict parameter name -> gradient (fp32, parameter shape) for every parameter on the path of `mode`.
+    fused = (rays_o, rays_d, viewdirs, z, masks): run the dX chain as one fused kernel launch."""
     lib, desc = L.load(), pk.desc
     W, Cf = net.W, net.W_features
     C3, H2 = 3 + Cf, W // 2
@@ -113,20 +117,27 @@ def weight_grads(net, pk, mode, N, S, raw_t, g_raw_t, acts):
     keep = []
     TB = lambda l: L.TB_L1 + (l - 1)
     # ---- backward through the layers: dacts rows of every hidden block become d loss / d pre-activation ----
-    if full:
-        w_th = torch.cat([w("transient_rgb.0"), w("transient_sigma.0"), w("transient_beta.0")], 0)     # raw channel order
-        keep.append(P.dx(L.TB_TH, 5, w_th, H2, L.TB_T2, False, True))
-        keep.append(P.dx(L.TB_T2, H2, w("transient_encoding.4"), H2, L.TB_T1, False, True))
-        keep.append(P.dx(L.TB_T1, H2, w("transient_encoding.2"), H2, L.TB_T0, False, True))
-    keep.append(P.dx(L.TB_RGB, C3, w("static_rgb.0"), H2, L.TB_DIR, False, True))
-    keep.append(P.dx(L.TB_DIR, H2, w("dir_encoding.0")[:, :W], W, L.TB_FINAL, False, False))
-    if full:
-        keep.append(P.dx(L.TB_T0, H2, w("transient_encoding.0")[:, :W], W, L.TB_FINAL, True, False))
-    keep.append(P.dx(L.TB_FINAL, W, w("xyz_encoding_final"), W, TB(8), False, False))
-    keep.append(P.dx(L.TB_SIG, 1, w("static_sigma.0"), W, TB(8), True, True))
-    for l in range(8, 1, -1):
-        wl = w(f"xyz_encoding_{l}.0")
-        keep.append(P.dx(TB(l), W, wl[:, EMB_XYZ:] if l == 5 else wl, W, TB(l - 1), False, True))
+    if fused is not None:
+        o, d, v, zz, masks = fused
+        g_pts, g_vs = torch.empty(N * S, 3, device=acts.device), torch.empty(N * S, 3, device=acts.device)
+        L.check(lib.nefes_field_bwd_train(C.byref(desc), pk.blob.data_ptr(), mode, N, S, o.data_ptr(), d.data_ptr(), zz.data_ptr(),
+                                          v.data_ptr(), raw_t.data_ptr(), g_raw_t.data_ptr(), masks.data_ptr(), dacts.data_ptr(),
+                                          g_pts.data_ptr(), g_vs.data_ptr(), ops._stream()), "nefes_field_bwd_train")
+    else:
+        if full:
+            w_th = torch.cat([w("transient_rgb.0"), w("transient_sigma.0"), w("transient_beta.0")], 0)     # raw channel order
+            keep.append(P.dx(L.TB_TH, 5, w_th, H2, L.TB_T2, False, True))
+            keep.append(P.dx(L.TB_T2, H2, w("transient_encoding.4"), H2, L.TB_T1, False, True))
+            keep.append(P.dx(L.TB_T1, H2, w("transient_encoding.2"), H2, L.TB_T0, False, True))
+        keep.append(P.dx(L.TB_RGB, C3, w("static_rgb.0"), H2, L.TB_DIR, False, True))
+        keep.append(P.dx(L.TB_DIR, H2, w("dir_encoding.0")[:, :W], W, L.TB_FINAL, False, False))
+        if full:
+            keep.append(P.dx(L.TB_T0, H2, w("transient_encoding.0")[:, :W], W, L.TB_FINAL, True, False))
+        keep.append(P.dx(L.TB_FINAL, W, w("xyz_encoding_final"), W, TB(8), False, False))
+        keep.append(P.dx(L.TB_SIG, 1, w("static_sigma.0"), W, TB(8), True, True))
+        for l in range(8, 1, -1):
+            wl = w(f"xyz_encoding_{l}.0")
+            keep.append(P.dx(TB(l), W, wl[:, EMB_XYZ:] if l == 5 else wl, W, TB(l - 1), False, True))
     # ---- weight gradients ----
     e_idx = _slot_rows(10, 64, EMB_XYZ, acts.device)
     d_idx = _slot_rows(4, 28, EMB_DIR, acts.device)
@@ -186,11 +197,18 @@ class FieldTrain(torch.autograd.Function):
         rows = int(lib.nefes_train_rows(C.byref(pk.desc)))
         raw_t = torch.empty(N, R, S, device=zz.device)
         acts = torch.empty(n_tiles, rows, 128, device=zz.device)
+        fused = FUSED_DX and pk.xyz_encoding == L.XYZ_FREQ10
+        masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=zz.device) if fused else None
         with ops._timed("field_fwd_train"):
             L.check(lib.nefes_field_fwd_train(C.byref(pk.desc), pk.blob.data_ptr(), mode, N, S, ops._chk(o, "rays_o"),
                                               ops._chk(d, "rays_d"), ops._chk(zz, "z"), None, ops._chk(v, "viewdirs"),
-                                              raw_t.data_ptr(), acts.data_ptr(), ops._stream()), "nefes_field_fwd_train")
-        ctx.save_for_backward(raw_t, acts)
+                                              raw_t.data_ptr(), acts.data_ptr(), None if masks is None else masks.data_ptr(),
+                                              ops._stream()), "nefes_field_fwd_train")
+        if fused:
+            ctx.save_for_backward(raw_t, acts, o, d, v, zz, masks)
+        else:
+            ctx.save_for_backward(raw_t, acts)
+        ctx.fused = fused
         if DEBUG is not None:
             DEBUG.update(acts=acts, rows=rows, off={b: int(lib.nefes_train_row_offset(C.byref(pk.desc), b)) for b in range(19)})
         ctx.net, ctx.pk, ctx.mode, ctx.NS = net, pk, mode, (N, S)
@@ -201,10 +219,11 @@ class FieldTrain(torch.autograd.Function):
         if any(ctx.needs_input_grad[:4]):
             raise NotImplementedError("nefes_amd: the train-mode pass produces weight gradients only; gradients w.r.t. the "
                                       "rays come from the refinement path (frozen weights, ops.FieldFromRays)")
-        raw_t, acts = ctx.saved_tensors
+        raw_t, acts = ctx.saved_tensors[:2]
         N, S = ctx.NS
         with ops._timed("field_bwd_train"):
-            g = weight_grads(ctx.net, ctx.pk, ctx.mode, N, S, raw_t, ops._f32(g_raw_t), acts)
+            g = weight_grads(ctx.net, ctx.pk, ctx.mode, N, S, raw_t, ops._f32(g_raw_t), acts,
+                             fused=tuple(ctx.saved_tensors[2:]) if ctx.fused else None)
         names = param_names(ctx.net, ctx.mode)
         return (None,) * 6 + tuple(g[n].contiguous() for n in names)
 
