@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEFES_ABI_VERSION 4
+#define NEFES_ABI_VERSION 5
 
 #define NEFES_E_BADARG (-1)     /* null pointer / non-positive size */
 #define NEFES_E_UNSUPPORTED (-2) /* width / feat_dim / sample count outside the compiled set */
@@ -80,6 +80,16 @@ int nefes_blob_info(const NefesNetDesc* desc, NefesBlobInfo* info);
  * transient_beta.0]; torch layout [out, in] row-major.  `blob` = host buffer of info.total_bytes. */
 int nefes_pack_weights(const NefesNetDesc* desc, const float* const* tensors, int n_tensors, void* blob,
                        size_t blob_bytes);
+/* Re-packing on the device, for training (script/run_nefes.py:42-108: the weights change at every optimizer.step()).
+ * nefes_pack_map (host): for every 16-bit slot of the blob, map[slot] = (flat index + 1) << 2 | part, where the flat index
+ * counts the elements of the tensor table above concatenated in order (tensor_elems_out[i] = elements of tensor i, may
+ * be NULL), part 0/1 = low/high half of the fp32 value, 1/2/3 = bf16 hi/mid/lo of the bf16x6 streams, code 0 = zero.
+ * n_entries >= total_bytes / 2.
+ * nefes_pack_device: blob[slot] = part(flat[...]) for every slot after the 256-byte header; flat, map, blob on the
+ * device; blob must have been initialised once by nefes_pack_weights.  Result bit-identical to nefes_pack_weights. */
+int nefes_pack_map(const NefesNetDesc* desc, uint32_t* map, size_t n_entries, int64_t* tensor_elems_out);
+int nefes_pack_device(const float* flat, int64_t n_params, const uint32_t* map, int64_t n_entries, void* blob,
+                      void* stream);
 
 /* ---- rays (script/models/ray_utils.py) ------------------------------------------------------- */
 /* get_rays (:5-16) + viewdirs = d/|d| (rendering.py:217) for image rows [row0, row0+nrows).

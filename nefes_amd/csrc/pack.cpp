@@ -360,6 +360,84 @@ extern "C" int nefes_blob_info(const NefesNetDesc* desc, NefesBlobInfo* info) {
     return 0;
 }
 
+// Number of elements of tensor i of the (weight, bias) table for this description (torch shapes, nerfh_nff.py:452-505).
+static int64_t tensor_elems(const Net& n, int i) {
+    const int l = i / 2;
+    const bool bias = i & 1;
+    int out, in;
+    if (l < 8) { out = n.W; in = l == 0 ? n.in_xyz : (l == 4 ? n.in_xyz + n.W : n.W); }
+    else if (l == L_FINAL) { out = n.W; in = n.W; }
+    else if (l == L_DIR || l == L_T0) { out = n.W2; in = n.W + 27; }
+    else if (l == L_SIGMA) { out = 1; in = n.W; }
+    else if (l == L_RGB) { out = 3 + n.C; in = n.W2; }
+    else if (l == L_T1 || l == L_T2) { out = n.W2; in = n.W2; }
+    else if (l == L_TRGB) { out = 3; in = n.W2; }
+    else { out = 1; in = n.W2; }    // transient sigma, beta
+    return bias ? out : (int64_t)out * in;
+}
+
+// One walk over the streams serves both products: `base` != null writes the blob (values); `map` != null writes, for every
+// 16-bit slot of the blob, the code (flat parameter index + 1) << 2 | part that nefes_pack_device expands on the GPU
+// (part 0/1 = low/high half of the fp32 value; 1/2/3 = the bf16 hi/mid/lo parts of the x6 split; code 0 = zero).  In map
+// mode the tensors hold float(flat index + 1), which every copy in build() and at()/at16() carries along unchanged.
+static int pack_walk(const NefesNetDesc* desc, const float* const* tensors, char* base, uint32_t* map, const NefesBlobInfo& info,
+                     Stream (&st)[NEFES_N_STREAMS]) {
+    auto code = [](float v, int part) { return v == 0.f ? 0u : (((uint32_t)v) << 2 | (uint32_t)part); };
+    for (int k = 0; k < NEFES_N_STREAMS; ++k) {
+        const NefesStreamInfo& si = info.stream[k];
+        if (si.n_slabs == 0) continue;
+        uint64_t boff = si.bias_off;
+        for (auto& bb : st[k].bias)
+            for (int r : bb.ridx) {
+                const float v = r < 0 ? 0.f : bb.b[r];
+                if (base) memcpy(base + boff, &v, 4);
+                if (map) { map[boff / 2] = code(v, 0); map[boff / 2 + 1] = code(v, 1); }
+                boff += 4;
+            }
+        uint64_t soff = si.slab_off;
+        const int frags = NEFES_FRAGS_OF_KIB(nefes_stream_slab_kib(k));
+        const uint64_t slab_bytes = (uint64_t)frags * 256;
+        for (auto& sg : st[k].segs) {
+            if (sg.x6) {   // units of three 1 KiB groups (hi, mid, lo): lane = 8 bf16 = A operand of one 32x32x16 MFMA
+                const int ups = (frags / 4) / 3;
+                for (int sl = 0; sl < sg.slabs(frags); ++sl, soff += slab_bytes) {
+                    for (int uu = 0; uu < ups && sl * ups + uu < sg.units(); ++uu) {
+                        const int u = sl * ups + uu, q = u / sg.nt, t = u % sg.nt;
+                        const uint64_t grp = soff + (uint64_t)uu * 3072;
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int i = 0; i < 8; ++i) {
+                                const float v = sg.at16(q, i, t, lane);
+                                uint16_t part[3];
+                                split_bf16x3(v, part);
+                                for (int pp = 0; pp < 3; ++pp) {
+                                    const uint64_t o = grp + 2ull * (pp * 512 + lane * 8 + i);
+                                    if (base) memcpy(base + o, &part[pp], 2);
+                                    if (map) map[o / 2] = code(v, 1 + pp);
+                                }
+                            }
+                    }
+                }
+                continue;
+            }
+            const int sps = nefes_steps_per_slab(sg.nt, frags);
+            for (int sl = 0; sl < sg.slabs(frags); ++sl, soff += slab_bytes) {
+                const int steps = (sg.ks - sl * sps) < sps ? (sg.ks - sl * sps) : sps;
+                for (int f = 0; f < steps * sg.nt; ++f) {
+                    const int s = sl * sps + f / sg.nt, t = f % sg.nt;
+                    const uint64_t dst = soff + 4ull * ((f >> 2) * 256 + (f & 3));   // b128 group f/4, component f%4
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const float v = sg.at(s, t, lane);
+                        const uint64_t o = dst + 16ull * lane;
+                        if (base) memcpy(base + o, &v, 4);
+                        if (map) { map[o / 2] = code(v, 0); map[o / 2 + 1] = code(v, 1); }
+                    }
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 extern "C" int nefes_pack_weights(const NefesNetDesc* desc, const float* const* tensors, int n_tensors, void* blob,
                                   size_t blob_bytes) {
     if (!desc || !tensors || !blob) return NEFES_E_BADARG;
@@ -380,41 +458,35 @@ extern "C" int nefes_pack_weights(const NefesNetDesc* desc, const float* const* 
     hdr[1] = NEFES_ABI_VERSION;
     memcpy(hdr + 2, desc, sizeof(*desc));
     memcpy(hdr + 8, &info, sizeof(info));
-    for (int k = 0; k < NEFES_N_STREAMS; ++k) {
-        const NefesStreamInfo& si = info.stream[k];
-        if (si.n_slabs == 0) continue;
-        float* bias = (float*)(base + si.bias_off);
-        for (auto& bb : st[k].bias)
-            for (int r : bb.ridx) *bias++ = r < 0 ? 0.f : bb.b[r];
-        float* slab = (float*)(base + si.slab_off);
-        for (auto& sg : st[k].segs) {
-            const int frags = NEFES_FRAGS_OF_KIB(nefes_stream_slab_kib(k));
-            if (sg.x6) {   // units of three 1 KiB groups (hi, mid, lo): lane = 8 bf16 = A operand of one 32x32x16 MFMA
-                const int ups = (frags / 4) / 3;
-                for (int sl = 0; sl < sg.slabs(frags); ++sl, slab += frags * 64) {
-                    for (int uu = 0; uu < ups && sl * ups + uu < sg.units(); ++uu) {
-                        const int u = sl * ups + uu, q = u / sg.nt, t = u % sg.nt;
-                        uint16_t* grp = (uint16_t*)(slab + uu * 3 * 256);
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int i = 0; i < 8; ++i) {
-                                uint16_t part[3];
-                                split_bf16x3(sg.at16(q, i, t, lane), part);
-                                for (int pp = 0; pp < 3; ++pp) grp[pp * 512 + lane * 8 + i] = part[pp];
-                            }
-                    }
-                }
-                continue;
-            }
-            const int sps = nefes_steps_per_slab(sg.nt, frags);
-            for (int sl = 0; sl < sg.slabs(frags); ++sl, slab += frags * 64) {
-                const int steps = (sg.ks - sl * sps) < sps ? (sg.ks - sl * sps) : sps;
-                for (int f = 0; f < steps * sg.nt; ++f) {
-                    const int s = sl * sps + f / sg.nt, t = f % sg.nt;
-                    float* dst = slab + (f >> 2) * 256 + (f & 3);   // b128 group f/4, component f%4
-                    for (int lane = 0; lane < 64; ++lane) dst[lane * 4] = sg.at(s, t, lane);
-                }
-            }
-        }
+    return pack_walk(desc, tensors, base, nullptr, info, st);
+}
+
+extern "C" int nefes_pack_map(const NefesNetDesc* desc, uint32_t* map, size_t n_entries, int64_t* tensor_elems_out) {
+    if (!desc || !map) return NEFES_E_BADARG;
+    Net n;
+    Stream st[NEFES_N_STREAMS];
+    {   // geometry first (tensor sizes depend on it)
+        Stream tmp[NEFES_N_STREAMS];
+        if (!build(desc, nullptr, n, tmp)) return NEFES_E_UNSUPPORTED;
     }
-    return 0;
+    const int need = desc->has_transient ? 36 : 24;
+    std::vector<std::vector<float>> idx(need);
+    const float* ptrs[36] = {nullptr};
+    int64_t flat = 0;
+    for (int i = 0; i < need; ++i) {
+        const int64_t ne = tensor_elems(n, i);
+        if (tensor_elems_out) tensor_elems_out[i] = ne;
+        idx[i].resize((size_t)ne);
+        for (int64_t e = 0; e < ne; ++e) idx[i][(size_t)e] = (float)(flat + e + 1);
+        flat += ne;
+        ptrs[i] = idx[i].data();
+    }
+    if (flat + 1 >= (1 << 24)) return NEFES_E_UNSUPPORTED;   // codes are carried as exact fp32 integers
+    Net n2;
+    if (!build(desc, ptrs, n2, st)) return NEFES_E_UNSUPPORTED;
+    NefesBlobInfo info;
+    fill_info(st, &info);
+    if (n_entries < info.total_bytes / 2) return NEFES_E_BADBLOB;
+    memset(map, 0, sizeof(uint32_t) * (info.total_bytes / 2));
+    return pack_walk(desc, ptrs, nullptr, map, info, st);
 }

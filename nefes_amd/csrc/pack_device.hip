@@ -1,0 +1,44 @@
+// Device-side weight repack: blob[slot] = part(flat[code >> 2], code & 3) for every 16-bit slot after the header, with the
+// slot -> code map of nefes_pack_map (pack.cpp).  One launch re-packs every stream of a network from the concatenated
+// parameter vector, so a training step (script/run_nefes.py:42-108: optimizer.step() changes the weights every iteration)
+// never copies parameters to the host.  Bit-identical to nefes_pack_weights (tests/test_gpu_train.py).
+#include <hip/hip_runtime.h>
+
+#include "../../include/nefes_hip.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t part16(const float* flat, uint32_t code) {
+    if (code == 0u) return 0u;
+    const float x = flat[(code >> 2) - 1u];
+    const uint32_t part = code & 3u, b = __float_as_uint(x);
+    if (part == 0u) return b & 0xffffu;
+    if (part == 1u) return b >> 16;
+    // truncation split, as split_bf16x3 (pack.cpp): both subtractions are exact
+    const float r = __fsub_rn(x, __uint_as_float(b & 0xffff0000u));
+    const uint32_t c = __float_as_uint(r);
+    if (part == 2u) return c >> 16;
+    return __float_as_uint(__fsub_rn(r, __uint_as_float(c & 0xffff0000u))) >> 16;
+}
+
+__global__ __launch_bounds__(256) void pack_device_kernel(const float* __restrict__ flat, const uint2* __restrict__ map2,
+                                                          long long first_word, long long n_words, uint32_t* __restrict__ blob) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long w = first_word + (long long)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+        const uint2 c = map2[w];
+        blob[w] = part16(flat, c.x) | (part16(flat, c.y) << 16);
+    }
+}
+
+}  // namespace
+
+extern "C" int nefes_pack_device(const float* flat, int64_t n_params, const uint32_t* map, int64_t n_entries, void* blob,
+                                 void* stream) {
+    if (!flat || !map || !blob || n_params <= 0 || n_entries <= 128 || (n_entries & 1)) return NEFES_E_BADARG;
+    const long long n_words = n_entries / 2, first = 64;        // the 256-byte header stays as the host packer wrote it
+    long long blocks = (n_words - first + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(pack_device_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, flat, (const uint2*)map, first,
+                       n_words, (uint32_t*)blob);
+    return (int)hipGetLastError();
+}

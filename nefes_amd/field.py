@@ -127,7 +127,10 @@ class NeRFH_NFF(nn.Module):
         sd = dict(self.named_parameters())
         prm = [sd[n + s] for n in names for s in (".weight", ".bias")]
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in prm)
-        if self._pk is None or key != self._pk_key:
+        if self._pk is not None and key != self._pk_key and all(p.is_cuda and p.device == self._pk.blob.device for p in prm):
+            self._pk.repack(prm)          # same network, new values (an optimizer step): re-packed on the device
+            self._pk_key = key
+        elif self._pk is None or key != self._pk_key:
             dev = prm[0].device if prm[0].is_cuda else torch.device("cuda")
             enc = L.XYZ_EXTERNAL32 if self.in_channels_xyz == 32 else L.XYZ_FREQ10      # 32 = externally encoded (hash grid)
             self._pk = ops.PackedField({n: p for n, p in sd.items()}, self.W, self.W_features, self.encode_transient, dev, enc)

@@ -31,7 +31,7 @@ class NefesHashGridDesc(C.Structure):
                 ("base_resolution", C.c_int32), ("per_level_scale", C.c_float), ("bound", C.c_float)]
 
 
-ABI_VERSION = 4        # NEFES_ABI_VERSION of include/nefes_hip.h
+ABI_VERSION = 5        # NEFES_ABI_VERSION of include/nefes_hip.h
 STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6, STREAM_BWD_FULL_X6, STREAM_BWD_STATIC = 0, 1, 2, 3, 4, 5, 6, 7
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
 XYZ_FREQ10, XYZ_EXTERNAL32 = 0, 1
@@ -47,6 +47,8 @@ SIGNATURES = {
     "nefes_version": (_i, []),
     "nefes_blob_info": (_i, [_desc, C.POINTER(NefesBlobInfo)]),
     "nefes_pack_weights": (_i, [_desc, C.POINTER(_p), _i, _p, _sz]),
+    "nefes_pack_map": (_i, [_desc, _p, _sz, _p]),
+    "nefes_pack_device": (_i, [_p, C.c_int64, _p, C.c_int64, _p, _p]),
     "nefes_raygen_fwd": (_i, [_i, _i, _f, _p, _i, _i, _p, _p, _p, _p]),
     "nefes_raygen_bwd_workspace": (_sz, [_i]),
     "nefes_raygen_bwd": (_i, [_i, _i, _f, _p, _i, _i, _p, _p, _p, _p, _p, _p]),

@@ -169,6 +169,31 @@ class PackedField:
                 "nefes_pack_weights")
         self.blob = blob.to(device)
         self.info = info
+        self.generation = 0          # bumped by repack(); autograd nodes refuse to run backward across it
+        self._map = None
+
+    def repack(self, params):
+        """Re-pack every stream on the device from the current parameter values (`params`: (weight, bias) per layer in
+        LAYERS order, CUDA tensors): one concatenation + one launch (nefes_pack_device), no host copy, no sync."""
+        lib = L.load()
+        if self._map is None:
+            n = self.info.total_bytes // 2
+            host_map = torch.zeros(n, dtype=torch.int32)
+            elems = (C.c_int64 * 36)()
+            L.check(lib.nefes_pack_map(self.desc, C.c_void_p(host_map.data_ptr()), n, C.cast(elems, C.c_void_p)), "nefes_pack_map")
+            self._map = host_map.to(self.blob.device)
+            self._elems = list(elems)[:36 if self.has_transient else 24]
+        if [int(p.numel()) for p in params] != self._elems:
+            raise RuntimeError("nefes_amd: parameter shapes do not match the packed network description")
+        flat = torch.cat([p.detach().reshape(-1) for p in params]).to(torch.float32)
+        L.check(lib.nefes_pack_device(flat.data_ptr(), flat.numel(), self._map.data_ptr(), self._map.numel(), self.blob.data_ptr(),
+                                      _stream()), "nefes_pack_device")
+        self.generation += 1
+
+    def check_generation(self, gen):
+        if gen != self.generation:
+            raise RuntimeError("nefes_amd: the network weights were modified (re-packed) between this forward pass and its "
+                               "backward pass")
 
     def mask_bytes(self, M):
         return L.load().nefes_field_mask_bytes(self.desc, M)
@@ -272,7 +297,7 @@ class FieldFromRays(torch.autograd.Function):
             raw_t, masks = field_fwd_x6(pk, mode, N, S, rays_o, rays_d, z, viewdirs=viewdirs, want_masks=need)
         else:
             raw_t, masks = field_fwd(pk, mode, N, S, rays_o=rays_o, rays_d=rays_d, z=z, viewdirs=viewdirs, want_masks=need)
-        ctx.pk, ctx.mode, ctx.have = pk, mode, need
+        ctx.pk, ctx.mode, ctx.have, ctx.pk_gen = pk, mode, need, pk.generation
         if need:
             ctx.save_for_backward(rays_o, rays_d, viewdirs, z, raw_t, masks)
         return raw_t
@@ -284,6 +309,7 @@ class FieldFromRays(torch.autograd.Function):
                                       "without gradients at test time: nerfh_nff.py:192-202)")
         rays_o, rays_d, viewdirs, z, raw_t, masks = ctx.saved_tensors
         N, S = z.shape
+        ctx.pk.check_generation(ctx.pk_gen)
         g_pts, g_vs = field_bwd(ctx.pk, N, S, raw_t, _f32(g_raw_t), masks, rays_o=rays_o, rays_d=rays_d, z=z,
                                 viewdirs=viewdirs, mode=ctx.mode)
         g_o, g_d, g_v = ray_grad_reduce(N, S, z, g_pts, g_vs)
@@ -305,7 +331,7 @@ class FieldFromPoints(torch.autograd.Function):
             raw_t, masks = field_fwd_x6(pk, mode, N, S, pts=pts.reshape(-1, 3), viewdirs=viewdirs, want_masks=need)
         else:
             raw_t, masks = field_fwd(pk, mode, N, S, pts=pts.reshape(-1, 3), viewdirs=viewdirs, want_masks=need)
-        ctx.pk, ctx.mode, ctx.have = pk, mode, need
+        ctx.pk, ctx.mode, ctx.have, ctx.pk_gen = pk, mode, need, pk.generation
         if need:
             ctx.save_for_backward(pts, viewdirs, raw_t, masks)
         return raw_t
@@ -316,6 +342,7 @@ class FieldFromPoints(torch.autograd.Function):
             raise NotImplementedError("nefes_amd: field backward is built for the FULL (fine) mode only")
         pts, viewdirs, raw_t, masks = ctx.saved_tensors
         N, S = pts.shape[0], pts.shape[1]
+        ctx.pk.check_generation(ctx.pk_gen)
         g_pts, g_vs = field_bwd(ctx.pk, N, S, raw_t, _f32(g_raw_t), masks, pts=pts.reshape(-1, 3), viewdirs=viewdirs)
         zeros = torch.zeros(N, S, device=pts.device)
         _, _, g_v = ray_grad_reduce(N, S, zeros, g_pts, g_vs)
@@ -336,7 +363,7 @@ class FieldFromEncoding(torch.autograd.Function):
             raw_t, masks = field_fwd_x6(pk, mode, N, S, xyz_enc=enc.reshape(-1, 32), viewdirs=viewdirs, want_masks=need)
         else:
             raw_t, masks = field_fwd(pk, mode, N, S, xyz_enc=enc.reshape(-1, 32), viewdirs=viewdirs, want_masks=need)
-        ctx.pk, ctx.have = pk, need
+        ctx.pk, ctx.have, ctx.pk_gen = pk, need, pk.generation
         if need:
             ctx.save_for_backward(viewdirs, raw_t, masks)
             ctx.shape = (N, S)
@@ -348,6 +375,7 @@ class FieldFromEncoding(torch.autograd.Function):
             raise NotImplementedError("nefes_amd: field backward is built for the FULL (fine) mode only")
         viewdirs, raw_t, masks = ctx.saved_tensors
         N, S = ctx.shape
+        ctx.pk.check_generation(ctx.pk_gen)
         g_enc, g_vs = field_bwd(ctx.pk, N, S, raw_t, _f32(g_raw_t), masks, viewdirs=viewdirs)
         zeros = torch.zeros(N, S, device=raw_t.device)
         _, _, g_v = ray_grad_reduce(N, S, zeros, g_vs, g_vs)

@@ -211,7 +211,7 @@ class FieldTrain(torch.autograd.Function):
         ctx.fused = fused
         if DEBUG is not None:
             DEBUG.update(acts=acts, rows=rows, off={b: int(lib.nefes_train_row_offset(C.byref(pk.desc), b)) for b in range(19)})
-        ctx.net, ctx.pk, ctx.mode, ctx.NS = net, pk, mode, (N, S)
+        ctx.net, ctx.pk, ctx.mode, ctx.NS, ctx.pk_gen = net, pk, mode, (N, S), pk.generation
         return raw_t
 
     @staticmethod
@@ -219,6 +219,7 @@ class FieldTrain(torch.autograd.Function):
         if any(ctx.needs_input_grad[:4]):
             raise NotImplementedError("nefes_amd: the train-mode pass produces weight gradients only; gradients w.r.t. the "
                                       "rays come from the refinement path (frozen weights, ops.FieldFromRays)")
+        ctx.pk.check_generation(ctx.pk_gen)
         raw_t, acts = ctx.saved_tensors[:2]
         N, S = ctx.NS
         with ops._timed("field_bwd_train"):

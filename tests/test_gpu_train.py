@@ -200,3 +200,42 @@ def test_train_mode_vs_reference_golden(golden, tag):
         assert float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30)) > 0.9995, k
         n += 1
     assert n >= 19
+
+
+@pytest.mark.parametrize("Wd,C,typ,xyz", [(128, 128, "coarse", 63), (128, 128, "fine", 63), (256, 16, "fine", 63), (256, 16, "fine", 32)])
+def test_device_repack_bit_identical(Wd, C, typ, xyz):
+    """nefes_pack_device (one launch, from the concatenated parameters) == nefes_pack_weights (host) on the same values."""
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    torch.manual_seed(5)
+    kw = dict(W=Wd, f_dim=C, in_channels_xyz=xyz)
+    net = (NeRFH_NFF('coarse', **kw) if typ == "coarse" else NeRFH_NFF('fine', encode_appearance=True, encode_transient=True, **kw)).to(DEV)
+    pk = net.packed()
+    blob0 = pk.blob.clone()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.01 * torch.randn_like(p))           # what an optimizer step does: same storage, new version
+    pk2 = net.packed()
+    assert pk2 is pk and pk.generation == 1              # re-packed in place, on the device
+    assert not torch.equal(pk.blob, blob0)
+    sd = {n: p for n, p in net.named_parameters()}
+    host = ops.PackedField(sd, net.W, net.W_features, net.encode_transient, DEV, pk.xyz_encoding)
+    assert torch.equal(pk.blob, host.blob)
+    assert net.packed() is pk and pk.generation == 1     # unchanged parameters: no work
+
+
+def test_backward_after_weight_update_raises():
+    from nefes_amd import lib as L
+    from nefes_amd.train import field_train
+    torch.manual_seed(6)
+    net = _net("coarse", 128, 128)
+    N, S = 64, 32
+    o, d = torch.randn(N, 3, device=DEV), torch.randn(N, 3, device=DEV)
+    v = d / d.norm(dim=-1, keepdim=True)
+    z = torch.linspace(0.1, 2.0, S, device=DEV).expand(N, S).contiguous()
+    raw = field_train(net, L.FIELD_STATIC, o, d, v, z)
+    with torch.no_grad():
+        net.xyz_encoding_1[0].weight.mul_(1.5)
+    net.packed()                                         # the next forward pass re-packs in place
+    with pytest.raises(RuntimeError, match="modified"):
+        raw.sum().backward()

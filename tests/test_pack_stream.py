@@ -25,7 +25,7 @@ def test_exports_match_header():
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.nefes_version() == L.ABI_VERSION == 4
+    assert lib.nefes_version() == L.ABI_VERSION == 5
 
 
 def test_missing_library_is_loud(monkeypatch):
@@ -468,3 +468,36 @@ def test_x6_full_stream_reproduces_the_mlp(Wd, Cf):
     sig = lambda x: 1 / (1 + np.exp(-x))
     got = np.concatenate([ar.reshape(NTR * 32, n)[:3 + Cf].T, softplus(sg[0, :1]).T, sig(th[0, :3]).T, softplus(th[0, 3:5]).T], 1)
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("Wd,C,tr,enc", [(128, 128, False, 0), (128, 128, True, 0), (256, 16, True, 0), (256, 16, True, 1)])
+def test_pack_map_reproduces_host_pack(Wd, C, tr, enc):
+    """nefes_pack_map: expanding the slot -> (parameter, part) codes in numpy exactly as pack_device_kernel does gives the
+    blob nefes_pack_weights writes, for every stream (fp32 and bf16x6) and the bias blocks."""
+    import ctypes as ct
+    from nefes_amd import lib as L
+    lib = L.load()
+    desc = L.NefesNetDesc(Wd, C, 1 if tr else 0, enc)
+    info = L.NefesBlobInfo()
+    assert lib.nefes_blob_info(desc, info) == 0
+    n = 36 if tr else 24
+    elems = (ct.c_int64 * 36)()
+    m = np.zeros(info.total_bytes // 2, dtype=np.uint32)
+    assert lib.nefes_pack_map(desc, m.ctypes.data_as(ct.c_void_p), m.size, ct.cast(elems, ct.c_void_p)) == 0
+    rng = np.random.default_rng(Wd + C + enc)
+    tens = [np.ascontiguousarray((rng.standard_normal(s) * 0.1).astype(np.float32)) for s in list(elems)[:n]]
+    ptrs = (ct.c_void_p * n)(*[t.ctypes.data for t in tens])
+    blob = np.zeros(info.total_bytes, dtype=np.uint8)
+    assert lib.nefes_pack_weights(desc, ptrs, n, blob.ctypes.data_as(ct.c_void_p), blob.size) == 0
+    flat = np.concatenate([[0.0]] + [t.ravel() for t in tens]).astype(np.float32)
+    assert int((m >> 2).max()) == flat.size - 1           # every parameter is addressed, none beyond
+    x = flat[(m >> 2).astype(np.int64)]
+    part = m & 3
+    b = x.view(np.uint32)
+    r = (x - (b & 0xffff0000).view(np.float32)).astype(np.float32)
+    c = r.view(np.uint32)
+    r2 = (r - (c & 0xffff0000).view(np.float32)).astype(np.float32)
+    out = np.select([part == 0, part == 1, part == 2], [b & 0xffff, b >> 16, c >> 16], r2.view(np.uint32) >> 16).astype(np.uint16)
+    out[m == 0] = 0
+    assert np.array_equal(out[128:], blob.view(np.uint16)[128:])
+    assert not m[:128].any()                              # header slots are never written by the device packer
