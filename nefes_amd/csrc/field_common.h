@@ -42,17 +42,18 @@ __device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, 
     // v_readfirstlane), and a VMEM instruction reading such an SGPR needs 5 wait states the compiler does not insert for
     // inline asm.  Instead of padding (s_nop 4 = 20 cycles, a large part of a 32-cycle bf16 MFMA gap) the base is copied
     // by the scalar ALU into a fresh pair that the DMA reads: SALU-written SGPRs carry no such hazard.
+    // M0 is declared clobbered rather than saved and restored: the restore would have to wait until the DMA has read M0
+    // (tools/probe/overlap_probe.hip, dma variant 2: one cycle per bf16 MFMA less in the x6 instruction mix).
     uint64_t base2;
+    (void)keep;
     asm volatile(
-        "s_mov_b64 %1, %3\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %4\n\t"
+        "s_mov_b64 %0, %2\n\t"
+        "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep), "=&s"(base2)
+        "global_load_lds_dwordx4 %1, %0"
+        : "=&s"(base2)
         : "v"(lane_off), "s"(gbase), "s"(lds_dst)
-        : "memory");
+        : "memory", "m0");
 #endif
 }
 // 1-instruction ReLU (fmaxf() costs a canonicalising v_max in front of the real one)

@@ -88,12 +88,23 @@ static void run_il(const char* name, float* d_out, unsigned long long* d_cyc) {
 
 // bf16x6 feasibility: per "slab" 96 bf16 MFMAs (16 units x 6), 48 ds_read_b128 (3 per unit), P LDS-DMA pieces per wave
 // (1 KiB each, from an L2-resident blob), one counted wait + workgroup barrier.  4 waves, one per SIMD.
+// DV = 0: padded (s_nop 4) + M0 saved/restored; 1: scalar copy of the base instead of the padding (what the kernels do);
+// 2: as 1 without restoring M0 (nothing else in these kernels reads it)
+template <int DV>
 __device__ __forceinline__ void dma16(const void* gbase, unsigned lane_off, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+    unsigned long long base2;
+    if (DV == 0)
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+    else if (DV == 1)
+        asm volatile("s_mov_b64 %1, %3\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(base2) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b64 %0, %2\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
+                     : "=&s"(base2) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
 }
-template <int P, int NV, int IL = 0>
+template <int P, int NV, int IL = 0, int DV = 0>
 __global__ __launch_bounds__(256, 1) void dma_mix(const char* blob, float* out, unsigned long long* cyc, int n_slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void dma_mix(const char* blob, float* out, 
             if (u * P / 16 != (u + 1) * P / 16) {
                 __builtin_amdgcn_sched_barrier(0);
                 for (int q = u * P / 16; q < (u + 1) * P / 16; ++q)
-                    dma16(src + q * 4096, lane_off, lds0 + ((slot + 2) % 3) * 49152 + wave * 1024 + q * 4096);
+                    dma16<DV>(src + q * 4096, lane_off, lds0 + ((slot + 2) % 3) * 49152 + wave * 1024 + q * 4096);
                 __builtin_amdgcn_sched_barrier(0);
             }
             acc[x1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[x1], 0, 0, 0);
@@ -147,15 +158,15 @@ __global__ __launch_bounds__(256, 1) void dma_mix(const char* blob, float* out, 
     out[threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
-template <int P, int NV, int IL = 0>
+template <int P, int NV, int IL = 0, int DV = 0>
 static void run_mix(float* d_out, unsigned long long* d_cyc, const char* blob) {
     unsigned long long h;
     const int n = 200;
-    hipFuncSetAttribute((const void*)dma_mix<P, NV, IL>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((dma_mix<P, NV, IL>), dim3(256), dim3(256), 3 * 49152, 0, blob, d_out, d_cyc, n);
+    hipFuncSetAttribute((const void*)dma_mix<P, NV, IL, DV>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((dma_mix<P, NV, IL, DV>), dim3(256), dim3(256), 3 * 49152, 0, blob, d_out, d_cyc, n);
     hipDeviceSynchronize();
     hipMemcpy(&h, d_cyc, sizeof(h), hipMemcpyDeviceToHost);
-    printf("%s", IL ? "[two accumulators alternating] " : ""); printf("bf16x6 mix: %2d DMA pieces + 48 ds_read_b128 + %2d VALU/unit per 96 MFMAs: %.1f cycles per MFMA (floor 32)\n", P, NV, (double)h / (n * 96.0));
+    printf("%s[dma variant %d] ", IL ? "[two accumulators alternating] " : "", DV); printf("bf16x6 mix: %2d DMA pieces + 48 ds_read_b128 + %2d VALU/unit per 96 MFMAs: %.1f cycles per MFMA (floor 32)\n", P, NV, (double)h / (n * 96.0));
 }
 
 template <int KIND>
@@ -187,5 +198,7 @@ int main() {
     run_mix<0, 0>(d_out, d_cyc, blob); run_mix<12, 0>(d_out, d_cyc, blob); run_mix<12, 8>(d_out, d_cyc, blob); run_mix<12, 16>(d_out, d_cyc, blob);
     run_mix<6, 8>(d_out, d_cyc, blob);
     run_mix<0, 0, 1>(d_out, d_cyc, blob); run_mix<12, 8, 1>(d_out, d_cyc, blob);
+    run_mix<12, 0, 0, 1>(d_out, d_cyc, blob); run_mix<12, 8, 0, 1>(d_out, d_cyc, blob); run_mix<12, 0, 0, 2>(d_out, d_cyc, blob); run_mix<12, 8, 0, 2>(d_out, d_cyc, blob);
+    run_mix<12, 8, 1, 2>(d_out, d_cyc, blob); run_mix<24, 8, 0, 2>(d_out, d_cyc, blob);
     return 0;
 }
