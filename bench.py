@@ -303,21 +303,22 @@ def main():
         fwd_key = next(k for k in kern if k.startswith("field_fwd[full"))
         bwd_key = next(k for k in kern if k.startswith("field_bwd"))
         dom_key = max((fwd_key, bwd_key), key=lambda k: kern[k])
-        x6 = dom_key.endswith("x6]")
+        x3 = dom_key.endswith("x3]")                      # opt-in reduced-precision run (NEFES_X6_PRODUCTS=3): labelled as such
+        x6 = dom_key.endswith("x6]") or x3
         ach = flop_fwd / (kern[dom_key] * 1e-3) / 1e12
         enc = int(wl['hashgrid'])
         if dom_key == bwd_key:
-            dom_name = f"field_bwd_kernel<{Wd},{3 + C},{enc}{',X6' if x6 else ''}>"
+            dom_name = f"field_bwd_kernel<{Wd},{3 + C},{enc}{',X6=3' if x3 else ',X6' if x6 else ''}>"
         else:
-            dom_name = "field_fwd_x6_kernel<FULL>" if x6 else f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{enc}>"
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x6 else PEAK_F32_MFMA_TFLOPS
+            dom_name = ("field_fwd_x6_kernel<FULL,NP=3>" if x3 else "field_fwd_x6_kernel<FULL>") if x6 else f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{enc}>"
+        peak = PEAK_BF16_MFMA_TFLOPS / (3.0 if x3 else 6.0) if x6 else PEAK_F32_MFMA_TFLOPS
         flop_frame = 2.0 * (Nc * macs_sigma(Wd, in_xyz) + 2 * (Nc + Ni) * macs_full(Wd, C, in_xyz)) * n_total
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure
         # comes from the committed rocprofv3 passes of this same command (profiles/, 2*FETCH_SIZE + WRITE_SIZE in KiB,
         # gfx950 correction of MI355X_MICROARCH.md) and is quoted only for the workload it was measured on.
         traffic = None
         try:
-            if (a.workload, H, W, world) == ("metric", 480, 640, 1):
+            if (a.workload, H, W, world) == ("metric", 480, 640, 1) and not x3:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_per_launch.json")))
                 if dom_key == bwd_key:
                     want = "field_bwd_kernel<256,19,0,true>" if x6 else "field_bwd_kernel<256,19,0"
@@ -331,15 +332,20 @@ def main():
             "metric": "rays/s (fwd+bwd) at 640x480x(64+128) samples, 8x256 MLP" if a.workload == "metric"
                       else f"rays/s (fwd+bwd), secondary workload '{a.workload}'", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16x3 (16-bit operands, NOT the headline precision)" if x3 else "f32",
+            "data": "synthetic",
             "config": {"workload": f"{wl['name']}; {W}x{H}, random seed-0 weights, fwd + bwd to the 3x4 pose",
                        "rays_per_step": n_total, "samples_per_ray": [Nc, Ni], "parallelism": f"rows/{world}",
-                       "arithmetic": ("fp32 in, fp32 out; matrix products as exact bf16x6 split products with fp32 accumulation "
+                       "arithmetic": ("REDUCED PRECISION (opt-in NEFES_X6_PRODUCTS=3): three leading bf16 split products, operands "
+                                      "carried to 16 bits, ~5e-6 of the output scale (tests/test_gpu_x6.py); not the default"
+                                      if x3 else
+                                      "fp32 in, fp32 out; matrix products as exact bf16x6 split products with fp32 accumulation "
                                       "(fp32-level accuracy, tests/test_gpu_x6.py); NEFES_X6=0 selects the fp32-MFMA kernels"
                                       if any(k.endswith("x6]") for k in kern) else "fp32 MFMA")},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "peak_basis": ("dense bf16 MFMA peak 2500 / 6: bf16x6 split products, fp32-level accuracy" if x6
+                         "peak_basis": ("dense bf16 MFMA peak 2500 / 3: three-product split, reduced precision" if x3 else
+                                        "dense bf16 MFMA peak 2500 / 6: bf16x6 split products, fp32-level accuracy" if x6
                                         else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                          "vs_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes/launch (HBM side, from profiles/r01 PMC passes)",

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEFES_ABI_VERSION 5
+#define NEFES_ABI_VERSION 6
 
 #define NEFES_E_BADARG (-1)     /* null pointer / non-positive size */
 #define NEFES_E_UNSUPPORTED (-2) /* width / feat_dim / sample count outside the compiled set */
@@ -81,9 +81,9 @@ int nefes_blob_info(const NefesNetDesc* desc, NefesBlobInfo* info);
 int nefes_pack_weights(const NefesNetDesc* desc, const float* const* tensors, int n_tensors, void* blob,
                        size_t blob_bytes);
 /* Re-packing on the device, for training (script/run_nefes.py:42-108: the weights change at every optimizer.step()).
- * nefes_pack_map (host): for every 16-bit slot of the blob, map[slot] = (flat index + 1) << 2 | part, where the flat index
+ * nefes_pack_map (host): for every 16-bit slot of the blob, map[slot] = (flat index + 1) << 3 | part, where the flat index
  * counts the elements of the tensor table above concatenated in order (tensor_elems_out[i] = elements of tensor i, may
- * be NULL), part 0/1 = low/high half of the fp32 value, 1/2/3 = bf16 hi/mid/lo of the bf16x6 streams, code 0 = zero.
+ * be NULL), part 0/1 = low/high half of the fp32 value, 2/3/4 = bf16 hi/mid/lo of the bf16x6 streams, code 0 = zero.
  * n_entries >= total_bytes / 2.
  * nefes_pack_device: blob[slot] = part(flat[...]) for every slot after the 256-byte header; flat, map, blob on the
  * device; blob must have been initialised once by nefes_pack_weights.  Result bit-identical to nefes_pack_weights. */
@@ -189,6 +189,17 @@ int nefes_field_bwd_static(const NefesNetDesc* desc, const void* packed, int N, 
 /* nefes_field_bwd (width 256, C = 16) with the transposed products as bf16x6 split
  * products; consumes the mask words of either forward kernel. */
 int nefes_field_bwd_x6(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
+                       const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
+                       const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);
+
+/* Opt-in reduced-precision variants of the two calls above (width 256, C = 16 only): the three leading products
+ * hi*hi + hi*mid + mid*hi of the same bf16 split, i.e. operands carried to 16 bits -- relative error ~5e-6 of the output
+ * scale instead of ~5e-7, half the matrix-core work.  Same streams, same arguments, same mask-word format.  Never the
+ * default: the callers select them explicitly (nefes_amd.ops.X6_PRODUCTS = 3). */
+int nefes_field_fwd_x3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                       const float* rays_d, const float* z, const float* pts, const float* xyz_enc, const float* viewdirs,
+                       float* raw_t, uint32_t* masks, void* stream);
+int nefes_field_bwd_x3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
                        const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
                        const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);
 

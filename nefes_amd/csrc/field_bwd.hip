@@ -41,7 +41,7 @@ struct FieldBwdArgs {
 // TRAIN: every gradient vector a product consumes (= d loss / d pre-activation of a hidden layer, ReLU mask applied) is
 // also written to a.dacts, where the weight-gradient kernel (train.hip) reads it: one fused launch replaces the
 // layer-by-layer nefes_train_dx chain.
-template <int W, int C3, int ENC, bool X6 = false, bool HAS_T = true, bool TRAIN = false>   // C3 = 3 + C; ENC = NEFES_XYZ_*
+template <int W, int C3, int ENC, int X6 = 0, bool HAS_T = true, bool TRAIN = false>   // C3 = 3 + C; ENC = NEFES_XYZ_*; X6 = 0, 6 or 3 products
 __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     constexpr int MW_TRUNK = 8 * WT;
     constexpr int KR = (C3 + 1) / 2;
     static_assert(MW % 4 == 0, "mask words are staged as 16-byte groups");
+    constexpr int NP = X6 == 3 ? 3 : 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -170,10 +171,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         mma_run<NTH, 3, 0, true>(ring, ring_lane, ArrayIn<3>{dth}, ZeroInit{}, T3);
         // ---- transient_encoding.4^T, .2^T ----
         load_bits(bh, MW_TRUNK + 3 * WH, WH);
-        if constexpr (X6) mma_run_x6<NTH, GS / 8, 0>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTH, WH, 0>{T3, bh}, gptr(NEFES_TB_T2)), ZeroInit{}, T4);
+        if constexpr (X6) mma_run_x6<NTH, GS / 8, 0, true, NP>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTH, WH, 0>{T3, bh}, gptr(NEFES_TB_T2)), ZeroInit{}, T4);
         else mma_run<NTH, GS, 0, true>(ring, ring_lane, wrap_store<TRAIN>(MaskedIn<NTH, WH>{T3, bh}, gptr(NEFES_TB_T2)), ZeroInit{}, T4);
         load_bits(bh, MW_TRUNK + 2 * WH, WH);
-        if constexpr (X6) mma_run_x6<NTH, GS / 8, 0>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTH, WH, 0>{T4, bh}, gptr(NEFES_TB_T1)), ZeroInit{}, T3);
+        if constexpr (X6) mma_run_x6<NTH, GS / 8, 0, true, NP>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTH, WH, 0>{T4, bh}, gptr(NEFES_TB_T1)), ZeroInit{}, T3);
         else mma_run<NTH, GS, 0, true>(ring, ring_lane, wrap_store<TRAIN>(MaskedIn<NTH, WH>{T4, bh}, gptr(NEFES_TB_T1)), ZeroInit{}, T3);
         }
         // Full-width accumulators, ping-pong.  Tiles [2, NTW+2) hold a layer's d hidden; XA tile 1 = d dir-embedding;
@@ -182,17 +183,17 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         // ---- [transient_encoding.0 ; dir_encoding]^T -> d dir-embedding (tile 1) + d final (tiles 2..) ----
         if constexpr (HAS_T) {
             load_bits(bh, MW_TRUNK + WH, WH);
-            if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTH, WH, 0>{T3, bh}, gptr(NEFES_TB_T0)), ZeroInit{}, XA);
+            if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1, true, NP>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTH, WH, 0>{T3, bh}, gptr(NEFES_TB_T0)), ZeroInit{}, XA);
             else mma_run<NTW + 1, GS, 1, true>(ring, ring_lane, wrap_store<TRAIN>(MaskedIn<NTH, WH>{T3, bh}, gptr(NEFES_TB_T0)), ZeroInit{}, XA);
         }
         load_bits(bh, MW_TRUNK, WH);
-        if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTH, WH, 0>{G2, bh}, gptr(NEFES_TB_DIR)), ZeroInit{}, XA);
+        if constexpr (X6) mma_run_x6<NTW + 1, GS / 8, 1, !HAS_T, NP>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTH, WH, 0>{G2, bh}, gptr(NEFES_TB_DIR)), ZeroInit{}, XA);
         else mma_run<NTW + 1, GS, 1, !HAS_T>(ring, ring_lane, wrap_store<TRAIN>(MaskedIn<NTH, WH>{G2, bh}, gptr(NEFES_TB_DIR)), ZeroInit{}, XA);
         // ---- xyz_encoding_final^T (no ReLU on its output) + static_sigma^T (one extra k-step) -> d h8 ----
         {
             float dsg[1];
             dsg[0] = STASH(6);
-            if constexpr (X6) mma_run_x6<NTW, W / 16, 2>(ring, ring_lane, wrap_store_x6<TRAIN>(IdentSplit<NTW + 2, 2>{XA}, gptr(NEFES_TB_FINAL)), ZeroInit{}, XB);
+            if constexpr (X6) mma_run_x6<NTW, W / 16, 2, true, NP>(ring, ring_lane, wrap_store_x6<TRAIN>(IdentSplit<NTW + 2, 2>{XA}, gptr(NEFES_TB_FINAL)), ZeroInit{}, XB);
             else mma_run<NTW, HS, 2, true>(ring, ring_lane, wrap_store<TRAIN>(IdentIn<NTW + 2, 2>{XA}, gptr(NEFES_TB_FINAL)), ZeroInit{}, XB);
             mma_run<NTW, 1, 2, false>(ring, ring_lane, ArrayIn<1>{dsg}, ZeroInit{}, XB);
         }
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         //      Layer 5 also emits the skip's d xyz-embedding into XB tiles 0,1. ----
 #define NEFES_BWD_LAYER(L, SRC, DST, NTILES, T0)                                                            \
         load_bits(bt, ((L) - 1) * WT, WT);                                                              \
-        if constexpr (X6) mma_run_x6<NTILES, W / 16, T0>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTW + 2, WT, 2>{SRC, bt}, gptr(NEFES_TB_L1 + (L) - 1)), ZeroInit{}, DST); \
+        if constexpr (X6) mma_run_x6<NTILES, W / 16, T0, true, NP>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTW + 2, WT, 2>{SRC, bt}, gptr(NEFES_TB_L1 + (L) - 1)), ZeroInit{}, DST); \
         else mma_run<NTILES, HS, T0, true>(ring, ring_lane, wrap_store<TRAIN>(MaskedIn<NTW + 2, WT, 2>{SRC, bt}, gptr(NEFES_TB_L1 + (L) - 1)), ZeroInit{}, DST);
         NEFES_BWD_LAYER(8, XB, XA, NTW, 2)
         NEFES_BWD_LAYER(7, XA, XB, NTW, 2)
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
 #undef NEFES_BWD_LAYER
         // ---- xyz_encoding_1^T accumulates onto the skip's d embedding ----
         load_bits(bt, 0, WT);
-        if constexpr (X6) mma_run_x6<2, W / 16, 0, false>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTW + 2, WT, 2>{XA, bt}, gptr(NEFES_TB_L1)), ZeroInit{}, XB);
+        if constexpr (X6) mma_run_x6<2, W / 16, 0, false, NP>(ring, ring_lane, wrap_store_x6<TRAIN>(MaskedSplit<NTW + 2, WT, 2>{XA, bt}, gptr(NEFES_TB_L1)), ZeroInit{}, XB);
         else mma_run<2, HS, 0, false>(ring, ring_lane, wrap_store<TRAIN>(MaskedIn<NTW + 2, WT, 2>{XA, bt}, gptr(NEFES_TB_L1)), ZeroInit{}, XB);
         float dDv[16];
 #pragma unroll
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     ring.drain();
 }
 
-template <int W, int C3, int ENC, bool X6 = false, bool HAS_T = true, bool TRAIN = false>
+template <int W, int C3, int ENC, int X6 = 0, bool HAS_T = true, bool TRAIN = false>
 static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_BWD_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (8 * (W / 64) + 4 * (W / 128) + 8) * 256;
     auto k = field_bwd_kernel<W, C3, ENC, X6, HAS_T, TRAIN>;
@@ -273,7 +274,7 @@ static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-static int field_bwd_impl(bool x6, bool full, float* dacts, const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+static int field_bwd_impl(int x6, bool full, float* dacts, const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
                           const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                           const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                           float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
@@ -301,24 +302,29 @@ static int field_bwd_impl(bool x6, bool full, float* dacts, const NefesNetDesc* 
     if (dacts) {   // train instances (frequency embedding): fused dX chain that also stores every layer's gradient vector
         if (ext) return NEFES_E_UNSUPPORTED;
         if (desc->width == 256 && desc->feat_dim == 16) {
-            if (full) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, true, true, true>(a, st);
-            return launch_bwd<256, 19, NEFES_XYZ_FREQ10, false, false, true>(a, st);
+            if (full) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 6, true, true>(a, st);
+            return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 0, false, true>(a, st);
         }
         if (desc->width == 128 && desc->feat_dim == 128) {
-            if (full) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, false, true, true>(a, st);
-            return launch_bwd<128, 131, NEFES_XYZ_FREQ10, false, false, true>(a, st);
+            if (full) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 0, true, true>(a, st);
+            return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 0, false, true>(a, st);
         }
         return NEFES_E_UNSUPPORTED;
     }
     if (!full) {   // static head only (fp32-MFMA instances)
-        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, false, false>(a, st);
-        if (desc->width == 128 && desc->feat_dim == 128 && !ext) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, false, false>(a, st);
+        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 0, false>(a, st);
+        if (desc->width == 128 && desc->feat_dim == 128 && !ext) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 0, false>(a, st);
+        return NEFES_E_UNSUPPORTED;
+    }
+    if (x6 == 3) {   // three-product instances: the headline shape only
+        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 3>(a, st);
+        if (desc->width == 256 && desc->feat_dim == 16 && ext) return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32, 3>(a, st);
         return NEFES_E_UNSUPPORTED;
     }
     if (x6) {
-        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, true>(a, st);
-        if (desc->width == 256 && desc->feat_dim == 16 && ext) return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32, true>(a, st);
-        if (desc->width == 128 && desc->feat_dim == 128 && !ext) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, true>(a, st);
+        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 6>(a, st);
+        if (desc->width == 256 && desc->feat_dim == 16 && ext) return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32, 6>(a, st);
+        if (desc->width == 128 && desc->feat_dim == 128 && !ext) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 6>(a, st);
         return NEFES_E_UNSUPPORTED;
     }
     if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10>(a, st);
@@ -331,7 +337,7 @@ extern "C" int nefes_field_bwd(const NefesNetDesc* desc, const void* packed, int
                                const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                                float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
-    return field_bwd_impl(false, true, nullptr, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
+    return field_bwd_impl(0, true, nullptr, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
                           g_viewdirs_s, stream);
 }
 
@@ -339,7 +345,15 @@ extern "C" int nefes_field_bwd_x6(const NefesNetDesc* desc, const void* packed, 
                                   const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                   const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                                   float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
-    return field_bwd_impl(true, true, nullptr, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
+    return field_bwd_impl(6, true, nullptr, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
+                          g_viewdirs_s, stream);
+}
+
+extern "C" int nefes_field_bwd_x3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+                                  const float* rays_d, const float* z, const float* pts, const float* viewdirs,
+                                  const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
+                                  float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
+    return field_bwd_impl(3, true, nullptr, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
                           g_viewdirs_s, stream);
 }
 
@@ -347,7 +361,7 @@ extern "C" int nefes_field_bwd_static(const NefesNetDesc* desc, const void* pack
                                       const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                       const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                                       float* g_viewdirs_s, void* stream) {
-    return field_bwd_impl(false, false, nullptr, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr,
+    return field_bwd_impl(0, false, nullptr, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr,
                           g_viewdirs_s, stream);
 }
 
@@ -358,7 +372,7 @@ extern "C" int nefes_field_bwd_train(const NefesNetDesc* desc, const void* packe
     if (!dacts || (mode != NEFES_FIELD_STATIC && mode != NEFES_FIELD_FULL)) return NEFES_E_BADARG;
     const bool full = mode == NEFES_FIELD_FULL;
     // the FULL instance at width 256 runs on the bf16x6 stream, everything else on the fp32 streams
-    const bool x6 = full && desc && desc->width == 256 && desc->feat_dim == 16;
+    const int x6 = (full && desc && desc->width == 256 && desc->feat_dim == 16) ? 6 : 0;
     return field_bwd_impl(x6, full, dacts, desc, packed, N, S, rays_o, rays_d, z, nullptr, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr,
                           g_viewdirs_s, stream);
 }

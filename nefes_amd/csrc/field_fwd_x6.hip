@@ -35,7 +35,8 @@ struct FieldFwdX6Args {
 
 // MODE: NEFES_FIELD_SIGMA or NEFES_FIELD_FULL; ENC: NEFES_XYZ_FREQ10 or NEFES_XYZ_EXTERNAL32 (hash grid);
 // (W, NTR) = (256, 1) [C = 16] or (128, 5) [C = 128: the reference-default shape]
-template <int MODE, int ENC, int W = 256, int NTR = 1>
+// NP = 6 (default, fp32-level accuracy) or 3 (the three leading products only: 16-bit operands, nefes_field_fwd_x3)
+template <int MODE, int ENC, int W = 256, int NTR = 1, int NP = 6>
 __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
     constexpr int ES = ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : NEFES_E_STEPS;
@@ -120,26 +121,26 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
         constexpr bool CAP = MODE == NEFES_FIELD_FULL;
         auto sigma_head = [&](const f32x16 (&X)[NTW]) {
             f32x16 sg[1];
-            mma_run_x6<1, W / 16, 0>(ring, ring_lane, ReluSplit<false, NTW, WT>{X, bits}, bias_at(B_SIG), sg);   // static_sigma
+            mma_run_x6<1, W / 16, 0, true, NP>(ring, ring_lane, ReluSplit<false, NTW, WT>{X, bits}, bias_at(B_SIG), sg);   // static_sigma
             if (valid && h == 0) {
                 const int ch = (MODE == NEFES_FIELD_SIGMA) ? 0 : 3 + a.C;
                 raw_col()[(size_t)ch * a.S] = softplus_ref(sg[0][0]);
             }
         };
-        mma_run_x6<NTW, ES / 8, 0>(ring, ring_lane, ArraySplit<ES>{E}, bias_at(0), A);               // layer 1
+        mma_run_x6<NTW, ES / 8, 0, true, NP>(ring, ring_lane, ArraySplit<ES>{E}, bias_at(0), A);               // layer 1
 #pragma unroll 1
         for (int p = 0; p < 4; ++p) {
             const int l1 = 2 + 2 * p, l2 = l1 + 1;
             clear_bits();
-            mma_run_x6<NTW, W / 16, 0>(ring, ring_lane, ReluSplit<CAP, NTW, WT>{A, bits}, bias_at((l1 - 1) * W), B);   // layers 2, 4, 6, 8
+            mma_run_x6<NTW, W / 16, 0, true, NP>(ring, ring_lane, ReluSplit<CAP, NTW, WT>{A, bits}, bias_at((l1 - 1) * W), B);   // layers 2, 4, 6, 8
             put_masks(bits, WT);                                                                      // mask of layer l1-1
             if (p == 3) {
                 if (MODE == NEFES_FIELD_SIGMA) break;
                 sigma_head(B);
             }
             clear_bits();
-            mma_run_x6<NTW, W / 16, 0>(ring, ring_lane, ReluSplit<CAP, NTW, WT>{B, bits}, bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);   // 3, 5, 7, final
-            if (p == 1) mma_run_x6<NTW, ES / 8, 0, false>(ring, ring_lane, ArraySplit<ES>{E}, ZeroInit{}, A);   // skip: + W5[:, :63] e
+            mma_run_x6<NTW, W / 16, 0, true, NP>(ring, ring_lane, ReluSplit<CAP, NTW, WT>{B, bits}, bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL), A);   // 3, 5, 7, final
+            if (p == 1) mma_run_x6<NTW, ES / 8, 0, false, NP>(ring, ring_lane, ArraySplit<ES>{E}, ZeroInit{}, A);   // skip: + W5[:, :63] e
             put_masks(bits, WT);                                                                      // mask of layer l1
         }
         if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head(B);
@@ -163,12 +164,12 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
                 BiasInit a, b;
                 __device__ __forceinline__ f32x16 operator()(int t) const { return t < NTH ? a(t) : b(t - NTH); }
             };
-            mma_run_x6<2 * NTH, W / 16, 0>(ring, ring_lane, IdentSplit<NTW, 0>{A}, Bias2{bias_at(B_DIR), bias_at(B_T0)}, dt);
-            mma_run_x6<2 * NTH, 2, 0, false>(ring, ring_lane, ArraySplit<16>{Dv}, ZeroInit{}, dt);
+            mma_run_x6<2 * NTH, W / 16, 0, true, NP>(ring, ring_lane, IdentSplit<NTW, 0>{A}, Bias2{bias_at(B_DIR), bias_at(B_T0)}, dt);
+            mma_run_x6<2 * NTH, 2, 0, false, NP>(ring, ring_lane, ArraySplit<16>{Dv}, ZeroInit{}, dt);
             {
                 f32x16 ar[NTR];
                 clear2();
-                mma_run_x6<NTR, W / 32, 0>(ring, ring_lane, ReluSplit<true, 2 * NTH, WH>{dt, bits2}, bias_at(B_RGB), ar);
+                mma_run_x6<NTR, W / 32, 0, true, NP>(ring, ring_lane, ReluSplit<true, 2 * NTH, WH>{dt, bits2}, bias_at(B_RGB), ar);
                 put_masks(bits2, WH);                                 // dir_encoding
                 if (valid) {
                     float* ph = raw_col() + (size_t)(4 * h) * a.S;
@@ -182,14 +183,14 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
                 }
             }
             clear2();
-            mma_run_x6<NTH, W / 32, 0>(ring, ring_lane, ReluSplit<true, 2 * NTH, WH, NTH>{dt, bits2}, bias_at(B_T1), acc3);
+            mma_run_x6<NTH, W / 32, 0, true, NP>(ring, ring_lane, ReluSplit<true, 2 * NTH, WH, NTH>{dt, bits2}, bias_at(B_T1), acc3);
             put_masks(bits2, WH);                                     // transient_encoding.0
             clear2();
-            mma_run_x6<NTH, W / 32, 0>(ring, ring_lane, ReluSplit<true, NTH, WH>{acc3, bits2}, bias_at(B_T2), acc2);
+            mma_run_x6<NTH, W / 32, 0, true, NP>(ring, ring_lane, ReluSplit<true, NTH, WH>{acc3, bits2}, bias_at(B_T2), acc2);
             put_masks(bits2, WH);                                     // transient_encoding.2
             f32x16 th[1];
             clear2();
-            mma_run_x6<1, W / 32, 0>(ring, ring_lane, ReluSplit<true, NTH, WH>{acc2, bits2}, bias_at(B_TH), th);
+            mma_run_x6<1, W / 32, 0, true, NP>(ring, ring_lane, ReluSplit<true, NTH, WH>{acc2, bits2}, bias_at(B_TH), th);
             put_masks(bits2, WH);
             if (valid) {
                 float* o = raw_col() + (size_t)(3 + a.C + 1) * a.S;
@@ -214,10 +215,10 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
 #endif
 }
 
-template <int MODE, int ENC, int W = 256, int NTR = 1>
+template <int MODE, int ENC, int W = 256, int NTR = 1, int NP = 6>
 static int launch_x6(const FieldFwdX6Args& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_X6_SLOTS * NEFES_SLAB_BYTES + ((a.bias_floats * 4 + 255) / 256) * 256;
-    auto k = field_fwd_x6_kernel<MODE, ENC, W, NTR>;
+    auto k = field_fwd_x6_kernel<MODE, ENC, W, NTR, NP>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -228,9 +229,9 @@ static int launch_x6(const FieldFwdX6Args& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-extern "C" int nefes_field_fwd_x6(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
-                                  const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
-                                  const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
+static int field_fwd_x6_impl(int np, const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                             const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
+                             const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
     if (!desc || !packed || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
     const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
     if (ext ? !xyz_enc : (!pts && !(rays_o && rays_d && z))) return NEFES_E_BADARG;
@@ -252,6 +253,15 @@ extern "C" int nefes_field_fwd_x6(const NefesNetDesc* desc, const void* packed, 
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
+    if (np == 3) {   // three-product instances: the headline shape only
+        if (!big) return NEFES_E_UNSUPPORTED;
+        if (ext) {
+            if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32, 256, 1, 3>(a, st);
+            return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32, 256, 1, 3>(a, st);
+        }
+        if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 256, 1, 3>(a, st);
+        return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 256, 1, 3>(a, st);
+    }
     if (small) {
         if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5>(a, st);
         return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5>(a, st);
@@ -262,4 +272,16 @@ extern "C" int nefes_field_fwd_x6(const NefesNetDesc* desc, const void* packed, 
     }
     if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10>(a, st);
     return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10>(a, st);
+}
+
+extern "C" int nefes_field_fwd_x6(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                                  const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
+                                  const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
+    return field_fwd_x6_impl(6, desc, packed, mode, N, S, rays_o, rays_d, z, pts, xyz_enc, viewdirs, raw_t, masks, stream);
+}
+
+extern "C" int nefes_field_fwd_x3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                                  const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
+                                  const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
+    return field_fwd_x6_impl(3, desc, packed, mode, N, S, rays_o, rays_d, z, pts, xyz_enc, viewdirs, raw_t, masks, stream);
 }

@@ -41,6 +41,28 @@ __device__ __forceinline__ void split_pair(Split3& o, int p, float x0, float x1)
     }
 }
 
+// Three-product mode: hi = RNE_bf16(x), mid = RNE_bf16(x - hi) (the residual is exact), so hi + mid is x rounded to ~16
+// significant bits with a zero-mean error (a truncation split leaves a one-sided remainder that adds up coherently over
+// the layers: measured 9e-5 instead of 2.6e-5 of the output scale).  v_cvt_pk_bf16_f32 converts a pair per instruction and the
+// residuals are one packed subtraction: 6 VALU per pair.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair16(Split3& o, int p, float x0, float x1) {
+    const bf16x2 h = {(__bf16)x0, (__bf16)x1};
+    uint32_t hb;
+    __builtin_memcpy(&hb, &h, 4);
+    const float e0 = x0 - __uint_as_float(hb << 16), e1 = x1 - __uint_as_float(hb & 0xffff0000u);    // exact
+    const bf16x2 m = {(__bf16)e0, (__bf16)e1};
+    uint32_t mb;
+    __builtin_memcpy(&mb, &m, 4);
+    o.h[p] = hb;
+    o.m[p] = mb;
+}
+template <int NP>
+__device__ __forceinline__ void split_pair_n(Split3& o, int p, float x0, float x1) {
+    if constexpr (NP == 3) split_pair16(o, p, x0, x1);
+    else split_pair(o, p, x0, x1);
+}
+
 // B-operand sources: get(q) = the 8 values of k16-step q (source tile T0 + q/2, registers 8(q%2) .. +7), transformed and
 // split.  The mask-touching ones walk the activations in the same order as the fp32 functors (activation 8q + i <-> k-step
 // 16T + r there), so forward and backward kernels of either kind exchange identical ReLU-mask words.
@@ -56,7 +78,8 @@ struct ReluSplit {              // forward: relu(X) (+ mask capture), source til
         }
         x0 = relu1<false>(v0); x1 = relu1<false>(v1);                          // one v_max each (fmaxf canonicalises first)
     }
-    __device__ __forceinline__ void pair(Split3& o, int q, int p) const { float x0, x1; vals(q, p, x0, x1); split_pair(o, p, x0, x1); }
+    template <int NP = 6>
+    __device__ __forceinline__ void pair(Split3& o, int q, int p) const { float x0, x1; vals(q, p, x0, x1); split_pair_n<NP>(o, p, x0, x1); }
 };
 template <int NX, int NWORDS, int T0>
 struct MaskedSplit {            // backward: mask bit ? X : 0
@@ -66,7 +89,8 @@ struct MaskedSplit {            // backward: mask bit ? X : 0
         x0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
         x1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
     }
-    __device__ __forceinline__ void pair(Split3& o, int q, int p) const { float x0, x1; vals(q, p, x0, x1); split_pair(o, p, x0, x1); }
+    template <int NP = 6>
+    __device__ __forceinline__ void pair(Split3& o, int q, int p) const { float x0, x1; vals(q, p, x0, x1); split_pair_n<NP>(o, p, x0, x1); }
 };
 template <int NX, int T0>
 struct IdentSplit {             // X as is
@@ -74,7 +98,8 @@ struct IdentSplit {             // X as is
     __device__ __forceinline__ void vals(int q, int p, float& x0, float& x1) const {
         x0 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]; x1 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1];
     }
-    __device__ __forceinline__ void pair(Split3& o, int q, int p) const { float x0, x1; vals(q, p, x0, x1); split_pair(o, p, x0, x1); }
+    template <int NP = 6>
+    __device__ __forceinline__ void pair(Split3& o, int q, int p) const { float x0, x1; vals(q, p, x0, x1); split_pair_n<NP>(o, p, x0, x1); }
 };
 
 // acc[T0 .. T0+NT) = W-block * src over KS16 steps of 16 k-values; init(t) (bias or zero) is the C operand of each tile's
@@ -84,13 +109,14 @@ template <class Inner>
 struct StoringSplit {
     Inner in;
     float* p;
+    template <int NP = 6>
     __device__ __forceinline__ void pair(Split3& o, int q, int pp) const {
         float x0, x1;
         in.vals(q, pp, x0, x1);
         const int s = 8 * q + 2 * pp;
         p[(32 * (s >> 4) + nefes_rho(0, s & 15)) * 128] = x0;
         p[(32 * ((s + 1) >> 4) + nefes_rho(0, (s + 1) & 15)) * 128] = x1;
-        split_pair(o, pp, x0, x1);
+        split_pair_n<NP>(o, pp, x0, x1);
     }
 };
 template <bool ON, class Inner>
@@ -102,11 +128,14 @@ __device__ __forceinline__ auto wrap_store_x6(const Inner& in, float* p) {
 template <int N>
 struct ArraySplit {             // per-lane values v[8q + i] (embedding slots) as they are
     const float (&v)[N];
-    __device__ __forceinline__ void pair(Split3& o, int q, int p) const { split_pair(o, p, v[8 * q + 2 * p], v[8 * q + 2 * p + 1]); }
+    template <int NP = 6>
+    __device__ __forceinline__ void pair(Split3& o, int q, int p) const { split_pair_n<NP>(o, p, v[8 * q + 2 * p], v[8 * q + 2 * p + 1]); }
 };
 
 // FIRST = false: accumulate onto acc (init unused).
-template <int NT, int KS16, int T0, bool FIRST = true, class SrcFn, class InitFn, int NACC, int SLOTS>
+// NP = 6: all six products (fp32-level accuracy).  NP = 3: hi*hi + hi*mid + mid*hi only (operands carried to 16 bits, error
+// ~2^-16 of the product scale; the lo parts and their three MFMAs drop out, the split of the lo part is dead code).
+template <int NT, int KS16, int T0, bool FIRST = true, int NP = 6, class SrcFn, class InitFn, int NACC, int SLOTS>
 __device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* ring_lane, const SrcFn& src,
                                            const InitFn& init, f32x16 (&acc)[NACC]) {
     static_assert(T0 + NT <= NACC, "accumulator array too small");
@@ -117,7 +146,7 @@ __device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* 
     // so that pair's ~17 VALU instructions sit in the gaps of one unit's six MFMAs (3-4 per gap)
     Split3 B, Bn;
 #pragma unroll
-    for (int pp = 0; pp < 4; ++pp) src.pair(B, 0, pp);
+    for (int pp = 0; pp < 4; ++pp) src.template pair<NP>(B, 0, pp);
     Bn = B;
     f32x16 c0;                                             // bias tile of the next first-step unit, fetched one unit ahead
     if (FIRST) c0 = init(0);
@@ -157,7 +186,8 @@ __device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* 
                 } else {
                     c = acc[T0 + t];
                 }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, c, 0, 0, 0);      // small terms first
+                if constexpr (NP == 6) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, c, 0, 0, 0);      // small terms first
+                else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, c, 0, 0, 0);
                 if (uu + 1 < nu) {
 #pragma unroll
                     for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
@@ -167,9 +197,11 @@ __device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* 
                             __builtin_amdgcn_sched_barrier(0);
                         }
                 }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, c, 0, 0, 0);
+                if constexpr (NP == 6) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, c, 0, 0, 0);
                 acc[T0 + t] = c;
@@ -178,10 +210,10 @@ __device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* 
 #pragma unroll
                     for (int pp = 0; pp < 4; ++pp)
                         if (NT >= 4 ? (t == pp * STRIDE + STRIDE - 1) : (t == (pp * NT) / 4)) {
-                            src.pair(Bn, q + 1, pp);
+                            src.template pair<NP>(Bn, q + 1, pp);
                             // interleave: one MFMA, then up to four VALU instructions, five times
 #pragma unroll
-                            for (int i = 0; i < 5; ++i) {
+                            for (int i = 0; i < (NP == 6 ? 5 : 2); ++i) {
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                             }

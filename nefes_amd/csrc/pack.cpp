@@ -41,16 +41,22 @@ struct Seg {
     }
 };
 
-// w = hi + mid + lo exactly, each a bf16 (truncation split: 24 mantissa bits = 3 x 8)
+// w = hi + mid + lo exactly, each a bf16: hi = RNE(w), mid = RNE(w - hi), lo = w - hi - mid (both residuals are exact in
+// fp32, the last one has at most 8 significant bits).  Round-to-nearest parts make hi + mid an unbiased 16-bit value of w,
+// which is what the three-product kernels (nefes_field_fwd_x3) consume; the six-product kernels see an exact triple either way.
+static uint16_t rne_bf16(float f) {
+    uint32_t b;
+    memcpy(&b, &f, 4);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (uint16_t)(b >> 16);
+}
 static void split_bf16x3(float w, uint16_t (&part)[3]) {
     float r = w;
     for (int p = 0; p < 3; ++p) {
-        uint32_t b;
-        memcpy(&b, &r, 4);
-        b &= 0xffff0000u;
+        part[p] = rne_bf16(r);
+        const uint32_t b = (uint32_t)part[p] << 16;
         float f;
         memcpy(&f, &b, 4);
-        part[p] = (uint16_t)(b >> 16);
         r -= f;
     }
 }
@@ -377,12 +383,12 @@ static int64_t tensor_elems(const Net& n, int i) {
 }
 
 // One walk over the streams serves both products: `base` != null writes the blob (values); `map` != null writes, for every
-// 16-bit slot of the blob, the code (flat parameter index + 1) << 2 | part that nefes_pack_device expands on the GPU
-// (part 0/1 = low/high half of the fp32 value; 1/2/3 = the bf16 hi/mid/lo parts of the x6 split; code 0 = zero).  In map
+// 16-bit slot of the blob, the code (flat parameter index + 1) << 3 | part that nefes_pack_device expands on the GPU
+// (part 0/1 = low/high half of the fp32 value; 2/3/4 = the bf16 hi/mid/lo parts of the x6 split; code 0 = zero).  In map
 // mode the tensors hold float(flat index + 1), which every copy in build() and at()/at16() carries along unchanged.
 static int pack_walk(const NefesNetDesc* desc, const float* const* tensors, char* base, uint32_t* map, const NefesBlobInfo& info,
                      Stream (&st)[NEFES_N_STREAMS]) {
-    auto code = [](float v, int part) { return v == 0.f ? 0u : (((uint32_t)v) << 2 | (uint32_t)part); };
+    auto code = [](float v, int part) { return v == 0.f ? 0u : (((uint32_t)v) << 3 | (uint32_t)part); };
     for (int k = 0; k < NEFES_N_STREAMS; ++k) {
         const NefesStreamInfo& si = info.stream[k];
         if (si.n_slabs == 0) continue;
@@ -412,7 +418,7 @@ static int pack_walk(const NefesNetDesc* desc, const float* const* tensors, char
                                 for (int pp = 0; pp < 3; ++pp) {
                                     const uint64_t o = grp + 2ull * (pp * 512 + lane * 8 + i);
                                     if (base) memcpy(base + o, &part[pp], 2);
-                                    if (map) map[o / 2] = code(v, 1 + pp);
+                                    if (map) map[o / 2] = code(v, 2 + pp);
                                 }
                             }
                     }

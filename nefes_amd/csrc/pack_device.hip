@@ -1,4 +1,4 @@
-// Device-side weight repack: blob[slot] = part(flat[code >> 2], code & 3) for every 16-bit slot after the header, with the
+// Device-side weight repack: blob[slot] = part(flat[(code >> 3) - 1], code & 7) for every 16-bit slot after the header, with the
 // slot -> code map of nefes_pack_map (pack.cpp).  One launch re-packs every stream of a network from the concatenated
 // parameter vector, so a training step (script/run_nefes.py:42-108: optimizer.step() changes the weights every iteration)
 // never copies parameters to the host.  Bit-identical to nefes_pack_weights (tests/test_gpu_train.py).
@@ -8,17 +8,25 @@
 
 namespace {
 
+__device__ __forceinline__ uint32_t rne_bf16(float f) {
+    uint32_t b = __float_as_uint(f);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return b >> 16;
+}
+
 __device__ __forceinline__ uint32_t part16(const float* flat, uint32_t code) {
     if (code == 0u) return 0u;
-    const float x = flat[(code >> 2) - 1u];
-    const uint32_t part = code & 3u, b = __float_as_uint(x);
+    const float x = flat[(code >> 3) - 1u];
+    const uint32_t part = code & 7u, b = __float_as_uint(x);
     if (part == 0u) return b & 0xffffu;
     if (part == 1u) return b >> 16;
-    // truncation split, as split_bf16x3 (pack.cpp): both subtractions are exact
-    const float r = __fsub_rn(x, __uint_as_float(b & 0xffff0000u));
-    const uint32_t c = __float_as_uint(r);
-    if (part == 2u) return c >> 16;
-    return __float_as_uint(__fsub_rn(r, __uint_as_float(c & 0xffff0000u))) >> 16;
+    // bf16 triple, as split_bf16x3 (pack.cpp): round-to-nearest-even parts, both subtractions exact
+    const uint32_t hi = rne_bf16(x);
+    if (part == 2u) return hi;
+    const float r = __fsub_rn(x, __uint_as_float(hi << 16));
+    const uint32_t mid = rne_bf16(r);
+    if (part == 3u) return mid;
+    return rne_bf16(__fsub_rn(r, __uint_as_float(mid << 16)));
 }
 
 __global__ __launch_bounds__(256) void pack_device_kernel(const float* __restrict__ flat, const uint2* __restrict__ map2,

@@ -219,6 +219,15 @@ def field_fwd(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, pts
 # v_mfma_f32_32x32x16_bf16 (csrc/field_fwd_x6.hip: fp32-level accuracy, checked against the float64 oracle in
 # tests/test_gpu_x6.py).  Set False (or NEFES_X6=0) for the plain fp32-MFMA kernels.
 USE_X6 = os.environ.get("NEFES_X6", "1") != "0"
+# Number of cross products of the split: 6 (default: fp32-level accuracy) or 3 (opt-in, NEFES_X6_PRODUCTS=3: operands carried
+# to 16 bits, ~5e-6 of the output scale, half the matrix-core work; width 256 / C = 16 only -- nefes_field_fwd_x3 / _bwd_x3).
+X6_PRODUCTS = int(os.environ.get("NEFES_X6_PRODUCTS", "6"))
+
+
+def _x3(pk):
+    if X6_PRODUCTS not in (3, 6):
+        raise ValueError("nefes_amd.ops.X6_PRODUCTS must be 6 or 3")
+    return X6_PRODUCTS == 3 and pk.width == 256 and pk.feat_dim == 16
 
 
 def x6_supported(pk: PackedField, mode, forward=True):
@@ -234,8 +243,10 @@ def field_fwd_x6(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, 
     dev = pk.blob.device
     raw_t = torch.empty(N, pk.n_raw(mode), S, device=dev)
     masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=dev) if want_masks else None
-    with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]},x6]"):
-        L.check(L.load().nefes_field_fwd_x6(pk.desc, _chk(pk.blob, "blob", torch.uint8), mode, N, S, _chk(rays_o, "rays_o"),
+    x3 = _x3(pk)
+    fn = L.load().nefes_field_fwd_x3 if x3 else L.load().nefes_field_fwd_x6
+    with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]},{'x3' if x3 else 'x6'}]"):
+        L.check(fn(pk.desc, _chk(pk.blob, "blob", torch.uint8), mode, N, S, _chk(rays_o, "rays_o"),
                                             _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(xyz_enc, "xyz_enc"),
                                             _chk(viewdirs, "viewdirs"),
                                             _chk(raw_t, "raw_t"), _chk(masks, "masks", torch.int32), _stream()),
@@ -259,8 +270,10 @@ def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=
     g_enc = torch.empty(N * S, 32, device=dev) if ext else None
     g_vs = torch.empty(N * S, 3, device=dev)
     if USE_X6 and x6_supported(pk, L.FIELD_FULL, forward=False):
-        with _timed("field_bwd[x6]"):
-            L.check(L.load().nefes_field_bwd_x6(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
+        x3 = _x3(pk)
+        fn = L.load().nefes_field_bwd_x3 if x3 else L.load().nefes_field_bwd_x6
+        with _timed("field_bwd[x3]" if x3 else "field_bwd[x6]"):
+            L.check(fn(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
                                                 _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),
                                                 _chk(raw_t, "raw_t"), _chk(g_raw_t, "g_raw_t"), _chk(masks, "masks", torch.int32),
                                                 _chk(g_pts, "g_pts"), _chk(g_enc, "g_enc"), _chk(g_vs, "g_vs"), _stream()),

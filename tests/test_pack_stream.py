@@ -25,7 +25,7 @@ def test_exports_match_header():
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.nefes_version() == L.ABI_VERSION == 5
+    assert lib.nefes_version() == L.ABI_VERSION == 6
 
 
 def test_missing_library_is_loud(monkeypatch):
@@ -490,14 +490,54 @@ def test_pack_map_reproduces_host_pack(Wd, C, tr, enc):
     blob = np.zeros(info.total_bytes, dtype=np.uint8)
     assert lib.nefes_pack_weights(desc, ptrs, n, blob.ctypes.data_as(ct.c_void_p), blob.size) == 0
     flat = np.concatenate([[0.0]] + [t.ravel() for t in tens]).astype(np.float32)
-    assert int((m >> 2).max()) == flat.size - 1           # every parameter is addressed, none beyond
-    x = flat[(m >> 2).astype(np.int64)]
-    part = m & 3
+    assert int((m >> 3).max()) == flat.size - 1           # every parameter is addressed, none beyond
+    x = flat[(m >> 3).astype(np.int64)]
+    part = m & 7
+
+    def rne(f):                                           # fp32 -> bf16 bits, round to nearest even
+        u = f.view(np.uint32).astype(np.uint64)
+        return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint32)
     b = x.view(np.uint32)
-    r = (x - (b & 0xffff0000).view(np.float32)).astype(np.float32)
-    c = r.view(np.uint32)
-    r2 = (r - (c & 0xffff0000).view(np.float32)).astype(np.float32)
-    out = np.select([part == 0, part == 1, part == 2], [b & 0xffff, b >> 16, c >> 16], r2.view(np.uint32) >> 16).astype(np.uint16)
+    hi = rne(x)
+    r = (x - (hi << 16).astype(np.uint32).view(np.float32)).astype(np.float32)
+    mid = rne(r)
+    lo = rne((r - (mid << 16).astype(np.uint32).view(np.float32)).astype(np.float32))
+    out = np.select([part == 0, part == 1, part == 2, part == 3], [b & 0xffff, b >> 16, hi, mid], lo).astype(np.uint16)
     out[m == 0] = 0
     assert np.array_equal(out[128:], blob.view(np.uint16)[128:])
     assert not m[:128].any()                              # header slots are never written by the device packer
+
+
+def test_m0_only_written_by_the_dma_helper(tmp_path):
+    """The LDS-DMA helper (field_common.h lds_dma16) leaves M0 holding the LDS destination instead of saving/restoring it.
+    That is sound only while nothing else in the device code reads or writes M0: disassemble every code object of the
+    library and check that M0 appears in `s_mov_b32 m0, <sgpr>` and nowhere else."""
+    import os, re, subprocess
+    from nefes_amd import lib as L
+    bindir = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(bindir, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not installed")
+    fat = tmp_path / "fatbin.bin"
+    subprocess.check_call([tools[0], "-O", "binary", "--only-section=.hip_fatbin", L.LIB_PATH, str(fat)])
+    data = fat.read_bytes()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), data)]
+    assert len(starts) >= 8                                  # one bundle per .hip translation unit
+    n_dma = 0
+    for i, a in enumerate(starts):
+        piece = tmp_path / f"bundle{i}.bin"
+        piece.write_bytes(data[a:starts[i + 1] if i + 1 < len(starts) else len(data)])
+        co = tmp_path / f"code{i}.o"
+        subprocess.check_call([tools[1], "--unbundle", "--type=o", f"--input={piece}", f"--output={co}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], stderr=subprocess.DEVNULL)
+        if co.stat().st_size == 0:
+            continue
+        dis = subprocess.run([tools[2], "-d", "--no-show-raw-insn", str(co)], capture_output=True, text=True, check=True).stdout
+        for line in dis.splitlines():
+            ins = line.split("//")[0].strip()
+            if not re.search(r"\bm0\b", ins) or not line.startswith((" ", "\t")):
+                continue
+            assert re.fullmatch(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi|ttmp\d+)", ins), f"unexpected use of M0: {ins!r}"
+            n_dma += 1
+    assert n_dma > 1000                                      # the unrolled weight-stream pieces of the field kernels
