@@ -27,7 +27,17 @@ __device__ __forceinline__ bf16x8 as_bf16x8(f32x4 v) {
     return r;
 }
 
-// two fp32 values -> their (hi, mid, lo) bf16 parts packed pairwise into dword p of the three operand vectors
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float x0, float x1) {      // v_cvt_pk_bf16_f32: (RNE(x1) << 16) | RNE(x0)
+    const bf16x2 h = {(__bf16)x0, (__bf16)x1};
+    uint32_t b;
+    __builtin_memcpy(&b, &h, 4);
+    return b;
+}
+
+// two fp32 values -> their (hi, mid, lo) bf16 parts packed pairwise into dword p of the three operand vectors.
+// (A round-to-nearest split on v_cvt_pk_bf16_f32 + packed subtractions is 9 instead of 11 VALU per pair and measured
+// 0.5 % slower per frame: the packed instructions take two passes.)
 __device__ __forceinline__ void split_pair(Split3& o, int p, float x0, float x1) {
     {
         const uint32_t b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
@@ -45,17 +55,11 @@ __device__ __forceinline__ void split_pair(Split3& o, int p, float x0, float x1)
 // significant bits with a zero-mean error (a truncation split leaves a one-sided remainder that adds up coherently over
 // the layers: measured 9e-5 instead of 2.6e-5 of the output scale).  v_cvt_pk_bf16_f32 converts a pair per instruction and the
 // residuals are one packed subtraction: 6 VALU per pair.
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair16(Split3& o, int p, float x0, float x1) {
-    const bf16x2 h = {(__bf16)x0, (__bf16)x1};
-    uint32_t hb;
-    __builtin_memcpy(&hb, &h, 4);
+    const uint32_t hb = cvt_pk_bf16(x0, x1);
     const float e0 = x0 - __uint_as_float(hb << 16), e1 = x1 - __uint_as_float(hb & 0xffff0000u);    // exact
-    const bf16x2 m = {(__bf16)e0, (__bf16)e1};
-    uint32_t mb;
-    __builtin_memcpy(&mb, &m, 4);
     o.h[p] = hb;
-    o.m[p] = mb;
+    o.m[p] = cvt_pk_bf16(e0, e1);
 }
 template <int NP>
 __device__ __forceinline__ void split_pair_n(Split3& o, int p, float x0, float x1) {

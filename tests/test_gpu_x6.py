@@ -229,6 +229,7 @@ def test_three_product_variant_within_north_star_tolerance(xyz):
     bk = dict(viewdirs=dd) if xyz == 32 else dict(rays_o=od, rays_d=dd, z=zd, viewdirs=dd)
     for prod in (6, 3):
         old, ops.X6_PRODUCTS = ops.X6_PRODUCTS, prod
+        old_use, ops.USE_X6 = ops.USE_X6, True              # (the suite also runs under NEFES_X6=0)
         try:
             fwd[prod] = ops.field_fwd_x6(pk, L.FIELD_FULL, N, S, **kw)
             # both backward variants on the SAME forward state (six-product outputs and mask words): a ReLU unit whose
@@ -238,7 +239,7 @@ def test_three_product_variant_within_north_star_tolerance(xyz):
             gx, gv = ops.field_bwd(pk, N, S, fwd[6][0], g_raw, fwd[6][1], **bk)
             out[prod] = (fwd[prod][0].cpu().double(), gx.cpu().double(), gv.cpu().double())
         finally:
-            ops.X6_PRODUCTS = old
+            ops.X6_PRODUCTS, ops.USE_X6 = old, old_use
     if xyz == 63:
         p = {k: v.detach().cpu().double() for k, v in net.named_parameters()}
         pts = o[:, None, :] + d[:, None, :] * z[..., None]
