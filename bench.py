@@ -321,7 +321,7 @@ def main():
             if (a.workload, H, W, world) == ("metric", 480, 640, 1) and not x3:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_per_launch.json")))
                 if dom_key == bwd_key:
-                    want = "field_bwd_kernel<256,19,0,true>" if x6 else "field_bwd_kernel<256,19,0"
+                    want = "field_bwd_kernel<256,19,0,6," if x6 else "field_bwd_kernel<256,19,0,0,"
                 else:
                     want = "field_fwd_x6_kernel<2," if x6 else "field_fwd_kernel<256,1,2"
                 pm = next(v for k, v in pm.items() if k.replace(" ", "").startswith(want))
