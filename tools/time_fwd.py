@@ -22,12 +22,17 @@ for mode, name in ((L.FIELD_SIGMA, 'sigma'), (L.FIELD_FULL, 'full')):
     ms = e0.elapsed_time(e1)
     mac = {('sigma', 256): 491264, ('full', 256): 665088, ('sigma', 128): 130944, ('full', 128): 184064}[(name, Wd)]
     print(f"{name}: {ms:.2f} ms  {2 * mac * N * S / ms / 1e9:.1f} TFLOP/s  checksum {float(raw.double().sum()):.6f}")
-if Wd == 256:
+# bf16 split-product instances (six products; NEFES_X6_PRODUCTS=3 selects the opt-in three-product variant)
+for mode, name in ((L.FIELD_SIGMA, 'sigma'), (L.FIELD_FULL, 'full')):
+    if not ops.x6_supported(pk, mode):
+        continue
     for it in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        raw = ops.field_fwd_sigma_x6(pk, N, S, o, d, z)
+        raw, m = ops.field_fwd_x6(pk, mode, N, S, o, d, z, viewdirs=d, want_masks=(mode == L.FIELD_FULL))
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    print(f"sigma bf16x6: {ms:.2f} ms  {2 * 491264 * N * S / ms / 1e9:.1f} TFLOP/s (algorithmic fp32 FLOPs)  checksum {float(raw.double().sum()):.6f}")
+    mac = {('sigma', 256): 491264, ('full', 256): 665088, ('sigma', 128): 130944, ('full', 128): 184064}[(name, Wd)]
+    print(f"{name} bf16x{ops.X6_PRODUCTS}: {ms:.2f} ms  {2 * mac * N * S / ms / 1e9:.1f} TFLOP/s (algorithmic fp32 FLOPs)  "
+          f"checksum {float(raw.double().sum()):.6f}")
