@@ -13,6 +13,30 @@
 #define SP_MAX_NC 256
 #define SP_MAX_S 512
 
+// #{k < n : a[k] < v} / #{k < n : a[k] <= v} of a non-decreasing LDS array: what the linear counts below return, in log2(n) steps
+__device__ __forceinline__ int count_less(const float* a, int n, float v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ int count_less_equal(const float* a, int n, float v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// true on every lane iff a[0..n) is non-decreasing (NaNs make it false: the callers then take the order-free linear path)
+__device__ __forceinline__ bool wave_sorted(const float* a, int n, int lane) {
+    bool ok = true;
+    for (int k = lane; k + 1 < n; k += 64) ok = ok && (a[k] <= a[k + 1]);
+    return __ballot(!ok) == 0ull;
+}
+
 __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(int N, int Nc, int Ni, int layout, const float* __restrict__ z_coarse,
                                                                const float* __restrict__ weights, const float* __restrict__ u,
                                                                int u_per_ray, const float* __restrict__ cdf_in, float* z_fine,
@@ -59,10 +83,13 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(int N, int Nc, in
     if (cdf_out)
         for (int k = lane; k < nb; k += 64) cdf_out[(size_t)ray * nb + k] = cdf[k];
 
+    // a cumulative sum of positive terms is non-decreasing; a caller-supplied CDF is checked rather than trusted
+    const bool cdf_sorted = wave_sorted(cdf, nb, lane);
     for (int i = lane; i < Ni; i += 64) {
         const float uu = u_per_ray ? u[(size_t)ray * Ni + i] : u[i];
         int cnt = 0;                                      // searchsorted(..., right=True): #{k : cdf[k] <= u}  (:51)
-        for (int k = 0; k < nb; ++k) cnt += (cdf[k] <= uu) ? 1 : 0;
+        if (cdf_sorted && uu == uu) cnt = count_less_equal(cdf, nb, uu);
+        else for (int k = 0; k < nb; ++k) cnt += (cdf[k] <= uu) ? 1 : 0;
         const int below = cnt - 1 > 0 ? cnt - 1 : 0;      // :52-53
         const int above = cnt < nb - 1 ? cnt : nb - 1;
         const float c_lo = cdf[below], c_hi = cdf[above], b_lo = bins[below], b_hi = bins[above];
@@ -79,12 +106,20 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(int N, int Nc, in
     if (z_fine) {
         // stable rank sort of cat[z_coarse, z_samples] (values identical to torch.sort(...)[0], :141)
         const int S = Nc + Ni;
+        // Both halves are already ordered at test time (coarse depths; inverse CDF of an increasing u): the stable rank is
+        // then own index + a binary-search count in the other half (ties: coarse first, as cat[z_vals, z_samples] sorts).
+        // Jittered u (train mode) or NaNs fall back to the all-pairs rank.
+        const bool ordered = wave_sorted(all, Nc, lane) && wave_sorted(all + Nc, Ni, lane);
         for (int i = lane; i < S; i += 64) {
             const float v = all[i];
             int rank = 0;
-            for (int k = 0; k < S; ++k) {
-                const float o = all[k];
-                rank += (o < v || (o == v && k < i)) ? 1 : 0;
+            if (ordered) {
+                rank = i < Nc ? i + count_less(all + Nc, Ni, v) : (i - Nc) + count_less_equal(all, Nc, v);
+            } else {
+                for (int k = 0; k < S; ++k) {
+                    const float o = all[k];
+                    rank += (o < v || (o == v && k < i)) ? 1 : 0;
+                }
             }
             z_fine[(size_t)ray * S + rank] = v;
         }
