@@ -2,10 +2,27 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Sum over the 64 lanes, result on every lane.  Within a row of 16 lanes the exchange runs on DPP (register-to-register,
+// no LDS crossbar: a ds_bpermute butterfly costs a round trip per step and the one-wave-per-ray kernels issue dozens of sums
+// back to back); the four row sums are then read with v_readlane and added in lane order.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_move<0xb1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4e>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    v += dpp_move<0x140>(v);     // row_mirror: every lane now holds its row's sum
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double t = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    t += __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    t += __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    t += __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return t;
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
