@@ -274,6 +274,49 @@ static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// The kernel instances are spread over four objects built from this one source (Makefile: -DNEFES_TU_PART=0..3), because each
+// fully unrolled instance takes hipcc the better part of a minute: part 0 = entry points + the fp32 FULL instances, part 1 =
+// bf16x6 instances, part 2 = three-product and static-head instances, part 3 = TRAIN instances.
+#ifndef NEFES_TU_PART
+#define NEFES_TU_PART 0
+#endif
+enum { BWD_X6_256 = 0, BWD_X6_256_EXT, BWD_X6_128, BWD_X3_256, BWD_X3_256_EXT, BWD_STATIC_256, BWD_STATIC_128, BWD_TRAIN_256_FULL,
+       BWD_TRAIN_256_STATIC, BWD_TRAIN_128_FULL, BWD_TRAIN_128_STATIC };
+int nefes_bwd_launch_part1(int which, const FieldBwdArgs& a, hipStream_t st);
+int nefes_bwd_launch_part2(int which, const FieldBwdArgs& a, hipStream_t st);
+int nefes_bwd_launch_part3(int which, const FieldBwdArgs& a, hipStream_t st);
+
+#if NEFES_TU_PART == 1
+int nefes_bwd_launch_part1(int which, const FieldBwdArgs& a, hipStream_t st) {
+    switch (which) {
+        case BWD_X6_256: return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 6>(a, st);
+        case BWD_X6_256_EXT: return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32, 6>(a, st);
+        case BWD_X6_128: return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 6>(a, st);
+    }
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 2
+int nefes_bwd_launch_part2(int which, const FieldBwdArgs& a, hipStream_t st) {
+    switch (which) {
+        case BWD_X3_256: return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 3>(a, st);
+        case BWD_X3_256_EXT: return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32, 3>(a, st);
+        case BWD_STATIC_256: return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 0, false>(a, st);
+        case BWD_STATIC_128: return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 0, false>(a, st);
+    }
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 3
+int nefes_bwd_launch_part3(int which, const FieldBwdArgs& a, hipStream_t st) {
+    switch (which) {
+        case BWD_TRAIN_256_FULL: return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 6, true, true>(a, st);
+        case BWD_TRAIN_256_STATIC: return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 0, false, true>(a, st);
+        case BWD_TRAIN_128_FULL: return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 0, true, true>(a, st);
+        case BWD_TRAIN_128_STATIC: return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 0, false, true>(a, st);
+    }
+    return NEFES_E_UNSUPPORTED;
+}
+#else   // part 0
+
 static int field_bwd_impl(int x6, bool full, float* dacts, const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
                           const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                           const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
@@ -302,29 +345,29 @@ static int field_bwd_impl(int x6, bool full, float* dacts, const NefesNetDesc* d
     if (dacts) {   // train instances (frequency embedding): fused dX chain that also stores every layer's gradient vector
         if (ext) return NEFES_E_UNSUPPORTED;
         if (desc->width == 256 && desc->feat_dim == 16) {
-            if (full) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 6, true, true>(a, st);
-            return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 0, false, true>(a, st);
+            if (full) return nefes_bwd_launch_part3(BWD_TRAIN_256_FULL, a, st);
+            return nefes_bwd_launch_part3(BWD_TRAIN_256_STATIC, a, st);
         }
         if (desc->width == 128 && desc->feat_dim == 128) {
-            if (full) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 0, true, true>(a, st);
-            return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 0, false, true>(a, st);
+            if (full) return nefes_bwd_launch_part3(BWD_TRAIN_128_FULL, a, st);
+            return nefes_bwd_launch_part3(BWD_TRAIN_128_STATIC, a, st);
         }
         return NEFES_E_UNSUPPORTED;
     }
     if (!full) {   // static head only (fp32-MFMA instances)
-        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 0, false>(a, st);
-        if (desc->width == 128 && desc->feat_dim == 128 && !ext) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 0, false>(a, st);
+        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return nefes_bwd_launch_part2(BWD_STATIC_256, a, st);
+        if (desc->width == 128 && desc->feat_dim == 128 && !ext) return nefes_bwd_launch_part2(BWD_STATIC_128, a, st);
         return NEFES_E_UNSUPPORTED;
     }
     if (x6 == 3) {   // three-product instances: the headline shape only
-        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 3>(a, st);
-        if (desc->width == 256 && desc->feat_dim == 16 && ext) return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32, 3>(a, st);
+        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return nefes_bwd_launch_part2(BWD_X3_256, a, st);
+        if (desc->width == 256 && desc->feat_dim == 16 && ext) return nefes_bwd_launch_part2(BWD_X3_256_EXT, a, st);
         return NEFES_E_UNSUPPORTED;
     }
     if (x6) {
-        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 6>(a, st);
-        if (desc->width == 256 && desc->feat_dim == 16 && ext) return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32, 6>(a, st);
-        if (desc->width == 128 && desc->feat_dim == 128 && !ext) return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 6>(a, st);
+        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return nefes_bwd_launch_part1(BWD_X6_256, a, st);
+        if (desc->width == 256 && desc->feat_dim == 16 && ext) return nefes_bwd_launch_part1(BWD_X6_256_EXT, a, st);
+        if (desc->width == 128 && desc->feat_dim == 128 && !ext) return nefes_bwd_launch_part1(BWD_X6_128, a, st);
         return NEFES_E_UNSUPPORTED;
     }
     if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd<256, 19, NEFES_XYZ_FREQ10>(a, st);
@@ -376,3 +419,4 @@ extern "C" int nefes_field_bwd_train(const NefesNetDesc* desc, const void* packe
     return field_bwd_impl(x6, full, dacts, desc, packed, N, S, rays_o, rays_d, z, nullptr, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr,
                           g_viewdirs_s, stream);
 }
+#endif   // NEFES_TU_PART

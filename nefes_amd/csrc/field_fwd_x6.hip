@@ -229,6 +229,37 @@ static int launch_x6(const FieldFwdX6Args& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// Kernel instances spread over three objects built from this one source (Makefile: -DNEFES_TU_PART=0..2): part 0 = entry points
+// + the Wd = 256 frequency-embedding instances, part 1 = hash-grid and Wd = 128 instances, part 2 = three-product instances.
+#ifndef NEFES_TU_PART
+#define NEFES_TU_PART 0
+#endif
+enum { FWD_EXT_SIGMA = 0, FWD_EXT_FULL, FWD_128_SIGMA, FWD_128_FULL, FWD_X3_SIGMA, FWD_X3_FULL, FWD_X3_EXT_SIGMA, FWD_X3_EXT_FULL };
+int nefes_fwd_x6_launch_part1(int which, const FieldFwdX6Args& a, hipStream_t st);
+int nefes_fwd_x6_launch_part2(int which, const FieldFwdX6Args& a, hipStream_t st);
+
+#if NEFES_TU_PART == 1
+int nefes_fwd_x6_launch_part1(int which, const FieldFwdX6Args& a, hipStream_t st) {
+    switch (which) {
+        case FWD_EXT_SIGMA: return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32>(a, st);
+        case FWD_EXT_FULL: return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32>(a, st);
+        case FWD_128_SIGMA: return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5>(a, st);
+        case FWD_128_FULL: return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5>(a, st);
+    }
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 2
+int nefes_fwd_x6_launch_part2(int which, const FieldFwdX6Args& a, hipStream_t st) {
+    switch (which) {
+        case FWD_X3_SIGMA: return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 256, 1, 3>(a, st);
+        case FWD_X3_FULL: return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 256, 1, 3>(a, st);
+        case FWD_X3_EXT_SIGMA: return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32, 256, 1, 3>(a, st);
+        case FWD_X3_EXT_FULL: return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32, 256, 1, 3>(a, st);
+    }
+    return NEFES_E_UNSUPPORTED;
+}
+#else   // part 0
+
 static int field_fwd_x6_impl(int np, const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                              const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
                              const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
@@ -256,19 +287,19 @@ static int field_fwd_x6_impl(int np, const NefesNetDesc* desc, const void* packe
     if (np == 3) {   // three-product instances: the headline shape only
         if (!big) return NEFES_E_UNSUPPORTED;
         if (ext) {
-            if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32, 256, 1, 3>(a, st);
-            return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32, 256, 1, 3>(a, st);
+            if (mode == NEFES_FIELD_SIGMA) return nefes_fwd_x6_launch_part2(FWD_X3_EXT_SIGMA, a, st);
+            return nefes_fwd_x6_launch_part2(FWD_X3_EXT_FULL, a, st);
         }
-        if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 256, 1, 3>(a, st);
-        return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 256, 1, 3>(a, st);
+        if (mode == NEFES_FIELD_SIGMA) return nefes_fwd_x6_launch_part2(FWD_X3_SIGMA, a, st);
+        return nefes_fwd_x6_launch_part2(FWD_X3_FULL, a, st);
     }
     if (small) {
-        if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5>(a, st);
-        return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5>(a, st);
+        if (mode == NEFES_FIELD_SIGMA) return nefes_fwd_x6_launch_part1(FWD_128_SIGMA, a, st);
+        return nefes_fwd_x6_launch_part1(FWD_128_FULL, a, st);
     }
     if (ext) {
-        if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32>(a, st);
-        return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32>(a, st);
+        if (mode == NEFES_FIELD_SIGMA) return nefes_fwd_x6_launch_part1(FWD_EXT_SIGMA, a, st);
+        return nefes_fwd_x6_launch_part1(FWD_EXT_FULL, a, st);
     }
     if (mode == NEFES_FIELD_SIGMA) return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10>(a, st);
     return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10>(a, st);
@@ -285,3 +316,4 @@ extern "C" int nefes_field_fwd_x3(const NefesNetDesc* desc, const void* packed, 
                                   const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
     return field_fwd_x6_impl(3, desc, packed, mode, N, S, rays_o, rays_d, z, pts, xyz_enc, viewdirs, raw_t, masks, stream);
 }
+#endif   // NEFES_TU_PART
