@@ -46,9 +46,17 @@ static int hg_geometry(const NefesHashGridDesc* d, HgGeom* g, uint64_t* total) {
     return 0;
 }
 
+// index % entries without the division on the common path: a hashed level has entries = 2^log2_hashmap_size (mask); a dense
+// level has entries >= res^3 and, for positions inside the bound, corner coordinates <= res, so its linear index is
+// < 2 * entries (one conditional subtraction).  Positions outside the bound take the division (same result as before).
 __device__ __forceinline__ uint32_t hg_index(const HgLevel& L, uint32_t x, uint32_t y, uint32_t z) {
-    const uint32_t i = L.hashed ? (x ^ (y * 2654435761u) ^ (z * 805459861u)) : (x + y * L.res + z * L.res * L.res);
-    return L.offset + i % L.entries;
+    if (L.hashed) return L.offset + ((x ^ (y * 2654435761u) ^ (z * 805459861u)) & (L.entries - 1u));
+    uint32_t i = x + y * L.res + z * L.res * L.res;
+    if (i >= L.entries) {
+        i -= L.entries;
+        if (i >= L.entries) i %= L.entries;
+    }
+    return L.offset + i;
 }
 
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(HgGeom g, const float2* __restrict__ table, long long M,

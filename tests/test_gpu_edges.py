@@ -210,6 +210,10 @@ def test_hashgrid_encoding_vs_oracle():
     HG.encode(x32, table, bound).backward(gen)
     assert rel(xh.grad, x32.grad) < 2e-4
     assert rel(xh.grad, xc.grad) < 1.5 * rel(x32.grad, xc.grad) + 1e-4
+    # positions beyond +bound: corner coordinates exceed the level resolution and the dense levels' linear index wraps more
+    # than once (the kernel's division-free index path hands these to the plain modulo)
+    xo = torch.rand(129, 3, generator=g) * (bound * 0.6) + bound * 0.9
+    assert rel(grid(xo.to(DEV)), HG.encode(xo, table, bound)) < 2e-5
 
 
 def test_hashgrid_in_front_of_the_field_mlp():
