@@ -46,7 +46,9 @@ def _worker(rank, world, port, q):
     loss = (feat ** 2).sum() / (H * W * C) + (rgb ** 2).sum() / (H * W * 3)
     loss.backward()                       # <- the all-reduce of the 3x4 pose gradient happens here
     full = D.gather_maps(rgb.detach(), H)
-    q.put((rank, c2w.grad.clone(), full.clone(), (row0, n)))
+    # by value (numpy): a torch tensor in a multiprocessing queue is handed over through the producer's shared-memory
+    # descriptor, which is gone if this process exits before the parent has read it
+    q.put((rank, c2w.grad.numpy().copy(), full.numpy().copy(), (row0, n)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,6 +74,7 @@ def test_two_rank_pose_gradient_equals_unsharded():
     rgb, feat = _oracle_render_rows(H, W, focal, c2w, (0, H), pc, pf, cfg)
     (O.bench_loss(rgb, feat)).backward()
     for rank, g, full, rows in got:
+        g, full = torch.from_numpy(g), torch.from_numpy(full)
         assert torch.allclose(g, c2w.grad, rtol=1e-4, atol=1e-7), (rank, g, c2w.grad)   # identical on every rank
         assert torch.allclose(full, rgb.detach(), rtol=1e-5, atol=1e-6)                 # gathered image == unsharded image
     assert got[0][3] == (0, 3) and got[1][3] == (3, 3)
