@@ -253,3 +253,33 @@ def test_three_product_variant_within_north_star_tolerance(xyz):
     e_raw, e_gx, e_gv = rel(out[3][0], out[6][0]), rel(out[3][1], out[6][1]), rel(out[3][2], out[6][2])
     print(f"[x3] vs six products: raw {e_raw:.2e}  d inputs {e_gx:.2e}  d viewdirs {e_gv:.2e}")
     assert 0 < e_raw < 5e-5 and 0 < e_gx < 5e-5 and 0 < e_gv < 5e-5
+
+
+def test_render_three_product_variant_end_to_end():
+    """render() at the headline shape per ray with ops.X6_PRODUCTS = 3 against the six-product run: maps within 1e-4
+    (north-star tolerance), pose gradient within 1e-3 (it also moves through ReLU units that take the other branch)."""
+    import types
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    from nefes_amd.render import render
+    coarse = NeRFH_NFF('coarse', W=256, f_dim=16).requires_grad_(False).to(DEV)
+    fine = NeRFH_NFF('fine', W=256, f_dim=16, encode_appearance=True, encode_transient=True).requires_grad_(False).to(DEV)
+    args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True)
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, N_samples=64, network_fn=coarse, network_fine=fine,
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=True, args=args, ndc=False, lindisp=False)
+    H, W, f = 12, 16, 525.505 * 16 / 640.
+    res = {}
+    for prod in (6, 3):
+        old, ops.X6_PRODUCTS = ops.X6_PRODUCTS, prod
+        old_use, ops.USE_X6 = ops.USE_X6, True
+        try:
+            c2w = O.bench_pose().to(DEV).requires_grad_()
+            rgb, disp, acc, ex = render(H, W, f, c2w=c2w, near=0., far=4., **kw)
+            O.bench_loss(rgb, ex["feat_map"]).backward()
+            res[prod] = (rgb.detach().cpu().double(), ex["feat_map"].detach().cpu().double(), c2w.grad.cpu().double())
+        finally:
+            ops.X6_PRODUCTS, ops.USE_X6 = old, old_use
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    e = [rel(res[3][i], res[6][i]) for i in range(3)]
+    print(f"[x3] render vs six products: rgb {e[0]:.2e}  feat {e[1]:.2e}  d c2w {e[2]:.2e}")
+    assert 0 < e[0] < 1e-4 and 0 < e[1] < 1e-4 and e[2] < 1e-3
