@@ -236,7 +236,9 @@ def main():
         sec_e, rays = refinement_loop(dev, graph=False)
         sec, rays = refinement_loop(dev, graph=True)
         print(json.dumps({"metric": "rays/s (fwd+bwd), secondary workload 'loop50'", "value": rays / sec, "unit": "rays/s",
-                          "n_gpus": 1, "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+                          "n_gpus": 1, "higher_is_better": True,
+                          "dtype": "bf16x3 (16-bit operands, opt-in reduced precision)" if ops.X6_PRODUCTS == 3 and ops.USE_X6 else "f32",
+                          "data": "synthetic", "vs_baseline": None,
                           "ms_per_image_50_iterations": sec * 1e3, "ms_per_image_50_iterations_eager": sec_e * 1e3,
                           "config": {"workload": "BASELINE configs[4] minus the DFNet CNN: 50 x [LearnPose -> render 80x60 "
                                                  "(64+64, 8x128, C=128) -> affine colour -> FusionNet -> bicubic x4 -> cosine "

@@ -192,7 +192,7 @@ int nefes_field_bwd_x6(const NefesNetDesc* desc, const void* packed, int N, int 
                        const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
                        const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);
 
-/* Opt-in reduced-precision variants of the two calls above (width 256, C = 16 only): the three leading products
+/* Opt-in reduced-precision variants of the two calls above (same shapes): the three leading products
  * hi*hi + hi*mid + mid*hi of the same bf16 split, i.e. operands carried to 16 bits -- relative error ~5e-6 of the output
  * scale instead of ~5e-7, half the matrix-core work.  Same streams, same arguments, same mask-word format.  Never the
  * default: the callers select them explicitly (nefes_amd.ops.X6_PRODUCTS = 3). */

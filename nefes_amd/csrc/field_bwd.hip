@@ -280,7 +280,7 @@ static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { BWD_X6_256 = 0, BWD_X6_256_EXT, BWD_X6_128, BWD_X3_256, BWD_X3_256_EXT, BWD_STATIC_256, BWD_STATIC_128, BWD_TRAIN_256_FULL,
+enum { BWD_X6_256 = 0, BWD_X6_256_EXT, BWD_X6_128, BWD_X3_256, BWD_X3_256_EXT, BWD_X3_128, BWD_STATIC_256, BWD_STATIC_128, BWD_TRAIN_256_FULL,
        BWD_TRAIN_256_STATIC, BWD_TRAIN_128_FULL, BWD_TRAIN_128_STATIC };
 int nefes_bwd_launch_part1(int which, const FieldBwdArgs& a, hipStream_t st);
 int nefes_bwd_launch_part2(int which, const FieldBwdArgs& a, hipStream_t st);
@@ -300,6 +300,7 @@ int nefes_bwd_launch_part2(int which, const FieldBwdArgs& a, hipStream_t st) {
     switch (which) {
         case BWD_X3_256: return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 3>(a, st);
         case BWD_X3_256_EXT: return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32, 3>(a, st);
+        case BWD_X3_128: return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 3>(a, st);
         case BWD_STATIC_256: return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 0, false>(a, st);
         case BWD_STATIC_128: return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 0, false>(a, st);
     }
@@ -359,7 +360,8 @@ static int field_bwd_impl(int x6, bool full, float* dacts, const NefesNetDesc* d
         if (desc->width == 128 && desc->feat_dim == 128 && !ext) return nefes_bwd_launch_part2(BWD_STATIC_128, a, st);
         return NEFES_E_UNSUPPORTED;
     }
-    if (x6 == 3) {   // three-product instances: the headline shape only
+    if (x6 == 3) {   // three-product instances
+        if (desc->width == 128 && desc->feat_dim == 128 && !ext) return nefes_bwd_launch_part2(BWD_X3_128, a, st);
         if (desc->width == 256 && desc->feat_dim == 16 && !ext) return nefes_bwd_launch_part2(BWD_X3_256, a, st);
         if (desc->width == 256 && desc->feat_dim == 16 && ext) return nefes_bwd_launch_part2(BWD_X3_256_EXT, a, st);
         return NEFES_E_UNSUPPORTED;

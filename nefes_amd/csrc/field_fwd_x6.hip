@@ -234,7 +234,8 @@ static int launch_x6(const FieldFwdX6Args& a, hipStream_t st) {
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { FWD_EXT_SIGMA = 0, FWD_EXT_FULL, FWD_128_SIGMA, FWD_128_FULL, FWD_X3_SIGMA, FWD_X3_FULL, FWD_X3_EXT_SIGMA, FWD_X3_EXT_FULL };
+enum { FWD_EXT_SIGMA = 0, FWD_EXT_FULL, FWD_128_SIGMA, FWD_128_FULL, FWD_X3_SIGMA, FWD_X3_FULL, FWD_X3_EXT_SIGMA, FWD_X3_EXT_FULL,
+       FWD_X3_128_SIGMA, FWD_X3_128_FULL };
 int nefes_fwd_x6_launch_part1(int which, const FieldFwdX6Args& a, hipStream_t st);
 int nefes_fwd_x6_launch_part2(int which, const FieldFwdX6Args& a, hipStream_t st);
 
@@ -255,6 +256,8 @@ int nefes_fwd_x6_launch_part2(int which, const FieldFwdX6Args& a, hipStream_t st
         case FWD_X3_FULL: return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 256, 1, 3>(a, st);
         case FWD_X3_EXT_SIGMA: return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32, 256, 1, 3>(a, st);
         case FWD_X3_EXT_FULL: return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32, 256, 1, 3>(a, st);
+        case FWD_X3_128_SIGMA: return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5, 3>(a, st);
+        case FWD_X3_128_FULL: return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5, 3>(a, st);
     }
     return NEFES_E_UNSUPPORTED;
 }
@@ -284,14 +287,10 @@ static int field_fwd_x6_impl(int np, const NefesNetDesc* desc, const void* packe
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
-    if (np == 3) {   // three-product instances: the headline shape only
-        if (!big) return NEFES_E_UNSUPPORTED;
-        if (ext) {
-            if (mode == NEFES_FIELD_SIGMA) return nefes_fwd_x6_launch_part2(FWD_X3_EXT_SIGMA, a, st);
-            return nefes_fwd_x6_launch_part2(FWD_X3_EXT_FULL, a, st);
-        }
-        if (mode == NEFES_FIELD_SIGMA) return nefes_fwd_x6_launch_part2(FWD_X3_SIGMA, a, st);
-        return nefes_fwd_x6_launch_part2(FWD_X3_FULL, a, st);
+    if (np == 3) {   // three-product instances
+        if (small) return nefes_fwd_x6_launch_part2(mode == NEFES_FIELD_SIGMA ? FWD_X3_128_SIGMA : FWD_X3_128_FULL, a, st);
+        if (ext) return nefes_fwd_x6_launch_part2(mode == NEFES_FIELD_SIGMA ? FWD_X3_EXT_SIGMA : FWD_X3_EXT_FULL, a, st);
+        return nefes_fwd_x6_launch_part2(mode == NEFES_FIELD_SIGMA ? FWD_X3_SIGMA : FWD_X3_FULL, a, st);
     }
     if (small) {
         if (mode == NEFES_FIELD_SIGMA) return nefes_fwd_x6_launch_part1(FWD_128_SIGMA, a, st);

@@ -220,14 +220,15 @@ def field_fwd(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, pts
 # tests/test_gpu_x6.py).  Set False (or NEFES_X6=0) for the plain fp32-MFMA kernels.
 USE_X6 = os.environ.get("NEFES_X6", "1") != "0"
 # Number of cross products of the split: 6 (default: fp32-level accuracy) or 3 (opt-in, NEFES_X6_PRODUCTS=3: operands carried
-# to 16 bits, ~5e-6 of the output scale, half the matrix-core work; width 256 / C = 16 only -- nefes_field_fwd_x3 / _bwd_x3).
+# to 16 bits, ~5e-6 of the output scale, half the matrix-core work; the shapes with bf16x6 instances -- nefes_field_fwd_x3 / _bwd_x3).
 X6_PRODUCTS = int(os.environ.get("NEFES_X6_PRODUCTS", "6"))
 
 
 def _x3(pk):
     if X6_PRODUCTS not in (3, 6):
         raise ValueError("nefes_amd.ops.X6_PRODUCTS must be 6 or 3")
-    return X6_PRODUCTS == 3 and pk.width == 256 and pk.feat_dim == 16
+    return X6_PRODUCTS == 3 and ((pk.width == 256 and pk.feat_dim == 16) or
+                                 (pk.width == 128 and pk.feat_dim == 128 and pk.xyz_encoding == L.XYZ_FREQ10))
 
 
 def x6_supported(pk: PackedField, mode, forward=True):
