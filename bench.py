@@ -186,6 +186,29 @@ def train_steps(dev, steps=10, warmup=2):
     return dt, H * W, kern, [float(l) for l in (losses[0], losses[-1])], cpu
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child and return its exit code."""
+    import socket
+    import subprocess
+    one_gpu = os.environ.get("NEFES_BENCH_ONE_GPU", "0") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not one_gpu:
+        print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible; refusing to run fewer ranks than asked "
+              f"(NEFES_BENCH_ONE_GPU=1 NEFES_BENCH_BACKEND=gloo runs all ranks on cuda:0 as a functional check)",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,8 +220,16 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["loop50", "train"], default="metric")
     a = ap.parse_args()
 
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # Not started by a launcher: start the N ranks ourselves (one process per GPU) and relay rank 0's JSON line.
+        # This parent makes no GPU call (torch.cuda.device_count() does not initialise the runtime on this image).
+        raise SystemExit(self_launch(a.gpus))
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # NEFES_BENCH_ONE_GPU=1 + NEFES_BENCH_BACKEND=gloo: functional test of the N>1 path on a single-GPU box (every rank on
@@ -333,7 +364,8 @@ def main():
         out = {
             "metric": "rays/s (fwd+bwd) at 640x480x(64+128) samples, 8x256 MLP" if a.workload == "metric"
                       else f"rays/s (fwd+bwd), secondary workload '{a.workload}'", "value": value, "unit": "rays/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1,
+            "collective_backend": (dist.get_backend() if world > 1 else None), "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16x3 (16-bit operands, NOT the headline precision)" if x3 else "f32",
             "data": "synthetic",
             "config": {"workload": f"{wl['name']}; {W}x{H}, random seed-0 weights, fwd + bwd to the 3x4 pose",

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEFES_ABI_VERSION 6
+#define NEFES_ABI_VERSION 7
 
 #define NEFES_E_BADARG (-1)     /* null pointer / non-positive size */
 #define NEFES_E_UNSUPPORTED (-2) /* width / feat_dim / sample count outside the compiled set */
@@ -110,6 +110,10 @@ int nefes_ndc_bwd(int H, int W, float focal, float near, int n, const float* ray
  * caller-supplied t_rand[N,Nc] (rendering.py:96-112).  t: dev [Nc] = torch.linspace(0,1,Nc). */
 int nefes_coarse_depths(int N, int Nc, float near, float far, int lindisp, const float* t, const float* t_rand,
                         float* z, void* stream);
+/* same with per-ray bounds, as render_rays reads them from the packed ray batch (rendering.py:90-93, columns 6:8 of
+ * the [n, 8+3+hist] batch built at :227-235): near = bounds[ray*stride], far = bounds[ray*stride + 1] (dev, floats). */
+int nefes_coarse_depths_rays(int N, int Nc, const float* bounds, int stride, int lindisp, const float* t,
+                             const float* t_rand, float* z, void* stream);
 
 /* ---- field MLP (nerfh_nff.py:168-231 run_network + :234-270 Embedder + :525-576 forward) ------- */
 /* Either (rays_o, rays_d, z) are given and pts = o + d*z is formed in-kernel (rendering.py:114,142),

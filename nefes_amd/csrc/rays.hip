@@ -186,11 +186,19 @@ extern "C" int nefes_ndc_bwd(int H, int W, float focal, float near, int n, const
 }
 
 // ---- coarse depths (rendering.py:96-112) ---------------------------------------------------------
-__global__ __launch_bounds__(256) void coarse_depths_kernel(int N, int Nc, float near, float far, int lindisp,
-                                                            const float* __restrict__ t, const float* t_rand, float* z) {
+// bounds != null: near/far are read per ray from bounds[ray*stride + 0/1] (the [n,21] ray batch of rendering.py:227-235,
+// columns 6:8), as render_rays does (:90-100); otherwise the scalars apply to every ray.
+__global__ __launch_bounds__(256) void coarse_depths_kernel(int N, int Nc, float near, float far, const float* __restrict__ bounds,
+                                                            int stride, int lindisp, const float* __restrict__ t,
+                                                            const float* t_rand, float* z) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)N * Nc) return;
     const int k = (int)(i % Nc);
+    if (bounds) {
+        const size_t ray = i / Nc;
+        near = bounds[ray * stride];
+        far = bounds[ray * stride + 1];
+    }
     auto zk = [&](int kk) {
         const float tt = t[kk];
         if (!lindisp) return __fadd_rn(__fmul_rn(near, __fsub_rn(1.f, tt)), __fmul_rn(far, tt));
@@ -209,7 +217,15 @@ extern "C" int nefes_coarse_depths(int N, int Nc, float near, float far, int lin
     if (!t || !z || N <= 0 || Nc <= 0) return NEFES_E_BADARG;
     const size_t n = (size_t)N * Nc;
     hipLaunchKernelGGL(coarse_depths_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, Nc, near,
-                       far, lindisp, t, t_rand, z);
+                       far, (const float*)nullptr, 0, lindisp, t, t_rand, z);
+    return (int)hipGetLastError();
+}
+extern "C" int nefes_coarse_depths_rays(int N, int Nc, const float* bounds, int stride, int lindisp, const float* t,
+                                        const float* t_rand, float* z, void* stream) {
+    if (!t || !z || !bounds || stride < 2 || N <= 0 || Nc <= 0) return NEFES_E_BADARG;
+    const size_t n = (size_t)N * Nc;
+    hipLaunchKernelGGL(coarse_depths_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, Nc, 0.f,
+                       0.f, bounds, stride, lindisp, t, t_rand, z);
     return (int)hipGetLastError();
 }
 

@@ -116,9 +116,14 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(int N, int Nc, in
             if (ordered) {
                 rank = i < Nc ? i + count_less(all + Nc, Ni, v) : (i - Nc) + count_less_equal(all, Nc, v);
             } else {
+                // torch.sort order: numbers ascending, NaNs last, ties (and NaNs among themselves) by index: every slot of
+                // z_fine is written exactly once whatever the values are
+                const bool v_nan = v != v;
                 for (int k = 0; k < S; ++k) {
                     const float o = all[k];
-                    rank += (o < v || (o == v && k < i)) ? 1 : 0;
+                    const bool o_nan = o != o;
+                    const bool before = v_nan ? (!o_nan || k < i) : (!o_nan && (o < v || (o == v && k < i)));
+                    rank += before ? 1 : 0;
                 }
             }
             z_fine[(size_t)ray * S + rank] = v;

@@ -34,7 +34,11 @@ class _PoseGradAllReduce(torch.autograd.Function):
 
 def replicate_pose(c2w: torch.Tensor, group=None) -> torch.Tensor:
     """Identity in forward; all-reduces the pose gradient in backward.  Wrap the pose once per iteration,
-    render this rank's rows from the result, and every rank ends up with the full d loss / d c2w."""
+    render this rank's rows from the result, and every rank ends up with the full d loss / d c2w.
+
+    The all-reduce is a SUM of the ranks' gradients: a per-rank loss must therefore be normalised by the size of the
+    FULL frame (e.g. `(rgb**2).sum() / (H*W*3)`), not by the local row count -- a local `mean()` would weight the
+    ranks' rays by world_size and mis-scale the pose gradient.  Every rank must run backward (the collective is in it)."""
     return _PoseGradAllReduce.apply(c2w, group)
 
 
@@ -45,22 +49,36 @@ def render_sharded(render_fn, H, W, focal, c2w, rank=None, world=None, group=Non
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
     row0, nrows = row_shard(H, rank, world)
-    return render_fn(H, W, focal, c2w=replicate_pose(c2w, group), row_range=(row0, nrows), **kw)
+    pose = replicate_pose(c2w, group)
+    if nrows == 0:
+        # more ranks than image rows: this rank renders nothing, but its (zero) loss must still reach the pose so that its
+        # backward takes part in the all-reduce
+        z = (pose.sum() * 0.).reshape(1, 1)
+        C = getattr(kw.get("network_fn", None), "W_features", 0)
+        return [z.expand(0, 3), z.expand(0, 1)[:, 0], z.expand(0, 1)[:, 0], {"feat_map": z.expand(0, C)}]
+    return render_fn(H, W, focal, c2w=pose, row_range=(row0, nrows), **kw)
 
 
-def gather_maps(local: torch.Tensor, H: int, group=None) -> torch.Tensor:
+def gather_maps(local: torch.Tensor, H: int, group=None, W: int = None) -> torch.Tensor:
     """all_gather of per-rank [rows*W, C] maps into the full image order (for whole-image losses).
-    Differentiable: the backward hands each rank the slice of the gradient that belongs to its rows."""
+    Differentiable: the backward hands each rank the slice of the gradient that belongs to its rows.
+    `W` (image width) is needed only when some rank may own zero rows (world_size > H)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
-    return _GatherRows.apply(local, H, group)
+    return _GatherRows.apply(local, H, group, W)
 
 
 class _GatherRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, local, H, group):
+    def forward(ctx, local, H, group, W=None):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        per_row = local.shape[0] // row_shard(H, rank, world)[1]
+        mine = row_shard(H, rank, world)[1]
+        if W is not None:
+            per_row = int(W)
+        elif mine > 0:
+            per_row = local.shape[0] // mine
+        else:
+            raise ValueError("nefes_amd.dist.gather_maps: this rank owns no image rows (world_size > H); pass W=<image width>")
         sizes = [row_shard(H, r, world)[1] * per_row for r in range(world)]
         bufs = [local.new_empty((s,) + tuple(local.shape[1:])) for s in sizes]
         dist.all_gather(bufs, local.contiguous(), group=group) if len(set(sizes)) == 1 else \
@@ -72,4 +90,4 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         off, n = ctx.slice
-        return g[off:off + n].contiguous(), None, None
+        return g[off:off + n].contiguous(), None, None, None

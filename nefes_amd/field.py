@@ -10,6 +10,8 @@ The per-sample evaluation on the render path is NOT torch: `run_network_NeRFH_NF
 `NeRFH_NFF.forward` (pre-embedded inputs, the nn.Module API) is kept in torch only so that code
 which calls the module directly keeps working; nothing on the render path calls it.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -118,8 +120,16 @@ class NeRFH_NFF(nn.Module):
         return (self.D == 8 and self.skips == [4] and self.in_channels_xyz in (63, 32) and self.in_channels_dir == 27
                 and self.W in (128, 256) and self.out_ch_size != 3)
 
+    def invalidate_packed(self):
+        """Force a re-pack on the next render.  The cache key is (data_ptr, _version, device) per parameter, which sees
+        optimizer steps, load_state_dict and no_grad in-place ops on the parameter itself -- but NOT edits made through
+        `.data` (`p.data.mul_()`, `p.data.copy_()`, EMA / clipping code): those leave both unchanged.  Call this after
+        such an edit (a captured PoseRefiner graph must be re-captured as well)."""
+        self._pk_key = None
+
     def packed(self) -> ops.PackedField:
-        """Fragment streams for the fused kernels; re-packed when any path parameter changes."""
+        """Fragment streams for the fused kernels; re-packed when any path parameter changes (see invalidate_packed for
+        the one kind of change this cannot see)."""
         if not self._supported():
             raise RuntimeError("nefes_amd: the HIP field kernels are built for D=8, skips=[4], 63/27 encodings, "
                                "W in {128,256} and a feature head (f_dim>0); got an unsupported NeRFH_NFF configuration")
@@ -127,6 +137,8 @@ class NeRFH_NFF(nn.Module):
         sd = dict(self.named_parameters())
         prm = [sd[n + s] for n in names for s in (".weight", ".bias")]
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in prm)
+        if os.environ.get("NEFES_DEBUG_PACK_CHECKSUM", "0") == "1":      # debug: also key on the values (one sync per call)
+            key += (float(sum(p.detach().double().sum() for p in prm)),)
         if self._pk is not None and key != self._pk_key and all(p.is_cuda and p.device == self._pk.blob.device for p in prm):
             self._pk.repack(prm)          # same network, new values (an optimizer step): re-packed on the device
             self._pk_key = key

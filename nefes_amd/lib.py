@@ -31,7 +31,7 @@ class NefesHashGridDesc(C.Structure):
                 ("base_resolution", C.c_int32), ("per_level_scale", C.c_float), ("bound", C.c_float)]
 
 
-ABI_VERSION = 6        # NEFES_ABI_VERSION of include/nefes_hip.h
+ABI_VERSION = 7        # NEFES_ABI_VERSION of include/nefes_hip.h
 STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6, STREAM_BWD_FULL_X6, STREAM_BWD_STATIC = 0, 1, 2, 3, 4, 5, 6, 7
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
 XYZ_FREQ10, XYZ_EXTERNAL32 = 0, 1
@@ -55,6 +55,7 @@ SIGNATURES = {
     "nefes_ndc_fwd": (_i, [_i, _i, _f, _f, _i, _p, _p, _p, _p, _p]),
     "nefes_ndc_bwd": (_i, [_i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_coarse_depths": (_i, [_i, _i, _f, _f, _i, _p, _p, _p, _p]),
+    "nefes_coarse_depths_rays": (_i, [_i, _i, _p, _i, _i, _p, _p, _p, _p]),
     "nefes_field_mask_bytes": (_sz, [_desc, C.c_int64]),
     "nefes_field_fwd": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_bwd": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -131,10 +131,20 @@ class NdcRays(torch.autograd.Function):
         return go.reshape(shape), gd.reshape(shape), None, None, None, None
 
 
-def coarse_depths(N, Nc, near, far, lindisp=False, t_rand=None, device="cuda"):
+def coarse_depths(N, Nc, near, far, lindisp=False, t_rand=None, device="cuda", bounds=None):
+    """rendering.py:95-112.  `bounds` = a float32 CUDA tensor whose rows start with (near, far) per ray (any row stride,
+    e.g. columns 6:8 of the reference's packed ray batch); then the scalars are ignored."""
     t = torch.linspace(0., 1., steps=Nc, device=device)            # rendering.py:95 (torch's own two-sided formula)
     z = torch.empty(N, Nc, device=device)
     t_rand = None if t_rand is None else _f32(t_rand)
+    if bounds is not None:
+        if not (bounds.is_cuda and bounds.dtype == torch.float32 and bounds.dim() == 2 and bounds.shape[0] == N
+                and bounds.shape[1] >= 2 and bounds.stride(1) == 1):
+            raise RuntimeError("nefes_amd: `bounds` must be a float32 CUDA tensor [N, >=2] with unit column stride")
+        L.check(L.load().nefes_coarse_depths_rays(N, Nc, C.c_void_p(bounds.data_ptr()), int(bounds.stride(0)),
+                                                  int(bool(lindisp)), _chk(t, "t"), _chk(t_rand, "t_rand"), _chk(z, "z"),
+                                                  _stream()), "nefes_coarse_depths_rays")
+        return z
     L.check(L.load().nefes_coarse_depths(N, Nc, float(near), float(far), int(bool(lindisp)), _chk(t, "t"),
                                          _chk(t_rand, "t_rand"), _chk(z, "z"), _stream()), "nefes_coarse_depths")
     return z

@@ -9,8 +9,10 @@ Kernel sequence of one render() at test time (perturb=0, test_time=True; SURVEY.
     sample_pdf_merge                             -> z_fine [N,Nc+Ni]
     FieldFromRays FULL (fine net, masks saved)   -> raw_t [N,R,S]                      [grad -> rays]
     Composite variant A/B                        -> rgb, feat, disp, acc               [grad -> raw_t]
-The ray batch is processed in one launch per kernel (no Python chunk loop; `chunk`/`netchunk`
-are accepted and only bound the internal batch when memory would not allow one launch).
+The ray batch is processed in one launch per kernel (no Python chunk loop over 32 768-ray chunks as in
+rendering.py:182-195): the batch is split only when its intermediates (raw_t, its gradient, the ReLU masks, train-mode
+activations) would not fit the free device memory -- see `rays_per_launch` -- or at MAX_RAYS_PER_LAUNCH.  `netchunk` is
+accepted and ignored (the fused kernel tiles internally).
 """
 import types
 
@@ -21,6 +23,27 @@ from . import ops
 
 _DEV = "cuda"
 MAX_RAYS_PER_LAUNCH = 1 << 22
+MEMORY_FRACTION = 0.6          # share of the free device memory one launch sequence may plan for
+
+
+def rays_per_launch(cfg, network_fn, network_fine, device, train=False):
+    """Largest ray count whose per-launch intermediates fit: per ray and fine sample 2 x R floats (raw_t and its gradient),
+    the 1-bit ReLU masks, d pts / d viewdirs, and in train mode the saved pre-activations (layout.h row map); plus the
+    depth / weight rows.  Bounded by MAX_RAYS_PER_LAUNCH."""
+    net = network_fine if (network_fine is not None and cfg.N_importance > 0) else network_fn
+    S = cfg.N_samples + cfg.N_importance if not cfg.use_fine_only or cfg.N_importance == 0 else cfg.N_importance
+    Wd, C = net.W, net.W_features
+    R = 3 + C + 6
+    per_sample = 2 * R * 4 + (8 * (Wd // 64) + 4 * (Wd // 128)) * 4 * 2 + 24 + 16
+    if train:
+        per_sample += 4 * (64 + 32 + 9 * Wd + 2 * Wd + 32 * ((3 + C + 31) // 32) + 64) * 2
+    per_ray = per_sample * S + (cfg.N_samples * 4) * 4 + 256
+    try:
+        free, _ = torch.cuda.mem_get_info(device)
+        free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)      # cached blocks are reusable
+    except Exception:
+        return MAX_RAYS_PER_LAUNCH
+    return int(max(1024, min(MAX_RAYS_PER_LAUNCH, (free * MEMORY_FRACTION) // per_ray)))
 
 
 def _cfg(kwargs):
@@ -45,8 +68,9 @@ def _field(pk, mode, rays_o, rays_d, viewdirs, z, xyz_encoder):
     return ops.FieldFromEncoding.apply(xyz_encoder(pts), viewdirs, pk, mode)
 
 
-def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, cfg):
-    """rendering.py:88-180 for n rays already on the GPU.  Returns the reference's `ret` dict."""
+def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, cfg, bounds=None):
+    """rendering.py:88-180 for n rays already on the GPU.  Returns the reference's `ret` dict.
+    `bounds` ([n, >=2] rows starting with near, far) overrides the scalars, as the packed ray batch does (:90-93)."""
     N = rays_o.shape[0]
     dev = rays_o.device
     Nc, Ni = cfg.N_samples, cfg.N_importance
@@ -67,7 +91,7 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
         return _field(pk, mode, rays_o, rays_d, viewdirs, z_, cfg.xyz_encoder)
 
     t_rand = torch.rand(N, Nc, device=dev) if cfg.perturb > 0. else None            # :110 (RNG stays in torch)
-    z = ops.coarse_depths(N, Nc, near, far, cfg.lindisp, t_rand, device=dev)
+    z = ops.coarse_depths(N, Nc, near, far, cfg.lindisp, t_rand, device=dev, bounds=bounds)
     store_rgb = (Ni == 0)
     pk_c = network_fn.packed()
     C = pk_c.feat_dim
@@ -126,24 +150,50 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
 def render_rays(ray_batch, network_fn, network_query_fn=None, N_samples=64, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False,
                 i_epoch=-1, embedding_a=None, embedding_t=None, test_time=False, args=None, volume=None):
-    """Reference signature (rendering.py:68-86) on a packed [n, 8+3(+hist)] ray batch."""
-    ray_batch = ray_batch.to(_DEV)
+    """Reference signature (rendering.py:68-86) on a packed [n, 8+3(+hist)] ray batch: columns 0:3 origins, 3:6
+    directions, 6:8 per-ray near/far (read on the device, no host sync), 8:11 view directions, 11: histogram (unused by
+    the field, as in the reference where `ts` never reaches NeRFH_NFF.forward)."""
+    if ray_batch.shape[-1] < 11:
+        raise NotImplementedError("nefes_amd: the NeFeS field always uses view directions (ray batch needs >= 11 columns)")
+    ray_batch = ray_batch.to(_DEV, torch.float32)
     rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
     viewdirs = ray_batch[:, 8:11].contiguous()
-    near, far = float(ray_batch[0, 6]), float(ray_batch[0, 7])     # constant columns (rendering.py:227)
     cfg = _cfg(dict(N_samples=N_samples, N_importance=N_importance, perturb=perturb, lindisp=lindisp,
                     white_bkgd=white_bkgd, raw_noise_std=raw_noise_std, test_time=test_time, args=args))
-    return _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, cfg)
+    return _render_core(rays_o, rays_d, viewdirs, 0., 0., network_fn, network_fine, cfg, bounds=ray_batch[:, 6:8])
+
+
+def _cat_parts(outs):
+    return outs[0] if len(outs) == 1 else {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
 
 
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
-    """Reference signature (rendering.py:182-195).  One launch unless the batch exceeds MAX_RAYS_PER_LAUNCH."""
-    step = max(int(chunk), MAX_RAYS_PER_LAUNCH)
-    parts = {}
-    for i in range(0, rays_flat.shape[0], step):
-        for k, v in render_rays(rays_flat[i:i + step], **kwargs).items():
-            parts.setdefault(k, []).append(v)
-    return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in parts.items()}
+    """Reference signature (rendering.py:182-195).  The reference's `chunk` exists to bound memory; here that bound is
+    computed from the free device memory (rays_per_launch) and the batch is split only when it would not fit."""
+    cfg = _cfg(dict(kwargs, N_samples=kwargs.get("N_samples", 64)))
+    rays_flat = rays_flat.to(_DEV)
+    step = rays_per_launch(cfg, kwargs["network_fn"], kwargs.get("network_fine", None), rays_flat.device,
+                           train=not cfg.test_time)
+    return _cat_parts([render_rays(rays_flat[i:i + step], **kwargs) for i in range(0, rays_flat.shape[0], step)])
+
+
+def _rays_for(H, W, focal, c2w, c2w_staticcam, row_range):
+    row0, nrows = (0, H) if row_range is None else row_range
+    rays_o, rays_d, viewdirs = ops.RayGen.apply(c2w.to(_DEV), H, W, float(focal), row0, nrows)
+    if c2w_staticcam is not None:                                   # rays of the static camera, view directions of c2w (:211-216)
+        rays_o, rays_d, _ = ops.RayGen.apply(c2w_staticcam.to(_DEV), H, W, float(focal), row0, nrows)
+    return rays_o, rays_d, viewdirs
+
+
+def _render_batch(rays_o, rays_d, viewdirs, near, far, chunk, kwargs, cfg):
+    network_fn, network_fine = kwargs["network_fn"], kwargs.get("network_fine", None)
+    N = rays_o.shape[0]
+    step = rays_per_launch(cfg, network_fn, network_fine, rays_o.device, train=not cfg.test_time)
+    outs = []
+    for i in range(0, N, step):
+        sl = slice(i, min(N, i + step))
+        outs.append(_render_core(rays_o[sl], rays_d[sl], viewdirs[sl], float(near), float(far), network_fn, network_fine, cfg))
+    return _cat_parts(outs)
 
 
 def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
@@ -153,29 +203,40 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
     if not use_viewdirs:
         raise NotImplementedError("nefes_amd: the NeFeS field always uses view directions (use_viewdirs=True)")
     cfg = _cfg(kwargs)
-    network_fn, network_fine = kwargs["network_fn"], kwargs.get("network_fine", None)
     if c2w is not None:
-        c2w = c2w.to(_DEV)
-        row0, nrows = (0, H) if row_range is None else row_range
-        rays_o, rays_d, viewdirs = ops.RayGen.apply(c2w, H, W, float(focal), row0, nrows)
-        if c2w_staticcam is not None:
-            rays_o, rays_d, _ = ops.RayGen.apply(c2w_staticcam.to(_DEV), H, W, float(focal), row0, nrows)
+        rays_o, rays_d, viewdirs = _rays_for(int(H), int(W), focal, c2w, c2w_staticcam, row_range)
     else:
         rays_o, rays_d = rays
         rays_o, rays_d = rays_o.to(_DEV).reshape(-1, 3).float(), rays_d.to(_DEV).reshape(-1, 3).float()
         viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)             # caller-supplied rays: torch glue
         if c2w_staticcam is not None:
-            rays_o, rays_d, _ = ops.RayGen.apply(c2w_staticcam.to(_DEV), H, W, float(focal), 0, H)
+            rays_o, rays_d, _ = ops.RayGen.apply(c2w_staticcam.to(_DEV), int(H), int(W), float(focal), 0, int(H))
     if ndc:
         rays_o, rays_d = ops.NdcRays.apply(rays_o, rays_d, H, W, float(focal), 1.)
-    N = rays_o.shape[0]
-    outs = []
-    for i in range(0, N, MAX_RAYS_PER_LAUNCH):
-        sl = slice(i, min(N, i + MAX_RAYS_PER_LAUNCH))
-        outs.append(_render_core(rays_o[sl], rays_d[sl], viewdirs[sl], float(near), float(far), network_fn, network_fine, cfg))
-    all_ret = outs[0] if len(outs) == 1 else {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+    all_ret = _render_batch(rays_o, rays_d, viewdirs, near, far, chunk, kwargs, cfg)
     k_extract = ["rgb_map", "disp_map", "acc_map"]
     return [all_ret[k] for k in k_extract] + [{k: v for k, v in all_ret.items() if k not in k_extract}]
+
+
+def render_poses(H, W, focal, poses, chunk=1024 * 32, ndc=True, near=0., far=1., use_viewdirs=False, **kwargs):
+    """Several camera poses in ONE launch sequence (the reference's render_path loops render() per
+    pose, rendering.py:270-273): rays of all B poses are generated (one small kernel per pose) and concatenated, then
+    every heavy kernel -- coarse field, compositing, sampling, fine field, compositing -- runs once over B*H*W rays.
+    poses [B,3,4] (or [B,4,4]).  Returns [rgb [B,H*W,3], disp [B,H*W], acc [B,H*W], extras {k: [B,H*W,...]}];
+    differentiable w.r.t. `poses` like render()."""
+    if not use_viewdirs:
+        raise NotImplementedError("nefes_amd: the NeFeS field always uses view directions (use_viewdirs=True)")
+    cfg = _cfg(kwargs)
+    H, W = int(H), int(W)
+    B = poses.shape[0]
+    parts = [_rays_for(H, W, focal, poses[b, :3, :4], None, None) for b in range(B)]
+    rays_o, rays_d, viewdirs = (torch.cat([p[k] for p in parts], 0) for k in range(3))
+    if ndc:
+        rays_o, rays_d = ops.NdcRays.apply(rays_o, rays_d, H, W, float(focal), 1.)
+    all_ret = _render_batch(rays_o, rays_d, viewdirs, near, far, chunk, kwargs, cfg)
+    shp = lambda v: v.reshape(B, H * W, *v.shape[1:])
+    k_extract = ["rgb_map", "disp_map", "acc_map"]
+    return [shp(all_ret[k]) for k in k_extract] + [{k: shp(v) for k, v in all_ret.items() if k not in k_extract}]
 
 
 def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
