@@ -50,11 +50,14 @@ typedef struct NefesStreamInfo {
     uint32_t n_slabs;    /* 32 KiB each (nefes_amd/csrc/layout.h: NEFES_FWD_SLAB_KIB / NEFES_BWD_SLAB_KIB) */
     uint32_t bias_floats;
     uint64_t bias_off;   /* bias block (fp32, natural row order per layer); 0 if none */
+    uint32_t scale_off;  /* _H3 streams: word index, inside the bias block, of the weight-scale exponent table (int32 per
+                            segment in stream order: the segment's weights are stored multiplied by 2^e); counted in bias_floats */
+    uint32_t scale_count;
 } NefesStreamInfo;
 
 typedef struct NefesBlobInfo {
     uint64_t total_bytes;
-    NefesStreamInfo stream[8]; /* indexed by NEFES_STREAM_* in csrc/layout.h; n_slabs == 0 if absent */
+    NefesStreamInfo stream[11]; /* indexed by NEFES_STREAM_* in csrc/layout.h; n_slabs == 0 if absent */
 } NefesBlobInfo;
 
 /* compositing variants of raw2outputs_NeRFH_NFF (script/models/nerfh_nff.py:25-166) */

@@ -76,14 +76,32 @@ NEFES_HD int nefes_segment_slabs(int nt, int ks, int slab_frags) {
 // stream kinds inside a packed blob
 // _X6 streams: trunk layers 2..8 as bf16x6 split products (v_mfma_f32_32x32x16_bf16 on exact hi/mid/lo bf16 triples, six
 // cross terms: fp32-level accuracy), everything else as in the fp32 stream; 48 KiB slabs = 16 units of 3 KiB.
+// _H3 streams: every product of the forward pass and the hidden products of the backward pass as fp16 two-part split
+// products (v_mfma_f32_32x32x16_f16 on (hi, lo) fp16 pairs of power-of-two scaled operands, three cross terms hh + hl + lh:
+// fp32-level accuracy at half the matrix-core work of bf16x6; field_h3.h); units of 2 KiB = hi | lo A operands; the
+// per-segment weight-scale exponents ride behind the bias blocks (NefesStreamInfo.scale_off).
 enum { NEFES_STREAM_FWD_SIGMA = 0, NEFES_STREAM_FWD_STATIC = 1, NEFES_STREAM_FWD_FULL = 2, NEFES_STREAM_BWD_FULL = 3,
        NEFES_STREAM_FWD_SIGMA_X6 = 4, NEFES_STREAM_FWD_FULL_X6 = 5, NEFES_STREAM_BWD_FULL_X6 = 6, NEFES_STREAM_BWD_STATIC = 7,
-       NEFES_N_STREAMS = 8 };
+       NEFES_STREAM_FWD_SIGMA_H3 = 8, NEFES_STREAM_FWD_FULL_H3 = 9, NEFES_STREAM_BWD_FULL_H3 = 10,
+       NEFES_N_STREAMS = 11 };
 #define NEFES_X6_SLAB_KIB 48
+#define NEFES_H3_FWD_SLAB_KIB 48       /* 24 units of 2 KiB */
+#define NEFES_H3_BWD_SLAB_KIB 32       /* 16 units */
+#define NEFES_H3_TARGET_EXP 14         /* operands are scaled so that the largest magnitude lies in [2^14, 2^15) */
 NEFES_HD int nefes_stream_slab_kib(int stream) {
     if (stream == NEFES_STREAM_BWD_FULL || stream == NEFES_STREAM_BWD_FULL_X6 || stream == NEFES_STREAM_BWD_STATIC) return NEFES_BWD_SLAB_KIB;
+    if (stream == NEFES_STREAM_BWD_FULL_H3) return NEFES_H3_BWD_SLAB_KIB;
+    if (stream == NEFES_STREAM_FWD_SIGMA_H3 || stream == NEFES_STREAM_FWD_FULL_H3) return NEFES_H3_FWD_SLAB_KIB;
     return stream >= NEFES_STREAM_FWD_SIGMA_X6 ? NEFES_X6_SLAB_KIB : NEFES_FWD_SLAB_KIB;
 }
+// Segment ordinals of the _H3 streams = index into the stream's weight-scale exponent table (pack.cpp emits one int32 per
+// segment, in stream order; fp32 segments carry 0).
+enum { NEFES_H3F_L1 = 0, NEFES_H3F_L2, NEFES_H3F_L3, NEFES_H3F_L4, NEFES_H3F_L5H, NEFES_H3F_L5E, NEFES_H3F_L6, NEFES_H3F_L7,
+       NEFES_H3F_L8, NEFES_H3F_SIG, NEFES_H3F_FINAL, NEFES_H3F_DT_H, NEFES_H3F_DT_D, NEFES_H3F_RGB, NEFES_H3F_T1, NEFES_H3F_T2,
+       NEFES_H3F_TH, NEFES_H3F_N };
+enum { NEFES_H3B_RGB = 0, NEFES_H3B_TH, NEFES_H3B_T2, NEFES_H3B_T1, NEFES_H3B_T0, NEFES_H3B_DIR, NEFES_H3B_FINAL, NEFES_H3B_SIG,
+       NEFES_H3B_L8, NEFES_H3B_L7, NEFES_H3B_L6, NEFES_H3B_L5, NEFES_H3B_L4, NEFES_H3B_L3, NEFES_H3B_L2, NEFES_H3B_L1,
+       NEFES_H3B_N };
 
 // ReLU-mask words (32 bit) written per lane per 32-sample tile by the full forward pass:
 // 8 trunk layers (W/64 words each) + dir + 3 transient layers (W/128 words each)

@@ -1,5 +1,6 @@
 // Host-side weight packer: NeRFH_NFF state_dict (torch [out,in] fp32) -> MFMA fragment streams.
 // See layout.h for the vocabulary.  Reference tensors: script/models/nerfh_nff.py:452-505.
+#include <math.h>
 #include <string.h>
 
 #include <vector>
@@ -20,6 +21,8 @@ struct Seg {
     int ld = 0;
     bool transposed = false;
     bool x6 = false;        // bf16x6 segment: fragments are bf16 triples (hi, mid, lo) for v_mfma_f32_32x32x16_bf16
+    bool h3 = false;        // fp16 two-part segment: (hi, lo) fp16 pairs of W * 2^wexp for v_mfma_f32_32x32x16_f16 (set with x6)
+    int wexp = 0;           // h3: power-of-two exponent the segment's weights are stored with
     float at(int s, int t, int lane) const {
         const int i = lane & 31, h = lane >> 5;
         const int r = ridx[t * 32 + i], k = kidx[s * 2 + h];
@@ -33,10 +36,11 @@ struct Seg {
         if (r < 0 || k < 0) return 0.f;
         return transposed ? W[(size_t)k * ld + r] : W[(size_t)r * ld + k];
     }
-    int units() const { return (ks / 8) * nt; }                       // x6: one unit = (k16-step, tile) = 3 KiB
+    int units() const { return (ks / 8) * nt; }                       // x6: one unit = (k16-step, tile) = 3 KiB; h3: 2 KiB
+    int unit_kib() const { return h3 ? 2 : 3; }
     int slabs(int slab_frags) const {
         if (!x6) return nefes_segment_slabs(nt, ks, slab_frags);
-        const int ups = (slab_frags / 4) / 3;
+        const int ups = (slab_frags / 4) / unit_kib();
         return (units() + ups - 1) / ups;
     }
 };
@@ -61,6 +65,45 @@ static void split_bf16x3(float w, uint16_t (&part)[3]) {
     }
 }
 
+// fp32 -> fp16 bits, round to nearest even, subnormals kept (what v_cvt_f16_f32 / v_fma_mixlo_f16 do in the kernels)
+static uint16_t rne_f16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));     // >= 2^16: inf / nan
+    if (x < 0x38800000u) {                                                                     // < 2^-14: subnormal or zero
+        float a;
+        memcpy(&a, &x, 4);
+        return (uint16_t)(sign | (uint32_t)nearbyintf(a * 16777216.0f));                        // units of 2^-24, ties to even
+    }
+    const uint32_t mant = x & 0x7fffffu, e = (x >> 23) - 112u;
+    uint32_t h = (e << 10) | (mant >> 13);
+    const uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;                                     // a carry walks into the exponent
+    return (uint16_t)(sign | h);
+}
+static float f16_value(uint16_t h) {
+    const int e = (h >> 10) & 31, m = h & 1023;
+    float v = e == 0 ? ldexpf((float)m, -24) : ldexpf((float)(1024 + m), e - 25);
+    return (h & 0x8000u) ? -v : v;
+}
+// w * 2^e = hi + lo (+ a remainder below 2^-22 of |w| 2^e): hi = RNE_f16(w 2^e), lo = RNE_f16(w 2^e - hi); the difference is
+// exact in fp32
+static void split_f16x2(float w, int e, uint16_t (&part)[2]) {
+    const float y = ldexpf(w, e);
+    part[0] = rne_f16(y);
+    part[1] = rne_f16(y - f16_value(part[0]));
+}
+// exponent e with max|w| * 2^e in [2^NEFES_H3_TARGET_EXP, 2^(NEFES_H3_TARGET_EXP+1))
+static int scale_exp(float amax) {
+    if (!(amax > 0.f) || !isfinite(amax)) return 0;
+    int e;
+    frexpf(amax, &e);                          // amax = m 2^e, m in [0.5, 1)
+    int r = NEFES_H3_TARGET_EXP + 1 - e;
+    return r < -60 ? -60 : (r > 60 ? 60 : r);
+}
+
 struct BiasBlk {
     const float* b;
     std::vector<int> ridx;  // [nt*32] index into b or -1
@@ -69,16 +112,19 @@ struct BiasBlk {
 struct Stream {
     std::vector<Seg> segs;
     std::vector<BiasBlk> bias;
+    bool h3 = false;        // carries a weight-scale exponent table (one int32 per segment) behind the bias blocks
     int n_slabs(int slab_frags) const {
         int n = 0;
         for (auto& s : segs) n += s.slabs(slab_frags);
         return n;
     }
-    int bias_floats() const {
+    int bias_only() const {
         int n = 0;
         for (auto& b : bias) n += (int)b.ridx.size();
         return n;
     }
+    int scale_count() const { return h3 ? ((int)segs.size() + 3) / 4 * 4 : 0; }
+    int bias_floats() const { return bias_only() + scale_count(); }
 };
 
 std::vector<int> rows_natural(int nt, int limit) {

@@ -40,6 +40,17 @@ class _timed:
         return False
 
 
+# Test tap: when TAP is a dict, the forward passes that save ReLU masks append (masks, N, S, width) under "masks" and the
+# hierarchical sampler appends its merged depths under "z_fine" -- so that a test can evaluate the float64 oracle on exactly
+# the samples and the ReLU branch pattern the kernels used (tests/branch.py).  Never set on the product path.
+TAP = None
+
+
+def _tap(key, value):
+    if TAP is not None:
+        TAP.setdefault(key, []).append(value)
+
+
 def _chk(t: Optional[torch.Tensor], name: str, dtype=torch.float32):
     if t is None:
         return None
@@ -222,6 +233,8 @@ def field_fwd(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, pts
                                      _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(xyz_enc, "xyz_enc"),
                                      _chk(viewdirs, "viewdirs"), _chk(raw_t, "raw_t"), _chk(masks, "masks", torch.int32),
                                      _stream()), "nefes_field_fwd")
+    if masks is not None:
+        _tap("masks", (masks, N, S, pk.width, mode))
     return raw_t, masks
 
 
@@ -262,6 +275,8 @@ def field_fwd_x6(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, 
                                             _chk(viewdirs, "viewdirs"),
                                             _chk(raw_t, "raw_t"), _chk(masks, "masks", torch.int32), _stream()),
                 "nefes_field_fwd_x6")
+    if masks is not None:
+        _tap("masks", (masks, N, S, pk.width, mode))
     return raw_t, masks
 
 
@@ -486,6 +501,8 @@ def sample_pdf_merge(z_coarse, weights, Ni, u=None, cdf=None, want_debug=False, 
                                             per_ray, _chk(cdf, "cdf"), _chk(z_fine, "z_fine"), _chk(z_samples, "z_samples"),
                                             _chk(inds, "inds", torch.int32), _chk(cdf_out, "cdf_out"), _stream()),
             "nefes_sample_pdf_merge")
+    _tap("z_fine", z_fine)
+    _tap("z_samples", z_samples)
     if want_debug:
         return z_fine, z_samples, inds, cdf_out
     return z_fine, z_samples

@@ -117,9 +117,15 @@ def make_field_params(typ: str, Wd: int = 256, C: int = 16, seed: int = 0, dtype
 
 
 def field_forward(p: Dict[str, Tensor], x: Tensor, sigma_only: bool = False, output_transient: bool = True,
-                  in_xyz: int = 63, in_dir: int = 27, D: int = 8, skip: int = 4) -> Tensor:
-    """NeRFH_NFF.forward on already-embedded inputs (nerfh_nff.py:525-576)."""
+                  in_xyz: int = 63, in_dir: int = 27, D: int = 8, skip: int = 4, act=None) -> Tensor:
+    """NeRFH_NFF.forward on already-embedded inputs (nerfh_nff.py:525-576).
+    `act` (tests only): callable (layer tag, pre-activation) -> activation replacing torch.relu for the hidden layers
+    ("L1".."L8", "DIR", "T0", "T1", "T2") -- used to record pre-activations and to evaluate the network on a GIVEN
+    ReLU branch pattern (the one a HIP forward pass took), where the function is smooth and gradients are comparable
+    to 1e-6 instead of being dominated by which side of a kink a rounding error lands on."""
     lin = lambda name, t: F.linear(t, p[name + ".weight"], p[name + ".bias"])
+    if act is not None:
+        return _field_forward_act(p, x, sigma_only, output_transient, in_xyz, in_dir, D, skip, act)
     if sigma_only:
         e_xyz = x
     else:
@@ -147,12 +153,40 @@ def field_forward(p: Dict[str, Tensor], x: Tensor, sigma_only: bool = False, out
     return torch.cat([static, t_rgb, t_sigma, t_beta], 1)               # :563,573-576
 
 
+def _field_forward_act(p, x, sigma_only, output_transient, in_xyz, in_dir, D, skip, act):
+    lin = lambda name, t: F.linear(t, p[name + ".weight"], p[name + ".bias"])
+    if sigma_only:
+        e_xyz = x
+    else:
+        e_xyz, e_dir = torch.split(x, [in_xyz, in_dir], dim=-1)
+    h = e_xyz
+    for i in range(D):
+        if i == skip:
+            h = torch.cat([e_xyz, h], 1)
+        h = act(f"L{i + 1}", lin(f"xyz_encoding_{i + 1}.0", h))
+    sigma = F.softplus(lin("static_sigma.0", h))
+    if sigma_only:
+        return sigma
+    feat = lin("xyz_encoding_final", h)
+    head_in = torch.cat([feat, e_dir], 1)
+    g = act("DIR", lin("dir_encoding.0", head_in))
+    static = torch.cat([lin("static_rgb.0", g), sigma], 1)
+    if not output_transient:
+        return static
+    t = act("T0", lin("transient_encoding.0", head_in))
+    t = act("T1", lin("transient_encoding.2", t))
+    t = act("T2", lin("transient_encoding.4", t))
+    return torch.cat([static, torch.sigmoid(lin("transient_rgb.0", t)), F.softplus(lin("transient_sigma.0", t)),
+                      F.softplus(lin("transient_beta.0", t))], 1)
+
+
 # --------------------------------------------------------------------------
 # a7: per-sample query with netchunk slicing   script/models/nerfh_nff.py:168-231
 # --------------------------------------------------------------------------
 def query_field(p: Dict[str, Tensor], pts: Tensor, viewdirs: Optional[Tensor], typ: str, output_transient: bool,
-                test_time: bool, netchunk: int = 1 << 21, n_freq_xyz: int = 10, n_freq_dir: int = 4) -> Tensor:
-    """run_network_NeRFH_NFF: [N,S,3] points (+ [N,3] view dirs) -> raw [N,S,R]."""
+                test_time: bool, netchunk: int = 1 << 21, n_freq_xyz: int = 10, n_freq_dir: int = 4, act=None) -> Tensor:
+    """run_network_NeRFH_NFF: [N,S,3] points (+ [N,3] view dirs) -> raw [N,S,R].
+    `act`: see field_forward (tests only; called as act(tag, preact, row0) with the first flat sample index of the slice)."""
     flat = pts.reshape(-1, 3)
     sigma_only = (typ == "coarse" and test_time)                        # :192-202
     if not sigma_only:
@@ -160,11 +194,12 @@ def query_field(p: Dict[str, Tensor], pts: Tensor, viewdirs: Optional[Tensor], t
     outs = []
     for i in range(0, flat.shape[0], netchunk):
         e = freq_encode(flat[i:i + netchunk], n_freq_xyz)
+        a = None if act is None else (lambda tag, pre, i=i: act(tag, pre, i))
         if sigma_only:
-            outs.append(field_forward(p, e, sigma_only=True))
+            outs.append(field_forward(p, e, sigma_only=True, act=a))
         else:
             ed = freq_encode(dirs[i:i + netchunk], n_freq_dir)
-            outs.append(field_forward(p, torch.cat([e, ed], 1), output_transient=output_transient))
+            outs.append(field_forward(p, torch.cat([e, ed], 1), output_transient=output_transient, act=a))
     out = torch.cat(outs, 0)
     return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
 
@@ -317,8 +352,10 @@ def coarse_depths(near: Tensor, far: Tensor, n: int, lindisp: bool, t_rand: Opti
 
 
 def render_rays(ray_batch: Tensor, p_coarse, p_fine, cfg: RenderCfg, t_rand: Optional[Tensor] = None,
-                u_rand: Optional[Tensor] = None, debug: Optional[dict] = None) -> Dict[str, Tensor]:
-    """rendering.py:68-180 for the nerfh_nff configuration."""
+                u_rand: Optional[Tensor] = None, debug: Optional[dict] = None, fine_act=None, z_fine=None) -> Dict[str, Tensor]:
+    """rendering.py:68-180 for the nerfh_nff configuration.
+    Tests only: `fine_act` = activation hook of the fine network (field_forward); `z_fine` = use these merged depths
+    instead of the ones sampled here (to evaluate the fine pass at exactly the samples another implementation drew)."""
     rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
     viewdirs = ray_batch[:, 8:11]
     near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
@@ -339,8 +376,10 @@ def render_rays(ray_batch: Tensor, p_coarse, p_fine, cfg: RenderCfg, t_rand: Opt
         z_samples = z_samples.detach()                                            # :136
         z_coarse = z
         z = z_samples if cfg.use_fine_only else torch.sort(torch.cat([z, z_samples], -1), -1)[0]
+        if z_fine is not None:
+            z = z_fine.to(z.dtype)
         pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]       # :142
-        raw = query_field(p_fine, pts, viewdirs, "fine", cfg.NeRFW, cfg.test_time, cfg.netchunk)
+        raw = query_field(p_fine, pts, viewdirs, "fine", cfg.NeRFW, cfg.test_time, cfg.netchunk, act=fine_act)
         out = composite(raw, z, cfg.raw_noise_std, output_transient=cfg.NeRFW, beta_min=0.1, white_bkgd=cfg.white_bkgd,
                         test_time=cfg.test_time, typ="fine", transient_at_test=cfg.transient_at_test)
         if debug is not None:
@@ -360,8 +399,9 @@ def render_rays(ray_batch: Tensor, p_coarse, p_fine, cfg: RenderCfg, t_rand: Opt
 
 def render(H: int, W: int, focal: float, p_coarse, p_fine, cfg: RenderCfg, chunk: int = 1024 * 32,
            rays=None, c2w: Optional[Tensor] = None, ndc: bool = False, near: float = 0., far: float = 1.,
-           hist: Optional[Tensor] = None, debug: Optional[dict] = None):
-    """rendering.py:197-243 (use_viewdirs=True).  Returns [rgb, disp, acc, extras]."""
+           hist: Optional[Tensor] = None, debug: Optional[dict] = None, fine_act=None, z_fine=None):
+    """rendering.py:197-243 (use_viewdirs=True).  Returns [rgb, disp, acc, extras].
+    `fine_act` / `z_fine` (tests only, whole-batch; need chunk >= the ray count): see render_rays."""
     if c2w is not None:
         rays_o, rays_d = ray_bundle(H, W, focal, c2w)
     else:
@@ -380,7 +420,8 @@ def render(H: int, W: int, focal: float, p_coarse, p_fine, cfg: RenderCfg, chunk
     pieces: Dict[str, list] = {}
     for i in range(0, bundle.shape[0], chunk):                                     # batchify_rays :182-195
         dbg = {} if debug is not None else None
-        r = render_rays(bundle[i:i + chunk], p_coarse, p_fine, cfg, debug=dbg)
+        r = render_rays(bundle[i:i + chunk], p_coarse, p_fine, cfg, debug=dbg, fine_act=fine_act,
+                        z_fine=None if z_fine is None else z_fine[i:i + chunk])
         if dbg:
             for k, v in dbg.items():
                 debug.setdefault(k, []).append(v)

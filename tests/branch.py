@@ -1,0 +1,82 @@
+"""Branch-pinned gradient parity (tests only).
+
+A ReLU network is piecewise linear: its gradient jumps when a pre-activation changes sign.  Two correct fp32 evaluations
+(the reference's and the kernels') round differently, so a handful of units with |pre-activation| ~ 1e-8 land on different
+sides of the kink and the two gradients differ by a finite amount that has nothing to do with arithmetic accuracy -- with the
+reference's own fp32 gradient 5e-4..5e-3 away from the float64 one on small ray batches (profiles/r02/parity.json).
+The 1e-4 target is therefore checked where it is meaningful:
+
+  1. the kernels' ReLU branch pattern (the 1-bit masks the forward pass stores) is decoded and compared with the float64
+     oracle's: every differing unit must have a float64 pre-activation within fp32 rounding of zero (`audit`);
+  2. the float64 oracle is evaluated ON the kernels' branch pattern and at the kernels' sample depths, where the function is
+     smooth; the kernels' gradient must match that to the north-star tolerance, next to the fp32 oracle on the same branch.
+"""
+import numpy as np
+import torch
+
+
+def rho(h, r):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def decode_masks(masks, M, Wd):
+    """int32 mask words of a FULL forward pass ([tiles32][MW][64 lanes], csrc/layout.h nefes_mask_words) ->
+    {tag: bool array [M, units]}, True = pre-activation negative (ReLU derivative 0).  Word w of a layer holds activations
+    s = 32w..32w+31 of the lane's half h (feature 32*(s/16) + rho(h, s%16)), first activation in bit 31."""
+    WT, WH = Wd // 64, Wd // 128
+    MW = 8 * WT + 4 * WH
+    a = masks.detach().cpu().numpy().view(np.uint32).reshape(-1, MW, 64)
+    t32 = (M + 31) // 32
+    a = a[:t32]
+    out, off = {}, 0
+    lane = np.arange(64)
+    j, h = lane & 31, lane >> 5
+    for tag, nw, units in [(f"L{i}", WT, Wd) for i in range(1, 9)] + [(t, WH, Wd // 2) for t in ("DIR", "T0", "T1", "T2")]:
+        neg = np.zeros((t32 * 32, units), bool)
+        for w in range(nw):
+            word = a[:, off + w, :]                                   # [t32, 64]
+            for k in range(32):
+                s = 32 * w + k
+                feat = 32 * (s >> 4) + np.array([rho(int(hh), s & 15) for hh in h])       # per lane
+                bit = (word >> np.uint32(31 - k)) & np.uint32(1)
+                rows = (np.arange(t32)[:, None] * 32 + j[None, :])   # [t32, 64] sample index
+                neg[rows, feat[None, :].repeat(t32, 0)] = bit.astype(bool)
+        out[tag] = neg[:M]
+        off += nw
+    return out
+
+
+class Pinned:
+    """The kernels' fine-pass branch pattern and depths from an ops.TAP capture."""
+
+    def __init__(self, tap, Wd):
+        masks, N, S, width, mode = tap["masks"][-1]
+        assert width == Wd
+        self.N, self.S = N, S
+        self.neg = {k: torch.from_numpy(v) for k, v in decode_masks(masks, N * S, Wd).items()}
+        self.z_fine = tap["z_fine"][-1].detach().cpu() if tap.get("z_fine") and tap["z_fine"][-1] is not None else None
+        if self.z_fine is not None and self.z_fine.shape[1] != S:     # use_fine_only: the fine pass ran on z_samples
+            self.z_fine = tap["z_samples"][-1].detach().cpu()
+        self.audit = {}
+
+    def act(self, record=True):
+        def f(tag, pre, row0):
+            neg = self.neg[tag][row0:row0 + pre.shape[0]]
+            if record:
+                with torch.no_grad():
+                    flips = (pre < 0) != neg
+                    n = int(flips.sum())
+                    a = self.audit.setdefault(tag, {"flips": 0, "units": 0, "worst": 0.0})
+                    a["units"] += pre.numel()
+                    a["flips"] += n
+                    if n:
+                        scale = float(pre.abs().max())
+                        a["worst"] = max(a["worst"], float(pre[flips].abs().max()) / scale)
+            return pre * (~neg).to(pre.dtype)
+        return f
+
+    def summary(self):
+        flips = sum(a["flips"] for a in self.audit.values())
+        units = sum(a["units"] for a in self.audit.values())
+        worst = max([a["worst"] for a in self.audit.values()] + [0.0])
+        return flips, units, worst

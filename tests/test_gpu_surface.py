@@ -13,6 +13,7 @@ import torch
 
 from oracle import ref_cpu as O
 from tests import parity_log as P
+from tests.branch import Pinned
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -72,6 +73,54 @@ def three_way(test, name, got, ref32, truth, tol=P.NORTH_STAR_TOL):
     P.check(test, name, e_hip, e_ref, direct, tol=tol)
 
 
+def maps_and_pose_gradient(tag, hip_maps, c2w_dev, tap, Wd, C, oracle_render, pose):
+    """The usual end-to-end comparison: maps against the (unpinned) fp32 / float64 oracle, the pose gradient of the bench
+    loss branch-pinned.  oracle_render(dtype, c2w, **kw) -> [rgb, disp, acc, extras]."""
+    rgb, feat, disp, acc = hip_maps
+    outs = {}
+    for dt in (torch.float32, torch.float64):
+        r, d_, a_, e = oracle_render(dt, pose.to(dt))
+        outs[dt] = (r, e["feat_map"], d_, a_)
+    for name, got, i in (("rgb", rgb, 0), ("feat", feat, 1), ("disp", disp, 2), ("acc", acc, 3)):
+        three_way(tag, name, got, outs[torch.float32][i], outs[torch.float64][i])
+    (gh,) = torch.autograd.grad(O.bench_loss(rgb, feat), c2w_dev)
+
+    def oracle_run(dt, act, zf):
+        c = pose.to(dt).requires_grad_()
+        r, _, _, e = oracle_render(dt, c, fine_act=act, z_fine=zf)
+        return {"d c2w": torch.autograd.grad(O.bench_loss(r, e["feat_map"]), c)[0]}
+
+    pinned_gradients(tag, {"d c2w": gh}, tap, Wd, oracle_run)
+
+
+class tapped:
+    """with tapped() as tap: ... -- collect the kernels' ReLU masks and sample depths (nefes_amd.ops.TAP)."""
+
+    def __enter__(self):
+        from nefes_amd import ops
+        ops.TAP = {}
+        return ops.TAP
+
+    def __exit__(self, *exc):
+        from nefes_amd import ops
+        ops.TAP = None
+        return False
+
+
+def pinned_gradients(tag, hip, tap, Wd, oracle_run):
+    """Gradient parity on the kernels' own ReLU branch pattern (tests/branch.py): `oracle_run(dtype, fine_act, z_fine)`
+    -> {name: gradient}; `hip` = the same dict from the kernels.  Also audits the branch pattern against float64."""
+    pin = Pinned(tap, Wd)
+    g64 = oracle_run(torch.float64, pin.act(True), pin.z_fine)
+    g32 = oracle_run(torch.float32, pin.act(False), pin.z_fine)
+    flips, units, worst = pin.summary()
+    print(f"[{tag}] ReLU branch pattern vs float64: {flips} of {units} units differ, worst |pre-activation| / layer max {worst:.1e}")
+    P.record(tag, "relu branch flips vs float64", flips=flips, units=units, worst_preact_rel=worst)
+    assert worst < 1e-5 and flips <= max(8, units // 100000)
+    for name in hip:
+        three_way(tag, name + " [branch-pinned]", hip[name], g32[name], g64[name])
+
+
 @pytest.mark.parametrize("Wd,C,Ni", [(128, 128, 64), (256, 16, 128)])
 def test_batchify_and_render_rays_on_the_packed_batch(Wd, C, Ni):
     R, M, _ = dropin()
@@ -84,8 +133,9 @@ def test_batchify_and_render_rays_on_the_packed_batch(Wd, C, Ni):
     batch[:, 6] = torch.rand(H * W, generator=g) * 0.3
     batch[:, 7] = 3.5 + torch.rand(H * W, generator=g)
     b_dev = batch.to(DEV).requires_grad_()
-    ret = R.batchify_rays(b_dev, 32768, **kw)
     one = R.render_rays(b_dev[:9], **kw)                      # the inner function on a slice: same rows
+    with tapped() as tap:
+        ret = R.batchify_rays(b_dev, 32768, **kw)
     for k in ("rgb_map", "feat_map", "disp_map", "acc_map"):
         assert torch.equal(one[k], ret[k][:9]), k
     cfg = O.RenderCfg(N_samples=64, N_importance=Ni)
@@ -100,10 +150,14 @@ def test_batchify_and_render_rays_on_the_packed_batch(Wd, C, Ni):
         three_way(tag, k, ret[k], r32[k], r64[k])
     loss = lambda r: O.bench_loss(r["rgb_map"], r["feat_map"])
     (gh,) = torch.autograd.grad(loss(ret), b_dev)
-    (g32,) = torch.autograd.grad(loss(r32), b32)
-    (g64,) = torch.autograd.grad(loss(r64), b64)
-    for name, sl in (("d rays_o", slice(0, 3)), ("d rays_d", slice(3, 6)), ("d viewdirs", slice(8, 11))):
-        three_way(tag, name, gh[:, sl], g32[:, sl], g64[:, sl])
+    cols = (("d rays_o", slice(0, 3)), ("d rays_d", slice(3, 6)), ("d viewdirs", slice(8, 11)))
+
+    def oracle_run(dt, act, zf):
+        b = batch.to(dt).requires_grad_()
+        (g,) = torch.autograd.grad(loss(O.render_rays(b, *params(Wd, C, dt), cfg, fine_act=act, z_fine=zf)), b)
+        return {name: g[:, sl] for name, sl in cols}
+
+    pinned_gradients(tag, {name: gh[:, sl] for name, sl in cols}, tap, Wd, oracle_run)
     assert float(gh[:, 6:8].abs().max()) == 0 and float(gh[:, 11:].abs().max()) == 0    # bounds/hist carry no gradient
 
 
@@ -113,18 +167,12 @@ def test_use_fine_only():
     kw = dict(kwargs(M, coarse, fine, 64, fine_only=True), use_viewdirs=True, ndc=False)
     H, W, focal = 4, 6, 5.0
     c2w = O.bench_pose().to(DEV).requires_grad_()
-    rgb, disp, acc, ex = R.render(H, W, focal, c2w=c2w, near=0., far=4., **kw)
+    with tapped() as tap:
+        rgb, disp, acc, ex = R.render(H, W, focal, c2w=c2w, near=0., far=4., **kw)
     cfg = O.RenderCfg(N_samples=64, N_importance=64, use_fine_only=True)
-    outs = {}
-    for dt in (torch.float32, torch.float64):
-        pc, pf = params(128, 128, dt)
-        c = O.bench_pose(dt).requires_grad_()
-        r, d_, a_, e = O.render(H, W, focal, pc, pf, cfg, c2w=c, near=0., far=4.)
-        (gc,) = torch.autograd.grad(O.bench_loss(r, e["feat_map"]), c)
-        outs[dt] = (r, e["feat_map"], d_, a_, gc)
-    (gh,) = torch.autograd.grad(O.bench_loss(rgb, ex["feat_map"]), c2w)
-    for name, got, i in (("rgb", rgb, 0), ("feat", ex["feat_map"], 1), ("disp", disp, 2), ("acc", acc, 3), ("d c2w", gh, 4)):
-        three_way("use_fine_only", name, got, outs[torch.float32][i], outs[torch.float64][i])
+    maps_and_pose_gradient("use_fine_only", (rgb, ex["feat_map"], disp, acc), c2w, tap, 128, 128,
+                           lambda dt, c, **k: O.render(H, W, focal, *params(128, 128, dt), cfg, c2w=c, near=0., far=4., **k),
+                           O.bench_pose())
 
 
 def test_c2w_staticcam():
@@ -136,22 +184,19 @@ def test_c2w_staticcam():
     cam = O.bench_pose()
     static = O.se3_exp_pose((-0.05, 0.12, 0.02), (0.0, -0.1, 0.2))
     c2w = cam.to(DEV).requires_grad_()
-    rgb, disp, acc, ex = R.render(H, W, focal, c2w=c2w, c2w_staticcam=static.to(DEV), near=0., far=4., **kw)
+    with tapped() as tap:
+        rgb, disp, acc, ex = R.render(H, W, focal, c2w=c2w, c2w_staticcam=static.to(DEV), near=0., far=4., **kw)
     cfg = O.RenderCfg(N_samples=64, N_importance=64)
-    res = {}
-    for dt in (torch.float32, torch.float64):
-        pc, pf = params(128, 128, dt)
-        c = cam.to(dt).requires_grad_()
+
+    def oracle(dt, c, fine_act=None, z_fine=None):
         batch = packed_batch(H, W, focal, static, 0., 4., dt)
         _, d_cam = O.ray_bundle(H, W, focal, c)
         v = (d_cam / torch.norm(d_cam, dim=-1, keepdim=True)).reshape(-1, 3)
-        batch = torch.cat([batch[:, :8], v, batch[:, 11:]], -1)
-        r = O.render_rays(batch, pc, pf, cfg)
-        (gc,) = torch.autograd.grad(O.bench_loss(r["rgb_map"], r["feat_map"]), c)
-        res[dt] = (r["rgb_map"], r["feat_map"], gc)
-    (gh,) = torch.autograd.grad(O.bench_loss(rgb, ex["feat_map"]), c2w)
-    for name, got, i in (("rgb", rgb, 0), ("feat", ex["feat_map"], 1), ("d c2w (through viewdirs only)", gh, 2)):
-        three_way("c2w_staticcam", name, got, res[torch.float32][i], res[torch.float64][i])
+        r = O.render_rays(torch.cat([batch[:, :8], v, batch[:, 11:]], -1), *params(128, 128, dt), cfg, fine_act=fine_act,
+                          z_fine=z_fine)
+        return [r["rgb_map"], r["disp_map"], r["acc_map"], {"feat_map": r["feat_map"]}]
+
+    maps_and_pose_gradient("c2w_staticcam", (rgb, ex["feat_map"], disp, acc), c2w, tap, 128, 128, oracle, cam)
 
 
 def test_get_rays_batch():
@@ -184,18 +229,12 @@ def test_lindisp_end_to_end():
     kw = dict(kwargs(M, coarse, fine, 64, lindisp=True), use_viewdirs=True, ndc=False)
     H, W, focal = 4, 6, 5.0
     c2w = O.bench_pose().to(DEV).requires_grad_()
-    rgb, disp, acc, ex = R.render(H, W, focal, c2w=c2w, near=0.5, far=6., **kw)
+    with tapped() as tap:
+        rgb, disp, acc, ex = R.render(H, W, focal, c2w=c2w, near=0.5, far=6., **kw)
     cfg = O.RenderCfg(N_samples=64, N_importance=64, lindisp=True)
-    outs = {}
-    for dt in (torch.float32, torch.float64):
-        pc, pf = params(128, 128, dt)
-        c = O.bench_pose(dt).requires_grad_()
-        r, d_, a_, e = O.render(H, W, focal, pc, pf, cfg, c2w=c, near=0.5, far=6.)
-        (gc,) = torch.autograd.grad(O.bench_loss(r, e["feat_map"]), c)
-        outs[dt] = (r, e["feat_map"], d_, a_, gc)
-    (gh,) = torch.autograd.grad(O.bench_loss(rgb, ex["feat_map"]), c2w)
-    for name, got, i in (("rgb", rgb, 0), ("feat", ex["feat_map"], 1), ("disp", disp, 2), ("acc", acc, 3), ("d c2w", gh, 4)):
-        three_way("lindisp", name, got, outs[torch.float32][i], outs[torch.float64][i])
+    maps_and_pose_gradient("lindisp", (rgb, ex["feat_map"], disp, acc), c2w, tap, 128, 128,
+                           lambda dt, c, **k: O.render(H, W, focal, *params(128, 128, dt), cfg, c2w=c, near=0.5, far=6., **k),
+                           O.bench_pose())
 
 
 @pytest.mark.parametrize("Wd,C,Ni", [(256, 16, 128), (128, 128, 64)])
@@ -210,19 +249,11 @@ def test_far20_frequency_embedding_render(Wd, C, Ni):
     focal = 744. * W / 854.
     pose = O.se3_exp_pose((0.4, -0.9, 0.15), (6.0, -3.5, 9.0))
     c2w = pose.to(DEV).requires_grad_()
-    rgb, disp, acc, ex = R.render(H, W, focal, c2w=c2w, near=0., far=20., **kw)
+    with tapped() as tap:
+        rgb, disp, acc, ex = R.render(H, W, focal, c2w=c2w, near=0., far=20., **kw)
     cfg = O.RenderCfg(N_samples=64, N_importance=Ni)
-    outs = {}
-    for dt in (torch.float32, torch.float64):
-        pc, pf = params(Wd, C, dt)
-        c = pose.to(dt).requires_grad_()
-        r, d_, a_, e = O.render(H, W, focal, pc, pf, cfg, c2w=c, near=0., far=20.)
-        (gc,) = torch.autograd.grad(O.bench_loss(r, e["feat_map"]), c)
-        outs[dt] = (r, e["feat_map"], d_, a_, gc)
-    (gh,) = torch.autograd.grad(O.bench_loss(rgb, ex["feat_map"]), c2w)
-    tag = f"far20[{Wd},{C}]"
-    for name, got, i in (("rgb", rgb, 0), ("feat", ex["feat_map"], 1), ("disp", disp, 2), ("acc", acc, 3), ("d c2w", gh, 4)):
-        three_way(tag, name, got, outs[torch.float32][i], outs[torch.float64][i])
+    maps_and_pose_gradient(f"far20[{Wd},{C}]", (rgb, ex["feat_map"], disp, acc), c2w, tap, Wd, C,
+                           lambda dt, c, **k: O.render(H, W, focal, *params(Wd, C, dt), cfg, c2w=c, near=0., far=20., **k), pose)
 
 
 @pytest.mark.parametrize("Wd,C", [(256, 16), (128, 128)])
