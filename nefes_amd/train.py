@@ -205,6 +205,7 @@ class FieldTrain(torch.autograd.Function):
                                               raw_t.data_ptr(), acts.data_ptr(), None if masks is None else masks.data_ptr(),
                                               ops._stream()), "nefes_field_fwd_train")
         if fused:
+            ops._tap("masks", (masks, N, S, pk.width, mode))
             ctx.save_for_backward(raw_t, acts, o, d, v, zz, masks)
         else:
             ctx.save_for_backward(raw_t, acts)

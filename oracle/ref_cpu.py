@@ -352,7 +352,8 @@ def coarse_depths(near: Tensor, far: Tensor, n: int, lindisp: bool, t_rand: Opti
 
 
 def render_rays(ray_batch: Tensor, p_coarse, p_fine, cfg: RenderCfg, t_rand: Optional[Tensor] = None,
-                u_rand: Optional[Tensor] = None, debug: Optional[dict] = None, fine_act=None, z_fine=None) -> Dict[str, Tensor]:
+                u_rand: Optional[Tensor] = None, debug: Optional[dict] = None, fine_act=None, z_fine=None,
+                coarse_act=None) -> Dict[str, Tensor]:
     """rendering.py:68-180 for the nerfh_nff configuration.
     Tests only: `fine_act` = activation hook of the fine network (field_forward); `z_fine` = use these merged depths
     instead of the ones sampled here (to evaluate the fine pass at exactly the samples another implementation drew)."""
@@ -364,7 +365,7 @@ def render_rays(ray_batch: Tensor, p_coarse, p_fine, cfg: RenderCfg, t_rand: Opt
     z = coarse_depths(near, far, cfg.N_samples, cfg.lindisp, t_rand if cfg.perturb > 0. else None)
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]          # :114
     store_rgb = (cfg.N_importance == 0)
-    raw = query_field(p_coarse, pts, viewdirs, "coarse", False, cfg.test_time, cfg.netchunk)      # :122
+    raw = query_field(p_coarse, pts, viewdirs, "coarse", False, cfg.test_time, cfg.netchunk, act=coarse_act)      # :122
     c0 = composite(raw, z, cfg.raw_noise_std, white_bkgd=cfg.white_bkgd, test_time=cfg.test_time, typ="coarse",
                    store_rgb=store_rgb)
     out = c0
@@ -399,7 +400,7 @@ def render_rays(ray_batch: Tensor, p_coarse, p_fine, cfg: RenderCfg, t_rand: Opt
 
 def render(H: int, W: int, focal: float, p_coarse, p_fine, cfg: RenderCfg, chunk: int = 1024 * 32,
            rays=None, c2w: Optional[Tensor] = None, ndc: bool = False, near: float = 0., far: float = 1.,
-           hist: Optional[Tensor] = None, debug: Optional[dict] = None, fine_act=None, z_fine=None):
+           hist: Optional[Tensor] = None, debug: Optional[dict] = None, fine_act=None, z_fine=None, coarse_act=None):
     """rendering.py:197-243 (use_viewdirs=True).  Returns [rgb, disp, acc, extras].
     `fine_act` / `z_fine` (tests only, whole-batch; need chunk >= the ray count): see render_rays."""
     if c2w is not None:
@@ -421,7 +422,7 @@ def render(H: int, W: int, focal: float, p_coarse, p_fine, cfg: RenderCfg, chunk
     for i in range(0, bundle.shape[0], chunk):                                     # batchify_rays :182-195
         dbg = {} if debug is not None else None
         r = render_rays(bundle[i:i + chunk], p_coarse, p_fine, cfg, debug=dbg, fine_act=fine_act,
-                        z_fine=None if z_fine is None else z_fine[i:i + chunk])
+                        z_fine=None if z_fine is None else z_fine[i:i + chunk], coarse_act=coarse_act)
         if dbg:
             for k, v in dbg.items():
                 debug.setdefault(k, []).append(v)

@@ -14,6 +14,8 @@ The 1e-4 target is therefore checked where it is meaningful:
 import numpy as np
 import torch
 
+from tests import parity_log as P
+
 
 def rho(h, r):
     return (r & 3) + 8 * (r >> 2) + 4 * h
@@ -49,8 +51,8 @@ def decode_masks(masks, M, Wd):
 class Pinned:
     """The kernels' fine-pass branch pattern and depths from an ops.TAP capture."""
 
-    def __init__(self, tap, Wd):
-        masks, N, S, width, mode = tap["masks"][-1]
+    def __init__(self, tap, Wd, index=-1):
+        masks, N, S, width, mode = tap["masks"][index]
         assert width == Wd
         self.N, self.S = N, S
         self.neg = {k: torch.from_numpy(v) for k, v in decode_masks(masks, N * S, Wd).items()}
@@ -80,3 +82,53 @@ class Pinned:
         units = sum(a["units"] for a in self.audit.values())
         worst = max([a["worst"] for a in self.audit.values()] + [0.0])
         return flips, units, worst
+
+
+# ---- shared comparison helpers of the GPU tests (and of __graft_entry__.smoke) ---------------------------------------
+def rel(a, b):
+    a = a.detach().cpu().double() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)).double()
+    b = b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def three_way(test, name, got, ref32, truth, tol=P.NORTH_STAR_TOL, factor=P.REF_FACTOR):
+    """hip vs float64, fp32 oracle vs float64, hip vs fp32 oracle; recorded (tests/parity_log.py) and asserted with the
+    shared rule e_hip <= max(tol, factor * e_ref)."""
+    e_hip, e_ref, direct = rel(got, truth), rel(ref32, truth), rel(got, ref32)
+    print(f"[{test}] {name}: hip-vs-f64 {e_hip:.2e}  fp32-oracle-vs-f64 {e_ref:.2e}  hip-vs-fp32-oracle {direct:.2e}")
+    P.check(test, name, e_hip, e_ref, direct, tol=tol, factor=factor)
+    return e_hip, e_ref, direct
+
+
+class tapped:
+    """with tapped() as tap: ... -- collect the kernels' ReLU masks and sample depths (nefes_amd.ops.TAP)."""
+
+    def __enter__(self):
+        from nefes_amd import ops
+        ops.TAP = {}
+        return ops.TAP
+
+    def __exit__(self, *exc):
+        from nefes_amd import ops
+        ops.TAP = None
+        return False
+
+
+def pinned_gradients(tag, hip, tap, Wd, oracle_run, tol=P.NORTH_STAR_TOL, audit_tol=2e-5):
+    """Gradient parity on the kernels' own ReLU branch pattern: `oracle_run(dtype, act, z_fine)` -> {name: gradient} of the
+    oracle evaluated with the activation hook `act` (and, for render-level runs, at the kernels' depths `z_fine`);
+    `hip` = the same dict from the kernels.  Also audits the branch pattern against the float64 pre-activations."""
+    pin = Pinned(tap, Wd)
+    g64 = oracle_run(torch.float64, pin.act(True), pin.z_fine)
+    g32 = oracle_run(torch.float32, pin.act(False), pin.z_fine)
+    flips, units, worst = pin.summary()
+    print(f"[{tag}] ReLU branch pattern vs float64: {flips} of {units} units differ, worst |pre-activation| / layer max {worst:.1e}")
+    P.record(tag, "relu branch flips vs float64", flips=flips, units=units, worst_preact_rel=worst)
+    # audit_tol: how far (relative to the layer's largest pre-activation) a float64 pre-activation may sit from zero and
+    # still land on the other side in fp32: ~1e-5 for identical inputs; more where the float64 oracle's INPUTS differ from
+    # the fp32 ones by rounding upstream of the network (e.g. an NDC warp evaluated in float64), amplified by 2^9 in the embedding
+    assert worst < audit_tol and flips <= max(8, units // 100000) * (audit_tol / 2e-5), (flips, units, worst)
+    out = {}
+    for name in hip:
+        out[name] = three_way(tag, name + " [branch-pinned]", hip[name], g32[name], g64[name], tol=tol)
+    return out

@@ -10,6 +10,8 @@ import pytest
 import torch
 
 from oracle import ref_cpu as O
+from tests import branch as B
+from tests import parity_log as P
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -261,14 +263,22 @@ def test_field_from_rays_vs_oracle(ops, L, Wd, C, S):
         raw.backward(g_raw.to(dt))
         res[dt] = (raw.detach(), oo.grad, dd.grad, vv.grad)
     oh, dh, vh = (t.to(DEV).clone().requires_grad_() for t in (o, d, v))
-    raw_t = ops.FieldFromRays.apply(oh, dh, vh, z.to(DEV), fine.packed(), L.FIELD_FULL)
+    with B.tapped() as tap:
+        raw_t = ops.FieldFromRays.apply(oh, dh, vh, z.to(DEV), fine.packed(), L.FIELD_FULL)
     raw_t.backward(g_raw.permute(0, 2, 1).contiguous().to(DEV))
-    assert rel(raw_t.permute(0, 2, 1), res[torch.float32][0]) < 1e-4
+    tag = f"field_from_rays[{Wd},{C},{S}]"
+    B.three_way(tag, "raw", raw_t.permute(0, 2, 1), res[torch.float32][0], res[torch.float64][0])
+
+    def oracle_run(dt, act, _):                     # the oracle on the kernels' ReLU branch pattern (tests/branch.py)
+        oo, dd, vv = (t.to(dt).clone().requires_grad_() for t in (o, d, v))
+        pts = oo[:, None, :] + dd[:, None, :] * z.to(dt)[..., None]
+        O.query_field({k: w.to(dt) for k, w in pf.items()}, pts, vv, "fine", True, True, act=act).backward(g_raw.to(dt))
+        return {"d rays_o": oo.grad, "d rays_d": dd.grad, "d viewdirs": vv.grad}
+
+    B.pinned_gradients(tag, {"d rays_o": oh.grad, "d rays_d": dh.grad, "d viewdirs": vh.grad}, tap, Wd, oracle_run)
     for name, got, i in (("rays_o", oh.grad, 1), ("rays_d", dh.grad, 2), ("viewdirs", vh.grad, 3)):
-        truth, ref32 = res[torch.float64][i], res[torch.float32][i]
-        e_hip, e_ref = rel(got, truth), rel(ref32, truth)
-        print(f"[{Wd},{C},{S}] d {name}: hip-vs-f64 {e_hip:.2e}  ref32-vs-f64 {e_ref:.2e}  hip-vs-ref32 {rel(got, ref32):.2e}")
-        assert e_hip <= max(1e-4, 3 * e_ref)
+        # not pinned: dominated by the few units whose fp32 pre-activation rounds to the other side of zero (recorded only)
+        P.record(tag, f"d {name} [unpinned]", e_hip=rel(got, res[torch.float64][i]), e_ref=rel(res[torch.float32][i], res[torch.float64][i]))
 
 
 @pytest.mark.parametrize("Wd,C,S", [(256, 16, 64), (128, 128, 40)])
@@ -292,14 +302,19 @@ def test_static_mode_field_backward_vs_oracle(ops, L, Wd, C, S):
         raw.backward(g_raw.to(dt))
         res[dt] = (raw.detach(), oo.grad, dd.grad, vv.grad)
     oh, dh, vh = (t.to(DEV).clone().requires_grad_() for t in (o, d, v))
-    raw_t = ops.FieldFromRays.apply(oh, dh, vh, z.to(DEV), coarse.packed(), L.FIELD_STATIC)
+    with B.tapped() as tap:
+        raw_t = ops.FieldFromRays.apply(oh, dh, vh, z.to(DEV), coarse.packed(), L.FIELD_STATIC)
     raw_t.backward(g_raw.permute(0, 2, 1).contiguous().to(DEV))
-    assert rel(raw_t.permute(0, 2, 1), res[torch.float32][0]) < 1e-4
-    for name, got, i in (("rays_o", oh.grad, 1), ("rays_d", dh.grad, 2), ("viewdirs", vh.grad, 3)):
-        truth, ref32 = res[torch.float64][i], res[torch.float32][i]
-        e_hip, e_ref = rel(got, truth), rel(ref32, truth)
-        print(f"[static {Wd},{C},{S}] d {name}: hip-vs-f64 {e_hip:.2e}  ref32-vs-f64 {e_ref:.2e}")
-        assert e_hip <= max(1e-4, 3 * e_ref)
+    tag = f"field_static[{Wd},{C},{S}]"
+    B.three_way(tag, "raw", raw_t.permute(0, 2, 1), res[torch.float32][0], res[torch.float64][0])
+
+    def oracle_run(dt, act, _):
+        oo, dd, vv = (t.to(dt).clone().requires_grad_() for t in (o, d, v))
+        pts = oo[:, None, :] + dd[:, None, :] * z.to(dt)[..., None]
+        O.query_field({k: w.to(dt) for k, w in pc.items()}, pts, vv, "coarse", False, False, act=act).backward(g_raw.to(dt))
+        return {"d rays_o": oo.grad, "d rays_d": dd.grad, "d viewdirs": vv.grad}
+
+    B.pinned_gradients(tag, {"d rays_o": oh.grad, "d rays_d": dh.grad, "d viewdirs": vh.grad}, tap, Wd, oracle_run)
 
 
 # ---- end to end through the drop-in module path ------------------------------------------------------------------
@@ -331,11 +346,14 @@ def test_render_end_to_end_vs_reference(golden, tag):
     coarse, fine = _modules(Wd, C, float(sscale))
     kw = _kwargs(M, coarse, fine, Ni, bool(tat))
     c2w = T(g[f"{tag}.c2w"]).to(DEV).clone().requires_grad_()
-    rgb, disp, acc, ex = R.render(H, W, float(focal), chunk=32768, c2w=c2w, near=0., far=4.,
-                                  img_idx=torch.full((1, 10), 10.), **kw)
+    with B.tapped() as tap:
+        rgb, disp, acc, ex = R.render(H, W, float(focal), chunk=32768, c2w=c2w, near=0., far=4.,
+                                      img_idx=torch.full((1, 10), 10.), **kw)
     feat = ex["feat_map"]
-    assert rel(rgb, g[f"{tag}.rgb"]) < 1e-4 and rel(feat, g[f"{tag}.feat"]) < 1e-4
-    assert rel(disp, g[f"{tag}.disp"]) < 1e-4 and rel(acc, g[f"{tag}.acc"]) < 1e-4
+    for name, got in (("rgb", rgb), ("feat", feat), ("disp", disp), ("acc", acc)):
+        e = rel(got, g[f"{tag}.{name}"])
+        P.record(f"end_to_end[{tag}]", f"{name} vs reference fixture", e_hip=e, e_ref=None, bound=1e-4)
+        assert e < 1e-4, (name, e)
     (g1,) = torch.autograd.grad(O.bench_loss(rgb, feat), c2w, retain_graph=True)
     (g2,) = torch.autograd.grad((rgb * T(g[f"{tag}.g_rgb"]).to(DEV)).sum() + (feat * T(g[f"{tag}.g_feat"]).to(DEV)).sum(), c2w)
     # ground truth for the pose gradient: the oracle evaluated in float64 (SURVEY.md §7 hard part 10)
@@ -348,9 +366,26 @@ def test_render_end_to_end_vs_reference(golden, tag):
     r64, _, _, e64 = O.render(H, W, float(focal), pc, pf, cfg, c2w=c64, near=0., far=4.)
     (t1,) = torch.autograd.grad(O.bench_loss(r64, e64["feat_map"]), c64, retain_graph=True)
     (t2,) = torch.autograd.grad((r64 * T(g[f"{tag}.g_rgb"]).double()).sum() + (e64["feat_map"] * T(g[f"{tag}.g_feat"]).double()).sum(), c64)
+    # (1) the north-star statement, on the kernels' own ReLU branch pattern (tests/branch.py): 1e-4 of the float64 gradient
+    def oracle_run(dt, act, zf):
+        p_c, p_f = O.make_field_params("coarse", Wd, C, dtype=dt), O.make_field_params("fine", Wd, C, dtype=dt)
+        for p in (p_c, p_f):
+            p["static_sigma.0.weight"] = p["static_sigma.0.weight"] * float(sscale)
+            p["static_sigma.0.bias"] = p["static_sigma.0.bias"] * float(sscale)
+        c = T(g[f"{tag}.c2w"]).to(dt).requires_grad_()
+        r, _, _, e = O.render(H, W, float(focal), p_c, p_f, cfg, c2w=c, near=0., far=4., fine_act=act, z_fine=zf)
+        (a,) = torch.autograd.grad(O.bench_loss(r, e["feat_map"]), c, retain_graph=True)
+        (b,) = torch.autograd.grad((r * T(g[f"{tag}.g_rgb"]).to(dt)).sum() + (e["feat_map"] * T(g[f"{tag}.g_feat"]).to(dt)).sum(), c)
+        return {"d c2w (bench loss)": a, "d c2w (linear functional)": b}
+
+    B.pinned_gradients(f"end_to_end[{tag}]", {"d c2w (bench loss)": g1, "d c2w (linear functional)": g2}, tap, Wd, oracle_run)
+    # (2) against the gradient the reference itself produced (fixture) and the unpinned float64 oracle: both sides carry the
+    #     kink noise of their own fp32 rounding, so the bound is the reference's own distance from float64 (recorded)
     for name, got, ref32, truth in (("loss", g1, g[f"{tag}.g_c2w_loss"], t1), ("linear", g2, g[f"{tag}.g_c2w_lin"], t2)):
         e_hip, e_ref, direct = rel(got, truth), rel(ref32, truth), rel(got, ref32)
-        print(f"[{tag}/{name}] d c2w: hip-vs-f64 {e_hip:.2e}  reference-fp32-vs-f64 {e_ref:.2e}  hip-vs-reference {direct:.2e}")
+        print(f"[{tag}/{name}] d c2w unpinned: hip-vs-f64 {e_hip:.2e}  reference-fp32-vs-f64 {e_ref:.2e}  hip-vs-reference {direct:.2e}")
+        P.record(f"end_to_end[{tag}]", f"d c2w ({name}) [unpinned, vs reference fixture]", e_hip=e_hip, e_ref=e_ref, direct=direct,
+                 bound=max(1e-4, 3 * e_ref))
         assert e_hip <= max(1e-4, 3 * e_ref), (name, e_hip, e_ref)
         assert direct <= max(1e-4, 4 * e_ref)
 

@@ -13,17 +13,11 @@ import torch
 
 from oracle import ref_cpu as O
 from tests import parity_log as P
-from tests.branch import Pinned
+from tests.branch import pinned_gradients, rel, tapped, three_way
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 T = lambda a: torch.from_numpy(np.asarray(a))
-
-
-def rel(a, b):
-    a = a.detach().cpu().double() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)).double()
-    b = b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).double()
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
 def dropin():
@@ -67,12 +61,6 @@ def packed_batch(H, W, focal, c2w, near, far, dtype=torch.float32):
     return torch.cat([o, d, near * ones, far * ones, v, hist], -1)
 
 
-def three_way(test, name, got, ref32, truth, tol=P.NORTH_STAR_TOL):
-    e_hip, e_ref, direct = rel(got, truth), rel(ref32, truth), rel(got, ref32)
-    print(f"[{test}] {name}: hip-vs-f64 {e_hip:.2e}  fp32-oracle-vs-f64 {e_ref:.2e}  hip-vs-fp32-oracle {direct:.2e}")
-    P.check(test, name, e_hip, e_ref, direct, tol=tol)
-
-
 def maps_and_pose_gradient(tag, hip_maps, c2w_dev, tap, Wd, C, oracle_render, pose):
     """The usual end-to-end comparison: maps against the (unpinned) fp32 / float64 oracle, the pose gradient of the bench
     loss branch-pinned.  oracle_render(dtype, c2w, **kw) -> [rgb, disp, acc, extras]."""
@@ -91,34 +79,6 @@ def maps_and_pose_gradient(tag, hip_maps, c2w_dev, tap, Wd, C, oracle_render, po
         return {"d c2w": torch.autograd.grad(O.bench_loss(r, e["feat_map"]), c)[0]}
 
     pinned_gradients(tag, {"d c2w": gh}, tap, Wd, oracle_run)
-
-
-class tapped:
-    """with tapped() as tap: ... -- collect the kernels' ReLU masks and sample depths (nefes_amd.ops.TAP)."""
-
-    def __enter__(self):
-        from nefes_amd import ops
-        ops.TAP = {}
-        return ops.TAP
-
-    def __exit__(self, *exc):
-        from nefes_amd import ops
-        ops.TAP = None
-        return False
-
-
-def pinned_gradients(tag, hip, tap, Wd, oracle_run):
-    """Gradient parity on the kernels' own ReLU branch pattern (tests/branch.py): `oracle_run(dtype, fine_act, z_fine)`
-    -> {name: gradient}; `hip` = the same dict from the kernels.  Also audits the branch pattern against float64."""
-    pin = Pinned(tap, Wd)
-    g64 = oracle_run(torch.float64, pin.act(True), pin.z_fine)
-    g32 = oracle_run(torch.float32, pin.act(False), pin.z_fine)
-    flips, units, worst = pin.summary()
-    print(f"[{tag}] ReLU branch pattern vs float64: {flips} of {units} units differ, worst |pre-activation| / layer max {worst:.1e}")
-    P.record(tag, "relu branch flips vs float64", flips=flips, units=units, worst_preact_rel=worst)
-    assert worst < 1e-5 and flips <= max(8, units // 100000)
-    for name in hip:
-        three_way(tag, name + " [branch-pinned]", hip[name], g32[name], g64[name])
 
 
 @pytest.mark.parametrize("Wd,C,Ni", [(128, 128, 64), (256, 16, 128)])
