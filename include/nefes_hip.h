@@ -210,6 +210,21 @@ int nefes_field_bwd_x3(const NefesNetDesc* desc, const void* packed, int N, int 
                        const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
                        const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);
 
+/* The same two functions (nefes_field_fwd in NEFES_FIELD_SIGMA / NEFES_FIELD_FULL mode, nefes_field_bwd) with the products as
+ * fp16 TWO-PART split products on v_mfma_f32_32x32x16_f16 -- (hi, lo) fp16 pairs of power-of-two scaled operands, three cross
+ * terms hh + hl + lh, fp32 accumulation: 22 significant bits per operand, fp32-level accuracy at half the matrix-core work of
+ * the _x6 calls (nefes_amd/csrc/field_h3.h; replaces script/models/nerfh_nff.py:168-231,525-576 + autograd like they do).
+ * Weights are scaled per matrix by the packer (exponent table in the NEFES_STREAM_*_H3 streams), activations / gradient vectors
+ * per sample and product inside the kernels.  Shapes: width 256 / C = 16 (either xyz encoding) and width 128 / C = 128.
+ * Same arguments, outputs and ReLU-mask words as the calls above, so forward and backward kernels of every kind combine.
+ * The fp16 streams are written by nefes_pack_weights only (not by nefes_pack_device). */
+int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                       const float* rays_d, const float* z, const float* pts, const float* xyz_enc, const float* viewdirs,
+                       float* raw_t, uint32_t* masks, void* stream);
+int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
+                       const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
+                       const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);
+
 /* ---- train mode: weight gradients (script/run_nefes.py:42-108 `loss.backward()` through models/nerfh_nff.py:525-576) ----
  * Buffers `acts` / `dacts`: fp32 [n_tiles = ceil(N*S/128)][rows][128 samples], rows = nefes_train_rows(desc); row blocks
  * NEFES_TB_* (nefes_amd/csrc/layout.h): E, DV (embeddings, slot order), L1..L8, FINAL, DIR, T0..T2 (natural feature

@@ -42,10 +42,12 @@ __device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, 
     // v_readfirstlane), and a VMEM instruction reading such an SGPR needs 5 wait states the compiler does not insert for
     // inline asm.  Instead of padding (s_nop 4 = 20 cycles, a large part of a 32-cycle bf16 MFMA gap) the base is copied
     // by the scalar ALU into a fresh pair that the DMA reads: SALU-written SGPRs carry no such hazard.
-    // M0 is left holding the LDS address rather than saved and restored, and is declared clobbered: should the compiler
-    // ever want M0 in these kernels (movrel indexing, readlane, sendmsg) it re-materialises it after this statement
-    // (today it uses M0 for nothing here -- tests/test_pack_stream.py::test_m0_only_written_by_the_dma_helper checks the
-    // disassembly as a second line of defence).  A save/restore would have to wait until the DMA has read M0
+    // M0 is left holding the LDS address rather than saved and restored.  It cannot be declared clobbered: M0 is a reserved
+    // register for this target and hipcc rejects the promise ("inline asm clobber list contains reserved registers: m0 ...
+    // may not be preserved"), so soundness rests on the compiler using M0 for nothing else in these kernels -- which
+    // tests/test_pack_stream.py::test_m0_only_written_by_the_dma_helper verifies on the disassembly of the shipped library
+    // (and which fails the CPU suite, not silently miscompiles, should a new hipcc start to).  A save/restore would have
+    // to wait until the DMA has read M0
     // (tools/probe/overlap_probe.hip, dma variant 2: one cycle per bf16 MFMA less in the x6 instruction mix).
     uint64_t base2;
     (void)keep;
@@ -56,7 +58,7 @@ __device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, 
         "global_load_lds_dwordx4 %1, %0"
         : "=&s"(base2)
         : "v"(lane_off), "s"(gbase), "s"(lds_dst)
-        : "memory", "m0");
+        : "memory");
 #endif
 }
 // 1-instruction ReLU (fmaxf() costs a canonicalising v_max in front of the real one)

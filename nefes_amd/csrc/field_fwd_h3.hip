@@ -1,0 +1,363 @@
+// Fused field forward with every product as an fp16 two-part split product (field_h3.h): sigma-only coarse pass and the full
+// fine pass.  Same function as field_fwd_kernel / field_fwd_x6_kernel (script/models/nerfh_nff.py:192-231,525-576 +
+// rendering.py:114,142): pts = o + d*z -> frequency embedding (or a supplied 32-feature encoding) -> 8-layer skip MLP -> heads,
+// same raw_t layout, same ReLU-mask words.  Every product runs on v_mfma_f32_32x32x16_f16 as hh + hl + lh of power-of-two
+// scaled (hi, lo) fp16 pairs: half the matrix-core work of the bf16x6 kernels at fp32-level accuracy.
+// Weight stream: 32 KiB slabs = 16 units of two 1 KiB groups (hi, lo); 3 slots.  The xyz embedding (32 slots per lane) waits
+// in LDS between layer 1 and the skip at layer 5 instead of in registers: with one accumulator set in VGPRs (the compiler keeps
+// the set the vector ALU reads there) the kernel has no 32 registers to spare.
+#define NEFES_SLAB_KIB NEFES_H3_FWD_SLAB_KIB
+#include "field_common.h"
+#include "../../include/nefes_hip.h"
+
+#include "field_x6.h"
+#include "field_h3.h"
+#define NEFES_H3_SLOTS 3   // 96 KiB ring
+
+struct FieldFwdH3Args {
+    const char* stream;
+    const float* bias;       // bias blocks followed by the segment exponent table (NefesStreamInfo.scale_off)
+    uint32_t n_slabs, bias_floats, scale_off;
+    const float* rays_o;
+    const float* rays_d;
+    const float* z;
+    const float* pts;
+    const float* xyz_enc;    // [M,32] (NEFES_XYZ_EXTERNAL32) or null
+    const float* viewdirs;   // [N,3] (FULL)
+    float* raw_t;            // [N][R][S]
+    uint32_t* masks;         // [tiles32][MW][64] or null (FULL)
+    int N, S, R, C;
+    long long M;
+    int n_tiles;
+    uint32_t s_magic, s_shift;   // m / S == mulhi(m, s_magic) >> s_shift for every m < 2^31 (host: magic_div)
+};
+
+// MODE: NEFES_FIELD_SIGMA or NEFES_FIELD_FULL; ENC: NEFES_XYZ_FREQ10 or NEFES_XYZ_EXTERNAL32 (hash grid);
+// (W, NTR) = (256, 1) [C = 16] or (128, 5) [C = 128: the reference-default shape]
+template <int MODE, int ENC, int W = 256, int NTR = 1>
+__global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) {
+    constexpr int NTW = W / 32, NTH = W / 64;
+    constexpr int ES = ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : NEFES_E_STEPS;
+    constexpr int MW = 8 * (W / 64) + 4 * (W / 128), WT = (NTW + 1) / 2, WH = (NTH + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring_base = smem;
+    float* bias_lds = (float*)(smem + NEFES_H3_SLOTS * NEFES_SLAB_BYTES);
+    // embedding stash: [wave][ES slots][64 lanes] floats behind the bias block (launch_h3 sizes the allocation)
+    float* e_lds = bias_lds + ((a.bias_floats + 63) / 64) * 64 + (threadIdx.x >> 6) * (ES * 64) + (threadIdx.x & 63);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    for (uint32_t i = threadIdx.x; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
+    WeightRing<NEFES_H3_SLOTS> ring;
+    ring.init(a.stream, a.n_slabs, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_base, wave, lane);
+    __syncthreads();
+    const char* ring_lane = ring_base + lane * 16;
+    const char* bias_half = (const char*)bias_lds + 16 * h;
+    const int* wexp = (const int*)(bias_lds + a.scale_off);     // weight-scale exponent per segment (layout.h NEFES_H3F_*)
+    ring.prime(ring_lane);
+    // bias block offsets (floats), in stream order: L1..L8, SIG, FINAL, DIR, RGB, T0, T1, T2, TH (as in field_fwd.hip)
+    constexpr int B_SIG = 8 * W, B_FINAL = B_SIG + 32, B_DIR = B_FINAL + W, B_RGB = B_DIR + W / 2,
+                  B_T0 = B_RGB + 32 * NTR, B_T1 = B_T0 + W / 2, B_T2 = B_T1 + W / 2, B_TH = B_T2 + W / 2;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        // sample / ray indices are recomputed where they are needed (loads here, three output points below) rather than kept
+        // alive across the tile: every long-lived per-lane value costs a register the accumulators need (M < 2^31: host check)
+        auto locate = [&](uint32_t& m, uint32_t& ray, uint32_t& smp) {
+            const uint32_t m_raw = (uint32_t)tile * 128u + (uint32_t)(wave * 32 + j);
+            const bool ok = m_raw < (uint32_t)a.M;
+            m = ok ? m_raw : (uint32_t)a.M - 1u;
+            ray = a.s_magic ? __umulhi(m, a.s_magic) >> a.s_shift : m;   // = m / S without a reciprocal kept in a register
+            smp = m - ray * (uint32_t)a.S;
+            return ok;
+        };
+        uint32_t m, ray, smp;
+        locate(m, ray, smp);
+        float in_o[3] = {0.f, 0.f, 0.f}, in_d[3] = {0.f, 0.f, 0.f}, in_z = 0.f;
+        float E[ES];
+        if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+#pragma unroll
+            for (int s = 0; s < ES; ++s) E[s] = a.xyz_enc[(size_t)m * 32 + 2 * s + h];    // compact slots: feature 2s+h
+        } else if (a.pts) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) in_o[c] = a.pts[(size_t)m * 3 + c];
+        } else {
+            in_z = a.z[m];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { in_o[c] = a.rays_o[ray * 3 + c]; in_d[c] = a.rays_d[ray * 3 + c]; }
+        }
+        loads_landed();
+        pin(in_o); pin(in_d); pin(in_z);
+        float mE;                                                   // largest embedding magnitude of the sample
+        if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+            pin(E);
+            mE = pair_max(array_max(E));
+        } else {
+            float x[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[c] = a.pts ? in_o[c] : add_rn(in_o[c], mul_rn(in_d[c], in_z));   // rendering.py:114,142
+            embed_slots<NEFES_N_FREQ_XYZ>(E, x, h);
+            mE = fmaxf(fmaxf(1.f, fabsf(x[0])), fmaxf(fabsf(x[1]), fabsf(x[2])));   // sin/cos <= 1, then x itself
+        }
+        const int exE = pick_exp(mE);
+#pragma unroll
+        for (int s = 0; s < ES; ++s) e_lds[s * 64] = E[s];          // own lane's column only: no barrier needed
+        int mask_word = 0;
+        auto put_masks = [&](const uint32_t* bits, int n) {
+            if (MODE == NEFES_FIELD_FULL && a.masks) {
+                uint32_t* mask_tile = a.masks + ((size_t)((long long)tile * 4 + wave) * MW) * 64;      // wave-uniform
+                for (int w = 0; w < n; ++w) mask_tile[(mask_word + w) * 64 + lane] = bits[w];
+                mask_word += n;
+            }
+        };
+        // column of this lane's sample in raw_t (null for the padding lanes of the last tile)
+        auto raw_col = [&]() -> float* {
+            uint32_t mm, rr, ss;
+            if (!locate(mm, rr, ss)) return nullptr;
+            return a.raw_t + ((size_t)rr * a.R * a.S + ss);
+        };
+        auto bias_at = [&](int off_floats, int es) { return BiasInitScaled{bias_half + off_floats * 4, pow2i(es)}; };
+        f32x16 A[NTW], B[NTW];
+        uint32_t bits[WT];
+        auto clear_bits = [&]() {
+#pragma unroll
+            for (int w = 0; w < WT; ++w) bits[w] = 0u;
+        };
+        constexpr bool CAP = MODE == NEFES_FIELD_FULL;
+        float mx[2];            // largest value / magnitude of the tiles the latest product completed (per lane: pair_max combines)
+        // exponent for the next product's operand from that maximum, capped so that the output scale stays finite
+        auto next_exp = [&](float m_lane, int es_in, int ew) { return cap_exp(pick_exp(pair_max(m_lane)), es_in, ew); };
+        auto sigma_head = [&](const f32x16 (&X)[NTW], int es_x, int ex) {      // ex: the exponent chosen for relu(X)
+            f32x16 sg[1];
+            const int es = es_x + ex + wexp[NEFES_H3F_SIG];
+            float mx_[2];
+            mma_run_h3<1, W / 16, 0, true>(ring, ring_lane, ReluSplitH<false, NTW, WT>{X, bits, pow2i(ex)}, bias_at(B_SIG, es), sg, mx_);
+            float* col = raw_col();
+            if (col && h == 0) {
+                const int ch = (MODE == NEFES_FIELD_SIGMA) ? 0 : 3 + a.C;
+                col[(size_t)ch * a.S] = softplus_ref(sg[0][0] * pow2i(-es));
+            }
+        };
+        int es_a, es_b = 0;
+        {
+            const int ex = cap_exp(exE, 0, wexp[NEFES_H3F_L1]);
+            es_a = ex + wexp[NEFES_H3F_L1];
+            mma_run_h3<NTW, ES / 8, 0, true, 1>(ring, ring_lane, LdsSplitH{e_lds, pow2i(ex)}, bias_at(0, es_a), A, mx);       // layer 1
+        }
+#pragma unroll 1
+        for (int p = 0; p < 4; ++p) {
+            const int l1 = 2 + 2 * p, l2 = l1 + 1;
+            const int seg1 = l1 <= 5 ? l1 - 1 : l1;                                    // layout.h NEFES_H3F_*: L5 is two segments
+            const int seg2 = l2 <= 5 ? l2 - 1 : (l2 <= 8 ? l2 : NEFES_H3F_FINAL);
+            clear_bits();
+            {
+                const int ew = wexp[seg1], ex = next_exp(mx[0], es_a, ew);
+                es_b = es_a + ex + ew;
+                mma_run_h3<NTW, W / 16, 0, true, 1>(ring, ring_lane, ReluSplitH<CAP, NTW, WT>{A, bits, pow2i(ex)}, bias_at((l1 - 1) * W, es_b), B, mx);   // layers 2, 4, 6, 8
+            }
+            put_masks(bits, WT);                                                                      // mask of layer l1-1
+            if (p == 3 && MODE == NEFES_FIELD_SIGMA) break;
+            clear_bits();
+            {
+                const int ew = wexp[seg2];
+                int ex = next_exp(mx[0], es_b, ew);
+                if (p == 3) sigma_head(B, es_b, cap_exp(ex, es_b, wexp[NEFES_H3F_SIG]));   // static_sigma reads the same relu(h8) as xyz_encoding_final
+                // skip layer: its xyz part accumulates into the same tiles, so the embedding must fit the common scale too
+                if (p == 1) ex = (es_b + ex <= exE) ? ex : exE - es_b;
+                es_a = es_b + ex + ew;
+                // the run that completes the tiles reports their maximum: values for the ReLU consumers, magnitudes behind
+                // xyz_encoding_final (no activation: abs_too); at the skip layer the xyz part completes them and reports
+                mma_run_h3<NTW, W / 16, 0, true, 1>(ring, ring_lane, ReluSplitH<CAP, NTW, WT>{B, bits, pow2i(ex)},
+                                                    bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL, es_a), A, mx, p == 3);   // 3, 5, 7, final
+                if (p == 1) mma_run_h3<NTW, ES / 8, 0, false, 1>(ring, ring_lane, LdsSplitH{e_lds, pow2i(es_b + ex)}, ZeroInit{}, A, mx);   // skip: + W5[:, :63] e
+            }
+            put_masks(bits, WT);                                                                      // mask of layer l1
+        }
+        if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head(B, es_b, next_exp(mx[0], es_b, wexp[NEFES_H3F_SIG]));
+        if constexpr (MODE == NEFES_FIELD_FULL) {
+            // dir_encoding and transient_encoding.0 as ONE stacked 2*NTH-tile product (pack.cpp add_heads_x6): tiles
+            // [0, NTH) = dir, [NTH, 2 NTH) = t0
+            // The view direction is fetched here, not at the top of the tile (three registers across the whole trunk).  A
+            // compiler-issued load must never overlap the weight ring's LDS-DMA (field_common.h), so the ring is drained
+            // around it: once per 128 samples, the slabs in flight land while the load's own latency passes.
+            float v[3];
+            {
+                uint32_t mm, rr, ss;
+                locate(mm, rr, ss);
+                ring.drain();
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[(size_t)rr * 3 + c];
+                loads_landed();
+                pin(v);
+            }
+            float Dv[16];                                              // 14 embedding slots + 2 padding slots (two 16-k steps)
+            {
+                float d14[NEFES_D_STEPS];
+                embed_slots<NEFES_N_FREQ_DIR>(d14, v, h);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) Dv[s] = s < NEFES_D_STEPS ? d14[s] : 0.f;
+            }
+            f32x16 dt[2 * NTH], acc3[NTH], acc2[NTH];
+            uint32_t bits2[WH];
+            auto clear2 = [&]() {
+#pragma unroll
+                for (int w = 0; w < WH; ++w) bits2[w] = 0u;
+            };
+            struct Bias2 {             // C operands of the stacked product: dir bias tiles, then t0 bias tiles
+                BiasInitScaled a, b;
+                __device__ __forceinline__ f32x16 operator()(int t) const { return t < NTH ? a(t) : b(t - NTH); }
+            };
+            int es_dt;
+            {
+                const int ew = wexp[NEFES_H3F_DT_H];
+                const int exD = pick_exp(pair_max(array_max(Dv)));                   // direction embedding (<= 1 for unit view dirs)
+                int ex = next_exp(mx[0], es_a, ew);
+                ex = (es_a + ex <= exD) ? ex : exD - es_a;                          // common scale with the direction part
+                es_dt = es_a + ex + ew;
+                mma_run_h3<2 * NTH, W / 16, 0, true>(ring, ring_lane, IdentSplitH<NTW, 0>{A, pow2i(ex)},
+                                                     Bias2{bias_at(B_DIR, es_dt), bias_at(B_T0, es_dt)}, dt, mx);
+                mma_run_h3<2 * NTH, 2, 0, false, 1, NTH>(ring, ring_lane, ArraySplitH<16>{Dv, pow2i(es_a + ex)}, ZeroInit{}, dt, mx);
+            }
+            {
+                f32x16 ar[NTR];
+                clear2();
+                const int ew = wexp[NEFES_H3F_RGB];
+                const int ex = next_exp(mx[0], es_dt, ew);                // dir_encoding tiles
+                const int es = es_dt + ex + ew;
+                float mx_[2];
+                mma_run_h3<NTR, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, 2 * NTH, WH>{dt, bits2, pow2i(ex)}, bias_at(B_RGB, es), ar, mx_);
+                put_masks(bits2, WH);                                 // dir_encoding
+                float* col = raw_col();
+                if (col) {
+                    float* ph = col + (size_t)(4 * h) * a.S;
+                    const float inv = pow2i(-es);
+#pragma unroll
+                    for (int t = 0; t < NTR; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int cu = 32 * t + nefes_rho(0, r);
+                            if (cu + 4 * h < 3 + a.C) ph[(size_t)cu * a.S] = ar[t][r] * inv;
+                        }
+                }
+            }
+            int es3, es2, es_th;
+            clear2();
+            {
+                const int ew = wexp[NEFES_H3F_T1];
+                const int ex = next_exp(mx[1], es_dt, ew);                // transient_encoding.0 tiles
+                es3 = es_dt + ex + ew;
+                mma_run_h3<NTH, W / 32, 0, true, 1>(ring, ring_lane, ReluSplitH<true, 2 * NTH, WH, NTH>{dt, bits2, pow2i(ex)}, bias_at(B_T1, es3), acc3, mx);
+            }
+            put_masks(bits2, WH);                                     // transient_encoding.0
+            clear2();
+            {
+                const int ew = wexp[NEFES_H3F_T2];
+                const int ex = next_exp(mx[0], es3, ew);
+                es2 = es3 + ex + ew;
+                mma_run_h3<NTH, W / 32, 0, true, 1>(ring, ring_lane, ReluSplitH<true, NTH, WH>{acc3, bits2, pow2i(ex)}, bias_at(B_T2, es2), acc2, mx);
+            }
+            put_masks(bits2, WH);                                     // transient_encoding.2
+            f32x16 th[1];
+            clear2();
+            {
+                const int ew = wexp[NEFES_H3F_TH];
+                const int ex = next_exp(mx[0], es2, ew);
+                es_th = es2 + ex + ew;
+                float mx_[2];
+                mma_run_h3<1, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, NTH, WH>{acc2, bits2, pow2i(ex)}, bias_at(B_TH, es_th), th, mx_);
+            }
+            put_masks(bits2, WH);
+            float* col = raw_col();
+            if (col) {
+                float* o = col + (size_t)(3 + a.C + 1) * a.S;
+                const float inv = pow2i(-es_th);
+                if (h == 0) {
+                    o[0] = sigmoid_ref(th[0][0] * inv);
+                    o[(size_t)a.S] = sigmoid_ref(th[0][1] * inv);
+                    o[(size_t)2 * a.S] = sigmoid_ref(th[0][2] * inv);
+                    o[(size_t)3 * a.S] = softplus_ref(th[0][3] * inv);
+                } else {
+                    o[(size_t)4 * a.S] = softplus_ref(th[0][0] * inv);
+                }
+            }
+        }
+    }
+    ring.drain();
+}
+
+// magic multiplier for unsigned division by d, exact for dividends below 2^31: q = mulhi(n, magic) >> shift
+static void magic_div(uint32_t d, uint32_t& magic, uint32_t& shift) {
+    if (d == 1) { magic = 0; shift = 0; return; }               // the kernel takes magic == 0 as "quotient = dividend"
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;                               // l = ceil(log2 d), 1..31
+    const uint64_t p = 31 + l;                                 // n < 2^31: error bound 2^31 / 2^p * ... <= 1/d
+    magic = (uint32_t)(((1ull << p) + d - 1) / d);             // ceil(2^p / d) < 2^32 because d > 2^(l-1)
+    shift = (uint32_t)(p - 32);
+}
+
+template <int MODE, int ENC, int W = 256, int NTR = 1>
+static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
+    constexpr int ES_ = ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : NEFES_E_STEPS;
+    const size_t lds = (size_t)NEFES_H3_SLOTS * NEFES_SLAB_BYTES + ((a.bias_floats + 63) / 64) * 256 + (size_t)4 * ES_ * 64 * 4;
+    auto k = field_fwd_h3_kernel<MODE, ENC, W, NTR>;
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int grid = a.n_tiles < cus ? a.n_tiles : cus;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+// Kernel instances spread over two objects built from this one source (Makefile: -DNEFES_TU_PART=0..1): part 0 = entry point +
+// the Wd = 256 frequency-embedding instances, part 1 = hash-grid and Wd = 128 instances.
+#ifndef NEFES_TU_PART
+#define NEFES_TU_PART 0
+#endif
+enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_128_SIGMA, H3_128_FULL };
+int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st);
+
+#if NEFES_TU_PART == 1
+int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st) {
+    switch (which) {
+        case H3_EXT_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32>(a, st);
+        case H3_EXT_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32>(a, st);
+        case H3_128_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5>(a, st);
+        case H3_128_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5>(a, st);
+    }
+    return NEFES_E_UNSUPPORTED;
+}
+#else   // part 0
+
+extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                                  const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
+                                  const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
+    if (!desc || !packed || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
+    const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
+    if (ext ? !xyz_enc : (!pts && !(rays_o && rays_d && z))) return NEFES_E_BADARG;
+    if (mode != NEFES_FIELD_SIGMA && mode != NEFES_FIELD_FULL) return NEFES_E_UNSUPPORTED;
+    if (mode == NEFES_FIELD_FULL && (!viewdirs || !desc->has_transient)) return NEFES_E_BADARG;
+    const bool big = desc->width == 256 && desc->feat_dim == 16, small = desc->width == 128 && desc->feat_dim == 128 && !ext;
+    if (!(big || small) || (desc->xyz_encoding != NEFES_XYZ_FREQ10 && !ext)) return NEFES_E_UNSUPPORTED;
+    NefesBlobInfo info;
+    int rc = nefes_blob_info(desc, &info);
+    if (rc) return rc;
+    const NefesStreamInfo& si = info.stream[mode == NEFES_FIELD_SIGMA ? NEFES_STREAM_FWD_SIGMA_H3 : NEFES_STREAM_FWD_FULL_H3];
+    if (si.n_slabs == 0) return NEFES_E_UNSUPPORTED;
+    FieldFwdH3Args a;
+    a.stream = (const char*)packed + si.slab_off;
+    a.bias = (const float*)((const char*)packed + si.bias_off);
+    a.n_slabs = si.n_slabs; a.bias_floats = si.bias_floats; a.scale_off = si.scale_off;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.xyz_enc = xyz_enc; a.viewdirs = viewdirs; a.raw_t = raw_t; a.masks = masks;
+    a.N = N; a.S = S; a.C = desc->feat_dim; a.R = mode == NEFES_FIELD_SIGMA ? 1 : 3 + a.C + 6;
+    a.M = (long long)N * S;
+    if (a.M >= (1ll << 31) - 256) return NEFES_E_UNSUPPORTED;      // the kernel indexes samples with 32 bits
+    a.n_tiles = (int)((a.M + 127) / 128);
+    magic_div((uint32_t)S, a.s_magic, a.s_shift);
+    hipStream_t st = (hipStream_t)stream;
+    if (small) return nefes_fwd_h3_launch_part1(mode == NEFES_FIELD_SIGMA ? H3_128_SIGMA : H3_128_FULL, a, st);
+    if (ext) return nefes_fwd_h3_launch_part1(mode == NEFES_FIELD_SIGMA ? H3_EXT_SIGMA : H3_EXT_FULL, a, st);
+    if (mode == NEFES_FIELD_SIGMA) return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10>(a, st);
+    return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10>(a, st);
+}
+#endif   // NEFES_TU_PART

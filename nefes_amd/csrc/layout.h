@@ -85,7 +85,7 @@ enum { NEFES_STREAM_FWD_SIGMA = 0, NEFES_STREAM_FWD_STATIC = 1, NEFES_STREAM_FWD
        NEFES_STREAM_FWD_SIGMA_H3 = 8, NEFES_STREAM_FWD_FULL_H3 = 9, NEFES_STREAM_BWD_FULL_H3 = 10,
        NEFES_N_STREAMS = 11 };
 #define NEFES_X6_SLAB_KIB 48
-#define NEFES_H3_FWD_SLAB_KIB 48       /* 24 units of 2 KiB */
+#define NEFES_H3_FWD_SLAB_KIB 32       /* 16 units of 2 KiB (3 slots = 96 KiB: the embedding is parked in LDS beside the ring) */
 #define NEFES_H3_BWD_SLAB_KIB 32       /* 16 units */
 #define NEFES_H3_TARGET_EXP 14         /* operands are scaled so that the largest magnitude lies in [2^14, 2^15) */
 NEFES_HD int nefes_stream_slab_kib(int stream) {

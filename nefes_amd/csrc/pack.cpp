@@ -199,37 +199,43 @@ std::vector<int> rows_xyz(const Net& n, int base) {
     return r;
 }
 
-void add_trunk(const Net& n, Stream& st, bool x6 = false) {
+// split kind of a stream's hidden products: 0 = fp32 fragments, 1 = bf16x6 triples, 2 = fp16 (hi, lo) pairs
+static void mark(Seg& s, int kind) {
+    s.x6 = kind != 0;
+    s.h3 = kind == 2;
+}
+
+void add_trunk(const Net& n, Stream& st, int x6 = 0) {
     const int W = n.W, NT = n.NTW;
     for (int l = 0; l < 8; ++l) {
         if (l == 0) {
             st.segs.push_back(seg(NT, n.e_steps, k_xyz(n, 0), rows_natural(NT, W), n.w(0), n.in_xyz));
-            st.segs.back().x6 = x6;
+            mark(st.segs.back(), x6);
         } else if (l == 4) {  // skip layer: columns [xyz(63), h(W)]  (nerfh_nff.py:472-473,551-552)
             // the kernels accumulate the hidden part first (its first k-step carries the bias), then the xyz part
             st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, n.in_xyz), rows_natural(NT, W), n.w(4), n.in_xyz + W));
-            st.segs.back().x6 = x6;
+            mark(st.segs.back(), x6);
             st.segs.push_back(seg(NT, n.e_steps, k_xyz(n, 0), rows_natural(NT, W), n.w(4), n.in_xyz + W));
-            st.segs.back().x6 = x6;
+            mark(st.segs.back(), x6);
         } else {
             st.segs.push_back(seg(NT, W / 2, k_natural(W / 2, 0), rows_natural(NT, W), n.w(l), W));
-            st.segs.back().x6 = x6;
+            mark(st.segs.back(), x6);
         }
         st.bias.push_back({n.b(l), rows_natural(NT, W)});
     }
     // static sigma head: one tile, row 0
     st.segs.push_back(seg(1, W / 2, k_natural(W / 2, 0), rows_natural(1, 1), n.w(L_SIGMA), W));
-    st.segs.back().x6 = x6;
+    mark(st.segs.back(), x6);
     st.bias.push_back({n.b(L_SIGMA), rows_natural(1, 1)});
 }
 
-void add_static_head(const Net& n, Stream& st, bool x6 = false) {
+void add_static_head(const Net& n, Stream& st, int x6 = 0) {
     const int W = n.W, W2 = n.W2;
     st.segs.push_back(seg(n.NTW, W / 2, k_natural(W / 2, 0), rows_natural(n.NTW, W), n.w(L_FINAL), W));
-    st.segs.back().x6 = x6;                                            // xyz_encoding_final: a 256x256 product like the trunk
+    mark(st.segs.back(), x6);                                          // xyz_encoding_final: a 256x256 product like the trunk
     st.bias.push_back({n.b(L_FINAL), rows_natural(n.NTW, W)});
     st.segs.push_back(seg(n.NTH, W / 2, k_natural(W / 2, 0), rows_natural(n.NTH, W2), n.w(L_DIR), W + 27));
-    st.segs.back().x6 = x6;
+    mark(st.segs.back(), x6);
     st.segs.push_back(seg(n.NTH, NEFES_D_STEPS, k_emb(4, NEFES_D_STEPS, W), rows_natural(n.NTH, W2), n.w(L_DIR), W + 27));
     st.bias.push_back({n.b(L_DIR), rows_natural(n.NTH, W2)});
     st.segs.push_back(seg(n.NTR, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTR, 3 + n.C), n.w(L_RGB), W2));
@@ -240,32 +246,32 @@ void add_static_head(const Net& n, Stream& st, bool x6 = false) {
 // product with 2*NTH tiles (rows: dir | t0): one operand split instead of two, and the standard 8-tile shape at Wd = 256.
 // Segment order: FINAL, [DIR;T0] hidden part, [DIR;T0] direction part, RGB, T1, T2, TH (all x6); bias blocks keep the
 // order of the fp32 streams (FINAL, DIR, RGB, T0, T1, T2, TH).
-void add_heads_x6(const Net& n, Stream& st) {
+void add_heads_x6(const Net& n, Stream& st, int kind = 1) {
     const int W = n.W, W2 = n.W2;
     st.segs.push_back(seg(n.NTW, W / 2, k_natural(W / 2, 0), rows_natural(n.NTW, W), n.w(L_FINAL), W));
-    st.segs.back().x6 = true;
+    mark(st.segs.back(), kind);
     st.bias.push_back({n.b(L_FINAL), rows_natural(n.NTW, W)});
     st.segs.push_back(seg(2 * n.NTH, W / 2, k_natural(W / 2, 0), rows_natural(2 * n.NTH, 2 * W2), n.dt_w.data(), W + 27));
-    st.segs.back().x6 = true;
+    mark(st.segs.back(), kind);
     // direction part: 14 k-steps padded to 16 (= two 16-k steps; slots 14, 15 are padding)
     st.segs.push_back(seg(2 * n.NTH, 16, k_emb(4, 16, W), rows_natural(2 * n.NTH, 2 * W2), n.dt_w.data(), W + 27));
-    st.segs.back().x6 = true;
+    mark(st.segs.back(), kind);
     st.bias.push_back({n.b(L_DIR), rows_natural(n.NTH, W2)});
     st.segs.push_back(seg(n.NTR, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTR, 3 + n.C), n.w(L_RGB), W2));
-    st.segs.back().x6 = true;
+    mark(st.segs.back(), kind);
     st.bias.push_back({n.b(L_RGB), rows_natural(n.NTR, 3 + n.C)});
     st.bias.push_back({n.b(L_T0), rows_natural(n.NTH, W2)});
     for (int l = L_T1; l <= L_T2; ++l) {
         st.segs.push_back(seg(n.NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTH, W2), n.w(l), W2));
-        st.segs.back().x6 = true;
+        mark(st.segs.back(), kind);
         st.bias.push_back({n.b(l), rows_natural(n.NTH, W2)});
     }
     st.segs.push_back(seg(1, W2 / 2, k_natural(W2 / 2, 0), rows_natural(1, 5), n.th_w.data(), W2));
-    st.segs.back().x6 = true;
+    mark(st.segs.back(), kind);
     st.bias.push_back({n.th_b.data(), rows_natural(1, 5)});
 }
 
-void add_transient_head(const Net& n, Stream& st, bool x6 = false) {
+void add_transient_head(const Net& n, Stream& st, int x6 = 0) {
     const int W = n.W, W2 = n.W2;
     // (transient_encoding.0 stays fp32: with both it and dir_encoding on bf16x6 the forward kernel spills registers)
     st.segs.push_back(seg(n.NTH, W / 2, k_natural(W / 2, 0), rows_natural(n.NTH, W2), n.w(L_T0), W + 27));
@@ -273,7 +279,7 @@ void add_transient_head(const Net& n, Stream& st, bool x6 = false) {
     st.bias.push_back({n.b(L_T0), rows_natural(n.NTH, W2)});
     for (int l = L_T1; l <= L_T2; ++l) {
         st.segs.push_back(seg(n.NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTH, W2), n.w(l), W2));
-        st.segs.back().x6 = x6;
+        mark(st.segs.back(), x6);
         st.bias.push_back({n.b(l), rows_natural(n.NTH, W2)});
     }
     st.segs.push_back(seg(1, W2 / 2, k_natural(W2 / 2, 0), rows_natural(1, 5), n.th_w.data(), W2));
@@ -281,7 +287,7 @@ void add_transient_head(const Net& n, Stream& st, bool x6 = false) {
 }
 
 // backward-to-inputs stream: A operand = W^T, B operand = upstream gradient vector
-void add_backward(const Net& n, Stream& st, bool x6 = false, bool transient = true) {
+void add_backward(const Net& n, Stream& st, int x6 = 0, bool transient = true) {
     const int W = n.W, W2 = n.W2, NTW = n.NTW, NTH = n.NTH;
     // static rgb/feature head^T first (its 3+C upstream values are consumed straight after the tile's loads):
     // in = 3+C grads (compact slots), out = d g
@@ -291,21 +297,21 @@ void add_backward(const Net& n, Stream& st, bool x6 = false, bool transient = tr
     // transient heads^T: in = 5 pre-activation grads (compact slots), out = d t2
     st.segs.push_back(seg(NTH, 3, k_compact(3, 5), rows_natural(NTH, W2), n.th_w.data(), W2, true));
     st.segs.push_back(seg(NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(NTH, W2), n.w(L_T2), W2, true));
-    st.segs.back().x6 = x6;
+    mark(st.segs.back(), x6);
     st.segs.push_back(seg(NTH, W2 / 2, k_natural(W2 / 2, 0), rows_natural(NTH, W2), n.w(L_T1), W2, true));
-    st.segs.back().x6 = x6;
+    mark(st.segs.back(), x6);
     }
     // [transient_encoding.0 ; dir_encoding]^T: out rows = dir-embedding slots (1 tile) then final features (NTW tiles)
     std::vector<int> rows_fd = concat(rows_emb(4, 1, W), rows_natural(NTW, W));
     if (transient) {
         st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_T0), W + 27, true));
-        st.segs.back().x6 = x6;
+        mark(st.segs.back(), x6);
     }
     st.segs.push_back(seg(NTW + 1, W2 / 2, k_natural(W2 / 2, 0), rows_fd, n.w(L_DIR), W + 27, true));
-    st.segs.back().x6 = x6;
+    mark(st.segs.back(), x6);
     // xyz_encoding_final^T, plus the static-sigma head as one extra k-step
     st.segs.push_back(seg(NTW, W / 2, k_natural(W / 2, 0), rows_natural(NTW, W), n.w(L_FINAL), W, true));
-    st.segs.back().x6 = x6;
+    mark(st.segs.back(), x6);
     st.segs.push_back(seg(NTW, 1, k_compact(1, 1), rows_natural(NTW, W), n.w(L_SIGMA), W, true));
     for (int l = 7; l >= 0; --l) {
         if (l == 4) {
@@ -314,16 +320,55 @@ void add_backward(const Net& n, Stream& st, bool x6 = false, bool transient = tr
             std::vector<int> rows = concat(re, rows_natural(NTW, W));
             for (int i = (int)re.size(); i < (int)rows.size(); ++i) rows[i] += n.in_xyz;
             st.segs.push_back(seg(NTW + (int)re.size() / 32, W / 2, k_natural(W / 2, 0), rows, n.w(4), n.in_xyz + W, true));
-            st.segs.back().x6 = x6;
+            mark(st.segs.back(), x6);
         } else if (l == 0) {
             const std::vector<int> re = rows_xyz(n, 0);
             st.segs.push_back(seg((int)re.size() / 32, W / 2, k_natural(W / 2, 0), re, n.w(0), n.in_xyz, true));
-            st.segs.back().x6 = x6;
+            mark(st.segs.back(), x6);
         } else {
             st.segs.push_back(seg(NTW, W / 2, k_natural(W / 2, 0), rows_natural(NTW, W), n.w(l), W, true));
-            st.segs.back().x6 = x6;
+            mark(st.segs.back(), x6);
         }
     }
+}
+
+// Elements of the weight matrix a segment reads (the whole torch tensor, or one of the virtual stacked matrices).
+static size_t matrix_elems(const Net& n, const float* Wm) {
+    if (Wm == n.th_w.data()) return n.th_w.size();
+    if (Wm == n.dt_w.data()) return n.dt_w.size();
+    const int W = n.W, W2 = n.W2;
+    for (int l = 0; l < 18; ++l) {
+        if (n.t[2 * l] != Wm) continue;
+        if (l < 8) return (size_t)W * (l == 0 ? n.in_xyz : (l == 4 ? n.in_xyz + W : W));
+        if (l == L_FINAL) return (size_t)W * W;
+        if (l == L_DIR || l == L_T0) return (size_t)W2 * (W + 27);
+        if (l == L_SIGMA) return (size_t)W;
+        if (l == L_RGB) return (size_t)(3 + n.C) * W2;
+        if (l == L_T1 || l == L_T2) return (size_t)W2 * W2;
+        if (l == L_TRGB) return (size_t)3 * W2;
+        return (size_t)W2;
+    }
+    return 0;
+}
+static float abs_max(const float* p, size_t cnt) {
+    float m = 0.f;
+    for (size_t i = 0; i < cnt; ++i) {
+        const float a = fabsf(p[i]);
+        if (a > m) m = a;
+    }
+    return m;
+}
+// fp16 segments: one power-of-two scale per weight MATRIX (all segments reading a matrix -- e.g. the hidden and the xyz part of
+// layer 5 -- accumulate into the same tiles and must agree); dir_encoding and transient_encoding.0 count as one matrix (their
+// products share accumulators in both directions).
+static void assign_weight_exponents(const Net& n, Stream (&st)[NEFES_N_STREAMS]) {
+    const int e_dt = n.transient ? scale_exp(abs_max(n.dt_w.data(), n.dt_w.size())) : 0;
+    for (auto& stream : st)
+        for (auto& sg : stream.segs) {
+            if (!sg.h3 || !sg.W) continue;
+            const bool dt = sg.W == n.dt_w.data() || (n.transient && (sg.W == n.w(L_DIR) || sg.W == n.w(L_T0)));
+            sg.wexp = dt ? e_dt : scale_exp(abs_max(sg.W, matrix_elems(n, sg.W)));
+        }
 }
 
 bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&st)[NEFES_N_STREAMS]) {
@@ -370,17 +415,24 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
     }
     const bool big = n.W == 256, small = n.W == 128 && n.C == 128 && !n.ext;   // shapes with bf16x6 instances (layout.h)
     if (big || small) {
-        add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_X6], true);
+        add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_X6], 1);
+        add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_H3], 2);
+        st[NEFES_STREAM_FWD_SIGMA_H3].h3 = true;
         if (n.transient && (small || n.C == 16)) {
-            add_trunk(n, st[NEFES_STREAM_FWD_FULL_X6], true);
+            add_trunk(n, st[NEFES_STREAM_FWD_FULL_X6], 1);
             add_heads_x6(n, st[NEFES_STREAM_FWD_FULL_X6]);
-            add_backward(n, st[NEFES_STREAM_BWD_FULL_X6], true);
+            add_backward(n, st[NEFES_STREAM_BWD_FULL_X6], 1);
+            add_trunk(n, st[NEFES_STREAM_FWD_FULL_H3], 2);
+            add_heads_x6(n, st[NEFES_STREAM_FWD_FULL_H3], 2);
+            add_backward(n, st[NEFES_STREAM_BWD_FULL_H3], 2);
+            st[NEFES_STREAM_FWD_FULL_H3].h3 = st[NEFES_STREAM_BWD_FULL_H3].h3 = true;
         }
     }
+    if (tensors) assign_weight_exponents(n, st);
     return true;
 }
 
-const uint64_t kHeaderBytes = 256;
+const uint64_t kHeaderBytes = 512;
 uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 void fill_info(const Stream (&st)[NEFES_N_STREAMS], NefesBlobInfo* info) {
@@ -390,7 +442,9 @@ void fill_info(const Stream (&st)[NEFES_N_STREAMS], NefesBlobInfo* info) {
         const int kib = nefes_stream_slab_kib(k);
         si.n_slabs = (uint32_t)st[k].n_slabs(NEFES_FRAGS_OF_KIB(kib));
         si.bias_floats = (uint32_t)st[k].bias_floats();
-        if (si.n_slabs == 0) { si.slab_off = si.bias_off = 0; si.bias_floats = 0; continue; }
+        si.scale_off = (uint32_t)st[k].bias_only();
+        si.scale_count = (uint32_t)st[k].scale_count();
+        if (si.n_slabs == 0) { si.slab_off = si.bias_off = 0; si.bias_floats = si.scale_off = si.scale_count = 0; continue; }
         si.bias_off = off;
         off = align_up(off + 4ull * si.bias_floats, 256);
         si.slab_off = off;
@@ -446,10 +500,39 @@ static int pack_walk(const NefesNetDesc* desc, const float* const* tensors, char
                 if (map) { map[boff / 2] = code(v, 0); map[boff / 2 + 1] = code(v, 1); }
                 boff += 4;
             }
+        if (st[k].h3) {   // weight-scale exponent table: one int32 per segment, padded to a multiple of four
+            for (int i = 0; i < st[k].scale_count(); ++i) {
+                const int32_t e = i < (int)st[k].segs.size() ? st[k].segs[i].wexp : 0;
+                if (base) memcpy(base + boff, &e, 4);
+                if (map) map[boff / 2] = map[boff / 2 + 1] = 0;     // (the device re-pack does not produce fp16 streams)
+                boff += 4;
+            }
+        }
         uint64_t soff = si.slab_off;
         const int frags = NEFES_FRAGS_OF_KIB(nefes_stream_slab_kib(k));
         const uint64_t slab_bytes = (uint64_t)frags * 256;
         for (auto& sg : st[k].segs) {
+            if (sg.h3) {   // units of two 1 KiB groups (hi, lo): lane = 8 fp16 of W 2^wexp = A operand of one 32x32x16 f16 MFMA
+                const int ups = (frags / 4) / 2;
+                for (int sl = 0; sl < sg.slabs(frags); ++sl, soff += slab_bytes) {
+                    for (int uu = 0; uu < ups && sl * ups + uu < sg.units(); ++uu) {
+                        const int u = sl * ups + uu, q = u / sg.nt, t = u % sg.nt;
+                        const uint64_t grp = soff + (uint64_t)uu * 2048;
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int i = 0; i < 8; ++i) {
+                                const float v = sg.at16(q, i, t, lane);
+                                uint16_t part[2] = {0, 0};
+                                if (!map) split_f16x2(v, sg.wexp, part);
+                                for (int pp = 0; pp < 2; ++pp) {
+                                    const uint64_t o = grp + 2ull * (pp * 512 + lane * 8 + i);
+                                    if (base) memcpy(base + o, &part[pp], 2);
+                                    if (map) map[o / 2] = 0;
+                                }
+                            }
+                    }
+                }
+                continue;
+            }
             if (sg.x6) {   // units of three 1 KiB groups (hi, mid, lo): lane = 8 bf16 = A operand of one 32x32x16 MFMA
                 const int ups = (frags / 4) / 3;
                 for (int sl = 0; sl < sg.slabs(frags); ++sl, soff += slab_bytes) {

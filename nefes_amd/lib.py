@@ -19,11 +19,12 @@ class NefesNetDesc(C.Structure):
 
 
 class NefesStreamInfo(C.Structure):
-    _fields_ = [("slab_off", C.c_uint64), ("n_slabs", C.c_uint32), ("bias_floats", C.c_uint32), ("bias_off", C.c_uint64)]
+    _fields_ = [("slab_off", C.c_uint64), ("n_slabs", C.c_uint32), ("bias_floats", C.c_uint32), ("bias_off", C.c_uint64),
+                ("scale_off", C.c_uint32), ("scale_count", C.c_uint32)]
 
 
 class NefesBlobInfo(C.Structure):
-    _fields_ = [("total_bytes", C.c_uint64), ("stream", NefesStreamInfo * 8)]
+    _fields_ = [("total_bytes", C.c_uint64), ("stream", NefesStreamInfo * 11)]
 
 
 class NefesHashGridDesc(C.Structure):
@@ -33,6 +34,7 @@ class NefesHashGridDesc(C.Structure):
 
 ABI_VERSION = 7        # NEFES_ABI_VERSION of include/nefes_hip.h
 STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6, STREAM_BWD_FULL_X6, STREAM_BWD_STATIC = 0, 1, 2, 3, 4, 5, 6, 7
+STREAM_FWD_SIGMA_H3, STREAM_FWD_FULL_H3, STREAM_BWD_FULL_H3 = 8, 9, 10
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
 XYZ_FREQ10, XYZ_EXTERNAL32 = 0, 1
 (TB_E, TB_DV, TB_L1, TB_FINAL, TB_DIR, TB_T0, TB_T1, TB_T2, TB_RGB, TB_SIG, TB_TH, TB_END) = (0, 1, 2, 10, 11, 12, 13, 14, 15, 16,
@@ -70,6 +72,8 @@ SIGNATURES = {
     "nefes_field_fwd_x6": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_bwd_x3": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_fwd_x3": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_field_bwd_h3": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_field_fwd_h3": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_train_rows": (_sz, [_desc]),
     "nefes_train_row_offset": (_i, [_desc, _i]),
     "nefes_field_fwd_train": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -191,6 +191,7 @@ class PackedField:
         self.blob = blob.to(device)
         self.info = info
         self.generation = 0          # bumped by repack(); autograd nodes refuse to run backward across it
+        self.h3_valid = True         # the fp16 two-part streams are written by the host packer only (repack() leaves them stale)
         self._map = None
 
     def repack(self, params):
@@ -210,6 +211,7 @@ class PackedField:
         L.check(lib.nefes_pack_device(flat.data_ptr(), flat.numel(), self._map.data_ptr(), self._map.numel(), self.blob.data_ptr(),
                                       _stream()), "nefes_pack_device")
         self.generation += 1
+        self.h3_valid = False        # the kernels fall back to the bf16x6 instances for this network from here on
 
     def check_generation(self, gen):
         if gen != self.generation:
@@ -238,9 +240,12 @@ def field_fwd(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, pts
     return raw_t, masks
 
 
-# Forward passes at the headline shape (width 256, C = 16) run the hidden 256x256 products as bf16x6 split products on
-# v_mfma_f32_32x32x16_bf16 (csrc/field_fwd_x6.hip: fp32-level accuracy, checked against the float64 oracle in
-# tests/test_gpu_x6.py).  Set False (or NEFES_X6=0) for the plain fp32-MFMA kernels.
+# Which matrix-core arithmetic the field kernels use where an instance exists (width 256 / C = 16, width 128 / C = 128):
+#   "h3"  (default) fp16 two-part split products, three cross terms on v_mfma_f32_32x32x16_f16 (csrc/field_h3.h): fp32-level
+#         accuracy at half the matrix-core work of bf16x6; tests/test_gpu_h3.py against the float64 oracle
+#   "x6"  bf16x6 split products (csrc/field_x6.h): the round-1 default; also what trainable / re-packed networks use
+#   "f32" the plain fp32-MFMA kernels (NEFES_X6=0 selects them too)
+SPLIT = os.environ.get("NEFES_SPLIT", "h3")
 USE_X6 = os.environ.get("NEFES_X6", "1") != "0"
 # Number of cross products of the split: 6 (default: fp32-level accuracy) or 3 (opt-in, NEFES_X6_PRODUCTS=3: operands carried
 # to 16 bits, ~5e-6 of the output scale, half the matrix-core work; the shapes with bf16x6 instances -- nefes_field_fwd_x3 / _bwd_x3).
@@ -261,15 +266,24 @@ def x6_supported(pk: PackedField, mode, forward=True):
     return ok and (mode == L.FIELD_SIGMA or (mode == L.FIELD_FULL and pk.has_transient))
 
 
+def _h3(pk):
+    """fp16 two-part instances apply: selected, this network's fp16 streams are current, and M fits the kernels' 32-bit index."""
+    if SPLIT not in ("h3", "x6", "f32"):
+        raise ValueError("nefes_amd.ops.SPLIT must be 'h3', 'x6' or 'f32'")
+    return SPLIT == "h3" and pk.h3_valid and X6_PRODUCTS == 6
+
+
 def field_fwd_x6(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, viewdirs=None, want_masks=False, xyz_enc=None,
                  pts=None):
-    """field_fwd with the hidden 256x256 layers as bf16x6 split products (same outputs, same mask words)."""
+    """field_fwd on the split-product instances (same outputs, same mask words): fp16 two-part (default), bf16x6, or the
+    opt-in three-product bf16 variant."""
     dev = pk.blob.device
     raw_t = torch.empty(N, pk.n_raw(mode), S, device=dev)
     masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=dev) if want_masks else None
     x3 = _x3(pk)
-    fn = L.load().nefes_field_fwd_x3 if x3 else L.load().nefes_field_fwd_x6
-    with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]},{'x3' if x3 else 'x6'}]"):
+    h3 = _h3(pk) and N * S < (1 << 31) - 256
+    fn = L.load().nefes_field_fwd_h3 if h3 else (L.load().nefes_field_fwd_x3 if x3 else L.load().nefes_field_fwd_x6)
+    with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]},{'h3' if h3 else 'x3' if x3 else 'x6'}]"):
         L.check(fn(pk.desc, _chk(pk.blob, "blob", torch.uint8), mode, N, S, _chk(rays_o, "rays_o"),
                                             _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(xyz_enc, "xyz_enc"),
                                             _chk(viewdirs, "viewdirs"),
@@ -295,10 +309,11 @@ def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=
     g_pts = None if ext else torch.empty(N * S, 3, device=dev)
     g_enc = torch.empty(N * S, 32, device=dev) if ext else None
     g_vs = torch.empty(N * S, 3, device=dev)
-    if USE_X6 and x6_supported(pk, L.FIELD_FULL, forward=False):
+    if USE_X6 and SPLIT != "f32" and x6_supported(pk, L.FIELD_FULL, forward=False):
         x3 = _x3(pk)
-        fn = L.load().nefes_field_bwd_x3 if x3 else L.load().nefes_field_bwd_x6
-        with _timed("field_bwd[x3]" if x3 else "field_bwd[x6]"):
+        h3 = _h3(pk)
+        fn = L.load().nefes_field_bwd_h3 if h3 else (L.load().nefes_field_bwd_x3 if x3 else L.load().nefes_field_bwd_x6)
+        with _timed("field_bwd[h3]" if h3 else "field_bwd[x3]" if x3 else "field_bwd[x6]"):
             L.check(fn(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
                                                 _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),
                                                 _chk(raw_t, "raw_t"), _chk(g_raw_t, "g_raw_t"), _chk(masks, "masks", torch.int32),
@@ -332,7 +347,7 @@ class FieldFromRays(torch.autograd.Function):
         rays_o, rays_d, viewdirs, z = _f32(rays_o), _f32(rays_d), _f32(viewdirs), _f32(z)
         N, S = z.shape
         need = mode in (L.FIELD_FULL, L.FIELD_STATIC) and any(ctx.needs_input_grad[:3])
-        if USE_X6 and x6_supported(pk, mode):
+        if USE_X6 and SPLIT != "f32" and x6_supported(pk, mode):
             raw_t, masks = field_fwd_x6(pk, mode, N, S, rays_o, rays_d, z, viewdirs=viewdirs, want_masks=need)
         else:
             raw_t, masks = field_fwd(pk, mode, N, S, rays_o=rays_o, rays_d=rays_d, z=z, viewdirs=viewdirs, want_masks=need)
@@ -366,7 +381,7 @@ class FieldFromPoints(torch.autograd.Function):
             viewdirs = torch.zeros(N, 3, device=pts.device)
         viewdirs = _f32(viewdirs)
         need = mode == L.FIELD_FULL and any(ctx.needs_input_grad[:2])
-        if USE_X6 and x6_supported(pk, mode) and pk.xyz_encoding == L.XYZ_FREQ10:
+        if USE_X6 and SPLIT != "f32" and x6_supported(pk, mode) and pk.xyz_encoding == L.XYZ_FREQ10:
             raw_t, masks = field_fwd_x6(pk, mode, N, S, pts=pts.reshape(-1, 3), viewdirs=viewdirs, want_masks=need)
         else:
             raw_t, masks = field_fwd(pk, mode, N, S, pts=pts.reshape(-1, 3), viewdirs=viewdirs, want_masks=need)
@@ -398,7 +413,7 @@ class FieldFromEncoding(torch.autograd.Function):
         N, S = enc.shape[0], enc.shape[1]
         viewdirs = torch.zeros(N, 3, device=enc.device) if viewdirs is None else _f32(viewdirs)
         need = mode == L.FIELD_FULL and any(ctx.needs_input_grad[:2])
-        if USE_X6 and x6_supported(pk, mode):
+        if USE_X6 and SPLIT != "f32" and x6_supported(pk, mode):
             raw_t, masks = field_fwd_x6(pk, mode, N, S, xyz_enc=enc.reshape(-1, 32), viewdirs=viewdirs, want_masks=need)
         else:
             raw_t, masks = field_fwd(pk, mode, N, S, xyz_enc=enc.reshape(-1, 32), viewdirs=viewdirs, want_masks=need)

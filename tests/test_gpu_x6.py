@@ -12,6 +12,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def _bf16x6_instances():
+    """This module pins the bf16 split-product instances (nefes_amd.ops.SPLIT = "x6"); the default fp16 two-part instances
+    have their own module, tests/test_gpu_h3.py."""
+    from nefes_amd import ops
+    old, ops.SPLIT = ops.SPLIT, "x6"
+    yield
+    ops.SPLIT = old
+
+
 @pytest.mark.parametrize("N,S", [(37, 64), (1, 5), (300, 64)])
 def test_sigma_x6_matches_fp32_kernel_and_oracle(N, S):
     from nefes_amd import lib as L

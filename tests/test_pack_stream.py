@@ -504,8 +504,19 @@ def test_pack_map_reproduces_host_pack(Wd, C, tr, enc):
     lo = rne((r - (mid << 16).astype(np.uint32).view(np.float32)).astype(np.float32))
     out = np.select([part == 0, part == 1, part == 2, part == 3], [b & 0xffff, b >> 16, hi, mid], lo).astype(np.uint16)
     out[m == 0] = 0
-    assert np.array_equal(out[128:], blob.view(np.uint16)[128:])
-    assert not m[:128].any()                              # header slots are never written by the device packer
+    # the fp16 two-part streams (and their exponent tables) are written by the host packer only: the map leaves them zero
+    is_h3 = np.zeros(m.size, bool)
+    for k in (L.STREAM_FWD_SIGMA_H3, L.STREAM_FWD_FULL_H3, L.STREAM_BWD_FULL_H3):
+        si = info.stream[k]
+        if si.n_slabs:
+            kib = int(re.search(r'#define NEFES_H3_%s_SLAB_KIB (\d+)' % ("BWD" if k == L.STREAM_BWD_FULL_H3 else "FWD"),
+                                open(os.path.join(ROOT, "nefes_amd", "csrc", "layout.h")).read()).group(1))
+            is_h3[si.slab_off // 2:(si.slab_off + si.n_slabs * kib * 1024) // 2] = True
+            is_h3[(si.bias_off + 4 * si.scale_off) // 2:(si.bias_off + 4 * si.bias_floats) // 2] = True
+    keep = ~is_h3                                         # (fp32 head segments inside the backward fp16 stream do get codes)
+    keep[:256] = False                                    # 512-byte header
+    assert np.array_equal(out[keep], blob.view(np.uint16)[keep])
+    assert not m[:256].any()                              # header slots are never written by the device packer
 
 
 def test_m0_only_written_by_the_dma_helper(tmp_path):
@@ -541,3 +552,293 @@ def test_m0_only_written_by_the_dma_helper(tmp_path):
             assert re.fullmatch(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi|ttmp\d+)", ins), f"unexpected use of M0: {ins!r}"
             n_dma += 1
     assert n_dma > 1000                                      # the unrolled weight-stream pieces of the field kernels
+
+
+# ---- fp16 two-part streams (layout.h NEFES_STREAM_*_H3, pack.cpp h3 segments, field_h3.h) -------------------------------------
+H3F = dict(L1=0, L2=1, L3=2, L4=3, L5H=4, L5E=5, L6=6, L7=7, L8=8, SIG=9, FINAL=10, DT_H=11, DT_D=12, RGB=13, T1=14, T2=15, TH=16)
+H3B = dict(RGB=0, TH=1, T2=2, T1=3, T0=4, DIR=5, FINAL=6, SIG=7, L8=8, L7=9, L6=10, L5=11, L4=12, L3=13, L2=14, L1=15)
+
+
+def _h3_slab_kib(which):
+    txt = open(os.path.join(os.path.dirname(__file__), '..', 'nefes_amd', 'csrc', 'layout.h')).read()
+    return int(re.search(r'#define NEFES_H3_%s_SLAB_KIB (\d+)' % which, txt).group(1))
+
+
+def pick_exp(m):
+    """field_h3.h pick_exp: exponent ex with m 2^ex in [2^14, 2^15), 0 for zero / tiny m (per sample)."""
+    m = np.asarray(m, np.float32)
+    be = (m.view(np.uint32) >> 23).astype(np.int64)
+    return np.where((be < 20) | (be > 250), 0, 14 + 127 - be)
+
+
+def split_f16(x):
+    """(hi, lo) fp16 parts of fp32 values: hi = RNE(x), lo = RNE(x - hi) (v_fma_mixlo/hi_f16 of field_h3.h split_pair_h)."""
+    x = np.asarray(x, np.float32)
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+class StreamH3:
+    """Consumption of an fp16 two-part stream exactly as mma_run_h3 does: units of two 1 KiB groups (hi | lo), slab_kib/2 units
+    per slab, a segment starts on a slab boundary; lane (m, g) of unit (k16-step q, tile t) multiplies slot (8q+i, g).  The
+    operand vector arrives in fp32 with a per-sample exponent `ex`; the three products hh + hl + lh are accumulated (in float64
+    here; fp32 in the matrix core).  fp32 segments of the same stream (backward heads) go through `mma32`."""
+
+    def __init__(self, blob, si, slab_kib):
+        self.slab_kib, self.half = slab_kib, slab_kib * 512
+        self.ups = slab_kib // 2
+        self.raw = np.frombuffer(blob, np.uint16, count=si.n_slabs * self.half, offset=si.slab_off).reshape(si.n_slabs, self.half)
+        self.f32 = np.frombuffer(blob, np.float32, count=si.n_slabs * slab_kib * 256, offset=si.slab_off).reshape(si.n_slabs, slab_kib, 64, 4)
+        nb = si.scale_off
+        self.bias = np.frombuffer(blob, np.float32, count=nb, offset=si.bias_off)
+        self.wexp = np.frombuffer(blob, np.int32, count=si.scale_count, offset=si.bias_off + 4 * nb)
+        self.pos = self.bpos = 0
+
+    def bias_tiles(self, nt, n):
+        b = self.bias[self.bpos:self.bpos + nt * 32].reshape(nt, 32)
+        self.bpos += nt * 32
+        return np.repeat(b[:, :, None], n, 2).astype(np.float64).copy()
+
+    def mma(self, nt, vec, ex, acc):
+        """acc[t] += (W 2^ew)(vec 2^ex) as hh + hl + lh.  vec [ks, 2, n] fp32 (ks a multiple of 8), ex [n] ints."""
+        k16 = vec.shape[0] // 8
+        n_units = k16 * nt
+        scaled = (vec.astype(np.float64) * np.exp2(ex.astype(np.float64))[None, None, :]).astype(np.float32)
+        assert np.all(np.abs(scaled) < 65504.0)
+        bh, bl = split_f16(scaled)
+        for u in range(n_units):
+            sl, uu = self.pos + u // self.ups, u % self.ups
+            q, t = u // nt, u % nt
+            unit = self.raw[sl, uu * 1024:(uu + 1) * 1024].reshape(2, 64, 8)
+            wh, wl = unit[0].view(np.float16).astype(np.float64), unit[1].view(np.float16).astype(np.float64)   # [lane][i]
+            for g in range(2):
+                rows = slice(32 * g, 32 * g + 32)
+                h_, l_ = bh[8 * q:8 * q + 8, g], bl[8 * q:8 * q + 8, g]
+                acc[t] += wl[rows] @ h_ + wh[rows] @ l_ + wh[rows] @ h_
+        self.pos += (n_units + self.ups - 1) // self.ups
+
+    def mma32(self, nt, vec, acc):
+        ks = vec.shape[0]
+        frags = self.slab_kib * 4
+        sps = frags // nt
+        for sl in range((ks + sps - 1) // sps):
+            slab = self.f32[self.pos]
+            self.pos += 1
+            for f in range(min(sps, ks - sl * sps) * nt):
+                s, t = sl * sps + f // nt, f % nt
+                a = slab[f // 4, :, f % 4].astype(np.float64)
+                acc[t] += a[:32, None] * vec[s, 0][None, :] + a[32:, None] * vec[s, 1][None, :]
+
+
+def cap(ex, es_in, ew):
+    return np.minimum(ex, 100 - es_in - ew)
+
+
+def relu_max(acc):
+    return np.maximum(acc, 0).max((0, 1)).astype(np.float32)
+
+
+def abs_max(acc):
+    return np.abs(acc).max((0, 1)).astype(np.float32)
+
+
+@pytest.mark.parametrize("Wd,Cf", [(256, 16), (128, 128)])
+def test_h3_streams_reproduce_the_mlp(Wd, Cf):
+    """The fp16 two-part streams consumed in kernel order with the kernels' scale bookkeeping (field_fwd_h3.hip /
+    field_bwd_h3.hip: per-sample operand exponents from the running maxima, per-matrix weight exponents from the stream's table,
+    common exponents where two products share accumulators, bias x 2^es, outputs x 2^-es): forward against the float64 oracle
+    to fp32-level accuracy -- sigma-only and full -- and backward-to-inputs against float64 autograd."""
+    n = 12
+    g = torch.Generator().manual_seed(8)
+    pts = (torch.rand(n, 3, generator=g) - .5) * 5
+    pts[0] *= 1e-3                                                 # a sample with tiny coordinates
+    pts[1] *= 6.                                                   # and one far out (|x| ~ 15)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    e63, e27 = O.freq_encode(pts, 10), O.freq_encode(dirs, 4)
+    NTW, NTH, NTR = Wd // 32, Wd // 64, (3 + Cf + 31) // 32
+    E, D = emb_vector(e63.numpy(), 10, 32), emb_vector(e27.numpy(), 4, 16)
+    exE = pick_exp(np.maximum(1.0, np.abs(pts.numpy()).max(1)).astype(np.float32))
+
+    def trunk(st, full):
+        b = {"L1": st.bias_tiles(NTW, n)}
+        for l in range(2, 9):
+            b[f"L{l}"] = st.bias_tiles(NTW, n)
+        b["SIG"] = st.bias_tiles(1, n)
+        if full:
+            for name, nt in (("FINAL", NTW), ("DIR", NTH), ("RGB", NTR), ("T0", NTH), ("T1", NTH), ("T2", NTH), ("TH", 1)):
+                b[name] = st.bias_tiles(nt, n)
+        w = st.wexp
+        masks = {}
+        ex = cap(exE, 0, w[H3F["L1"]])
+        es = ex + w[H3F["L1"]]
+        acc = b["L1"] * np.exp2(es)[None, None, :]
+        st.mma(NTW, E, ex, acc)
+        out = {}
+        for l in range(2, 10 if full else 9):
+            name = f"L{l}" if l <= 8 else "FINAL"
+            seg = H3F["L5H"] if l == 5 else H3F[name]
+            masks[f"L{l - 1}"] = acc > 0
+            H = acc_to_vec(np.maximum(acc, 0).astype(np.float32))
+            ex = cap(pick_exp(relu_max(acc)), es, w[seg])
+            if l == 9 or (l == 8 and not full):
+                pass
+            if name == "FINAL" or (not full and l == 9):
+                pass
+            if l == 9:                                              # static_sigma reads the same relu(h8)
+                exs = cap(ex, es, w[H3F["SIG"]])
+                sg = b["SIG"] * np.exp2(es + exs + w[H3F["SIG"]])[None, None, :]
+                st.mma(1, H, exs, sg)
+                out["sigma"] = softplus(sg[0, 0] * np.exp2(-(es + exs + w[H3F["SIG"]])))
+            if l == 5:
+                ex = np.where(es + ex <= exE, ex, exE - es)
+            es_new = es + ex + w[seg]
+            acc = b[name] * np.exp2(es_new)[None, None, :]
+            st.mma(NTW, H, ex, acc)
+            if l == 5:
+                assert w[H3F["L5E"]] == w[H3F["L5H"]]
+                st.mma(NTW, E, es + ex, acc)
+            es = es_new
+        if not full:
+            H = acc_to_vec(np.maximum(acc, 0).astype(np.float32))
+            exs = cap(pick_exp(relu_max(acc)), es, w[H3F["SIG"]])
+            sg = b["SIG"] * np.exp2(es + exs + w[H3F["SIG"]])[None, None, :]
+            st.mma(1, H, exs, sg)
+            out["sigma"] = softplus(sg[0, 0] * np.exp2(-(es + exs + w[H3F["SIG"]])))
+            return out, masks
+        # acc = xyz_encoding_final output (no activation), scale es
+        exD = pick_exp(np.abs(D).max((0, 1)).astype(np.float32))
+        ew = w[H3F["DT_H"]]
+        assert w[H3F["DT_D"]] == ew
+        ex = cap(pick_exp(abs_max(acc)), es, ew)
+        ex = np.where(es + ex <= exD, ex, exD - es)
+        es_dt = es + ex + ew
+        dt = np.concatenate([b["DIR"], b["T0"]], 0) * np.exp2(es_dt)[None, None, :]
+        st.mma(2 * NTH, acc_to_vec(acc.astype(np.float32)), ex, dt)
+        st.mma(2 * NTH, D, es + ex, dt)
+        masks["DIR"], masks["T0"] = dt[:NTH] > 0, dt[NTH:] > 0
+        ex = cap(pick_exp(relu_max(dt[:NTH])), es_dt, w[H3F["RGB"]])
+        es_ar = es_dt + ex + w[H3F["RGB"]]
+        ar = b["RGB"] * np.exp2(es_ar)[None, None, :]
+        st.mma(NTR, acc_to_vec(np.maximum(dt[:NTH], 0).astype(np.float32)), ex, ar)
+        out["rgbfeat"] = (ar * np.exp2(-es_ar)[None, None, :]).reshape(NTR * 32, n)[:3 + Cf].T
+        src, es_s = dt[NTH:], es_dt
+        for name in ("T1", "T2"):
+            ex = cap(pick_exp(relu_max(src)), es_s, w[H3F[name]])
+            es_n = es_s + ex + w[H3F[name]]
+            acc2 = b[name] * np.exp2(es_n)[None, None, :]
+            st.mma(NTH, acc_to_vec(np.maximum(src, 0).astype(np.float32)), ex, acc2)
+            masks[name] = acc2 > 0
+            src, es_s = acc2, es_n
+        ex = cap(pick_exp(relu_max(src)), es_s, w[H3F["TH"]])
+        es_th = es_s + ex + w[H3F["TH"]]
+        th = b["TH"] * np.exp2(es_th)[None, None, :]
+        st.mma(1, acc_to_vec(np.maximum(src, 0).astype(np.float32)), ex, th)
+        th = th * np.exp2(-es_th)[None, None, :]
+        sig = lambda x: 1 / (1 + np.exp(-x))
+        out["t_rgb"], out["t_sigma"], out["t_beta"] = sig(th[0, :3]).T, softplus(th[0, 3]), softplus(th[0, 4])
+        assert st.pos == st.raw.shape[0] and st.bpos == st.bias.shape[0]
+        return out, masks
+
+    # sigma-only stream of the coarse net
+    pc, info_c, blob_c = pack(Wd, Cf, "coarse")
+    si = info_c.stream[L.STREAM_FWD_SIGMA_H3]
+    assert si.n_slabs > 0 and si.scale_count >= 10
+    out, _ = trunk(StreamH3(blob_c, si, _h3_slab_kib("FWD")), False)
+    p64 = {k: v.double() for k, v in pc.items()}
+    ref = O.field_forward(p64, e63.double(), sigma_only=True)[:, 0].numpy()
+    assert np.abs(out["sigma"] - ref).max() <= 2e-6 * np.abs(ref).max()
+
+    # full stream of the fine net
+    pf, info_f, blob_f = pack(Wd, Cf, "fine")
+    out, masks = trunk(StreamH3(blob_f, info_f.stream[L.STREAM_FWD_FULL_H3], _h3_slab_kib("FWD")), True)
+    p64 = {k: v.double() for k, v in pf.items()}
+    emb = torch.cat([e63, e27], 1).double().requires_grad_()
+    raw = O.field_forward(p64, emb, output_transient=True)
+    r = raw.detach().numpy()
+    C3 = 3 + Cf
+    got = np.concatenate([out["rgbfeat"], out["sigma"][:, None], out["t_rgb"], out["t_sigma"][:, None], out["t_beta"][:, None]], 1)
+    err = np.abs(got - r).max(0) / np.abs(r).max(0)
+    assert err.max() <= 3e-6, err                                   # fp32-level (the fp32 oracle itself: ~1e-6)
+
+    # backward-to-inputs on the fp16 stream, against float64 autograd
+    g_raw = torch.randn(raw.shape, generator=g).double()
+    (g_emb,) = torch.autograd.grad(raw, emb, g_raw)
+    gr = g_raw.numpy()
+    d_pre = {"rgbfeat": gr[:, :C3], "sigma": gr[:, C3] * (1 - np.exp(-r[:, C3])),
+             "t_rgb": gr[:, C3 + 1:C3 + 4] * r[:, C3 + 1:C3 + 4] * (1 - r[:, C3 + 1:C3 + 4]),
+             "t_sigma": gr[:, C3 + 4] * (1 - np.exp(-r[:, C3 + 4])), "t_beta": gr[:, C3 + 5] * (1 - np.exp(-r[:, C3 + 5]))}
+    st = StreamH3(blob_f, info_f.stream[L.STREAM_BWD_FULL_H3], _h3_slab_kib("BWD"))
+    w = st.wexp
+    assert st.bias.size == 0 and w[H3B["T0"]] == w[H3B["DIR"]] and all(w[H3B[k]] == 0 for k in ("RGB", "TH", "SIG"))
+    Z = lambda nt: np.zeros((nt, 32, n), np.float64)
+    f32v = lambda v: v.astype(np.float32)
+    G2 = Z(NTH)
+    st.mma32(NTH, compact([d_pre["rgbfeat"][:, k] for k in range(C3)], (C3 + 1) // 2), G2)
+    T3 = Z(NTH)
+    st.mma32(NTH, compact([d_pre["t_rgb"][:, 0], d_pre["t_rgb"][:, 1], d_pre["t_rgb"][:, 2], d_pre["t_sigma"], d_pre["t_beta"]], 3), T3)
+    src, es = T3, np.zeros(n, np.int64)
+    for name, mk in (("T2", "T2"), ("T1", "T1")):                   # transient_encoding.4^T, .2^T
+        ex = cap(pick_exp(abs_max(src)), es, w[H3B[name]])
+        dst = Z(NTH)
+        st.mma(NTH, acc_to_vec(f32v(src * masks[mk])), ex, dst)
+        src, es = dst, es + ex + w[H3B[name]]
+    tau = np.minimum(np.minimum(es + pick_exp(abs_max(src)), pick_exp(abs_max(G2))), 100 - w[H3B["T0"]])
+    es_dt = tau + w[H3B["T0"]]
+    a9 = Z(NTW + 1)
+    st.mma(NTW + 1, acc_to_vec(f32v(src * masks["T0"])), tau - es, a9)
+    st.mma(NTW + 1, acc_to_vec(f32v(G2 * masks["DIR"])), tau, a9)
+    dD = acc_to_vec(f32v(a9), 0, 1) * np.exp2(-es_dt)[None, None, :]
+    ex = cap(pick_exp(abs_max(a9[1:])), es_dt, w[H3B["FINAL"]])
+    es = es_dt + ex + w[H3B["FINAL"]]
+    acc = Z(NTW)
+    st.mma(NTW, acc_to_vec(f32v(a9), 1, NTW), ex, acc)
+    st.mma32(NTW, compact([d_pre["sigma"] * np.exp2(es)], 1), acc)
+    accE, es_e = None, None
+    for l in range(8, 1, -1):
+        ex = cap(pick_exp(abs_max(acc)), es, w[H3B[f"L{l}"]])
+        Hm = acc_to_vec(f32v(acc * masks[f"L{l}"]))
+        es = es + ex + w[H3B[f"L{l}"]]
+        if l == 5:
+            a10 = Z(NTW + 2)
+            st.mma(NTW + 2, Hm, ex, a10)
+            accE, es_e, acc = a10[:2].copy(), es, a10[2:]
+        else:
+            acc = Z(NTW)
+            st.mma(NTW, Hm, ex, acc)
+    ex = cap(pick_exp(abs_max(acc)), es, w[H3B["L1"]])
+    es1 = es + ex + w[H3B["L1"]]
+    accE = accE * np.exp2(es1 - es_e)[None, None, :]
+    st.mma(2, acc_to_vec(f32v(acc * masks["L1"])), ex, accE)
+    assert st.pos == st.raw.shape[0]
+    g63 = emb_vector_T(acc_to_vec(f32v(accE * np.exp2(-es1)[None, None, :])), 10, 63)
+    g27 = emb_vector_T(f32v(dD[:14]), 4, 27)
+    scale = np.abs(g_emb.numpy()).max(1, keepdims=True)
+    assert (np.abs(g63 - g_emb.numpy()[:, :63]) / scale).max() <= 5e-6
+    assert (np.abs(g27 - g_emb.numpy()[:, 63:]) / scale).max() <= 5e-6
+
+
+def test_h3_stream_decodes_to_scaled_weights():
+    """Every weight of an fp16 segment is stored as (hi, lo) = (RNE_f16(w 2^e), RNE_f16(w 2^e - hi)) with e from the stream's
+    exponent table and max |w| 2^e in [2^14, 2^15): hi + lo reproduces w to 2^-22 of the matrix' largest weight."""
+    Wd, Cf = 256, 16
+    p, info, blob = pack(Wd, Cf, "coarse")
+    si = info.stream[L.STREAM_FWD_SIGMA_H3]
+    st = StreamH3(blob, si, _h3_slab_kib("FWD"))
+    nt, k16, ups = Wd // 32, Wd // 16, st.ups
+    l1_slabs = (4 * nt + ups - 1) // ups
+    Wm = p["xyz_encoding_2.0.weight"].numpy().astype(np.float64)
+    e = int(st.wexp[H3F["L2"]])
+    assert 2.0 ** 14 <= np.abs(Wm).max() * 2.0 ** e < 2.0 ** 15
+    got = np.zeros_like(Wm)
+    for u in range(k16 * nt):
+        sl, uu = l1_slabs + u // ups, u % ups
+        q, t = u // nt, u % nt
+        unit = st.raw[sl, uu * 1024:(uu + 1) * 1024].reshape(2, 64, 8)
+        val = unit[0].view(np.float16).astype(np.float64) + unit[1].view(np.float16).astype(np.float64)
+        for lane in range(64):
+            m_, g_ = lane & 31, lane >> 5
+            for i in range(8):
+                s = 8 * q + i
+                got[32 * t + m_, 32 * (s >> 4) + rho(g_, s & 15)] = val[lane, i]
+    assert np.abs(got * 2.0 ** -e - Wm).max() <= 2.0 ** -22 * np.abs(Wm).max()
