@@ -139,8 +139,12 @@ class NeRFH_NFF(nn.Module):
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in prm)
         if os.environ.get("NEFES_DEBUG_PACK_CHECKSUM", "0") == "1":      # debug: also key on the values (one sync per call)
             key += (float(sum(p.detach().double().sum() for p in prm)),)
-        if self._pk is not None and key != self._pk_key and all(p.is_cuda and p.device == self._pk.blob.device for p in prm):
-            self._pk.repack(prm)          # same network, new values (an optimizer step): re-packed on the device
+        if (self._pk is not None and key != self._pk_key and any(p.requires_grad for p in prm)
+                and all(p.is_cuda and p.device == self._pk.blob.device for p in prm)):
+            # a trainable network after an optimizer step: re-packed on the device, no host copy, no sync (the fp16 two-part
+            # streams are not produced there -- the train path runs on the bf16x6 / fp32 instances).  A FROZEN network whose
+            # values changed (load_state_dict, an in-place edit) takes the host packer below and keeps its fp16 streams.
+            self._pk.repack(prm)
             self._pk_key = key
         elif self._pk is None or key != self._pk_key:
             dev = prm[0].device if prm[0].is_cuda else torch.device("cuda")

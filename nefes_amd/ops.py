@@ -213,6 +213,16 @@ class PackedField:
         self.generation += 1
         self.h3_valid = False        # the kernels fall back to the bf16x6 instances for this network from here on
 
+    def h3_byte_ranges(self):
+        """[(begin, end)] byte ranges of the blob that only the host packer writes: the fp16 two-part units and exponent tables."""
+        out = []
+        for k, kib in ((L.STREAM_FWD_SIGMA_H3, 32), (L.STREAM_FWD_FULL_H3, 32), (L.STREAM_BWD_FULL_H3, 32)):
+            si = self.info.stream[k]
+            if si.n_slabs:
+                out.append((int(si.slab_off), int(si.slab_off + si.n_slabs * kib * 1024)))
+                out.append((int(si.bias_off + 4 * si.scale_off), int(si.bias_off + 4 * si.bias_floats)))
+        return out
+
     def check_generation(self, gen):
         if gen != self.generation:
             raise RuntimeError("nefes_amd: the network weights were modified (re-packed) between this forward pass and its "

@@ -197,7 +197,7 @@ def test_create_nerf_checkpoint_roundtrip_and_repack(tmp_path):
     for net in (test_kw2["network_fn"], test_kw2["network_fine"]):
         net.requires_grad_(False)
     rgb2, _, _, _ = R.render(3, 3, 2.0, c2w=c2w, near=0., far=4., **test_kw2)
-    assert torch.equal(rgb1, rgb2)
+    assert torch.equal(rgb1, rgb2)                                                     # frozen nets: host-packed both times
 
 
 def test_hashgrid_encoding_vs_oracle():

@@ -236,7 +236,12 @@ def test_device_repack_bit_identical(Wd, C, typ, xyz):
     assert not torch.equal(pk.blob, blob0)
     sd = {n: p for n, p in net.named_parameters()}
     host = ops.PackedField(sd, net.W, net.W_features, net.encode_transient, DEV, pk.xyz_encoding)
-    assert torch.equal(pk.blob, host.blob)
+    # everything the device packer produces is bit-identical to the host packer's; the fp16 two-part streams are the host
+    # packer's alone (the kernels use the bf16x6 instances for a re-packed network: tests/test_gpu_h3.py)
+    same = torch.ones(pk.blob.numel(), dtype=torch.bool, device=DEV)
+    for a, b in pk.h3_byte_ranges():
+        same[a:b] = False
+    assert torch.equal(pk.blob[same], host.blob[same]) and not pk.h3_valid and host.h3_valid
     assert net.packed() is pk and pk.generation == 1     # unchanged parameters: no work
 
 
