@@ -46,6 +46,7 @@ WORKLOADS = {
 
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_F16_MFMA_TFLOPS = 2500.0    # same rate: v_mfma_f32_32x32x16_f16 = 32 cycles per 32x32x16 like the bf16 form
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
@@ -337,14 +338,18 @@ def main():
         bwd_key = next(k for k in kern if k.startswith("field_bwd"))
         dom_key = max((fwd_key, bwd_key), key=lambda k: kern[k])
         x3 = dom_key.endswith("x3]")                      # opt-in reduced-precision run (NEFES_X6_PRODUCTS=3): labelled as such
+        h3 = dom_key.endswith("h3]")                      # fp16 two-part split products: three MFMAs per algorithmic product
         x6 = dom_key.endswith("x6]") or x3
         ach = flop_fwd / (kern[dom_key] * 1e-3) / 1e12
         enc = int(wl['hashgrid'])
         if dom_key == bwd_key:
-            dom_name = f"field_bwd_kernel<{Wd},{3 + C},{enc}{',X6=3' if x3 else ',X6' if x6 else ''}>"
+            dom_name = (f"field_bwd_h3_kernel<{Wd},{3 + C},{enc}>" if h3 else
+                        f"field_bwd_kernel<{Wd},{3 + C},{enc}{',X6=3' if x3 else ',X6' if x6 else ''}>")
         else:
-            dom_name = ("field_fwd_x6_kernel<FULL,NP=3>" if x3 else "field_fwd_x6_kernel<FULL>") if x6 else f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{enc}>"
-        peak = PEAK_BF16_MFMA_TFLOPS / (3.0 if x3 else 6.0) if x6 else PEAK_F32_MFMA_TFLOPS
+            dom_name = (f"field_fwd_h3_kernel<FULL,{enc},{Wd},{(3 + C + 31) // 32}>" if h3 else
+                        ("field_fwd_x6_kernel<FULL,NP=3>" if x3 else "field_fwd_x6_kernel<FULL>") if x6
+                        else f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{enc}>")
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if h3 else (PEAK_BF16_MFMA_TFLOPS / (3.0 if x3 else 6.0) if x6 else PEAK_F32_MFMA_TFLOPS)
         flop_frame = 2.0 * (Nc * macs_sigma(Wd, in_xyz) + 2 * (Nc + Ni) * macs_full(Wd, C, in_xyz)) * n_total
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure
         # comes from the committed rocprofv3 passes of this same command (profiles/, 2*FETCH_SIZE + WRITE_SIZE in KiB,
@@ -352,11 +357,11 @@ def main():
         traffic = None
         try:
             if (a.workload, H, W, world) == ("metric", 480, 640, 1) and not x3:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_per_launch.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02" if h3 else "r01", "pmc_per_launch.json")))
                 if dom_key == bwd_key:
-                    want = "field_bwd_kernel<256,19,0,6," if x6 else "field_bwd_kernel<256,19,0,0,"
+                    want = "field_bwd_h3_kernel<256,19,0" if h3 else ("field_bwd_kernel<256,19,0,6," if x6 else "field_bwd_kernel<256,19,0,0,")
                 else:
-                    want = "field_fwd_x6_kernel<2," if x6 else "field_fwd_kernel<256,1,2"
+                    want = "field_fwd_h3_kernel<2,0,256" if h3 else ("field_fwd_x6_kernel<2," if x6 else "field_fwd_kernel<256,1,2")
                 pm = next(v for k, v in pm.items() if k.replace(" ", "").startswith(want))
                 traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
         except Exception:
@@ -367,10 +372,15 @@ def main():
             "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1,
             "collective_backend": (dist.get_backend() if world > 1 else None), "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16x3 (16-bit operands, NOT the headline precision)" if x3 else "f32",
+            "matrix_core_arithmetic": "fp16 two-part split (3 products)" if h3 else ("bf16x3" if x3 else "bf16x6" if x6 else "fp32 MFMA"),
             "data": "synthetic",
             "config": {"workload": f"{wl['name']}; {W}x{H}, random seed-0 weights, fwd + bwd to the 3x4 pose",
                        "rays_per_step": n_total, "samples_per_ray": [Nc, Ni], "parallelism": f"rows/{world}",
-                       "arithmetic": ("REDUCED PRECISION (opt-in NEFES_X6_PRODUCTS=3): three leading bf16 split products, operands "
+                       "arithmetic": ("fp32 in, fp32 out; matrix products as fp16 two-part split products (hi, lo fp16 pairs of power-of-two "
+                                      "scaled operands, 22 significant bits, three cross terms, fp32 accumulation: fp32-level accuracy, "
+                                      "tests/test_gpu_h3.py); NEFES_SPLIT=x6 / f32 select the bf16x6 / fp32-MFMA kernels"
+                                      if h3 else
+                                      "REDUCED PRECISION (opt-in NEFES_X6_PRODUCTS=3): three leading bf16 split products, operands "
                                       "carried to 16 bits, ~5e-6 of the output scale (tests/test_gpu_x6.py); not the default"
                                       if x3 else
                                       "fp32 in, fp32 out; matrix products as exact bf16x6 split products with fp32 accumulation "
@@ -378,11 +388,13 @@ def main():
                                       if any(k.endswith("x6]") for k in kern) else "fp32 MFMA")},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "peak_basis": ("dense bf16 MFMA peak 2500 / 3: three-product split, reduced precision" if x3 else
+                         "peak_basis": ("dense fp16 MFMA peak 2500 / 3: fp16 two-part split, three products per algorithmic product, "
+                                        "fp32-level accuracy" if h3 else
+                                        "dense bf16 MFMA peak 2500 / 3: three-product split, reduced precision" if x3 else
                                         "dense bf16 MFMA peak 2500 / 6: bf16x6 split products, fp32-level accuracy" if x6
                                         else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                          "vs_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch (HBM side, from profiles/r01 PMC passes)",
+                         "traffic": traffic, "traffic_unit": "bytes/launch (HBM side: 2 x FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC passes, profiles/)",
                          "end_to_end_frac": value * (flop_frame / n_total) / (PEAK_F32_MFMA_TFLOPS * 1e12 * world)},
             "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items())},
             "pose_grad_abs_max": float(g.abs().max()),

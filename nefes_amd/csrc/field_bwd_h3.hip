@@ -11,11 +11,11 @@
 #include "field_x6.h"
 #include "field_h3.h"
 #include "../../include/nefes_hip.h"
-#define NEFES_H3B_SLOTS 3   // 96 KiB ring (+ the tile's ReLU masks and the exponent table)
+#define NEFES_H3B_SLOTS 2   // 64 KiB ring (StagedRing: two slots) + the tile's ReLU masks and the scale table
 
 struct FieldBwdH3Args {
     const char* stream;
-    const int* wexp;        // weight-scale exponent per segment (layout.h NEFES_H3B_*), in the blob
+    const int* tab;         // scale table of the stream (layout.h: per segment weight exponent + row bound), in the blob
     uint32_t n_slabs;
     const float* rays_o;
     const float* rays_d;
@@ -33,15 +33,6 @@ struct FieldBwdH3Args {
     int n_tiles;
 };
 
-// largest magnitude of accumulator tiles [T0, T0 + NT) (outputs of the fp32 head products; the fp16 products report theirs)
-template <int NT, int T0, int NX>
-__device__ __forceinline__ float tiles_absmax(const f32x16 (&X)[NX]) {
-    float m = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) tile_max_acc<2>(m, X[T0 + t]);
-    return m;
-}
-
 template <int W, int C3, int ENC>   // C3 = 3 + C; ENC = NEFES_XYZ_*
 __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
@@ -54,13 +45,15 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    int* wexp = (int*)(smem + NEFES_H3B_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (MW + 8) * 256);
-    if (threadIdx.x < NEFES_H3B_N) wexp[threadIdx.x] = a.wexp[threadIdx.x];
-    WeightRing<NEFES_H3B_SLOTS> ring;
-    ring.init(a.stream, a.n_slabs, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem, wave, lane);
-    __syncthreads();
+    int* tab_i = (int*)(smem + NEFES_H3B_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (MW + 8) * 256);
+    const float* tab_f = (const float*)tab_i;
+    if (threadIdx.x < 2 * NEFES_H3B_N) tab_i[threadIdx.x] = a.tab[threadIdx.x];
+    auto wexp = [&](int seg) { return tab_i[nefes_h3_tab_exp(seg)]; };
+    auto rowb = [&](int seg) { return tab_f[nefes_h3_tab_bound(seg)]; };
+    StagedRing ring;
+    ring.init(a.stream, a.n_slabs, smem, wave, lane);
     const char* ring_lane = smem + lane * 16;
-    ring.prime(ring_lane);
+    ring.prime(ring_lane);                                       // (its barrier also publishes the scale table)
     // this wave's mask words in LDS: [MW/4][64 lanes][4 words]
     uint32_t* mlds = (uint32_t*)(smem + NEFES_H3B_SLOTS * NEFES_SLAB_BYTES) + wave * ((MW + 8) * 64) + lane * 4;
     auto MASKW = [&](int w) { return mlds[(w >> 2) * 256 + (w & 3)]; };
@@ -76,7 +69,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
         const int smp = (int)(m - (long long)ray * a.S);
         const size_t chan0 = (size_t)ray * a.R * a.S + smp;   // + ch*S
 
-        // ================= all global loads of the tile, then ONE explicit completion point =================
+        // ================= the tile's global loads (the weight ring moves through registers here: the compiler counts all loads) =====
         float in_o[3] = {0.f, 0.f, 0.f}, in_d[3] = {0.f, 0.f, 0.f}, in_z = 0.f, v[3];
         if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
             // the gradient w.r.t. the supplied embedding does not depend on the sample position
@@ -115,10 +108,6 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
                 mq[q].z = mk32[(4 * q + 2) * 64]; mq[q].w = mk32[(4 * q + 3) * 64];
             }
         }
-        loads_landed();
-        pin(in_o); pin(in_d); pin(in_z); pin(v); pin(y_th); pin(g_th); pin(y_sg); pin(g_sg); pin(dr);
-#pragma unroll
-        for (int q = 0; q < MW / 4; ++q) { pin(mq[q].x); pin(mq[q].y); pin(mq[q].z); pin(mq[q].w); }
         // ======================================================================================================
 #pragma unroll
         for (int q = 0; q < MW / 4; ++q) *(uint4*)(mlds + q * 256) = mq[q];     // own lane's words only: no barrier needed
@@ -154,91 +143,102 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
             for (int w = 0; w < n; ++w) b[w] = MASKW(word0 + w);
         };
         uint32_t bh[WH], bt[WT];
-        float mx[2], mx_[2];
-        // exponent for the next operand from the lane pair's largest magnitude, capped so that the output scale stays finite
-        auto next_exp = [&](float m_lane, int es_in, int ew) { return cap_exp(pick_exp(pair_max(m_lane)), es_in, ew); };
-
+        // Scale bookkeeping as in field_fwd_h3.hip: es_x = exponent an accumulator set carries, M = upper bound of a gradient
+        // vector's largest magnitude in true units (packer's row bounds x the exactly measured maximum of the previous operand),
+        // tau = exponent the operand is brought to; output exponent = tau + weight exponent.
+        auto tau_of = [&](float M, int ew) {
+            const int t = pick_exp(M);
+            return t < 100 - ew ? t : 100 - ew;
+        };
         f32x16 G2[NTH], T3[NTH], T4[NTH];
-        // ---- static_rgb^T (fp32): 3+C gradients in compact slots -> d(dir_encoding output), scale 2^0 ----
+        // ---- static_rgb^T (fp32): 3+C gradients in compact slots -> d(dir_encoding output), exponent 0 ----
         mma_run<NTH, KR, 0, true>(ring, ring_lane, ArrayIn<KR>{dr}, ZeroInit{}, G2);
-        // ---- transient heads^T (fp32): 5 pre-activation gradients -> d(transient_encoding.4 output), scale 2^0 ----
+        const float M_g2 = rowb(NEFES_H3B_RGB) * pair_max(array_max(dr));
+        // ---- transient heads^T (fp32): 5 pre-activation gradients -> d(transient_encoding.4 output), exponent 0 ----
         mma_run<NTH, 3, 0, true>(ring, ring_lane, ArrayIn<3>{dth}, ZeroInit{}, T3);
+        float M = rowb(NEFES_H3B_TH) * pair_max(array_max(dth));
         // ---- transient_encoding.4^T, .2^T ----
         int es4, es3;
         {
             load_bits(bh, MW_TRUNK + 3 * WH, WH);
-            const int ew = wexp[NEFES_H3B_T2], ex = next_exp(tiles_absmax<NTH, 0>(T3), 0, ew);
-            es4 = ex + ew;
-            mma_run_h3<NTH, GS / 8, 0, true, 2>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{T3, bh, pow2i(ex)}, ZeroInit{}, T4, mx);
+            const int ew = wexp(NEFES_H3B_T2), tau = tau_of(M, ew);
+            float mx = 0.f;
+            es4 = tau + ew;
+            mma_run_h3<NTH, GS / 8, 0, true>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{T3, bh, pow2i(tau), mx}, ZeroInit{}, T4);
+            M = rowb(NEFES_H3B_T2) * pair_max(mx);
         }
         {
             load_bits(bh, MW_TRUNK + 2 * WH, WH);
-            const int ew = wexp[NEFES_H3B_T1], ex = next_exp(mx[0], es4, ew);
-            es3 = es4 + ex + ew;
-            mma_run_h3<NTH, GS / 8, 0, true, 2>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{T4, bh, pow2i(ex)}, ZeroInit{}, T3, mx);
+            const int ew = wexp(NEFES_H3B_T1), tau = tau_of(M, ew);
+            float mx = 0.f;
+            es3 = tau + ew;
+            mma_run_h3<NTH, GS / 8, 0, true>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{T4, bh, pow2i(tau - es4), mx}, ZeroInit{}, T3);
+            M = rowb(NEFES_H3B_T1) * (pair_max(mx) * pow2i(-es4));
         }
         // Full-width accumulators, ping-pong.  Tiles [2, NTW+2) hold a layer's d hidden; XA tile 1 = d dir-embedding;
         // XB tiles 0,1 = d xyz-embedding (written by layer 5, accumulated by layer 1).
         f32x16 XA[NTW + 2], XB[NTW + 2];
         // ---- [transient_encoding.0 ; dir_encoding]^T -> d dir-embedding (tile 1) + d final (tiles 2..): both products
-        //      accumulate into the same tiles, so both operands are brought to one common scale 2^tau ----
+        //      accumulate into the same tiles, so both operands are brought to one common exponent ----
         int es_dt;
         {
-            const int ew = wexp[NEFES_H3B_T0];                                    // = wexp[NEFES_H3B_DIR]: one scale for the pair (pack.cpp)
-            const int tau_t = es3 + pick_exp(pair_max(mx[0]));                    // what d(transient_encoding.0 output) could carry
-            const int tau_g = pick_exp(pair_max(tiles_absmax<NTH, 0>(G2)));       // what d(dir_encoding output) could carry (scale 2^0)
-            int tau = tau_t < tau_g ? tau_t : tau_g;
-            tau = tau < 100 - ew ? tau : 100 - ew;
+            const int ew = wexp(NEFES_H3B_T0);                                    // = wexp(NEFES_H3B_DIR): one scale for the pair (pack.cpp)
+            const int tau = tau_of(fmaxf(M, M_g2), ew);
+            float mt = 0.f, mg = 0.f;
             es_dt = tau + ew;
             load_bits(bh, MW_TRUNK + WH, WH);
-            mma_run_h3<NTW + 1, GS / 8, 1, true>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{T3, bh, pow2i(tau - es3)}, ZeroInit{}, XA, mx_);
+            mma_run_h3<NTW + 1, GS / 8, 1, true>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{T3, bh, pow2i(tau - es3), mt}, ZeroInit{}, XA);
             load_bits(bh, MW_TRUNK, WH);
-            mma_run_h3<NTW + 1, GS / 8, 1, false, 2, 1>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{G2, bh, pow2i(tau)}, ZeroInit{}, XA, mx);
+            mma_run_h3<NTW + 1, GS / 8, 1, false>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{G2, bh, pow2i(tau), mg}, ZeroInit{}, XA);
+            M = rowb(NEFES_H3B_T0) * (pair_max(mt) * pow2i(-es3)) + rowb(NEFES_H3B_DIR) * pair_max(mg);
         }
         // ---- xyz_encoding_final^T (no ReLU on its output) + static_sigma^T (one extra fp32 k-step) -> d h8 ----
         int es_b;
         {
-            const int ew = wexp[NEFES_H3B_FINAL], ex = next_exp(mx[1], es_dt, ew);   // mx[1]: the d final tiles (tile 1 is the dir part)
-            es_b = es_dt + ex + ew;
-            mma_run_h3<NTW, W / 16, 2, true>(ring, ring_lane, IdentSplitH<NTW + 2, 2>{XA, pow2i(ex)}, ZeroInit{}, XB, mx_);
+            const int ew = wexp(NEFES_H3B_FINAL), tau = tau_of(M, ew);
+            float mx = 0.f;
+            es_b = tau + ew;
+            mma_run_h3<NTW, W / 16, 2, true>(ring, ring_lane, IdentSplitH<NTW + 2, 2>{XA, pow2i(tau - es_dt), mx}, ZeroInit{}, XB);
+            const float dsig = STASH(6);
             float dsg[1];
-            dsg[0] = STASH(6) * pow2i(es_b);
+            dsg[0] = dsig * pow2i(es_b);
             mma_run<NTW, 1, 2, false>(ring, ring_lane, ArrayIn<1>{dsg}, ZeroInit{}, XB);
-            mx[0] = tiles_absmax<NTW, 2>(XB);
+            M = rowb(NEFES_H3B_FINAL) * (pair_max(mx) * pow2i(-es_dt)) + rowb(NEFES_H3B_SIG) * pair_max(fabsf(dsig));
         }
         // ---- xyz_encoding_8^T .. xyz_encoding_2^T, straight-line (XB -> XA -> XB ...).  Layer 5 also emits the skip's d
-        //      xyz-embedding into XB tiles 0,1 (reported apart: mx[0]; the d hidden tiles: mx[1]). ----
+        //      xyz-embedding into XB tiles 0,1. ----
         int es_a = 0, es_e = 0;
-#define NEFES_BWD_LAYER(L, SRC, DST, ES_SRC, ES_DST, NTILES, T0, MSRC)                                                 \
+#define NEFES_BWD_LAYER(L, SRC, DST, ES_SRC, ES_DST, NTILES, T0)                                                       \
         {                                                                                                           \
             load_bits(bt, ((L) - 1) * WT, WT);                                                                      \
-            const int ew = wexp[NEFES_H3B_L8 + 8 - (L)], ex = next_exp(MSRC, ES_SRC, ew);                           \
-            ES_DST = ES_SRC + ex + ew;                                                                              \
-            mma_run_h3<NTILES, W / 16, T0, true, 2, 2 - (T0)>(ring, ring_lane, MaskedSplitH<NTW + 2, WT, 2>{SRC, bt, pow2i(ex)}, ZeroInit{}, DST, mx); \
+            const int ew = wexp(NEFES_H3B_L8 + 8 - (L)), tau = tau_of(M, ew);                                       \
+            float mx = 0.f;                                                                                         \
+            ES_DST = tau + ew;                                                                                      \
+            mma_run_h3<NTILES, W / 16, T0, true>(ring, ring_lane, MaskedSplitH<NTW + 2, WT, 2>{SRC, bt, pow2i(tau - ES_SRC), mx}, ZeroInit{}, DST); \
+            M = rowb(NEFES_H3B_L8 + 8 - (L)) * (pair_max(mx) * pow2i(-(ES_SRC)));                                   \
         }
-        NEFES_BWD_LAYER(8, XB, XA, es_b, es_a, NTW, 2, mx[0])
-        NEFES_BWD_LAYER(7, XA, XB, es_a, es_b, NTW, 2, mx[1])
-        NEFES_BWD_LAYER(6, XB, XA, es_b, es_a, NTW, 2, mx[1])
-        NEFES_BWD_LAYER(5, XA, XB, es_a, es_b, NTW + 2, 0, mx[1])
-        es_e = es_b;                                                         // scale of the d xyz-embedding tiles XB[0], XB[1]
-        NEFES_BWD_LAYER(4, XB, XA, es_b, es_a, NTW, 2, mx[1])
-        NEFES_BWD_LAYER(3, XA, XB, es_a, es_b, NTW, 2, mx[1])
-        NEFES_BWD_LAYER(2, XB, XA, es_b, es_a, NTW, 2, mx[1])
+        NEFES_BWD_LAYER(8, XB, XA, es_b, es_a, NTW, 2)
+        NEFES_BWD_LAYER(7, XA, XB, es_a, es_b, NTW, 2)
+        NEFES_BWD_LAYER(6, XB, XA, es_b, es_a, NTW, 2)
+        NEFES_BWD_LAYER(5, XA, XB, es_a, es_b, NTW + 2, 0)
+        es_e = es_b;                                                         // exponent of the d xyz-embedding tiles XB[0], XB[1]
+        NEFES_BWD_LAYER(4, XB, XA, es_b, es_a, NTW, 2)
+        NEFES_BWD_LAYER(3, XA, XB, es_a, es_b, NTW, 2)
+        NEFES_BWD_LAYER(2, XB, XA, es_b, es_a, NTW, 2)
 #undef NEFES_BWD_LAYER
-        // ---- xyz_encoding_1^T accumulates onto the skip's d embedding: bring those two tiles to the new product's scale ----
+        // ---- xyz_encoding_1^T accumulates onto the skip's d embedding: bring those two tiles to the new product's exponent ----
         int es_1;
         {
             load_bits(bt, 0, WT);
-            const int ew = wexp[NEFES_H3B_L1], ex = next_exp(mx[1], es_a, ew);
-            es_1 = es_a + ex + ew;
-            int de = es_1 - es_e;
-            de = de < -120 ? -120 : (de > 120 ? 120 : de);
-            const float resc = pow2i(de);
+            const int ew = wexp(NEFES_H3B_L1), tau = tau_of(M, ew);
+            float mx = 0.f;
+            es_1 = tau + ew;
+            const float resc = pow2i(es_1 - es_e);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) XB[t][r] *= resc;
-            mma_run_h3<2, W / 16, 0, false>(ring, ring_lane, MaskedSplitH<NTW + 2, WT, 2>{XA, bt, pow2i(ex)}, ZeroInit{}, XB, mx_);
+            mma_run_h3<2, W / 16, 0, false>(ring, ring_lane, MaskedSplitH<NTW + 2, WT, 2>{XA, bt, pow2i(tau - es_a), mx}, ZeroInit{}, XB);
         }
         float dDv[16];
         {
@@ -332,10 +332,10 @@ extern "C" int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, 
     int rc = nefes_blob_info(desc, &info);
     if (rc) return rc;
     const NefesStreamInfo& si = info.stream[NEFES_STREAM_BWD_FULL_H3];
-    if (si.n_slabs == 0 || si.scale_count < NEFES_H3B_N) return NEFES_E_UNSUPPORTED;
+    if (si.n_slabs == 0 || si.scale_count < 2 * NEFES_H3B_N) return NEFES_E_UNSUPPORTED;
     FieldBwdH3Args a;
     a.stream = (const char*)packed + si.slab_off;
-    a.wexp = (const int*)((const char*)packed + si.bias_off) + si.scale_off;
+    a.tab = (const int*)((const char*)packed + si.bias_off) + si.scale_off;
     a.n_slabs = si.n_slabs;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.viewdirs = viewdirs;
     a.raw_t = raw_t; a.g_raw_t = g_raw_t; a.masks = masks; a.g_pts = g_pts; a.g_enc = g_xyz_enc; a.g_vs = g_viewdirs_s;

@@ -32,6 +32,10 @@ __device__ __forceinline__ float sigmoid_ref(float x) { return 1.f / (1.f + expf
 // Source address = wave-uniform 64-bit base (SGPR pair, advanced by scalar ALU) + a constant 32-bit per-lane offset:
 // the refill costs no vector ALU instruction (VALU ops are never hidden behind an fp32 MFMA of the same wave).
 __device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, uint32_t lds_dst) {
+#ifdef H3_ABL_NODMA     // timing ablation (tools/ablate_h3.sh): no transfer; the consumers read whatever the LDS holds
+    asm volatile("" :: "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+    return;
+#endif
     uint32_t keep;
 #ifdef NEFES_DBG_OLD_DMA
     const char* gsrc = (const char*)gbase + lane_off;
@@ -160,8 +164,12 @@ struct WeightRing {
         const unsigned long long t2 = now();
         dbg_wait += t1 - t0; dbg_barrier += t2 - t1;
 #else
+#ifdef H3_ABL_NOBARRIER
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEFES_SLAB_PIECES * (SLOTS - 2)) : "memory");
         __builtin_amdgcn_s_barrier();
+#endif
 #endif
         const uint32_t off = c_slot * NEFES_SLAB_BYTES;
         c_slot = (c_slot + 1 == SLOTS) ? 0 : c_slot + 1;
@@ -272,8 +280,8 @@ struct BiasInit {               // C operand of the first k-step = bias rows of 
 // acc[T0 .. T0+NT) (+)= W-block * in   over KS k-steps, fully unrolled: every register index below is a compile-time
 // constant after unrolling.  FIRST: the first k-step takes its C operand from init(t) (bias or zero) instead of acc,
 // so accumulators need no initialisation pass.  ring_lane = LDS pointer of the ring base + lane*16.
-template <int NT, int KS, int T0, bool FIRST, class InFn, class InitFn, int NACC, int SLOTS>
-__device__ __forceinline__ void mma_run(WeightRing<SLOTS>& ring, const char* ring_lane, const InFn& in, const InitFn& init,
+template <int NT, int KS, int T0, bool FIRST, class InFn, class InitFn, int NACC, class Ring>
+__device__ __forceinline__ void mma_run(Ring& ring, const char* ring_lane, const InFn& in, const InitFn& init,
                                         f32x16 (&acc)[NACC]) {
     static_assert(T0 + NT <= NACC, "accumulator array too small");
     constexpr int SPS = NEFES_SLAB_FRAGS / NT;
@@ -373,8 +381,8 @@ __device__ __forceinline__ void mma_run(WeightRing<SLOTS>& ring, const char* rin
     }
 }
 // array-input, accumulate-into-acc form (callers initialise acc themselves)
-template <int NT, int KS, int T0 = 0, int NACC, int SLOTS>
-__device__ __forceinline__ void mma_segment(WeightRing<SLOTS>& ring, const char* ring_lane, const float (&in)[KS],
+template <int NT, int KS, int T0 = 0, int NACC, class Ring>
+__device__ __forceinline__ void mma_segment(Ring& ring, const char* ring_lane, const float (&in)[KS],
                                             f32x16 (&acc)[NACC]) {
     mma_run<NT, KS, T0, false>(ring, ring_lane, ArrayIn<KS>{in}, ZeroInit{}, acc);
 }

@@ -3,7 +3,8 @@
 // rendering.py:114,142): pts = o + d*z -> frequency embedding (or a supplied 32-feature encoding) -> 8-layer skip MLP -> heads,
 // same raw_t layout, same ReLU-mask words.  Every product runs on v_mfma_f32_32x32x16_f16 as hh + hl + lh of power-of-two
 // scaled (hi, lo) fp16 pairs: half the matrix-core work of the bf16x6 kernels at fp32-level accuracy.
-// Weight stream: 32 KiB slabs = 16 units of two 1 KiB groups (hi, lo); 3 slots.  The xyz embedding (32 slots per lane) waits
+// Weight stream: 32 KiB slabs = 16 units of two 1 KiB groups (hi, lo), moved through registers into a two-slot LDS ring
+// (field_h3.h StagedRing).  The xyz embedding (32 slots per lane) waits
 // in LDS between layer 1 and the skip at layer 5 instead of in registers: with one accumulator set in VGPRs (the compiler keeps
 // the set the vector ALU reads there) the kernel has no 32 registers to spare.
 #define NEFES_SLAB_KIB NEFES_H3_FWD_SLAB_KIB
@@ -12,7 +13,7 @@
 
 #include "field_x6.h"
 #include "field_h3.h"
-#define NEFES_H3_SLOTS 3   // 96 KiB ring
+#define NEFES_H3_SLOTS 2   // 64 KiB ring (StagedRing: two slots)
 
 struct FieldFwdH3Args {
     const char* stream;
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
     constexpr int NTW = W / 32, NTH = W / 64;
     constexpr int ES = ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : NEFES_E_STEPS;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128), WT = (NTW + 1) / 2, WH = (NTH + 1) / 2;
+    constexpr int NSEG = MODE == NEFES_FIELD_SIGMA ? NEFES_H3F_SIG + 1 : NEFES_H3F_N;      // segments of the stream
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring_base = smem;
     float* bias_lds = (float*)(smem + NEFES_H3_SLOTS * NEFES_SLAB_BYTES);
@@ -48,13 +50,17 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     for (uint32_t i = threadIdx.x; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
-    WeightRing<NEFES_H3_SLOTS> ring;
-    ring.init(a.stream, a.n_slabs, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_base, wave, lane);
-    __syncthreads();
+    StagedRing ring;
+    ring.init(a.stream, a.n_slabs, ring_base, wave, lane);
     const char* ring_lane = ring_base + lane * 16;
     const char* bias_half = (const char*)bias_lds + 16 * h;
-    const int* wexp = (const int*)(bias_lds + a.scale_off);     // weight-scale exponent per segment (layout.h NEFES_H3F_*)
-    ring.prime(ring_lane);
+    // scale table (layout.h): per segment (weight exponent, row bound), then max |b| per bias block
+    const int* tab_i = (const int*)(bias_lds + a.scale_off);
+    const float* tab_f = bias_lds + a.scale_off;
+    auto wexp = [&](int seg) { return tab_i[nefes_h3_tab_exp(seg)]; };
+    auto rowb = [&](int seg) { return tab_f[nefes_h3_tab_bound(seg)]; };
+    auto bmax = [&](int blk) { return tab_f[nefes_h3_tab_bias(NSEG, blk)]; };
+    ring.prime(ring_lane);                                       // (its barrier also publishes the bias block)
     // bias block offsets (floats), in stream order: L1..L8, SIG, FINAL, DIR, RGB, T0, T1, T2, TH (as in field_fwd.hip)
     constexpr int B_SIG = 8 * W, B_FINAL = B_SIG + 32, B_DIR = B_FINAL + W, B_RGB = B_DIR + W / 2,
                   B_T0 = B_RGB + 32 * NTR, B_T1 = B_T0 + W / 2, B_T2 = B_T1 + W / 2, B_TH = B_T2 + W / 2;
@@ -85,11 +91,8 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
 #pragma unroll
             for (int c = 0; c < 3; ++c) { in_o[c] = a.rays_o[ray * 3 + c]; in_d[c] = a.rays_d[ray * 3 + c]; }
         }
-        loads_landed();
-        pin(in_o); pin(in_d); pin(in_z);
-        float mE;                                                   // largest embedding magnitude of the sample
+        float mE;                                                   // largest embedding magnitude of the sample (true units)
         if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
-            pin(E);
             mE = pair_max(array_max(E));
         } else {
             float x[3];
@@ -98,7 +101,6 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
             embed_slots<NEFES_N_FREQ_XYZ>(E, x, h);
             mE = fmaxf(fmaxf(1.f, fabsf(x[0])), fmaxf(fabsf(x[1]), fabsf(x[2])));   // sin/cos <= 1, then x itself
         }
-        const int exE = pick_exp(mE);
 #pragma unroll
         for (int s = 0; s < ES; ++s) e_lds[s * 64] = E[s];          // own lane's column only: no barrier needed
         int mask_word = 0;
@@ -123,14 +125,22 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
             for (int w = 0; w < WT; ++w) bits[w] = 0u;
         };
         constexpr bool CAP = MODE == NEFES_FIELD_FULL;
-        float mx[2];            // largest value / magnitude of the tiles the latest product completed (per lane: pair_max combines)
-        // exponent for the next product's operand from that maximum, capped so that the output scale stays finite
-        auto next_exp = [&](float m_lane, int es_in, int ew) { return cap_exp(pick_exp(pair_max(m_lane)), es_in, ew); };
-        auto sigma_head = [&](const f32x16 (&X)[NTW], int es_x, int ex) {      // ex: the exponent chosen for relu(X)
+        // Scale bookkeeping (field_h3.h), all per lane and identical on the two lanes of a sample:
+        //   es_x  exponent an accumulator set carries (acc = 2^es_x * true value)
+        //   M_x   upper bound of the set's largest (ReLU'd / absolute) true value, from the packer's row bounds
+        //   tau   exponent the operand is brought to (operand = true value * 2^tau, largest magnitude below 2^15): tau =
+        //         pick_exp(M_x), the conversion multiplies the accumulator by 2^(tau - es_x); output exponent = tau + weight exponent
+        // tau_of: capped so that the output scale 2^(tau + ew) stays a finite float
+        auto tau_of = [&](float M, int ew) {
+            const int t = pick_exp(M);
+            return t < 100 - ew ? t : 100 - ew;
+        };
+        auto sigma_head = [&](const f32x16 (&X)[NTW], int es_x, int tau_x) {      // tau_x: exponent chosen for relu(X)
             f32x16 sg[1];
-            const int es = es_x + ex + wexp[NEFES_H3F_SIG];
-            float mx_[2];
-            mma_run_h3<1, W / 16, 0, true>(ring, ring_lane, ReluSplitH<false, NTW, WT>{X, bits, pow2i(ex)}, bias_at(B_SIG, es), sg, mx_);
+            float mdummy = 0.f;
+            const int es = tau_x + wexp(NEFES_H3F_SIG);
+            mma_run_h3<1, W / 16, 0, true>(ring, ring_lane, ReluSplitH<false, NTW, WT>{X, bits, pow2i(tau_x - es_x), mdummy},
+                                           bias_at(B_SIG, es), sg);
             float* col = raw_col();
             if (col && h == 0) {
                 const int ch = (MODE == NEFES_FIELD_SIGMA) ? 0 : 3 + a.C;
@@ -138,10 +148,12 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
             }
         };
         int es_a, es_b = 0;
+        float M;                                                    // bound of the latest layer's output (true units)
         {
-            const int ex = cap_exp(exE, 0, wexp[NEFES_H3F_L1]);
-            es_a = ex + wexp[NEFES_H3F_L1];
-            mma_run_h3<NTW, ES / 8, 0, true, 1>(ring, ring_lane, LdsSplitH{e_lds, pow2i(ex)}, bias_at(0, es_a), A, mx);       // layer 1
+            const int tau = tau_of(mE, wexp(NEFES_H3F_L1));
+            es_a = tau + wexp(NEFES_H3F_L1);
+            mma_run_h3<NTW, ES / 8, 0, true>(ring, ring_lane, LdsSplitH{e_lds, pow2i(tau)}, bias_at(0, es_a), A);            // layer 1
+            M = rowb(NEFES_H3F_L1) * mE + bmax(NEFES_H3BB_L1);
         }
 #pragma unroll 1
         for (int p = 0; p < 4; ++p) {
@@ -150,44 +162,41 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
             const int seg2 = l2 <= 5 ? l2 - 1 : (l2 <= 8 ? l2 : NEFES_H3F_FINAL);
             clear_bits();
             {
-                const int ew = wexp[seg1], ex = next_exp(mx[0], es_a, ew);
-                es_b = es_a + ex + ew;
-                mma_run_h3<NTW, W / 16, 0, true, 1>(ring, ring_lane, ReluSplitH<CAP, NTW, WT>{A, bits, pow2i(ex)}, bias_at((l1 - 1) * W, es_b), B, mx);   // layers 2, 4, 6, 8
+                const int ew = wexp(seg1), tau = tau_of(M, ew);
+                float mx = 0.f;
+                mma_run_h3<NTW, W / 16, 0, true>(ring, ring_lane, ReluSplitH<CAP, NTW, WT>{A, bits, pow2i(tau - es_a), mx},
+                                                 bias_at((l1 - 1) * W, tau + ew), B);                 // layers 2, 4, 6, 8
+                M = rowb(seg1) * (pair_max(mx) * pow2i(-es_a)) + bmax(l1 - 1);
+                es_b = tau + ew;
             }
             put_masks(bits, WT);                                                                      // mask of layer l1-1
             if (p == 3 && MODE == NEFES_FIELD_SIGMA) break;
             clear_bits();
             {
-                const int ew = wexp[seg2];
-                int ex = next_exp(mx[0], es_b, ew);
-                if (p == 3) sigma_head(B, es_b, cap_exp(ex, es_b, wexp[NEFES_H3F_SIG]));   // static_sigma reads the same relu(h8) as xyz_encoding_final
-                // skip layer: its xyz part accumulates into the same tiles, so the embedding must fit the common scale too
-                if (p == 1) ex = (es_b + ex <= exE) ? ex : exE - es_b;
-                es_a = es_b + ex + ew;
-                // the run that completes the tiles reports their maximum: values for the ReLU consumers, magnitudes behind
-                // xyz_encoding_final (no activation: abs_too); at the skip layer the xyz part completes them and reports
-                mma_run_h3<NTW, W / 16, 0, true, 1>(ring, ring_lane, ReluSplitH<CAP, NTW, WT>{B, bits, pow2i(ex)},
-                                                    bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL, es_a), A, mx, p == 3);   // 3, 5, 7, final
-                if (p == 1) mma_run_h3<NTW, ES / 8, 0, false, 1>(ring, ring_lane, LdsSplitH{e_lds, pow2i(es_b + ex)}, ZeroInit{}, A, mx);   // skip: + W5[:, :63] e
+                const int ew = wexp(seg2);
+                // skip layer: its xyz part accumulates into the same tiles, so the common exponent must suit the embedding too
+                const int tau = tau_of(p == 1 ? fmaxf(M, mE) : M, ew);
+                if (p == 3) sigma_head(B, es_b, tau_of(M, wexp(NEFES_H3F_SIG)));   // static_sigma reads the same relu(h8)
+                float mx = 0.f;
+                mma_run_h3<NTW, W / 16, 0, true>(ring, ring_lane, ReluSplitH<CAP, NTW, WT>{B, bits, pow2i(tau - es_b), mx},
+                                                 bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL, tau + ew), A);   // 3, 5, 7, final
+                if (p == 1) mma_run_h3<NTW, ES / 8, 0, false>(ring, ring_lane, LdsSplitH{e_lds, pow2i(tau)}, ZeroInit{}, A);   // skip: + W5[:, :63] e
+                M = rowb(seg2) * (pair_max(mx) * pow2i(-es_b)) + (p == 1 ? rowb(NEFES_H3F_L5E) * mE : 0.f)
+                    + bmax(l2 <= 8 ? l2 - 1 : NEFES_H3BB_FINAL);
+                es_a = tau + ew;
             }
             put_masks(bits, WT);                                                                      // mask of layer l1
         }
-        if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head(B, es_b, next_exp(mx[0], es_b, wexp[NEFES_H3F_SIG]));
+        if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head(B, es_b, tau_of(M, wexp(NEFES_H3F_SIG)));
         if constexpr (MODE == NEFES_FIELD_FULL) {
             // dir_encoding and transient_encoding.0 as ONE stacked 2*NTH-tile product (pack.cpp add_heads_x6): tiles
             // [0, NTH) = dir, [NTH, 2 NTH) = t0
-            // The view direction is fetched here, not at the top of the tile (three registers across the whole trunk).  A
-            // compiler-issued load must never overlap the weight ring's LDS-DMA (field_common.h), so the ring is drained
-            // around it: once per 128 samples, the slabs in flight land while the load's own latency passes.
             float v[3];
             {
                 uint32_t mm, rr, ss;
                 locate(mm, rr, ss);
-                ring.drain();
 #pragma unroll
                 for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[(size_t)rr * 3 + c];
-                loads_landed();
-                pin(v);
             }
             float Dv[16];                                              // 14 embedding slots + 2 padding slots (two 16-k steps)
             {
@@ -208,23 +217,24 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
             };
             int es_dt;
             {
-                const int ew = wexp[NEFES_H3F_DT_H];
-                const int exD = pick_exp(pair_max(array_max(Dv)));                   // direction embedding (<= 1 for unit view dirs)
-                int ex = next_exp(mx[0], es_a, ew);
-                ex = (es_a + ex <= exD) ? ex : exD - es_a;                          // common scale with the direction part
-                es_dt = es_a + ex + ew;
-                mma_run_h3<2 * NTH, W / 16, 0, true>(ring, ring_lane, IdentSplitH<NTW, 0>{A, pow2i(ex)},
-                                                     Bias2{bias_at(B_DIR, es_dt), bias_at(B_T0, es_dt)}, dt, mx);
-                mma_run_h3<2 * NTH, 2, 0, false, 1, NTH>(ring, ring_lane, ArraySplitH<16>{Dv, pow2i(es_a + ex)}, ZeroInit{}, dt, mx);
+                const int ew = wexp(NEFES_H3F_DT_H);                                   // = wexp(DT_D): one matrix
+                const float mD = pair_max(array_max(Dv));                            // direction embedding (<= 1 for unit view dirs)
+                const int tau = tau_of(fmaxf(M, mD), ew);                            // common exponent of both parts
+                float mx = 0.f;
+                es_dt = tau + ew;
+                mma_run_h3<2 * NTH, W / 16, 0, true>(ring, ring_lane, IdentSplitH<NTW, 0>{A, pow2i(tau - es_a), mx},
+                                                     Bias2{bias_at(B_DIR, es_dt), bias_at(B_T0, es_dt)}, dt);
+                mma_run_h3<2 * NTH, 2, 0, false>(ring, ring_lane, ArraySplitH<16>{Dv, pow2i(tau)}, ZeroInit{}, dt);
+                M = rowb(NEFES_H3F_DT_H) * (pair_max(mx) * pow2i(-es_a)) + rowb(NEFES_H3F_DT_D) * mD
+                    + fmaxf(bmax(NEFES_H3BB_DIR), bmax(NEFES_H3BB_T0));               // both halves of the stacked output
             }
             {
                 f32x16 ar[NTR];
                 clear2();
-                const int ew = wexp[NEFES_H3F_RGB];
-                const int ex = next_exp(mx[0], es_dt, ew);                // dir_encoding tiles
-                const int es = es_dt + ex + ew;
-                float mx_[2];
-                mma_run_h3<NTR, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, 2 * NTH, WH>{dt, bits2, pow2i(ex)}, bias_at(B_RGB, es), ar, mx_);
+                const int ew = wexp(NEFES_H3F_RGB), tau = tau_of(M, ew), es = tau + ew;
+                float mdummy = 0.f;
+                mma_run_h3<NTR, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, 2 * NTH, WH>{dt, bits2, pow2i(tau - es_dt), mdummy},
+                                                 bias_at(B_RGB, es), ar);
                 put_masks(bits2, WH);                                 // dir_encoding
                 float* col = raw_col();
                 if (col) {
@@ -242,28 +252,32 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
             int es3, es2, es_th;
             clear2();
             {
-                const int ew = wexp[NEFES_H3F_T1];
-                const int ex = next_exp(mx[1], es_dt, ew);                // transient_encoding.0 tiles
-                es3 = es_dt + ex + ew;
-                mma_run_h3<NTH, W / 32, 0, true, 1>(ring, ring_lane, ReluSplitH<true, 2 * NTH, WH, NTH>{dt, bits2, pow2i(ex)}, bias_at(B_T1, es3), acc3, mx);
+                const int ew = wexp(NEFES_H3F_T1), tau = tau_of(M, ew);
+                float mx = 0.f;
+                es3 = tau + ew;
+                mma_run_h3<NTH, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, 2 * NTH, WH, NTH>{dt, bits2, pow2i(tau - es_dt), mx},
+                                                 bias_at(B_T1, es3), acc3);
+                M = rowb(NEFES_H3F_T1) * (pair_max(mx) * pow2i(-es_dt)) + bmax(NEFES_H3BB_T1);
             }
             put_masks(bits2, WH);                                     // transient_encoding.0
             clear2();
             {
-                const int ew = wexp[NEFES_H3F_T2];
-                const int ex = next_exp(mx[0], es3, ew);
-                es2 = es3 + ex + ew;
-                mma_run_h3<NTH, W / 32, 0, true, 1>(ring, ring_lane, ReluSplitH<true, NTH, WH>{acc3, bits2, pow2i(ex)}, bias_at(B_T2, es2), acc2, mx);
+                const int ew = wexp(NEFES_H3F_T2), tau = tau_of(M, ew);
+                float mx = 0.f;
+                es2 = tau + ew;
+                mma_run_h3<NTH, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, NTH, WH>{acc3, bits2, pow2i(tau - es3), mx},
+                                                 bias_at(B_T2, es2), acc2);
+                M = rowb(NEFES_H3F_T2) * (pair_max(mx) * pow2i(-es3)) + bmax(NEFES_H3BB_T2);
             }
             put_masks(bits2, WH);                                     // transient_encoding.2
             f32x16 th[1];
             clear2();
             {
-                const int ew = wexp[NEFES_H3F_TH];
-                const int ex = next_exp(mx[0], es2, ew);
-                es_th = es2 + ex + ew;
-                float mx_[2];
-                mma_run_h3<1, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, NTH, WH>{acc2, bits2, pow2i(ex)}, bias_at(B_TH, es_th), th, mx_);
+                const int ew = wexp(NEFES_H3F_TH), tau = tau_of(M, ew);
+                float mdummy = 0.f;
+                es_th = tau + ew;
+                mma_run_h3<1, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, NTH, WH>{acc2, bits2, pow2i(tau - es2), mdummy},
+                                               bias_at(B_TH, es_th), th);
             }
             put_masks(bits2, WH);
             float* col = raw_col();
@@ -281,7 +295,6 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
             }
         }
     }
-    ring.drain();
 }
 
 // magic multiplier for unsigned division by d, exact for dividends below 2^31: q = mulhi(n, magic) >> shift

@@ -9,9 +9,14 @@
 //
 // fp16 carries 5 exponent bits, so every operand is scaled by a power of two first:
 //   * weights per MATRIX, by the packer (pack.cpp: max |w| 2^ew in [2^14, 2^15); ew rides in the stream's exponent table);
-//   * activations / gradient vectors per SAMPLE and product: the largest magnitude of the lane pair's values picks ex
-//     (v_max3_f32 over the accumulators, one cross-lane exchange), and the split multiplies by 2^ex inside the conversion
-//     (v_fma_mixlo/mixhi_f16: hi = RNE_f16(x 2^ex), lo = RNE_f16(x 2^ex - hi): four VALU per pair of values).
+//   * activations / gradient vectors per SAMPLE and product, inside the conversion (v_fma_mixlo/mixhi_f16: hi = RNE_f16(x 2^ex),
+//     lo = RNE_f16(x 2^ex - hi): four VALU per pair of values).  ex comes from an upper BOUND of the sample's largest magnitude:
+//     |W x + b|_inf <= rowbound(W) |x|_inf + |b|_inf, with rowbound and max|b| from the packer's table and |x|_inf measured
+//     exactly while x was split for the previous product (one v_max3_f32 per pair of values, on registers the split reads
+//     anyway).  Scanning the finished accumulators for their maximum instead costs a read of all 128 accumulator registers per
+//     layer and a serial tail: measured 17 % (forward) / 24 % (backward) of the kernel time.  The bound is loose by the ratio
+//     rowbound / actual gain (~2^3..2^4 for random weights, not cumulative), i.e. operands land 3-4 binades below 2^15; fp16
+//     subnormals (consumed by the MFMA: tools/probe/h3_probe.hip) keep the absolute resolution at 2^-24, 2^-35 of the maximum.
 // Powers of two commute with the products, with ReLU and with the sign bits the masks record, so an accumulator set simply
 // carries its exponent: acc = 2^es * (true value), es per lane (an int the kernels thread through the layer chain).  Bias tiles enter multiplied by 2^es; products
 // that accumulate into the same tiles use a common exponent; raw outputs are multiplied by 2^-es on the way out.
@@ -36,7 +41,8 @@ __device__ __forceinline__ f16x8 as_f16x8(f32x4 v) {
 }
 
 // ---- exponent bookkeeping (all per lane, integers: exact) -----------------------------------------------------------------
-__device__ __forceinline__ float pow2i(int e) {            // 2^e, e in [-126, 127]
+__device__ __forceinline__ float pow2i(int e) {            // 2^e, e clamped to [-126, 127]
+    e = e < -126 ? -126 : (e > 127 ? 127 : e);
     return __uint_as_float((uint32_t)(e + 127) << 23);
 }
 // exponent ex with m 2^ex in [2^14, 2^15) for the lane pair's largest magnitude m >= 0; 0 when m is zero / tiny
@@ -54,18 +60,12 @@ __device__ __forceinline__ float pair_max(float m) {
     const uint32_t a = r[0], b = r[1];
     return __uint_as_float(a > b ? a : b);                  // non-negative floats order like their bit patterns
 }
-// m = max(m, tile): the largest value (MODE 1: ReLU consumers; negative values lose against m >= 0) or magnitude (MODE 2) of
-// one finished accumulator tile.  The reads go through inline asm on purpose: a plain read would be CSE'd with the consumer's
-// read of the same accumulator a whole layer later, i.e. the compiler would park all 128 values of the set in VGPRs (measured:
-// the kernel then needs 256 + 128 vector registers).
-template <int MODE>
-__device__ __forceinline__ void tile_max_acc(float& m, const f32x16& X) {
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        if (MODE == 1) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(X[r]), "v"(X[r + 1]));
-        else if (MODE == 2) asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(X[r]), "v"(X[r + 1]));
-        else asm volatile("v_max3_f32 %0, %0, -%1, -%2" : "+v"(m) : "v"(X[r]), "v"(X[r + 1]));     // MODE 3: negated values
-    }
+// running maximum of the values a product consumes (they sit in VGPRs for the split): one instruction per pair
+__device__ __forceinline__ void max3_acc(float& m, float x0, float x1) {
+    asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(x0), "v"(x1));
+}
+__device__ __forceinline__ void absmax3_acc(float& m, float x0, float x1) {
+    asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(x0), "v"(x1));
 }
 template <int N>
 __device__ __forceinline__ float array_max(const float (&v)[N]) {
@@ -116,6 +116,7 @@ struct ReluSplitH {
     const f32x16 (&X)[NX];
     uint32_t (&bits)[NWORDS];
     float r;
+    float& m;                   // running max of the consumed values (accumulator units), this lane
     template <bool NOP>
     __device__ __forceinline__ void pair(Split2& o, int q, int p) const {
         const float v0 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p], v1 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1];
@@ -123,7 +124,9 @@ struct ReluSplitH {
             mask_shift_in(bits[(8 * q + 2 * p) >> 5], v0);
             mask_shift_in(bits[(8 * q + 2 * p + 1) >> 5], v1);
         }
-        split_pair_h<NOP>(o, p, relu1<false>(v0), relu1<false>(v1), r);
+        const float x0 = relu1<false>(v0), x1 = relu1<false>(v1);
+        max3_acc(m, x0, x1);
+        split_pair_h<NOP>(o, p, x0, x1, r);
     }
 };
 template <int NX, int NWORDS, int T0>
@@ -131,10 +134,12 @@ struct MaskedSplitH {
     const f32x16 (&X)[NX];
     uint32_t (&bits)[NWORDS];
     float r;
+    float& m;
     template <bool NOP>
     __device__ __forceinline__ void pair(Split2& o, int q, int p) const {
         const float x0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
         const float x1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
+        absmax3_acc(m, x0, x1);
         split_pair_h<NOP>(o, p, x0, x1, r);
     }
 };
@@ -142,9 +147,12 @@ template <int NX, int T0>
 struct IdentSplitH {
     const f32x16 (&X)[NX];
     float r;
+    float& m;
     template <bool NOP>
     __device__ __forceinline__ void pair(Split2& o, int q, int p) const {
-        split_pair_h<NOP>(o, p, X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1], r);
+        const float x0 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p], x1 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1];
+        absmax3_acc(m, x0, x1);
+        split_pair_h<NOP>(o, p, x0, x1, r);
     }
 };
 template <int N>
@@ -185,25 +193,76 @@ struct BiasInitScaled {
     }
 };
 
+// Weight-stream ring filled THROUGH REGISTERS: each wave moves NEFES_SLAB_PIECES contiguous 1 KiB pieces of every slab with
+// plain global_load_dwordx4 (into `stage`) and ds_write_b128, instead of global_load_lds_dwordx4 (WeightRing).  Issuing an
+// LDS-DMA piece stalls the issuing wave for 60-185 cycles among MFMAs and ds_reads (MI355X_MICROARCH.md); in the fp16 kernels,
+// whose units carry three MFMAs for 2 KiB of weights, that was a quarter of the kernel time (tools/ablate_h3.sh: 215 -> 164 ms
+// without the transfers).  A register-staged piece costs two ordinary issues, the compiler counts the loads itself (no
+// "no compiler load while a DMA is in flight" rule, field_common.h), and two slots suffice:
+//     while slab i is consumed from slot i%2, piece q of slab i+1 (loaded during slab i-1, one slab time of latency cover) is
+//     written to slot (i+1)%2 and the piece q of slab i+2 is requested into the same four registers;
+//     acquire() = own writes done (lgkmcnt) + workgroup barrier: slab i+1 is complete and nobody reads slab i any more.
+// Same interface as WeightRing towards mma_run / mma_run_h3.
+struct StagedRing {
+    const char* src;        // stream base (wave-uniform)
+    uint32_t n_slabs;       // slabs in the stream (wraps)
+    uint32_t g_next;        // slab the next loads fetch
+    uint32_t c_slot;        // slot being consumed (0/1)
+    uint32_t cur_off;       // its LDS offset
+    uint32_t my_off;        // wave * PIECES KiB + lane * 16: this lane's share of every slab
+    char* my_lds;           // ring base + my_off
+    f32x4 pf;               // first fragment group of the slab being consumed
+    f32x4 stage[NEFES_SLAB_PIECES];
+
+    __device__ __forceinline__ void load_piece(int q) {
+        stage[q] = *(const f32x4*)(src + (size_t)g_next * NEFES_SLAB_BYTES + my_off + q * 1024);
+    }
+    __device__ __forceinline__ void init(const char* stream, uint32_t nslabs, char* ring_base, int wave, int lane) {
+        src = stream; n_slabs = nslabs;
+        my_off = (uint32_t)(wave * NEFES_SLAB_PIECES * 1024 + lane * 16);
+        my_lds = ring_base + my_off;
+        g_next = 0; c_slot = 0; cur_off = 0;
+#pragma unroll
+        for (int q = 0; q < NEFES_SLAB_PIECES; ++q) load_piece(q);
+#pragma unroll
+        for (int q = 0; q < NEFES_SLAB_PIECES; ++q) *(f32x4*)(my_lds + q * 1024) = stage[q];      // slab 0 -> slot 0
+        g_next = n_slabs > 1 ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < NEFES_SLAB_PIECES; ++q) load_piece(q);                                 // slab 1 in flight
+        g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
+    }
+    // piece q of the next slab: registers -> the idle slot; then request the same piece of the slab after it
+    __device__ __forceinline__ void issue_piece(int q) {
+        *(f32x4*)(my_lds + (c_slot ^ 1u) * NEFES_SLAB_BYTES + q * 1024) = stage[q];
+        load_piece(q);
+        if (q == NEFES_SLAB_PIECES - 1) g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
+    }
+    __device__ __forceinline__ uint32_t acquire() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        c_slot ^= 1u;
+        return c_slot * NEFES_SLAB_BYTES;
+    }
+    __device__ __forceinline__ void prime(const char* ring_lane) {      // after init(): publish slab 0
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur_off = 0;
+        pf = *(const f32x4*)(ring_lane);
+    }
+    __device__ __forceinline__ void drain() {}
+};
+
 // acc[T0 .. T0+NT) = W-block * src over KS16 steps of 16 k-values; init(t) is the C operand of each tile's first MFMA
 // (FIRST = false: accumulate onto acc).
-// MAXMODE != 0: this run completes the tiles, and their largest value (1: for a ReLU consumer) / magnitude (2) is needed to
-// scale the NEXT product's operand: mx[0] covers tiles [0, SPLIT), mx[1] tiles [SPLIT, NT) (per lane; combine the lane pair with
-// pair_max).  Tile t is folded in two units after its last MFMA, in the shadow of the following ones; the last two after the run.
-// abs_too (run time, with MAXMODE 1): also fold the negated values, i.e. report magnitudes -- lets one instantiation inside a
-// rolled layer loop serve both kinds of consumer.  Stream order: for k16-step q, for tile t: [A_hi | A_lo] (2 KiB unit);
-// floor(slab KiB / 2) units per slab; a segment starts on a slab boundary.  Same ring protocol, look-ahead (the operand of
-// step q+1 is produced during step q, one pair of values behind every (second) tile) and small-terms-first order as
-// mma_run_x6.
-template <int NT, int KS16, int T0, bool FIRST = true, int MAXMODE = 0, int SPLIT = NT, class SrcFn, class InitFn, int NACC, int SLOTS>
-__device__ __forceinline__ void mma_run_h3(WeightRing<SLOTS>& ring, const char* ring_lane, const SrcFn& src, const InitFn& init,
-                                           f32x16 (&acc)[NACC], float (&mx)[2], bool abs_too = false) {
+template <int NT, int KS16, int T0, bool FIRST = true, class SrcFn, class InitFn, int NACC, class Ring>
+__device__ __forceinline__ void mma_run_h3(Ring& ring, const char* ring_lane, const SrcFn& src, const InitFn& init,
+                                           f32x16 (&acc)[NACC]) {
     static_assert(T0 + NT <= NACC, "accumulator array too small");
-    if (MAXMODE) mx[0] = mx[1] = 0.f;
     constexpr int UPS = (NEFES_SLAB_FRAGS / 4) / 2;       // units per slab
     constexpr int NU = KS16 * NT;
     constexpr int NSLAB = (NU + UPS - 1) / UPS;
     Split2 B, Bn;
+    // H3_ABL_* macros: timing ablations only (tools/ablate_h3.sh builds side libraries with them; results are garbage)
     src.template pair<false>(B, 0, 0);
     src.template pair<false>(B, 0, 1);
     src.template pair<false>(B, 0, 2);
@@ -212,7 +271,11 @@ __device__ __forceinline__ void mma_run_h3(WeightRing<SLOTS>& ring, const char* 
     // FIRST: the C operand of a tile's first MFMA (bias x 2^es, or zero) is written straight into the tile's own registers,
     // one unit ahead of its first use -- the output tiles are dead until then -- rather than into a 16-register staging tile
     // (this kernel family sits a handful of registers below its 512: DESIGN.md)
+#ifdef H3_ABL_NOBIAS
+    if (FIRST) acc[T0] = ZeroInit{}(0);
+#else
     if (FIRST) acc[T0] = init(0);
+#endif
     const char* p = ring_lane + ring.cur_off;
     f32x4 ah = ring.pf, al = *(const f32x4*)(p + 1024);
 #pragma unroll
@@ -227,7 +290,11 @@ __device__ __forceinline__ void mma_run_h3(WeightRing<SLOTS>& ring, const char* 
                 f32x4 nh;
                 const bool last = !(uu + 1 < nu);
                 if (!last) {
+#ifdef H3_ABL_NOAREAD
+                    nh = ah;
+#else
                     nh = *(const f32x4*)(p + (2 * uu + 2) * 1024);
+#endif
                 } else {
 #pragma unroll
                     for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
@@ -242,8 +309,14 @@ __device__ __forceinline__ void mma_run_h3(WeightRing<SLOTS>& ring, const char* 
                 const f16x8 Bh = as_f16x8(B.h), Bl = as_f16x8(B.l);
                 f32x16 c = acc[T0 + t];
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, c, 0, 0, 0);          // small terms first
+#ifndef H3_ABL_NOAREAD
                 al = *(const f32x4*)(p + (last ? 1 : 2 * uu + 3) * 1024);
+#endif
+#ifdef H3_ABL_NOBIAS
+                if (FIRST && q == 0 && t + 1 < NT) acc[T0 + t + 1] = ZeroInit{}(0);
+#else
                 if (FIRST && q == 0 && t + 1 < NT) acc[T0 + t + 1] = init(t + 1);
+#endif
                 if (uu + 1 < nu) {
 #pragma unroll
                     for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
@@ -261,8 +334,10 @@ __device__ __forceinline__ void mma_run_h3(WeightRing<SLOTS>& ring, const char* 
 #pragma unroll
                     for (int pp = 0; pp < 4; ++pp)
                         if (NT >= 4 ? (t == pp * STRIDE + STRIDE - 1) : (t == (pp * NT) / 4)) {
+#ifndef H3_ABL_NOSPLIT
                             if (pp == 3) src.template pair<true>(Bn, q + 1, pp);
                             else src.template pair<false>(Bn, q + 1, pp);
+#endif
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {                     // interleave: one MFMA, then up to four VALU
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -270,20 +345,9 @@ __device__ __forceinline__ void mma_run_h3(WeightRing<SLOTS>& ring, const char* 
                             }
                         }
                 }
-                if (MAXMODE && q == KS16 - 1 && t >= 2) {
-                    tile_max_acc<MAXMODE>(mx[(t - 2) < SPLIT ? 0 : 1], acc[T0 + t - 2]);
-                    if (MAXMODE == 1 && abs_too) tile_max_acc<3>(mx[(t - 2) < SPLIT ? 0 : 1], acc[T0 + t - 2]);
-                }
                 ah = nh;
             }
         }
     }
     ring.pf = ah;
-    if (MAXMODE) {
-#pragma unroll
-        for (int t = (NT >= 2 ? NT - 2 : 0); t < NT; ++t) {
-            tile_max_acc<MAXMODE>(mx[t < SPLIT ? 0 : 1], acc[T0 + t]);
-            if (MAXMODE == 1 && abs_too) tile_max_acc<3>(mx[t < SPLIT ? 0 : 1], acc[T0 + t]);
-        }
-    }
 }

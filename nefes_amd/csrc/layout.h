@@ -94,11 +94,19 @@ NEFES_HD int nefes_stream_slab_kib(int stream) {
     if (stream == NEFES_STREAM_FWD_SIGMA_H3 || stream == NEFES_STREAM_FWD_FULL_H3) return NEFES_H3_FWD_SLAB_KIB;
     return stream >= NEFES_STREAM_FWD_SIGMA_X6 ? NEFES_X6_SLAB_KIB : NEFES_FWD_SLAB_KIB;
 }
-// Segment ordinals of the _H3 streams = index into the stream's weight-scale exponent table (pack.cpp emits one int32 per
-// segment, in stream order; fp32 segments carry 0).
+// Segment ordinals of the _H3 streams.  The stream's scale table (pack.cpp; words behind the bias blocks, NefesStreamInfo.
+// scale_off) holds per segment s: word 2s = weight-scale exponent e (int32: the weights are stored times 2^e; 0 for fp32
+// segments), word 2s+1 = row bound (float: max over the segment's output rows of the sum of |w| over its k-values, so that
+// |W x|_inf <= bound |x|_inf); then, per bias block of the stream in order, max |b| (float).
 enum { NEFES_H3F_L1 = 0, NEFES_H3F_L2, NEFES_H3F_L3, NEFES_H3F_L4, NEFES_H3F_L5H, NEFES_H3F_L5E, NEFES_H3F_L6, NEFES_H3F_L7,
        NEFES_H3F_L8, NEFES_H3F_SIG, NEFES_H3F_FINAL, NEFES_H3F_DT_H, NEFES_H3F_DT_D, NEFES_H3F_RGB, NEFES_H3F_T1, NEFES_H3F_T2,
        NEFES_H3F_TH, NEFES_H3F_N };
+NEFES_HD int nefes_h3_tab_exp(int seg) { return 2 * seg; }
+NEFES_HD int nefes_h3_tab_bound(int seg) { return 2 * seg + 1; }
+NEFES_HD int nefes_h3_tab_bias(int n_segs, int block) { return 2 * n_segs + block; }
+/* bias blocks of the forward streams, in stream order */
+enum { NEFES_H3BB_L1 = 0, NEFES_H3BB_SIG = 8, NEFES_H3BB_FINAL, NEFES_H3BB_DIR, NEFES_H3BB_RGB, NEFES_H3BB_T0, NEFES_H3BB_T1,
+       NEFES_H3BB_T2, NEFES_H3BB_TH };
 enum { NEFES_H3B_RGB = 0, NEFES_H3B_TH, NEFES_H3B_T2, NEFES_H3B_T1, NEFES_H3B_T0, NEFES_H3B_DIR, NEFES_H3B_FINAL, NEFES_H3B_SIG,
        NEFES_H3B_L8, NEFES_H3B_L7, NEFES_H3B_L6, NEFES_H3B_L5, NEFES_H3B_L4, NEFES_H3B_L3, NEFES_H3B_L2, NEFES_H3B_L1,
        NEFES_H3B_N };

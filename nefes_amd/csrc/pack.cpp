@@ -36,6 +36,25 @@ struct Seg {
         if (r < 0 || k < 0) return 0.f;
         return transposed ? W[(size_t)k * ld + r] : W[(size_t)r * ld + k];
     }
+    // max over the segment's output rows of sum_k |w|: |W x|_inf <= row_bound |x|_inf (the fp16 kernels scale the NEXT operand
+    // from this bound instead of scanning the accumulators for their maximum)
+    float row_bound() const {
+        if (!W) return 0.f;
+        float best = 0.f;
+        for (int t = 0; t < nt; ++t)
+            for (int i = 0; i < 32; ++i) {
+                const int r = ridx[t * 32 + i];
+                if (r < 0) continue;
+                double sum = 0.0;
+                for (int s = 0; s < ks; ++s)
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int kk = kidx[s * 2 + hh];
+                        if (kk >= 0) sum += fabs((double)(transposed ? W[(size_t)kk * ld + r] : W[(size_t)r * ld + kk]));
+                    }
+                if ((float)sum > best) best = (float)sum;
+            }
+        return best * 1.0001f;
+    }
     int units() const { return (ks / 8) * nt; }                       // x6: one unit = (k16-step, tile) = 3 KiB; h3: 2 KiB
     int unit_kib() const { return h3 ? 2 : 3; }
     int slabs(int slab_frags) const {
@@ -123,7 +142,7 @@ struct Stream {
         for (auto& b : bias) n += (int)b.ridx.size();
         return n;
     }
-    int scale_count() const { return h3 ? ((int)segs.size() + 3) / 4 * 4 : 0; }
+    int scale_count() const { return h3 ? (2 * (int)segs.size() + (int)bias.size() + 3) / 4 * 4 : 0; }
     int bias_floats() const { return bias_only() + scale_count(); }
 };
 
@@ -500,10 +519,22 @@ static int pack_walk(const NefesNetDesc* desc, const float* const* tensors, char
                 if (map) { map[boff / 2] = code(v, 0); map[boff / 2 + 1] = code(v, 1); }
                 boff += 4;
             }
-        if (st[k].h3) {   // weight-scale exponent table: one int32 per segment, padded to a multiple of four
+        if (st[k].h3) {   // scale table (layout.h): per segment (exponent, row bound), then max |b| per bias block; padded to 4 words
+            const int ns = (int)st[k].segs.size(), nb = (int)st[k].bias.size();
             for (int i = 0; i < st[k].scale_count(); ++i) {
-                const int32_t e = i < (int)st[k].segs.size() ? st[k].segs[i].wexp : 0;
-                if (base) memcpy(base + boff, &e, 4);
+                uint32_t word = 0;
+                if (!map && i < 2 * ns) {
+                    const Seg& sg = st[k].segs[i / 2];
+                    if (i % 2 == 0) { const int32_t e = sg.wexp; memcpy(&word, &e, 4); }
+                    else { const float b = sg.row_bound(); memcpy(&word, &b, 4); }
+                } else if (!map && i < 2 * ns + nb) {
+                    const BiasBlk& bb = st[k].bias[i - 2 * ns];
+                    float m = 0.f;
+                    for (int r : bb.ridx)
+                        if (r >= 0 && fabsf(bb.b[r]) > m) m = fabsf(bb.b[r]);
+                    memcpy(&word, &m, 4);
+                }
+                if (base) memcpy(base + boff, &word, 4);
                 if (map) map[boff / 2] = map[boff / 2 + 1] = 0;     // (the device re-pack does not produce fp16 streams)
                 boff += 4;
             }

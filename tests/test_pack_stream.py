@@ -582,17 +582,21 @@ def split_f16(x):
 class StreamH3:
     """Consumption of an fp16 two-part stream exactly as mma_run_h3 does: units of two 1 KiB groups (hi | lo), slab_kib/2 units
     per slab, a segment starts on a slab boundary; lane (m, g) of unit (k16-step q, tile t) multiplies slot (8q+i, g).  The
-    operand vector arrives in fp32 with a per-sample exponent `ex`; the three products hh + hl + lh are accumulated (in float64
-    here; fp32 in the matrix core).  fp32 segments of the same stream (backward heads) go through `mma32`."""
+    operand vector arrives in fp32 with a per-sample multiplier 2^ex; the three products hh + hl + lh are accumulated (in
+    float64 here; fp32 in the matrix core).  fp32 segments of the same stream (backward heads) go through `mma32`.
+    Scale table (layout.h): per segment (weight exponent, row bound), then max |b| per bias block."""
 
-    def __init__(self, blob, si, slab_kib):
+    def __init__(self, blob, si, slab_kib, n_segs):
         self.slab_kib, self.half = slab_kib, slab_kib * 512
         self.ups = slab_kib // 2
         self.raw = np.frombuffer(blob, np.uint16, count=si.n_slabs * self.half, offset=si.slab_off).reshape(si.n_slabs, self.half)
         self.f32 = np.frombuffer(blob, np.float32, count=si.n_slabs * slab_kib * 256, offset=si.slab_off).reshape(si.n_slabs, slab_kib, 64, 4)
         nb = si.scale_off
         self.bias = np.frombuffer(blob, np.float32, count=nb, offset=si.bias_off)
-        self.wexp = np.frombuffer(blob, np.int32, count=si.scale_count, offset=si.bias_off + 4 * nb)
+        tab = np.frombuffer(blob, np.uint32, count=si.scale_count, offset=si.bias_off + 4 * nb)
+        self.wexp = tab[0:2 * n_segs:2].view(np.int32)
+        self.rowb = tab[1:2 * n_segs:2].view(np.float32)
+        self.bmax = tab[2 * n_segs:].view(np.float32)
         self.pos = self.bpos = 0
 
     def bias_tiles(self, nt, n):
@@ -605,7 +609,8 @@ class StreamH3:
         k16 = vec.shape[0] // 8
         n_units = k16 * nt
         scaled = (vec.astype(np.float64) * np.exp2(ex.astype(np.float64))[None, None, :]).astype(np.float32)
-        assert np.all(np.abs(scaled) < 65504.0)
+        assert np.all(np.abs(scaled) < 65504.0), "operand exponent lets a value overflow fp16"
+        self.headroom = min(getattr(self, "headroom", 99.), float(np.log2(65536.0 / max(np.abs(scaled).max(), 1e-30))))
         bh, bl = split_f16(scaled)
         for u in range(n_units):
             sl, uu = self.pos + u // self.ups, u % self.ups
@@ -631,24 +636,27 @@ class StreamH3:
                 acc[t] += a[:32, None] * vec[s, 0][None, :] + a[32:, None] * vec[s, 1][None, :]
 
 
-def cap(ex, es_in, ew):
-    return np.minimum(ex, 100 - es_in - ew)
+def tau_of(M, ew):
+    """field_fwd_h3.hip / field_bwd_h3.hip tau_of: exponent the operand is brought to, from the BOUND M of its largest magnitude."""
+    return np.minimum(pick_exp(np.asarray(M, np.float32)), 100 - ew)
 
 
-def relu_max(acc):
-    return np.maximum(acc, 0).max((0, 1)).astype(np.float32)
+def relu_max(acc, es):
+    """what ReluSplitH measures while splitting: the largest ReLU'd value, back in true units"""
+    return (np.maximum(acc, 0).max((0, 1)) * np.exp2(-es.astype(np.float64))).astype(np.float32)
 
 
-def abs_max(acc):
-    return np.abs(acc).max((0, 1)).astype(np.float32)
+def abs_max(acc, es):
+    return (np.abs(acc).max((0, 1)) * np.exp2(-es.astype(np.float64))).astype(np.float32)
 
 
 @pytest.mark.parametrize("Wd,Cf", [(256, 16), (128, 128)])
 def test_h3_streams_reproduce_the_mlp(Wd, Cf):
     """The fp16 two-part streams consumed in kernel order with the kernels' scale bookkeeping (field_fwd_h3.hip /
-    field_bwd_h3.hip: per-sample operand exponents from the running maxima, per-matrix weight exponents from the stream's table,
-    common exponents where two products share accumulators, bias x 2^es, outputs x 2^-es): forward against the float64 oracle
-    to fp32-level accuracy -- sigma-only and full -- and backward-to-inputs against float64 autograd."""
+    field_bwd_h3.hip): operand exponents from BOUNDS of the largest magnitude (the packer's row bounds x the exactly measured
+    maximum of the previous operand + max |b|), per-matrix weight exponents from the table, common exponents where two products
+    share accumulators, bias x 2^es, outputs x 2^-es.  No operand may overflow fp16 (asserted in StreamH3.mma); forward against
+    the float64 oracle to fp32-level accuracy -- sigma-only and full -- and backward-to-inputs against float64 autograd."""
     n = 12
     g = torch.Generator().manual_seed(8)
     pts = (torch.rand(n, 3, generator=g) - .5) * 5
@@ -658,7 +666,8 @@ def test_h3_streams_reproduce_the_mlp(Wd, Cf):
     e63, e27 = O.freq_encode(pts, 10), O.freq_encode(dirs, 4)
     NTW, NTH, NTR = Wd // 32, Wd // 64, (3 + Cf + 31) // 32
     E, D = emb_vector(e63.numpy(), 10, 32), emb_vector(e27.numpy(), 4, 16)
-    exE = pick_exp(np.maximum(1.0, np.abs(pts.numpy()).max(1)).astype(np.float32))
+    mE = np.maximum(1.0, np.abs(pts.numpy()).max(1)).astype(np.float32)
+    zeros = np.zeros(n, np.int64)
 
     def trunk(st, full):
         b = {"L1": st.bias_tiles(NTW, n)}
@@ -668,72 +677,80 @@ def test_h3_streams_reproduce_the_mlp(Wd, Cf):
         if full:
             for name, nt in (("FINAL", NTW), ("DIR", NTH), ("RGB", NTR), ("T0", NTH), ("T1", NTH), ("T2", NTH), ("TH", 1)):
                 b[name] = st.bias_tiles(nt, n)
-        w = st.wexp
-        masks = {}
-        ex = cap(exE, 0, w[H3F["L1"]])
-        es = ex + w[H3F["L1"]]
+        w, rb, bm = st.wexp, st.rowb, st.bmax
+        BB = dict(L1=0, SIG=8, FINAL=9, DIR=10, RGB=11, T0=12, T1=13, T2=14, TH=15)
+        masks, out = {}, {}
+        tau = tau_of(mE, w[H3F["L1"]])
+        es = tau + w[H3F["L1"]]
         acc = b["L1"] * np.exp2(es)[None, None, :]
-        st.mma(NTW, E, ex, acc)
-        out = {}
+        st.mma(NTW, E, tau, acc)
+        M = rb[H3F["L1"]] * mE + bm[BB["L1"]]
+
+        def sigma(acc, es, M):
+            H = acc_to_vec(np.maximum(acc, 0).astype(np.float32))
+            tau = tau_of(M, w[H3F["SIG"]])
+            e_sg = tau + w[H3F["SIG"]]
+            sg = b["SIG"] * np.exp2(e_sg)[None, None, :]
+            st.mma(1, H, tau - es, sg)
+            out["sigma"] = softplus(sg[0, 0] * np.exp2(-e_sg))
+
         for l in range(2, 10 if full else 9):
             name = f"L{l}" if l <= 8 else "FINAL"
             seg = H3F["L5H"] if l == 5 else H3F[name]
+            assert np.all(relu_max(acc, es) <= M), "row bound violated"
             masks[f"L{l - 1}"] = acc > 0
+            if l == 9:
+                sigma(acc, es, M)                                   # static_sigma reads the same relu(h8)
             H = acc_to_vec(np.maximum(acc, 0).astype(np.float32))
-            ex = cap(pick_exp(relu_max(acc)), es, w[seg])
-            if l == 9 or (l == 8 and not full):
-                pass
-            if name == "FINAL" or (not full and l == 9):
-                pass
-            if l == 9:                                              # static_sigma reads the same relu(h8)
-                exs = cap(ex, es, w[H3F["SIG"]])
-                sg = b["SIG"] * np.exp2(es + exs + w[H3F["SIG"]])[None, None, :]
-                st.mma(1, H, exs, sg)
-                out["sigma"] = softplus(sg[0, 0] * np.exp2(-(es + exs + w[H3F["SIG"]])))
-            if l == 5:
-                ex = np.where(es + ex <= exE, ex, exE - es)
-            es_new = es + ex + w[seg]
-            acc = b[name] * np.exp2(es_new)[None, None, :]
-            st.mma(NTW, H, ex, acc)
+            mx = relu_max(acc, es)
+            tau = tau_of(np.maximum(M, mE) if l == 5 else M, w[seg])
+            es_new = tau + w[seg]
+            nxt = b[name] * np.exp2(es_new)[None, None, :]
+            st.mma(NTW, H, tau - es, nxt)
+            M = rb[seg] * mx + bm[BB["FINAL"] if l == 9 else l - 1]
             if l == 5:
                 assert w[H3F["L5E"]] == w[H3F["L5H"]]
-                st.mma(NTW, E, es + ex, acc)
-            es = es_new
+                st.mma(NTW, E, tau, nxt)
+                M = M + rb[H3F["L5E"]] * mE
+            acc, es = nxt, es_new
         if not full:
-            H = acc_to_vec(np.maximum(acc, 0).astype(np.float32))
-            exs = cap(pick_exp(relu_max(acc)), es, w[H3F["SIG"]])
-            sg = b["SIG"] * np.exp2(es + exs + w[H3F["SIG"]])[None, None, :]
-            st.mma(1, H, exs, sg)
-            out["sigma"] = softplus(sg[0, 0] * np.exp2(-(es + exs + w[H3F["SIG"]])))
+            assert np.all(relu_max(acc, es) <= M)
+            sigma(acc, es, M)
             return out, masks
-        # acc = xyz_encoding_final output (no activation), scale es
-        exD = pick_exp(np.abs(D).max((0, 1)).astype(np.float32))
+        # acc = xyz_encoding_final output (no activation), exponent es
+        assert np.all(abs_max(acc, es) <= M)
+        mD = np.abs(D).max((0, 1)).astype(np.float32)
         ew = w[H3F["DT_H"]]
         assert w[H3F["DT_D"]] == ew
-        ex = cap(pick_exp(abs_max(acc)), es, ew)
-        ex = np.where(es + ex <= exD, ex, exD - es)
-        es_dt = es + ex + ew
+        tau = tau_of(np.maximum(M, mD), ew)
+        es_dt = tau + ew
         dt = np.concatenate([b["DIR"], b["T0"]], 0) * np.exp2(es_dt)[None, None, :]
-        st.mma(2 * NTH, acc_to_vec(acc.astype(np.float32)), ex, dt)
-        st.mma(2 * NTH, D, es + ex, dt)
+        mx = abs_max(acc, es)
+        st.mma(2 * NTH, acc_to_vec(acc.astype(np.float32)), tau - es, dt)
+        st.mma(2 * NTH, D, tau, dt)
+        M = rb[H3F["DT_H"]] * mx + rb[H3F["DT_D"]] * mD + max(bm[BB["DIR"]], bm[BB["T0"]])
+        assert np.all(abs_max(dt, es_dt) <= M)
         masks["DIR"], masks["T0"] = dt[:NTH] > 0, dt[NTH:] > 0
-        ex = cap(pick_exp(relu_max(dt[:NTH])), es_dt, w[H3F["RGB"]])
-        es_ar = es_dt + ex + w[H3F["RGB"]]
+        tau = tau_of(M, w[H3F["RGB"]])
+        es_ar = tau + w[H3F["RGB"]]
         ar = b["RGB"] * np.exp2(es_ar)[None, None, :]
-        st.mma(NTR, acc_to_vec(np.maximum(dt[:NTH], 0).astype(np.float32)), ex, ar)
+        st.mma(NTR, acc_to_vec(np.maximum(dt[:NTH], 0).astype(np.float32)), tau - es_dt, ar)
         out["rgbfeat"] = (ar * np.exp2(-es_ar)[None, None, :]).reshape(NTR * 32, n)[:3 + Cf].T
         src, es_s = dt[NTH:], es_dt
         for name in ("T1", "T2"):
-            ex = cap(pick_exp(relu_max(src)), es_s, w[H3F[name]])
-            es_n = es_s + ex + w[H3F[name]]
+            tau = tau_of(M, w[H3F[name]])
+            es_n = tau + w[H3F[name]]
             acc2 = b[name] * np.exp2(es_n)[None, None, :]
-            st.mma(NTH, acc_to_vec(np.maximum(src, 0).astype(np.float32)), ex, acc2)
+            mx = relu_max(src, es_s)
+            st.mma(NTH, acc_to_vec(np.maximum(src, 0).astype(np.float32)), tau - es_s, acc2)
+            M = rb[H3F[name]] * mx + bm[BB[name]]
+            assert np.all(relu_max(acc2, es_n) <= M)
             masks[name] = acc2 > 0
             src, es_s = acc2, es_n
-        ex = cap(pick_exp(relu_max(src)), es_s, w[H3F["TH"]])
-        es_th = es_s + ex + w[H3F["TH"]]
+        tau = tau_of(M, w[H3F["TH"]])
+        es_th = tau + w[H3F["TH"]]
         th = b["TH"] * np.exp2(es_th)[None, None, :]
-        st.mma(1, acc_to_vec(np.maximum(src, 0).astype(np.float32)), ex, th)
+        st.mma(1, acc_to_vec(np.maximum(src, 0).astype(np.float32)), tau - es_s, th)
         th = th * np.exp2(-es_th)[None, None, :]
         sig = lambda x: 1 / (1 + np.exp(-x))
         out["t_rgb"], out["t_sigma"], out["t_beta"] = sig(th[0, :3]).T, softplus(th[0, 3]), softplus(th[0, 4])
@@ -743,15 +760,18 @@ def test_h3_streams_reproduce_the_mlp(Wd, Cf):
     # sigma-only stream of the coarse net
     pc, info_c, blob_c = pack(Wd, Cf, "coarse")
     si = info_c.stream[L.STREAM_FWD_SIGMA_H3]
-    assert si.n_slabs > 0 and si.scale_count >= 10
-    out, _ = trunk(StreamH3(blob_c, si, _h3_slab_kib("FWD")), False)
+    assert si.n_slabs > 0 and si.scale_count >= 2 * 10 + 9
+    st = StreamH3(blob_c, si, _h3_slab_kib("FWD"), 10)
+    out, _ = trunk(st, False)
     p64 = {k: v.double() for k, v in pc.items()}
     ref = O.field_forward(p64, e63.double(), sigma_only=True)[:, 0].numpy()
     assert np.abs(out["sigma"] - ref).max() <= 2e-6 * np.abs(ref).max()
 
     # full stream of the fine net
     pf, info_f, blob_f = pack(Wd, Cf, "fine")
-    out, masks = trunk(StreamH3(blob_f, info_f.stream[L.STREAM_FWD_FULL_H3], _h3_slab_kib("FWD")), True)
+    st = StreamH3(blob_f, info_f.stream[L.STREAM_FWD_FULL_H3], _h3_slab_kib("FWD"), 17)
+    out, masks = trunk(st, True)
+    print(f"least fp16 headroom of any operand (binades below 2^16): {st.headroom:.1f}")
     p64 = {k: v.double() for k, v in pf.items()}
     emb = torch.cat([e63, e27], 1).double().requires_grad_()
     raw = O.field_forward(p64, emb, output_transient=True)
@@ -768,49 +788,67 @@ def test_h3_streams_reproduce_the_mlp(Wd, Cf):
     d_pre = {"rgbfeat": gr[:, :C3], "sigma": gr[:, C3] * (1 - np.exp(-r[:, C3])),
              "t_rgb": gr[:, C3 + 1:C3 + 4] * r[:, C3 + 1:C3 + 4] * (1 - r[:, C3 + 1:C3 + 4]),
              "t_sigma": gr[:, C3 + 4] * (1 - np.exp(-r[:, C3 + 4])), "t_beta": gr[:, C3 + 5] * (1 - np.exp(-r[:, C3 + 5]))}
-    st = StreamH3(blob_f, info_f.stream[L.STREAM_BWD_FULL_H3], _h3_slab_kib("BWD"))
-    w = st.wexp
+    st = StreamH3(blob_f, info_f.stream[L.STREAM_BWD_FULL_H3], _h3_slab_kib("BWD"), 16)
+    w, rb = st.wexp, st.rowb
     assert st.bias.size == 0 and w[H3B["T0"]] == w[H3B["DIR"]] and all(w[H3B[k]] == 0 for k in ("RGB", "TH", "SIG"))
     Z = lambda nt: np.zeros((nt, 32, n), np.float64)
     f32v = lambda v: v.astype(np.float32)
     G2 = Z(NTH)
     st.mma32(NTH, compact([d_pre["rgbfeat"][:, k] for k in range(C3)], (C3 + 1) // 2), G2)
+    M_g2 = rb[H3B["RGB"]] * np.abs(d_pre["rgbfeat"]).max(1).astype(np.float32)
+    assert np.all(abs_max(G2, zeros) <= M_g2)
     T3 = Z(NTH)
-    st.mma32(NTH, compact([d_pre["t_rgb"][:, 0], d_pre["t_rgb"][:, 1], d_pre["t_rgb"][:, 2], d_pre["t_sigma"], d_pre["t_beta"]], 3), T3)
-    src, es = T3, np.zeros(n, np.int64)
+    dth = [d_pre["t_rgb"][:, 0], d_pre["t_rgb"][:, 1], d_pre["t_rgb"][:, 2], d_pre["t_sigma"], d_pre["t_beta"]]
+    st.mma32(NTH, compact(dth, 3), T3)
+    M = rb[H3B["TH"]] * np.abs(np.stack(dth, 1)).max(1).astype(np.float32)
+    src, es = T3, zeros
     for name, mk in (("T2", "T2"), ("T1", "T1")):                   # transient_encoding.4^T, .2^T
-        ex = cap(pick_exp(abs_max(src)), es, w[H3B[name]])
+        assert np.all(abs_max(src, es) <= M)
+        tau = tau_of(M, w[H3B[name]])
         dst = Z(NTH)
-        st.mma(NTH, acc_to_vec(f32v(src * masks[mk])), ex, dst)
-        src, es = dst, es + ex + w[H3B[name]]
-    tau = np.minimum(np.minimum(es + pick_exp(abs_max(src)), pick_exp(abs_max(G2))), 100 - w[H3B["T0"]])
+        mx = abs_max(src * masks[mk], es)
+        st.mma(NTH, acc_to_vec(f32v(src * masks[mk])), tau - es, dst)
+        M = rb[H3B[name]] * mx
+        src, es = dst, tau + w[H3B[name]]
+    tau = tau_of(np.maximum(M, M_g2), w[H3B["T0"]])
     es_dt = tau + w[H3B["T0"]]
     a9 = Z(NTW + 1)
+    mt, mg = abs_max(src * masks["T0"], es), abs_max(G2 * masks["DIR"], zeros)
     st.mma(NTW + 1, acc_to_vec(f32v(src * masks["T0"])), tau - es, a9)
     st.mma(NTW + 1, acc_to_vec(f32v(G2 * masks["DIR"])), tau, a9)
+    M = rb[H3B["T0"]] * mt + rb[H3B["DIR"]] * mg
+    assert np.all(abs_max(a9, es_dt) <= M)
     dD = acc_to_vec(f32v(a9), 0, 1) * np.exp2(-es_dt)[None, None, :]
-    ex = cap(pick_exp(abs_max(a9[1:])), es_dt, w[H3B["FINAL"]])
-    es = es_dt + ex + w[H3B["FINAL"]]
+    tau = tau_of(M, w[H3B["FINAL"]])
+    es = tau + w[H3B["FINAL"]]
     acc = Z(NTW)
-    st.mma(NTW, acc_to_vec(f32v(a9), 1, NTW), ex, acc)
+    mx = abs_max(a9[1:], es_dt)
+    st.mma(NTW, acc_to_vec(f32v(a9), 1, NTW), tau - es_dt, acc)
     st.mma32(NTW, compact([d_pre["sigma"] * np.exp2(es)], 1), acc)
+    M = rb[H3B["FINAL"]] * mx + rb[H3B["SIG"]] * np.abs(d_pre["sigma"]).astype(np.float32)
     accE, es_e = None, None
     for l in range(8, 1, -1):
-        ex = cap(pick_exp(abs_max(acc)), es, w[H3B[f"L{l}"]])
-        Hm = acc_to_vec(f32v(acc * masks[f"L{l}"]))
-        es = es + ex + w[H3B[f"L{l}"]]
+        assert np.all(abs_max(acc, es) <= M)
+        tau = tau_of(M, w[H3B[f"L{l}"]])
+        masked = acc * masks[f"L{l}"]
+        mx = abs_max(masked, es)
+        Hm = acc_to_vec(f32v(masked))
+        es_new = tau + w[H3B[f"L{l}"]]
         if l == 5:
             a10 = Z(NTW + 2)
-            st.mma(NTW + 2, Hm, ex, a10)
-            accE, es_e, acc = a10[:2].copy(), es, a10[2:]
+            st.mma(NTW + 2, Hm, tau - es, a10)
+            accE, es_e, acc = a10[:2].copy(), es_new, a10[2:]
         else:
             acc = Z(NTW)
-            st.mma(NTW, Hm, ex, acc)
-    ex = cap(pick_exp(abs_max(acc)), es, w[H3B["L1"]])
-    es1 = es + ex + w[H3B["L1"]]
+            st.mma(NTW, Hm, tau - es, acc)
+        M = rb[H3B[f"L{l}"]] * mx
+        es = es_new
+    tau = tau_of(M, w[H3B["L1"]])
+    es1 = tau + w[H3B["L1"]]
     accE = accE * np.exp2(es1 - es_e)[None, None, :]
-    st.mma(2, acc_to_vec(f32v(acc * masks["L1"])), ex, accE)
+    st.mma(2, acc_to_vec(f32v(acc * masks["L1"])), tau - es, accE)
     assert st.pos == st.raw.shape[0]
+    print(f"backward: least fp16 headroom of any operand: {st.headroom:.1f} binades")
     g63 = emb_vector_T(acc_to_vec(f32v(accE * np.exp2(-es1)[None, None, :])), 10, 63)
     g27 = emb_vector_T(f32v(dD[:14]), 4, 27)
     scale = np.abs(g_emb.numpy()).max(1, keepdims=True)
@@ -824,7 +862,7 @@ def test_h3_stream_decodes_to_scaled_weights():
     Wd, Cf = 256, 16
     p, info, blob = pack(Wd, Cf, "coarse")
     si = info.stream[L.STREAM_FWD_SIGMA_H3]
-    st = StreamH3(blob, si, _h3_slab_kib("FWD"))
+    st = StreamH3(blob, si, _h3_slab_kib("FWD"), 10)
     nt, k16, ups = Wd // 32, Wd // 16, st.ups
     l1_slabs = (4 * nt + ups - 1) // ups
     Wm = p["xyz_encoding_2.0.weight"].numpy().astype(np.float64)
