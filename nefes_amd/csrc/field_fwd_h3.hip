@@ -8,6 +8,8 @@
 // in LDS between layer 1 and the skip at layer 5 instead of in registers: with one accumulator set in VGPRs (the compiler keeps
 // the set the vector ALU reads there) the kernel has no 32 registers to spare.
 #define NEFES_SLAB_KIB NEFES_H3_FWD_SLAB_KIB
+#include <stdlib.h>
+
 #include "field_common.h"
 #include "../../include/nefes_hip.h"
 
@@ -64,6 +66,9 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
     // bias block offsets (floats), in stream order: L1..L8, SIG, FINAL, DIR, RGB, T0, T1, T2, TH (as in field_fwd.hip)
     constexpr int B_SIG = 8 * W, B_FINAL = B_SIG + 32, B_DIR = B_FINAL + W, B_RGB = B_DIR + W / 2,
                   B_T0 = B_RGB + 32 * NTR, B_T1 = B_T0 + W / 2, B_T2 = B_T1 + W / 2, B_TH = B_T2 + W / 2;
+#ifdef H3_STAMP
+    const unsigned long long stamp_k0 = h3_now();
+#endif
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         // sample / ray indices are recomputed where they are needed (loads here, three output points below) rather than kept
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
         auto put_masks = [&](const uint32_t* bits, int n) {
             if (MODE == NEFES_FIELD_FULL && a.masks) {
                 uint32_t* mask_tile = a.masks + ((size_t)((long long)tile * 4 + wave) * MW) * 64;      // wave-uniform
-                for (int w = 0; w < n; ++w) mask_tile[(mask_word + w) * 64 + lane] = bits[w];
+                for (int w = 0; w < n; ++w) __builtin_nontemporal_store(bits[w], &mask_tile[(mask_word + w) * 64 + lane]);   // written once, read once by the backward: keep it out of the way of the weight stream in L2
                 mask_word += n;
             }
         };
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
             float* col = raw_col();
             if (col && h == 0) {
                 const int ch = (MODE == NEFES_FIELD_SIGMA) ? 0 : 3 + a.C;
-                col[(size_t)ch * a.S] = softplus_ref(sg[0][0] * pow2i(-es));
+                __builtin_nontemporal_store(softplus_ref(sg[0][0] * pow2i(-es)), &col[(size_t)ch * a.S]);
             }
         };
         int es_a, es_b = 0;
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int cu = 32 * t + nefes_rho(0, r);
-                            if (cu + 4 * h < 3 + a.C) ph[(size_t)cu * a.S] = ar[t][r] * inv;
+                            if (cu + 4 * h < 3 + a.C) __builtin_nontemporal_store(ar[t][r] * inv, &ph[(size_t)cu * a.S]);
                         }
                 }
             }
@@ -285,16 +290,19 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) 
                 float* o = col + (size_t)(3 + a.C + 1) * a.S;
                 const float inv = pow2i(-es_th);
                 if (h == 0) {
-                    o[0] = sigmoid_ref(th[0][0] * inv);
-                    o[(size_t)a.S] = sigmoid_ref(th[0][1] * inv);
-                    o[(size_t)2 * a.S] = sigmoid_ref(th[0][2] * inv);
-                    o[(size_t)3 * a.S] = softplus_ref(th[0][3] * inv);
+                    __builtin_nontemporal_store(sigmoid_ref(th[0][0] * inv), &o[0]);
+                    __builtin_nontemporal_store(sigmoid_ref(th[0][1] * inv), &o[(size_t)a.S]);
+                    __builtin_nontemporal_store(sigmoid_ref(th[0][2] * inv), &o[(size_t)2 * a.S]);
+                    __builtin_nontemporal_store(softplus_ref(th[0][3] * inv), &o[(size_t)3 * a.S]);
                 } else {
-                    o[(size_t)4 * a.S] = softplus_ref(th[0][0] * inv);
+                    __builtin_nontemporal_store(softplus_ref(th[0][0] * inv), &o[(size_t)4 * a.S]);
                 }
             }
         }
     }
+#ifdef H3_STAMP
+    if (threadIdx.x == 0) atomicAdd(&h3_stamp_total, h3_now() - stamp_k0);
+#endif
 }
 
 // magic multiplier for unsigned division by d, exact for dividends below 2^31: q = mulhi(n, magic) >> shift
@@ -318,6 +326,10 @@ static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int grid = a.n_tiles < cus ? a.n_tiles : cus;
+    if (const char* cap = getenv("NEFES_DEBUG_MAX_GRID")) {          // experiments only: fewer workgroups than CUs
+        const int c = atoi(cap);
+        if (c > 0 && c < grid) grid = c;
+    }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
     return (int)hipGetLastError();
 }
@@ -341,6 +353,22 @@ int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st
     return NEFES_E_UNSUPPORTED;
 }
 #else   // part 0
+
+#ifdef H3_STAMP
+extern "C" int nefes_debug_h3_stamps(unsigned long long* out3) {
+    unsigned long long v[4] = {0, 0, 0, 0};
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(&v[3], HIP_SYMBOL(h3_stamp_total), 8);
+    hipMemcpyFromSymbol(&v[0], HIP_SYMBOL(h3_stamp_run), 8);
+    hipMemcpyFromSymbol(&v[1], HIP_SYMBOL(h3_stamp_acq), 8);
+    hipMemcpyFromSymbol(&v[2], HIP_SYMBOL(h3_stamp_n), 8);
+    out3[0] = v[0]; out3[1] = v[1]; out3[2] = v[2]; out3[3] = v[3];
+    const unsigned long long z = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(h3_stamp_total), &z, 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(h3_stamp_run), &z, 8); hipMemcpyToSymbol(HIP_SYMBOL(h3_stamp_acq), &z, 8); hipMemcpyToSymbol(HIP_SYMBOL(h3_stamp_n), &z, 8);
+    return 0;
+}
+#endif
 
 extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                                   const float* rays_d, const float* z, const float* pts, const float* xyz_enc,

@@ -23,6 +23,9 @@
 // Values more than 2^-25 below the lane's maximum lose low bits (fp16 subnormals resolve 2^-24): an absolute error of 2^-39
 // relative to that maximum, i.e. nothing.
 #pragma once
+#ifndef NEFES_H3_WIDE_MIN
+#define NEFES_H3_WIDE_MIN 8   /* segments with at least this many tiles take the gap-by-gap schedule (mma_run_h3_wide) */
+#endif
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -84,8 +87,43 @@ __device__ __forceinline__ int cap_exp(int ex, int es_in, int ew) {
 // two fp32 values times 2^ex (r = pow2i(ex)) -> their (hi, lo) fp16 parts, packed pairwise into dword p of the two operands.
 // NOP: this is the last pair of an operand that the very next MFMA may read -- a VGPR written inside inline asm needs two
 // wait states before an MFMA reads it, which hipcc does not pad (field_common.h, relu1); once per k16-step.
+// the same in two halves, for two different MFMA gaps: v_fma_mix* issues at half rate (tools/probe/issue_probe.hip: 9.3 cycles
+// each, a gap hides ~24), so four of them in one gap overrun it
+__device__ __forceinline__ void split_pair_hi(Split2& o, int p, float x0, float x1, float r) {
+    uint32_t h;
+    asm volatile(
+        "v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+        : "=&v"(h)
+        : "v"(x0), "v"(x1), "v"(r));
+    o.h[p] = h;
+}
+template <bool NOP>
+__device__ __forceinline__ void split_pair_lo(Split2& o, int p, float x0, float x1, float r) {
+    uint32_t l;
+    const uint32_t h = o.h[p];
+    if (NOP)
+        asm volatile(
+            "v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "s_nop 1"
+            : "=&v"(l)
+            : "v"(x0), "v"(x1), "v"(r), "v"(h));
+    else
+        asm volatile(
+            "v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(l)
+            : "v"(x0), "v"(x1), "v"(r), "v"(h));
+    o.l[p] = l;
+}
 template <bool NOP>
 __device__ __forceinline__ void split_pair_h(Split2& o, int p, float x0, float x1, float r) {
+#ifdef H3_ABL_CHEAPSPLIT      // timing ablation: one VALU per pair instead of four, dataflow kept
+    o.h[p] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+    o.l[p] = __float_as_uint(r);
+    return;
+#endif
     uint32_t h, l;
     if (NOP)
         asm volatile(
@@ -108,26 +146,45 @@ __device__ __forceinline__ void split_pair_h(Split2& o, int p, float x0, float x
     o.l[p] = l;
 }
 
-// ---- B-operand sources: pair(o, q, p) = values 2p, 2p+1 of k16-step q (source tile T0 + q/2, registers 8(q%2)..+7),
-// transformed, scaled by r = 2^ex and split.  Mask words are walked exactly as in field_x6.h / field_common.h, so the fp16
-// kernels exchange ReLU masks with every other forward / backward kernel. ---------------------------------------------------
+// ---- B-operand sources.  Values 2p, 2p+1 of k16-step q (source tile T0 + q/2, registers 8(q%2)..+7) are transformed, scaled
+// by r = 2^ex and split in three STAGES that mma_run_h3 places in three different MFMA gaps (an MFMA hides about six other
+// issues; a whole pair in one gap overruns it):
+//     A  fetch the two values (accumulator reads, LDS reads) and touch the ReLU-mask word (capture forward, apply backward)
+//     B  activation and the running maximum of the consumed values (field_h3.h header: next operand's exponent)
+//     C  the four conversions into dword p of the (hi, lo) operand
+// Mask words are walked exactly as in field_x6.h / field_common.h, so the fp16 kernels exchange ReLU masks with every other
+// forward / backward kernel. ---------------------------------------------------------------------------------------------
+struct PairRegs {
+    float x0, x1;
+};
 template <bool CAPTURE, int NX, int NWORDS, int T0 = 0>
 struct ReluSplitH {
     const f32x16 (&X)[NX];
     uint32_t (&bits)[NWORDS];
     float r;
     float& m;                   // running max of the consumed values (accumulator units), this lane
-    template <bool NOP>
-    __device__ __forceinline__ void pair(Split2& o, int q, int p) const {
-        const float v0 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p], v1 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1];
+    __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
+        s.x0 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p];
+        s.x1 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1];
+#ifndef H3_ABL_NOMASK
         if (CAPTURE) {
-            mask_shift_in(bits[(8 * q + 2 * p) >> 5], v0);
-            mask_shift_in(bits[(8 * q + 2 * p + 1) >> 5], v1);
+            mask_shift_in(bits[(8 * q + 2 * p) >> 5], s.x0);
+            mask_shift_in(bits[(8 * q + 2 * p + 1) >> 5], s.x1);
         }
-        const float x0 = relu1<false>(v0), x1 = relu1<false>(v1);
-        max3_acc(m, x0, x1);
-        split_pair_h<NOP>(o, p, x0, x1, r);
+#endif
     }
+    __device__ __forceinline__ void stage_b(PairRegs& s) const {
+        s.x0 = relu1<false>(s.x0);
+        s.x1 = relu1<false>(s.x1);
+#ifndef H3_ABL_NOMAX3
+        max3_acc(m, s.x0, s.x1);
+#endif
+    }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
+    __device__ __forceinline__ void stage_c1(Split2& o, int p, const PairRegs& s) const { split_pair_hi(o, p, s.x0, s.x1, r); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
 };
 template <int NX, int NWORDS, int T0>
 struct MaskedSplitH {
@@ -135,43 +192,64 @@ struct MaskedSplitH {
     uint32_t (&bits)[NWORDS];
     float r;
     float& m;
-    template <bool NOP>
-    __device__ __forceinline__ void pair(Split2& o, int q, int p) const {
-        const float x0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
-        const float x1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
-        absmax3_acc(m, x0, x1);
-        split_pair_h<NOP>(o, p, x0, x1, r);
+    __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
+        s.x0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
+        s.x1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
     }
+    __device__ __forceinline__ void stage_b(PairRegs& s) const {
+#ifndef H3_ABL_NOMAX3
+        absmax3_acc(m, s.x0, s.x1);
+#endif
+    }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
+    __device__ __forceinline__ void stage_c1(Split2& o, int p, const PairRegs& s) const { split_pair_hi(o, p, s.x0, s.x1, r); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
 };
 template <int NX, int T0>
 struct IdentSplitH {
     const f32x16 (&X)[NX];
     float r;
     float& m;
-    template <bool NOP>
-    __device__ __forceinline__ void pair(Split2& o, int q, int p) const {
-        const float x0 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p], x1 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1];
-        absmax3_acc(m, x0, x1);
-        split_pair_h<NOP>(o, p, x0, x1, r);
+    __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
+        s.x0 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p];
+        s.x1 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1];
     }
+    __device__ __forceinline__ void stage_b(PairRegs& s) const { absmax3_acc(m, s.x0, s.x1); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
+    __device__ __forceinline__ void stage_c1(Split2& o, int p, const PairRegs& s) const { split_pair_hi(o, p, s.x0, s.x1, r); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
 };
 template <int N>
-struct ArraySplitH {            // per-lane values v[8q + i] (embedding slots)
+struct ArraySplitH {            // per-lane values v[8q + i] (embedding slots); their maximum is known to the caller
     const float (&v)[N];
     float r;
+    __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const { s.x0 = v[8 * q + 2 * p]; s.x1 = v[8 * q + 2 * p + 1]; }
+    __device__ __forceinline__ void stage_b(PairRegs&) const {}
     template <bool NOP>
-    __device__ __forceinline__ void pair(Split2& o, int q, int p) const { split_pair_h<NOP>(o, p, v[8 * q + 2 * p], v[8 * q + 2 * p + 1], r); }
+    __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
+    __device__ __forceinline__ void stage_c1(Split2& o, int p, const PairRegs& s) const { split_pair_hi(o, p, s.x0, s.x1, r); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
 };
-
 // per-lane values parked in LDS between their uses (the xyz embedding: layer 1 and the skip at layer 5): slot s of this lane
 // at base[s * 64] (base already carries wave and lane: lane-consecutive dwords, conflict-free)
 struct LdsSplitH {
     const float* base;
     float r;
-    template <bool NOP>
-    __device__ __forceinline__ void pair(Split2& o, int q, int p) const {
-        split_pair_h<NOP>(o, p, base[(8 * q + 2 * p) * 64], base[(8 * q + 2 * p + 1) * 64], r);
+    __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
+        s.x0 = base[(8 * q + 2 * p) * 64];
+        s.x1 = base[(8 * q + 2 * p + 1) * 64];
     }
+    __device__ __forceinline__ void stage_b(PairRegs&) const {}
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
+    __device__ __forceinline__ void stage_c1(Split2& o, int p, const PairRegs& s) const { split_pair_hi(o, p, s.x0, s.x1, r); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
 };
 
 // C operand of a tile's first MFMA: bias rows times 2^es_out (the lane's output scale)
@@ -231,15 +309,44 @@ struct StagedRing {
         for (int q = 0; q < NEFES_SLAB_PIECES; ++q) load_piece(q);                                 // slab 1 in flight
         g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
     }
+    // the two halves of issue_piece for callers that place them in different MFMA gaps (mma_run_h3_wide)
+    __device__ __forceinline__ void store_piece(int q) {
+#if !defined(H3_ABL_NODMA) && !defined(H3_ABL_NOSTORE)
+        *(f32x4*)(my_lds + (c_slot ^ 1u) * NEFES_SLAB_BYTES + q * 1024) = stage[q];
+#endif
+    }
+    __device__ __forceinline__ void fetch_piece(int q) {
+#if !defined(H3_ABL_NODMA) && !defined(H3_ABL_NOLOAD)
+        load_piece(q);
+#endif
+        if (q == NEFES_SLAB_PIECES - 1) g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
+    }
     // piece q of the next slab: registers -> the idle slot; then request the same piece of the slab after it
     __device__ __forceinline__ void issue_piece(int q) {
+#ifdef H3_ABL_NODMA
+        return;
+#endif
+#ifndef H3_ABL_NOSTORE
+#if defined(H3_STORE_B64)      // experiment: two 8-byte stores instead of one 16-byte store
+        {
+            const uint32_t a_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(my_lds + (c_slot ^ 1u) * NEFES_SLAB_BYTES + q * 1024);
+            const float2 lo_ = {stage[q][0], stage[q][1]}, hi_ = {stage[q][2], stage[q][3]};
+            asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8" ::"v"(a_), "v"(lo_), "v"(hi_) : "memory");
+        }
+#else
         *(f32x4*)(my_lds + (c_slot ^ 1u) * NEFES_SLAB_BYTES + q * 1024) = stage[q];
+#endif
+#endif
+#ifndef H3_ABL_NOLOAD
         load_piece(q);
+#endif
         if (q == NEFES_SLAB_PIECES - 1) g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
     }
     __device__ __forceinline__ uint32_t acquire() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef H3_ABL_NOBARRIER
         __builtin_amdgcn_s_barrier();
+#endif
         c_slot ^= 1u;
         return c_slot * NEFES_SLAB_BYTES;
     }
@@ -253,9 +360,207 @@ struct StagedRing {
 };
 
 // acc[T0 .. T0+NT) = W-block * src over KS16 steps of 16 k-values; init(t) is the C operand of each tile's first MFMA
-// (FIRST = false: accumulate onto acc).
+// (FIRST = false: accumulate onto acc).  Stream order: for k16-step q, for tile t: [A_hi | A_lo] (2 KiB unit);
+// floor(slab KiB / 2) units per slab; a segment starts on a slab boundary.
+//
+// One unit = three dependent MFMAs (small terms first: Al Bh, Ah Bl, Ah Bh) and three issue gaps.  The matrix pipe takes an MFMA
+// every 32 cycles and an MFMA occupies the issue port for 8, so each gap hides about six other instructions -- IF they are there:
+// the kernel's side work (operand split, weight-ring moves, A-operand reads, bias tiles) is placed gap by gap in source order and
+// pinned with sched_barrier(0), instead of leaving a ten-instruction block per pair to the scheduler (measured: a single extra
+// v_max3 per pair moved the kernel by 8-12 %: the old placement overran its gaps).  Per unit:
+//     M1   gap 1: read next unit's A_hi            + stage A of a pair hosted by this tile
+//     M2   gap 2: read next unit's A_lo (into al)  + stage B of that pair      + bias tile of the next output tile (first k-step)
+//     M3   gap 3: stage C of that pair  -- or, on the units that host none, one weight-ring piece (write + load)
+// The operand of k16-step q+1 is produced during step q: pair pp by tile pp * STRIDE (every second tile of a >= 8-tile segment), so
+// its last conversion is at least one whole unit ahead of its first consumer and needs no wait-state padding there.
+// The MFMA of the wide runs as a volatile asm statement: every other instruction of mma_run_h3_wide's unit is volatile asm or
+// pinned between volatile statements, but an MFMA builtin is a pure value to the compiler, which linearises the block's DAG
+// with the three MFMAs of a unit back to back and the side work in clumps -- whatever the source order and sched_barrier say
+// (seen in the disassembly).  As asm the MFMAs ARE the skeleton of the instruction stream.  Accumulators live in AGPRs ("+a").
+// Hazards the compiler no longer pads for (it does not look inside asm): an asm-written B operand needs two instructions before
+// the MFMA that reads it (stage C2 of a pair is two MFMAs ahead of its consumer; the run's first operand ends in s_nop 1); a VALU
+// read of a tile follows the tile's last MFMA by a whole layer, a VALU write of a bias tile precedes its first MFMA by a unit;
+// operands returned by LDS reads are waited for by the compiler's own s_waitcnt (it tracks asm operands).
+__device__ __forceinline__ void mfma_h3_asm(f32x16& c, const f32x4& a, const u32x4& b) {
+#ifdef H3_BUILTIN_MFMA     // debugging: the compiler's MFMA (its own hazard padding, its own placement)
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(a), as_f16x8(b), c, 0, 0, 0);
+#else
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#endif
+}
+#ifdef H3_STAMP   // diagnostic build (tools/stamp_h3.sh): cycles inside the wide runs / inside ring acquires, per wave
+__device__ unsigned long long h3_stamp_run = 0, h3_stamp_acq = 0, h3_stamp_n = 0, h3_stamp_total = 0;
+static __device__ __forceinline__ unsigned long long h3_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#endif
 template <int NT, int KS16, int T0, bool FIRST = true, class SrcFn, class InitFn, int NACC, class Ring>
-__device__ __forceinline__ void mma_run_h3(Ring& ring, const char* ring_lane, const SrcFn& src, const InitFn& init,
+__device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lane, const SrcFn& src, const InitFn& init,
+                                                f32x16 (&acc)[NACC]) {
+    static_assert(T0 + NT <= NACC, "accumulator array too small");
+    static_assert(NT >= 8 && NT % 2 == 0, "the gap schedule below pairs tiles: an even tile hosts a pair, the odd one a ring piece");
+#ifdef H3_STAMP
+    const unsigned long long stamp0 = h3_now();
+    unsigned long long stamp_acq = 0;
+#endif
+    constexpr int UPS = (NEFES_SLAB_FRAGS / 4) / 2;       // units per slab
+    constexpr int NU = KS16 * NT;
+    constexpr int NSLAB = (NU + UPS - 1) / UPS;
+    // No register is copied inside the unit loop: a copy lands right behind an MFMA that may still be READING the copy's
+    // destination as an operand (the compiler pads that write-after-read hazard for its own MFMAs, not for asm ones -- seen as
+    // garbage results).  The operand of step q lives in B0 / B1 by the parity of q, unit u's weight groups in (ha, la)[u % 3];
+    // everything is selected at compile time (the loops are fully unrolled).
+    Split2 B0, B1;
+    auto BQ = [&](int k) -> Split2& { return (k & 1) ? B1 : B0; };
+    // H3_ABL_* macros: timing ablations only (tools/ablate_h3.sh, tools/stamp_h3.sh build side libraries with them; results are garbage)
+    {
+        PairRegs s0;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            src.stage_a(s0, 0, pp);
+            src.stage_b(s0);
+            if (pp == 3) src.template stage_c<true>(B0, pp, s0);
+            else src.template stage_c<false>(B0, pp, s0);
+        }
+    }
+    // FIRST: the C operand of a tile's first MFMA (bias x 2^es, or zero) is written straight into the tile's own registers,
+    // one unit ahead of its first use -- the output tiles are dead until then -- rather than into a 16-register staging tile
+#ifdef H3_ABL_NOBIAS
+    if (FIRST) acc[T0] = ZeroInit{}(0);
+#else
+    if (FIRST) acc[T0] = init(0);
+#endif
+    // A operands are requested TWO units (six MFMAs) ahead of their use; (h0,l0), (h1,l1) = this and the next unit's, the reads
+    // in flight are the unit's after that.  ring.pf carries the first unit's hi group across segments.
+    const char* p = ring_lane + ring.cur_off;
+    f32x4 ha0 = ring.pf, la0 = *(const f32x4*)(p + 1024);
+    f32x4 ha1 = *(const f32x4*)(p + 2048), la1 = *(const f32x4*)(p + 3072);
+    f32x4 ha2, la2;
+    auto HA = [&](int k) -> f32x4& { return k % 3 == 0 ? ha0 : (k % 3 == 1 ? ha1 : ha2); };
+    auto LA = [&](int k) -> f32x4& { return k % 3 == 0 ? la0 : (k % 3 == 1 ? la1 : la2); };
+    PairRegs ps[4];                                        // pairs in flight between their stages
+#pragma unroll
+    for (int sl = 0; sl < NSLAB; ++sl) {
+        const int nu = (NU - sl * UPS) < UPS ? (NU - sl * UPS) : UPS;
+        // The slab after this one is acquired in unit acq_u (two units before the end: the request for unit u+2 then crosses into
+        // it).  Ring piece qq is written to LDS and re-requested in the odd unit piece_unit(qq); what is left goes in front of the acquire.
+        const int acq_u = nu >= 2 ? nu - 2 : 0;
+        auto piece_unit = [&](int qq) { const int m_ = ((2 * qq + 1) * nu) / UPS; return m_ < acq_u ? m_ : acq_u; };
+#pragma unroll
+        for (int uu = 0; uu < UPS; ++uu) {
+            if (uu < nu) {
+                const int u = sl * UPS + uu, q = u / NT, t = u % NT;
+                const bool make = q + 1 < KS16;            // this step produces the next step's operand
+                const bool host = make && (t % 2 == 0);    // pair t/2: stages A, B, C1 here, C2 in the next (odd) unit
+                const bool tail = make && (t % 2 == 1);
+                const int pp = t / 2;
+                const char* pn = p + (2 * uu + 4) * 1024;  // unit u + 2's hi group (lo: + 1 KiB)
+                Split2& B = BQ(q);
+                Split2& Bn = BQ(q + 1);
+                f32x4 &h0 = HA(u), &l0 = LA(u), &h2 = HA(u + 2), &l2 = LA(u + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                // the tile's C operand was written by the vector ALU (bias tile): materialise it in its AGPRs HERE, then two wait states
+                if (FIRST && q == 0) asm volatile("s_nop 1" : "+a"(acc[T0 + t]));
+                mfma_h3_asm(acc[T0 + t], l0, B.h);                                                  // M1 (small terms first)
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- gap 1 ----
+#ifndef H3_ABL_NOSPLIT
+                if (host) src.stage_a(ps[pp], q + 1, pp);
+                if (tail) src.template stage_c2<false>(Bn, pp, ps[pp]);
+#endif
+#ifndef H3_ABL_NOAREAD
+                if (!host && uu != acq_u) h2 = *(const f32x4*)(pn);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                // An asm's inputs are dead to the compiler once it has issued, but the MFMA is still reading them: without these
+                // empty uses the registers are handed to the gap's instructions and overwritten under the MFMA (seen in the
+                // disassembly as conversions writing the previous MFMA's operand registers; the results were garbage).
+                asm volatile("" ::"v"(l0), "v"(B.h));
+                mfma_h3_asm(acc[T0 + t], h0, B.l);                                                  // M2
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- gap 2 ----
+#ifndef H3_ABL_NOSPLIT
+                if (host) src.stage_b(ps[pp]);
+#endif
+#ifndef H3_ABL_NOAREAD
+                if (host && uu != acq_u) h2 = *(const f32x4*)(pn);
+#endif
+                if (!host) {
+#pragma unroll
+                    for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
+                        if (piece_unit(qq) == uu) ring.store_piece(qq);
+                }
+#ifdef H3_ABL_NOBIAS
+                if (FIRST && q == 0 && t + 1 < NT) acc[T0 + t + 1] = ZeroInit{}(0);
+#else
+                if (FIRST && q == 0 && t + 1 < NT) {
+                    acc[T0 + t + 1] = init(t + 1);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" ::"v"(B.l));
+                mfma_h3_asm(acc[T0 + t], h0, B.h);                                                  // M3
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- gap 3 ----
+#ifndef H3_ABL_NOSPLIT
+                if (host) src.stage_c1(Bn, pp, ps[pp]);
+#endif
+                if (!host) {
+#pragma unroll
+                    for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
+                        if (piece_unit(qq) == uu) ring.fetch_piece(qq);
+                }
+                if (uu == acq_u) {                         // next slab: everyone's pieces written, nobody requests from this one any more
+#pragma unroll
+                    for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
+                        if (piece_unit(qq) == uu && host) { ring.store_piece(qq); ring.fetch_piece(qq); }
+#ifdef H3_STAMP
+                    const unsigned long long ta = h3_now();
+                    ring.cur_off = ring.acquire();
+                    stamp_acq += h3_now() - ta;
+#else
+                    ring.cur_off = ring.acquire();
+#endif
+                    p = ring_lane + ring.cur_off - (size_t)nu * 2048;      // so that unit index uu + 2 >= nu addresses the new slab
+                    pn = p + (2 * uu + 4) * 1024;
+#ifndef H3_ABL_NOAREAD
+                    h2 = *(const f32x4*)(pn);
+#endif
+                }
+#ifndef H3_ABL_NOAREAD
+                l2 = *(const f32x4*)(pn + 1024);
+#else
+                h2 = HA(u + 1); l2 = LA(u + 1);
+#endif
+                if (uu + 1 == nu) p = ring_lane + ring.cur_off;            // plain addressing again from the new slab's unit 0
+                asm volatile("" ::"v"(h0), "v"(B.h));                      // M3's operands stay untouched through its gap
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    ring.pf = HA(NU);
+#ifndef H3_BUILTIN_MFMA
+    // The layer's functor reads the tiles with the vector ALU: 18 wait states between an MFMA and such a read of its result are the
+    // program's to provide (the compiler pads them for its own MFMAs only).  Tying the two youngest tiles to the statement keeps their
+    // reads behind it; the older tiles' last MFMAs are at least six MFMAs back.
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1" : "+a"(acc[T0 + NT - 1]), "+a"(acc[T0 + NT - 2]));
+#endif
+#ifdef H3_STAMP
+    if (threadIdx.x == 0) {      // wave 0 of every workgroup
+        atomicAdd(&h3_stamp_run, h3_now() - stamp0);
+        atomicAdd(&h3_stamp_acq, stamp_acq);
+        atomicAdd(&h3_stamp_n, (unsigned long long)(3 * NT * KS16));
+    }
+#endif
+}
+
+// Narrow segments (fewer than eight tiles: the half-width layers and the heads, a few per cent of the MFMAs): the operand of the
+// next step is produced in one block behind a tile's third MFMA and left to the scheduler's interleaving hints.  (The gap-by-gap
+// form above, applied to them, made hipcc sink the whole segment's MFMAs behind its operand production and spill every A operand.)
+template <int NT, int KS16, int T0, bool FIRST = true, class SrcFn, class InitFn, int NACC, class Ring>
+__device__ __forceinline__ void mma_run_h3_small(Ring& ring, const char* ring_lane, const SrcFn& src, const InitFn& init,
                                            f32x16 (&acc)[NACC]) {
     static_assert(T0 + NT <= NACC, "accumulator array too small");
     constexpr int UPS = (NEFES_SLAB_FRAGS / 4) / 2;       // units per slab
@@ -263,10 +568,16 @@ __device__ __forceinline__ void mma_run_h3(Ring& ring, const char* ring_lane, co
     constexpr int NSLAB = (NU + UPS - 1) / UPS;
     Split2 B, Bn;
     // H3_ABL_* macros: timing ablations only (tools/ablate_h3.sh builds side libraries with them; results are garbage)
-    src.template pair<false>(B, 0, 0);
-    src.template pair<false>(B, 0, 1);
-    src.template pair<false>(B, 0, 2);
-    src.template pair<true>(B, 0, 3);
+    {
+        PairRegs s0;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            src.stage_a(s0, 0, pp);
+            src.stage_b(s0);
+            if (pp == 3) src.template stage_c<true>(B, pp, s0);
+            else src.template stage_c<false>(B, pp, s0);
+        }
+    }
     Bn = B;
     // FIRST: the C operand of a tile's first MFMA (bias x 2^es, or zero) is written straight into the tile's own registers,
     // one unit ahead of its first use -- the output tiles are dead until then -- rather than into a 16-register staging tile
@@ -335,8 +646,11 @@ __device__ __forceinline__ void mma_run_h3(Ring& ring, const char* ring_lane, co
                     for (int pp = 0; pp < 4; ++pp)
                         if (NT >= 4 ? (t == pp * STRIDE + STRIDE - 1) : (t == (pp * NT) / 4)) {
 #ifndef H3_ABL_NOSPLIT
-                            if (pp == 3) src.template pair<true>(Bn, q + 1, pp);
-                            else src.template pair<false>(Bn, q + 1, pp);
+                            PairRegs s1;
+                            src.stage_a(s1, q + 1, pp);
+                            src.stage_b(s1);
+                            if (pp == 3) src.template stage_c<true>(Bn, pp, s1);
+                            else src.template stage_c<false>(Bn, pp, s1);
 #endif
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {                     // interleave: one MFMA, then up to four VALU
@@ -350,4 +664,11 @@ __device__ __forceinline__ void mma_run_h3(Ring& ring, const char* ring_lane, co
         }
     }
     ring.pf = ah;
+}
+
+template <int NT, int KS16, int T0, bool FIRST = true, class SrcFn, class InitFn, int NACC, class Ring>
+__device__ __forceinline__ void mma_run_h3(Ring& ring, const char* ring_lane, const SrcFn& src, const InitFn& init,
+                                           f32x16 (&acc)[NACC]) {
+    if constexpr (NT >= NEFES_H3_WIDE_MIN) mma_run_h3_wide<NT, KS16, T0, FIRST>(ring, ring_lane, src, init, acc);
+    else mma_run_h3_small<NT, KS16, T0, FIRST>(ring, ring_lane, src, init, acc);
 }

@@ -94,6 +94,8 @@ NEFES_HD int nefes_stream_slab_kib(int stream) {
     if (stream == NEFES_STREAM_FWD_SIGMA_H3 || stream == NEFES_STREAM_FWD_FULL_H3) return NEFES_H3_FWD_SLAB_KIB;
     return stream >= NEFES_STREAM_FWD_SIGMA_X6 ? NEFES_X6_SLAB_KIB : NEFES_FWD_SLAB_KIB;
 }
+#define NEFES_BLOB_HEADER_BYTES 512   /* NefesBlobInfo, padded: written by the host packer only (pack.cpp, pack_device.hip) */
+
 // Segment ordinals of the _H3 streams.  The stream's scale table (pack.cpp; words behind the bias blocks, NefesStreamInfo.
 // scale_off) holds per segment s: word 2s = weight-scale exponent e (int32: the weights are stored times 2^e; 0 for fp32
 // segments), word 2s+1 = row bound (float: max over the segment's output rows of the sum of |w| over its k-values, so that

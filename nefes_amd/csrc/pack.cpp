@@ -451,7 +451,8 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
     return true;
 }
 
-const uint64_t kHeaderBytes = 512;
+const uint64_t kHeaderBytes = NEFES_BLOB_HEADER_BYTES;
+static_assert(sizeof(NefesBlobInfo) <= NEFES_BLOB_HEADER_BYTES, "blob header too small");
 uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 void fill_info(const Stream (&st)[NEFES_N_STREAMS], NefesBlobInfo* info) {

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/nefes_hip.h"
+#include "layout.h"
 
 namespace {
 
@@ -42,8 +43,8 @@ __global__ __launch_bounds__(256) void pack_device_kernel(const float* __restric
 
 extern "C" int nefes_pack_device(const float* flat, int64_t n_params, const uint32_t* map, int64_t n_entries, void* blob,
                                  void* stream) {
-    if (!flat || !map || !blob || n_params <= 0 || n_entries <= 128 || (n_entries & 1)) return NEFES_E_BADARG;
-    const long long n_words = n_entries / 2, first = 64;        // the 256-byte header stays as the host packer wrote it
+    if (!flat || !map || !blob || n_params <= 0 || n_entries <= NEFES_BLOB_HEADER_BYTES / 2 || (n_entries & 1)) return NEFES_E_BADARG;
+    const long long n_words = n_entries / 2, first = NEFES_BLOB_HEADER_BYTES / 4;     // the header stays as the host packer wrote it
     long long blocks = (n_words - first + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(pack_device_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, flat, (const uint2*)map, first,

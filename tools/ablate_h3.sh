@@ -7,7 +7,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CS=$ROOT/nefes_amd/csrc
 OUT=$ROOT/nefes_amd/abl
-VARIANTS="base:-DH3_ABL_BASE nodma:-DH3_ABL_NODMA nobarrier:-DH3_ABL_NODMA,-DH3_ABL_NOBARRIER nosplit:-DH3_ABL_NOSPLIT nomax:-DH3_ABL_NOMAX nobias:-DH3_ABL_NOBIAS noaread:-DH3_ABL_NOAREAD mfmaonly:-DH3_ABL_NODMA,-DH3_ABL_NOBARRIER,-DH3_ABL_NOSPLIT,-DH3_ABL_NOMAX,-DH3_ABL_NOBIAS,-DH3_ABL_NOAREAD nodma_nosplit:-DH3_ABL_NODMA,-DH3_ABL_NOSPLIT"
+VARIANTS="base:-DH3_ABL_BASE cheapsplit:-DH3_ABL_CHEAPSPLIT nomask:-DH3_ABL_NOMASK norelu:-DH3_ABL_NORELU nomax3:-DH3_ABL_NOMAX3 allvalu:-DH3_ABL_CHEAPSPLIT,-DH3_ABL_NOMASK,-DH3_ABL_NORELU,-DH3_ABL_NOMAX3 allvalu_nodma:-DH3_ABL_CHEAPSPLIT,-DH3_ABL_NOMASK,-DH3_ABL_NORELU,-DH3_ABL_NOMAX3,-DH3_ABL_NODMA allvalu_nodma_nobias:-DH3_ABL_CHEAPSPLIT,-DH3_ABL_NOMASK,-DH3_ABL_NORELU,-DH3_ABL_NOMAX3,-DH3_ABL_NODMA,-DH3_ABL_NOBIAS"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-gpu-rdc -Wno-unused-function -Wno-unused-variable -mllvm -pragma-unroll-threshold=65536"
 if [ "$1" = "build" ]; then
   mkdir -p $OUT
