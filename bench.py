@@ -248,7 +248,7 @@ def main():
     dev = torch.device("cuda", dev_index)
 
     from nefes_amd import dist as D
-    from nefes_amd import ops
+    from nefes_amd import lib as L, ops
     from nefes_amd.field import NeRFH_NFF
     from nefes_amd.render import render
 
@@ -399,6 +399,22 @@ def main():
             "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items())},
             "pose_grad_abs_max": float(g.abs().max()),
         }
+        if h3 or x6:
+            # The 2 500 TFLOP/s data-sheet peak is a 2.4 GHz figure; under sustained MFMA issue with operands whose bits toggle
+            # the chip's power management holds a lower clock.  Measured here, on this box, right after the timed region
+            # (csrc/probe.hip: back-to-back v_mfma_f32_32x32x16_f16 on every SIMD for ~40 ms; fp16 and bf16 MFMAs issue alike).
+            try:
+                import ctypes as _C
+                ghz, tf = _C.c_double(), _C.c_double()
+                L.check(L.load().nefes_probe_mfma_clock(1, 40, _C.byref(ghz), _C.byref(tf), None), "nefes_probe_mfma_clock")
+                per = 3.0 if (h3 or x3) else 6.0
+                out["roofline"]["sustained"] = {
+                    "clock_ghz": round(ghz.value, 3), "dense_16bit_mfma_tflops": round(tf.value, 1),
+                    "peak": tf.value / per, "frac": ach / (tf.value / per),
+                    "basis": "back-to-back v_mfma_f32_32x32x16_f16 with random operands on all CUs, measured in this run "
+                             "(power-limited clock; the data-sheet peak assumes 2.4 GHz)"}
+            except Exception as e:                       # the probe is an aid, never a reason to lose the bench line
+                out["roofline"]["sustained"] = {"error": str(e)}
         if world == 1 and a.cpu_rows > 0 and a.workload == "metric":
             out["cpu_baseline"] = cpu_baseline(Wd, C, Nc, Ni, a.cpu_rows, W, focal)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -262,6 +262,11 @@ int nefes_bicubic_up_fwd(int64_t planes, int h, int w, int OH, int OW, const flo
 int nefes_bicubic_up_bwd(int64_t planes, int h, int w, int OH, int OW, const float* g_out, float* tmp, float* g_in,
                          void* stream);
 
+/* ---- measurement aid (bench.py's roofline): the matrix-core rate this GPU SUSTAINS under its power management.  Runs
+ *      v_mfma_f32_32x32x16_f16 back to back on every SIMD for ~ms_target milliseconds (operands all zero, or random bits) and
+ *      returns the settled shader clock and the dense fp16 rate.  Synchronises the stream.  Not part of the render path. ---- */
+int nefes_probe_mfma_clock(int random_operands, int ms_target, double* clock_ghz, double* fp16_dense_tflops, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,80 @@
+// Sustained matrix-core rate of THIS GPU under its power management: every SIMD issues v_mfma_f32_32x32x16_f16 back to back on
+// four independent accumulator tiles for a few tens of milliseconds; s_memtime cycles / wall time is the shader clock the chip
+// settles on.  With all-zero operands an MI355X holds ~2.35 GHz (the 2.5 PFLOP/s of the data sheet); with operands whose bits
+// toggle it falls to ~1.65 GHz = ~1.72 PFLOP/s, and VALU work beside the MFMAs lowers it further (tools/probe/clock_probe.hip:
+// the full table, including v_mfma_f32_16x16x32_f16).  bench.py quotes the field kernels against BOTH peaks.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nefes_hip.h"
+
+namespace {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void mfma_clock_kernel(int random, int iters, unsigned long long* cyc, float* sink) {
+    f16x8 A, B;
+    uint32_t x = 0x9e3779b9u * (threadIdx.x + 1u) + blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {            // xorshift: values in (-2, 2), every mantissa bit in play
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        A[i] = random ? (_Float16)(((int)(x & 0xffff) - 32768) * (1.f / 16384.f)) : (_Float16)0.f;
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        B[i] = random ? (_Float16)(((int)(x & 0xffff) - 32768) * (1.f / 16384.f)) : (_Float16)0.f;
+    }
+    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c0) : "v"(A), "v"(B));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c1) : "v"(A), "v"(B));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c2) : "v"(A), "v"(B));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c3) : "v"(A), "v"(B));
+        }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3));      // results readable by the VALU below
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    sink[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+}  // namespace
+
+extern "C" int nefes_probe_mfma_clock(int random_operands, int ms_target, double* clock_ghz, double* fp16_dense_tflops,
+                                      void* stream) {
+    if (!clock_ghz || !fp16_dense_tflops || ms_target <= 0 || ms_target > 2000) return NEFES_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    unsigned long long* cyc = nullptr;
+    float* sink = nullptr;
+    if (hipMalloc(&cyc, (size_t)cus * 8) != hipSuccess || hipMalloc(&sink, (size_t)cus * 256 * 4) != hipSuccess) return NEFES_E_BADARG;
+    const int iters = ms_target * 2000;          // 32 MFMAs x 32 cycles per iteration ~ 0.5 us at 2 GHz
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfma_clock_kernel, dim3(cus), dim3(256), 0, st, random_operands, iters / 4 + 1, cyc, sink);   // ramp
+    (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL(mfma_clock_kernel, dim3(cus), dim3(256), 0, st, random_operands, iters, cyc, sink);
+    (void)hipEventRecord(e1, st);
+    int rc = (int)hipGetLastError();
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long* h = new unsigned long long[cus];
+    (void)hipMemcpy(h, cyc, (size_t)cus * 8, hipMemcpyDeviceToHost);
+    double mean = 0;
+    for (int i = 0; i < cus; ++i) mean += (double)h[i];
+    mean /= cus;
+    delete[] h;
+    (void)hipFree(cyc);
+    (void)hipFree(sink);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != 0 || ms <= 0.f) return rc ? rc : NEFES_E_BADARG;
+    *clock_ghz = mean / ms / 1e6;
+    *fp16_dense_tflops = (double)iters * 32.0 * (2.0 * 32 * 32 * 16) * 4.0 * cus / ms / 1e9;
+    return 0;
+}

@@ -22,4 +22,5 @@ json.dump({"rule": "e_hip <= max(tol, factor * e_ref); e_* are max-abs errors re
 print(f"{len(out)} records -> {dst}")
 worst = sorted(out, key=lambda r: -(r.get("e_hip") or 0) / max(r.get("bound") or 1e-30, 1e-30))[:10]
 for r in worst:
-    print(f"  {r['test']:60s} {r['quantity']:24s} e_hip {r.get('e_hip'):.2e}  e_ref {r.get('e_ref'):.2e}  bound {r.get('bound'):.2e}")
+    f = lambda v: "   n/a  " if v is None else f"{v:.2e}"
+    print(f"  {r['test']:60s} {r['quantity']:24s} e_hip {f(r.get('e_hip'))}  e_ref {f(r.get('e_ref'))}  bound {f(r.get('bound'))}")
