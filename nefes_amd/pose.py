@@ -10,24 +10,36 @@ import torch
 import torch.nn as nn
 
 
+_CONST = {}
+
+
+def _consts(like):
+    """Per (device, dtype): the so(3) generators G[i,j,k] (skew(v) = G @ v), eye(3) and the [0,0,0,1] row.  Built once, outside
+    any graph capture that follows the first call, so a refinement iteration issues no fill / host-to-device copy for them."""
+    key = (like.device, like.dtype)
+    c = _CONST.get(key)
+    if c is None:
+        G = torch.zeros(3, 3, 3)
+        G[0, 1, 2], G[0, 2, 1], G[1, 0, 2], G[1, 2, 0], G[2, 0, 1], G[2, 1, 0] = -1., 1., 1., -1., -1., 1.
+        c = _CONST[key] = (G.to(like.device, like.dtype), torch.eye(3, device=like.device, dtype=like.dtype),
+                           torch.tensor([[0., 0., 0., 1.]], device=like.device, dtype=like.dtype))
+    return c
+
+
 def _skew(v):
-    z = torch.zeros_like(v[..., 0])
-    return torch.stack([torch.stack([z, -v[..., 2], v[..., 1]], -1),
-                        torch.stack([v[..., 2], z, -v[..., 0]], -1),
-                        torch.stack([-v[..., 1], v[..., 0], z], -1)], -2)
+    """[[0,-z,y],[z,0,-x],[-y,x,0]] (lie_group_helper.vec2skew :45-57) as one contraction with the constant generators."""
+    return torch.matmul(_consts(v)[0], v[..., None, :, None])[..., 0] if v.dim() > 1 else _consts(v)[0] @ v
 
 
 def _bottom_row(like, shape):
-    """[0,0,0,1] built by fill kernels on the device (no host->device copy, so the pose chain is graph-capturable)."""
-    row = torch.cat([torch.zeros(3, dtype=like.dtype, device=like.device), torch.ones(1, dtype=like.dtype, device=like.device)])
-    return row.expand(*shape, 1, 4)
+    return _consts(like)[2].expand(*shape, 1, 4)
 
 
 def so3_exp(r):
     """Rodrigues, same expression as lie_group_helper.Exp (:60-69): eps only guards the division."""
     K = _skew(r)
     n = r.norm(dim=-1, keepdim=True)[..., None] + 1e-15
-    eye = torch.eye(3, dtype=r.dtype, device=r.device).expand(K.shape)
+    eye = _consts(r)[1].expand(K.shape)
     return eye + (torch.sin(n) / n) * K + ((1 - torch.cos(n)) / n ** 2) * (K @ K)
 
 
@@ -50,7 +62,7 @@ def se3_exp(tau_phi):
     a = torch.where(small, 1 - th2 / 6, torch.sin(th) / th)
     b = torch.where(small, 0.5 - th2 / 24, (1 - torch.cos(th)) / th2.clamp_min(1e-30))
     c = torch.where(small, 1. / 6 - th2 / 120, (th - torch.sin(th)) / (th2 * th).clamp_min(1e-30))
-    eye = torch.eye(3, dtype=phi.dtype, device=phi.device).expand(K.shape)
+    eye = _consts(phi)[1].expand(K.shape)
     R = eye + a * K + b * (K @ K)
     V = eye + b * K + c * (K @ K)
     t = (V @ tau[..., None])[..., 0]

@@ -79,7 +79,8 @@ class PoseRefiner:
         self.use_graph, self.graph = bool(graph), None
 
     # one iteration on the static buffers -------------------------------------------------------------------------
-    def _iteration(self):
+    def _loss(self):
+        """DFM_optimization_NFF (:310-337): pose -> render -> affine colour transform -> fusion CNN -> feature loss."""
         c2w = self.model(0)[None, :3, :4]
         if self.world_setup is not None:
             c2w = fix_coord_supp(c2w, self.world_setup)
@@ -90,11 +91,23 @@ class PoseRefiner:
         _, _, fused = self.coarse.run_fusion_net(rgb, ex["feat_map"], self.h, self.w, 1)
         if self.upsample:
             fused = ops.bicubic_upsample(fused, (self.H, self.W))[:, :, 10:-10, 10:-10]
-        loss = feature_loss(fused[0], self.target, per_pixel=self.per_pixel)
-        loss.backward()
-        self.opt.step()
-        self.opt.zero_grad(set_to_none=False)
+        return feature_loss(fused[0], self.target, per_pixel=self.per_pixel)
+
+    def loss_and_grad(self):
+        """Loss at the current (r, t) and its gradient, written into the parameters' static .grad buffers (no optimizer step).
+        The gradients are copied over the previous ones: nothing has to be zeroed between iterations."""
+        loss = self._loss()
+        gr, gt = torch.autograd.grad(loss, [self.model.r, self.model.t])
+        for p, g in ((self.model.r, gr), (self.model.t, gt)):
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(g)
         self.loss.copy_(loss.detach())
+        return self.loss
+
+    def _iteration(self):
+        self.loss_and_grad()
+        self.opt.step()
 
     def _reset(self, init_c2w, feature_target, hist):
         with torch.no_grad():

@@ -1,0 +1,175 @@
+"""CPU oracle for the per-image pose-refinement loop around the render path.
+
+TEST INFRASTRUCTURE ONLY (same rule as oracle/ref_cpu.py: imported by tests/ only; the product never imports it).
+
+A plain-torch, dtype-generic restatement of one iteration of script/dm/DFM_pose_refine.py:290-348 (`DFM_optimization_NFF`,
+paths relative to /root/reference):
+
+    LearnPose.forward         script/models/poses.py:26-50 (lietorch=False)  +  script/utils/lie_group_helper.py:60-81
+    fix_coord_supp            script/dm/direct_pose_model.py:210-232
+    render                    oracle/ref_cpu.py (script/models/rendering.py:197-243)
+    affine_color_transform    script/models/nerfh_nff.py:605-626   (exposure network: see below)
+    run_fusion_net            script/models/nerfh_nff.py:578-603, FusionNet :356-418 (BatchNorm in TRAIN mode: the reference
+                              never calls .eval() on the NeRF modules -- batch statistics of the one image, biased variance)
+    feature_loss              script/dm/DFM_pose_refine.py:211-233  (1 - mean over channels of the cosine similarity over pixels)
+    Adam                      torch.optim.Adam defaults (betas 0.9/0.999, eps 1e-8), restated so that it runs in float64
+
+Parity status: PINNED for everything above except the exposure network, by tests/golden/refine.npz and affine.npz, which
+tools/make_golden_refine.py produces by running the reference's own functions on the CPU (tests/test_refine_oracle.py).
+`exposure_mlp` restates tiny-cuda-nn's FullyFusedMLP(10 -> 12, 32 neurons, 3 hidden layers, ReLU, no bias) in fp32 with the
+flat parameter layout of nefes_amd.field.ExposureMLP; tiny-cuda-nn is neither vendored by the reference nor installed, so its
+layout and its fp16 arithmetic are UNPINNED.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+from . import ref_cpu as O
+
+Tensor = torch.Tensor
+
+
+def skew(v: Tensor) -> Tensor:
+    """lie_group_helper.py:45-57."""
+    z = torch.zeros((), dtype=v.dtype)
+    return torch.stack([torch.stack([z, -v[2], v[1]]), torch.stack([v[2], z, -v[0]]), torch.stack([-v[1], v[0], z])])
+
+
+def learn_pose(r: Tensor, t: Tensor, init_c2w: Tensor) -> Tensor:
+    """poses.py:43-50 with make_c2w (lie_group_helper.py:60-81): [Exp(r) R0 | t + t0] as 3x4."""
+    K = skew(r)
+    n = r.norm() + 1e-15
+    R = torch.eye(3, dtype=r.dtype) + (torch.sin(n) / n) * K + ((1 - torch.cos(n)) / n ** 2) * (K @ K)
+    return torch.cat([R @ init_c2w[:3, :3], (t + init_c2w[:3, 3])[:, None]], 1)
+
+
+def fix_coord_supp(pose: Tensor, pose_scale: float, move_all_cam_vec, pose_scale2: float) -> Tensor:
+    """direct_pose_model.py:224-231: t' = (t * sc + move) * sc2 (the reference edits a view in place; same values)."""
+    mv = torch.as_tensor(move_all_cam_vec, dtype=pose.dtype)
+    return torch.cat([pose[:, :3], ((pose[:, 3] * pose_scale + mv) * pose_scale2)[:, None]], 1)
+
+
+EXPOSURE_SHAPES = [(32, 16), (32, 32), (32, 32), (16, 32)]
+
+
+def exposure_mlp(params: Tensor, hist: Tensor) -> Tensor:
+    """Stand-in for tcnn.Network (nerfh_nff.py:511-522), UNPINNED: [B,10] -> [B,12]."""
+    h = F.pad(hist.to(params.dtype), (0, 6))
+    off = 0
+    for k, (o, i) in enumerate(EXPOSURE_SHAPES):
+        h = h @ params[off:off + o * i].view(o, i).t()
+        off += o * i
+        if k < 3:
+            h = torch.relu(h)
+    return h[:, :12]
+
+
+def affine_color_transform(params: Tensor, rgb: Tensor, hist: Tensor, batch_size: int) -> Tensor:
+    """nerfh_nff.py:605-626: hist.long() -> exposure network -> rgb' = sigmoid(K rgb + b) per image."""
+    a = exposure_mlp(params, hist.long())
+    kernel, bias = a[:, :9].reshape(-1, 3, 3), a[:, 9:].reshape(-1, 3, 1)
+    x = rgb.reshape(batch_size, -1, 3)
+    x = torch.bmm(kernel, x.transpose(1, 2)) + bias
+    return torch.sigmoid(x.transpose(1, 2).reshape(-1, 3))
+
+
+FUSION_MEAN, FUSION_STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]      # nerfh_nff.py:359-360
+
+
+def fusion_net(sd: Dict[str, Tensor], rgb: Tensor, feat: Tensor, H: int, W: int, B: int, residual: bool = False) -> Tensor:
+    """run_fusion_net (:578-603) + FusionNet.forward (:395-418), BatchNorm2d in train mode (batch statistics, eps 1e-5).
+    `sd`: the fusion_net state dict (net.0/2/4/6 conv weight+bias, net.7 BatchNorm weight+bias), any dtype."""
+    dt = rgb.dtype
+    x = torch.cat([rgb.reshape(B, H, W, 3).permute(0, 3, 1, 2), feat.reshape(B, H, W, -1).permute(0, 3, 1, 2)], 1)
+    mean, std = torch.tensor(FUSION_MEAN, dtype=dt), torch.tensor(FUSION_STD, dtype=dt)
+    x = torch.cat([(x[:, :3] - mean[:, None, None]) / std[:, None, None], x[:, 3:]], 1)
+    h = x
+    for k, pad in ((0, 1), (2, 1), (4, 1), (6, 2)):
+        h = F.conv2d(h, sd[f"net.{k}.weight"].to(dt), sd[f"net.{k}.bias"].to(dt), stride=1, padding=pad)
+        if k != 6:
+            h = torch.relu(h)
+    if "net.7.weight" in sd:
+        mu = h.mean(dim=(0, 2, 3), keepdim=True)
+        var = ((h - mu) ** 2).mean(dim=(0, 2, 3), keepdim=True)                 # biased, as BatchNorm normalises with
+        h = (h - mu) / torch.sqrt(var + 1e-5)
+        h = h * sd["net.7.weight"].to(dt)[None, :, None, None] + sd["net.7.bias"].to(dt)[None, :, None, None]
+    return x[:, 3:] + h if residual else h
+
+
+def feature_loss(feature_rgb: Tensor, feature_target: Tensor, per_pixel: bool = False) -> Tensor:
+    """DFM_pose_refine.py:211-233 with img_in=True: [C,H,W] each."""
+    C = feature_rgb.shape[0]
+    a, b = feature_rgb.reshape(C, -1), feature_target.reshape(C, -1)
+    return 1 - F.cosine_similarity(a, b, dim=0 if per_pixel else 1, eps=1e-6).mean()
+
+
+class Adam:
+    """torch.optim.Adam (defaults) on a list of (tensor, lr): same update order as torch's single-tensor path."""
+
+    def __init__(self, params: List[Tensor], lrs: List[float], betas=(0.9, 0.999), eps: float = 1e-8):
+        self.params, self.lrs, self.b1, self.b2, self.eps = params, lrs, betas[0], betas[1], eps
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+        self.step_count = 0
+
+    def step(self, grads: List[Tensor]):
+        self.step_count += 1
+        c1, c2 = 1 - self.b1 ** self.step_count, 1 - self.b2 ** self.step_count
+        for p, g, m, v, lr in zip(self.params, grads, self.m, self.v, self.lrs):
+            m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+            v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            denom = (v.sqrt() / (c2 ** 0.5)).add_(self.eps)
+            p.addcdiv_(m, denom, value=-lr / c1)
+
+
+class Problem:
+    """Everything one image's refinement needs, cast to `dtype` once."""
+
+    def __init__(self, p_coarse, p_fine, fusion_sd, exposure_params, cfg: O.RenderCfg, hwf, tinyscale: int, near: float,
+                 far: float, init_c2w: Tensor, target: Tensor, hist: Tensor, world: dict, dtype=torch.float64):
+        H, W, focal = hwf
+        self.h, self.w, self.f = int(H // tinyscale), int(W // tinyscale), float(focal) / tinyscale
+        cast = lambda d: {k: v.to(dtype) for k, v in d.items()}
+        self.p_coarse, self.p_fine, self.fusion_sd = cast(p_coarse), cast(p_fine), cast(fusion_sd)
+        self.exposure_params, self.init_c2w = exposure_params.to(dtype), init_c2w.to(dtype)
+        self.target, self.hist = target.to(dtype), hist.to(dtype)
+        self.cfg, self.near, self.far, self.world, self.dtype = cfg, near, far, world, dtype
+
+    def loss(self, r: Tensor, t: Tensor) -> Tensor:
+        """DFM_optimization_NFF (:310-337)."""
+        pose = learn_pose(r, t, self.init_c2w)
+        pose = fix_coord_supp(pose, self.world["pose_scale"], self.world["move_all_cam_vec"], self.world["pose_scale2"])
+        rgb, _, _, extras = O.render(self.h, self.w, self.f, self.p_coarse, self.p_fine, self.cfg, c2w=pose, near=self.near,
+                                     far=self.far, hist=self.hist)
+        rgb = affine_color_transform(self.exposure_params, rgb, self.hist, 1)
+        fused = fusion_net(self.fusion_sd, rgb, extras["feat_map"], self.h, self.w, 1)
+        return feature_loss(fused[0], self.target)
+
+    def loss_and_grad(self, r, t):
+        """(loss, d loss / d [r, t] as one 6-vector) at the given pose parameters."""
+        r = torch.as_tensor(r, dtype=self.dtype).clone().requires_grad_()
+        t = torch.as_tensor(t, dtype=self.dtype).clone().requires_grad_()
+        loss = self.loss(r, t)
+        gr, gt = torch.autograd.grad(loss, [r, t])
+        return loss.detach(), torch.cat([gr, gt])
+
+
+def refine(prob: Problem, lr_r: float, lr_t: float, iters: int):
+    """`iters` iterations of DFM_optimization_NFF (:310-341) for one image.  Returns dict(losses [iters], poses [iters,3,4],
+    r [iters,3], t [iters,3], grads [iters,6]) -- the pose after each optimizer step, the loss and gradient before it."""
+    r = torch.zeros(3, dtype=prob.dtype)
+    t = torch.zeros(3, dtype=prob.dtype)
+    opt = Adam([r, t], [lr_r, lr_t])
+    out = {"losses": [], "poses": [], "r": [], "t": [], "grads": []}
+    for _ in range(iters):
+        loss, g = prob.loss_and_grad(r, t)
+        opt.step([g[:3], g[3:]])
+        out["losses"].append(loss)
+        out["poses"].append(learn_pose(r, t, prob.init_c2w).clone())
+        out["r"].append(r.clone())
+        out["t"].append(t.clone())
+        out["grads"].append(g)
+    return {k: torch.stack(v) for k, v in out.items()}
