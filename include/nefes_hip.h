@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEFES_ABI_VERSION 7
+#define NEFES_ABI_VERSION 8
 
 #define NEFES_E_BADARG (-1)     /* null pointer / non-positive size */
 #define NEFES_E_UNSUPPORTED (-2) /* width / feat_dim / sample count outside the compiled set */
@@ -256,11 +256,33 @@ int nefes_train_dw(int64_t n_tiles, int rows, const float* dacts, int g_row0, in
 
 /* ---- bicubic up-sampling of the fused feature image (script/dm/DFM_APR_refine.py:114,118: torch.nn.Upsample(size,
  *      mode='bicubic'), align_corners=False, A=-0.75) ---- */
-/* in [planes,h,w] -> out [planes,OH,OW] (planes = batch*channels, contiguous NCHW). */
-int nefes_bicubic_up_fwd(int64_t planes, int h, int w, int OH, int OW, const float* in, float* out, void* stream);
-/* g_out [planes,OH,OW] -> g_in [planes,h,w]; separable gather (no atomics, deterministic); tmp: [planes,h,OW] scratch. */
-int nefes_bicubic_up_bwd(int64_t planes, int h, int w, int OH, int OW, const float* g_out, float* tmp, float* g_in,
+/* in [planes,h,w] -> out [planes,CH,CW] = the window [oy0, oy0+CH) x [ox0, ox0+CW) of the OH x OW up-sampled image (planes =
+ * batch*channels, contiguous NCHW).  The loop crops 10 pixels per side right after up-sampling (DFM_APR_refine.py:115,119): pass
+ * the crop here and only the window is computed; the full image is (0, 0, OH, OW). */
+int nefes_bicubic_up_fwd(int64_t planes, int h, int w, int OH, int OW, int oy0, int ox0, int CH, int CW, const float* in, float* out,
                          void* stream);
+/* g_out [planes,CH,CW] (gradient of the window) -> g_in [planes,h,w]; separable gather (no atomics, deterministic);
+ * tmp: [planes,h,CW] scratch. */
+int nefes_bicubic_up_bwd(int64_t planes, int h, int w, int OH, int OW, int oy0, int ox0, int CH, int CW, const float* g_out, float* tmp,
+                         float* g_in, void* stream);
+
+/* ---- the per-image refinement loop's glue (script/dm/DFM_pose_refine.py:290-348) ---- */
+/* LearnPose.forward (script/models/poses.py:43-50, lietorch=False: utils/lie_group_helper.py:60-81) + fix_coord_supp
+ * (script/dm/direct_pose_model.py:224-231): c2w [3,4] = [Exp(r) R0 | ((t + t0) sc + move) sc2].
+ * r, t: dev [3]; init_c2w: dev [4,4] row-major; move: HOST [3]; c2w: dev [12]. */
+int nefes_pose_compose_fwd(const float* r, const float* t, const float* init_c2w, float pose_scale, const float* move,
+                           float pose_scale2, float* c2w, void* stream);
+/* g_c2w dev [12] -> g_r, g_t dev [3] (analytic derivative of the Rodrigues formula, float64 inside). */
+int nefes_pose_compose_bwd(const float* r, const float* t, const float* init_c2w, float pose_scale, const float* move,
+                           float pose_scale2, const float* g_c2w, float* g_r, float* g_t, void* stream);
+/* feature_loss (DFM_pose_refine.py:211-233, per_pixel=False): loss = 1 - mean_c cos(a[c,:], b[c,:]), a, b dev [C,P] contiguous,
+ * torch.nn.CosineSimilarity(dim=1, eps=1e-6) semantics, float64 accumulation.  scratch: dev doubles,
+ * nefes_cosine_loss_scratch_doubles(C) of them, kept by the caller for the backward. */
+size_t nefes_cosine_loss_scratch_doubles(int C);
+int nefes_cosine_loss_fwd(int C, int64_t P, const float* a, const float* b, double* scratch, float* loss, void* stream);
+/* g_a [C,P] = g_loss[0] * d loss / d a (g_loss: dev scalar). */
+int nefes_cosine_loss_bwd(int C, int64_t P, const float* a, const float* b, const double* scratch, const float* g_loss, float* g_a,
+                          void* stream);
 
 /* ---- measurement aid (bench.py's roofline): the matrix-core rate this GPU SUSTAINS under its power management.  Runs
  *      v_mfma_f32_32x32x16_f16 back to back on every SIMD for ~ms_target milliseconds (operands all zero, or random bits) and

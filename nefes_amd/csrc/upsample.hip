@@ -34,12 +34,14 @@ __device__ __forceinline__ Taps taps_of(float scale, int dst) {
 
 __device__ __forceinline__ int clampi(int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); }
 
-__global__ __launch_bounds__(256) void bicubic_up_fwd_kernel(long planes, int h, int w, int OH, int OW, float sy, float sx,
+// out = the window [oy0, oy0+CH) x [ox0, ox0+CW) of the up-sampled OH x OW image (the loop crops 10 pixels per side right after
+// up-sampling, DFM_APR_refine.py:115,119: only the window is ever computed, stored, or differentiated)
+__global__ __launch_bounds__(256) void bicubic_up_fwd_kernel(long planes, int h, int w, int CH, int CW, int oy0, int ox0, float sy, float sx,
                                                              const float* __restrict__ in, float* __restrict__ out) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= planes * OH * OW) return;
-    const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH);
-    const long p = idx / ((long)OW * OH);
+    if (idx >= planes * CH * CW) return;
+    const int ox = (int)(idx % CW) + ox0, oy = (int)((idx / CW) % CH) + oy0;
+    const long p = idx / ((long)CW * CH);
     const Taps ty = taps_of(sy, oy), tx = taps_of(sx, ox);
     const float* src = in + p * h * w;
     int xs[4];
@@ -56,7 +58,8 @@ __global__ __launch_bounds__(256) void bicubic_up_fwd_kernel(long planes, int h,
 
 // One gather pass along one axis.  src is [planes, n_out_axis, inner] (AXIS_ROWS) or [planes*rows, n_out_axis] (columns):
 // generalised as dst[p][y][q] = sum_o W(o -> y) src[p][o][q] with strides given.
-__global__ __launch_bounds__(256) void bicubic_gather_kernel(long outer, int n_in, int n_out, long inner, float scale,
+// src holds only the window [o0, o0 + n_win) of the n_out up-sampled positions along the axis.
+__global__ __launch_bounds__(256) void bicubic_gather_kernel(long outer, int n_in, int n_out, int o0, int n_win, long inner, float scale,
                                                              float inv_scale, const float* __restrict__ src, float* __restrict__ dst) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= outer * n_in * inner) return;
@@ -65,9 +68,10 @@ __global__ __launch_bounds__(256) void bicubic_gather_kernel(long outer, int n_i
     const long p = idx / (inner * n_in);
     int lo = (int)floorf(((float)y - 1.5f) * inv_scale - 0.5f) - 1;
     int hi = (int)ceilf(((float)y + 2.5f) * inv_scale - 0.5f) + 1;
-    lo = lo < 0 ? 0 : lo;
-    hi = hi > n_out - 1 ? n_out - 1 : hi;
-    const float* s = src + p * n_out * inner + q;
+    lo = lo < o0 ? o0 : lo;
+    hi = hi > o0 + n_win - 1 ? o0 + n_win - 1 : hi;
+    (void)n_out;
+    const float* s = src + p * n_win * inner + q - (long)o0 * inner;
     float acc = 0.f;
     for (int o = lo; o <= hi; ++o) {
         const Taps t = taps_of(scale, o);
@@ -83,23 +87,29 @@ __global__ __launch_bounds__(256) void bicubic_gather_kernel(long outer, int n_i
 
 }   // namespace
 
-extern "C" int nefes_bicubic_up_fwd(int64_t planes, int h, int w, int OH, int OW, const float* in, float* out, void* stream_) {
-    if (planes < 0 || h <= 0 || w <= 0 || OH <= 0 || OW <= 0 || !in || !out) return NEFES_E_BADARG;
-    const long n = (long)planes * OH * OW;
+static bool window_ok(int O, int o0, int n) { return o0 >= 0 && n > 0 && o0 + n <= O; }
+
+extern "C" int nefes_bicubic_up_fwd(int64_t planes, int h, int w, int OH, int OW, int oy0, int ox0, int CH, int CW, const float* in,
+                                    float* out, void* stream_) {
+    if (planes < 0 || h <= 0 || w <= 0 || OH <= 0 || OW <= 0 || !window_ok(OH, oy0, CH) || !window_ok(OW, ox0, CW) || !in || !out)
+        return NEFES_E_BADARG;
+    const long n = (long)planes * CH * CW;
     if (n == 0) return 0;
-    bicubic_up_fwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_>>>(planes, h, w, OH, OW, (float)h / OH, (float)w / OW, in, out);
+    bicubic_up_fwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_>>>(planes, h, w, CH, CW, oy0, ox0, (float)h / OH, (float)w / OW, in, out);
     return (int)hipGetLastError();
 }
 
-extern "C" int nefes_bicubic_up_bwd(int64_t planes, int h, int w, int OH, int OW, const float* g_out, float* tmp, float* g_in,
-                                    void* stream_) {
-    if (planes < 0 || h <= 0 || w <= 0 || OH <= 0 || OW <= 0 || !g_out || !tmp || !g_in) return NEFES_E_BADARG;
+extern "C" int nefes_bicubic_up_bwd(int64_t planes, int h, int w, int OH, int OW, int oy0, int ox0, int CH, int CW, const float* g_out,
+                                    float* tmp, float* g_in, void* stream_) {
+    if (planes < 0 || h <= 0 || w <= 0 || OH <= 0 || OW <= 0 || !window_ok(OH, oy0, CH) || !window_ok(OW, ox0, CW) || !g_out || !tmp ||
+        !g_in)
+        return NEFES_E_BADARG;
     if (planes == 0) return 0;
-    // rows: tmp[p][y][ox] = sum_oy Wy(oy->y) g_out[p][oy][ox]
-    long n1 = (long)planes * h * OW;
-    bicubic_gather_kernel<<<dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream_>>>(planes, h, OH, OW, (float)h / OH, (float)OH / h, g_out, tmp);
-    // columns: g_in[p*h + y][x] = sum_ox Wx(ox->x) tmp[p*h + y][ox]
+    // rows: tmp[p][y][cx] = sum_{oy in window} Wy(oy->y) g_out[p][oy - oy0][cx]                       (tmp: [planes, h, CW])
+    long n1 = (long)planes * h * CW;
+    bicubic_gather_kernel<<<dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream_>>>(planes, h, OH, oy0, CH, CW, (float)h / OH, (float)OH / h, g_out, tmp);
+    // columns: g_in[p*h + y][x] = sum_{ox in window} Wx(ox->x) tmp[p*h + y][ox - ox0]
     long n2 = (long)planes * h * w;
-    bicubic_gather_kernel<<<dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream_>>>((long)planes * h, w, OW, 1, (float)w / OW, (float)OW / w, tmp, g_in);
+    bicubic_gather_kernel<<<dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream_>>>((long)planes * h, w, OW, ox0, CW, 1, (float)w / OW, (float)OW / w, tmp, g_in);
     return (int)hipGetLastError();
 }

@@ -37,14 +37,25 @@ class FusionNet(nn.Module):
         self.net = nn.Sequential(*layers)
         self._norm = {}                                             # (device, dtype) -> (mean, std); not in the state_dict
 
-    def forward(self, x):
+    def _mean_std(self, x):
         key = (x.device, x.dtype)
         if key not in self._norm:                                   # one host->device copy per device, outside any graph capture
             self._norm[key] = (x.new_tensor(self.mean), x.new_tensor(self.std))
-        mean, std = self._norm[key]
+        return self._norm[key]
+
+    def forward(self, x):
+        mean, std = self._mean_std(x)
         x[:, :3] = (x[:, :3] - mean[:, None, None]) / std[:, None, None]     # in place, as the reference does
         out = self.net(x)
         return x[:, 3:] + out if self.fusion_residule else out
+
+    def forward_parts(self, rgb_nchw, feat_nchw):
+        """forward(cat([rgb, feat], 1)) without the in-place slice assignment (whose autograd costs a fill and two copies):
+        the colour channels are normalised before the concatenation -- same values, same order of operations."""
+        mean, std = self._mean_std(rgb_nchw)
+        x = torch.cat([(rgb_nchw - mean[:, None, None]) / std[:, None, None], feat_nchw], dim=1)
+        out = self.net(x)
+        return feat_nchw + out if self.fusion_residule else out
 
 
 class ExposureMLP(nn.Module):
@@ -179,17 +190,25 @@ class NeRFH_NFF(nn.Module):
     def run_fusion_net(self, rgb, feature, H, W, B):
         render_rgb = rgb.reshape(B, H, W, 3).permute(0, 3, 1, 2)
         render_feature = feature.reshape(B, H, W, self.W_features).permute(0, 3, 1, 2)
-        fused = self.fusion_net(torch.cat([render_rgb, render_feature], dim=1))
+        fused = self.fusion_net.forward_parts(render_rgb, render_feature)
         return render_rgb, render_feature, fused
 
-    def affine_color_transform(self, args, rgb, hist, batch_size):
-        assert args.encode_hist and self.typ == 'coarse'
-        self.a_embedded = self.exposure_embedding(hist.long()).float()
-        kernel = self.a_embedded[:, :9].reshape(-1, 3, 3)
-        bias = self.a_embedded[:, 9:].reshape(-1, 3, 1)
+    def exposure_coefficients(self, hist):
+        """[B,10] histogram -> [B,12] (3x3 kernel, 3 bias): the first line of affine_color_transform (nerfh_nff.py:616)."""
+        return self.exposure_embedding(hist.long()).float()
+
+    def apply_affine(self, a_embedded, rgb, batch_size):
+        """nerfh_nff.py:617-625: rgb' = sigmoid(K rgb + b) per image."""
+        kernel = a_embedded[:, :9].reshape(-1, 3, 3)
+        bias = a_embedded[:, 9:].reshape(-1, 3, 1)
         rgb = rgb.reshape(batch_size, -1, 3)
         rgb = torch.bmm(kernel, rgb.transpose(1, 2)) + bias
         return self.sigmoid(rgb.transpose(1, 2).reshape(-1, 3))
+
+    def affine_color_transform(self, args, rgb, hist, batch_size):
+        assert args.encode_hist and self.typ == 'coarse'
+        self.a_embedded = self.exposure_coefficients(hist)
+        return self.apply_affine(self.a_embedded, rgb, batch_size)
 
 
 def run_network_NeRFH_NFF(inputs, viewdirs, ts, fn, embed_fn=None, embeddirs_fn=None, typ='coarse', output_transient=False,

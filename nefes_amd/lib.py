@@ -32,7 +32,7 @@ class NefesHashGridDesc(C.Structure):
                 ("base_resolution", C.c_int32), ("per_level_scale", C.c_float), ("bound", C.c_float)]
 
 
-ABI_VERSION = 7        # NEFES_ABI_VERSION of include/nefes_hip.h
+ABI_VERSION = 8        # NEFES_ABI_VERSION of include/nefes_hip.h
 STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6, STREAM_BWD_FULL_X6, STREAM_BWD_STATIC = 0, 1, 2, 3, 4, 5, 6, 7
 STREAM_FWD_SIGMA_H3, STREAM_FWD_FULL_H3, STREAM_BWD_FULL_H3 = 8, 9, 10
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
@@ -82,8 +82,13 @@ SIGNATURES = {
     "nefes_train_head_grad": (_i, [_desc, _i, _i, _i, _p, _p, _p, _p]),
     "nefes_train_dx": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
     "nefes_train_dw": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p]),
-    "nefes_bicubic_up_fwd": (_i, [C.c_int64, _i, _i, _i, _i, _p, _p, _p]),
-    "nefes_bicubic_up_bwd": (_i, [C.c_int64, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "nefes_bicubic_up_fwd": (_i, [C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "nefes_bicubic_up_bwd": (_i, [C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "nefes_pose_compose_fwd": (_i, [_p, _p, _p, C.c_float, C.POINTER(C.c_float), C.c_float, _p, _p]),
+    "nefes_pose_compose_bwd": (_i, [_p, _p, _p, C.c_float, C.POINTER(C.c_float), C.c_float, _p, _p, _p, _p]),
+    "nefes_cosine_loss_scratch_doubles": (_sz, [_i]),
+    "nefes_cosine_loss_fwd": (_i, [_i, C.c_int64, _p, _p, _p, _p, _p]),
+    "nefes_cosine_loss_bwd": (_i, [_i, C.c_int64, _p, _p, _p, _p, _p, _p]),
     "nefes_sample_pdf_merge": (_i, [_i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
 }
 

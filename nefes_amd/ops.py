@@ -142,10 +142,22 @@ class NdcRays(torch.autograd.Function):
         return go.reshape(shape), gd.reshape(shape), None, None, None, None
 
 
+_LINSPACE = {}
+
+
+def _linspace01(n, device):
+    """torch.linspace(0, 1, n) on the device, built once per (n, device): rendering.py:33,95 create it on every call."""
+    key = (int(n), str(device))
+    t = _LINSPACE.get(key)
+    if t is None:
+        t = _LINSPACE[key] = torch.linspace(0., 1., steps=int(n), device=device)
+    return t
+
+
 def coarse_depths(N, Nc, near, far, lindisp=False, t_rand=None, device="cuda", bounds=None):
     """rendering.py:95-112.  `bounds` = a float32 CUDA tensor whose rows start with (near, far) per ray (any row stride,
     e.g. columns 6:8 of the reference's packed ray batch); then the scalars are ignored."""
-    t = torch.linspace(0., 1., steps=Nc, device=device)            # rendering.py:95 (torch's own two-sided formula)
+    t = _linspace01(Nc, device)                                    # rendering.py:95 (torch's own two-sided formula)
     z = torch.empty(N, Nc, device=device)
     t_rand = None if t_rand is None else _f32(t_rand)
     if bounds is not None:
@@ -475,6 +487,7 @@ class Composite(torch.autograd.Function):
     def forward(ctx, raw_t, z, C_feat, flags, beta_min):
         raw_t, z = _f32(raw_t), _f32(z)
         outs = composite_fwd(raw_t, z, C_feat, flags, beta_min)
+        ctx.set_materialize_grads(False)      # maps nobody differentiates arrive as None, not as freshly zero-filled tensors
         ctx.save_for_backward(raw_t, z)
         ctx.cfg = (C_feat, flags)
         if flags & L.COMP_SIGMA_ONLY:
@@ -513,7 +526,7 @@ def sample_pdf_merge(z_coarse, weights, Ni, u=None, cdf=None, want_debug=False, 
         Nc += 1
     dev = z_coarse.device
     if u is None:
-        u = torch.linspace(0., 1., steps=Ni, device=dev)             # rendering.py:33 bits
+        u = _linspace01(Ni, dev)                                     # rendering.py:33 bits
     u = _f32(u)
     per_ray = 1 if u.dim() == 2 else 0
     z_fine = None if bins_layout else torch.empty(N, Nc + Ni, device=dev)
@@ -584,31 +597,98 @@ class HashGridEncode(torch.autograd.Function):
 
 
 class BicubicUpsample(torch.autograd.Function):
-    """torch.nn.Upsample(size=(OH, OW), mode='bicubic') on a contiguous [B,C,h,w] image (DFM_APR_refine.py:114,118);
-    the backward is a separable gather instead of the library's atomic scatter."""
+    """torch.nn.Upsample(size=(OH, OW), mode='bicubic') on a contiguous [B,C,h,w] image (DFM_APR_refine.py:114,118), optionally
+    only the window `crop` pixels inside every border (the loop's `[:, :, 10:-10, 10:-10]`, :115,119: the cropped-away pixels are
+    never computed and the slice's backward -- a 39 MB fill plus a copy -- disappears); the backward is a separable gather
+    instead of the library's atomic scatter."""
 
     @staticmethod
-    def forward(ctx, x, OH, OW):
+    def forward(ctx, x, OH, OW, crop):
         B, Cc, h, w = x.shape
         xf = _f32(x)
-        out = torch.empty(B, Cc, OH, OW, device=xf.device)
+        CH, CW = OH - 2 * crop, OW - 2 * crop
+        out = torch.empty(B, Cc, CH, CW, device=xf.device)
         with _timed("bicubic_up_fwd"):
-            L.check(L.load().nefes_bicubic_up_fwd(B * Cc, h, w, OH, OW, _chk(xf, "x"), _chk(out, "out"), _stream()),
+            L.check(L.load().nefes_bicubic_up_fwd(B * Cc, h, w, OH, OW, crop, crop, CH, CW, _chk(xf, "x"), _chk(out, "out"), _stream()),
                     "nefes_bicubic_up_fwd")
-        ctx.dims = (B, Cc, h, w, OH, OW)
+        ctx.dims = (B, Cc, h, w, OH, OW, crop, CH, CW)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        B, Cc, h, w, OH, OW = ctx.dims
+        B, Cc, h, w, OH, OW, crop, CH, CW = ctx.dims
         g = _f32(g_out)
-        tmp = torch.empty(B * Cc, h, OW, device=g.device)
+        tmp = torch.empty(B * Cc, h, CW, device=g.device)
         g_in = torch.empty(B, Cc, h, w, device=g.device)
         with _timed("bicubic_up_bwd"):
-            L.check(L.load().nefes_bicubic_up_bwd(B * Cc, h, w, OH, OW, _chk(g, "g_out"), _chk(tmp, "tmp"), _chk(g_in, "g_in"),
-                                                  _stream()), "nefes_bicubic_up_bwd")
-        return g_in, None, None
+            L.check(L.load().nefes_bicubic_up_bwd(B * Cc, h, w, OH, OW, crop, crop, CH, CW, _chk(g, "g_out"), _chk(tmp, "tmp"),
+                                                  _chk(g_in, "g_in"), _stream()), "nefes_bicubic_up_bwd")
+        return g_in, None, None, None
 
 
-def bicubic_upsample(x, size):
-    return BicubicUpsample.apply(x, int(size[0]), int(size[1]))
+def bicubic_upsample(x, size, crop=0):
+    return BicubicUpsample.apply(x, int(size[0]), int(size[1]), int(crop))
+
+
+class PoseCompose(torch.autograd.Function):
+    """LearnPose.forward (models/poses.py:43-50, lietorch=False) + fix_coord_supp (dm/direct_pose_model.py:224-231) in one
+    launch each way: (r [3], t [3]) -> c2w [3,4] in NeRF coordinates.  `init_c2w` [4,4] on the device, no gradient."""
+
+    @staticmethod
+    def forward(ctx, r, t, init_c2w, pose_scale, move, pose_scale2):
+        rf, tf, i0 = _f32(r), _f32(t), _f32(init_c2w)
+        mv = (C.c_float * 3)(*[float(v) for v in move])
+        out = torch.empty(3, 4, device=rf.device)
+        L.check(L.load().nefes_pose_compose_fwd(_chk(rf, "r"), _chk(tf, "t"), _chk(i0, "init_c2w"), float(pose_scale), mv,
+                                                float(pose_scale2), _chk(out, "c2w"), _stream()), "nefes_pose_compose_fwd")
+        ctx.save_for_backward(rf, tf, i0)
+        ctx.consts = (float(pose_scale), mv, float(pose_scale2))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rf, tf, i0 = ctx.saved_tensors
+        sc, mv, sc2 = ctx.consts
+        gf = _f32(g)
+        g_r, g_t = torch.empty(3, device=gf.device), torch.empty(3, device=gf.device)
+        L.check(L.load().nefes_pose_compose_bwd(_chk(rf, "r"), _chk(tf, "t"), _chk(i0, "init_c2w"), sc, mv, sc2, _chk(gf, "g_c2w"),
+                                                _chk(g_r, "g_r"), _chk(g_t, "g_t"), _stream()), "nefes_pose_compose_bwd")
+        return g_r, g_t, None, None, None, None
+
+
+def pose_compose(r, t, init_c2w, pose_scale=1.0, move=(0., 0., 0.), pose_scale2=1.0):
+    return PoseCompose.apply(r, t, init_c2w, pose_scale, move, pose_scale2)
+
+
+class CosineFeatureLoss(torch.autograd.Function):
+    """feature_loss (dm/DFM_pose_refine.py:211-233, per_pixel=False) on [C, ...] maps: 1 - mean over channels of the cosine
+    similarity over pixels; two launches forward, one backward (to `a` only: the target carries no gradient)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        Cc = a.shape[0]
+        af, bf = _f32(a).reshape(Cc, -1), _f32(b).reshape(Cc, -1)
+        if af.shape != bf.shape:
+            raise ValueError(f"nefes_amd: feature maps of different shapes: {tuple(a.shape)} vs {tuple(b.shape)}")
+        lib = L.load()
+        scratch = torch.empty(lib.nefes_cosine_loss_scratch_doubles(Cc), dtype=torch.float64, device=af.device)
+        loss = torch.empty((), device=af.device)
+        L.check(lib.nefes_cosine_loss_fwd(Cc, af.shape[1], _chk(af, "a"), _chk(bf, "b"), _chk(scratch, "scratch", torch.float64),
+                                          _chk(loss, "loss"), _stream()), "nefes_cosine_loss_fwd")
+        ctx.save_for_backward(af, bf, scratch)
+        ctx.shape = a.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        af, bf, scratch = ctx.saved_tensors
+        gf = _f32(g).reshape(1)
+        g_a = torch.empty_like(af)
+        L.check(L.load().nefes_cosine_loss_bwd(af.shape[0], af.shape[1], _chk(af, "a"), _chk(bf, "b"),
+                                               _chk(scratch, "scratch", torch.float64), _chk(gf, "g_loss"), _chk(g_a, "g_a"), _stream()),
+                "nefes_cosine_loss_bwd")
+        return g_a.reshape(ctx.shape), None
+
+
+def cosine_feature_loss(a, b):
+    return CosineFeatureLoss.apply(a, b)

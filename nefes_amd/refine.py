@@ -59,7 +59,8 @@ class PoseRefiner:
     move_all_cam_vec) or None.  `graph=True` replays one captured HIP graph per iteration."""
 
     def __init__(self, render_kwargs, args, hwf, near, far, tinyscale=4, lr_r=0.01, lr_t=0.1, lietorch=False,
-                 upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda", adam_capturable=None):
+                 upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda", adam_capturable=None,
+                 fused_glue=True):
         self.kw, self.args = dict(render_kwargs), args
         H, W, focal = hwf
         self.H, self.W = int(H), int(W)
@@ -70,27 +71,46 @@ class PoseRefiner:
         self.C = self.coarse.W_features
         self.dev = torch.device(device)
         self.model = LearnPose(1, True, True, init_c2w=torch.eye(4)[None].clone(), lietorch=lietorch).to(self.dev)
+        # fused_glue: the pose chain, the crop and the feature loss as library kernels (ops.pose_compose, the windowed
+        # ops.bicubic_upsample, ops.cosine_feature_loss) and one fused Adam launch -- ~80 launches per iteration instead of ~215.
+        # False keeps the torch expressions (the tests compare the two).
+        self.fused_glue = bool(fused_glue)
         self.opt = torch.optim.Adam([{"params": [self.model.r], "lr": lr_r}, {"params": [self.model.t], "lr": lr_t}],
-                                    capturable=bool(graph) if adam_capturable is None else bool(adam_capturable))
+                                    capturable=bool(graph) if adam_capturable is None else bool(adam_capturable),
+                                    fused=True if self.fused_glue else None)
         th, tw = (self.H - 20, self.W - 20) if upsample else (self.h, self.w)
         self.target = torch.zeros(self.C, th, tw, device=self.dev)
         self.hist = torch.zeros(1, 10, device=self.dev)
         self.loss = torch.zeros((), device=self.dev)
+        self._affine = None            # static [1,12] buffer with the image's colour transform when the exposure network is frozen
         self.use_graph, self.graph = bool(graph), None
 
     # one iteration on the static buffers -------------------------------------------------------------------------
     def _loss(self):
         """DFM_optimization_NFF (:310-337): pose -> render -> affine colour transform -> fusion CNN -> feature loss."""
-        c2w = self.model(0)[None, :3, :4]
-        if self.world_setup is not None:
-            c2w = fix_coord_supp(c2w, self.world_setup)
-        rgb, _, _, ex = render(self.h, self.w, self.focal, c2w=c2w[0], near=self.near, far=self.far, img_idx=self.hist,
-                               **self.kw)
+        if self.fused_glue and not self.model.lietorch:
+            ws = self.world_setup or {"pose_scale": 1.0, "pose_scale2": 1.0, "move_all_cam_vec": (0., 0., 0.)}
+            c2w = ops.pose_compose(self.model.r.view(3), self.model.t.view(3), self.model.init_c2w[0], ws["pose_scale"],
+                                   ws["move_all_cam_vec"], ws["pose_scale2"])
+        else:
+            c2w = self.model(0)[None, :3, :4]
+            if self.world_setup is not None:
+                c2w = fix_coord_supp(c2w, self.world_setup)
+            c2w = c2w[0]
+        rgb, _, _, ex = render(self.h, self.w, self.focal, c2w=c2w, near=self.near, far=self.far, img_idx=self.hist, **self.kw)
         if getattr(self.args, "encode_hist", False):
-            rgb = self.coarse.affine_color_transform(self.args, rgb, self.hist, 1)
+            if self._affine is not None:                   # frozen exposure network: its 12 numbers were computed once per image
+                rgb = self.coarse.apply_affine(self._affine, rgb, 1)
+            else:
+                rgb = self.coarse.affine_color_transform(self.args, rgb, self.hist, 1)
         _, _, fused = self.coarse.run_fusion_net(rgb, ex["feat_map"], self.h, self.w, 1)
         if self.upsample:
-            fused = ops.bicubic_upsample(fused, (self.H, self.W))[:, :, 10:-10, 10:-10]
+            if self.fused_glue:
+                fused = ops.bicubic_upsample(fused, (self.H, self.W), crop=10)
+            else:
+                fused = ops.bicubic_upsample(fused, (self.H, self.W))[:, :, 10:-10, 10:-10]
+        if self.fused_glue and not self.per_pixel:
+            return ops.cosine_feature_loss(fused[0], self.target)
         return feature_loss(fused[0], self.target, per_pixel=self.per_pixel)
 
     def loss_and_grad(self):
@@ -116,6 +136,14 @@ class PoseRefiner:
             self.model.init_c2w.copy_(init_c2w.reshape(1, 4, 4))
             self.target.copy_(feature_target.reshape(self.target.shape))
             self.hist.copy_(hist.reshape(1, 10))
+            expo = getattr(self.coarse, "exposure_embedding", None)
+            if (self.fused_glue and getattr(self.args, "encode_hist", False) and expo is not None
+                    and not any(p.requires_grad for p in expo.parameters())):
+                a = self.coarse.exposure_coefficients(self.hist)
+                if self._affine is None:
+                    self._affine = a.clone()
+                else:
+                    self._affine.copy_(a)                  # in place: a captured graph keeps reading the same buffer
             for st in self.opt.state.values():
                 for v in st.values():
                     if torch.is_tensor(v):

@@ -189,6 +189,8 @@ def _render_batch(rays_o, rays_d, viewdirs, near, far, chunk, kwargs, cfg):
     network_fn, network_fine = kwargs["network_fn"], kwargs.get("network_fine", None)
     N = rays_o.shape[0]
     step = rays_per_launch(cfg, network_fn, network_fine, rays_o.device, train=not cfg.test_time)
+    if N <= step:       # the usual case: no slicing (a slice of a differentiable tensor costs a fill and a copy in its backward)
+        return _render_core(rays_o, rays_d, viewdirs, float(near), float(far), network_fn, network_fine, cfg)
     outs = []
     for i in range(0, N, step):
         sl = slice(i, min(N, i + step))

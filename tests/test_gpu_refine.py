@@ -10,7 +10,7 @@ import torch
 
 from oracle import refine_cpu as RC
 from tests import parity_log as P
-from tests.test_refine_oracle import problem, rel
+from tests.test_refine_oracle import problem, rel  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -105,3 +105,92 @@ def test_fusion_net_and_affine_transform_on_the_gpu(golden):
     e = rel(out.cpu().numpy(), a["rgb_out"])
     P.record("affine_color_transform_gpu", "rgb", e_hip=e, e_ref=None, direct=e, bound=1e-6)
     assert e < 1e-6
+
+
+# ---- the loop's glue as library kernels (csrc/refine.hip, csrc/upsample.hip) against the torch expressions they replace ----
+@pytest.mark.parametrize("r0", [(0., 0., 0.), (0.11, -0.07, 0.03), (1e-6, -2e-6, 5e-7), (1.2, 0.7, -2.1)])
+def test_pose_compose_matches_learnpose_and_fix_coord(r0):
+    """nefes_pose_compose_fwd/bwd == LearnPose.forward (poses.py:43-50) + fix_coord_supp (direct_pose_model.py:224-231) and
+    their autograd, evaluated by torch in float64 (the kernel computes in float64 and rounds once)."""
+    from nefes_amd import ops
+    from nefes_amd.pose import LearnPose
+    from nefes_amd.refine import fix_coord_supp
+    g = torch.Generator().manual_seed(3)
+    init = torch.eye(4, dtype=torch.float64)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    init[:3, :3], init[:3, 3] = q, torch.randn(3, generator=g, dtype=torch.float64)
+    ws = dict(pose_scale=0.8, pose_scale2=1.25, move_all_cam_vec=[0.1, -0.05, 0.2])
+    G = torch.randn(3, 4, generator=g, dtype=torch.float64)
+    m = LearnPose(1, True, True, init_c2w=init[None].clone()).double()
+    with torch.no_grad():
+        m.r.copy_(torch.tensor([r0], dtype=torch.float64))
+        m.t.copy_(torch.tensor([[0.3, -0.2, 0.1]], dtype=torch.float64))
+    ref = fix_coord_supp(m(0)[None, :3, :4], ws)[0]
+    (ref * G).sum().backward()
+    r = m.r.detach().float().reshape(3).to(DEV).requires_grad_()
+    t = m.t.detach().float().reshape(3).to(DEV).requires_grad_()
+    out = ops.pose_compose(r, t, init.float().to(DEV), ws["pose_scale"], ws["move_all_cam_vec"], ws["pose_scale2"])
+    (out * G.float().to(DEV)).sum().backward()
+    assert rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 3e-7
+    assert rel(r.grad.cpu().numpy(), m.r.grad[0].numpy()) < 1e-6 and rel(t.grad.cpu().numpy(), m.t.grad[0].numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("C,P", [(128, 220 * 300), (16, 12 * 16), (3, 1000)])
+def test_cosine_feature_loss_matches_torch(C, P):
+    """nefes_cosine_loss_fwd/bwd == feature_loss (DFM_pose_refine.py:211-233) in float64 torch, value and gradient; one channel is
+    all zeros (the eps clamp of CosineSimilarity)."""
+    from nefes_amd import ops
+    from nefes_amd.refine import feature_loss
+    g = torch.Generator().manual_seed(C)
+    a, b = torch.randn(C, P, generator=g), torch.randn(C, P, generator=g)
+    b = b + 0.7 * a                               # correlated, as rendered and target features are
+    a[0] = 0.
+    ad = a.double().requires_grad_()
+    ref = feature_loss(ad.reshape(C, 1, P), b.double().reshape(C, 1, P))
+    ref.backward()
+    ag = a.to(DEV).requires_grad_()
+    out = ops.cosine_feature_loss(ag.reshape(C, 1, P), b.to(DEV).reshape(C, 1, P))
+    (3.0 * out).backward()
+    assert abs(float(out.detach()) - float(ref.detach())) < 2e-7
+    assert rel(ag.grad.cpu().numpy() / 3.0, ad.grad.numpy()) < 1e-6
+
+
+def test_bicubic_upsample_window_equals_cropped_full_image():
+    """The windowed up-sampling (crop=10) == the full up-sampling sliced [10:-10, 10:-10], forward and backward."""
+    from nefes_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(1, 5, 15, 20, generator=g).to(DEV)
+    go = torch.randn(1, 5, 40, 60, generator=g).to(DEV)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya = ops.bicubic_upsample(xa, (60, 80), crop=10)
+    yb = ops.bicubic_upsample(xb, (60, 80))[:, :, 10:-10, 10:-10]
+    ya.backward(go)
+    yb.backward(go)
+    assert ya.shape == yb.shape == (1, 5, 40, 60) and torch.equal(ya, yb)
+    assert torch.allclose(xa.grad, xb.grad, rtol=0, atol=2e-6 * float(xb.grad.abs().max()))
+
+
+def test_fused_glue_iteration_equals_torch_glue(golden):
+    """One PoseRefiner iteration with the glue kernels == the same iteration with the torch expressions (APR variant: bicubic
+    up-sampling + 10 px crop; DFM variant without): loss and (r, t) gradient."""
+    g = golden("refine")
+    H, W, _ = g["hwf"].tolist()
+    for up in (False, True):
+        res = []
+        for fused in (True, False):
+            ref = refiner(g, graph=False)
+            ref.fused_glue, ref.upsample = fused, up
+            tgt = T(g["target"]).to(DEV)
+            if up:
+                from nefes_amd import ops
+                tgt = ops.bicubic_upsample(tgt[None], (int(H), int(W)), crop=10)[0]
+                ref.target = torch.zeros_like(tgt)
+            ref._reset(T(g["init_c2w"]).to(DEV), tgt, T(g["hist"]).to(DEV))
+            with torch.no_grad():
+                ref.model.r.copy_(T(g["r"][3]).reshape(1, 3))
+                ref.model.t.copy_(T(g["t"][3]).reshape(1, 3))
+            loss = float(ref.loss_and_grad())
+            res.append((loss, torch.cat([ref.model.r.grad[0], ref.model.t.grad[0]]).cpu().numpy()))
+        (la, ga), (lb, gb) = res
+        assert abs(la - lb) < 2e-4 * abs(lb) + 1e-7, (up, la, lb)
+        assert rel(ga, gb) < 2e-4, (up, ga, gb)

@@ -25,7 +25,7 @@ def test_exports_match_header():
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.nefes_version() == L.ABI_VERSION == 7
+    assert lib.nefes_version() == L.ABI_VERSION == 8
 
 
 def test_missing_library_is_loud(monkeypatch):

@@ -59,6 +59,52 @@ __global__ __launch_bounds__(256) void burn16(const _Float16* in, unsigned long 
     sink[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+
+// operands that CHANGE from MFMA to MFMA (four A/B register pairs in rotation), as in a real kernel
+__global__ __launch_bounds__(256) void burnR(const _Float16* in, unsigned long long* cyc, float* sink, int iters) {
+    f16x8 A[4], B[4];
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 8; ++i) { A[k][i] = in[(threadIdx.x * 8 + i + 512 * k) & 4095]; B[k][i] = in[(threadIdx.x * 8 + i + 2048 + 384 * k) & 4095]; }
+    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c0) : "v"(A[0]), "v"(B[m & 3]));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c1) : "v"(A[1]), "v"(B[(m + 1) & 3]));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c2) : "v"(A[2]), "v"(B[(m + 2) & 3]));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c3) : "v"(A[3]), "v"(B[(m + 3) & 3]));
+        }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3));
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    sink[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+__global__ __launch_bounds__(256) void burn16R(const _Float16* in, unsigned long long* cyc, float* sink, int iters) {
+    f16x8 A[4], B[4];
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 8; ++i) { A[k][i] = in[(threadIdx.x * 8 + i + 512 * k) & 4095]; B[k][i] = in[(threadIdx.x * 8 + i + 2048 + 384 * k) & 4095]; }
+    f32x4 c[8];
+    for (int i = 0; i < 8; ++i) c[i] = f32x4{0, 0, 0, 0};
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c[k]) : "v"(A[k & 3]), "v"(B[(k + m) & 3]));
+        }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(c[0]), "+a"(c[1]), "+a"(c[2]), "+a"(c[3]), "+a"(c[4]), "+a"(c[5]), "+a"(c[6]), "+a"(c[7]));
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += c[i][0];
+    sink[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <int GAP>
 static void run(const char* what, const _Float16* in, int iters) {
     int cus = 0;
@@ -67,9 +113,9 @@ static void run(const char* what, const _Float16* in, int iters) {
     (void)hipMalloc(&cyc, cus * 8); (void)hipMalloc(&sink, cus * 256 * 4);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    if (GAP < 0) burn16<<<cus, 256>>>(in, cyc, sink, iters / 8); else burn<(GAP < 0 ? 0 : GAP)><<<cus, 256>>>(in, cyc, sink, iters / 8);   // warm
+    if (GAP == -2) burnR<<<cus, 256>>>(in, cyc, sink, iters / 8); else if (GAP == -3) burn16R<<<cus, 256>>>(in, cyc, sink, iters / 8); else if (GAP < 0) burn16<<<cus, 256>>>(in, cyc, sink, iters / 8); else burn<(GAP < 0 ? 0 : GAP)><<<cus, 256>>>(in, cyc, sink, iters / 8);   // warm
     (void)hipEventRecord(e0);
-    if (GAP < 0) burn16<<<cus, 256>>>(in, cyc, sink, iters); else burn<(GAP < 0 ? 0 : GAP)><<<cus, 256>>>(in, cyc, sink, iters);
+    if (GAP == -2) burnR<<<cus, 256>>>(in, cyc, sink, iters); else if (GAP == -3) burn16R<<<cus, 256>>>(in, cyc, sink, iters); else if (GAP < 0) burn16<<<cus, 256>>>(in, cyc, sink, iters); else burn<(GAP < 0 ? 0 : GAP)><<<cus, 256>>>(in, cyc, sink, iters);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms = 0;
@@ -79,8 +125,8 @@ static void run(const char* what, const _Float16* in, int iters) {
     double mean = 0;
     for (int i = 0; i < cus; ++i) mean += (double)h[i];
     mean /= cus;
-    const double n_mfma = (double)iters * (GAP < 0 ? 64 : 32);
-    const double flops = n_mfma * 2.0 * (GAP < 0 ? 16 * 16 * 32 : 32 * 32 * 16) * 4 * cus;       // per wave x 4 waves x CUs
+    const double n_mfma = (double)iters * ((GAP == -1 || GAP == -3) ? 64 : 32);
+    const double flops = n_mfma * 2.0 * ((GAP == -1 || GAP == -3) ? 16 * 16 * 32 : 32 * 32 * 16) * 4 * cus;       // per wave x 4 waves x CUs
     printf("%-34s %6.1f ms  %5.1f cycles/MFMA  clock %.2f GHz  %7.1f TFLOP/s fp16 dense\n", what, ms, mean / n_mfma, mean / ms / 1e6,
            flops / ms / 1e9);
     free(h); (void)hipFree(cyc); (void)hipFree(sink);
@@ -101,6 +147,8 @@ int main() {
     run<4>("MFMA + 4 v_fma_f32, random", dr, iters);
     run<-1>("16x16x32 MFMA only, zero operands", dz, iters);
     run<-1>("16x16x32 MFMA only, random operands", dr, iters);
+    run<-2>("32x32x16, random ROTATING operands", dr, iters);
+    run<-3>("16x16x32, random ROTATING operands", dr, iters);
     run<0>("MFMA only, random operands, 4x longer", dr, iters * 4);
     return 0;
 }
