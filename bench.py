@@ -97,7 +97,7 @@ def cpu_baseline(Wd, C, Nc, Ni, n_rows, W, focal):
                       f"8x{Wd} MLP, C={C}, torch {torch.__version__} CPU, {dt:.1f} s"}
 
 
-def refinement_loop(dev, iters=50, graph=True):
+def refinement_loop(dev, iters=50, graph=True, images=1):
     """BASELINE configs[4] without the DFNet CNN (out of scope): per query image `iters` iterations of
     LearnPose -> render(80x60) -> affine colour transform -> FusionNet -> bicubic upsample + crop -> cosine feature loss
     against a fixed target -> backward -> Adam  (script/dm/DFM_APR_refine.py:84-156, DFM_pose_refine.py:290-348),
@@ -118,7 +118,10 @@ def refinement_loop(dev, iters=50, graph=True):
     init[:3, :4] = bench_pose().to(dev)
     hist = torch.full((1, 10), 10., device=dev)
     target = torch.nn.functional.normalize(torch.randn(C, 4 * H - 20, 4 * W - 20, device=dev), dim=0)
-    ref = PoseRefiner(kw, args, (4 * H, 4 * W, 4 * focal), 0., 4., tinyscale=4, upsample=True, graph=graph, device=dev)
+    if images > 1:        # `images` query images refined side by side (PoseRefiner(images=B)); time is reported per image
+        init, hist, target = init[None].repeat(images, 1, 1), hist.repeat(images, 1), target[None].repeat(images, 1, 1, 1)
+    ref = PoseRefiner(kw, args, (4 * H, 4 * W, 4 * focal), 0., 4., tinyscale=4, upsample=True, graph=graph, device=dev,
+                      images=images)
     ref.refine(init, target, hist, iters)                      # packs weights, warms MIOpen, captures the graph
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -126,7 +129,7 @@ def refinement_loop(dev, iters=50, graph=True):
     for _ in range(n_img):
         ref.refine(init, target, hist, iters)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n_img, iters * H * W
+    return (time.perf_counter() - t0) / n_img / images, iters * H * W
 
 
 def train_steps(dev, steps=10, warmup=2):
@@ -267,11 +270,13 @@ def main():
     if a.workload == "loop50":
         sec_e, rays = refinement_loop(dev, graph=False)
         sec, rays = refinement_loop(dev, graph=True)
+        sec_b, _ = refinement_loop(dev, graph=True, images=8)
         print(json.dumps({"metric": "rays/s (fwd+bwd), secondary workload 'loop50'", "value": rays / sec, "unit": "rays/s",
                           "n_gpus": 1, "higher_is_better": True,
                           "dtype": "bf16x3 (16-bit operands, opt-in reduced precision)" if ops.X6_PRODUCTS == 3 and ops.USE_X6 else "f32",
                           "data": "synthetic", "vs_baseline": None,
                           "ms_per_image_50_iterations": sec * 1e3, "ms_per_image_50_iterations_eager": sec_e * 1e3,
+                          "ms_per_image_50_iterations_8_images_side_by_side": sec_b * 1e3,
                           "config": {"workload": "BASELINE configs[4] minus the DFNet CNN: 50 x [LearnPose -> render 80x60 "
                                                  "(64+64, 8x128, C=128) -> affine colour -> FusionNet -> bicubic x4 -> cosine "
                                                  "feature loss -> backward -> Adam]"}}), flush=True)

@@ -269,11 +269,11 @@ int nefes_bicubic_up_bwd(int64_t planes, int h, int w, int OH, int OW, int oy0, 
 /* ---- the per-image refinement loop's glue (script/dm/DFM_pose_refine.py:290-348) ---- */
 /* LearnPose.forward (script/models/poses.py:43-50, lietorch=False: utils/lie_group_helper.py:60-81) + fix_coord_supp
  * (script/dm/direct_pose_model.py:224-231): c2w [3,4] = [Exp(r) R0 | ((t + t0) sc + move) sc2].
- * r, t: dev [3]; init_c2w: dev [4,4] row-major; move: HOST [3]; c2w: dev [12]. */
-int nefes_pose_compose_fwd(const float* r, const float* t, const float* init_c2w, float pose_scale, const float* move,
+ * n_poses cameras at once: r, t: dev [n,3]; init_c2w: dev [n,4,4] row-major; move: HOST [3]; c2w: dev [n,3,4]. */
+int nefes_pose_compose_fwd(int n_poses, const float* r, const float* t, const float* init_c2w, float pose_scale, const float* move,
                            float pose_scale2, float* c2w, void* stream);
-/* g_c2w dev [12] -> g_r, g_t dev [3] (analytic derivative of the Rodrigues formula, float64 inside). */
-int nefes_pose_compose_bwd(const float* r, const float* t, const float* init_c2w, float pose_scale, const float* move,
+/* g_c2w dev [n,3,4] -> g_r, g_t dev [n,3] (analytic derivative of the Rodrigues formula, float64 inside). */
+int nefes_pose_compose_bwd(int n_poses, const float* r, const float* t, const float* init_c2w, float pose_scale, const float* move,
                            float pose_scale2, const float* g_c2w, float* g_r, float* g_t, void* stream);
 /* feature_loss (DFM_pose_refine.py:211-233, per_pixel=False): loss = 1 - mean_c cos(a[c,:], b[c,:]), a, b dev [C,P] contiguous,
  * torch.nn.CosineSimilarity(dim=1, eps=1e-6) semantics, float64 accumulation.  scratch: dev doubles,

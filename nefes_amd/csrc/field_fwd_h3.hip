@@ -342,19 +342,7 @@ static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
 enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_128_SIGMA, H3_128_FULL };
 int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st);
 
-#if NEFES_TU_PART == 1
-int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st) {
-    switch (which) {
-        case H3_EXT_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32>(a, st);
-        case H3_EXT_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32>(a, st);
-        case H3_128_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5>(a, st);
-        case H3_128_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5>(a, st);
-    }
-    return NEFES_E_UNSUPPORTED;
-}
-#else   // part 0
-
-#ifdef H3_STAMP
+#if defined(H3_STAMP) && defined(H3_STAMP_READER)   // exactly one translation unit of a diagnostic build (tools/stamp_h3.sh)
 extern "C" int nefes_debug_h3_stamps(unsigned long long* out3) {
     unsigned long long v[4] = {0, 0, 0, 0};
     hipDeviceSynchronize();
@@ -369,6 +357,19 @@ extern "C" int nefes_debug_h3_stamps(unsigned long long* out3) {
     return 0;
 }
 #endif
+
+#if NEFES_TU_PART == 1
+int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st) {
+    switch (which) {
+        case H3_EXT_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32>(a, st);
+        case H3_EXT_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32>(a, st);
+        case H3_128_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5>(a, st);
+        case H3_128_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5>(a, st);
+    }
+    return NEFES_E_UNSUPPORTED;
+}
+#else   // part 0
+
 
 extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                                   const float* rays_d, const float* z, const float* pts, const float* xyz_enc,

@@ -64,7 +64,8 @@ __device__ void rodrigues(const double r[3], double R[3][3], double dR[3][3][3])
 }
 
 __global__ void pose_compose_fwd_kernel(PoseArgs p, float* __restrict__ c2w) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    p.r += 3 * blockIdx.x; p.t += 3 * blockIdx.x; p.init += 16 * blockIdx.x; c2w += 12 * blockIdx.x;      // one pose per block
     const double r[3] = {p.r[0], p.r[1], p.r[2]};
     double R[3][3];
     rodrigues(r, R, nullptr);
@@ -83,7 +84,9 @@ __global__ void pose_compose_fwd_kernel(PoseArgs p, float* __restrict__ c2w) {
 }
 
 __global__ void pose_compose_bwd_kernel(PoseArgs p, const float* __restrict__ g, float* __restrict__ g_r, float* __restrict__ g_t) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    p.r += 3 * blockIdx.x; p.t += 3 * blockIdx.x; p.init += 16 * blockIdx.x;
+    g += 12 * blockIdx.x; g_r += 3 * blockIdx.x; g_t += 3 * blockIdx.x;
     const double r[3] = {p.r[0], p.r[1], p.r[2]};
     double R[3][3], dR[3][3][3];
     rodrigues(r, R, dR);
@@ -179,19 +182,19 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(int C, long P, double e
 
 }  // namespace
 
-extern "C" int nefes_pose_compose_fwd(const float* r, const float* t, const float* init_c2w, float pose_scale, const float* move,
-                                      float pose_scale2, float* c2w, void* stream) {
-    if (!r || !t || !init_c2w || !move || !c2w) return NEFES_E_BADARG;
+extern "C" int nefes_pose_compose_fwd(int n_poses, const float* r, const float* t, const float* init_c2w, float pose_scale,
+                                      const float* move, float pose_scale2, float* c2w, void* stream) {
+    if (n_poses <= 0 || !r || !t || !init_c2w || !move || !c2w) return NEFES_E_BADARG;
     PoseArgs p{r, t, init_c2w, pose_scale, pose_scale2, {move[0], move[1], move[2]}};
-    hipLaunchKernelGGL(pose_compose_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, c2w);
+    hipLaunchKernelGGL(pose_compose_fwd_kernel, dim3(n_poses), dim3(64), 0, (hipStream_t)stream, p, c2w);
     return (int)hipGetLastError();
 }
 
-extern "C" int nefes_pose_compose_bwd(const float* r, const float* t, const float* init_c2w, float pose_scale, const float* move,
-                                      float pose_scale2, const float* g_c2w, float* g_r, float* g_t, void* stream) {
-    if (!r || !t || !init_c2w || !move || !g_c2w || !g_r || !g_t) return NEFES_E_BADARG;
+extern "C" int nefes_pose_compose_bwd(int n_poses, const float* r, const float* t, const float* init_c2w, float pose_scale,
+                                      const float* move, float pose_scale2, const float* g_c2w, float* g_r, float* g_t, void* stream) {
+    if (n_poses <= 0 || !r || !t || !init_c2w || !move || !g_c2w || !g_r || !g_t) return NEFES_E_BADARG;
     PoseArgs p{r, t, init_c2w, pose_scale, pose_scale2, {move[0], move[1], move[2]}};
-    hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, g_c2w, g_r, g_t);
+    hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3(n_poses), dim3(64), 0, (hipStream_t)stream, p, g_c2w, g_r, g_t);
     return (int)hipGetLastError();
 }
 

@@ -49,12 +49,20 @@ class FusionNet(nn.Module):
         out = self.net(x)
         return x[:, 3:] + out if self.fusion_residule else out
 
-    def forward_parts(self, rgb_nchw, feat_nchw):
+    def forward_parts(self, rgb_nchw, feat_nchw, per_image_norm=False):
         """forward(cat([rgb, feat], 1)) without the in-place slice assignment (whose autograd costs a fill and two copies):
-        the colour channels are normalised before the concatenation -- same values, same order of operations."""
+        the colour channels are normalised before the concatenation -- same values, same order of operations.
+        per_image_norm: B independent images in one batch (PoseRefiner(images=B)).  The reference runs this net on one image at
+        a time with BatchNorm in train mode, i.e. normalised by that image's own statistics; for a batch the same arithmetic is
+        an instance norm with the BatchNorm's affine parameters (the running statistics, which train mode never reads, are
+        not updated on this path)."""
         mean, std = self._mean_std(rgb_nchw)
         x = torch.cat([(rgb_nchw - mean[:, None, None]) / std[:, None, None], feat_nchw], dim=1)
-        out = self.net(x)
+        if per_image_norm and not self.no_BN and x.shape[0] > 1:
+            bn = self.net[-1]
+            out = nn.functional.instance_norm(self.net[:-1](x), weight=bn.weight, bias=bn.bias, eps=bn.eps)
+        else:
+            out = self.net(x)
         return feat_nchw + out if self.fusion_residule else out
 
 
@@ -187,10 +195,10 @@ class NeRFH_NFF(nn.Module):
         return torch.cat([static, self.transient_rgb(t), self.transient_sigma(t), self.transient_beta(t)], 1)
 
     # -- post-render helpers used by the refinement loop (nerfh_nff.py:578-626) ----------------------
-    def run_fusion_net(self, rgb, feature, H, W, B):
+    def run_fusion_net(self, rgb, feature, H, W, B, per_image_norm=False):
         render_rgb = rgb.reshape(B, H, W, 3).permute(0, 3, 1, 2)
         render_feature = feature.reshape(B, H, W, self.W_features).permute(0, 3, 1, 2)
-        fused = self.fusion_net.forward_parts(render_rgb, render_feature)
+        fused = self.fusion_net.forward_parts(render_rgb, render_feature, per_image_norm)
         return render_rgb, render_feature, fused
 
     def exposure_coefficients(self, hist):

@@ -84,8 +84,8 @@ SIGNATURES = {
     "nefes_train_dw": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p]),
     "nefes_bicubic_up_fwd": (_i, [C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "nefes_bicubic_up_bwd": (_i, [C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
-    "nefes_pose_compose_fwd": (_i, [_p, _p, _p, C.c_float, C.POINTER(C.c_float), C.c_float, _p, _p]),
-    "nefes_pose_compose_bwd": (_i, [_p, _p, _p, C.c_float, C.POINTER(C.c_float), C.c_float, _p, _p, _p, _p]),
+    "nefes_pose_compose_fwd": (_i, [_i, _p, _p, _p, C.c_float, C.POINTER(C.c_float), C.c_float, _p, _p]),
+    "nefes_pose_compose_bwd": (_i, [_i, _p, _p, _p, C.c_float, C.POINTER(C.c_float), C.c_float, _p, _p, _p, _p]),
     "nefes_cosine_loss_scratch_doubles": (_sz, [_i]),
     "nefes_cosine_loss_fwd": (_i, [_i, C.c_int64, _p, _p, _p, _p, _p]),
     "nefes_cosine_loss_bwd": (_i, [_i, C.c_int64, _p, _p, _p, _p, _p, _p]),

@@ -632,32 +632,38 @@ def bicubic_upsample(x, size, crop=0):
 
 class PoseCompose(torch.autograd.Function):
     """LearnPose.forward (models/poses.py:43-50, lietorch=False) + fix_coord_supp (dm/direct_pose_model.py:224-231) in one
-    launch each way: (r [3], t [3]) -> c2w [3,4] in NeRF coordinates.  `init_c2w` [4,4] on the device, no gradient."""
+    launch each way: (r [n,3], t [n,3]) -> c2w [n,3,4] in NeRF coordinates.  `init_c2w` [n,4,4] on the device, no gradient."""
 
     @staticmethod
     def forward(ctx, r, t, init_c2w, pose_scale, move, pose_scale2):
-        rf, tf, i0 = _f32(r), _f32(t), _f32(init_c2w)
+        rf, tf, i0 = _f32(r).reshape(-1, 3), _f32(t).reshape(-1, 3), _f32(init_c2w).reshape(-1, 4, 4)
+        n = rf.shape[0]
+        if tf.shape[0] != n or i0.shape[0] != n:
+            raise ValueError("nefes_amd: pose_compose needs as many translations and initial poses as rotations")
         mv = (C.c_float * 3)(*[float(v) for v in move])
-        out = torch.empty(3, 4, device=rf.device)
-        L.check(L.load().nefes_pose_compose_fwd(_chk(rf, "r"), _chk(tf, "t"), _chk(i0, "init_c2w"), float(pose_scale), mv,
+        out = torch.empty(n, 3, 4, device=rf.device)
+        L.check(L.load().nefes_pose_compose_fwd(n, _chk(rf, "r"), _chk(tf, "t"), _chk(i0, "init_c2w"), float(pose_scale), mv,
                                                 float(pose_scale2), _chk(out, "c2w"), _stream()), "nefes_pose_compose_fwd")
         ctx.save_for_backward(rf, tf, i0)
-        ctx.consts = (float(pose_scale), mv, float(pose_scale2))
+        ctx.consts = (float(pose_scale), mv, float(pose_scale2), r.shape, t.shape)
         return out
 
     @staticmethod
     def backward(ctx, g):
         rf, tf, i0 = ctx.saved_tensors
-        sc, mv, sc2 = ctx.consts
+        sc, mv, sc2, r_shape, t_shape = ctx.consts
         gf = _f32(g)
-        g_r, g_t = torch.empty(3, device=gf.device), torch.empty(3, device=gf.device)
-        L.check(L.load().nefes_pose_compose_bwd(_chk(rf, "r"), _chk(tf, "t"), _chk(i0, "init_c2w"), sc, mv, sc2, _chk(gf, "g_c2w"),
-                                                _chk(g_r, "g_r"), _chk(g_t, "g_t"), _stream()), "nefes_pose_compose_bwd")
-        return g_r, g_t, None, None, None, None
+        g_r, g_t = torch.empty_like(rf), torch.empty_like(tf)
+        L.check(L.load().nefes_pose_compose_bwd(rf.shape[0], _chk(rf, "r"), _chk(tf, "t"), _chk(i0, "init_c2w"), sc, mv, sc2,
+                                                _chk(gf, "g_c2w"), _chk(g_r, "g_r"), _chk(g_t, "g_t"), _stream()),
+                "nefes_pose_compose_bwd")
+        return g_r.reshape(r_shape), g_t.reshape(t_shape), None, None, None, None
 
 
 def pose_compose(r, t, init_c2w, pose_scale=1.0, move=(0., 0., 0.), pose_scale2=1.0):
-    return PoseCompose.apply(r, t, init_c2w, pose_scale, move, pose_scale2)
+    """[n,3,4] for n cameras; [3,4] when r is a single 3-vector."""
+    out = PoseCompose.apply(r, t, init_c2w, pose_scale, move, pose_scale2)
+    return out[0] if r.dim() == 1 else out
 
 
 class CosineFeatureLoss(torch.autograd.Function):
@@ -677,10 +683,12 @@ class CosineFeatureLoss(torch.autograd.Function):
                                           _chk(loss, "loss"), _stream()), "nefes_cosine_loss_fwd")
         ctx.save_for_backward(af, bf, scratch)
         ctx.shape = a.shape
-        return loss
+        cos = scratch[:4 * Cc].view(Cc, 4)[:, 3]          # float64 cosine similarity per channel (a view of the scratch)
+        ctx.mark_non_differentiable(cos)
+        return loss, cos
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_cos):
         af, bf, scratch = ctx.saved_tensors
         gf = _f32(g).reshape(1)
         g_a = torch.empty_like(af)
@@ -690,5 +698,8 @@ class CosineFeatureLoss(torch.autograd.Function):
         return g_a.reshape(ctx.shape), None
 
 
-def cosine_feature_loss(a, b):
-    return CosineFeatureLoss.apply(a, b)
+def cosine_feature_loss(a, b, return_cos=False):
+    """1 - mean over the leading (channel) dimension of the cosine similarity over everything else; `return_cos` adds the
+    per-channel similarities (float64, no gradient) -- per-image losses of a batch folded into the channel dimension."""
+    loss, cos = CosineFeatureLoss.apply(a, b)
+    return (loss, cos) if return_cos else loss

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import ops
 from .pose import LearnPose
-from .render import render
+from .render import render, render_poses
 
 
 def fix_coord_supp(pose, world_setup_dict, device=None):
@@ -51,7 +51,8 @@ class FeatureLoss(nn.Module):
 
 
 class PoseRefiner:
-    """One query image at a time: `refine(init_c2w, feature_target, hist, iters)` -> (refined 4x4 c2w, losses [iters]).
+    """`refine(init_c2w, feature_target, hist, iters)` -> (refined 4x4 c2w, losses [iters]) for one query image, or for
+    `images=B` of them side by side (see refine()).
 
     hwf: full-resolution (H, W, focal); the render runs at 1/tinyscale.  `upsample=True` is the APR variant (bicubic
     upsample of the fused features to (H, W) and a 10-pixel crop; `feature_target` is [C, H, W]); False is the
@@ -60,7 +61,7 @@ class PoseRefiner:
 
     def __init__(self, render_kwargs, args, hwf, near, far, tinyscale=4, lr_r=0.01, lr_t=0.1, lietorch=False,
                  upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda", adam_capturable=None,
-                 fused_glue=True):
+                 fused_glue=True, images=1):
         self.kw, self.args = dict(render_kwargs), args
         H, W, focal = hwf
         self.H, self.W = int(H), int(W)
@@ -70,7 +71,15 @@ class PoseRefiner:
         self.coarse = self.kw["network_fn"]
         self.C = self.coarse.W_features
         self.dev = torch.device(device)
-        self.model = LearnPose(1, True, True, init_c2w=torch.eye(4)[None].clone(), lietorch=lietorch).to(self.dev)
+        # images = B > 1: B query images refined side by side in ONE launch sequence per iteration (render_poses, a batched
+        # FusionNet with per-image normalisation, per-image losses summed).  Every image's loss depends on its own six numbers
+        # only and Adam is element-wise, so each image walks the trajectory it would walk alone; what is shared is the launch
+        # overhead and the GPU (an 80x60 frame is 19 sample tiles per CU).  The reference refines one image at a time.
+        self.B = int(images)
+        if self.B > 1 and (not fused_glue or lietorch or per_pixel):
+            raise NotImplementedError("nefes_amd: batched refinement runs on the fused glue kernels (fused_glue=True, "
+                                      "lietorch=False, per_pixel=False)")
+        self.model = LearnPose(self.B, True, True, init_c2w=torch.eye(4)[None].repeat(self.B, 1, 1), lietorch=lietorch).to(self.dev)
         # fused_glue: the pose chain, the crop and the feature loss as library kernels (ops.pose_compose, the windowed
         # ops.bicubic_upsample, ops.cosine_feature_loss) and one fused Adam launch -- ~80 launches per iteration instead of ~215.
         # False keeps the torch expressions (the tests compare the two).
@@ -79,50 +88,62 @@ class PoseRefiner:
                                     capturable=bool(graph) if adam_capturable is None else bool(adam_capturable),
                                     fused=True if self.fused_glue else None)
         th, tw = (self.H - 20, self.W - 20) if upsample else (self.h, self.w)
-        self.target = torch.zeros(self.C, th, tw, device=self.dev)
-        self.hist = torch.zeros(1, 10, device=self.dev)
-        self.loss = torch.zeros((), device=self.dev)
+        self.target = torch.zeros(self.C, th, tw, device=self.dev) if self.B == 1 else torch.zeros(self.B, self.C, th, tw, device=self.dev)
+        self.hist = torch.zeros(self.B, 10, device=self.dev)
+        self.loss = torch.zeros((), device=self.dev) if self.B == 1 else torch.zeros(self.B, device=self.dev)
         self._affine = None            # static [1,12] buffer with the image's colour transform when the exposure network is frozen
         self.use_graph, self.graph = bool(graph), None
 
     # one iteration on the static buffers -------------------------------------------------------------------------
     def _loss(self):
-        """DFM_optimization_NFF (:310-337): pose -> render -> affine colour transform -> fusion CNN -> feature loss."""
+        """DFM_optimization_NFF (:310-337): pose -> render -> affine colour transform -> fusion CNN -> feature loss.
+        Returns (scalar to differentiate, per-image losses [B] or the same scalar)."""
+        B = self.B
         if self.fused_glue and not self.model.lietorch:
             ws = self.world_setup or {"pose_scale": 1.0, "pose_scale2": 1.0, "move_all_cam_vec": (0., 0., 0.)}
-            c2w = ops.pose_compose(self.model.r.view(3), self.model.t.view(3), self.model.init_c2w[0], ws["pose_scale"],
-                                   ws["move_all_cam_vec"], ws["pose_scale2"])
+            c2w = ops.pose_compose(self.model.r, self.model.t, self.model.init_c2w, ws["pose_scale"], ws["move_all_cam_vec"],
+                                   ws["pose_scale2"])                                     # [B,3,4]
         else:
             c2w = self.model(0)[None, :3, :4]
             if self.world_setup is not None:
                 c2w = fix_coord_supp(c2w, self.world_setup)
-            c2w = c2w[0]
-        rgb, _, _, ex = render(self.h, self.w, self.focal, c2w=c2w, near=self.near, far=self.far, img_idx=self.hist, **self.kw)
+        if B == 1:
+            rgb, _, _, ex = render(self.h, self.w, self.focal, c2w=c2w[0], near=self.near, far=self.far, img_idx=self.hist, **self.kw)
+            feat = ex["feat_map"]
+        else:
+            rgb, _, _, ex = render_poses(self.h, self.w, self.focal, c2w, near=self.near, far=self.far, **self.kw)
+            rgb, feat = rgb.reshape(-1, 3), ex["feat_map"].reshape(-1, self.C)
         if getattr(self.args, "encode_hist", False):
             if self._affine is not None:                   # frozen exposure network: its 12 numbers were computed once per image
-                rgb = self.coarse.apply_affine(self._affine, rgb, 1)
+                rgb = self.coarse.apply_affine(self._affine, rgb, B)
             else:
-                rgb = self.coarse.affine_color_transform(self.args, rgb, self.hist, 1)
-        _, _, fused = self.coarse.run_fusion_net(rgb, ex["feat_map"], self.h, self.w, 1)
+                rgb = self.coarse.affine_color_transform(self.args, rgb, self.hist, B)
+        _, _, fused = self.coarse.run_fusion_net(rgb, feat, self.h, self.w, B, per_image_norm=B > 1)
         if self.upsample:
             if self.fused_glue:
                 fused = ops.bicubic_upsample(fused, (self.H, self.W), crop=10)
             else:
                 fused = ops.bicubic_upsample(fused, (self.H, self.W))[:, :, 10:-10, 10:-10]
+        if B > 1:
+            # sum over images of (1 - mean_c cos) = B x (1 - mean over all B*C channels): one launch pair for the whole batch
+            mean_loss, cos = ops.cosine_feature_loss(fused.reshape(B * self.C, -1), self.target.reshape(B * self.C, -1), return_cos=True)
+            return mean_loss * float(B), (1.0 - cos.view(B, self.C).mean(1)).float()
         if self.fused_glue and not self.per_pixel:
-            return ops.cosine_feature_loss(fused[0], self.target)
-        return feature_loss(fused[0], self.target, per_pixel=self.per_pixel)
+            loss = ops.cosine_feature_loss(fused[0], self.target)
+        else:
+            loss = feature_loss(fused[0], self.target, per_pixel=self.per_pixel)
+        return loss, loss.detach()
 
     def loss_and_grad(self):
         """Loss at the current (r, t) and its gradient, written into the parameters' static .grad buffers (no optimizer step).
         The gradients are copied over the previous ones: nothing has to be zeroed between iterations."""
-        loss = self._loss()
+        loss, per_image = self._loss()
         gr, gt = torch.autograd.grad(loss, [self.model.r, self.model.t])
         for p, g in ((self.model.r, gr), (self.model.t, gt)):
             if p.grad is None:
                 p.grad = torch.empty_like(p)
             p.grad.copy_(g)
-        self.loss.copy_(loss.detach())
+        self.loss.copy_(per_image)
         return self.loss
 
     def _iteration(self):
@@ -133,9 +154,9 @@ class PoseRefiner:
         with torch.no_grad():
             self.model.r.zero_()
             self.model.t.zero_()
-            self.model.init_c2w.copy_(init_c2w.reshape(1, 4, 4))
+            self.model.init_c2w.copy_(init_c2w.reshape(self.B, 4, 4))
             self.target.copy_(feature_target.reshape(self.target.shape))
-            self.hist.copy_(hist.reshape(1, 10))
+            self.hist.copy_(hist.reshape(self.B, 10))
             expo = getattr(self.coarse, "exposure_embedding", None)
             if (self.fused_glue and getattr(self.args, "encode_hist", False) and expo is not None
                     and not any(p.requires_grad for p in expo.parameters())):
@@ -167,12 +188,14 @@ class PoseRefiner:
         self.graph = g
 
     def refine(self, init_c2w, feature_target, hist, iters=50):
+        """One image (images=1): (refined 4x4 c2w, losses [iters]).  A batch (images=B): init_c2w [B,4,4], feature_target
+        [B,C,h,w], hist [B,10] -> (refined poses [B,4,4], losses [iters,B]), each image as if refined alone."""
         init_c2w, feature_target, hist = init_c2w.to(self.dev), feature_target.to(self.dev), hist.to(self.dev)
         self._reset(init_c2w, feature_target, hist)
         if self.use_graph and self.graph is None:
             self._capture()
             self._reset(init_c2w, feature_target, hist)
-        losses = torch.empty(iters, device=self.dev)
+        losses = torch.empty((iters,) + tuple(self.loss.shape), device=self.dev)
         for i in range(iters):
             if self.use_graph:
                 self.graph.replay()
@@ -180,4 +203,8 @@ class PoseRefiner:
                 self._iteration()
             losses[i] = self.loss
         with torch.no_grad():
-            return self.model(0).detach().clone(), losses
+            if self.B == 1:
+                return self.model(0).detach().clone(), losses
+            return self.model(torch.arange(self.B, device=self.dev)).detach().clone(), losses
+
+    refine_batch = refine

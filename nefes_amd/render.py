@@ -231,7 +231,8 @@ def render_poses(H, W, focal, poses, chunk=1024 * 32, ndc=True, near=0., far=1.,
     cfg = _cfg(kwargs)
     H, W = int(H), int(W)
     B = poses.shape[0]
-    parts = [_rays_for(H, W, focal, poses[b, :3, :4], None, None) for b in range(B)]
+    p34 = poses if tuple(poses.shape[-2:]) == (3, 4) else poses[:, :3, :4]
+    parts = [_rays_for(H, W, focal, c, None, None) for c in p34.unbind(0)]      # unbind: one stack in the backward, no fills
     rays_o, rays_d, viewdirs = (torch.cat([p[k] for p in parts], 0) for k in range(3))
     if ndc:
         rays_o, rays_d = ops.NdcRays.apply(rays_o, rays_d, H, W, float(focal), 1.)

@@ -194,3 +194,38 @@ def test_fused_glue_iteration_equals_torch_glue(golden):
         (la, ga), (lb, gb) = res
         assert abs(la - lb) < 2e-4 * abs(lb) + 1e-7, (up, la, lb)
         assert rel(ga, gb) < 2e-4, (up, ga, gb)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_batched_refinement_equals_one_image_at_a_time(golden, graph):
+    """PoseRefiner(images=3): three query images (different initial poses, targets, histograms) refined side by side walk the
+    trajectories they walk alone -- the batch shares launches, not arithmetic (per-image FusionNet normalisation, per-image
+    losses, element-wise Adam).  The batched convolutions may take another MIOpen solver than the single-image ones, so the two
+    runs are two fp32 roundings of the loop: equal to 2e-5 after two iterations, then drifting as any two do (test_refine_oracle.py:
+    x100 per iteration in the translation) -- bounded at 2e-3 after four."""
+    g = golden("refine")
+    B, n = 3, 4
+    gen = torch.Generator().manual_seed(11)
+    inits = T(g["init_c2w"])[None].repeat(B, 1, 1).clone()
+    inits[1, :3, 3] += torch.tensor([0.05, -0.02, 0.03])
+    inits[2, :3, 3] += torch.tensor([-0.04, 0.06, -0.01])
+    targets = T(g["target"])[None].repeat(B, 1, 1, 1).clone()
+    targets[1] += 0.05 * torch.randn(targets[1].shape, generator=gen)
+    targets[2] += 0.10 * torch.randn(targets[2].shape, generator=gen)
+    hists = torch.stack([T(g["hist"])[0], T(g["hist"])[0].flip(0), torch.full((10,), 10.)])
+    single = refiner(g, graph=graph)
+    alone = [single.refine(inits[b], targets[b], hists[b][None], n) for b in range(B)]
+    from nefes_amd.refine import PoseRefiner
+    batch = PoseRefiner(single.kw, single.args, (single.H, single.W, single.focal * (single.H // single.h)), single.near, single.far,
+                        tinyscale=single.H // single.h, lr_r=float(g["lr"][0]), lr_t=float(g["lr"][1]), world_setup=single.world_setup,
+                        graph=graph, device=DEV, images=B)
+    poses, losses = batch.refine(inits, targets, hists, n)
+    assert poses.shape == (B, 4, 4) and losses.shape == (n, B)
+    for b in range(B):
+        p1, l1 = alone[b]
+        assert rel(losses[:, b].cpu().numpy(), l1.cpu().numpy()) < 2e-4, (b, losses[:, b], l1)
+        assert float((poses[b] - p1).abs().max()) < 2e-3, (b, (poses[b] - p1).abs().max())
+    poses2, _ = batch.refine(inits, targets, hists, 2)                  # re-uses the captured graph
+    for b in range(B):
+        p1, _ = single.refine(inits[b], targets[b], hists[b][None], 2)
+        assert float((poses2[b] - p1).abs().max()) < 2e-5, (b, (poses2[b] - p1).abs().max())

@@ -4,13 +4,15 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd); CS=$ROOT/nefes_amd/csrc; OUT=$ROOT/nefes_amd/abl
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-gpu-rdc -Wno-unused-function -Wno-unused-variable -mllvm -pragma-unroll-threshold=65536 -DH3_STAMP"
-VARIANTS="base: mfmaonly:-DH3_ABL_NOSPLIT,-DH3_ABL_NOSTORE,-DH3_ABL_NOLOAD,-DH3_ABL_NOAREAD,-DH3_ABL_NOBIAS"
+VARIANTS="base: nosplit:-DH3_ABL_NOSPLIT mfmaonly:-DH3_ABL_NOSPLIT,-DH3_ABL_NOSTORE,-DH3_ABL_NOLOAD,-DH3_ABL_NOAREAD,-DH3_ABL_NOBIAS"
 if [ "$1" = "build" ]; then
   mkdir -p $OUT
-  OTHERS=$(ls $CS/build/*.o | grep -v "field_fwd_h3.hip.o")
+  # STAMP_W=128: the Wd=128 instances live in the second translation unit of field_fwd_h3.hip (NEFES_TU_PART=1)
+  if [ "${STAMP_W:-256}" = "128" ]; then SKIP="field_fwd_h3.p1.o"; PART="-DNEFES_TU_PART=1"; else SKIP="field_fwd_h3.hip.o"; PART=""; fi
+  OTHERS=$(ls $CS/build/*.o | grep -v "$SKIP")
   for v in $VARIANTS; do
     name=${v%%:*}; defs=$(echo ${v#*:} | tr ',' ' ')
-    ( cd $CS && /opt/rocm/bin/hipcc $FLAGS $defs -c field_fwd_h3.hip -o $OUT/fwd_stamp_$name.o 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libnefes_stamp_$name.so $OTHERS $OUT/fwd_stamp_$name.o ) &
+    ( cd $CS && /opt/rocm/bin/hipcc $FLAGS -DH3_STAMP_READER $PART $defs -c field_fwd_h3.hip -o $OUT/fwd_stamp_$name.o 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libnefes_stamp_$name.so $OTHERS $OUT/fwd_stamp_$name.o ) &
   done
   wait
   rm -f $OUT/*.o
@@ -26,7 +28,9 @@ from nefes_amd import lib as L, ops
 from nefes_amd.field import NeRFH_NFF
 lib = L.load()
 raw = ctypes.CDLL(L.LIB_PATH)
-net = NeRFH_NFF('coarse', W=256, f_dim=16).requires_grad_(False).cuda()
+import os
+WD = int(os.environ.get('STAMP_W', '256')); CF = 16 if WD == 256 else 128
+net = NeRFH_NFF('coarse', W=WD, f_dim=CF).requires_grad_(False).cuda()
 pk = net.packed()
 N, S = 76800, 64
 g = torch.Generator().manual_seed(0)
