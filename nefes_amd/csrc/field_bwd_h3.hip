@@ -301,20 +301,23 @@ static int launch_bwd_h3(const FieldBwdH3Args& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// Instances spread over two objects built from this one source (Makefile: -DNEFES_TU_PART=0..1): part 0 = entry point + the
-// Wd = 256 frequency-embedding instance, part 1 = hash-grid and Wd = 128 instances.
+// Instances spread over three objects built from this one source (Makefile: -DNEFES_TU_PART=0..2): part 0 = entry point + the
+// Wd = 256 frequency-embedding instance, part 1 = hash-grid instance, part 2 = Wd = 128 instance.
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
 enum { BWD_H3_256_EXT = 0, BWD_H3_128 };
 int nefes_bwd_h3_launch_part1(int which, const FieldBwdH3Args& a, hipStream_t st);
+int nefes_bwd_h3_launch_part2(int which, const FieldBwdH3Args& a, hipStream_t st);
 
 #if NEFES_TU_PART == 1
 int nefes_bwd_h3_launch_part1(int which, const FieldBwdH3Args& a, hipStream_t st) {
-    switch (which) {
-        case BWD_H3_256_EXT: return launch_bwd_h3<256, 19, NEFES_XYZ_EXTERNAL32>(a, st);
-        case BWD_H3_128: return launch_bwd_h3<128, 131, NEFES_XYZ_FREQ10>(a, st);
-    }
+    if (which == BWD_H3_256_EXT) return launch_bwd_h3<256, 19, NEFES_XYZ_EXTERNAL32>(a, st);
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 2      // built with -mllvm -amdgpu-mfma-vgpr-form: see field_fwd_h3.hip
+int nefes_bwd_h3_launch_part2(int which, const FieldBwdH3Args& a, hipStream_t st) {
+    if (which == BWD_H3_128) return launch_bwd_h3<128, 131, NEFES_XYZ_FREQ10>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #else   // part 0
@@ -345,7 +348,7 @@ extern "C" int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, 
     hipStream_t st = (hipStream_t)stream;
     if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd_h3<256, 19, NEFES_XYZ_FREQ10>(a, st);
     if (desc->width == 256 && desc->feat_dim == 16 && ext) return nefes_bwd_h3_launch_part1(BWD_H3_256_EXT, a, st);
-    if (desc->width == 128 && desc->feat_dim == 128 && !ext) return nefes_bwd_h3_launch_part1(BWD_H3_128, a, st);
+    if (desc->width == 128 && desc->feat_dim == 128 && !ext) return nefes_bwd_h3_launch_part2(BWD_H3_128, a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #endif   // NEFES_TU_PART

@@ -334,13 +334,14 @@ static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// Kernel instances spread over two objects built from this one source (Makefile: -DNEFES_TU_PART=0..1): part 0 = entry point +
-// the Wd = 256 frequency-embedding instances, part 1 = hash-grid and Wd = 128 instances.
+// Kernel instances spread over three objects built from this one source (Makefile: -DNEFES_TU_PART=0..2): part 0 = entry point +
+// the Wd = 256 frequency-embedding instances, part 1 = hash-grid instances, part 2 = Wd = 128 instances.
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
 enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_128_SIGMA, H3_128_FULL };
 int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st);
+int nefes_fwd_h3_launch_part2(int which, const FieldFwdH3Args& a, hipStream_t st);
 
 #if defined(H3_STAMP) && defined(H3_STAMP_READER)   // exactly one translation unit of a diagnostic build (tools/stamp_h3.sh)
 extern "C" int nefes_debug_h3_stamps(unsigned long long* out3) {
@@ -363,6 +364,17 @@ int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st
     switch (which) {
         case H3_EXT_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32>(a, st);
         case H3_EXT_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32>(a, st);
+    }
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 2
+// The Wd = 128 instances hold 2 x 4 accumulator tiles = 128 registers: with ~120 more for everything else the whole kernel fits
+// the 256 architectural VGPRs, and this object is built with -mllvm -amdgpu-mfma-vgpr-form (Makefile) so that the MFMAs
+// accumulate there.  Left to its heuristics hipcc parks the tiles in AGPRs and pays a v_accvgpr_read / _write for every value
+// the vector ALU touches (1.7 of the kernel's 6.3 VALU per MFMA: it is VALU-bound at this width): forward 0.85 -> 0.78 ms,
+// backward 0.77 -> 0.73 ms on the 80x60 refinement frame.
+int nefes_fwd_h3_launch_part2(int which, const FieldFwdH3Args& a, hipStream_t st) {
+    switch (which) {
         case H3_128_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5>(a, st);
         case H3_128_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5>(a, st);
     }
@@ -397,7 +409,7 @@ extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, 
     a.n_tiles = (int)((a.M + 127) / 128);
     magic_div((uint32_t)S, a.s_magic, a.s_shift);
     hipStream_t st = (hipStream_t)stream;
-    if (small) return nefes_fwd_h3_launch_part1(mode == NEFES_FIELD_SIGMA ? H3_128_SIGMA : H3_128_FULL, a, st);
+    if (small) return nefes_fwd_h3_launch_part2(mode == NEFES_FIELD_SIGMA ? H3_128_SIGMA : H3_128_FULL, a, st);
     if (ext) return nefes_fwd_h3_launch_part1(mode == NEFES_FIELD_SIGMA ? H3_EXT_SIGMA : H3_EXT_FULL, a, st);
     if (mode == NEFES_FIELD_SIGMA) return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10>(a, st);
     return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10>(a, st);
