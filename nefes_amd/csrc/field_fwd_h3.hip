@@ -7,7 +7,12 @@
 // (field_h3.h StagedRing).  The xyz embedding (32 slots per lane) waits
 // in LDS between layer 1 and the skip at layer 5 instead of in registers: with one accumulator set in VGPRs (the compiler keeps
 // the set the vector ALU reads there) the kernel has no 32 registers to spare.
-#define NEFES_SLAB_KIB NEFES_H3_FWD_SLAB_KIB
+// (layout.h is included below; the two sizes are repeated there as NEFES_H3_FWD_SLAB_KIB / _128 and checked against these)
+#if defined(NEFES_TU_PART) && NEFES_TU_PART == 2
+#define NEFES_SLAB_KIB 16      // the Wd = 128 instances: 2 x 16 KiB of ring, two workgroups per CU (see launch_h3)
+#else
+#define NEFES_SLAB_KIB 32
+#endif
 #include <stdlib.h>
 
 #include "field_common.h"
@@ -38,7 +43,8 @@ struct FieldFwdH3Args {
 // MODE: NEFES_FIELD_SIGMA or NEFES_FIELD_FULL; ENC: NEFES_XYZ_FREQ10 or NEFES_XYZ_EXTERNAL32 (hash grid);
 // (W, NTR) = (256, 1) [C = 16] or (128, 5) [C = 128: the reference-default shape]
 template <int MODE, int ENC, int W = 256, int NTR = 1>
-__global__ __launch_bounds__(256, 1) void field_fwd_h3_kernel(FieldFwdH3Args a) {
+__global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(FieldFwdH3Args a) {
+    static_assert(NEFES_SLAB_KIB == (W == 128 ? NEFES_H3_FWD_SLAB_KIB_128 : NEFES_H3_FWD_SLAB_KIB), "ring slab size != the packer's for this width");
     constexpr int NTW = W / 32, NTH = W / 64;
     constexpr int ES = ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : NEFES_E_STEPS;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128), WT = (NTW + 1) / 2, WH = (NTH + 1) / 2;
@@ -325,7 +331,10 @@ static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int grid = a.n_tiles < cus ? a.n_tiles : cus;
+    // Wd = 128: the kernel fits 256 registers and 70 KiB of LDS, so two workgroups share a CU -- two waves per SIMD, one's vector
+    // work (6 VALU per MFMA at this width) under the other's MFMAs
+    const int per_cu = W == 128 ? 2 : 1;
+    int grid = a.n_tiles < cus * per_cu ? a.n_tiles : cus * per_cu;
     if (const char* cap = getenv("NEFES_DEBUG_MAX_GRID")) {          // experiments only: fewer workgroups than CUs
         const int c = atoi(cap);
         if (c > 0 && c < grid) grid = c;

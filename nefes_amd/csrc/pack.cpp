@@ -455,11 +455,11 @@ const uint64_t kHeaderBytes = NEFES_BLOB_HEADER_BYTES;
 static_assert(sizeof(NefesBlobInfo) <= NEFES_BLOB_HEADER_BYTES, "blob header too small");
 uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
-void fill_info(const Stream (&st)[NEFES_N_STREAMS], NefesBlobInfo* info) {
+void fill_info(const Stream (&st)[NEFES_N_STREAMS], int width, NefesBlobInfo* info) {
     uint64_t off = kHeaderBytes;
     for (int k = 0; k < NEFES_N_STREAMS; ++k) {
         NefesStreamInfo& si = info->stream[k];
-        const int kib = nefes_stream_slab_kib(k);
+        const int kib = nefes_stream_slab_kib(k, width);
         si.n_slabs = (uint32_t)st[k].n_slabs(NEFES_FRAGS_OF_KIB(kib));
         si.bias_floats = (uint32_t)st[k].bias_floats();
         si.scale_off = (uint32_t)st[k].bias_only();
@@ -482,7 +482,7 @@ extern "C" int nefes_blob_info(const NefesNetDesc* desc, NefesBlobInfo* info) {
     Net n;
     Stream st[NEFES_N_STREAMS];
     if (!build(desc, nullptr, n, st)) return NEFES_E_UNSUPPORTED;
-    fill_info(st, info);
+    fill_info(st, desc->width, info);
     return 0;
 }
 
@@ -541,7 +541,7 @@ static int pack_walk(const NefesNetDesc* desc, const float* const* tensors, char
             }
         }
         uint64_t soff = si.slab_off;
-        const int frags = NEFES_FRAGS_OF_KIB(nefes_stream_slab_kib(k));
+        const int frags = NEFES_FRAGS_OF_KIB(nefes_stream_slab_kib(k, desc->width));
         const uint64_t slab_bytes = (uint64_t)frags * 256;
         for (auto& sg : st[k].segs) {
             if (sg.h3) {   // units of two 1 KiB groups (hi, lo): lane = 8 fp16 of W 2^wexp = A operand of one 32x32x16 f16 MFMA
@@ -616,7 +616,7 @@ extern "C" int nefes_pack_weights(const NefesNetDesc* desc, const float* const* 
     Stream st[NEFES_N_STREAMS];
     if (!build(desc, tensors, n, st)) return NEFES_E_UNSUPPORTED;
     NefesBlobInfo info;
-    fill_info(st, &info);
+    fill_info(st, desc->width, &info);
     if (blob_bytes < info.total_bytes) return NEFES_E_BADBLOB;
     char* base = (char*)blob;
     memset(base, 0, info.total_bytes);
@@ -652,7 +652,7 @@ extern "C" int nefes_pack_map(const NefesNetDesc* desc, uint32_t* map, size_t n_
     Net n2;
     if (!build(desc, ptrs, n2, st)) return NEFES_E_UNSUPPORTED;
     NefesBlobInfo info;
-    fill_info(st, &info);
+    fill_info(st, desc->width, &info);
     if (n_entries < info.total_bytes / 2) return NEFES_E_BADBLOB;
     memset(map, 0, sizeof(uint32_t) * (info.total_bytes / 2));
     return pack_walk(desc, ptrs, nullptr, map, info, st);

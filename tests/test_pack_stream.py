@@ -509,8 +509,7 @@ def test_pack_map_reproduces_host_pack(Wd, C, tr, enc):
     for k in (L.STREAM_FWD_SIGMA_H3, L.STREAM_FWD_FULL_H3, L.STREAM_BWD_FULL_H3):
         si = info.stream[k]
         if si.n_slabs:
-            kib = int(re.search(r'#define NEFES_H3_%s_SLAB_KIB (\d+)' % ("BWD" if k == L.STREAM_BWD_FULL_H3 else "FWD"),
-                                open(os.path.join(ROOT, "nefes_amd", "csrc", "layout.h")).read()).group(1))
+            kib = _h3_slab_kib("BWD" if k == L.STREAM_BWD_FULL_H3 else "FWD", Wd)
             is_h3[si.slab_off // 2:(si.slab_off + si.n_slabs * kib * 1024) // 2] = True
             is_h3[(si.bias_off + 4 * si.scale_off) // 2:(si.bias_off + 4 * si.bias_floats) // 2] = True
     keep = ~is_h3                                         # (fp32 head segments inside the backward fp16 stream do get codes)
@@ -559,9 +558,11 @@ H3F = dict(L1=0, L2=1, L3=2, L4=3, L5H=4, L5E=5, L6=6, L7=7, L8=8, SIG=9, FINAL=
 H3B = dict(RGB=0, TH=1, T2=2, T1=3, T0=4, DIR=5, FINAL=6, SIG=7, L8=8, L7=9, L6=10, L5=11, L4=12, L3=13, L2=14, L1=15)
 
 
-def _h3_slab_kib(which):
+def _h3_slab_kib(which, Wd=256):
+    """KiB per slab of the fp16 two-part streams (layout.h nefes_stream_slab_kib): the Wd=128 forward streams use their own size."""
     txt = open(os.path.join(os.path.dirname(__file__), '..', 'nefes_amd', 'csrc', 'layout.h')).read()
-    return int(re.search(r'#define NEFES_H3_%s_SLAB_KIB (\d+)' % which, txt).group(1))
+    name = 'NEFES_H3_FWD_SLAB_KIB_128' if (which == "FWD" and Wd == 128) else 'NEFES_H3_%s_SLAB_KIB' % which
+    return int(re.search(r'#define %s (\d+)' % name, txt).group(1))
 
 
 def pick_exp(m):
@@ -761,7 +762,7 @@ def test_h3_streams_reproduce_the_mlp(Wd, Cf):
     pc, info_c, blob_c = pack(Wd, Cf, "coarse")
     si = info_c.stream[L.STREAM_FWD_SIGMA_H3]
     assert si.n_slabs > 0 and si.scale_count >= 2 * 10 + 9
-    st = StreamH3(blob_c, si, _h3_slab_kib("FWD"), 10)
+    st = StreamH3(blob_c, si, _h3_slab_kib("FWD", Wd), 10)
     out, _ = trunk(st, False)
     p64 = {k: v.double() for k, v in pc.items()}
     ref = O.field_forward(p64, e63.double(), sigma_only=True)[:, 0].numpy()
@@ -769,7 +770,7 @@ def test_h3_streams_reproduce_the_mlp(Wd, Cf):
 
     # full stream of the fine net
     pf, info_f, blob_f = pack(Wd, Cf, "fine")
-    st = StreamH3(blob_f, info_f.stream[L.STREAM_FWD_FULL_H3], _h3_slab_kib("FWD"), 17)
+    st = StreamH3(blob_f, info_f.stream[L.STREAM_FWD_FULL_H3], _h3_slab_kib("FWD", Wd), 17)
     out, masks = trunk(st, True)
     print(f"least fp16 headroom of any operand (binades below 2^16): {st.headroom:.1f}")
     p64 = {k: v.double() for k, v in pf.items()}
@@ -862,7 +863,7 @@ def test_h3_stream_decodes_to_scaled_weights():
     Wd, Cf = 256, 16
     p, info, blob = pack(Wd, Cf, "coarse")
     si = info.stream[L.STREAM_FWD_SIGMA_H3]
-    st = StreamH3(blob, si, _h3_slab_kib("FWD"), 10)
+    st = StreamH3(blob, si, _h3_slab_kib("FWD", Wd), 10)
     nt, k16, ups = Wd // 32, Wd // 16, st.ups
     l1_slabs = (4 * nt + ups - 1) // ups
     Wm = p["xyz_encoding_2.0.weight"].numpy().astype(np.float64)
