@@ -319,10 +319,19 @@ def main():
     barrier()
     ops.TIMERS = {}
     t0 = time.perf_counter()
+    trace = os.environ.get("NEFES_BENCH_TRACE", "0") == "1"           # debugging: host time of every step (adds a sync per step)
     for _ in range(a.steps):
+        ts = time.perf_counter()
         g = step()
+        if trace:
+            if os.environ.get("NEFES_BENCH_TRACE_SYNC", "1") == "1":
+                torch.cuda.synchronize()
+            print(f"step {time.perf_counter() - ts:.4f} s", file=sys.stderr, flush=True)
+    t_enq = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    if trace:
+        print(f"enqueue {t_enq:.4f} s, with the final sync {dt:.4f} s", file=sys.stderr, flush=True)
     timers, ops.TIMERS = ops.TIMERS, None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
