@@ -310,3 +310,47 @@ def test_merge_with_nans_fills_every_slot():
     want = torch.sort(torch.cat([z.to(DEV), z_samples], -1), -1)[0]
     assert torch.equal(torch.isnan(z_fine), torch.isnan(want))
     assert torch.equal(torch.nan_to_num(z_fine, nan=-1.), torch.nan_to_num(want, nan=-1.))
+
+
+def test_every_shipped_config_runs_on_the_hip_path():
+    """tests/golden/configs.json: every configuration file the reference ships, parsed by the reference's own config_parser
+    (tools/make_golden_configs.py).  For each distinct render-path setting: the drop-in create_nerf(args) builds the networks,
+    render() with the returned render_kwargs_test produces the oracle's maps and a finite pose gradient; the training
+    configurations (stage 1 / 2) also take one render with render_kwargs_train and a backward to the weights."""
+    import json
+    R, M, RU = dropin()
+    cfgs = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "configs.json")))
+    assert len(cfgs) >= 33
+    distinct = {}
+    for name, c in cfgs.items():
+        distinct.setdefault(json.dumps(c, sort_keys=True), name)
+    H, W, focal = 6, 8, 10.0
+    for key, name in distinct.items():
+        c = json.loads(key)
+        args = types.SimpleNamespace(**c, basedir="/nonexistent", expname="none", ft_path=None, no_reload=True)
+        kw_train, kw_test, start, grad_vars, optimizer = M.create_nerf(args)
+        coarse, fine = kw_test["network_fn"], kw_test["network_fine"]
+        assert (coarse.W, coarse.W_features, kw_test["N_samples"], kw_test["N_importance"]) == (c["netwidth"], 128, c["N_samples"], c["N_importance"])
+        assert (grad_vars is None) == bool(c["no_grad_update"])
+        near, far = (0., 4.) if c["dataset_type"].startswith("7Scenes") else (0., 20.)
+        pose = O.bench_pose()
+        coarse.requires_grad_(False), fine.requires_grad_(False)
+        c2w = pose.to(DEV).requires_grad_()
+        rgb, disp, acc, ex = R.render(H, W, focal, chunk=c["chunk"], c2w=c2w, near=near, far=far, img_idx=torch.full((1, 10), 10.),
+                                      **kw_test)
+        O.bench_loss(rgb, ex["feat_map"]).backward()
+        assert torch.isfinite(c2w.grad).all() and float(c2w.grad.abs().max()) > 0
+        cfg = O.RenderCfg()
+        cfg.N_samples, cfg.N_importance, cfg.transient_at_test = c["N_samples"], c["N_importance"], c["transient_at_test"]
+        pc, pf = params(c["netwidth"], 128)
+        r_rgb, _, r_acc, r_ex = O.render(H, W, focal, pc, pf, cfg, c2w=pose, near=near, far=far)
+        assert rel(rgb, r_rgb) < 1e-4 and rel(ex["feat_map"], r_ex["feat_map"]) < 1e-4 and rel(acc, r_acc) < 1e-4, name
+        if not c["no_grad_update"]:                       # stage 1 / stage 2: the training render of run_nefes.py:42-108
+            coarse.requires_grad_(True), fine.requires_grad_(True)
+            torch.manual_seed(0)
+            rgb_t, _, _, ex_t = R.render(H, W, focal, chunk=c["chunk"], c2w=pose.to(DEV), near=near, far=far,
+                                         img_idx=torch.full((1, 10), 10.), **kw_train)
+            (M.img2mse(rgb_t, torch.zeros_like(rgb_t)) + M.img2mse(ex_t["rgb0"], torch.zeros_like(rgb_t))).backward()
+            g = [p.grad for n, p in fine.named_parameters() if p.grad is not None]
+            assert g and all(torch.isfinite(x).all() for x in g), name
+            optimizer.step()
