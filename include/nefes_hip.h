@@ -289,6 +289,14 @@ int nefes_cosine_loss_bwd(int C, int64_t P, const float* a, const float* b, cons
  *      returns the settled shader clock and the dense fp16 rate.  Synchronises the stream.  Not part of the render path. ---- */
 int nefes_probe_mfma_clock(int random_operands, int ms_target, double* clock_ghz, double* fp16_dense_tflops, void* stream);
 
+/* ---- EXPERIMENT (not reachable from render()): the sigma-only forward of the Wd = 256 coarse network on
+ *      v_mfma_f32_16x16x32_f16 (8 waves x 16 samples, two waves per SIMD), with its own self-contained weight blob.
+ *      tensors: the (weight, bias) table of nefes_pack_weights.  raw_t: [N][1][S] = softplus(sigma). ---- */
+size_t nefes_h4_sigma_blob_bytes(const NefesNetDesc* desc);                 /* 0 = unsupported description */
+int nefes_h4_sigma_pack(const NefesNetDesc* desc, const float* const* tensors, int n_tensors, void* blob, size_t blob_bytes);  /* host */
+int nefes_field_fwd_h4_sigma(const NefesNetDesc* desc, const void* blob, int N, int S, const float* rays_o, const float* rays_d,
+                             const float* z, float* raw_t, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

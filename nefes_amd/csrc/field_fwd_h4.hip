@@ -1,0 +1,525 @@
+// EXPERIMENT (round 2): the sigma-only forward of the 8x256 network on v_mfma_f32_16x16x32_f16.
+//
+// Under this chip's power limit the 16x16x32 MFMA sustains 1.15 x the rate of the 32x32x16 one (tools/probe/clock_probe.hip).
+// This kernel measures what that is worth inside a real field kernel before the FULL forward and the backward are re-laid out:
+// same arithmetic as field_fwd_h3_kernel<SIGMA> (fp16 two-part split, three products, bound-based exponents), different tiling.
+//
+//   workgroup = 8 waves x 16 samples (128 samples per pass over the weight stream, as before); lane = (j = l % 16, g = l / 16):
+//   sample j of the wave, lane group g.  A 16x16 C tile holds rows 16 t + 4 g + r (r = 0..3) of the sample: 2 x 16 tiles x 4 =
+//   128 accumulator registers, so TWO waves fit a SIMD and hide each other's vector work (no hand-placed gap schedule here).
+//   The operand of a 32-k step q is the eight registers of tiles 2q and 2q+1: logical k = 8 g + e  <->  input row
+//   32 q + 16 (e / 4) + 4 g + e % 4, a column permutation the packer applies (h4_col below).
+//   Weight unit = [A_hi | A_lo] of (32-k step, 16-row tile): 2 KiB, lane (i = l % 16, g) holds W[16 t + i][h4_col(q, g, 0..7)].
+//   Price: every one of the 8 waves reads every A operand from LDS (twice the traffic of the 4-wave kernels).
+//
+// Self-contained on purpose: its own small blob (nefes_h4_sigma_pack), no entry in NefesBlobInfo, not reachable from render().
+// tests/test_gpu_h4.py checks it against the float64 oracle and times it against the production kernel.
+#define NEFES_SLAB_KIB 32
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "field_common.h"
+#include "../../include/nefes_hip.h"
+
+#include "field_x6.h"
+#include "field_h3.h"
+
+namespace {
+
+constexpr int kW = 256, kNT = kW / 16, kKSH = kW / 32, kKSE = 2, kSegs = 10, kBiasBlocks = 9;
+constexpr int kBiasFloats = 8 * kW + 16;                       // L1..L8, then the sigma head's tile (row 0 real)
+constexpr int kTabOff = kBiasFloats;                            // (exp, bound) per segment, then max |b| per bias block
+constexpr int kBlobFloats = ((kTabOff + 2 * kSegs + kBiasBlocks + 63) / 64) * 64;
+enum { S_L1 = 0, S_L2, S_L3, S_L4, S_L5H, S_L5E, S_L6, S_L7, S_L8, S_SIG };
+
+// feature of embedding slot u (0..15) of lane group g: pairs (frequency k, component a) n = 3 k + a are dealt round-robin to the
+// groups (n = g + 4 i), slot 2i = sin, 2i+1 = cos; the two free slots of groups 2 and 3 carry x, y and z.  -1 = padding.
+__host__ __device__ inline int h4_feature(int g, int u) {
+    const int n = g + 4 * (u >> 1);
+    if (n < 30) return 3 + 6 * (n / 3) + ((u & 1) ? 3 : 0) + n % 3;
+    if (g == 2) return u & 1;             // x, y
+    return (u & 1) ? -1 : 2;              // z, pad
+}
+__host__ __device__ inline int h4_col(int q, int g, int e) { return 32 * q + 16 * (e >> 2) + 4 * g + (e & 3); }
+
+struct H4Args {
+    const char* stream;
+    const float* bias;
+    uint32_t n_slabs;
+    const float *rays_o, *rays_d, *z;
+    float* raw_t;
+    int N, S;
+    long long M;
+    int n_tiles;
+    uint32_t s_magic, s_shift;
+};
+
+// weight ring through registers for 8 waves: each wave moves four 1 KiB pieces of every 32 KiB slab (field_h3.h StagedRing)
+struct Ring8 {
+    const char* src;
+    uint32_t n_slabs, g_next, c_slot, cur_off, my_off;
+    char* my_lds;
+    f32x4 pf;
+    f32x4 stage[4];
+    __device__ __forceinline__ void load_piece(int q) { stage[q] = *(const f32x4*)(src + (size_t)g_next * 32768 + my_off + q * 1024); }
+    __device__ __forceinline__ void init(const char* stream, uint32_t nslabs, char* ring_base, int wave, int lane) {
+        src = stream; n_slabs = nslabs;
+        my_off = (uint32_t)(wave * 4096 + lane * 16);
+        my_lds = ring_base + my_off;
+        g_next = 0; c_slot = 0; cur_off = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_piece(q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4*)(my_lds + q * 1024) = stage[q];
+        g_next = n_slabs > 1 ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_piece(q);
+        g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
+    }
+    __device__ __forceinline__ void issue_piece(int q) {
+        *(f32x4*)(my_lds + (c_slot ^ 1u) * 32768 + q * 1024) = stage[q];
+        load_piece(q);
+        if (q == 3) g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
+    }
+    __device__ __forceinline__ uint32_t acquire() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        c_slot ^= 1u;
+        return c_slot * 32768;
+    }
+    __device__ __forceinline__ void prime(const char* ring_lane) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur_off = 0;
+        pf = *(const f32x4*)(ring_lane);
+    }
+};
+
+// B-operand sources on 16-row tiles: pair p (0..3) of 32-k step q = registers 2 (p & 1), +1 of tile T0 + 2 q + (p >> 1)
+template <int NX, int T0 = 0>
+struct ReluSplit4 {
+    const f32x4 (&X)[NX];
+    float r;
+    float& m;
+    __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
+        s.x0 = X[T0 + 2 * q + (p >> 1)][2 * (p & 1)];
+        s.x1 = X[T0 + 2 * q + (p >> 1)][2 * (p & 1) + 1];
+    }
+    __device__ __forceinline__ void stage_b(PairRegs& s) const {
+        s.x0 = relu1<false>(s.x0);
+        s.x1 = relu1<false>(s.x1);
+        max3_acc(m, s.x0, s.x1);
+    }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
+};
+struct LdsSplit4 {
+    const float* base;       // this lane's column of the parked embedding: slot s at base[s * 64]
+    float r;
+    __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
+        s.x0 = base[(8 * q + 2 * p) * 64];
+        s.x1 = base[(8 * q + 2 * p + 1) * 64];
+    }
+    __device__ __forceinline__ void stage_b(PairRegs&) const {}
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
+};
+struct BiasInit4 {
+    const char* p;            // bias block + 16 g bytes
+    float s;
+    __device__ __forceinline__ f32x4 operator()(int t) const {
+        const f32x4 b = *(const f32x4*)(p + t * 64);
+        return f32x4{b[0] * s, b[1] * s, b[2] * s, b[3] * s};
+    }
+};
+struct ZeroInit4 {
+    __device__ __forceinline__ f32x4 operator()(int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+};
+
+// acc[0 .. NT) (+)= W-block * src over KS steps of 32 k-values; stream order: for step q, for tile t: one 2 KiB unit.
+// Block-per-pair placement and compiler-scheduled MFMAs: the SIMD's second wave fills the gaps.
+template <int NT, int KS, bool FIRST, class SrcFn, class InitFn, int NACC>
+__device__ __forceinline__ void run_h4_single(Ring8& ring, const char* ring_lane, const SrcFn& src, const InitFn& init, f32x4 (&acc)[NACC]) {
+    static_assert(NT <= NACC, "accumulator array too small");
+    constexpr int UPS = 16, NU = KS * NT, NSLAB = (NU + UPS - 1) / UPS;
+    Split2 B, Bn;
+    {
+        PairRegs s0;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            src.stage_a(s0, 0, pp);
+            src.stage_b(s0);
+            if (pp == 3) src.template stage_c<true>(B, pp, s0);
+            else src.template stage_c<false>(B, pp, s0);
+        }
+    }
+    Bn = B;
+    const char* p = ring_lane + ring.cur_off;
+    f32x4 ah = ring.pf, al = *(const f32x4*)(p + 1024);
+#pragma unroll
+    for (int sl = 0; sl < NSLAB; ++sl) {
+        const int nu = (NU - sl * UPS) < UPS ? (NU - sl * UPS) : UPS;
+#pragma unroll
+        for (int uu = 0; uu < UPS; ++uu) {
+            if (uu < nu) {
+                const int u = sl * UPS + uu, q = u / NT, t = u % NT;
+                f32x4 nh;
+                const bool last = !(uu + 1 < nu);
+                if (!last) {
+                    nh = *(const f32x4*)(p + (2 * uu + 2) * 1024);
+                } else {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        if ((qq * nu) / 4 >= uu) ring.issue_piece(qq);
+                    ring.cur_off = ring.acquire();
+                    p = ring_lane + ring.cur_off;
+                    nh = *(const f32x4*)(p);
+                }
+                if (t == 0 && q > 0) B = Bn;
+                const f16x8 Ah = as_f16x8(ah), Al = as_f16x8(al), Bh = as_f16x8(B.h), Bl = as_f16x8(B.l);
+                f32x4 c = (FIRST && q == 0) ? init(t) : acc[t];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, c, 0, 0, 0);          // small terms first
+                al = *(const f32x4*)(p + (last ? 1 : 2 * uu + 3) * 1024);
+                if (uu + 1 < nu) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        if ((qq * nu) / 4 == uu) ring.issue_piece(qq);
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, c, 0, 0, 0);
+                acc[t] = c;
+                if (q + 1 < KS) {
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp)
+                        if (NT >= 4 ? (t == pp * (NT / 4) + NT / 4 - 1) : (t == (pp * NT) / 4)) {
+                            PairRegs s1;
+                            src.stage_a(s1, q + 1, pp);
+                            src.stage_b(s1);
+                            if (pp == 3) src.template stage_c<true>(Bn, pp, s1);
+                            else src.template stage_c<false>(Bn, pp, s1);
+                        }
+                }
+                ah = nh;
+            }
+        }
+    }
+    ring.pf = ah;
+}
+
+// The same for an even number of tiles, two units at a time: the six MFMAs of a pair of tiles alternate between the two
+// accumulators (no MFMA waits for the one issued just before it) and the A operands of the NEXT pair are requested at the top
+// of the pair -- twice the look-ahead of run_h4_single for 16 more registers.
+template <int NT, int KS, bool FIRST, class SrcFn, class InitFn, int NACC>
+__device__ __forceinline__ void run_h4_pairs(Ring8& ring, const char* ring_lane, const SrcFn& src, const InitFn& init, f32x4 (&acc)[NACC]) {
+    static_assert(NT <= NACC && NT % 2 == 0, "pairs of tiles");
+    constexpr int UPS = 16, NU = KS * NT, NSLAB = (NU + UPS - 1) / UPS;
+    Split2 B, Bn;
+    {
+        PairRegs s0;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            src.stage_a(s0, 0, pp);
+            src.stage_b(s0);
+            if (pp == 3) src.template stage_c<true>(B, pp, s0);
+            else src.template stage_c<false>(B, pp, s0);
+        }
+    }
+    Bn = B;
+    const char* p = ring_lane + ring.cur_off;
+    f32x4 h0 = ring.pf, l0 = *(const f32x4*)(p + 1024), h1 = *(const f32x4*)(p + 2048), l1 = *(const f32x4*)(p + 3072);
+#pragma unroll
+    for (int sl = 0; sl < NSLAB; ++sl) {
+        const int nu = (NU - sl * UPS) < UPS ? (NU - sl * UPS) : UPS;          // even
+#pragma unroll
+        for (int uu = 0; uu < UPS; uu += 2) {
+            if (uu < nu) {
+                const int u = sl * UPS + uu, q = u / NT, t = u % NT;
+                const bool last = !(uu + 2 < nu);
+                f32x4 nh0, nl0, nh1, nl1;
+                if (!last) {
+                    const char* pn = p + (2 * uu + 4) * 1024;
+#ifdef H4_ABL_NOAREAD      // timing ablation (garbage results): what the doubled A-operand traffic of this layout costs
+                    nh0 = h0; nl0 = l0; nh1 = h1; nl1 = l1;
+#else
+                    nh0 = *(const f32x4*)(pn); nl0 = *(const f32x4*)(pn + 1024); nh1 = *(const f32x4*)(pn + 2048); nl1 = *(const f32x4*)(pn + 3072);
+#endif
+                } else {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        if ((qq * nu) / 4 >= uu) ring.issue_piece(qq);
+                    ring.cur_off = ring.acquire();
+                    p = ring_lane + ring.cur_off;
+                    nh0 = *(const f32x4*)(p); nl0 = *(const f32x4*)(p + 1024); nh1 = *(const f32x4*)(p + 2048); nl1 = *(const f32x4*)(p + 3072);
+                }
+                // the requests stay HERE, a whole pair ahead of their use: left alone, the scheduler sinks every read to just in
+                // front of its MFMA to save registers, and every MFMA then waits out an LDS round trip (seen: wait 39 %)
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 0 && q > 0) B = Bn;
+                const f16x8 Bh = as_f16x8(B.h), Bl = as_f16x8(B.l);
+                f32x4 c0 = (FIRST && q == 0) ? init(t) : acc[t], c1 = (FIRST && q == 0) ? init(t + 1) : acc[t + 1];
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(l0), Bh, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(l1), Bh, c1, 0, 0, 0);
+                if (!last) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        if ((qq * nu) / 4 == uu) ring.issue_piece(qq);
+                }
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(h0), Bl, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(h1), Bl, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(h0), Bh, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(h1), Bh, c1, 0, 0, 0);
+                acc[t] = c0;
+                acc[t + 1] = c1;
+                if (q + 1 < KS) {
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp)
+                        if (NT >= 8 ? (t == pp * (NT / 4) + NT / 4 - 2) : (t == 0 && (pp * NT) / 4 <= 1)) {
+                            PairRegs s1;
+                            src.stage_a(s1, q + 1, pp);
+                            src.stage_b(s1);
+                            if (pp == 3) src.template stage_c<true>(Bn, pp, s1);
+                            else src.template stage_c<false>(Bn, pp, s1);
+                        }
+                }
+                h0 = nh0; l0 = nl0; h1 = nh1; l1 = nl1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    ring.pf = h0;
+}
+template <int NT, int KS, bool FIRST, class SrcFn, class InitFn, int NACC>
+__device__ __forceinline__ void run_h4(Ring8& ring, const char* ring_lane, const SrcFn& src, const InitFn& init, f32x4 (&acc)[NACC]) {
+#ifndef H4_SINGLE
+    if constexpr (NT % 2 == 0 && NT >= 8) run_h4_pairs<NT, KS, FIRST>(ring, ring_lane, src, init, acc);
+    else
+#endif
+        run_h4_single<NT, KS, FIRST>(ring, ring_lane, src, init, acc);
+}
+
+// max over the four lanes (j, j+16, j+32, j+48) that share a sample
+__device__ __forceinline__ float quad_max(float m) {
+    m = pair_max(m);
+    return fmaxf(m, __shfl_xor(m, 16));
+}
+
+__global__ __launch_bounds__(512) void field_fwd_h4_sigma_kernel(H4Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring_base = smem;
+    float* bias_lds = (float*)(smem + 2 * 32768);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    float* e_lds = bias_lds + kBlobFloats + wave * (16 * 64) + lane;           // [wave][16 slots][64 lanes]
+    for (int i = threadIdx.x; i < kBlobFloats; i += 512) bias_lds[i] = a.bias[i];
+    Ring8 ring;
+    ring.init(a.stream, a.n_slabs, ring_base, wave, lane);
+    const char* ring_lane = ring_base + lane * 16;
+    const char* bias_grp = (const char*)bias_lds + 16 * g;
+    const int* tab_i = (const int*)(bias_lds + kTabOff);
+    const float* tab_f = bias_lds + kTabOff;
+    auto wexp = [&](int seg) { return tab_i[2 * seg]; };
+    auto rowb = [&](int seg) { return tab_f[2 * seg + 1]; };
+    auto bmax = [&](int blk) { return tab_f[2 * kSegs + blk]; };
+    ring.prime(ring_lane);
+    auto tau_of = [&](float M, int ew) {
+        const int t = pick_exp(M);
+        return t < 100 - ew ? t : 100 - ew;
+    };
+    auto bias_at = [&](int off_floats, int es) { return BiasInit4{bias_grp + off_floats * 4, pow2i(es)}; };
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const uint32_t m_raw = (uint32_t)tile * 128u + (uint32_t)(wave * 16 + j);
+        const bool ok = m_raw < (uint32_t)a.M;
+        const uint32_t m = ok ? m_raw : (uint32_t)a.M - 1u;
+        const uint32_t ray = a.s_magic ? __umulhi(m, a.s_magic) >> a.s_shift : m;
+        const uint32_t smp = m - ray * (uint32_t)a.S;
+        float x[3];
+        {
+            const float zz = a.z[m];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[c] = add_rn(a.rays_o[ray * 3 + c], mul_rn(a.rays_d[ray * 3 + c], zz));
+        }
+        {   // this lane group's 16 embedding slots (h4_feature): 7 or 8 (frequency, component) pairs, sin and cos of each
+            double t3[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t3[c] = (double)x[c] * 0.15915494309189533577;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int n = g + 4 * i;
+                float sn = 0.f, cs = 0.f;
+                if (n < 30) {
+                    const int k = n / 3, c = n - 3 * k;
+                    const double tc = c == 0 ? t3[0] : (c == 1 ? t3[1] : t3[2]);
+                    sincos_turns(tc, k, sn, cs);
+                } else {
+                    sn = g == 2 ? x[0] : x[2];
+                    cs = g == 2 ? x[1] : 0.f;
+                }
+                e_lds[(2 * i) * 64] = sn;
+                e_lds[(2 * i + 1) * 64] = cs;
+            }
+        }
+        const float mE = fmaxf(fmaxf(1.f, fabsf(x[0])), fmaxf(fabsf(x[1]), fabsf(x[2])));
+        f32x4 A[kNT], B[kNT];
+        int es_a, es_b = 0;
+        float M;
+        {
+            const int tau = tau_of(mE, wexp(S_L1));
+            es_a = tau + wexp(S_L1);
+            run_h4<kNT, kKSE, true>(ring, ring_lane, LdsSplit4{e_lds, pow2i(tau)}, bias_at(0, es_a), A);
+            M = rowb(S_L1) * mE + bmax(0);
+        }
+#pragma unroll 1
+        for (int p = 0; p < 4; ++p) {
+            const int l1 = 2 + 2 * p, l2 = l1 + 1;
+            const int seg1 = l1 <= 5 ? l1 - 1 : l1;            // L2 -> 1, L4 -> 3, L6 -> 6, L8 -> 8
+            {
+                const int ew = wexp(seg1), tau = tau_of(M, ew);
+                float mx = 0.f;
+                run_h4<kNT, kKSH, true>(ring, ring_lane, ReluSplit4<kNT>{A, pow2i(tau - es_a), mx}, bias_at((l1 - 1) * kW, tau + ew), B);
+                M = rowb(seg1) * (quad_max(mx) * pow2i(-es_a)) + bmax(l1 - 1);
+                es_b = tau + ew;
+            }
+            if (p == 3) break;
+            {
+                const int seg2 = l2 <= 4 ? l2 - 1 : (l2 == 5 ? S_L5H : l2);      // L3 -> 2, L5 -> L5H, L7 -> 7
+                const int ew = wexp(seg2);
+                const int tau = tau_of(p == 1 ? fmaxf(M, mE) : M, ew);
+                float mx = 0.f;
+                run_h4<kNT, kKSH, true>(ring, ring_lane, ReluSplit4<kNT>{B, pow2i(tau - es_b), mx}, bias_at((l2 - 1) * kW, tau + ew), A);
+                if (p == 1) run_h4<kNT, kKSE, false>(ring, ring_lane, LdsSplit4{e_lds, pow2i(tau)}, ZeroInit4{}, A);
+                M = rowb(seg2) * (quad_max(mx) * pow2i(-es_b)) + (p == 1 ? rowb(S_L5E) * mE : 0.f) + bmax(l2 - 1);
+                es_a = tau + ew;
+            }
+        }
+        {
+            f32x4 sg[1];
+            float mdummy = 0.f;
+            const int tau = tau_of(M, wexp(S_SIG)), es = tau + wexp(S_SIG);
+            run_h4<1, kKSH, true>(ring, ring_lane, ReluSplit4<kNT>{B, pow2i(tau - es_b), mdummy}, bias_at(8 * kW, es), sg);
+            if (ok && g == 0) __builtin_nontemporal_store(softplus_ref(sg[0][0] * pow2i(-es)), &a.raw_t[(size_t)ray * a.S + smp]);
+        }
+    }
+}
+
+// ---- host side: the blob -------------------------------------------------------------------------------------------------------
+struct SegDesc { int rows, real_rows, ks, layer, col0, n_cols, emb; };       // layer: index into the (weight, bias) table
+const SegDesc kSeg[kSegs] = {
+    {256, 256, kKSE, 0, 0, 63, 1},  {256, 256, kKSH, 1, 0, 256, 0}, {256, 256, kKSH, 2, 0, 256, 0}, {256, 256, kKSH, 3, 0, 256, 0},
+    {256, 256, kKSH, 4, 63, 256, 0}, {256, 256, kKSE, 4, 0, 63, 1}, {256, 256, kKSH, 5, 0, 256, 0}, {256, 256, kKSH, 6, 0, 256, 0},
+    {256, 256, kKSH, 7, 0, 256, 0},  {16, 1, kKSH, 10, 0, 256, 0}};
+int seg_slabs(const SegDesc& s) { return (s.ks * (s.rows / 16) + 15) / 16; }
+int total_slabs() { int n = 0; for (const auto& s : kSeg) n += seg_slabs(s); return n; }
+int ld_of(int layer) { return layer == 0 ? 63 : (layer == 4 ? 63 + 256 : 256); }
+
+uint16_t f16_bits(float f) { const _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+float f16_val(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+
+void magic_div(uint32_t d, uint32_t& magic, uint32_t& shift) {
+    if (d == 1) { magic = 0; shift = 0; return; }
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    const uint64_t p = 31 + l;
+    magic = (uint32_t)(((1ull << p) + d - 1) / d);
+    shift = (uint32_t)(p - 32);
+}
+
+}  // namespace
+
+extern "C" size_t nefes_h4_sigma_blob_bytes(const NefesNetDesc* desc) {
+    if (!desc || desc->width != 256 || desc->xyz_encoding != NEFES_XYZ_FREQ10) return 0;
+    return (size_t)kBlobFloats * 4 + (size_t)total_slabs() * 32768;
+}
+
+// tensors: the (weight, bias) table of nefes_pack_weights (xyz_encoding_1..8, xyz_encoding_final, dir_encoding, static_sigma, ...)
+extern "C" int nefes_h4_sigma_pack(const NefesNetDesc* desc, const float* const* tensors, int n_tensors, void* blob, size_t blob_bytes) {
+    const size_t need = nefes_h4_sigma_blob_bytes(desc);
+    if (!need) return NEFES_E_UNSUPPORTED;
+    if (!tensors || n_tensors < 22 || !blob || blob_bytes < need) return NEFES_E_BADARG;
+    memset(blob, 0, need);
+    float* fl = (float*)blob;
+    int* tab_i = (int*)(fl + kTabOff);
+    float* tab_f = fl + kTabOff;
+    for (int l = 0; l < 8; ++l) {
+        const float* b = tensors[2 * l + 1];
+        float mb = 0.f;
+        for (int i = 0; i < 256; ++i) { fl[l * 256 + i] = b[i]; mb = fmaxf(mb, fabsf(b[i])); }
+        tab_f[2 * kSegs + l] = mb;
+    }
+    fl[8 * 256] = tensors[21][0];
+    tab_f[2 * kSegs + 8] = fabsf(tensors[21][0]);
+    // weight exponents: max |w| 2^e in [2^14, 2^15); the two parts of layer 5 share one (they accumulate into the same tiles)
+    int wexp[kSegs];
+    for (int s = 0; s < kSegs; ++s) {
+        const SegDesc& sd = kSeg[s];
+        const float* w = tensors[2 * sd.layer];
+        const int ld = ld_of(sd.layer);
+        float mx = 0.f, bound = 0.f;
+        for (int r = 0; r < sd.real_rows; ++r) {
+            float rs = 0.f;
+            for (int c = 0; c < sd.n_cols; ++c) { const float v = fabsf(w[(size_t)r * ld + sd.col0 + c]); mx = fmaxf(mx, v); rs += v; }
+            bound = fmaxf(bound, rs);
+        }
+        int e = 0;
+        if (mx > 0.f) { int ex; frexpf(mx, &ex); e = 15 - ex; }          // mx = f 2^ex, f in [0.5, 1): mx 2^(15 - ex) in [2^14, 2^15)
+        wexp[s] = e;
+        tab_f[2 * s + 1] = bound;
+    }
+    wexp[S_L5H] = wexp[S_L5E] = wexp[S_L5H] < wexp[S_L5E] ? wexp[S_L5H] : wexp[S_L5E];
+    for (int s = 0; s < kSegs; ++s) tab_i[2 * s] = wexp[s];
+    char* slabs = (char*)blob + (size_t)kBlobFloats * 4;
+    int slab0 = 0;
+    for (int s = 0; s < kSegs; ++s) {
+        const SegDesc& sd = kSeg[s];
+        const float* w = tensors[2 * sd.layer];
+        const int ld = ld_of(sd.layer), nt = sd.rows / 16;
+        const float sc = ldexpf(1.f, wexp[s]);
+        for (int q = 0; q < sd.ks; ++q)
+            for (int t = 0; t < nt; ++t) {
+                const int idx = q * nt + t;
+                char* unit = slabs + (size_t)(slab0 + idx / 16) * 32768 + (size_t)(idx % 16) * 2048;
+                for (int l = 0; l < 64; ++l) {
+                    const int i = l & 15, g = l >> 4, row = 16 * t + i;
+                    for (int e = 0; e < 8; ++e) {
+                        int col;
+                        if (sd.emb) col = h4_feature(g, 8 * q + e);
+                        else col = h4_col(q, g, e);
+                        float v = 0.f;
+                        if (row < sd.real_rows && col >= 0 && col < sd.n_cols) v = w[(size_t)row * ld + sd.col0 + col] * sc;
+                        const uint16_t hi = f16_bits(v), lo = f16_bits(v - f16_val(hi));
+                        memcpy(unit + l * 16 + e * 2, &hi, 2);
+                        memcpy(unit + 1024 + l * 16 + e * 2, &lo, 2);
+                    }
+                }
+            }
+        slab0 += seg_slabs(sd);
+    }
+    return 0;
+}
+
+extern "C" int nefes_field_fwd_h4_sigma(const NefesNetDesc* desc, const void* blob, int N, int S, const float* rays_o, const float* rays_d,
+                                        const float* z, float* raw_t, void* stream) {
+    if (!nefes_h4_sigma_blob_bytes(desc)) return NEFES_E_UNSUPPORTED;
+    if (!blob || !rays_o || !rays_d || !z || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
+    H4Args a;
+    a.bias = (const float*)blob;
+    a.stream = (const char*)blob + (size_t)kBlobFloats * 4;
+    a.n_slabs = (uint32_t)total_slabs();
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.raw_t = raw_t; a.N = N; a.S = S;
+    a.M = (long long)N * S;
+    if (a.M >= (1ll << 31) - 256) return NEFES_E_UNSUPPORTED;
+    a.n_tiles = (int)((a.M + 127) / 128);
+    magic_div((uint32_t)S, a.s_magic, a.s_shift);
+    const size_t lds = 2 * 32768 + (size_t)kBlobFloats * 4 + (size_t)8 * 16 * 64 * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)field_fwd_h4_sigma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = a.n_tiles < cus ? a.n_tiles : cus;
+    hipLaunchKernelGGL(field_fwd_h4_sigma_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}

@@ -704,3 +704,33 @@ def cosine_feature_loss(a, b, return_cos=False):
     per-channel similarities (float64, no gradient) -- per-image losses of a batch folded into the channel dimension."""
     loss, cos = CosineFeatureLoss.apply(a, b)
     return (loss, cos) if return_cos else loss
+
+
+# ---------------------------------------------------------------------------------------------
+# EXPERIMENT (DESIGN.md section 7 item 1): sigma-only forward on v_mfma_f32_16x16x32_f16.  Not used by render().
+# ---------------------------------------------------------------------------------------------
+class H4Sigma:
+    """The coarse network's sigma-only branch (run_network_NeRFH_NFF with typ='coarse', test_time=True) on the 16x16x32 kernel:
+    its own weight blob, packed on the host from the module's parameters."""
+
+    def __init__(self, net, device="cuda"):
+        lib = L.load()
+        self.desc = L.NefesNetDesc(int(net.W), int(net.W_features), 0, L.XYZ_FREQ10)
+        n = lib.nefes_h4_sigma_blob_bytes(self.desc)
+        if n == 0:
+            raise RuntimeError("nefes_amd: the 16x16x32 experiment is built for Wd = 256 with the frequency embedding")
+        sd = dict(net.named_parameters())
+        tens = [sd[name + s].detach().to("cpu", torch.float32).contiguous() for name in PackedField.LAYERS_COARSE for s in (".weight", ".bias")]
+        ptrs = (C.c_void_p * len(tens))(*[t.data_ptr() for t in tens])
+        host = torch.zeros(n, dtype=torch.uint8)
+        L.check(lib.nefes_h4_sigma_pack(self.desc, ptrs, len(tens), C.c_void_p(host.data_ptr()), n), "nefes_h4_sigma_pack")
+        self.blob = host.to(device)
+
+    def forward(self, N, S, rays_o, rays_d, z):
+        o, d, zz = _f32(rays_o), _f32(rays_d), _f32(z)
+        raw_t = torch.empty(N, 1, S, device=o.device)
+        with _timed("field_fwd[sigma,h4]"):
+            L.check(L.load().nefes_field_fwd_h4_sigma(self.desc, _chk(self.blob, "blob", torch.uint8), N, S, _chk(o, "rays_o"),
+                                                      _chk(d, "rays_d"), _chk(zz, "z"), _chk(raw_t, "raw_t"), _stream()),
+                    "nefes_field_fwd_h4_sigma")
+        return raw_t

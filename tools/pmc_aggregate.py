@@ -14,9 +14,8 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"^void ", "", name)
-    name = re.sub(r"\(.*$", "", name)
-    return name.replace("(anonymous namespace)::", "")
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
+    return re.sub(r"\(.*$", "", name)
 
 
 def main():
