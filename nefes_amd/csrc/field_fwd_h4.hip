@@ -405,6 +405,208 @@ __global__ __launch_bounds__(512) void field_fwd_h4_sigma_kernel(H4Args a) {
     }
 }
 
+// ================================================================================================================================
+// Layout (a): FOUR waves, each lane serving TWO 16-sample halves (samples 32 w + j and 32 w + 16 + j): every A operand read from LDS
+// feeds six MFMAs (three products x two halves), so the LDS traffic equals the production kernel's; the price is 2 x 2 x 64 = 256
+// accumulator registers again (one wave per SIMD) and two of every per-sample scalar.  Same blob as layout (b).
+template <int NT, int KS, bool FIRST, class Src0, class Src1, class Init0, class Init1, int NACC>
+__device__ __forceinline__ void run_h4a(StagedRing& ring, const char* ring_lane, const Src0& src0, const Src1& src1, const Init0& init0,
+                                        const Init1& init1, f32x4 (&acc0)[NACC], f32x4 (&acc1)[NACC]) {
+    static_assert(NT <= NACC, "accumulator array too small");
+    constexpr int UPS = 16, NU = KS * NT, NSLAB = (NU + UPS - 1) / UPS;
+    Split2 B0, B1, Bn0, Bn1;
+    auto produce = [&](auto& dst, const auto& src, int q, int pp) {
+        PairRegs s1;
+        src.stage_a(s1, q, pp);
+        src.stage_b(s1);
+        if (pp == 3) src.template stage_c<true>(dst, pp, s1);
+        else src.template stage_c<false>(dst, pp, s1);
+    };
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) { produce(B0, src0, 0, pp); produce(B1, src1, 0, pp); }
+    Bn0 = B0; Bn1 = B1;
+    const char* p = ring_lane + ring.cur_off;
+    f32x4 h0 = ring.pf, l0 = *(const f32x4*)(p + 1024);
+#pragma unroll
+    for (int sl = 0; sl < NSLAB; ++sl) {
+        const int nu = (NU - sl * UPS) < UPS ? (NU - sl * UPS) : UPS;
+#pragma unroll
+        for (int uu = 0; uu < UPS; ++uu) {
+            if (uu < nu) {
+                const int u = sl * UPS + uu, q = u / NT, t = u % NT;
+                // unit u + 1's operands are requested now (pinned: see run_h4_pairs); the slab's last unit acquires the next slab first
+                // (one unit of look-ahead only: this kernel has no registers for two -- 256 accumulators + two operand pairs)
+                f32x4 nh, nl;
+                if (uu + 1 == nu) {
+#pragma unroll
+                    for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
+                        if ((qq * nu) / NEFES_SLAB_PIECES >= uu) ring.issue_piece(qq);
+                    ring.cur_off = ring.acquire();
+                    p = ring_lane + ring.cur_off - (size_t)nu * 2048;     // unit index uu + 1 == nu now addresses the new slab
+                }
+                {
+                    const char* pn = p + (size_t)(uu + 1) * 2048;
+                    nh = *(const f32x4*)(pn);
+                    nl = *(const f32x4*)(pn + 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 0 && q > 0) { B0 = Bn0; B1 = Bn1; }
+                f32x4 c0 = (FIRST && q == 0) ? init0(t) : acc0[t], c1 = (FIRST && q == 0) ? init1(t) : acc1[t];
+                const f16x8 Al = as_f16x8(l0), Ah = as_f16x8(h0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, as_f16x8(B0.h), c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, as_f16x8(B1.h), c1, 0, 0, 0);
+                if (uu + 1 < nu) {
+#pragma unroll
+                    for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
+                        if ((qq * nu) / NEFES_SLAB_PIECES == uu) ring.issue_piece(qq);
+                }
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, as_f16x8(B0.l), c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, as_f16x8(B1.l), c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, as_f16x8(B0.h), c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, as_f16x8(B1.h), c1, 0, 0, 0);
+                acc0[t] = c0;
+                acc1[t] = c1;
+                if (q + 1 < KS) {                                  // eight operand pairs per step (four per half)
+#pragma unroll
+                    for (int idx = 0; idx < 8; ++idx) {
+                        const bool here = NT >= 16 ? (t == 2 * idx + 1) : (NT >= 8 ? (t == idx) : (t == (idx * NT) / 8));
+                        if (here) {
+                            if (idx < 4) produce(Bn0, src0, q + 1, idx);
+                            else produce(Bn1, src1, q + 1, idx - 4);
+                        }
+                    }
+                }
+                h0 = nh; l0 = nl;
+                if (uu + 1 == nu) p = ring_lane + ring.cur_off;       // plain addressing again from the new slab's unit 0
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    ring.pf = h0;
+}
+
+__global__ __launch_bounds__(256, 1) void field_fwd_h4a_sigma_kernel(H4Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring_base = smem;
+    float* bias_lds = (float*)(smem + 2 * 32768);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    float* e_lds = bias_lds + kBlobFloats + wave * (2 * 16 * 64) + lane;       // [wave][half][16 slots][64 lanes]
+    for (int i = threadIdx.x; i < kBlobFloats; i += 256) bias_lds[i] = a.bias[i];
+    StagedRing ring;
+    ring.init(a.stream, a.n_slabs, ring_base, wave, lane);
+    const char* ring_lane = ring_base + lane * 16;
+    const char* bias_grp = (const char*)bias_lds + 16 * g;
+    const int* tab_i = (const int*)(bias_lds + kTabOff);
+    const float* tab_f = bias_lds + kTabOff;
+    auto wexp = [&](int seg) { return tab_i[2 * seg]; };
+    auto rowb = [&](int seg) { return tab_f[2 * seg + 1]; };
+    auto bmax = [&](int blk) { return tab_f[2 * kSegs + blk]; };
+    ring.prime(ring_lane);
+    auto tau_of = [&](float M, int ew) {
+        const int t = pick_exp(M);
+        return t < 100 - ew ? t : 100 - ew;
+    };
+    auto bias_at = [&](int off_floats, int es) { return BiasInit4{bias_grp + off_floats * 4, pow2i(es)}; };
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        bool ok[2];
+        uint32_t ray[2], smp[2];
+        float mE[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t m_raw = (uint32_t)tile * 128u + (uint32_t)(wave * 32 + 16 * c + j);
+            ok[c] = m_raw < (uint32_t)a.M;
+            const uint32_t m = ok[c] ? m_raw : (uint32_t)a.M - 1u;
+            ray[c] = a.s_magic ? __umulhi(m, a.s_magic) >> a.s_shift : m;
+            smp[c] = m - ray[c] * (uint32_t)a.S;
+            float x[3];
+            const float zz = a.z[m];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x[k] = add_rn(a.rays_o[ray[c] * 3 + k], mul_rn(a.rays_d[ray[c] * 3 + k], zz));
+            double t3[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t3[k] = (double)x[k] * 0.15915494309189533577;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int n = g + 4 * i;
+                float sn = 0.f, cs = 0.f;
+                if (n < 30) {
+                    const int k = n / 3, cc = n - 3 * k;
+                    sincos_turns(cc == 0 ? t3[0] : (cc == 1 ? t3[1] : t3[2]), k, sn, cs);
+                } else {
+                    sn = g == 2 ? x[0] : x[2];
+                    cs = g == 2 ? x[1] : 0.f;
+                }
+                e_lds[(c * 16 + 2 * i) * 64] = sn;
+                e_lds[(c * 16 + 2 * i + 1) * 64] = cs;
+            }
+            mE[c] = fmaxf(fmaxf(1.f, fabsf(x[0])), fmaxf(fabsf(x[1]), fabsf(x[2])));
+        }
+        f32x4 A0[kNT], A1[kNT], B0[kNT], B1[kNT];
+        int es_a[2], es_b[2] = {0, 0};
+        float M[2];
+        {
+            int tau[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { tau[c] = tau_of(mE[c], wexp(S_L1)); es_a[c] = tau[c] + wexp(S_L1); M[c] = rowb(S_L1) * mE[c] + bmax(0); }
+            run_h4a<kNT, kKSE, true>(ring, ring_lane, LdsSplit4{e_lds, pow2i(tau[0])}, LdsSplit4{e_lds + 16 * 64, pow2i(tau[1])},
+                                     bias_at(0, es_a[0]), bias_at(0, es_a[1]), A0, A1);
+        }
+#pragma unroll 1
+        for (int p = 0; p < 4; ++p) {
+            const int l1 = 2 + 2 * p, l2 = l1 + 1;
+            const int seg1 = l1 <= 5 ? l1 - 1 : l1;
+            {
+                const int ew = wexp(seg1);
+                int tau[2];
+                float mx[2] = {0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) tau[c] = tau_of(M[c], ew);
+                run_h4a<kNT, kKSH, true>(ring, ring_lane, ReluSplit4<kNT>{A0, pow2i(tau[0] - es_a[0]), mx[0]},
+                                         ReluSplit4<kNT>{A1, pow2i(tau[1] - es_a[1]), mx[1]}, bias_at((l1 - 1) * kW, tau[0] + ew),
+                                         bias_at((l1 - 1) * kW, tau[1] + ew), B0, B1);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) { M[c] = rowb(seg1) * (quad_max(mx[c]) * pow2i(-es_a[c])) + bmax(l1 - 1); es_b[c] = tau[c] + ew; }
+            }
+            if (p == 3) break;
+            {
+                const int seg2 = l2 <= 4 ? l2 - 1 : (l2 == 5 ? S_L5H : l2);
+                const int ew = wexp(seg2);
+                int tau[2];
+                float mx[2] = {0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) tau[c] = tau_of(p == 1 ? fmaxf(M[c], mE[c]) : M[c], ew);
+                run_h4a<kNT, kKSH, true>(ring, ring_lane, ReluSplit4<kNT>{B0, pow2i(tau[0] - es_b[0]), mx[0]},
+                                         ReluSplit4<kNT>{B1, pow2i(tau[1] - es_b[1]), mx[1]}, bias_at((l2 - 1) * kW, tau[0] + ew),
+                                         bias_at((l2 - 1) * kW, tau[1] + ew), A0, A1);
+                if (p == 1)
+                    run_h4a<kNT, kKSE, false>(ring, ring_lane, LdsSplit4{e_lds, pow2i(tau[0])}, LdsSplit4{e_lds + 16 * 64, pow2i(tau[1])},
+                                              ZeroInit4{}, ZeroInit4{}, A0, A1);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    M[c] = rowb(seg2) * (quad_max(mx[c]) * pow2i(-es_b[c])) + (p == 1 ? rowb(S_L5E) * mE[c] : 0.f) + bmax(l2 - 1);
+                    es_a[c] = tau[c] + ew;
+                }
+            }
+        }
+        {
+            f32x4 sg0[1], sg1[1];
+            float md0 = 0.f, md1 = 0.f;
+            int tau[2], es[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { tau[c] = tau_of(M[c], wexp(S_SIG)); es[c] = tau[c] + wexp(S_SIG); }
+            run_h4a<1, kKSH, true>(ring, ring_lane, ReluSplit4<kNT>{B0, pow2i(tau[0] - es_b[0]), md0}, ReluSplit4<kNT>{B1, pow2i(tau[1] - es_b[1]), md1},
+                                   bias_at(8 * kW, es[0]), bias_at(8 * kW, es[1]), sg0, sg1);
+            if (g == 0) {
+                if (ok[0]) __builtin_nontemporal_store(softplus_ref(sg0[0][0] * pow2i(-es[0])), &a.raw_t[(size_t)ray[0] * a.S + smp[0]]);
+                if (ok[1]) __builtin_nontemporal_store(softplus_ref(sg1[0][0] * pow2i(-es[1])), &a.raw_t[(size_t)ray[1] * a.S + smp[1]]);
+            }
+        }
+    }
+}
+
 // ---- host side: the blob -------------------------------------------------------------------------------------------------------
 struct SegDesc { int rows, real_rows, ks, layer, col0, n_cols, emb; };       // layer: index into the (weight, bias) table
 const SegDesc kSeg[kSegs] = {
@@ -514,12 +716,16 @@ extern "C" int nefes_field_fwd_h4_sigma(const NefesNetDesc* desc, const void* bl
     a.n_tiles = (int)((a.M + 127) / 128);
     magic_div((uint32_t)S, a.s_magic, a.s_shift);
     const size_t lds = 2 * 32768 + (size_t)kBlobFloats * 4 + (size_t)8 * 16 * 64 * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)field_fwd_h4_sigma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const char* lay = getenv("NEFES_H4_LAYOUT");                  // experiment switch: "a" = four waves x two halves, default "b"
+    const bool layout_a = lay && lay[0] == 'a';
+    const void* k = layout_a ? (const void*)field_fwd_h4a_sigma_kernel : (const void*)field_fwd_h4_sigma_kernel;
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = a.n_tiles < cus ? a.n_tiles : cus;
-    hipLaunchKernelGGL(field_fwd_h4_sigma_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    if (layout_a) hipLaunchKernelGGL(field_fwd_h4a_sigma_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(field_fwd_h4_sigma_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

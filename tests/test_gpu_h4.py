@@ -19,8 +19,10 @@ def rays(N, S, seed=0, scale=0.3, zmax=4.0):
     return o, d, z
 
 
+@pytest.mark.parametrize("layout", ["b", "a"])
 @pytest.mark.parametrize("N,S", [(300, 64), (1, 1), (7, 19)])
-def test_h4_sigma_matches_the_oracle(N, S):
+def test_h4_sigma_matches_the_oracle(N, S, layout, monkeypatch):
+    monkeypatch.setenv("NEFES_H4_LAYOUT", layout)
     from nefes_amd import lib as L, ops
     from nefes_amd.field import NeRFH_NFF
     net = NeRFH_NFF('coarse', W=256, f_dim=16).requires_grad_(False).to(DEV)
@@ -37,7 +39,7 @@ def test_h4_sigma_matches_the_oracle(N, S):
     ref32 = O.field_forward(p32, O.freq_encode((o[:, None] + d[:, None] * z[..., None]).reshape(-1, 3), 10), sigma_only=True)[:, 0].reshape(N, S).double()
     scale = float(ref.abs().max())
     e_hip, e_ref = float((got - ref).abs().max()) / scale, float((ref32 - ref).abs().max()) / scale
-    P.check(f"h4_sigma[{N},{S}]", "sigma", e_hip, e_ref, float((got - prod).abs().max()) / scale, tol=3e-6, factor=3.0)
+    P.check(f"h4_sigma[{layout},{N},{S}]", "sigma", e_hip, e_ref, float((got - prod).abs().max()) / scale, tol=3e-6, factor=3.0)
 
 
 def test_h4_sigma_speed_against_production():

@@ -10,7 +10,9 @@ N, S = 76800, 64
 g = torch.Generator().manual_seed(0)
 o = (torch.randn(N, 3, generator=g) * 0.3).cuda(); d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).cuda()
 z = torch.sort(torch.rand(N, S, generator=g) * 4, -1)[0].cuda()
-for name, fn in (("production", lambda: ops.field_fwd_x6(pk, L.FIELD_SIGMA, N, S, o, d, z)), ("h4", lambda: h4.forward(N, S, o, d, z))):
+for name, fn in (("production", lambda: ops.field_fwd_x6(pk, L.FIELD_SIGMA, N, S, o, d, z)), ("h4 layout b", lambda: h4.forward(N, S, o, d, z)),
+                 ("h4 layout a", lambda: h4.forward(N, S, o, d, z))):
+    os.environ["NEFES_H4_LAYOUT"] = "a" if name.endswith(" a") else "b"
     for _ in range(2): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
