@@ -229,3 +229,29 @@ def test_batched_refinement_equals_one_image_at_a_time(golden, graph):
     for b in range(B):
         p1, _ = single.refine(inits[b], targets[b], hists[b][None], 2)
         assert float((poses2[b] - p1).abs().max()) < 2e-5, (b, (poses2[b] - p1).abs().max())
+
+
+@pytest.mark.parametrize("upsample,encode_hist,world", [(False, False, False), (True, True, True), (True, False, False)])
+def test_pose_refiner_option_matrix(golden, upsample, encode_hist, world):
+    """PoseRefiner(images=2) across its options (APR / DFM variant, with and without the exposure transform and the world
+    set-up): finite, decreasing losses, and the fused glue equals the torch glue for one image."""
+    from nefes_amd import ops
+    from nefes_amd.refine import PoseRefiner
+    g = golden("refine")
+    base = refiner(g, graph=False)
+    args = types.SimpleNamespace(**vars(base.args))
+    args.encode_hist = encode_hist
+    H, W = base.H, base.W
+    ws = base.world_setup if world else None
+    tgt = T(g["target"]).to(DEV)
+    if upsample:
+        tgt = ops.bicubic_upsample(tgt[None], (H, W), crop=10)[0]
+    mk = lambda **k: PoseRefiner(base.kw, args, (H, W, base.focal * (H // base.h)), base.near, base.far, tinyscale=H // base.h,
+                                 lr_r=0.01, lr_t=0.01, world_setup=ws, upsample=upsample, graph=False, device=DEV, **k)
+    init, hist = T(g["init_c2w"]).to(DEV), T(g["hist"]).to(DEV)
+    p1, l1 = mk().refine(init, tgt, hist, 3)
+    p0, l0 = mk(fused_glue=False).refine(init, tgt, hist, 3)
+    assert torch.isfinite(l1).all() and rel(l1.cpu().numpy(), l0.cpu().numpy()) < 5e-4 and float((p1 - p0).abs().max()) < 5e-4
+    p2, l2 = mk(images=2).refine(init[None].repeat(2, 1, 1), tgt[None].repeat(2, 1, 1, 1), hist.repeat(2, 1), 3)
+    assert l2.shape == (3, 2) and torch.isfinite(l2).all() and float(l2[-1].max()) < float(l2[0].min())
+    assert rel(l2[:, 0].cpu().numpy(), l1.cpu().numpy()) < 5e-4 and rel(l2[:, 1].cpu().numpy(), l1.cpu().numpy()) < 5e-4
