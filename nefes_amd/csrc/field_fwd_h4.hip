@@ -114,6 +114,9 @@ struct ReluSplit4 {
     }
     template <bool NOP>
     __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
+    __device__ __forceinline__ void stage_c1(Split2& o, int p, const PairRegs& s) const { split_pair_hi(o, p, s.x0, s.x1, r); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
 };
 struct LdsSplit4 {
     const float* base;       // this lane's column of the parked embedding: slot s at base[s * 64]
@@ -125,6 +128,9 @@ struct LdsSplit4 {
     __device__ __forceinline__ void stage_b(PairRegs&) const {}
     template <bool NOP>
     __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
+    __device__ __forceinline__ void stage_c1(Split2& o, int p, const PairRegs& s) const { split_pair_hi(o, p, s.x0, s.x1, r); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
 };
 struct BiasInit4 {
     const char* p;            // bias block + 16 g bytes
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(512) void field_fwd_h4_sigma_kernel(H4Args a) {
 // feeds six MFMAs (three products x two halves), so the LDS traffic equals the production kernel's; the price is 2 x 2 x 64 = 256
 // accumulator registers again (one wave per SIMD) and two of every per-sample scalar.  Same blob as layout (b).
 template <int NT, int KS, bool FIRST, class Src0, class Src1, class Init0, class Init1, int NACC>
-__device__ __forceinline__ void run_h4a(StagedRing& ring, const char* ring_lane, const Src0& src0, const Src1& src1, const Init0& init0,
+__device__ __forceinline__ void run_h4a_simple(StagedRing& ring, const char* ring_lane, const Src0& src0, const Src1& src1, const Init0& init0,
                                         const Init1& init1, f32x4 (&acc0)[NACC], f32x4 (&acc1)[NACC]) {
     static_assert(NT <= NACC, "accumulator array too small");
     constexpr int UPS = 16, NU = KS * NT, NSLAB = (NU + UPS - 1) / UPS;
@@ -485,6 +491,121 @@ __device__ __forceinline__ void run_h4a(StagedRing& ring, const char* ring_lane,
     ring.pf = h0;
 }
 
+// Layout (a), 16 tiles per k-step (= one 32 KiB slab per step), with the production kernels' means (field_h3.h mma_run_h3_wide): the
+// MFMAs as asm statements on AGPR accumulators, the side work placed in their six gaps per unit, A operands requested two units ahead,
+// copy-free operand rotation.  An even tile t hosts operand pair t/2 of the NEXT step (pairs 0-3: half 0, 4-7: half 1: stage A behind
+// the first MFMA, B behind the third, C1 behind the fifth, C2 in the odd unit that follows), the odd tile one ring piece.
+__device__ __forceinline__ void mfma16_asm(f32x4& c, const f32x4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <int KS, bool FIRST, class Src0, class Src1, class Init0, class Init1, int NACC>
+__device__ __forceinline__ void run_h4a_wide(StagedRing& ring, const char* ring_lane, const Src0& src0, const Src1& src1, const Init0& init0,
+                                             const Init1& init1, f32x4 (&acc0)[NACC], f32x4 (&acc1)[NACC]) {
+    constexpr int NT = 16, UPS = 16, NU = KS * NT;
+    static_assert(NT <= NACC, "accumulator array too small");
+    Split2 Ba0, Ba1, Bb0, Bb1;                                  // operands of even / odd steps, per half
+    auto B0 = [&](int k) -> Split2& { return (k & 1) ? Bb0 : Ba0; };
+    auto B1 = [&](int k) -> Split2& { return (k & 1) ? Bb1 : Ba1; };
+    {
+        PairRegs s0;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            src0.stage_a(s0, 0, pp); src0.stage_b(s0); src0.template stage_c<false>(Ba0, pp, s0);
+            src1.stage_a(s0, 0, pp); src1.stage_b(s0);
+            if (pp == 3) src1.template stage_c<true>(Ba1, pp, s0);
+            else src1.template stage_c<false>(Ba1, pp, s0);
+        }
+    }
+    if (FIRST) { acc0[0] = init0(0); acc1[0] = init1(0); }
+    const char* p = ring_lane + ring.cur_off;
+    // A operands two units ahead (three register pairs), as in the production schedule: with ONE unit of look-ahead (two pairs, no
+    // spills) every unit waits out an LDS round trip and the kernel takes 13.8 ms instead of 11.6
+    f32x4 ha0 = ring.pf, la0 = *(const f32x4*)(p + 1024);
+    f32x4 ha1 = *(const f32x4*)(p + 2048), la1 = *(const f32x4*)(p + 3072);
+    f32x4 ha2, la2;
+    auto HA = [&](int k) -> f32x4& { return k % 3 == 0 ? ha0 : (k % 3 == 1 ? ha1 : ha2); };
+    auto LA = [&](int k) -> f32x4& { return k % 3 == 0 ? la0 : (k % 3 == 1 ? la1 : la2); };
+    PairRegs pr;                                               // one pair in flight: hosted by tile 2i, completed behind tile 2i+1's first MFMA
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int u = q * NT + t, uu = t;
+            const bool make = q + 1 < KS, host = make && (t % 2 == 0), tail = make && (t % 2 == 1);
+            const int pp = t / 2;                                  // pair hosted here / completed here
+            const bool acq = uu == UPS - 2;                        // the request for unit u + 2 crosses into the next slab here
+            const char* pn = p + (2 * uu + 4) * 1024;
+            Split2 &Bc0 = B0(q), &Bc1 = B1(q), &Bn0 = B0(q + 1), &Bn1 = B1(q + 1);
+            f32x4 &h0 = HA(u), &l0 = LA(u), &h2 = HA(u + 2), &l2 = LA(u + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (FIRST && q == 0) asm volatile("s_nop 1" : "+a"(acc0[t]), "+a"(acc1[t]));   // VALU-written C operands: two wait states
+            mfma16_asm(acc0[t], l0, Bc0.h);
+            __builtin_amdgcn_sched_barrier(0);
+            if (host) { if (pp < 4) src0.stage_a(pr, q + 1, pp); else src1.stage_a(pr, q + 1, pp - 4); }
+            if (tail) { if (pp < 4) src0.template stage_c2<false>(Bn0, pp, pr); else src1.template stage_c2<false>(Bn1, pp - 4, pr); }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16_asm(acc1[t], l0, Bc1.h);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!acq) h2 = *(const f32x4*)(pn);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::"v"(l0), "v"(Bc0.h));
+            mfma16_asm(acc0[t], h0, Bc0.l);
+            __builtin_amdgcn_sched_barrier(0);
+            if (host) { if (pp < 4) src0.stage_b(pr); else src1.stage_b(pr); }
+            if (FIRST && q == 0 && t + 1 < NT) { acc0[t + 1] = init0(t + 1); acc1[t + 1] = init1(t + 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::"v"(Bc1.h));
+            mfma16_asm(acc1[t], h0, Bc1.l);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!host) {
+#pragma unroll
+                for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
+                    if (2 * qq + 1 == uu && uu < UPS - 2) ring.store_piece(qq);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::"v"(Bc0.l));
+            mfma16_asm(acc0[t], h0, Bc0.h);
+            __builtin_amdgcn_sched_barrier(0);
+            if (host) { if (pp < 4) src0.stage_c1(Bn0, pp, pr); else src1.stage_c1(Bn1, pp - 4, pr); }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::"v"(Bc1.l));
+            mfma16_asm(acc1[t], h0, Bc1.h);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!host) {
+#pragma unroll
+                for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
+                    if (2 * qq + 1 == uu && uu < UPS - 2) ring.fetch_piece(qq);
+            }
+            if (acq) {                                             // the last piece goes in front of the acquire
+#pragma unroll
+                for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
+                    if (2 * qq + 1 >= UPS - 2) { ring.store_piece(qq); ring.fetch_piece(qq); }
+                ring.cur_off = ring.acquire();
+                p = ring_lane + ring.cur_off - (size_t)UPS * 2048;      // unit index uu + 2 >= 16 addresses the new slab
+                pn = p + (2 * uu + 4) * 1024;
+                h2 = *(const f32x4*)(pn);
+            }
+            l2 = *(const f32x4*)(pn + 1024);
+            if (uu + 1 == UPS) p = ring_lane + ring.cur_off;
+            asm volatile("" ::"v"(h0), "v"(Bc0.h), "v"(Bc1.h));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    ring.pf = HA(NU);
+    // the functor of the next layer reads these tiles with the vector ALU: wait states after the last MFMAs (4 passes each)
+    asm volatile("s_nop 7\n\ts_nop 3" : "+a"(acc0[NT - 1]), "+a"(acc1[NT - 1]), "+a"(acc0[NT - 2]), "+a"(acc1[NT - 2]));
+}
+
+template <int NT, int KS, bool FIRST, class Src0, class Src1, class Init0, class Init1, int NACC>
+__device__ __forceinline__ void run_h4a(StagedRing& ring, const char* ring_lane, const Src0& src0, const Src1& src1, const Init0& init0,
+                                        const Init1& init1, f32x4 (&acc0)[NACC], f32x4 (&acc1)[NACC]) {
+#ifndef H4A_NOWIDE
+    if constexpr (NT == 16) run_h4a_wide<KS, FIRST>(ring, ring_lane, src0, src1, init0, init1, acc0, acc1);
+    else
+#endif
+        run_h4a_simple<NT, KS, FIRST>(ring, ring_lane, src0, src1, init0, init1, acc0, acc1);
+}
+
 __global__ __launch_bounds__(256, 1) void field_fwd_h4a_sigma_kernel(H4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring_base = smem;
@@ -511,20 +632,24 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h4a_sigma_kernel(H4Args a) {
     auto bias_at = [&](int off_floats, int es) { return BiasInit4{bias_grp + off_floats * 4, pow2i(es)}; };
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        bool ok[2];
-        uint32_t ray[2], smp[2];
+        // sample / ray indices are recomputed where they are needed (here and at the output) rather than kept alive across the tile
+        auto locate = [&](int c, uint32_t& m, uint32_t& ray, uint32_t& smp) {
+            const uint32_t m_raw = (uint32_t)tile * 128u + (uint32_t)(wave * 32 + 16 * c + j);
+            const bool okc = m_raw < (uint32_t)a.M;
+            m = okc ? m_raw : (uint32_t)a.M - 1u;
+            ray = a.s_magic ? __umulhi(m, a.s_magic) >> a.s_shift : m;
+            smp = m - ray * (uint32_t)a.S;
+            return okc;
+        };
         float mE[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const uint32_t m_raw = (uint32_t)tile * 128u + (uint32_t)(wave * 32 + 16 * c + j);
-            ok[c] = m_raw < (uint32_t)a.M;
-            const uint32_t m = ok[c] ? m_raw : (uint32_t)a.M - 1u;
-            ray[c] = a.s_magic ? __umulhi(m, a.s_magic) >> a.s_shift : m;
-            smp[c] = m - ray[c] * (uint32_t)a.S;
+            uint32_t m, ray, smp;
+            locate(c, m, ray, smp);
             float x[3];
             const float zz = a.z[m];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) x[k] = add_rn(a.rays_o[ray[c] * 3 + k], mul_rn(a.rays_d[ray[c] * 3 + k], zz));
+            for (int k = 0; k < 3; ++k) x[k] = add_rn(a.rays_o[ray * 3 + k], mul_rn(a.rays_d[ray * 3 + k], zz));
             double t3[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) t3[k] = (double)x[k] * 0.15915494309189533577;
@@ -600,8 +725,9 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h4a_sigma_kernel(H4Args a) {
             run_h4a<1, kKSH, true>(ring, ring_lane, ReluSplit4<kNT>{B0, pow2i(tau[0] - es_b[0]), md0}, ReluSplit4<kNT>{B1, pow2i(tau[1] - es_b[1]), md1},
                                    bias_at(8 * kW, es[0]), bias_at(8 * kW, es[1]), sg0, sg1);
             if (g == 0) {
-                if (ok[0]) __builtin_nontemporal_store(softplus_ref(sg0[0][0] * pow2i(-es[0])), &a.raw_t[(size_t)ray[0] * a.S + smp[0]]);
-                if (ok[1]) __builtin_nontemporal_store(softplus_ref(sg1[0][0] * pow2i(-es[1])), &a.raw_t[(size_t)ray[1] * a.S + smp[1]]);
+                uint32_t m, ray, smp;
+                if (locate(0, m, ray, smp)) __builtin_nontemporal_store(softplus_ref(sg0[0][0] * pow2i(-es[0])), &a.raw_t[(size_t)ray * a.S + smp]);
+                if (locate(1, m, ray, smp)) __builtin_nontemporal_store(softplus_ref(sg1[0][0] * pow2i(-es[1])), &a.raw_t[(size_t)ray * a.S + smp]);
             }
         }
     }
