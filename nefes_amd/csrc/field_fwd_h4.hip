@@ -411,12 +411,64 @@ __global__ __launch_bounds__(512) void field_fwd_h4_sigma_kernel(H4Args a) {
     }
 }
 
+// The four-wave ring with HALF a slab of staging registers (layout (a) has no room for StagedRing's 32): register k carries pieces
+// k and k + 4 of every slab in turn -- right behind the store of a piece the piece four places on is requested, so a load has four
+// piece slots (eight units) to land instead of a whole slab.
+struct Ring4 {
+    const char* src;
+    uint32_t n_slabs, g_next, c_slot, cur_off, my_off;   // g_next: slab the pieces k < 4 that are requested next belong to
+    char* my_lds;
+    f32x4 pf;
+    f32x4 stage[4];
+    __device__ __forceinline__ const char* piece_src(uint32_t slab, int q) const { return src + (size_t)slab * 32768 + my_off + q * 1024; }
+    __device__ __forceinline__ void init(const char* stream, uint32_t nslabs, char* ring_base, int wave, int lane) {
+        src = stream; n_slabs = nslabs;
+        my_off = (uint32_t)(wave * 8192 + lane * 16);
+        my_lds = ring_base + my_off;
+        c_slot = 0; cur_off = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                                     // slab 0 -> slot 0, four pieces at a time
+#pragma unroll
+            for (int k = 0; k < 4; ++k) stage[k] = *(const f32x4*)piece_src(0, 4 * h + k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *(f32x4*)(my_lds + (4 * h + k) * 1024) = stage[k];
+        }
+        g_next = n_slabs > 1 ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) stage[k] = *(const f32x4*)piece_src(g_next, k);       // first half of slab 1 in flight
+    }
+    // piece q of the slab after the one being consumed: registers -> the idle slot; then request the piece four places on
+    __device__ __forceinline__ void store_piece(int q) { *(f32x4*)(my_lds + (c_slot ^ 1u) * 32768 + q * 1024) = stage[q & 3]; }
+    __device__ __forceinline__ void fetch_piece(int q) {
+        if (q < 4) {
+            stage[q] = *(const f32x4*)piece_src(g_next, q + 4);
+        } else {
+            const uint32_t nxt = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
+            stage[q & 3] = *(const f32x4*)piece_src(nxt, q - 4);
+            if (q == 7) g_next = nxt;
+        }
+    }
+    __device__ __forceinline__ void issue_piece(int q) { store_piece(q); fetch_piece(q); }
+    __device__ __forceinline__ uint32_t acquire() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        c_slot ^= 1u;
+        return c_slot * 32768;
+    }
+    __device__ __forceinline__ void prime(const char* ring_lane) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur_off = 0;
+        pf = *(const f32x4*)(ring_lane);
+    }
+};
+
 // ================================================================================================================================
 // Layout (a): FOUR waves, each lane serving TWO 16-sample halves (samples 32 w + j and 32 w + 16 + j): every A operand read from LDS
 // feeds six MFMAs (three products x two halves), so the LDS traffic equals the production kernel's; the price is 2 x 2 x 64 = 256
 // accumulator registers again (one wave per SIMD) and two of every per-sample scalar.  Same blob as layout (b).
 template <int NT, int KS, bool FIRST, class Src0, class Src1, class Init0, class Init1, int NACC>
-__device__ __forceinline__ void run_h4a_simple(StagedRing& ring, const char* ring_lane, const Src0& src0, const Src1& src1, const Init0& init0,
+__device__ __forceinline__ void run_h4a_simple(Ring4& ring, const char* ring_lane, const Src0& src0, const Src1& src1, const Init0& init0,
                                         const Init1& init1, f32x4 (&acc0)[NACC], f32x4 (&acc1)[NACC]) {
     static_assert(NT <= NACC, "accumulator array too small");
     constexpr int UPS = 16, NU = KS * NT, NSLAB = (NU + UPS - 1) / UPS;
@@ -499,7 +551,7 @@ __device__ __forceinline__ void mfma16_asm(f32x4& c, const f32x4& a, const u32x4
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 template <int KS, bool FIRST, class Src0, class Src1, class Init0, class Init1, int NACC>
-__device__ __forceinline__ void run_h4a_wide(StagedRing& ring, const char* ring_lane, const Src0& src0, const Src1& src1, const Init0& init0,
+__device__ __forceinline__ void run_h4a_wide(Ring4& ring, const char* ring_lane, const Src0& src0, const Src1& src1, const Init0& init0,
                                              const Init1& init1, f32x4 (&acc0)[NACC], f32x4 (&acc1)[NACC]) {
     constexpr int NT = 16, UPS = 16, NU = KS * NT;
     static_assert(NT <= NACC, "accumulator array too small");
@@ -541,18 +593,26 @@ __device__ __forceinline__ void run_h4a_wide(StagedRing& ring, const char* ring_
             if (FIRST && q == 0) asm volatile("s_nop 1" : "+a"(acc0[t]), "+a"(acc1[t]));   // VALU-written C operands: two wait states
             mfma16_asm(acc0[t], l0, Bc0.h);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef H4A_ABL_NOSPLIT
             if (host) { if (pp < 4) src0.stage_a(pr, q + 1, pp); else src1.stage_a(pr, q + 1, pp - 4); }
             if (tail) { if (pp < 4) src0.template stage_c2<false>(Bn0, pp, pr); else src1.template stage_c2<false>(Bn1, pp - 4, pr); }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             mfma16_asm(acc1[t], l0, Bc1.h);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef H4A_ABL_NOAREAD
             if (!acq) h2 = *(const f32x4*)(pn);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::"v"(l0), "v"(Bc0.h));
             mfma16_asm(acc0[t], h0, Bc0.l);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef H4A_ABL_NOSPLIT
             if (host) { if (pp < 4) src0.stage_b(pr); else src1.stage_b(pr); }
+#endif
+#ifndef H4A_ABL_NOBIAS
             if (FIRST && q == 0 && t + 1 < NT) { acc0[t + 1] = init0(t + 1); acc1[t + 1] = init1(t + 1); }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::"v"(Bc1.h));
             mfma16_asm(acc1[t], h0, Bc1.l);
@@ -560,13 +620,19 @@ __device__ __forceinline__ void run_h4a_wide(StagedRing& ring, const char* ring_
             if (!host) {
 #pragma unroll
                 for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
-                    if (2 * qq + 1 == uu && uu < UPS - 2) ring.store_piece(qq);
+                    if (2 * qq + 1 == uu && uu < UPS - 2) {
+#ifndef H4A_ABL_NORING
+                        ring.store_piece(qq);
+#endif
+                    }
             }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::"v"(Bc0.l));
             mfma16_asm(acc0[t], h0, Bc0.h);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef H4A_ABL_NOSPLIT
             if (host) { if (pp < 4) src0.stage_c1(Bn0, pp, pr); else src1.stage_c1(Bn1, pp - 4, pr); }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::"v"(Bc1.l));
             mfma16_asm(acc1[t], h0, Bc1.h);
@@ -574,7 +640,13 @@ __device__ __forceinline__ void run_h4a_wide(StagedRing& ring, const char* ring_
             if (!host) {
 #pragma unroll
                 for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
-                    if (2 * qq + 1 == uu && uu < UPS - 2) ring.fetch_piece(qq);
+                    if (2 * qq + 1 == uu && uu < UPS - 2) {
+#ifndef H4A_ABL_NORING
+                        ring.fetch_piece(qq);
+#else
+                        if (qq == 7) ring.g_next = (ring.g_next + 1 == ring.n_slabs) ? 0 : ring.g_next + 1;
+#endif
+                    }
             }
             if (acq) {                                             // the last piece goes in front of the acquire
 #pragma unroll
@@ -585,7 +657,11 @@ __device__ __forceinline__ void run_h4a_wide(StagedRing& ring, const char* ring_
                 pn = p + (2 * uu + 4) * 1024;
                 h2 = *(const f32x4*)(pn);
             }
+#ifndef H4A_ABL_NOAREAD
             l2 = *(const f32x4*)(pn + 1024);
+#else
+            h2 = h0; l2 = l0;
+#endif
             if (uu + 1 == UPS) p = ring_lane + ring.cur_off;
             asm volatile("" ::"v"(h0), "v"(Bc0.h), "v"(Bc1.h));
             __builtin_amdgcn_sched_barrier(0);
@@ -597,7 +673,7 @@ __device__ __forceinline__ void run_h4a_wide(StagedRing& ring, const char* ring_
 }
 
 template <int NT, int KS, bool FIRST, class Src0, class Src1, class Init0, class Init1, int NACC>
-__device__ __forceinline__ void run_h4a(StagedRing& ring, const char* ring_lane, const Src0& src0, const Src1& src1, const Init0& init0,
+__device__ __forceinline__ void run_h4a(Ring4& ring, const char* ring_lane, const Src0& src0, const Src1& src1, const Init0& init0,
                                         const Init1& init1, f32x4 (&acc0)[NACC], f32x4 (&acc1)[NACC]) {
 #ifndef H4A_NOWIDE
     if constexpr (NT == 16) run_h4a_wide<KS, FIRST>(ring, ring_lane, src0, src1, init0, init1, acc0, acc1);
@@ -615,7 +691,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h4a_sigma_kernel(H4Args a) {
     const int j = lane & 15, g = lane >> 4;
     float* e_lds = bias_lds + kBlobFloats + wave * (2 * 16 * 64) + lane;       // [wave][half][16 slots][64 lanes]
     for (int i = threadIdx.x; i < kBlobFloats; i += 256) bias_lds[i] = a.bias[i];
-    StagedRing ring;
+    Ring4 ring;
     ring.init(a.stream, a.n_slabs, ring_base, wave, lane);
     const char* ring_lane = ring_base + lane * 16;
     const char* bias_grp = (const char*)bias_lds + 16 * g;
