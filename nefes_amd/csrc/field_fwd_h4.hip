@@ -26,9 +26,18 @@
 #include "field_x6.h"
 #include "field_h3.h"
 
+// Built twice (Makefile): H4_W = 256 with 8 waves per workgroup (the headline network; this object also holds layout (a) and the C
+// entry points) and H4_W = 128 with 16 waves (the width every configuration file of the reference uses: 2 x 8 tiles x 4 = 64
+// accumulator registers per wave, four waves per SIMD, 256 samples per pass over the weight stream).
+#ifndef H4_W
+#define H4_W 256
+#endif
+#ifndef H4_NW
+#define H4_NW 8
+#endif
 namespace {
 
-constexpr int kW = 256, kNT = kW / 16, kKSH = kW / 32, kKSE = 2, kSegs = 10, kBiasBlocks = 9;
+constexpr int kW = H4_W, kNW = H4_NW, kPieces = 32 / kNW, kNT = kW / 16, kKSH = kW / 32, kKSE = 2, kSegs = 10, kBiasBlocks = 9;
 constexpr int kBiasFloats = 8 * kW + 16;                       // L1..L8, then the sigma head's tile (row 0 real)
 constexpr int kTabOff = kBiasFloats;                            // (exp, bound) per segment, then max |b| per bias block
 constexpr int kBlobFloats = ((kTabOff + 2 * kSegs + kBiasBlocks + 63) / 64) * 64;
@@ -56,32 +65,32 @@ struct H4Args {
     uint32_t s_magic, s_shift;
 };
 
-// weight ring through registers for 8 waves: each wave moves four 1 KiB pieces of every 32 KiB slab (field_h3.h StagedRing)
+// weight ring through registers for kNW waves: each wave moves kPieces 1 KiB pieces of every 32 KiB slab (field_h3.h StagedRing)
 struct Ring8 {
     const char* src;
     uint32_t n_slabs, g_next, c_slot, cur_off, my_off;
     char* my_lds;
     f32x4 pf;
-    f32x4 stage[4];
+    f32x4 stage[kPieces];
     __device__ __forceinline__ void load_piece(int q) { stage[q] = *(const f32x4*)(src + (size_t)g_next * 32768 + my_off + q * 1024); }
     __device__ __forceinline__ void init(const char* stream, uint32_t nslabs, char* ring_base, int wave, int lane) {
         src = stream; n_slabs = nslabs;
-        my_off = (uint32_t)(wave * 4096 + lane * 16);
+        my_off = (uint32_t)(wave * (kPieces * 1024) + lane * 16);
         my_lds = ring_base + my_off;
         g_next = 0; c_slot = 0; cur_off = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) load_piece(q);
+        for (int q = 0; q < kPieces; ++q) load_piece(q);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *(f32x4*)(my_lds + q * 1024) = stage[q];
+        for (int q = 0; q < kPieces; ++q) *(f32x4*)(my_lds + q * 1024) = stage[q];
         g_next = n_slabs > 1 ? 1 : 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) load_piece(q);
+        for (int q = 0; q < kPieces; ++q) load_piece(q);
         g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
     }
     __device__ __forceinline__ void issue_piece(int q) {
         *(f32x4*)(my_lds + (c_slot ^ 1u) * 32768 + q * 1024) = stage[q];
         load_piece(q);
-        if (q == 3) g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
+        if (q == kPieces - 1) g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
     }
     __device__ __forceinline__ uint32_t acquire() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -177,8 +186,8 @@ __device__ __forceinline__ void run_h4_single(Ring8& ring, const char* ring_lane
                     nh = *(const f32x4*)(p + (2 * uu + 2) * 1024);
                 } else {
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq)
-                        if ((qq * nu) / 4 >= uu) ring.issue_piece(qq);
+                    for (int qq = 0; qq < kPieces; ++qq)
+                        if ((qq * nu) / kPieces >= uu) ring.issue_piece(qq);
                     ring.cur_off = ring.acquire();
                     p = ring_lane + ring.cur_off;
                     nh = *(const f32x4*)(p);
@@ -190,8 +199,8 @@ __device__ __forceinline__ void run_h4_single(Ring8& ring, const char* ring_lane
                 al = *(const f32x4*)(p + (last ? 1 : 2 * uu + 3) * 1024);
                 if (uu + 1 < nu) {
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq)
-                        if ((qq * nu) / 4 == uu) ring.issue_piece(qq);
+                    for (int qq = 0; qq < kPieces; ++qq)
+                        if ((qq * nu) / kPieces == uu) ring.issue_piece(qq);
                 }
                 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, c, 0, 0, 0);
@@ -253,8 +262,8 @@ __device__ __forceinline__ void run_h4_pairs(Ring8& ring, const char* ring_lane,
 #endif
                 } else {
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq)
-                        if ((qq * nu) / 4 >= uu) ring.issue_piece(qq);
+                    for (int qq = 0; qq < kPieces; ++qq)
+                        if ((qq * nu) / kPieces >= uu) ring.issue_piece(qq);
                     ring.cur_off = ring.acquire();
                     p = ring_lane + ring.cur_off;
                     nh0 = *(const f32x4*)(p); nl0 = *(const f32x4*)(p + 1024); nh1 = *(const f32x4*)(p + 2048); nl1 = *(const f32x4*)(p + 3072);
@@ -269,8 +278,8 @@ __device__ __forceinline__ void run_h4_pairs(Ring8& ring, const char* ring_lane,
                 c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(l1), Bh, c1, 0, 0, 0);
                 if (!last) {
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq)
-                        if ((qq * nu) / 4 == uu) ring.issue_piece(qq);
+                    for (int qq = 0; qq < kPieces; ++qq)
+                        if ((qq * nu) / kPieces == uu) ring.issue_piece(qq);
                 }
                 c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(h0), Bl, c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(h1), Bl, c1, 0, 0, 0);
@@ -311,7 +320,7 @@ __device__ __forceinline__ float quad_max(float m) {
     return fmaxf(m, __shfl_xor(m, 16));
 }
 
-__global__ __launch_bounds__(512) void field_fwd_h4_sigma_kernel(H4Args a) {
+__global__ __launch_bounds__(64 * kNW) void field_fwd_h4_sigma_kernel(H4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring_base = smem;
     float* bias_lds = (float*)(smem + 2 * 32768);
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(512) void field_fwd_h4_sigma_kernel(H4Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
     float* e_lds = bias_lds + kBlobFloats + wave * (16 * 64) + lane;           // [wave][16 slots][64 lanes]
-    for (int i = threadIdx.x; i < kBlobFloats; i += 512) bias_lds[i] = a.bias[i];
+    for (int i = threadIdx.x; i < kBlobFloats; i += 64 * kNW) bias_lds[i] = a.bias[i];
     Ring8 ring;
     ring.init(a.stream, a.n_slabs, ring_base, wave, lane);
     const char* ring_lane = ring_base + lane * 16;
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(512) void field_fwd_h4_sigma_kernel(H4Args a) {
     auto bias_at = [&](int off_floats, int es) { return BiasInit4{bias_grp + off_floats * 4, pow2i(es)}; };
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const uint32_t m_raw = (uint32_t)tile * 128u + (uint32_t)(wave * 16 + j);
+        const uint32_t m_raw = (uint32_t)tile * (uint32_t)(16 * kNW) + (uint32_t)(wave * 16 + j);
         const bool ok = m_raw < (uint32_t)a.M;
         const uint32_t m = ok ? m_raw : (uint32_t)a.M - 1u;
         const uint32_t ray = a.s_magic ? __umulhi(m, a.s_magic) >> a.s_shift : m;
@@ -411,6 +420,7 @@ __global__ __launch_bounds__(512) void field_fwd_h4_sigma_kernel(H4Args a) {
     }
 }
 
+#if H4_W == 256
 // The four-wave ring with HALF a slab of staging registers (layout (a) has no room for StagedRing's 32): register k carries pieces
 // k and k + 4 of every slab in turn -- right behind the store of a piece the piece four places on is requested, so a load has four
 // piece slots (eight units) to land instead of a whole slab.
@@ -809,15 +819,17 @@ __global__ __launch_bounds__(256, 1) void field_fwd_h4a_sigma_kernel(H4Args a) {
     }
 }
 
+#endif   // layout (a): H4_W == 256 only
+
 // ---- host side: the blob -------------------------------------------------------------------------------------------------------
 struct SegDesc { int rows, real_rows, ks, layer, col0, n_cols, emb; };       // layer: index into the (weight, bias) table
 const SegDesc kSeg[kSegs] = {
-    {256, 256, kKSE, 0, 0, 63, 1},  {256, 256, kKSH, 1, 0, 256, 0}, {256, 256, kKSH, 2, 0, 256, 0}, {256, 256, kKSH, 3, 0, 256, 0},
-    {256, 256, kKSH, 4, 63, 256, 0}, {256, 256, kKSE, 4, 0, 63, 1}, {256, 256, kKSH, 5, 0, 256, 0}, {256, 256, kKSH, 6, 0, 256, 0},
-    {256, 256, kKSH, 7, 0, 256, 0},  {16, 1, kKSH, 10, 0, 256, 0}};
+    {kW, kW, kKSE, 0, 0, 63, 1},  {kW, kW, kKSH, 1, 0, kW, 0}, {kW, kW, kKSH, 2, 0, kW, 0}, {kW, kW, kKSH, 3, 0, kW, 0},
+    {kW, kW, kKSH, 4, 63, kW, 0}, {kW, kW, kKSE, 4, 0, 63, 1}, {kW, kW, kKSH, 5, 0, kW, 0}, {kW, kW, kKSH, 6, 0, kW, 0},
+    {kW, kW, kKSH, 7, 0, kW, 0},  {16, 1, kKSH, 10, 0, kW, 0}};
 int seg_slabs(const SegDesc& s) { return (s.ks * (s.rows / 16) + 15) / 16; }
 int total_slabs() { int n = 0; for (const auto& s : kSeg) n += seg_slabs(s); return n; }
-int ld_of(int layer) { return layer == 0 ? 63 : (layer == 4 ? 63 + 256 : 256); }
+int ld_of(int layer) { return layer == 0 ? 63 : (layer == 4 ? 63 + kW : kW); }
 
 uint16_t f16_bits(float f) { const _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
 float f16_val(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
@@ -833,14 +845,38 @@ void magic_div(uint32_t d, uint32_t& magic, uint32_t& shift) {
 
 }  // namespace
 
-extern "C" size_t nefes_h4_sigma_blob_bytes(const NefesNetDesc* desc) {
-    if (!desc || desc->width != 256 || desc->xyz_encoding != NEFES_XYZ_FREQ10) return 0;
+// the H4_W = 128 object exports these three under other names; the H4_W = 256 object holds the C entry points and forwards
+size_t nefes_h4_w128_blob_bytes(const NefesNetDesc* desc);
+int nefes_h4_w128_pack(const NefesNetDesc* desc, const float* const* tensors, int n_tensors, void* blob, size_t blob_bytes);
+int nefes_h4_w128_fwd(const NefesNetDesc* desc, const void* blob, int N, int S, const float* rays_o, const float* rays_d, const float* z,
+                      float* raw_t, void* stream);
+#if H4_W == 256
+#define H4_FN(name) extern "C" name
+#define H4_BYTES nefes_h4_sigma_blob_bytes
+#define H4_PACK nefes_h4_sigma_pack
+#define H4_FWD nefes_field_fwd_h4_sigma
+#else
+#define H4_FN(name) name
+#define H4_BYTES nefes_h4_w128_blob_bytes
+#define H4_PACK nefes_h4_w128_pack
+#define H4_FWD nefes_h4_w128_fwd
+#endif
+
+H4_FN(size_t) H4_BYTES(const NefesNetDesc* desc) {
+    if (!desc || desc->xyz_encoding != NEFES_XYZ_FREQ10) return 0;
+#if H4_W == 256
+    if (desc->width == 128) return nefes_h4_w128_blob_bytes(desc);
+#endif
+    if (desc->width != kW) return 0;
     return (size_t)kBlobFloats * 4 + (size_t)total_slabs() * 32768;
 }
 
 // tensors: the (weight, bias) table of nefes_pack_weights (xyz_encoding_1..8, xyz_encoding_final, dir_encoding, static_sigma, ...)
-extern "C" int nefes_h4_sigma_pack(const NefesNetDesc* desc, const float* const* tensors, int n_tensors, void* blob, size_t blob_bytes) {
-    const size_t need = nefes_h4_sigma_blob_bytes(desc);
+H4_FN(int) H4_PACK(const NefesNetDesc* desc, const float* const* tensors, int n_tensors, void* blob, size_t blob_bytes) {
+#if H4_W == 256
+    if (desc && desc->width == 128) return nefes_h4_w128_pack(desc, tensors, n_tensors, blob, blob_bytes);
+#endif
+    const size_t need = H4_BYTES(desc);
     if (!need) return NEFES_E_UNSUPPORTED;
     if (!tensors || n_tensors < 22 || !blob || blob_bytes < need) return NEFES_E_BADARG;
     memset(blob, 0, need);
@@ -850,10 +886,10 @@ extern "C" int nefes_h4_sigma_pack(const NefesNetDesc* desc, const float* const*
     for (int l = 0; l < 8; ++l) {
         const float* b = tensors[2 * l + 1];
         float mb = 0.f;
-        for (int i = 0; i < 256; ++i) { fl[l * 256 + i] = b[i]; mb = fmaxf(mb, fabsf(b[i])); }
+        for (int i = 0; i < kW; ++i) { fl[l * kW + i] = b[i]; mb = fmaxf(mb, fabsf(b[i])); }
         tab_f[2 * kSegs + l] = mb;
     }
-    fl[8 * 256] = tensors[21][0];
+    fl[8 * kW] = tensors[21][0];
     tab_f[2 * kSegs + 8] = fabsf(tensors[21][0]);
     // weight exponents: max |w| 2^e in [2^14, 2^15); the two parts of layer 5 share one (they accumulate into the same tiles)
     int wexp[kSegs];
@@ -904,9 +940,12 @@ extern "C" int nefes_h4_sigma_pack(const NefesNetDesc* desc, const float* const*
     return 0;
 }
 
-extern "C" int nefes_field_fwd_h4_sigma(const NefesNetDesc* desc, const void* blob, int N, int S, const float* rays_o, const float* rays_d,
+H4_FN(int) H4_FWD(const NefesNetDesc* desc, const void* blob, int N, int S, const float* rays_o, const float* rays_d,
                                         const float* z, float* raw_t, void* stream) {
-    if (!nefes_h4_sigma_blob_bytes(desc)) return NEFES_E_UNSUPPORTED;
+#if H4_W == 256
+    if (desc && desc->width == 128) return nefes_h4_w128_fwd(desc, blob, N, S, rays_o, rays_d, z, raw_t, stream);
+#endif
+    if (!H4_BYTES(desc)) return NEFES_E_UNSUPPORTED;
     if (!blob || !rays_o || !rays_d || !z || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
     H4Args a;
     a.bias = (const float*)blob;
@@ -915,19 +954,28 @@ extern "C" int nefes_field_fwd_h4_sigma(const NefesNetDesc* desc, const void* bl
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.raw_t = raw_t; a.N = N; a.S = S;
     a.M = (long long)N * S;
     if (a.M >= (1ll << 31) - 256) return NEFES_E_UNSUPPORTED;
-    a.n_tiles = (int)((a.M + 127) / 128);
+    a.n_tiles = (int)((a.M + 16 * kNW - 1) / (16 * kNW));
     magic_div((uint32_t)S, a.s_magic, a.s_shift);
-    const size_t lds = 2 * 32768 + (size_t)kBlobFloats * 4 + (size_t)8 * 16 * 64 * 4;
+    const size_t lds = 2 * 32768 + (size_t)kBlobFloats * 4 + (size_t)kNW * 16 * 64 * 4;
+#if H4_W == 256
     const char* lay = getenv("NEFES_H4_LAYOUT");                  // experiment switch: "a" = four waves x two halves, default "b"
     const bool layout_a = lay && lay[0] == 'a';
     const void* k = layout_a ? (const void*)field_fwd_h4a_sigma_kernel : (const void*)field_fwd_h4_sigma_kernel;
+#else
+    const bool layout_a = false;
+    const void* k = (const void*)field_fwd_h4_sigma_kernel;
+#endif
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = a.n_tiles < cus ? a.n_tiles : cus;
+#if H4_W == 256
     if (layout_a) hipLaunchKernelGGL(field_fwd_h4a_sigma_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(field_fwd_h4_sigma_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    else
+#endif
+        hipLaunchKernelGGL(field_fwd_h4_sigma_kernel, dim3(grid), dim3(64 * kNW), lds, (hipStream_t)stream, a);
+    (void)layout_a;
     return (int)hipGetLastError();
 }

@@ -718,7 +718,7 @@ class H4Sigma:
         self.desc = L.NefesNetDesc(int(net.W), int(net.W_features), 0, L.XYZ_FREQ10)
         n = lib.nefes_h4_sigma_blob_bytes(self.desc)
         if n == 0:
-            raise RuntimeError("nefes_amd: the 16x16x32 experiment is built for Wd = 256 with the frequency embedding")
+            raise RuntimeError("nefes_amd: the 16x16x32 experiment is built for Wd = 256 / 128 with the frequency embedding")
         sd = dict(net.named_parameters())
         tens = [sd[name + s].detach().to("cpu", torch.float32).contiguous() for name in PackedField.LAYERS_COARSE for s in (".weight", ".bias")]
         ptrs = (C.c_void_p * len(tens))(*[t.data_ptr() for t in tens])
