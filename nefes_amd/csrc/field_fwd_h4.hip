@@ -106,6 +106,17 @@ struct Ring8 {
     }
 };
 
+// The split of one pair as NINE single instructions (layout (a) places them one per 16-cycle MFMA gap):
+//   m0/m1: fetch x0 / x1     m2/m3: ReLU     m4: running maximum     m5/m6: hi halves     m7/m8: lo halves
+struct MicroPair { float x0, x1; uint32_t h, l; };
+__device__ __forceinline__ void mix_hi_lo(uint32_t& h, float x, float r) { asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x), "v"(r)); }
+__device__ __forceinline__ void mix_hi_hi(uint32_t& h, float x, float r) { asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x), "v"(r)); }
+__device__ __forceinline__ void mix_lo_lo(uint32_t& l, float x, float r, uint32_t h) {
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x), "v"(r), "v"(h));
+}
+__device__ __forceinline__ void mix_lo_hi(uint32_t& l, float x, float r, uint32_t h) {
+    asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x), "v"(r), "v"(h));
+}
 // B-operand sources on 16-row tiles: pair p (0..3) of 32-k step q = registers 2 (p & 1), +1 of tile T0 + 2 q + (p >> 1)
 template <int NX, int T0 = 0>
 struct ReluSplit4 {
@@ -126,6 +137,17 @@ struct ReluSplit4 {
     __device__ __forceinline__ void stage_c1(Split2& o, int p, const PairRegs& s) const { split_pair_hi(o, p, s.x0, s.x1, r); }
     template <bool NOP>
     __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
+    __device__ __forceinline__ void micro(int k, MicroPair& s, Split2& o, int q, int p) const {
+        if (k == 0) s.x0 = X[T0 + 2 * q + (p >> 1)][2 * (p & 1)];
+        if (k == 1) s.x1 = X[T0 + 2 * q + (p >> 1)][2 * (p & 1) + 1];
+        if (k == 2) s.x0 = relu1<false>(s.x0);
+        if (k == 3) s.x1 = relu1<false>(s.x1);
+        if (k == 4) max3_acc(m, s.x0, s.x1);
+        if (k == 5) mix_hi_lo(s.h, s.x0, r);
+        if (k == 6) { mix_hi_hi(s.h, s.x1, r); o.h[p] = s.h; }
+        if (k == 7) mix_lo_lo(s.l, s.x0, r, s.h);
+        if (k == 8) { mix_lo_hi(s.l, s.x1, r, s.h); o.l[p] = s.l; }
+    }
 };
 struct LdsSplit4 {
     const float* base;       // this lane's column of the parked embedding: slot s at base[s * 64]
@@ -140,16 +162,27 @@ struct LdsSplit4 {
     __device__ __forceinline__ void stage_c1(Split2& o, int p, const PairRegs& s) const { split_pair_hi(o, p, s.x0, s.x1, r); }
     template <bool NOP>
     __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
+    __device__ __forceinline__ void micro(int k, MicroPair& s, Split2& o, int q, int p) const {
+        if (k == 0) s.x0 = base[(8 * q + 2 * p) * 64];
+        if (k == 1) s.x1 = base[(8 * q + 2 * p + 1) * 64];
+        if (k == 5) mix_hi_lo(s.h, s.x0, r);
+        if (k == 6) { mix_hi_hi(s.h, s.x1, r); o.h[p] = s.h; }
+        if (k == 7) mix_lo_lo(s.l, s.x0, r, s.h);
+        if (k == 8) { mix_lo_hi(s.l, s.x1, r, s.h); o.l[p] = s.l; }
+    }
 };
 struct BiasInit4 {
     const char* p;            // bias block + 16 g bytes
     float s;
+    __device__ __forceinline__ f32x4 raw(int t) const { return *(const f32x4*)(p + t * 64); }
     __device__ __forceinline__ f32x4 operator()(int t) const {
-        const f32x4 b = *(const f32x4*)(p + t * 64);
+        const f32x4 b = raw(t);
         return f32x4{b[0] * s, b[1] * s, b[2] * s, b[3] * s};
     }
 };
 struct ZeroInit4 {
+    float s = 0.f;
+    __device__ __forceinline__ f32x4 raw(int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
     __device__ __forceinline__ f32x4 operator()(int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 };
 
@@ -449,6 +482,12 @@ struct Ring4 {
     }
     // piece q of the slab after the one being consumed: registers -> the idle slot; then request the piece four places on
     __device__ __forceinline__ void store_piece(int q) { *(f32x4*)(my_lds + (c_slot ^ 1u) * 32768 + q * 1024) = stage[q & 3]; }
+    // the same as two 8-byte stores for two different MFMA gaps (a 16-byte store's 13 cycles of register-to-LDS transfer overrun a
+    // 16-cycle gap on their own)
+    __device__ __forceinline__ void store_half(int q, int part) {
+        float2 v; v.x = stage[q & 3][2 * part]; v.y = stage[q & 3][2 * part + 1];
+        *(float2*)(my_lds + (c_slot ^ 1u) * 32768 + q * 1024 + 8 * part) = v;
+    }
     __device__ __forceinline__ void fetch_piece(int q) {
         if (q < 4) {
             stage[q] = *(const f32x4*)piece_src(g_next, q + 4);
@@ -588,6 +627,12 @@ __device__ __forceinline__ void run_h4a_wide(Ring4& ring, const char* ring_lane,
     auto HA = [&](int k) -> f32x4& { return k % 3 == 0 ? ha0 : (k % 3 == 1 ? ha1 : ha2); };
     auto LA = [&](int k) -> f32x4& { return k % 3 == 0 ? la0 : (k % 3 == 1 ? la1 : la2); };
     PairRegs pr;                                               // one pair in flight: hosted by tile 2i, completed behind tile 2i+1's first MFMA
+    MicroPair mp;
+    // H4A_MICRO (default): the pair's nine instructions one per gap -- even unit gaps 1..6 = m0..m5, odd unit gaps 1, 3, 5 = m6..m8
+    auto micro = [&](int k, int q1, int pp_) {
+        if (pp_ < 4) src0.micro(k, mp, B0(q1), q1, pp_);
+        else src1.micro(k, mp, B1(q1), q1, pp_ - 4);
+    };
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
 #pragma unroll
@@ -603,36 +648,55 @@ __device__ __forceinline__ void run_h4a_wide(Ring4& ring, const char* ring_lane,
             if (FIRST && q == 0) asm volatile("s_nop 1" : "+a"(acc0[t]), "+a"(acc1[t]));   // VALU-written C operands: two wait states
             mfma16_asm(acc0[t], l0, Bc0.h);
             __builtin_amdgcn_sched_barrier(0);
-#ifndef H4A_ABL_NOSPLIT
+            const bool binit = FIRST && q == 0 && t + 1 < NT;      // the next tile's C operands: bias rows (shared by the halves) x 2^es
+            f32x4 braw;
+            if (binit) braw = init0.raw(t + 1);
+#if !defined(H4A_ABL_NOSPLIT) && !defined(H4A_NOMICRO)
+            if (host) micro(0, q + 1, pp);
+            if (tail) micro(6, q + 1, pp);
+#elif !defined(H4A_ABL_NOSPLIT)
             if (host) { if (pp < 4) src0.stage_a(pr, q + 1, pp); else src1.stage_a(pr, q + 1, pp - 4); }
             if (tail) { if (pp < 4) src0.template stage_c2<false>(Bn0, pp, pr); else src1.template stage_c2<false>(Bn1, pp - 4, pr); }
 #endif
             __builtin_amdgcn_sched_barrier(0);
             mfma16_asm(acc1[t], l0, Bc1.h);
             __builtin_amdgcn_sched_barrier(0);
+#if !defined(H4A_ABL_NOSPLIT) && !defined(H4A_NOMICRO)
+            if (host) micro(1, q + 1, pp);
+#endif
 #ifndef H4A_ABL_NOAREAD
             if (!acq) h2 = *(const f32x4*)(pn);
 #endif
+            if (binit) { acc0[t + 1][0] = braw[0] * init0.s; acc0[t + 1][1] = braw[1] * init0.s; }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::"v"(l0), "v"(Bc0.h));
             mfma16_asm(acc0[t], h0, Bc0.l);
             __builtin_amdgcn_sched_barrier(0);
-#ifndef H4A_ABL_NOSPLIT
+#if !defined(H4A_ABL_NOSPLIT) && !defined(H4A_NOMICRO)
+            if (host) micro(2, q + 1, pp);
+            if (tail) micro(7, q + 1, pp);
+#elif !defined(H4A_ABL_NOSPLIT)
             if (host) { if (pp < 4) src0.stage_b(pr); else src1.stage_b(pr); }
 #endif
-#ifndef H4A_ABL_NOBIAS
-            if (FIRST && q == 0 && t + 1 < NT) { acc0[t + 1] = init0(t + 1); acc1[t + 1] = init1(t + 1); }
-#endif
+            if (binit) { acc0[t + 1][2] = braw[2] * init0.s; acc0[t + 1][3] = braw[3] * init0.s; }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::"v"(Bc1.h));
             mfma16_asm(acc1[t], h0, Bc1.l);
             __builtin_amdgcn_sched_barrier(0);
+#if !defined(H4A_ABL_NOSPLIT) && !defined(H4A_NOMICRO)
+            if (host) micro(3, q + 1, pp);
+#endif
+            if (binit) { acc1[t + 1][0] = braw[0] * init1.s; acc1[t + 1][1] = braw[1] * init1.s; }
             if (!host) {
 #pragma unroll
                 for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
                     if (2 * qq + 1 == uu && uu < UPS - 2) {
 #ifndef H4A_ABL_NORING
+#ifndef H4A_STORE_B64      // two 8-byte stores in two gaps: tried, 21 % LDS bank conflicts (16-byte stride), slower
                         ring.store_piece(qq);
+#else
+                        ring.store_half(qq, 0);
+#endif
 #endif
                     }
             }
@@ -640,13 +704,27 @@ __device__ __forceinline__ void run_h4a_wide(Ring4& ring, const char* ring_lane,
             asm volatile("" ::"v"(Bc0.l));
             mfma16_asm(acc0[t], h0, Bc0.h);
             __builtin_amdgcn_sched_barrier(0);
-#ifndef H4A_ABL_NOSPLIT
+            if (binit) { acc1[t + 1][2] = braw[2] * init1.s; acc1[t + 1][3] = braw[3] * init1.s; }
+#if !defined(H4A_ABL_NORING) && defined(H4A_STORE_B64)
+            if (!host) {
+#pragma unroll
+                for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
+                    if (2 * qq + 1 == uu && uu < UPS - 2) ring.store_half(qq, 1);
+            }
+#endif
+#if !defined(H4A_ABL_NOSPLIT) && !defined(H4A_NOMICRO)
+            if (host) micro(4, q + 1, pp);
+            if (tail) micro(8, q + 1, pp);
+#elif !defined(H4A_ABL_NOSPLIT)
             if (host) { if (pp < 4) src0.stage_c1(Bn0, pp, pr); else src1.stage_c1(Bn1, pp - 4, pr); }
 #endif
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::"v"(Bc1.l));
             mfma16_asm(acc1[t], h0, Bc1.h);
             __builtin_amdgcn_sched_barrier(0);
+#if !defined(H4A_ABL_NOSPLIT) && !defined(H4A_NOMICRO)
+            if (host) micro(5, q + 1, pp);
+#endif
             if (!host) {
 #pragma unroll
                 for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
