@@ -7,8 +7,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-gpu-rdc
 VARIANTS="base: nosplit:-DH3_ABL_NOSPLIT mfmaonly:-DH3_ABL_NOSPLIT,-DH3_ABL_NOSTORE,-DH3_ABL_NOLOAD,-DH3_ABL_NOAREAD,-DH3_ABL_NOBIAS"
 if [ "$1" = "build" ]; then
   mkdir -p $OUT
-  # STAMP_W=128: the Wd=128 instances live in the second translation unit of field_fwd_h3.hip (NEFES_TU_PART=1)
-  if [ "${STAMP_W:-256}" = "128" ]; then SKIP="field_fwd_h3.p1.o"; PART="-DNEFES_TU_PART=1"; else SKIP="field_fwd_h3.hip.o"; PART=""; fi
+  # STAMP_W=128: the Wd=128 instances live in the third translation unit of field_fwd_h3.hip (NEFES_TU_PART=2, VGPR-form MFMAs)
+  if [ "${STAMP_W:-256}" = "128" ]; then SKIP="field_fwd_h3.p2.o"; PART="-DNEFES_TU_PART=2 -mllvm -amdgpu-mfma-vgpr-form"; else SKIP="field_fwd_h3.hip.o"; PART=""; fi
   OTHERS=$(ls $CS/build/*.o | grep -v "$SKIP")
   for v in $VARIANTS; do
     name=${v%%:*}; defs=$(echo ${v#*:} | tr ',' ' ')
