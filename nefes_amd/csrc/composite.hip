@@ -89,6 +89,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs p) {
     const float* zr = p.z + (size_t)ray * S;
     const bool transient = p.flags & NEFES_COMP_TRANSIENT, sigma_only = p.flags & NEFES_COMP_SIGMA_ONLY;
     const bool static_only = p.flags & NEFES_COMP_STATIC_ONLY;
+    // blockIdx.y splits the FEATURE channels of a ray over several workgroups (small frames with many channels: the 80x60
+    // refinement frame has 4800 rays x 128 channels, i.e. five waves per SIMD walking 131 reductions each); split 0 also writes
+    // everything else.  Every split recomputes the ray's weights (two scans: small next to its share of the channels).
+    const int split = blockIdx.y, n_split = gridDim.y;
+    const bool lead = split == 0;
     RayState<Q> r;
     ray_forward<Q>(p, raw, zr, lane, r);
 
@@ -104,12 +109,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs p) {
             s_acc += w[q];
             s_wo += wo[q];
             s_dep += (double)(wo[q] * r.zz[q]);
-            if (p.weights) p.weights[(size_t)ray * S + lane + 64 * q] = wo[q];
+            if (p.weights && lead) p.weights[(size_t)ray * S + lane + 64 * q] = wo[q];
         }
     }
     const float acc = (float)wave_sum(s_acc);
-    if (lane == 0 && p.acc) p.acc[ray] = acc;
+    if (lane == 0 && p.acc && lead) p.acc[ray] = acc;
     if (sigma_only) return;                                              // variant D: weights + acc only (:83-89)
+    if (lead) {
     const float depth = (float)wave_sum(s_dep);
     const float sum_wo = static_only ? (float)wave_sum(s_wo) : acc;
     if (lane == 0) {
@@ -134,11 +140,14 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs p) {
         if (lane == c) rgb_keep = v;
     }
     if (lane < 3 && p.rgb) p.rgb[(size_t)ray * 3 + lane] = rgb_keep;
+    }   // lead
     // features use the same (static) weights, detached (:108-111,122-125,155-157)
     if (p.feat) {
-        for (int c0 = 0; c0 < C; c0 += 64) {
+        const int per = ((C + n_split - 1) / n_split + 31) / 32 * 32;      // whole 32-channel groups per split
+        const int c_lo = split * per, c_hi = (c_lo + per) < C ? (c_lo + per) : C;
+        for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
             float keep = 0.f;
-            const int nc = (C - c0) < 64 ? (C - c0) : 64;
+            const int nc = (c_hi - c0) < 64 ? (c_hi - c0) : 64;
             for (int c = 0; c < nc; ++c) {
                 double a = 0;
 #pragma unroll
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs p) {
             if (lane < nc) p.feat[(size_t)ray * C + c0 + lane] = keep;
         }
     }
-    if (p.beta) {
+    if (p.beta && lead) {
         float bv = 0.f;
         if (transient && !static_only) {
 #pragma unroll
@@ -311,7 +320,9 @@ extern "C" int nefes_composite_fwd(int N, int S, int C, uint32_t flags, float be
     if (!raw_t || !z) return NEFES_E_BADARG;
     a.beta_min = beta_min; a.raw_t = raw_t; a.z = z;
     a.rgb = rgb; a.feat = feat; a.disp = disp; a.acc = acc; a.depth = depth; a.weights = weights; a.beta = beta;
-    const dim3 grid((N + 3) / 4), block(256);
+    // small frames with many feature channels: split the channels of a ray over up to four workgroups (composite_fwd_kernel)
+    const int n_split = (feat && C >= 64 && N < 40000) ? ((C + 31) / 32 < 4 ? (C + 31) / 32 : 4) : 1;
+    const dim3 grid((N + 3) / 4, n_split), block(256);
     hipStream_t st = (hipStream_t)stream;
     switch ((S + 63) / 64) {
         case 1: hipLaunchKernelGGL(composite_fwd_kernel<1>, grid, block, 0, st, a); break;
