@@ -4,7 +4,11 @@
 // (field_bwd.hip); the transposed products of transient_encoding.{4,2,0}, dir_encoding, xyz_encoding_final and layers 8..1 run on
 // v_mfma_f32_32x32x16_f16 as hh + hl + lh of power-of-two scaled (hi, lo) fp16 pairs; the three narrow head products (3+C, 5 and
 // 1 k-values) stay on the fp32 MFMA.  Every gradient vector carries a per-lane scale exponent (field_h3.h).
-#define NEFES_SLAB_KIB NEFES_H3_BWD_SLAB_KIB
+#if defined(NEFES_TU_PART) && NEFES_TU_PART == 2
+#define NEFES_SLAB_KIB 16      // the Wd = 128 instance (layout.h NEFES_H3_BWD_SLAB_KIB_128)
+#else
+#define NEFES_SLAB_KIB 32
+#endif
 #define NEFES_B_BATCH 2
 #define NEFES_B_BATCH_NT8 4
 #include "field_common.h"

@@ -88,10 +88,11 @@ enum { NEFES_STREAM_FWD_SIGMA = 0, NEFES_STREAM_FWD_STATIC = 1, NEFES_STREAM_FWD
 #define NEFES_H3_FWD_SLAB_KIB 32       /* 16 units of 2 KiB (3 slots = 96 KiB: the embedding is parked in LDS beside the ring) */
 #define NEFES_H3_FWD_SLAB_KIB_128 16   /* Wd = 128 forward streams: 8 units; 2 slots = 32 KiB so that TWO workgroups share a CU's 160 KiB LDS */
 #define NEFES_H3_BWD_SLAB_KIB 32       /* 16 units */
+#define NEFES_H3_BWD_SLAB_KIB_128 16   /* Wd = 128 backward stream: 8 units (16 staging registers less in a kernel that spills into AGPRs) */
 #define NEFES_H3_TARGET_EXP 14         /* operands are scaled so that the largest magnitude lies in [2^14, 2^15) */
 NEFES_HD int nefes_stream_slab_kib(int stream, int width) {
     if (stream == NEFES_STREAM_BWD_FULL || stream == NEFES_STREAM_BWD_FULL_X6 || stream == NEFES_STREAM_BWD_STATIC) return NEFES_BWD_SLAB_KIB;
-    if (stream == NEFES_STREAM_BWD_FULL_H3) return NEFES_H3_BWD_SLAB_KIB;
+    if (stream == NEFES_STREAM_BWD_FULL_H3) return width == 128 ? NEFES_H3_BWD_SLAB_KIB_128 : NEFES_H3_BWD_SLAB_KIB;
     if (stream == NEFES_STREAM_FWD_SIGMA_H3 || stream == NEFES_STREAM_FWD_FULL_H3)
         return width == 128 ? NEFES_H3_FWD_SLAB_KIB_128 : NEFES_H3_FWD_SLAB_KIB;
     return stream >= NEFES_STREAM_FWD_SIGMA_X6 ? NEFES_X6_SLAB_KIB : NEFES_FWD_SLAB_KIB;

@@ -228,8 +228,8 @@ class PackedField:
     def h3_byte_ranges(self):
         """[(begin, end)] byte ranges of the blob that only the host packer writes: the fp16 two-part units and exponent tables."""
         out = []
-        fwd_kib = 16 if int(self.desc.width) == 128 else 32            # csrc/layout.h: NEFES_H3_FWD_SLAB_KIB_128 / NEFES_H3_FWD_SLAB_KIB
-        for k, kib in ((L.STREAM_FWD_SIGMA_H3, fwd_kib), (L.STREAM_FWD_FULL_H3, fwd_kib), (L.STREAM_BWD_FULL_H3, 32)):
+        fwd_kib = 16 if int(self.desc.width) == 128 else 32            # csrc/layout.h: NEFES_H3_{FWD,BWD}_SLAB_KIB_128 / NEFES_H3_{FWD,BWD}_SLAB_KIB
+        for k, kib in ((L.STREAM_FWD_SIGMA_H3, fwd_kib), (L.STREAM_FWD_FULL_H3, fwd_kib), (L.STREAM_BWD_FULL_H3, fwd_kib)):
             si = self.info.stream[k]
             if si.n_slabs:
                 out.append((int(si.slab_off), int(si.slab_off + si.n_slabs * kib * 1024)))

@@ -561,7 +561,7 @@ H3B = dict(RGB=0, TH=1, T2=2, T1=3, T0=4, DIR=5, FINAL=6, SIG=7, L8=8, L7=9, L6=
 def _h3_slab_kib(which, Wd=256):
     """KiB per slab of the fp16 two-part streams (layout.h nefes_stream_slab_kib): the Wd=128 forward streams use their own size."""
     txt = open(os.path.join(os.path.dirname(__file__), '..', 'nefes_amd', 'csrc', 'layout.h')).read()
-    name = 'NEFES_H3_FWD_SLAB_KIB_128' if (which == "FWD" and Wd == 128) else 'NEFES_H3_%s_SLAB_KIB' % which
+    name = 'NEFES_H3_%s_SLAB_KIB_128' % which if Wd == 128 else 'NEFES_H3_%s_SLAB_KIB' % which
     return int(re.search(r'#define %s (\d+)' % name, txt).group(1))
 
 
@@ -789,7 +789,7 @@ def test_h3_streams_reproduce_the_mlp(Wd, Cf):
     d_pre = {"rgbfeat": gr[:, :C3], "sigma": gr[:, C3] * (1 - np.exp(-r[:, C3])),
              "t_rgb": gr[:, C3 + 1:C3 + 4] * r[:, C3 + 1:C3 + 4] * (1 - r[:, C3 + 1:C3 + 4]),
              "t_sigma": gr[:, C3 + 4] * (1 - np.exp(-r[:, C3 + 4])), "t_beta": gr[:, C3 + 5] * (1 - np.exp(-r[:, C3 + 5]))}
-    st = StreamH3(blob_f, info_f.stream[L.STREAM_BWD_FULL_H3], _h3_slab_kib("BWD"), 16)
+    st = StreamH3(blob_f, info_f.stream[L.STREAM_BWD_FULL_H3], _h3_slab_kib("BWD", Wd), 16)
     w, rb = st.wexp, st.rowb
     assert st.bias.size == 0 and w[H3B["T0"]] == w[H3B["DIR"]] and all(w[H3B[k]] == 0 for k in ("RGB", "TH", "SIG"))
     Z = lambda nt: np.zeros((nt, 32, n), np.float64)
