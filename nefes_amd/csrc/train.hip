@@ -13,6 +13,7 @@
 #include "../../include/nefes_hip.h"
 #include "layout.h"
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -170,12 +171,109 @@ __global__ __launch_bounds__(64) void train_dw_kernel(int n_tiles, int rows, con
             for (int r = 0; r < 16; ++r) out[(size_t)(32 * to + nefes_rho(0, r)) * n_in_pad + 32 * ti] = acc[to][ti][r];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same product on the bf16 pipe: G and act(X) are split exactly into three bf16 each as they are loaded (x = h + m + l:
+// 24 = 3 x 8 mantissa bits, no scaling needed -- bf16 has fp32's exponent range) and a 16-sample step of a 32x32 block is
+// six v_mfma_f32_32x32x16_bf16 (l.h, h.l, m.m, m.h, h.m, h.h: dropped terms 2^-24 relative) instead of eight
+// v_mfma_f32_32x32x2_f32: 192 matrix-core cycles instead of 512.  Operand lane (row m, kh) holds samples 8 kh .. 8 kh + 7 of
+// the step: two 16-byte loads; a step's two loads per row cover 64 bytes of its 128-byte line, the next step the other 64.
+// Same C layout as the fp32 kernel, same partial-sum scheme, same epilogue.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+struct Tri { u32x4_t h, m, l; };
+__device__ __forceinline__ bf16x8_t as_bf(u32x4_t v) { bf16x8_t r; __builtin_memcpy(&r, &v, 16); return r; }
+__device__ __forceinline__ void tri_pair(Tri& o, int p, float x0, float x1) {      // truncation split, exact (field_x6.h split_pair)
+    const uint32_t b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+    const float e0 = x0 - __uint_as_float(b0 & 0xffff0000u), e1 = x1 - __uint_as_float(b1 & 0xffff0000u);
+    const uint32_t c0 = __float_as_uint(e0), c1 = __float_as_uint(e1);
+    const float f0 = e0 - __uint_as_float(c0 & 0xffff0000u), f1 = e1 - __uint_as_float(c1 & 0xffff0000u);
+    o.h[p] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    o.m[p] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+    o.l[p] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+}
+__device__ __forceinline__ void tri_of(Tri& o, float4 a, float4 b, bool relu) {
+    if (relu) {
+        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+        b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
+    }
+    tri_pair(o, 0, a.x, a.y); tri_pair(o, 1, a.z, a.w); tri_pair(o, 2, b.x, b.y); tri_pair(o, 3, b.z, b.w);
+}
+template <int NTO, int NTI>
+__global__ __launch_bounds__(64) void train_dw_x6_kernel(int n_tiles, int rows, const float* __restrict__ gbuf, int g_row0,
+                                                         const float* __restrict__ xbuf, int x_row0, int x_relu, int in_blocks,
+                                                         int splits, int n_in_pad, int n_out_pad, float* __restrict__ partial) {
+    const int lane = threadIdx.x, m = lane & 31, kh = lane >> 5;
+    const int ib = blockIdx.x % in_blocks, ob = blockIdx.x / in_blocks, sp = blockIdx.y;
+    const int t_lo = (int)((long long)n_tiles * sp / splits), t_hi = (int)((long long)n_tiles * (sp + 1) / splits);
+    f32x16 acc[NTO][NTI];
+#pragma unroll
+    for (int to = 0; to < NTO; ++to)
+#pragma unroll
+        for (int ti = 0; ti < NTI; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[to][ti][r] = 0.f;
+    const size_t go = (size_t)(g_row0 + 32 * NTO * ob + m) * 128 + 8 * kh;
+    const size_t xo = (size_t)(x_row0 + 32 * NTI * ib + m) * 128 + 8 * kh;
+    // one wave per SIMD at most (256 accumulator registers for the 128 x 128 block): the loads of step s + 1 are requested before
+    // the MFMAs of step s issue -- the raw values wait in registers, the split happens when their step comes
+    float4 ra[NTO][2], rb[NTI][2];
+    auto request = [&](int tile, int grp) {
+        const float* g = gbuf + (size_t)tile * rows * 128 + go + 16 * grp;
+        const float* x = xbuf + (size_t)tile * rows * 128 + xo + 16 * grp;
+#pragma unroll
+        for (int to = 0; to < NTO; ++to) { ra[to][0] = *(const float4*)(g + (size_t)32 * to * 128); ra[to][1] = *(const float4*)(g + (size_t)32 * to * 128 + 4); }
+#pragma unroll
+        for (int ti = 0; ti < NTI; ++ti) { rb[ti][0] = *(const float4*)(x + (size_t)32 * ti * 128); rb[ti][1] = *(const float4*)(x + (size_t)32 * ti * 128 + 4); }
+    };
+    if (t_lo < t_hi) request(t_lo, 0);
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+#pragma unroll 2
+        for (int grp = 0; grp < 8; ++grp) {                    // 16 samples per step
+            Tri A[NTO], B[NTI];
+#pragma unroll
+            for (int to = 0; to < NTO; ++to) tri_of(A[to], ra[to][0], ra[to][1], false);
+#pragma unroll
+            for (int ti = 0; ti < NTI; ++ti) tri_of(B[ti], rb[ti][0], rb[ti][1], x_relu != 0);
+            {
+                const int ng = grp + 1 < 8 ? grp + 1 : 0, nt = grp + 1 < 8 ? tile : tile + 1;
+                if (nt < t_hi) request(nt, ng);
+            }
+#pragma unroll
+            for (int to = 0; to < NTO; ++to)
+#pragma unroll
+                for (int ti = 0; ti < NTI; ++ti) {
+                    f32x16 c = acc[to][ti];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A[to].l), as_bf(B[ti].h), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A[to].h), as_bf(B[ti].l), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A[to].m), as_bf(B[ti].m), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A[to].m), as_bf(B[ti].h), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A[to].h), as_bf(B[ti].m), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(A[to].h), as_bf(B[ti].h), c, 0, 0, 0);
+                    acc[to][ti] = c;
+                }
+        }
+    }
+    float* out = partial + (size_t)sp * n_out_pad * n_in_pad + (size_t)(32 * NTO * ob + 4 * kh) * n_in_pad + 32 * NTI * ib + m;
+#pragma unroll
+    for (int to = 0; to < NTO; ++to)
+#pragma unroll
+        for (int ti = 0; ti < NTI; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[(size_t)(32 * to + nefes_rho(0, r)) * n_in_pad + 32 * ti] = acc[to][ti][r];
+}
+
 template <int NTO, int NTI>
 int launch_dw(int n_tiles, int rows, const float* g, int g_row0, int out_tiles, const float* x, int x_row0, int in_tiles,
               int x_relu, int splits, float* partial, hipStream_t st) {
     const int ob = out_tiles / NTO, ib = in_tiles / NTI;
-    train_dw_kernel<NTO, NTI><<<dim3((unsigned)(ob * ib), (unsigned)splits), dim3(64), 0, st>>>(
-        n_tiles, rows, g, g_row0, x, x_row0, x_relu, ib, splits, 32 * in_tiles, 32 * out_tiles, partial);
+    static const bool f32_path = [] { const char* e = getenv("NEFES_TRAIN_DW"); return e && e[0] == 'f'; }();   // "f32": the fp32-MFMA kernel
+    if (f32_path)
+        train_dw_kernel<NTO, NTI><<<dim3((unsigned)(ob * ib), (unsigned)splits), dim3(64), 0, st>>>(
+            n_tiles, rows, g, g_row0, x, x_row0, x_relu, ib, splits, 32 * in_tiles, 32 * out_tiles, partial);
+    else
+        train_dw_x6_kernel<NTO, NTI><<<dim3((unsigned)(ob * ib), (unsigned)splits), dim3(64), 0, st>>>(
+            n_tiles, rows, g, g_row0, x, x_row0, x_relu, ib, splits, 32 * in_tiles, 32 * out_tiles, partial);
     return (int)hipGetLastError();
 }
 
@@ -217,6 +315,9 @@ extern "C" int nefes_train_dw(int64_t n_tiles, int rows, const float* dacts, int
     if (n_out <= 0 || n_out % 32 || n_in <= 0 || n_in % 32 || g_row0 < 0 || x_row0 < 0) return NEFES_E_BADARG;
     const int ot = n_out / 32, it = n_in / 32;
     hipStream_t st = (hipStream_t)stream;
+    static const bool f32_dw = [] { const char* e = getenv("NEFES_TRAIN_DW"); return e && e[0] == 'f'; }();
+    // bf16x6 kernel: a 128 x 128 block per wave where the shapes allow (every row of G and X is then read by ONE workgroup)
+    if (!f32_dw && ot % 4 == 0 && it % 4 == 0) return launch_dw<4, 4>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, partial, st);
     const int nto = ot % 2 == 0 ? 2 : 1, nti = it % 4 == 0 ? 4 : (it % 2 == 0 ? 2 : 1);
 #define NEFES_DW(O, I) \
     if (nto == O && nti == I) return launch_dw<O, I>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, partial, st);
