@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEFES_ABI_VERSION 8
+#define NEFES_ABI_VERSION 9
 
 #define NEFES_E_BADARG (-1)     /* null pointer / non-positive size */
 #define NEFES_E_UNSUPPORTED (-2) /* width / feat_dim / sample count outside the compiled set */
@@ -57,7 +57,7 @@ typedef struct NefesStreamInfo {
 
 typedef struct NefesBlobInfo {
     uint64_t total_bytes;
-    NefesStreamInfo stream[11]; /* indexed by NEFES_STREAM_* in csrc/layout.h; n_slabs == 0 if absent */
+    NefesStreamInfo stream[13]; /* indexed by NEFES_STREAM_* in csrc/layout.h; n_slabs == 0 if absent */
 } NefesBlobInfo;
 
 /* compositing variants of raw2outputs_NeRFH_NFF (script/models/nerfh_nff.py:25-166) */
@@ -88,11 +88,17 @@ int nefes_pack_weights(const NefesNetDesc* desc, const float* const* tensors, in
  * counts the elements of the tensor table above concatenated in order (tensor_elems_out[i] = elements of tensor i, may
  * be NULL), part 0/1 = low/high half of the fp32 value, 2/3/4 = bf16 hi/mid/lo of the bf16x6 streams, code 0 = zero.
  * n_entries >= total_bytes / 2.
- * nefes_pack_device: blob[slot] = part(flat[...]) for every slot after the 256-byte header; flat, map, blob on the
- * device; blob must have been initialised once by nefes_pack_weights.  Result bit-identical to nefes_pack_weights. */
+ * The fp16 two-part streams: parts 5/6 = fp16 hi/lo of value * 2^e with the matrix's exponent group in bits 27..31 of the
+ * code, part 7 = a half of the exponent word; code 0xffffffff = word written by the plan's reductions.
+ * nefes_pack_h3_plan (host): the reductions those streams need from the parameter vector (one exponent per weight matrix,
+ * row bounds and bias maxima of the scale tables); `needed` = ints required (query with plan = NULL); plan[0] = n_jobs.
+ * nefes_pack_device: blob[slot] = part(flat[...]) for every slot after the 512-byte header; flat, map, plan, scratch
+ * (>= 32 ints), blob on the device; blob must have been initialised once by nefes_pack_weights.  plan = NULL leaves the fp16
+ * streams as they are.  Result bit-identical to nefes_pack_weights. */
 int nefes_pack_map(const NefesNetDesc* desc, uint32_t* map, size_t n_entries, int64_t* tensor_elems_out);
-int nefes_pack_device(const float* flat, int64_t n_params, const uint32_t* map, int64_t n_entries, void* blob,
-                      void* stream);
+int nefes_pack_h3_plan(const NefesNetDesc* desc, int32_t* plan, size_t n_ints, size_t* needed);
+int nefes_pack_device(const float* flat, int64_t n_params, const uint32_t* map, int64_t n_entries, const int32_t* plan,
+                      int n_jobs, int32_t* scratch, void* blob, void* stream);
 
 /* ---- rays (script/models/ray_utils.py) ------------------------------------------------------- */
 /* get_rays (:5-16) + viewdirs = d/|d| (rendering.py:217) for image rows [row0, row0+nrows).
@@ -217,7 +223,7 @@ int nefes_field_bwd_x3(const NefesNetDesc* desc, const void* packed, int N, int 
  * Weights are scaled per matrix by the packer (exponent table in the NEFES_STREAM_*_H3 streams), activations / gradient vectors
  * per sample and product inside the kernels.  Shapes: width 256 / C = 16 (either xyz encoding) and width 128 / C = 128.
  * Same arguments, outputs and ReLU-mask words as the calls above, so forward and backward kernels of every kind combine.
- * The fp16 streams are written by nefes_pack_weights only (not by nefes_pack_device). */
+ * nefes_pack_device refreshes the fp16 streams when it is given the plan of nefes_pack_h3_plan. */
 int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                        const float* rays_d, const float* z, const float* pts, const float* xyz_enc, const float* viewdirs,
                        float* raw_t, uint32_t* masks, void* stream);
@@ -253,6 +259,11 @@ int nefes_train_dx(int64_t n_tiles, int rows, const float* dacts_in, int g_row0,
  * f = ReLU if x_relu else identity; n_out, n_in multiples of 32; the caller sums the `splits` partials. */
 int nefes_train_dw(int64_t n_tiles, int rows, const float* dacts, int g_row0, int n_out, const float* acts, int x_row0,
                    int n_in, int x_relu, int splits, float* partial, void* stream);
+/* The same with the bias gradient riding along: partial[sp][o][n_in + 1], column n_in = sum over the share's samples of
+ * dacts[g_row0 + o][s] (the row sums autograd gives a Linear's bias; the operand is in registers for the product anyway, a
+ * separate reduction would read the whole gradient buffer a second time). */
+int nefes_train_dw_bias(int64_t n_tiles, int rows, const float* dacts, int g_row0, int n_out, const float* acts, int x_row0,
+                        int n_in, int x_relu, int splits, float* partial, void* stream);
 
 /* ---- bicubic up-sampling of the fused feature image (script/dm/DFM_APR_refine.py:114,118: torch.nn.Upsample(size,
  *      mode='bicubic'), align_corners=False, A=-0.75) ---- */

@@ -83,7 +83,8 @@ NEFES_HD int nefes_segment_slabs(int nt, int ks, int slab_frags) {
 enum { NEFES_STREAM_FWD_SIGMA = 0, NEFES_STREAM_FWD_STATIC = 1, NEFES_STREAM_FWD_FULL = 2, NEFES_STREAM_BWD_FULL = 3,
        NEFES_STREAM_FWD_SIGMA_X6 = 4, NEFES_STREAM_FWD_FULL_X6 = 5, NEFES_STREAM_BWD_FULL_X6 = 6, NEFES_STREAM_BWD_STATIC = 7,
        NEFES_STREAM_FWD_SIGMA_H3 = 8, NEFES_STREAM_FWD_FULL_H3 = 9, NEFES_STREAM_BWD_FULL_H3 = 10,
-       NEFES_N_STREAMS = 11 };
+       NEFES_STREAM_FWD_STATIC_H3 = 11, NEFES_STREAM_BWD_STATIC_H3 = 12,   /* static head only (coarse network in train mode) */
+       NEFES_N_STREAMS = 13 };
 #define NEFES_X6_SLAB_KIB 48
 #define NEFES_H3_FWD_SLAB_KIB 32       /* 16 units of 2 KiB (3 slots = 96 KiB: the embedding is parked in LDS beside the ring) */
 #define NEFES_H3_FWD_SLAB_KIB_128 16   /* Wd = 128 forward streams: 8 units; 2 slots = 32 KiB so that TWO workgroups share a CU's 160 KiB LDS */
@@ -92,11 +93,12 @@ enum { NEFES_STREAM_FWD_SIGMA = 0, NEFES_STREAM_FWD_STATIC = 1, NEFES_STREAM_FWD
 #define NEFES_H3_TARGET_EXP 14         /* operands are scaled so that the largest magnitude lies in [2^14, 2^15) */
 NEFES_HD int nefes_stream_slab_kib(int stream, int width) {
     if (stream == NEFES_STREAM_BWD_FULL || stream == NEFES_STREAM_BWD_FULL_X6 || stream == NEFES_STREAM_BWD_STATIC) return NEFES_BWD_SLAB_KIB;
-    if (stream == NEFES_STREAM_BWD_FULL_H3) return width == 128 ? NEFES_H3_BWD_SLAB_KIB_128 : NEFES_H3_BWD_SLAB_KIB;
-    if (stream == NEFES_STREAM_FWD_SIGMA_H3 || stream == NEFES_STREAM_FWD_FULL_H3)
+    if (stream == NEFES_STREAM_BWD_FULL_H3 || stream == NEFES_STREAM_BWD_STATIC_H3) return width == 128 ? NEFES_H3_BWD_SLAB_KIB_128 : NEFES_H3_BWD_SLAB_KIB;
+    if (stream == NEFES_STREAM_FWD_SIGMA_H3 || stream == NEFES_STREAM_FWD_FULL_H3 || stream == NEFES_STREAM_FWD_STATIC_H3)
         return width == 128 ? NEFES_H3_FWD_SLAB_KIB_128 : NEFES_H3_FWD_SLAB_KIB;
     return stream >= NEFES_STREAM_FWD_SIGMA_X6 ? NEFES_X6_SLAB_KIB : NEFES_FWD_SLAB_KIB;
 }
+#define NEFES_PACK_KEEP 0xffffffffu   /* nefes_pack_map code: this 32-bit word is not written by the slot expansion (both halves carry it) */
 #define NEFES_BLOB_HEADER_BYTES 512   /* NefesBlobInfo, padded: written by the host packer only (pack.cpp, pack_device.hip) */
 
 // Segment ordinals of the _H3 streams.  The stream's scale table (pack.cpp; words behind the bias blocks, NefesStreamInfo.
@@ -115,6 +117,11 @@ enum { NEFES_H3BB_L1 = 0, NEFES_H3BB_SIG = 8, NEFES_H3BB_FINAL, NEFES_H3BB_DIR, 
 enum { NEFES_H3B_RGB = 0, NEFES_H3B_TH, NEFES_H3B_T2, NEFES_H3B_T1, NEFES_H3B_T0, NEFES_H3B_DIR, NEFES_H3B_FINAL, NEFES_H3B_SIG,
        NEFES_H3B_L8, NEFES_H3B_L7, NEFES_H3B_L6, NEFES_H3B_L5, NEFES_H3B_L4, NEFES_H3B_L3, NEFES_H3B_L2, NEFES_H3B_L1,
        NEFES_H3B_N };
+/* the static-head streams hold a subset of those segments in the same order: forward = the first NEFES_H3F_RGB + 1 (DT_H / DT_D
+ * are then dir_encoding alone), backward = RGB, then DIR .. L1 (no TH, T2, T1, T0) */
+#define NEFES_H3F_N_STATIC (NEFES_H3F_RGB + 1)
+#define NEFES_H3B_N_STATIC (NEFES_H3B_N - 4)
+NEFES_HD int nefes_h3b_seg(int has_transient, int seg) { return (has_transient || seg == NEFES_H3B_RGB) ? seg : seg - 4; }
 
 // ReLU-mask words (32 bit) written per lane per 32-sample tile by the full forward pass:
 // 8 trunk layers (W/64 words each) + dir + 3 transient layers (W/128 words each)

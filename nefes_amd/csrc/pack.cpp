@@ -261,6 +261,23 @@ void add_static_head(const Net& n, Stream& st, int x6 = 0) {
     st.bias.push_back({n.b(L_RGB), rows_natural(n.NTR, 3 + n.C)});
 }
 
+// the same head with every product as an fp16 two-part split product (NEFES_STREAM_FWD_STATIC_H3): the segment order is the
+// first NEFES_H3F_N_STATIC segments of the full fp16 stream, with dir_encoding alone where that one stacks [dir ; t0]
+void add_static_head_h3(const Net& n, Stream& st) {
+    const int W = n.W, W2 = n.W2;
+    st.segs.push_back(seg(n.NTW, W / 2, k_natural(W / 2, 0), rows_natural(n.NTW, W), n.w(L_FINAL), W));
+    mark(st.segs.back(), 2);
+    st.bias.push_back({n.b(L_FINAL), rows_natural(n.NTW, W)});
+    st.segs.push_back(seg(n.NTH, W / 2, k_natural(W / 2, 0), rows_natural(n.NTH, W2), n.w(L_DIR), W + 27));
+    mark(st.segs.back(), 2);
+    st.segs.push_back(seg(n.NTH, 16, k_emb(4, 16, W), rows_natural(n.NTH, W2), n.w(L_DIR), W + 27));   // 14 k-steps padded to 16
+    mark(st.segs.back(), 2);
+    st.bias.push_back({n.b(L_DIR), rows_natural(n.NTH, W2)});
+    st.segs.push_back(seg(n.NTR, W2 / 2, k_natural(W2 / 2, 0), rows_natural(n.NTR, 3 + n.C), n.w(L_RGB), W2));
+    mark(st.segs.back(), 2);
+    st.bias.push_back({n.b(L_RGB), rows_natural(n.NTR, 3 + n.C)});
+}
+
 // x6 forward streams: dir_encoding and transient_encoding.0 read the same input (cat[final, dir-emb]), so they run as ONE
 // product with 2*NTH tiles (rows: dir | t0): one operand split instead of two, and the standard 8-tile shape at Wd = 256.
 // Segment order: FINAL, [DIR;T0] hidden part, [DIR;T0] direction part, RGB, T1, T2, TH (all x6); bias blocks keep the
@@ -390,6 +407,17 @@ static void assign_weight_exponents(const Net& n, Stream (&st)[NEFES_N_STREAMS])
         }
 }
 
+// Exponent group of a weight matrix = the layer index whose scale it shares (assign_weight_exponents): its own, except
+// transient_encoding.0 -> dir_encoding (transient networks) and the three transient heads -> one stacked matrix.  -1: none.
+static int group_of(const Net& n, const float* Wm) {
+    if (!Wm) return -1;
+    if (Wm == n.th_w.data()) return L_TRGB;
+    if (Wm == n.dt_w.data()) return L_DIR;
+    for (int l = 0; l < 18; ++l)
+        if (n.t[2 * l] == Wm) return (n.transient && l == L_T0) ? (int)L_DIR : ((l == L_TSIGMA || l == L_TBETA) ? (int)L_TRGB : l);
+    return -1;
+}
+
 bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&st)[NEFES_N_STREAMS]) {
     if (!d) return false;
     if (d->width != 128 && d->width != 256) return false;
@@ -437,6 +465,12 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
         add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_X6], 1);
         add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_H3], 2);
         st[NEFES_STREAM_FWD_SIGMA_H3].h3 = true;
+        if (!n.ext && (small || n.C == 16)) {          // static head only: what a coarse network runs in train mode
+            add_trunk(n, st[NEFES_STREAM_FWD_STATIC_H3], 2);
+            add_static_head_h3(n, st[NEFES_STREAM_FWD_STATIC_H3]);
+            add_backward(n, st[NEFES_STREAM_BWD_STATIC_H3], 2, false);
+            st[NEFES_STREAM_FWD_STATIC_H3].h3 = st[NEFES_STREAM_BWD_STATIC_H3].h3 = true;
+        }
         if (n.transient && (small || n.C == 16)) {
             add_trunk(n, st[NEFES_STREAM_FWD_FULL_X6], 1);
             add_heads_x6(n, st[NEFES_STREAM_FWD_FULL_X6]);
@@ -506,9 +540,11 @@ static int64_t tensor_elems(const Net& n, int i) {
 // 16-bit slot of the blob, the code (flat parameter index + 1) << 3 | part that nefes_pack_device expands on the GPU
 // (part 0/1 = low/high half of the fp32 value; 2/3/4 = the bf16 hi/mid/lo parts of the x6 split; code 0 = zero).  In map
 // mode the tensors hold float(flat index + 1), which every copy in build() and at()/at16() carries along unchanged.
-static int pack_walk(const NefesNetDesc* desc, const float* const* tensors, char* base, uint32_t* map, const NefesBlobInfo& info,
+static int pack_walk(const NefesNetDesc* desc, const Net& n, char* base, uint32_t* map, const NefesBlobInfo& info,
                      Stream (&st)[NEFES_N_STREAMS]) {
     auto code = [](float v, int part) { return v == 0.f ? 0u : (((uint32_t)v) << 3 | (uint32_t)part); };
+    // fp16 two-part slots: the exponent group (bits 27..31) rides along, parts 5 / 6 = hi / lo of value * 2^(group exponent)
+    auto code16 = [](float v, int part, int group) { return v == 0.f ? 0u : ((uint32_t)group << 27 | ((uint32_t)v) << 3 | (uint32_t)part); };
     for (int k = 0; k < NEFES_N_STREAMS; ++k) {
         const NefesStreamInfo& si = info.stream[k];
         if (si.n_slabs == 0) continue;
@@ -536,7 +572,18 @@ static int pack_walk(const NefesNetDesc* desc, const float* const* tensors, char
                     memcpy(&word, &m, 4);
                 }
                 if (base) memcpy(base + boff, &word, 4);
-                if (map) map[boff / 2] = map[boff / 2 + 1] = 0;     // (the device re-pack does not produce fp16 streams)
+                if (map) {   // exponent words: halves 1 / 2 of the group's exponent (part 7); bounds and bias maxima are written by
+                             // the device plan's reductions (nefes_pack_h3_plan): the expansion leaves those words alone
+                    uint32_t lo = 0, hi = 0;
+                    if (i < 2 * ns && i % 2 == 0) {
+                        const Seg& sg = st[k].segs[i / 2];
+                        const int g = sg.h3 ? group_of(n, sg.W) : -1;
+                        if (g >= 0) { lo = (uint32_t)g << 27 | 1u << 3 | 7u; hi = (uint32_t)g << 27 | 2u << 3 | 7u; }
+                    } else if (i < 2 * ns + nb) {
+                        lo = hi = NEFES_PACK_KEEP;
+                    }
+                    map[boff / 2] = lo; map[boff / 2 + 1] = hi;
+                }
                 boff += 4;
             }
         }
@@ -558,7 +605,7 @@ static int pack_walk(const NefesNetDesc* desc, const float* const* tensors, char
                                 for (int pp = 0; pp < 2; ++pp) {
                                     const uint64_t o = grp + 2ull * (pp * 512 + lane * 8 + i);
                                     if (base) memcpy(base + o, &part[pp], 2);
-                                    if (map) map[o / 2] = 0;
+                                    if (map) map[o / 2] = code16(v, 5 + pp, group_of(n, sg.W));
                                 }
                             }
                     }
@@ -625,35 +672,123 @@ extern "C" int nefes_pack_weights(const NefesNetDesc* desc, const float* const* 
     hdr[1] = NEFES_ABI_VERSION;
     memcpy(hdr + 2, desc, sizeof(*desc));
     memcpy(hdr + 8, &info, sizeof(info));
-    return pack_walk(desc, tensors, base, nullptr, info, st);
+    return pack_walk(desc, n, base, nullptr, info, st);
+}
+
+// The network built over index tensors: tensor i holds float(flat index + 1) of its elements (flat = the tensor table
+// concatenated in order), which every copy in build() and at()/at16() carries along unchanged.
+struct Indexed {
+    std::vector<std::vector<float>> idx;
+    const float* ptrs[36] = {nullptr};
+    int64_t off[37] = {0};
+    int need = 0;
+    Net n;
+    Stream st[NEFES_N_STREAMS];
+    NefesBlobInfo info;
+};
+static int build_indexed(const NefesNetDesc* desc, Indexed& x, int64_t* tensor_elems_out) {
+    {   // geometry first (tensor sizes depend on it)
+        Stream tmp[NEFES_N_STREAMS];
+        if (!build(desc, nullptr, x.n, tmp)) return NEFES_E_UNSUPPORTED;
+    }
+    x.need = desc->has_transient ? 36 : 24;
+    x.idx.resize(x.need);
+    int64_t flat = 0;
+    for (int i = 0; i < x.need; ++i) {
+        const int64_t ne = tensor_elems(x.n, i);
+        if (tensor_elems_out) tensor_elems_out[i] = ne;
+        x.idx[i].resize((size_t)ne);
+        for (int64_t e = 0; e < ne; ++e) x.idx[i][(size_t)e] = (float)(flat + e + 1);
+        x.off[i] = flat;
+        flat += ne;
+        x.ptrs[i] = x.idx[i].data();
+    }
+    x.off[x.need] = flat;
+    if (flat + 1 >= (1 << 24)) return NEFES_E_UNSUPPORTED;   // codes are carried as exact fp32 integers
+    if (!build(desc, x.ptrs, x.n, x.st)) return NEFES_E_UNSUPPORTED;   // (x is used in place: the segments point into x.n)
+    fill_info(x.st, desc->width, &x.info);
+    return 0;
 }
 
 extern "C" int nefes_pack_map(const NefesNetDesc* desc, uint32_t* map, size_t n_entries, int64_t* tensor_elems_out) {
     if (!desc || !map) return NEFES_E_BADARG;
-    Net n;
-    Stream st[NEFES_N_STREAMS];
-    {   // geometry first (tensor sizes depend on it)
-        Stream tmp[NEFES_N_STREAMS];
-        if (!build(desc, nullptr, n, tmp)) return NEFES_E_UNSUPPORTED;
+    Indexed x;
+    const int rc = build_indexed(desc, x, tensor_elems_out);
+    if (rc) return rc;
+    if (n_entries < x.info.total_bytes / 2) return NEFES_E_BADBLOB;
+    memset(map, 0, sizeof(uint32_t) * (x.info.total_bytes / 2));
+    return pack_walk(desc, x.n, nullptr, map, x.info, x.st);
+}
+
+// Reductions the device re-pack of the fp16 two-part streams needs before the slot expansion (pack_device.hip runs one
+// workgroup per job): plan = [n_jobs, 0, jobs (8 ints each) ..., index pool ...]
+//   kind 0  exponent of group `out`      = scale_exp(max |w|) over up to three flat ranges (offset, count)
+//   kind 1  row bound -> blob word `out` : rows a, k-values b, flat index of (row r, k) = pool[c + r] + pool[d + k]
+//   kind 2  max |b|   -> blob word `out` : over up to three flat ranges
+extern "C" int nefes_pack_h3_plan(const NefesNetDesc* desc, int32_t* plan, size_t n_ints, size_t* needed) {
+    if (!desc) return NEFES_E_BADARG;
+    Indexed x;
+    const int rc = build_indexed(desc, x, nullptr);
+    if (rc) return rc;
+    const Net& n = x.n;
+    std::vector<int32_t> jobs, pool;
+    auto job = [&](int kind, int out, const int (&arg)[6]) {
+        jobs.push_back(kind); jobs.push_back(out);
+        for (int v : arg) jobs.push_back(v);
+    };
+    const int n_layers = x.need / 2;
+    for (int g = 0; g < n_layers; ++g) {
+        if (group_of(n, n.t[2 * g]) != g) continue;
+        int arg[6] = {0, 0, 0, 0, 0, 0}, cnt = 0;
+        for (int l = 0; l < n_layers && cnt < 3; ++l)
+            if (group_of(n, n.t[2 * l]) == g) { arg[2 * cnt] = (int)x.off[2 * l]; arg[2 * cnt + 1] = (int)(x.off[2 * l + 1] - x.off[2 * l]); ++cnt; }
+        job(0, g, arg);
     }
-    const int need = desc->has_transient ? 36 : 24;
-    std::vector<std::vector<float>> idx(need);
-    const float* ptrs[36] = {nullptr};
-    int64_t flat = 0;
-    for (int i = 0; i < need; ++i) {
-        const int64_t ne = tensor_elems(n, i);
-        if (tensor_elems_out) tensor_elems_out[i] = ne;
-        idx[i].resize((size_t)ne);
-        for (int64_t e = 0; e < ne; ++e) idx[i][(size_t)e] = (float)(flat + e + 1);
-        flat += ne;
-        ptrs[i] = idx[i].data();
+    auto tensor_range = [&](const float* p, int& o, int& c) {
+        for (int i = 0; i < x.need; ++i)
+            if (n.t[i] == p) { o = (int)x.off[i]; c = (int)(x.off[i + 1] - x.off[i]); return true; }
+        return false;
+    };
+    for (int k = 0; k < NEFES_N_STREAMS; ++k) {
+        const NefesStreamInfo& si = x.info.stream[k];
+        if (!x.st[k].h3 || si.n_slabs == 0) continue;
+        const int ns = (int)x.st[k].segs.size(), nb = (int)x.st[k].bias.size();
+        const int tab = (int)(si.bias_off / 4) + (int)si.scale_off;
+        for (int i = 0; i < ns; ++i) {
+            const Seg& sg = x.st[k].segs[i];
+            int arg[6] = {0, 0, (int)pool.size(), 0, 0, 0};
+            std::vector<int> rows, ks;
+            for (int r : sg.ridx) if (r >= 0) rows.push_back(r);
+            for (int kk : sg.kidx) if (kk >= 0) ks.push_back(kk);
+            for (int r : rows) pool.push_back(sg.transposed ? r : (int)sg.W[(size_t)r * sg.ld] - 1);
+            arg[3] = (int)pool.size();
+            for (int kk : ks) pool.push_back(sg.transposed ? (int)sg.W[(size_t)kk * sg.ld] - 1 : kk);
+            arg[0] = (int)rows.size(); arg[1] = (int)ks.size();
+            job(1, tab + 2 * i + 1, arg);
+        }
+        for (int j = 0; j < nb; ++j) {
+            const BiasBlk& bb = x.st[k].bias[j];
+            int arg[6] = {0, 0, 0, 0, 0, 0};
+            if (bb.b == n.th_b.data()) {
+                tensor_range(n.b(L_TRGB), arg[0], arg[1]);
+                tensor_range(n.b(L_TSIGMA), arg[2], arg[3]);
+                tensor_range(n.b(L_TBETA), arg[4], arg[5]);
+            } else if (!tensor_range(bb.b, arg[0], arg[1])) {
+                return NEFES_E_UNSUPPORTED;
+            }
+            job(2, tab + 2 * ns + j, arg);
+        }
     }
-    if (flat + 1 >= (1 << 24)) return NEFES_E_UNSUPPORTED;   // codes are carried as exact fp32 integers
-    Net n2;
-    if (!build(desc, ptrs, n2, st)) return NEFES_E_UNSUPPORTED;
-    NefesBlobInfo info;
-    fill_info(st, desc->width, &info);
-    if (n_entries < info.total_bytes / 2) return NEFES_E_BADBLOB;
-    memset(map, 0, sizeof(uint32_t) * (info.total_bytes / 2));
-    return pack_walk(desc, ptrs, nullptr, map, info, st);
+    const int n_jobs = (int)jobs.size() / 8, head = 2 + (int)jobs.size();
+    const size_t total = (size_t)head + pool.size();
+    if (needed) *needed = total;
+    if (!plan) return 0;
+    if (n_ints < total) return NEFES_E_BADBLOB;
+    plan[0] = n_jobs; plan[1] = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        for (int f = 0; f < 8; ++f) plan[2 + 8 * j + f] = jobs[8 * j + f];
+        if (jobs[8 * j] == 1) { plan[2 + 8 * j + 4] += head; plan[2 + 8 * j + 5] += head; }   // pool offsets -> absolute
+    }
+    for (size_t i = 0; i < pool.size(); ++i) plan[head + i] = pool[i];
+    return 0;
 }

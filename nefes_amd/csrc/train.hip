@@ -117,17 +117,21 @@ __global__ __launch_bounds__(256, 2) void train_dx_kernel(int rows, const float*
 template <int NTO, int NTI>
 __global__ __launch_bounds__(64) void train_dw_kernel(int n_tiles, int rows, const float* __restrict__ gbuf, int g_row0,
                                                       const float* __restrict__ xbuf, int x_row0, int x_relu, int in_blocks,
-                                                      int splits, int n_in_pad, int n_out_pad, float* __restrict__ partial) {
+                                                      int splits, int ld, int with_bias, int n_out_pad, float* __restrict__ partial) {
     const int lane = threadIdx.x, m = lane & 31, kh = lane >> 5;
     const int ib = blockIdx.x % in_blocks, ob = blockIdx.x / in_blocks, sp = blockIdx.y;
     const int t_lo = (int)((long long)n_tiles * sp / splits), t_hi = (int)((long long)n_tiles * (sp + 1) / splits);
+    const bool bias = with_bias && ib == 0;              // the first input block of every output block also sums G's rows
+    float bsum[NTO];
     f32x16 acc[NTO][NTI];
 #pragma unroll
-    for (int to = 0; to < NTO; ++to)
+    for (int to = 0; to < NTO; ++to) {
+        bsum[to] = 0.f;
 #pragma unroll
         for (int ti = 0; ti < NTI; ++ti)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[to][ti][r] = 0.f;
+    }
     const size_t go = (size_t)(g_row0 + 32 * NTO * ob + m) * 128 + 4 * kh;
     const size_t xo = (size_t)(x_row0 + 32 * NTI * ib + m) * 128 + 4 * kh;
     for (int tile = t_lo; tile < t_hi; ++tile) {
@@ -149,6 +153,12 @@ __global__ __launch_bounds__(64) void train_dw_kernel(int n_tiles, int rows, con
                     if (x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     b[ti][u] = v;
                 }
+            if (bias) {
+#pragma unroll
+                for (int to = 0; to < NTO; ++to)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bsum[to] += (a[to][u].x + a[to][u].y) + (a[to][u].z + a[to][u].w);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -162,13 +172,20 @@ __global__ __launch_bounds__(64) void train_dw_kernel(int n_tiles, int rows, con
                     }
         }
     }
-    float* out = partial + (size_t)sp * n_out_pad * n_in_pad + (size_t)(32 * NTO * ob + 4 * kh) * n_in_pad + 32 * NTI * ib + m;
+    float* out = partial + (size_t)sp * n_out_pad * ld + (size_t)(32 * NTO * ob + 4 * kh) * ld + 32 * NTI * ib + m;
 #pragma unroll
     for (int to = 0; to < NTO; ++to)
 #pragma unroll
         for (int ti = 0; ti < NTI; ++ti)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) out[(size_t)(32 * to + nefes_rho(0, r)) * n_in_pad + 32 * ti] = acc[to][ti][r];
+            for (int r = 0; r < 16; ++r) out[(size_t)(32 * to + nefes_rho(0, r)) * ld + 32 * ti] = acc[to][ti][r];
+    if (bias) {                                          // column ld - 1 of the block's rows: sum over this split's samples
+#pragma unroll
+        for (int to = 0; to < NTO; ++to) {
+            const float t = bsum[to] + __shfl_xor(bsum[to], 32);
+            if (kh == 0) partial[(size_t)sp * n_out_pad * ld + (size_t)(32 * NTO * ob + 32 * to + m) * ld + ld - 1] = t;
+        }
+    }
 }
 
 
@@ -202,17 +219,21 @@ __device__ __forceinline__ void tri_of(Tri& o, float4 a, float4 b, bool relu) {
 template <int NTO, int NTI>
 __global__ __launch_bounds__(64) void train_dw_x6_kernel(int n_tiles, int rows, const float* __restrict__ gbuf, int g_row0,
                                                          const float* __restrict__ xbuf, int x_row0, int x_relu, int in_blocks,
-                                                         int splits, int n_in_pad, int n_out_pad, float* __restrict__ partial) {
+                                                         int splits, int ld, int with_bias, int n_out_pad, float* __restrict__ partial) {
     const int lane = threadIdx.x, m = lane & 31, kh = lane >> 5;
     const int ib = blockIdx.x % in_blocks, ob = blockIdx.x / in_blocks, sp = blockIdx.y;
     const int t_lo = (int)((long long)n_tiles * sp / splits), t_hi = (int)((long long)n_tiles * (sp + 1) / splits);
+    const bool bias = with_bias && ib == 0;              // bias gradient = row sums of G: the operand is in registers anyway
+    float bsum[NTO];
     f32x16 acc[NTO][NTI];
 #pragma unroll
-    for (int to = 0; to < NTO; ++to)
+    for (int to = 0; to < NTO; ++to) {
+        bsum[to] = 0.f;
 #pragma unroll
         for (int ti = 0; ti < NTI; ++ti)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[to][ti][r] = 0.f;
+    }
     const size_t go = (size_t)(g_row0 + 32 * NTO * ob + m) * 128 + 8 * kh;
     const size_t xo = (size_t)(x_row0 + 32 * NTI * ib + m) * 128 + 8 * kh;
     // one wave per SIMD at most (256 accumulator registers for the 128 x 128 block): the loads of step s + 1 are requested before
@@ -231,6 +252,11 @@ __global__ __launch_bounds__(64) void train_dw_x6_kernel(int n_tiles, int rows, 
 #pragma unroll 2
         for (int grp = 0; grp < 8; ++grp) {                    // 16 samples per step
             Tri A[NTO], B[NTI];
+            if (bias) {
+#pragma unroll
+                for (int to = 0; to < NTO; ++to)
+                    bsum[to] += ((ra[to][0].x + ra[to][0].y) + (ra[to][0].z + ra[to][0].w)) + ((ra[to][1].x + ra[to][1].y) + (ra[to][1].z + ra[to][1].w));
+            }
 #pragma unroll
             for (int to = 0; to < NTO; ++to) tri_of(A[to], ra[to][0], ra[to][1], false);
 #pragma unroll
@@ -254,26 +280,34 @@ __global__ __launch_bounds__(64) void train_dw_x6_kernel(int n_tiles, int rows, 
                 }
         }
     }
-    float* out = partial + (size_t)sp * n_out_pad * n_in_pad + (size_t)(32 * NTO * ob + 4 * kh) * n_in_pad + 32 * NTI * ib + m;
+    float* out = partial + (size_t)sp * n_out_pad * ld + (size_t)(32 * NTO * ob + 4 * kh) * ld + 32 * NTI * ib + m;
 #pragma unroll
     for (int to = 0; to < NTO; ++to)
 #pragma unroll
         for (int ti = 0; ti < NTI; ++ti)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) out[(size_t)(32 * to + nefes_rho(0, r)) * n_in_pad + 32 * ti] = acc[to][ti][r];
+            for (int r = 0; r < 16; ++r) out[(size_t)(32 * to + nefes_rho(0, r)) * ld + 32 * ti] = acc[to][ti][r];
+    if (bias) {                                          // column ld - 1 of the block's rows: sum over this split's samples
+#pragma unroll
+        for (int to = 0; to < NTO; ++to) {
+            const float t = bsum[to] + __shfl_xor(bsum[to], 32);
+            if (kh == 0) partial[(size_t)sp * n_out_pad * ld + (size_t)(32 * NTO * ob + 32 * to + m) * ld + ld - 1] = t;
+        }
+    }
 }
 
 template <int NTO, int NTI>
 int launch_dw(int n_tiles, int rows, const float* g, int g_row0, int out_tiles, const float* x, int x_row0, int in_tiles,
-              int x_relu, int splits, float* partial, hipStream_t st) {
+              int x_relu, int splits, int with_bias, float* partial, hipStream_t st) {
+    const int ld = 32 * in_tiles + (with_bias ? 1 : 0);
     const int ob = out_tiles / NTO, ib = in_tiles / NTI;
     static const bool f32_path = [] { const char* e = getenv("NEFES_TRAIN_DW"); return e && e[0] == 'f'; }();   // "f32": the fp32-MFMA kernel
     if (f32_path)
         train_dw_kernel<NTO, NTI><<<dim3((unsigned)(ob * ib), (unsigned)splits), dim3(64), 0, st>>>(
-            n_tiles, rows, g, g_row0, x, x_row0, x_relu, ib, splits, 32 * in_tiles, 32 * out_tiles, partial);
+            n_tiles, rows, g, g_row0, x, x_row0, x_relu, ib, splits, ld, with_bias, 32 * out_tiles, partial);
     else
         train_dw_x6_kernel<NTO, NTI><<<dim3((unsigned)(ob * ib), (unsigned)splits), dim3(64), 0, st>>>(
-            n_tiles, rows, g, g_row0, x, x_row0, x_relu, ib, splits, 32 * in_tiles, 32 * out_tiles, partial);
+            n_tiles, rows, g, g_row0, x, x_row0, x_relu, ib, splits, ld, with_bias, 32 * out_tiles, partial);
     return (int)hipGetLastError();
 }
 
@@ -309,19 +343,29 @@ extern "C" int nefes_train_dx(int64_t n_tiles, int rows, const float* dacts_in, 
     return (int)hipGetLastError();
 }
 
-extern "C" int nefes_train_dw(int64_t n_tiles, int rows, const float* dacts, int g_row0, int n_out, const float* acts,
-                              int x_row0, int n_in, int x_relu, int splits, float* partial, void* stream) {
+static int train_dw_impl(int64_t n_tiles, int rows, const float* dacts, int g_row0, int n_out, const float* acts,
+                         int x_row0, int n_in, int x_relu, int splits, int with_bias, float* partial, void* stream) {
     if (n_tiles <= 0 || rows <= 0 || !dacts || !acts || !partial || splits <= 0 || splits > n_tiles) return NEFES_E_BADARG;
     if (n_out <= 0 || n_out % 32 || n_in <= 0 || n_in % 32 || g_row0 < 0 || x_row0 < 0) return NEFES_E_BADARG;
     const int ot = n_out / 32, it = n_in / 32;
     hipStream_t st = (hipStream_t)stream;
     static const bool f32_dw = [] { const char* e = getenv("NEFES_TRAIN_DW"); return e && e[0] == 'f'; }();
     // bf16x6 kernel: a 128 x 128 block per wave where the shapes allow (every row of G and X is then read by ONE workgroup)
-    if (!f32_dw && ot % 4 == 0 && it % 4 == 0) return launch_dw<4, 4>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, partial, st);
+    if (!f32_dw && ot % 4 == 0 && it % 4 == 0) return launch_dw<4, 4>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, partial, st);
     const int nto = ot % 2 == 0 ? 2 : 1, nti = it % 4 == 0 ? 4 : (it % 2 == 0 ? 2 : 1);
 #define NEFES_DW(O, I) \
-    if (nto == O && nti == I) return launch_dw<O, I>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, partial, st);
+    if (nto == O && nti == I) return launch_dw<O, I>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, partial, st);
     NEFES_DW(2, 4) NEFES_DW(2, 2) NEFES_DW(2, 1) NEFES_DW(1, 4) NEFES_DW(1, 2) NEFES_DW(1, 1)
 #undef NEFES_DW
     return NEFES_E_UNSUPPORTED;
+}
+
+extern "C" int nefes_train_dw(int64_t n_tiles, int rows, const float* dacts, int g_row0, int n_out, const float* acts,
+                              int x_row0, int n_in, int x_relu, int splits, float* partial, void* stream) {
+    return train_dw_impl(n_tiles, rows, dacts, g_row0, n_out, acts, x_row0, n_in, x_relu, splits, 0, partial, stream);
+}
+
+extern "C" int nefes_train_dw_bias(int64_t n_tiles, int rows, const float* dacts, int g_row0, int n_out, const float* acts,
+                                   int x_row0, int n_in, int x_relu, int splits, float* partial, void* stream) {
+    return train_dw_impl(n_tiles, rows, dacts, g_row0, n_out, acts, x_row0, n_in, x_relu, splits, 1, partial, stream);
 }

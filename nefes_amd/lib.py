@@ -24,7 +24,7 @@ class NefesStreamInfo(C.Structure):
 
 
 class NefesBlobInfo(C.Structure):
-    _fields_ = [("total_bytes", C.c_uint64), ("stream", NefesStreamInfo * 11)]
+    _fields_ = [("total_bytes", C.c_uint64), ("stream", NefesStreamInfo * 13)]
 
 
 class NefesHashGridDesc(C.Structure):
@@ -32,9 +32,9 @@ class NefesHashGridDesc(C.Structure):
                 ("base_resolution", C.c_int32), ("per_level_scale", C.c_float), ("bound", C.c_float)]
 
 
-ABI_VERSION = 8        # NEFES_ABI_VERSION of include/nefes_hip.h
+ABI_VERSION = 9        # NEFES_ABI_VERSION of include/nefes_hip.h
 STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6, STREAM_BWD_FULL_X6, STREAM_BWD_STATIC = 0, 1, 2, 3, 4, 5, 6, 7
-STREAM_FWD_SIGMA_H3, STREAM_FWD_FULL_H3, STREAM_BWD_FULL_H3 = 8, 9, 10
+STREAM_FWD_SIGMA_H3, STREAM_FWD_FULL_H3, STREAM_BWD_FULL_H3, STREAM_FWD_STATIC_H3, STREAM_BWD_STATIC_H3 = 8, 9, 10, 11, 12
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
 XYZ_FREQ10, XYZ_EXTERNAL32 = 0, 1
 (TB_E, TB_DV, TB_L1, TB_FINAL, TB_DIR, TB_T0, TB_T1, TB_T2, TB_RGB, TB_SIG, TB_TH, TB_END) = (0, 1, 2, 10, 11, 12, 13, 14, 15, 16,
@@ -50,7 +50,8 @@ SIGNATURES = {
     "nefes_blob_info": (_i, [_desc, C.POINTER(NefesBlobInfo)]),
     "nefes_pack_weights": (_i, [_desc, C.POINTER(_p), _i, _p, _sz]),
     "nefes_pack_map": (_i, [_desc, _p, _sz, _p]),
-    "nefes_pack_device": (_i, [_p, C.c_int64, _p, C.c_int64, _p, _p]),
+    "nefes_pack_h3_plan": (_i, [_desc, _p, _sz, C.POINTER(_sz)]),
+    "nefes_pack_device": (_i, [_p, C.c_int64, _p, C.c_int64, _p, _i, _p, _p, _p]),
     "nefes_raygen_fwd": (_i, [_i, _i, _f, _p, _i, _i, _p, _p, _p, _p]),
     "nefes_raygen_bwd_workspace": (_sz, [_i]),
     "nefes_raygen_bwd": (_i, [_i, _i, _f, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
@@ -85,6 +86,7 @@ SIGNATURES = {
     "nefes_train_head_grad": (_i, [_desc, _i, _i, _i, _p, _p, _p, _p]),
     "nefes_train_dx": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
     "nefes_train_dw": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p]),
+    "nefes_train_dw_bias": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p]),
     "nefes_bicubic_up_fwd": (_i, [C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "nefes_bicubic_up_bwd": (_i, [C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "nefes_pose_compose_fwd": (_i, [_i, _p, _p, _p, C.c_float, C.POINTER(C.c_float), C.c_float, _p, _p]),

@@ -203,7 +203,7 @@ class PackedField:
         self.blob = blob.to(device)
         self.info = info
         self.generation = 0          # bumped by repack(); autograd nodes refuse to run backward across it
-        self.h3_valid = True         # the fp16 two-part streams are written by the host packer only (repack() leaves them stale)
+        self.h3_valid = True         # False once a re-pack WITHOUT the fp16 plan left the fp16 two-part streams stale (REPACK_H3 = False)
         self._map = None
 
     def repack(self, params):
@@ -217,19 +217,33 @@ class PackedField:
             L.check(lib.nefes_pack_map(self.desc, C.c_void_p(host_map.data_ptr()), n, C.cast(elems, C.c_void_p)), "nefes_pack_map")
             self._map = host_map.to(self.blob.device)
             self._elems = list(elems)[:36 if self.has_transient else 24]
+            # reductions the fp16 two-part streams need (one exponent per weight matrix, row bounds, bias maxima)
+            need = C.c_size_t(0)
+            L.check(lib.nefes_pack_h3_plan(self.desc, None, 0, C.byref(need)), "nefes_pack_h3_plan")
+            plan = torch.zeros(int(need.value), dtype=torch.int32)
+            L.check(lib.nefes_pack_h3_plan(self.desc, C.c_void_p(plan.data_ptr()), plan.numel(), None), "nefes_pack_h3_plan")
+            self._plan_jobs = int(plan[0])
+            self._plan = plan.to(self.blob.device)
+            self._plan_scratch = torch.zeros(32, dtype=torch.int32, device=self.blob.device)
         if [int(p.numel()) for p in params] != self._elems:
             raise RuntimeError("nefes_amd: parameter shapes do not match the packed network description")
         flat = torch.cat([p.detach().reshape(-1) for p in params]).to(torch.float32)
-        L.check(lib.nefes_pack_device(flat.data_ptr(), flat.numel(), self._map.data_ptr(), self._map.numel(), self.blob.data_ptr(),
-                                      _stream()), "nefes_pack_device")
+        h3 = REPACK_H3 and self._plan_jobs > 0
+        L.check(lib.nefes_pack_device(flat.data_ptr(), flat.numel(), self._map.data_ptr(), self._map.numel(),
+                                      self._plan.data_ptr() if h3 else None, self._plan_jobs if h3 else 0,
+                                      self._plan_scratch.data_ptr() if h3 else None, self.blob.data_ptr(), _stream()),
+                "nefes_pack_device")
         self.generation += 1
-        self.h3_valid = False        # the kernels fall back to the bf16x6 instances for this network from here on
+        if not h3:
+            self.h3_valid = False    # the kernels fall back to the bf16x6 instances for this network from here on
 
     def h3_byte_ranges(self):
-        """[(begin, end)] byte ranges of the blob that only the host packer writes: the fp16 two-part units and exponent tables."""
+        """[(begin, end)] byte ranges of the fp16 two-part units and their scale tables (refreshed by repack() only with the
+        fp16 plan, REPACK_H3)."""
         out = []
         fwd_kib = 16 if int(self.desc.width) == 128 else 32            # csrc/layout.h: NEFES_H3_{FWD,BWD}_SLAB_KIB_128 / NEFES_H3_{FWD,BWD}_SLAB_KIB
-        for k, kib in ((L.STREAM_FWD_SIGMA_H3, fwd_kib), (L.STREAM_FWD_FULL_H3, fwd_kib), (L.STREAM_BWD_FULL_H3, fwd_kib)):
+        for k, kib in ((L.STREAM_FWD_SIGMA_H3, fwd_kib), (L.STREAM_FWD_FULL_H3, fwd_kib), (L.STREAM_BWD_FULL_H3, fwd_kib),
+                       (L.STREAM_FWD_STATIC_H3, fwd_kib), (L.STREAM_BWD_STATIC_H3, fwd_kib)):
             si = self.info.stream[k]
             if si.n_slabs:
                 out.append((int(si.slab_off), int(si.slab_off + si.n_slabs * kib * 1024)))
@@ -269,6 +283,9 @@ def field_fwd(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, pts
 #   "x6"  bf16x6 split products (csrc/field_x6.h): the round-1 default; also what trainable / re-packed networks use
 #   "f32" the plain fp32-MFMA kernels (NEFES_X6=0 selects them too)
 SPLIT = os.environ.get("NEFES_SPLIT", "h3")
+# repack() also refreshes the fp16 two-part streams on the device (csrc/pack_device.hip h3_scales_kernel); "0": leave them stale and
+# let re-packed networks run on the bf16x6 instances (the round-2 behaviour)
+REPACK_H3 = os.environ.get("NEFES_REPACK_H3", "1") != "0"
 USE_X6 = os.environ.get("NEFES_X6", "1") != "0"
 # Number of cross products of the split: 6 (default: fp32-level accuracy) or 3 (opt-in, NEFES_X6_PRODUCTS=3: operands carried
 # to 16 bits, ~5e-6 of the output scale, half the matrix-core work; the shapes with bf16x6 instances -- nefes_field_fwd_x3 / _bwd_x3).

@@ -64,6 +64,7 @@ class _Pass:
         self.stream = ops._stream()
         self.dev = acts.device
         self.want = 2048                                              # waves per dW launch (1024 SIMDs x 2-3 resident)
+        self.db = {}                                                  # block -> bias gradient (filled by dw)
 
     def off(self, block):                                             # (a method, not a closure: no reference cycle
         return self.offsets[block]                                    #  may keep the multi-GB buffers alive)
@@ -76,16 +77,21 @@ class _Pass:
                                         self.dacts.data_ptr(), self.stream), "nefes_train_dx")
         return wt                                                     # kept alive by the caller until the stream is done
 
-    def dw(self, g_block, n_out, x_block, n_in, relu):
-        """-> [n_out_pad, n_in_pad] = sum_s G[o][s] f(X[i][s])"""
+    def dw(self, g_block, n_out, x_block, n_in, relu, bias=True):
+        """-> [n_out_pad, n_in_pad] = sum_s G[o][s] f(X[i][s]); bias: the row sums of G (the Linear's bias gradient) ride along as
+        one more column of the partials and are kept in self.db[g_block]."""
         op, ip = (n_out + 31) // 32 * 32, (n_in + 31) // 32 * 32
         blocks = max(1, (op // 32) * (ip // 32) // 8)
         splits = max(1, min(self.n_tiles, self.want // blocks))
-        partial = torch.empty(splits, op, ip, device=self.dev)
-        L.check(self.lib.nefes_train_dw(self.n_tiles, self.rows, self.dacts.data_ptr(), self.off(g_block), op,
-                                        self.acts.data_ptr(), self.off(x_block), ip, int(relu), splits, partial.data_ptr(),
-                                        self.stream), "nefes_train_dw")
-        return partial.sum(0)
+        partial = torch.empty(splits, op, ip + (1 if bias else 0), device=self.dev)
+        fn = self.lib.nefes_train_dw_bias if bias else self.lib.nefes_train_dw
+        L.check(fn(self.n_tiles, self.rows, self.dacts.data_ptr(), self.off(g_block), op, self.acts.data_ptr(), self.off(x_block),
+                   ip, int(relu), splits, partial.data_ptr(), self.stream), "nefes_train_dw")
+        out = partial.sum(0)
+        if bias:
+            self.db[g_block] = out[:, ip]
+            out = out[:, :ip]
+        return out
 
 
 def param_names(net, mode):
@@ -146,25 +152,22 @@ def weight_grads(net, pk, mode, N, S, raw_t, g_raw_t, acts, fused=None):
     for l in range(2, 9):
         dh = P.dw(TB(l), W, TB(l - 1), W, True)[:W, :W]
         if l == 5:
-            dh = torch.cat([P.dw(TB(5), W, L.TB_E, 64, False)[:W][:, e_idx], dh], 1)
+            dh = torch.cat([P.dw(TB(5), W, L.TB_E, 64, False, bias=False)[:W][:, e_idx], dh], 1)
         g[f"xyz_encoding_{l}.0.weight"] = dh
     g["static_sigma.0.weight"] = P.dw(L.TB_SIG, 1, TB(8), W, True)[:1, :W]
     g["xyz_encoding_final.weight"] = P.dw(L.TB_FINAL, W, TB(8), W, True)[:W, :W]
     g["dir_encoding.0.weight"] = torch.cat([P.dw(L.TB_DIR, H2, L.TB_FINAL, W, False)[:H2, :W],
-                                            P.dw(L.TB_DIR, H2, L.TB_DV, 32, False)[:H2][:, d_idx]], 1)
+                                            P.dw(L.TB_DIR, H2, L.TB_DV, 32, False, bias=False)[:H2][:, d_idx]], 1)
     g["static_rgb.0.weight"] = P.dw(L.TB_RGB, C3, L.TB_DIR, H2, True)[:C3, :H2]
     if full:
         g["transient_encoding.0.weight"] = torch.cat([P.dw(L.TB_T0, H2, L.TB_FINAL, W, False)[:H2, :W],
-                                                      P.dw(L.TB_T0, H2, L.TB_DV, 32, False)[:H2][:, d_idx]], 1)
+                                                      P.dw(L.TB_T0, H2, L.TB_DV, 32, False, bias=False)[:H2][:, d_idx]], 1)
         g["transient_encoding.2.weight"] = P.dw(L.TB_T1, H2, L.TB_T0, H2, True)[:H2, :H2]
         g["transient_encoding.4.weight"] = P.dw(L.TB_T2, H2, L.TB_T1, H2, True)[:H2, :H2]
         d_th = P.dw(L.TB_TH, 5, L.TB_T2, H2, True)[:5, :H2]
         g["transient_rgb.0.weight"], g["transient_sigma.0.weight"], g["transient_beta.0.weight"] = d_th[:3], d_th[3:4], d_th[4:5]
-    # ---- bias gradients: row sums over all samples ----
-    lo, hi = P.off(L.TB_L1), P.off(L.TB_END if full else L.TB_TH)
-    db = torch.zeros(P.rows, device=acts.device)
-    db[lo:hi] = dacts[:, lo:hi, :].sum((0, 2))
-    blk = lambda b, n: db[P.off(b):P.off(b) + n]
+    # ---- bias gradients: row sums of the gradient blocks over all samples, summed inside the dW launches ----
+    blk = lambda b, n: P.db[b][:n]
     for l in range(1, 9):
         g[f"xyz_encoding_{l}.0.bias"] = blk(TB(l), W)
     g["xyz_encoding_final.bias"], g["dir_encoding.0.bias"] = blk(L.TB_FINAL, W), blk(L.TB_DIR, H2)

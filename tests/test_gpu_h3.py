@@ -224,11 +224,39 @@ def test_h3_scale_bookkeeping_under_stress(case):
         assert e < 2e-5, name
 
 
-def test_repacked_network_falls_back_to_bf16x6():
-    """nefes_pack_device (re-pack after an optimizer step) does not write the fp16 streams: a re-packed network must use the
+def test_repacked_network_keeps_the_fp16_instances():
+    """nefes_pack_device with the fp16 plan (the default) refreshes the fp16 streams: a re-packed network stays on the fp16
+    instances and sees the new weights."""
+    from nefes_amd import lib as L
+    from nefes_amd import ops
+    net = _net("fine").requires_grad_(True)
+    pk = net.packed()
+    o, d, z, _ = _rays(9, 16, 5)
+    args = (pk, L.FIELD_FULL, 9, 16, o.to(DEV), d.to(DEV), z.to(DEV))
+    (a, _), keys = _timer_keys(lambda: ops.field_fwd_x6(*args, viewdirs=d.to(DEV)))
+    assert keys == {"field_fwd[full,h3]"}
+    with torch.no_grad():
+        net.xyz_encoding_2[0].weight.mul_(1.5)
+    assert net.packed() is pk and pk.h3_valid and pk.generation == 1
+    (b, _), keys = _timer_keys(lambda: ops.field_fwd_x6(*args, viewdirs=d.to(DEV)))
+    assert keys == {"field_fwd[full,h3]"}
+    assert float((a - b).abs().max()) > 1e-4                        # the new weights are in use
+    ops_split = ops.SPLIT
+    try:
+        ops.SPLIT = "x6"
+        (c, _), keys = _timer_keys(lambda: ops.field_fwd_x6(*args, viewdirs=d.to(DEV)))
+    finally:
+        ops.SPLIT = ops_split
+    assert keys == {"field_fwd[full,x6]"}
+    assert float((c - b).abs().max() / c.abs().max()) < 1e-5        # ... and they are the same weights the bf16x6 stream holds
+
+
+def test_repacked_network_falls_back_to_bf16x6(monkeypatch):
+    """A re-pack WITHOUT the fp16 plan (ops.REPACK_H3 = False) does not write the fp16 streams: such a network must use the
     bf16x6 instances, never stale fp16 weights."""
     from nefes_amd import lib as L
     from nefes_amd import ops
+    monkeypatch.setattr(ops, "REPACK_H3", False)
     net = _net("fine").requires_grad_(True)                         # trainable: parameter updates re-pack on the device
     pk = net.packed()
     o, d, z, _ = _rays(9, 16, 5)

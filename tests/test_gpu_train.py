@@ -236,13 +236,39 @@ def test_device_repack_bit_identical(Wd, C, typ, xyz):
     assert not torch.equal(pk.blob, blob0)
     sd = {n: p for n, p in net.named_parameters()}
     host = ops.PackedField(sd, net.W, net.W_features, net.encode_transient, DEV, pk.xyz_encoding)
-    # everything the device packer produces is bit-identical to the host packer's; the fp16 two-part streams are the host
-    # packer's alone (the kernels use the bf16x6 instances for a re-packed network: tests/test_gpu_h3.py)
+    # every stream the device packer produces is bit-identical to the host packer's -- fp32 fragments, bf16 triples, and the
+    # fp16 two-part units with their scale tables (exponent per matrix, row bounds, bias maxima: csrc/pack_device.hip)
+    assert pk.h3_valid and host.h3_valid
+    if not torch.equal(pk.blob, host.blob):
+        bad = (pk.blob != host.blob).nonzero().flatten()
+        where = [k for k in range(13) if pk.info.stream[k].n_slabs and int(pk.info.stream[k].bias_off) <= int(bad[0])]
+        raise AssertionError(f"{bad.numel()} bytes differ, first at {int(bad[0])} (stream {where[-1] if where else '?'})")
+    assert len(pk.h3_byte_ranges()) >= 4
+    assert net.packed() is pk and pk.generation == 1     # unchanged parameters: no work
+
+
+def test_device_repack_without_fp16_plan_leaves_fp16_streams(monkeypatch):
+    """ops.REPACK_H3 = False (NEFES_REPACK_H3=0): the round-2 behaviour -- fp16 streams untouched and flagged stale."""
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    monkeypatch.setattr(ops, "REPACK_H3", False)
+    torch.manual_seed(5)
+    net = NeRFH_NFF('coarse', W=128, f_dim=128).to(DEV)
+    pk = net.packed()
+    blob0 = pk.blob.clone()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    assert net.packed() is pk and not pk.h3_valid
+    host = ops.PackedField({n: p for n, p in net.named_parameters()}, net.W, net.W_features, net.encode_transient, DEV, pk.xyz_encoding)
     same = torch.ones(pk.blob.numel(), dtype=torch.bool, device=DEV)
     for a, b in pk.h3_byte_ranges():
         same[a:b] = False
-    assert torch.equal(pk.blob[same], host.blob[same]) and not pk.h3_valid and host.h3_valid
-    assert net.packed() is pk and pk.generation == 1     # unchanged parameters: no work
+    assert torch.equal(pk.blob[same], host.blob[same])
+    from nefes_amd import lib as L
+    si = pk.info.stream[L.STREAM_FWD_SIGMA_H3]           # an all-fp16 stream: left exactly as the host packer wrote it
+    a, b = int(si.slab_off), int(si.slab_off + si.n_slabs * 16 * 1024)
+    assert torch.equal(pk.blob[a:b], blob0[a:b]) and not torch.equal(host.blob[a:b], blob0[a:b])
 
 
 def test_backward_after_weight_update_raises():

@@ -25,7 +25,7 @@ def test_exports_match_header():
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.nefes_version() == L.ABI_VERSION == 8
+    assert lib.nefes_version() == L.ABI_VERSION == 9
 
 
 def test_missing_library_is_loud(monkeypatch):
@@ -490,9 +490,46 @@ def test_pack_map_reproduces_host_pack(Wd, C, tr, enc):
     blob = np.zeros(info.total_bytes, dtype=np.uint8)
     assert lib.nefes_pack_weights(desc, ptrs, n, blob.ctypes.data_as(ct.c_void_p), blob.size) == 0
     flat = np.concatenate([[0.0]] + [t.ravel() for t in tens]).astype(np.float32)
-    assert int((m >> 3).max()) == flat.size - 1           # every parameter is addressed, none beyond
-    x = flat[(m >> 3).astype(np.int64)]
-    part = m & 7
+    KEEP = np.uint32(0xffffffff)
+    keepw = m == KEEP
+    mc = np.where(keepw, 0, m).astype(np.uint32)
+    part, field, group = mc & 7, (mc >> 3) & 0xffffff, (mc >> 27).astype(np.int64)
+    is_val = (mc != 0) & (part != 7)
+    assert int(field[is_val].max()) == flat.size - 1       # every parameter is addressed, none beyond
+    x = flat[np.where(is_val, field, 0).astype(np.int64)]
+
+    # ---- the reductions of the fp16 plan (pack_device.hip h3_scales_kernel), in numpy ----
+    need = ct.c_size_t(0)
+    assert lib.nefes_pack_h3_plan(desc, None, 0, ct.byref(need)) == 0
+    plan = np.zeros(need.value, dtype=np.int32)
+    assert lib.nefes_pack_h3_plan(desc, plan.ctypes.data_as(ct.c_void_p), plan.size, None) == 0
+    f0 = flat[1:]
+    gexp = np.zeros(32, dtype=np.int32)
+    words = {}
+
+    def ranges_max(j):
+        best = np.float32(0)
+        for q in range(3):
+            off, cnt = int(j[2 + 2 * q]), int(j[3 + 2 * q])
+            if cnt:
+                best = max(best, np.abs(f0[off:off + cnt]).max())
+        return np.float32(best)
+    for jb in range(int(plan[0])):
+        j = plan[2 + 8 * jb:10 + 8 * jb]
+        kind, out = int(j[0]), int(j[1])
+        if kind == 0:
+            amax = ranges_max(j)
+            e = 0
+            if amax > 0 and np.isfinite(amax):
+                e = int(np.clip(14 + 1 - int(np.frexp(amax)[1]), -60, 60))
+            gexp[out] = e
+        elif kind == 1:
+            A, B = plan[j[4]:j[4] + j[2]].astype(np.int64), plan[j[5]:j[5] + j[3]].astype(np.int64)
+            sums = np.cumsum(np.abs(f0[A[:, None] + B[None, :]].astype(np.float64)), axis=1)[:, -1]   # sequential, in double
+            best = sums.astype(np.float32).max() if sums.size else np.float32(0)
+            words[out] = np.float32(best * np.float32(1.0001))
+        else:
+            words[out] = ranges_max(j)
 
     def rne(f):                                           # fp32 -> bf16 bits, round to nearest even
         u = f.view(np.uint32).astype(np.uint64)
@@ -502,20 +539,33 @@ def test_pack_map_reproduces_host_pack(Wd, C, tr, enc):
     r = (x - (hi << 16).astype(np.uint32).view(np.float32)).astype(np.float32)
     mid = rne(r)
     lo = rne((r - (mid << 16).astype(np.uint32).view(np.float32)).astype(np.float32))
-    out = np.select([part == 0, part == 1, part == 2, part == 3], [b & 0xffff, b >> 16, hi, mid], lo).astype(np.uint16)
-    out[m == 0] = 0
-    # the fp16 two-part streams (and their exponent tables) are written by the host packer only: the map leaves them zero
-    is_h3 = np.zeros(m.size, bool)
-    for k in (L.STREAM_FWD_SIGMA_H3, L.STREAM_FWD_FULL_H3, L.STREAM_BWD_FULL_H3):
-        si = info.stream[k]
-        if si.n_slabs:
-            kib = _h3_slab_kib("BWD" if k == L.STREAM_BWD_FULL_H3 else "FWD", Wd)
-            is_h3[si.slab_off // 2:(si.slab_off + si.n_slabs * kib * 1024) // 2] = True
-            is_h3[(si.bias_off + 4 * si.scale_off) // 2:(si.bias_off + 4 * si.bias_floats) // 2] = True
-    keep = ~is_h3                                         # (fp32 head segments inside the backward fp16 stream do get codes)
+    y = np.ldexp(x, gexp[np.where(part >= 5, group, 0)]).astype(np.float32)              # fp16 two-part: (hi, lo) of x 2^e
+    with np.errstate(over="ignore"):
+        h_hi = y.astype(np.float16)
+        h_lo = (y - h_hi.astype(np.float32)).astype(np.float32).astype(np.float16)
+    ge = gexp[group].astype(np.uint32)
+    ew = np.where(field == 1, ge & 0xffff, ge >> 16)
+    out = np.select([part == 0, part == 1, part == 2, part == 3, part == 4, part == 5, part == 6],
+                    [b & 0xffff, b >> 16, hi, mid, lo, h_hi.view(np.uint16).astype(np.uint32), h_lo.view(np.uint16).astype(np.uint32)],
+                    ew).astype(np.uint16)
+    out[mc == 0] = 0
+    out32 = out.view(np.uint32).copy()
+    assert np.array_equal(keepw[0::2], keepw[1::2])        # KEEP marks whole 32-bit words
+    kw = np.flatnonzero(keepw[0::2])
+    assert sorted(words) == sorted(kw.tolist())           # ... exactly the words the plan's reductions write
+    for w, v in words.items():
+        out32[w] = np.float32(v).view(np.uint32)
+    got = out32.view(np.uint16)
+    want = blob.view(np.uint16)
+    keep = np.ones(m.size, bool)
     keep[:256] = False                                    # 512-byte header
-    assert np.array_equal(out[keep], blob.view(np.uint16)[keep])
+    if not np.array_equal(got[keep], want[keep]):
+        bad = np.flatnonzero((got != want) & keep)
+        raise AssertionError(f"{bad.size} slots differ, first at byte {2 * int(bad[0])}: got {got[bad[0]]:#x} want {want[bad[0]]:#x} code {m[bad[0]]:#x}")
     assert not m[:256].any()                              # header slots are never written by the device packer
+    n_h3 = sum(1 for k in (L.STREAM_FWD_SIGMA_H3, L.STREAM_FWD_FULL_H3, L.STREAM_BWD_FULL_H3, L.STREAM_FWD_STATIC_H3, L.STREAM_BWD_STATIC_H3)
+               if info.stream[k].n_slabs)
+    assert n_h3 >= (3 if enc else 3 + (2 if tr else 0)) and (part >= 5).any()
 
 
 def test_m0_only_written_by_the_dma_helper(tmp_path):
