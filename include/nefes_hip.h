@@ -241,6 +241,11 @@ int nefes_train_row_offset(const NefesNetDesc* desc, int block);      /* block 0
 int nefes_field_fwd_train(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                           const float* rays_d, const float* z, const float* pts, const float* viewdirs, float* raw_t,
                           float* acts, uint32_t* masks, void* stream);
+/* The same on the fp16 two-part pipe (nefes_field_fwd_h3 instances with the static-head / full streams; widths 256 / C = 16
+ * and 128 / C = 128): same raw_t, acts rows and mask words. */
+int nefes_field_fwd_train_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                             const float* rays_d, const float* z, const float* pts, const float* viewdirs, float* raw_t,
+                             float* acts, uint32_t* masks, void* stream);
 /* The fused backward kernel (nefes_field_bwd / _static) that also stores, for every hidden layer, the gradient w.r.t. its
  * pre-activation into `dacts` (blocks L1..L8, FINAL, DIR, T0..T2): replaces the nefes_train_dx chain.  g_pts / g_viewdirs_s
  * [N*S,3] receive the per-sample input gradients as in nefes_field_bwd. */
@@ -248,6 +253,11 @@ int nefes_field_bwd_train(const NefesNetDesc* desc, const void* packed, int mode
                           const float* rays_d, const float* z, const float* viewdirs, const float* raw_t,
                           const float* g_raw_t, const uint32_t* masks, float* dacts, float* g_pts, float* g_viewdirs_s,
                           void* stream);
+/* The same on the fp16 two-part pipe (nefes_field_bwd_h3 instances, static-head / full streams): same dacts rows. */
+int nefes_field_bwd_train_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                             const float* rays_d, const float* z, const float* viewdirs, const float* raw_t,
+                             const float* g_raw_t, const uint32_t* masks, float* dacts, float* g_pts, float* g_viewdirs_s,
+                             void* stream);
 /* d raw_t [N][R][S] -> head pre-activation gradients in dacts blocks RGB, SIG (, TH); samples beyond N*S are zeroed. */
 int nefes_train_head_grad(const NefesNetDesc* desc, int mode, int N, int S, const float* raw_t, const float* g_raw_t,
                           float* dacts, void* stream);

@@ -4,8 +4,8 @@
 // (field_bwd.hip); the transposed products of transient_encoding.{4,2,0}, dir_encoding, xyz_encoding_final and layers 8..1 run on
 // v_mfma_f32_32x32x16_f16 as hh + hl + lh of power-of-two scaled (hi, lo) fp16 pairs; the three narrow head products (3+C, 5 and
 // 1 k-values) stay on the fp32 MFMA.  Every gradient vector carries a per-lane scale exponent (field_h3.h).
-#if defined(NEFES_TU_PART) && NEFES_TU_PART == 2
-#define NEFES_SLAB_KIB 16      // the Wd = 128 instance (layout.h NEFES_H3_BWD_SLAB_KIB_128)
+#if defined(NEFES_TU_PART) && (NEFES_TU_PART == 2 || NEFES_TU_PART == 4)
+#define NEFES_SLAB_KIB 16      // the Wd = 128 instances (layout.h NEFES_H3_BWD_SLAB_KIB_128)
 #else
 #define NEFES_SLAB_KIB 32
 #endif
@@ -35,9 +35,41 @@ struct FieldBwdH3Args {
     int N, S, R, C;
     long long M;
     int n_tiles;
+    float* dacts;           // TRAIN instances: [n_tiles][rows][128] gradient buffer (layout.h row map)
+    int rows;
 };
 
-template <int W, int C3, int ENC>   // C3 = 3 + C; ENC = NEFES_XYZ_*
+// TRAIN instances: the (masked) gradient vector a product consumes is d loss / d pre-activation of a hidden layer, which the
+// weight-gradient kernels (train.hip) need: it is stored on the way in, in true units (inv = 2^-exponent of the source tiles).
+// Element e = 8q + 2p (+1) of this lane's sample <-> feature 32 (e / 16) + rho_h(e % 16): row p[...] of the block (p carries the
+// block's first row, the lane half's +4 rows and the sample column) -- as Storing / StoringSplit of the fp32 / bf16x6 kernels.
+template <class Inner>
+struct StoringSplitH {
+    Inner in;
+    float* p;
+    float inv;
+    __device__ __forceinline__ void stage_a(PairRegs& s, int q, int pp) const {
+        in.stage_a(s, q, pp);
+        const int e = 8 * q + 2 * pp;
+        __builtin_nontemporal_store(s.x0 * inv, &p[(32 * (e >> 4) + nefes_rho(0, e & 15)) * 128]);
+        __builtin_nontemporal_store(s.x1 * inv, &p[(32 * ((e + 1) >> 4) + nefes_rho(0, (e + 1) & 15)) * 128]);
+    }
+    __device__ __forceinline__ void stage_b(PairRegs& s) const { in.stage_b(s); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c(Split2& o, int pp, const PairRegs& s) const { in.template stage_c<NOP>(o, pp, s); }
+    __device__ __forceinline__ void stage_c1(Split2& o, int pp, const PairRegs& s) const { in.stage_c1(o, pp, s); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c2(Split2& o, int pp, const PairRegs& s) const { in.template stage_c2<NOP>(o, pp, s); }
+};
+template <bool ON, class Inner>
+__device__ __forceinline__ auto wrap_store_h3(const Inner& in, float* p, float inv) {
+    if constexpr (ON) return StoringSplitH<Inner>{in, p, inv};
+    else return in;
+}
+
+// HAS_T = false: the static head only (NEFES_FIELD_STATIC forward: raw channels rgb+feature, sigma); the stream then is
+// NEFES_STREAM_BWD_STATIC_H3 and the transient segments are absent.  TRAIN: see StoringSplitH.
+template <int W, int C3, int ENC, bool HAS_T = true, bool TRAIN = false>   // C3 = 3 + C; ENC = NEFES_XYZ_*
 __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
@@ -51,9 +83,9 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
     const int j = lane & 31, h = lane >> 5;
     int* tab_i = (int*)(smem + NEFES_H3B_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (MW + 8) * 256);
     const float* tab_f = (const float*)tab_i;
-    if (threadIdx.x < 2 * NEFES_H3B_N) tab_i[threadIdx.x] = a.tab[threadIdx.x];
-    auto wexp = [&](int seg) { return tab_i[nefes_h3_tab_exp(seg)]; };
-    auto rowb = [&](int seg) { return tab_f[nefes_h3_tab_bound(seg)]; };
+    if (threadIdx.x < 2 * (HAS_T ? NEFES_H3B_N : NEFES_H3B_N_STATIC)) tab_i[threadIdx.x] = a.tab[threadIdx.x];
+    auto wexp = [&](int seg) { return tab_i[nefes_h3_tab_exp(nefes_h3b_seg(HAS_T, seg))]; };     // (segment ordinals of the full stream)
+    auto rowb = [&](int seg) { return tab_f[nefes_h3_tab_bound(nefes_h3b_seg(HAS_T, seg))]; };
     StagedRing ring;
     ring.init(a.stream, a.n_slabs, smem, wave, lane);
     const char* ring_lane = smem + lane * 16;
@@ -89,12 +121,14 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
         for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[ray * 3 + c];
         const int cT = C3 + 1;                       // transient rgb channels start
         float y_th[3] = {0.f, 0.f, 0.f}, g_th[3] = {0.f, 0.f, 0.f}, y_sg, g_sg, dr[KR];
+        if constexpr (HAS_T) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {            // compact slot (s,h) <-> transient-head row 2s+h (5 rows)
-            const int row = 2 * s + h;
-            const int ch = cT + (row < 5 ? row : 4);
-            y_th[s] = a.raw_t[chan0 + (size_t)ch * a.S];
-            g_th[s] = a.g_raw_t[chan0 + (size_t)ch * a.S];
+            for (int s = 0; s < 3; ++s) {            // compact slot (s,h) <-> transient-head row 2s+h (5 rows)
+                const int row = 2 * s + h;
+                const int ch = cT + (row < 5 ? row : 4);
+                y_th[s] = a.raw_t[chan0 + (size_t)ch * a.S];
+                g_th[s] = a.g_raw_t[chan0 + (size_t)ch * a.S];
+            }
         }
         y_sg = a.raw_t[chan0 + (size_t)C3 * a.S];
         g_sg = a.g_raw_t[chan0 + (size_t)C3 * a.S];
@@ -154,21 +188,29 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
             const int t = pick_exp(M);
             return t < 100 - ew ? t : 100 - ew;
         };
+        // TRAIN: this lane's column of a hidden block in the gradient buffer (first row + 4 rows for lane half 1)
+        auto gptr = [&](int block) -> float* {
+            if constexpr (!TRAIN) return nullptr;
+            else return a.dacts + ((size_t)tile * a.rows + nefes_train_row(W, 0, block) + 4 * h) * 128 + wave * 32 + j;
+        };
         f32x16 G2[NTH], T3[NTH], T4[NTH];
         // ---- static_rgb^T (fp32): 3+C gradients in compact slots -> d(dir_encoding output), exponent 0 ----
         mma_run<NTH, KR, 0, true>(ring, ring_lane, ArrayIn<KR>{dr}, ZeroInit{}, G2);
         const float M_g2 = rowb(NEFES_H3B_RGB) * pair_max(array_max(dr));
+        float M = 0.f;
+        int es3 = 0;
+        if constexpr (HAS_T) {
         // ---- transient heads^T (fp32): 5 pre-activation gradients -> d(transient_encoding.4 output), exponent 0 ----
         mma_run<NTH, 3, 0, true>(ring, ring_lane, ArrayIn<3>{dth}, ZeroInit{}, T3);
-        float M = rowb(NEFES_H3B_TH) * pair_max(array_max(dth));
+        M = rowb(NEFES_H3B_TH) * pair_max(array_max(dth));
         // ---- transient_encoding.4^T, .2^T ----
-        int es4, es3;
+        int es4;
         {
             load_bits(bh, MW_TRUNK + 3 * WH, WH);
             const int ew = wexp(NEFES_H3B_T2), tau = tau_of(M, ew);
             float mx = 0.f;
             es4 = tau + ew;
-            mma_run_h3<NTH, GS / 8, 0, true>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{T3, bh, pow2i(tau), mx}, ZeroInit{}, T4);
+            mma_run_h3<NTH, GS / 8, 0, true>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{T3, bh, pow2i(tau), mx}, gptr(NEFES_TB_T2), 1.f), ZeroInit{}, T4);
             M = rowb(NEFES_H3B_T2) * pair_max(mx);
         }
         {
@@ -176,8 +218,9 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
             const int ew = wexp(NEFES_H3B_T1), tau = tau_of(M, ew);
             float mx = 0.f;
             es3 = tau + ew;
-            mma_run_h3<NTH, GS / 8, 0, true>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{T4, bh, pow2i(tau - es4), mx}, ZeroInit{}, T3);
+            mma_run_h3<NTH, GS / 8, 0, true>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{T4, bh, pow2i(tau - es4), mx}, gptr(NEFES_TB_T1), pow2i(-es4)), ZeroInit{}, T3);
             M = rowb(NEFES_H3B_T1) * (pair_max(mx) * pow2i(-es4));
+        }
         }
         // Full-width accumulators, ping-pong.  Tiles [2, NTW+2) hold a layer's d hidden; XA tile 1 = d dir-embedding;
         // XB tiles 0,1 = d xyz-embedding (written by layer 5, accumulated by layer 1).
@@ -186,15 +229,17 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
         //      accumulate into the same tiles, so both operands are brought to one common exponent ----
         int es_dt;
         {
-            const int ew = wexp(NEFES_H3B_T0);                                    // = wexp(NEFES_H3B_DIR): one scale for the pair (pack.cpp)
-            const int tau = tau_of(fmaxf(M, M_g2), ew);
+            const int ew = wexp(NEFES_H3B_DIR);                                   // = wexp(NEFES_H3B_T0): one scale for the pair (pack.cpp)
+            const int tau = tau_of(HAS_T ? fmaxf(M, M_g2) : M_g2, ew);
             float mt = 0.f, mg = 0.f;
             es_dt = tau + ew;
-            load_bits(bh, MW_TRUNK + WH, WH);
-            mma_run_h3<NTW + 1, GS / 8, 1, true>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{T3, bh, pow2i(tau - es3), mt}, ZeroInit{}, XA);
+            if constexpr (HAS_T) {
+                load_bits(bh, MW_TRUNK + WH, WH);
+                mma_run_h3<NTW + 1, GS / 8, 1, true>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{T3, bh, pow2i(tau - es3), mt}, gptr(NEFES_TB_T0), pow2i(-es3)), ZeroInit{}, XA);
+            }
             load_bits(bh, MW_TRUNK, WH);
-            mma_run_h3<NTW + 1, GS / 8, 1, false>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{G2, bh, pow2i(tau), mg}, ZeroInit{}, XA);
-            M = rowb(NEFES_H3B_T0) * (pair_max(mt) * pow2i(-es3)) + rowb(NEFES_H3B_DIR) * pair_max(mg);
+            mma_run_h3<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{G2, bh, pow2i(tau), mg}, gptr(NEFES_TB_DIR), 1.f), ZeroInit{}, XA);
+            M = (HAS_T ? rowb(NEFES_H3B_T0) * (pair_max(mt) * pow2i(-es3)) : 0.f) + rowb(NEFES_H3B_DIR) * pair_max(mg);
         }
         // ---- xyz_encoding_final^T (no ReLU on its output) + static_sigma^T (one extra fp32 k-step) -> d h8 ----
         int es_b;
@@ -202,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
             const int ew = wexp(NEFES_H3B_FINAL), tau = tau_of(M, ew);
             float mx = 0.f;
             es_b = tau + ew;
-            mma_run_h3<NTW, W / 16, 2, true>(ring, ring_lane, IdentSplitH<NTW + 2, 2>{XA, pow2i(tau - es_dt), mx}, ZeroInit{}, XB);
+            mma_run_h3<NTW, W / 16, 2, true>(ring, ring_lane, wrap_store_h3<TRAIN>(IdentSplitH<NTW + 2, 2>{XA, pow2i(tau - es_dt), mx}, gptr(NEFES_TB_FINAL), pow2i(-es_dt)), ZeroInit{}, XB);
             const float dsig = STASH(6);
             float dsg[1];
             dsg[0] = dsig * pow2i(es_b);
@@ -218,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
             const int ew = wexp(NEFES_H3B_L8 + 8 - (L)), tau = tau_of(M, ew);                                       \
             float mx = 0.f;                                                                                         \
             ES_DST = tau + ew;                                                                                      \
-            mma_run_h3<NTILES, W / 16, T0, true>(ring, ring_lane, MaskedSplitH<NTW + 2, WT, 2>{SRC, bt, pow2i(tau - ES_SRC), mx}, ZeroInit{}, DST); \
+            mma_run_h3<NTILES, W / 16, T0, true>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTW + 2, WT, 2>{SRC, bt, pow2i(tau - ES_SRC), mx}, gptr(NEFES_TB_L1 + (L) - 1), pow2i(-(ES_SRC))), ZeroInit{}, DST); \
             M = rowb(NEFES_H3B_L8 + 8 - (L)) * (pair_max(mx) * pow2i(-(ES_SRC)));                                   \
         }
         NEFES_BWD_LAYER(8, XB, XA, es_b, es_a, NTW, 2)
@@ -242,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) XB[t][r] *= resc;
-            mma_run_h3<2, W / 16, 0, false>(ring, ring_lane, MaskedSplitH<NTW + 2, WT, 2>{XA, bt, pow2i(tau - es_a), mx}, ZeroInit{}, XB);
+            mma_run_h3<2, W / 16, 0, false>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTW + 2, WT, 2>{XA, bt, pow2i(tau - es_a), mx}, gptr(NEFES_TB_L1), pow2i(-es_a)), ZeroInit{}, XB);
         }
         float dDv[16];
         {
@@ -290,10 +335,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
     ring.drain();
 }
 
-template <int W, int C3, int ENC>
+template <int W, int C3, int ENC, bool HAS_T = true, bool TRAIN = false>
 static int launch_bwd_h3(const FieldBwdH3Args& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_H3B_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (8 * (W / 64) + 4 * (W / 128) + 8) * 256 + 256;
-    auto k = field_bwd_h3_kernel<W, C3, ENC>;
+    auto k = field_bwd_h3_kernel<W, C3, ENC, HAS_T, TRAIN>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -310,9 +355,11 @@ static int launch_bwd_h3(const FieldBwdH3Args& a, hipStream_t st) {
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { BWD_H3_256_EXT = 0, BWD_H3_128 };
+enum { BWD_H3_256_EXT = 0, BWD_H3_128, BWD_H3_TRAIN_STATIC, BWD_H3_TRAIN_FULL };
 int nefes_bwd_h3_launch_part1(int which, const FieldBwdH3Args& a, hipStream_t st);
 int nefes_bwd_h3_launch_part2(int which, const FieldBwdH3Args& a, hipStream_t st);
+int nefes_bwd_h3_launch_part3(int which, const FieldBwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256
+int nefes_bwd_h3_launch_part4(int which, const FieldBwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 128
 
 #if NEFES_TU_PART == 1
 int nefes_bwd_h3_launch_part1(int which, const FieldBwdH3Args& a, hipStream_t st) {
@@ -324,7 +371,52 @@ int nefes_bwd_h3_launch_part2(int which, const FieldBwdH3Args& a, hipStream_t st
     if (which == BWD_H3_128) return launch_bwd_h3<128, 131, NEFES_XYZ_FREQ10>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
+#elif NEFES_TU_PART == 3
+int nefes_bwd_h3_launch_part3(int which, const FieldBwdH3Args& a, hipStream_t st) {
+    if (which == BWD_H3_TRAIN_STATIC) return launch_bwd_h3<256, 19, NEFES_XYZ_FREQ10, false, true>(a, st);
+    if (which == BWD_H3_TRAIN_FULL) return launch_bwd_h3<256, 19, NEFES_XYZ_FREQ10, true, true>(a, st);
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 4      // (built like part 2)
+int nefes_bwd_h3_launch_part4(int which, const FieldBwdH3Args& a, hipStream_t st) {
+    if (which == BWD_H3_TRAIN_STATIC) return launch_bwd_h3<128, 131, NEFES_XYZ_FREQ10, false, true>(a, st);
+    if (which == BWD_H3_TRAIN_FULL) return launch_bwd_h3<128, 131, NEFES_XYZ_FREQ10, true, true>(a, st);
+    return NEFES_E_UNSUPPORTED;
+}
 #else   // part 0
+
+// The fused dX chain of the train-mode backward on the fp16 pipe: as nefes_field_bwd_train (field_bwd.hip), same `dacts` rows.
+extern "C" int nefes_field_bwd_train_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                                        const float* rays_d, const float* z, const float* viewdirs, const float* raw_t,
+                                        const float* g_raw_t, const uint32_t* masks, float* dacts, float* g_pts,
+                                        float* g_viewdirs_s, void* stream) {
+    if (!desc || !packed || !viewdirs || !raw_t || !g_raw_t || !masks || !dacts || !g_pts || !g_viewdirs_s || N <= 0 || S <= 0)
+        return NEFES_E_BADARG;
+    if (!(rays_o && rays_d && z)) return NEFES_E_BADARG;
+    if (mode != NEFES_FIELD_STATIC && mode != NEFES_FIELD_FULL) return NEFES_E_BADARG;
+    const bool full = mode == NEFES_FIELD_FULL;
+    if (full && !desc->has_transient) return NEFES_E_UNSUPPORTED;
+    const bool big = desc->width == 256 && desc->feat_dim == 16, small = desc->width == 128 && desc->feat_dim == 128;
+    if (!(big || small) || desc->xyz_encoding != NEFES_XYZ_FREQ10) return NEFES_E_UNSUPPORTED;
+    NefesBlobInfo info;
+    int rc = nefes_blob_info(desc, &info);
+    if (rc) return rc;
+    const NefesStreamInfo& si = info.stream[full ? NEFES_STREAM_BWD_FULL_H3 : NEFES_STREAM_BWD_STATIC_H3];
+    if (si.n_slabs == 0 || si.scale_count < 2 * (uint32_t)(full ? NEFES_H3B_N : NEFES_H3B_N_STATIC)) return NEFES_E_UNSUPPORTED;
+    FieldBwdH3Args a;
+    a.stream = (const char*)packed + si.slab_off;
+    a.tab = (const int*)((const char*)packed + si.bias_off) + si.scale_off;
+    a.n_slabs = si.n_slabs;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = nullptr; a.viewdirs = viewdirs;
+    a.raw_t = raw_t; a.g_raw_t = g_raw_t; a.masks = masks; a.g_pts = g_pts; a.g_enc = nullptr; a.g_vs = g_viewdirs_s;
+    a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + (full ? 6 : 1);
+    a.M = (long long)N * S;
+    a.n_tiles = (int)((a.M + 127) / 128);
+    a.dacts = dacts;
+    a.rows = nefes_train_row(desc->width, desc->feat_dim, NEFES_TB_END);
+    const int which = full ? BWD_H3_TRAIN_FULL : BWD_H3_TRAIN_STATIC;
+    return small ? nefes_bwd_h3_launch_part4(which, a, (hipStream_t)stream) : nefes_bwd_h3_launch_part3(which, a, (hipStream_t)stream);
+}
 
 extern "C" int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
                                   const float* rays_d, const float* z, const float* pts, const float* viewdirs,
@@ -349,6 +441,7 @@ extern "C" int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, 
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + 6;
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
+    a.dacts = nullptr; a.rows = 0;
     hipStream_t st = (hipStream_t)stream;
     if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd_h3<256, 19, NEFES_XYZ_FREQ10>(a, st);
     if (desc->width == 256 && desc->feat_dim == 16 && ext) return nefes_bwd_h3_launch_part1(BWD_H3_256_EXT, a, st);

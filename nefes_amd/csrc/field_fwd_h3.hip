@@ -8,7 +8,7 @@
 // in LDS between layer 1 and the skip at layer 5 instead of in registers: with one accumulator set in VGPRs (the compiler keeps
 // the set the vector ALU reads there) the kernel has no 32 registers to spare.
 // (layout.h is included below; the two sizes are repeated there as NEFES_H3_FWD_SLAB_KIB / _128 and checked against these)
-#if defined(NEFES_TU_PART) && NEFES_TU_PART == 2
+#if defined(NEFES_TU_PART) && (NEFES_TU_PART == 2 || NEFES_TU_PART == 4)
 #define NEFES_SLAB_KIB 16      // the Wd = 128 instances: 2 x 16 KiB of ring, two workgroups per CU (see launch_h3)
 #else
 #define NEFES_SLAB_KIB 32
@@ -38,17 +38,31 @@ struct FieldFwdH3Args {
     long long M;
     int n_tiles;
     uint32_t s_magic, s_shift;   // m / S == mulhi(m, s_magic) >> s_shift for every m < 2^31 (host: magic_div)
+    float* acts;             // TRAIN instances: [n_tiles][rows][128] pre-activations + embeddings (layout.h row map)
+    int rows;
 };
 
-// MODE: NEFES_FIELD_SIGMA or NEFES_FIELD_FULL; ENC: NEFES_XYZ_FREQ10 or NEFES_XYZ_EXTERNAL32 (hash grid);
-// (W, NTR) = (256, 1) [C = 16] or (128, 5) [C = 128: the reference-default shape]
-template <int MODE, int ENC, int W = 256, int NTR = 1>
+// TRAIN: tiles X[T0 .. T0+NT) hold a layer's pre-activations times 2^es; rows [row0, row0 + 32 NT) of this tile of `acts` get
+// the true values (inv = 2^-es).  One register = two 128-byte row segments (lane halves hold rows rho and rho + 4).
+template <int NT, int T0, int NX>
+__device__ __forceinline__ void train_save_h3(float* tile_base, uint32_t voff, int row0, const f32x16 (&X)[NX], float inv) {
+    float* p = tile_base + (size_t)row0 * 128 + voff;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(X[T0 + t][r] * inv, &p[(32 * t + nefes_rho(0, r)) * 128]);
+}
+
+// MODE: NEFES_FIELD_SIGMA, NEFES_FIELD_STATIC (static head only: the TRAIN instances of a coarse network) or NEFES_FIELD_FULL;
+// ENC: NEFES_XYZ_FREQ10 or NEFES_XYZ_EXTERNAL32 (hash grid); (W, NTR) = (256, 1) [C = 16] or (128, 5) [C = 128: the
+// reference-default shape].  TRAIN: every hidden layer's pre-activation and both embeddings also go to a.acts (weight gradients).
+template <int MODE, int ENC, int W = 256, int NTR = 1, bool TRAIN = false>
 __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(FieldFwdH3Args a) {
     static_assert(NEFES_SLAB_KIB == (W == 128 ? NEFES_H3_FWD_SLAB_KIB_128 : NEFES_H3_FWD_SLAB_KIB), "ring slab size != the packer's for this width");
     constexpr int NTW = W / 32, NTH = W / 64;
     constexpr int ES = ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : NEFES_E_STEPS;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128), WT = (NTW + 1) / 2, WH = (NTH + 1) / 2;
-    constexpr int NSEG = MODE == NEFES_FIELD_SIGMA ? NEFES_H3F_SIG + 1 : NEFES_H3F_N;      // segments of the stream
+    constexpr int NSEG = MODE == NEFES_FIELD_SIGMA ? NEFES_H3F_SIG + 1 : (MODE == NEFES_FIELD_STATIC ? NEFES_H3F_N_STATIC : NEFES_H3F_N);   // segments of the stream
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring_base = smem;
     float* bias_lds = (float*)(smem + NEFES_H3_SLOTS * NEFES_SLAB_BYTES);
@@ -114,9 +128,20 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
         }
 #pragma unroll
         for (int s = 0; s < ES; ++s) e_lds[s * 64] = E[s];          // own lane's column only: no barrier needed
+        float* act_tile = nullptr;                                  // wave-uniform
+        const uint32_t act_voff = (uint32_t)(4 * h * 128 + wave * 32 + j);
+        if constexpr (TRAIN) {
+            act_tile = a.acts + (size_t)tile * a.rows * 128;
+            float* pe = act_tile + (size_t)nefes_train_row(W, 0, NEFES_TB_E) * 128 + (h * 128 + wave * 32 + j);
+#pragma unroll
+            for (int s = 0; s < ES; ++s) __builtin_nontemporal_store(E[s], &pe[2 * s * 128]);     // slot (s,h) -> row 2s+h
+        }
+        auto save_trunk = [&](int layer, const f32x16 (&X)[NTW], int es) {   // layer 1..9 (9 = xyz_encoding_final)
+            if constexpr (TRAIN) train_save_h3<NTW, 0>(act_tile, act_voff, nefes_train_row(W, 0, NEFES_TB_L1) + (layer - 1) * W, X, pow2i(-es));
+        };
         int mask_word = 0;
         auto put_masks = [&](const uint32_t* bits, int n) {
-            if (MODE == NEFES_FIELD_FULL && a.masks) {
+            if (MODE != NEFES_FIELD_SIGMA && a.masks) {
                 uint32_t* mask_tile = a.masks + ((size_t)((long long)tile * 4 + wave) * MW) * 64;      // wave-uniform
                 for (int w = 0; w < n; ++w) __builtin_nontemporal_store(bits[w], &mask_tile[(mask_word + w) * 64 + lane]);   // written once, read once by the backward: keep it out of the way of the weight stream in L2
                 mask_word += n;
@@ -135,7 +160,7 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
 #pragma unroll
             for (int w = 0; w < WT; ++w) bits[w] = 0u;
         };
-        constexpr bool CAP = MODE == NEFES_FIELD_FULL;
+        constexpr bool CAP = MODE != NEFES_FIELD_SIGMA;
         // Scale bookkeeping (field_h3.h), all per lane and identical on the two lanes of a sample:
         //   es_x  exponent an accumulator set carries (acc = 2^es_x * true value)
         //   M_x   upper bound of the set's largest (ReLU'd / absolute) true value, from the packer's row bounds
@@ -165,6 +190,7 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
             es_a = tau + wexp(NEFES_H3F_L1);
             mma_run_h3<NTW, ES / 8, 0, true>(ring, ring_lane, LdsSplitH{e_lds, pow2i(tau)}, bias_at(0, es_a), A);            // layer 1
             M = rowb(NEFES_H3F_L1) * mE + bmax(NEFES_H3BB_L1);
+            save_trunk(1, A, es_a);
         }
 #pragma unroll 1
         for (int p = 0; p < 4; ++p) {
@@ -179,6 +205,7 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                                                  bias_at((l1 - 1) * W, tau + ew), B);                 // layers 2, 4, 6, 8
                 M = rowb(seg1) * (pair_max(mx) * pow2i(-es_a)) + bmax(l1 - 1);
                 es_b = tau + ew;
+                save_trunk(l1, B, es_b);
             }
             put_masks(bits, WT);                                                                      // mask of layer l1-1
             if (p == 3 && MODE == NEFES_FIELD_SIGMA) break;
@@ -195,13 +222,16 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                 M = rowb(seg2) * (pair_max(mx) * pow2i(-es_b)) + (p == 1 ? rowb(NEFES_H3F_L5E) * mE : 0.f)
                     + bmax(l2 <= 8 ? l2 - 1 : NEFES_H3BB_FINAL);
                 es_a = tau + ew;
+                save_trunk(l2, A, es_a);
             }
             put_masks(bits, WT);                                                                      // mask of layer l1
         }
         if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head(B, es_b, tau_of(M, wexp(NEFES_H3F_SIG)));
-        if constexpr (MODE == NEFES_FIELD_FULL) {
-            // dir_encoding and transient_encoding.0 as ONE stacked 2*NTH-tile product (pack.cpp add_heads_x6): tiles
-            // [0, NTH) = dir, [NTH, 2 NTH) = t0
+        if constexpr (MODE != NEFES_FIELD_SIGMA) {
+            // FULL: dir_encoding and transient_encoding.0 as ONE stacked 2*NTH-tile product (pack.cpp add_heads_x6): tiles
+            // [0, NTH) = dir, [NTH, 2 NTH) = t0.  STATIC: dir_encoding alone (add_static_head_h3), NTH tiles.
+            constexpr bool FULL = MODE == NEFES_FIELD_FULL;
+            constexpr int NDT = FULL ? 2 * NTH : NTH;
             float v[3];
             {
                 uint32_t mm, rr, ss;
@@ -216,7 +246,12 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
 #pragma unroll
                 for (int s = 0; s < 16; ++s) Dv[s] = s < NEFES_D_STEPS ? d14[s] : 0.f;
             }
-            f32x16 dt[2 * NTH], acc3[NTH], acc2[NTH];
+            if constexpr (TRAIN) {
+                float* pd = act_tile + (size_t)nefes_train_row(W, 0, NEFES_TB_DV) * 128 + (h * 128 + wave * 32 + j);
+#pragma unroll
+                for (int s = 0; s < NEFES_D_STEPS; ++s) __builtin_nontemporal_store(Dv[s], &pd[2 * s * 128]);
+            }
+            f32x16 dt[NDT];
             uint32_t bits2[WH];
             auto clear2 = [&]() {
 #pragma unroll
@@ -233,18 +268,25 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                 const int tau = tau_of(fmaxf(M, mD), ew);                            // common exponent of both parts
                 float mx = 0.f;
                 es_dt = tau + ew;
-                mma_run_h3<2 * NTH, W / 16, 0, true>(ring, ring_lane, IdentSplitH<NTW, 0>{A, pow2i(tau - es_a), mx},
+                if constexpr (FULL)
+                    mma_run_h3<NDT, W / 16, 0, true>(ring, ring_lane, IdentSplitH<NTW, 0>{A, pow2i(tau - es_a), mx},
                                                      Bias2{bias_at(B_DIR, es_dt), bias_at(B_T0, es_dt)}, dt);
-                mma_run_h3<2 * NTH, 2, 0, false>(ring, ring_lane, ArraySplitH<16>{Dv, pow2i(tau)}, ZeroInit{}, dt);
+                else
+                    mma_run_h3<NDT, W / 16, 0, true>(ring, ring_lane, IdentSplitH<NTW, 0>{A, pow2i(tau - es_a), mx}, bias_at(B_DIR, es_dt), dt);
+                mma_run_h3<NDT, 2, 0, false>(ring, ring_lane, ArraySplitH<16>{Dv, pow2i(tau)}, ZeroInit{}, dt);
                 M = rowb(NEFES_H3F_DT_H) * (pair_max(mx) * pow2i(-es_a)) + rowb(NEFES_H3F_DT_D) * mD
-                    + fmaxf(bmax(NEFES_H3BB_DIR), bmax(NEFES_H3BB_T0));               // both halves of the stacked output
+                    + (FULL ? fmaxf(bmax(NEFES_H3BB_DIR), bmax(NEFES_H3BB_T0)) : bmax(NEFES_H3BB_DIR));   // both halves of the stacked output
+                if constexpr (TRAIN) {
+                    train_save_h3<NTH, 0>(act_tile, act_voff, nefes_train_row(W, 0, NEFES_TB_DIR), dt, pow2i(-es_dt));
+                    if constexpr (FULL) train_save_h3<NTH, NTH>(act_tile, act_voff, nefes_train_row(W, 0, NEFES_TB_T0), dt, pow2i(-es_dt));
+                }
             }
             {
                 f32x16 ar[NTR];
                 clear2();
                 const int ew = wexp(NEFES_H3F_RGB), tau = tau_of(M, ew), es = tau + ew;
                 float mdummy = 0.f;
-                mma_run_h3<NTR, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, 2 * NTH, WH>{dt, bits2, pow2i(tau - es_dt), mdummy},
+                mma_run_h3<NTR, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, NDT, WH>{dt, bits2, pow2i(tau - es_dt), mdummy},
                                                  bias_at(B_RGB, es), ar);
                 put_masks(bits2, WH);                                 // dir_encoding
                 float* col = raw_col();
@@ -260,15 +302,18 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                         }
                 }
             }
+            if constexpr (FULL) {
+            f32x16 acc3[NTH], acc2[NTH];
             int es3, es2, es_th;
             clear2();
             {
                 const int ew = wexp(NEFES_H3F_T1), tau = tau_of(M, ew);
                 float mx = 0.f;
                 es3 = tau + ew;
-                mma_run_h3<NTH, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, 2 * NTH, WH, NTH>{dt, bits2, pow2i(tau - es_dt), mx},
+                mma_run_h3<NTH, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, NDT, WH, NTH>{dt, bits2, pow2i(tau - es_dt), mx},
                                                  bias_at(B_T1, es3), acc3);
                 M = rowb(NEFES_H3F_T1) * (pair_max(mx) * pow2i(-es_dt)) + bmax(NEFES_H3BB_T1);
+                if constexpr (TRAIN) train_save_h3<NTH, 0>(act_tile, act_voff, nefes_train_row(W, 0, NEFES_TB_T1), acc3, pow2i(-es3));
             }
             put_masks(bits2, WH);                                     // transient_encoding.0
             clear2();
@@ -279,6 +324,7 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                 mma_run_h3<NTH, W / 32, 0, true>(ring, ring_lane, ReluSplitH<true, NTH, WH>{acc3, bits2, pow2i(tau - es3), mx},
                                                  bias_at(B_T2, es2), acc2);
                 M = rowb(NEFES_H3F_T2) * (pair_max(mx) * pow2i(-es3)) + bmax(NEFES_H3BB_T2);
+                if constexpr (TRAIN) train_save_h3<NTH, 0>(act_tile, act_voff, nefes_train_row(W, 0, NEFES_TB_T2), acc2, pow2i(-es2));
             }
             put_masks(bits2, WH);                                     // transient_encoding.2
             f32x16 th[1];
@@ -304,6 +350,7 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                     __builtin_nontemporal_store(softplus_ref(th[0][0] * inv), &o[(size_t)4 * a.S]);
                 }
             }
+            }
         }
     }
 #ifdef H3_STAMP
@@ -321,11 +368,11 @@ static void magic_div(uint32_t d, uint32_t& magic, uint32_t& shift) {
     shift = (uint32_t)(p - 32);
 }
 
-template <int MODE, int ENC, int W = 256, int NTR = 1>
+template <int MODE, int ENC, int W = 256, int NTR = 1, bool TRAIN = false>
 static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
     constexpr int ES_ = ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : NEFES_E_STEPS;
     const size_t lds = (size_t)NEFES_H3_SLOTS * NEFES_SLAB_BYTES + ((a.bias_floats + 63) / 64) * 256 + (size_t)4 * ES_ * 64 * 4;
-    auto k = field_fwd_h3_kernel<MODE, ENC, W, NTR>;
+    auto k = field_fwd_h3_kernel<MODE, ENC, W, NTR, TRAIN>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -348,9 +395,11 @@ static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_128_SIGMA, H3_128_FULL };
+enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_128_SIGMA, H3_128_FULL, H3_TRAIN_STATIC, H3_TRAIN_FULL };
 int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st);
 int nefes_fwd_h3_launch_part2(int which, const FieldFwdH3Args& a, hipStream_t st);
+int nefes_fwd_h3_launch_part3(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256
+int nefes_fwd_h3_launch_part4(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 128
 
 #if defined(H3_STAMP) && defined(H3_STAMP_READER)   // exactly one translation unit of a diagnostic build (tools/stamp_h3.sh)
 extern "C" int nefes_debug_h3_stamps(unsigned long long* out3) {
@@ -389,8 +438,54 @@ int nefes_fwd_h3_launch_part2(int which, const FieldFwdH3Args& a, hipStream_t st
     }
     return NEFES_E_UNSUPPORTED;
 }
+#elif NEFES_TU_PART == 3
+int nefes_fwd_h3_launch_part3(int which, const FieldFwdH3Args& a, hipStream_t st) {
+    switch (which) {
+        case H3_TRAIN_STATIC: return launch_h3<NEFES_FIELD_STATIC, NEFES_XYZ_FREQ10, 256, 1, true>(a, st);
+        case H3_TRAIN_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 256, 1, true>(a, st);
+    }
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 4      // (built like part 2)
+int nefes_fwd_h3_launch_part4(int which, const FieldFwdH3Args& a, hipStream_t st) {
+    switch (which) {
+        case H3_TRAIN_STATIC: return launch_h3<NEFES_FIELD_STATIC, NEFES_XYZ_FREQ10, 128, 5, true>(a, st);
+        case H3_TRAIN_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5, true>(a, st);
+    }
+    return NEFES_E_UNSUPPORTED;
+}
 #else   // part 0
 
+// Train-mode forward on the fp16 pipe: as nefes_field_fwd_train (field_fwd.hip), same `acts` rows, same masks, same raw_t.
+extern "C" int nefes_field_fwd_train_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                                        const float* rays_d, const float* z, const float* pts, const float* viewdirs,
+                                        float* raw_t, float* acts, uint32_t* masks, void* stream) {
+    if (!desc || !packed || !raw_t || !acts || !viewdirs || N <= 0 || S <= 0) return NEFES_E_BADARG;
+    if (!pts && !(rays_o && rays_d && z)) return NEFES_E_BADARG;
+    if (mode != NEFES_FIELD_STATIC && mode != NEFES_FIELD_FULL) return NEFES_E_UNSUPPORTED;
+    if (mode == NEFES_FIELD_FULL && !desc->has_transient) return NEFES_E_BADARG;
+    const bool big = desc->width == 256 && desc->feat_dim == 16, small = desc->width == 128 && desc->feat_dim == 128;
+    if (!(big || small) || desc->xyz_encoding != NEFES_XYZ_FREQ10) return NEFES_E_UNSUPPORTED;
+    NefesBlobInfo info;
+    int rc = nefes_blob_info(desc, &info);
+    if (rc) return rc;
+    const NefesStreamInfo& si = info.stream[mode == NEFES_FIELD_STATIC ? NEFES_STREAM_FWD_STATIC_H3 : NEFES_STREAM_FWD_FULL_H3];
+    if (si.n_slabs == 0) return NEFES_E_UNSUPPORTED;
+    FieldFwdH3Args a;
+    a.stream = (const char*)packed + si.slab_off;
+    a.bias = (const float*)((const char*)packed + si.bias_off);
+    a.n_slabs = si.n_slabs; a.bias_floats = si.bias_floats; a.scale_off = si.scale_off;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.xyz_enc = nullptr; a.viewdirs = viewdirs; a.raw_t = raw_t; a.masks = masks;
+    a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + (mode == NEFES_FIELD_STATIC ? 1 : 6);
+    a.M = (long long)N * S;
+    if (a.M >= (1ll << 31) - 256) return NEFES_E_UNSUPPORTED;      // the kernel indexes samples with 32 bits
+    a.n_tiles = (int)((a.M + 127) / 128);
+    a.acts = acts;
+    a.rows = nefes_train_row(desc->width, desc->feat_dim, NEFES_TB_END);
+    magic_div((uint32_t)S, a.s_magic, a.s_shift);
+    const int which = mode == NEFES_FIELD_STATIC ? H3_TRAIN_STATIC : H3_TRAIN_FULL;
+    return small ? nefes_fwd_h3_launch_part4(which, a, (hipStream_t)stream) : nefes_fwd_h3_launch_part3(which, a, (hipStream_t)stream);
+}
 
 extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                                   const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
@@ -412,6 +507,7 @@ extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, 
     a.bias = (const float*)((const char*)packed + si.bias_off);
     a.n_slabs = si.n_slabs; a.bias_floats = si.bias_floats; a.scale_off = si.scale_off;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.xyz_enc = xyz_enc; a.viewdirs = viewdirs; a.raw_t = raw_t; a.masks = masks;
+    a.acts = nullptr; a.rows = 0;
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = mode == NEFES_FIELD_SIGMA ? 1 : 3 + a.C + 6;
     a.M = (long long)N * S;
     if (a.M >= (1ll << 31) - 256) return NEFES_E_UNSUPPORTED;      // the kernel indexes samples with 32 bits

@@ -82,7 +82,9 @@ SIGNATURES = {
     "nefes_train_rows": (_sz, [_desc]),
     "nefes_train_row_offset": (_i, [_desc, _i]),
     "nefes_field_fwd_train": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_field_fwd_train_h3": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_bwd_train": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_field_bwd_train_h3": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_train_head_grad": (_i, [_desc, _i, _i, _i, _p, _p, _p, _p]),
     "nefes_train_dx": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
     "nefes_train_dw": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p]),

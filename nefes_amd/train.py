@@ -103,6 +103,13 @@ def param_names(net, mode):
     return [n + s for n in names for s in (".weight", ".bias")]
 
 
+def fp16_pipe(pk):
+    """The train-mode forward (and the fused dX chain) run on the fp16 two-part instances when ops.SPLIT selects them, the
+    network's fp16 streams are current, and the shape has them (Wd = 256 / C = 16, Wd = 128 / C = 128, frequency embedding)."""
+    shape = (pk.width == 256 and pk.feat_dim == 16) or (pk.width == 128 and pk.feat_dim == 128)
+    return ops._h3(pk) and shape and pk.xyz_encoding == L.XYZ_FREQ10
+
+
 FUSED_DX = True       # one fused backward launch (nefes_field_bwd_train) instead of the layer-by-layer nefes_train_dx chain
 
 
@@ -126,9 +133,10 @@ def weight_grads(net, pk, mode, N, S, raw_t, g_raw_t, acts, fused=None):
     if fused is not None:
         o, d, v, zz, masks = fused
         g_pts, g_vs = torch.empty(N * S, 3, device=acts.device), torch.empty(N * S, 3, device=acts.device)
-        L.check(lib.nefes_field_bwd_train(C.byref(desc), pk.blob.data_ptr(), mode, N, S, o.data_ptr(), d.data_ptr(), zz.data_ptr(),
-                                          v.data_ptr(), raw_t.data_ptr(), g_raw_t.data_ptr(), masks.data_ptr(), dacts.data_ptr(),
-                                          g_pts.data_ptr(), g_vs.data_ptr(), ops._stream()), "nefes_field_bwd_train")
+        bwd = lib.nefes_field_bwd_train_h3 if fp16_pipe(pk) else lib.nefes_field_bwd_train
+        L.check(bwd(C.byref(desc), pk.blob.data_ptr(), mode, N, S, o.data_ptr(), d.data_ptr(), zz.data_ptr(), v.data_ptr(),
+                    raw_t.data_ptr(), g_raw_t.data_ptr(), masks.data_ptr(), dacts.data_ptr(), g_pts.data_ptr(), g_vs.data_ptr(),
+                    ops._stream()), "nefes_field_bwd_train")
     else:
         if full:
             w_th = torch.cat([w("transient_rgb.0"), w("transient_sigma.0"), w("transient_beta.0")], 0)     # raw channel order
@@ -202,11 +210,12 @@ class FieldTrain(torch.autograd.Function):
         acts = torch.empty(n_tiles, rows, 128, device=zz.device)
         fused = FUSED_DX and pk.xyz_encoding == L.XYZ_FREQ10
         masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=zz.device) if fused else None
-        with ops._timed("field_fwd_train"):
-            L.check(lib.nefes_field_fwd_train(C.byref(pk.desc), pk.blob.data_ptr(), mode, N, S, ops._chk(o, "rays_o"),
-                                              ops._chk(d, "rays_d"), ops._chk(zz, "z"), None, ops._chk(v, "viewdirs"),
-                                              raw_t.data_ptr(), acts.data_ptr(), None if masks is None else masks.data_ptr(),
-                                              ops._stream()), "nefes_field_fwd_train")
+        h3 = fused and fp16_pipe(pk)
+        fwd = lib.nefes_field_fwd_train_h3 if h3 else lib.nefes_field_fwd_train
+        with ops._timed("field_fwd_train[h3]" if h3 else "field_fwd_train"):
+            L.check(fwd(C.byref(pk.desc), pk.blob.data_ptr(), mode, N, S, ops._chk(o, "rays_o"), ops._chk(d, "rays_d"),
+                        ops._chk(zz, "z"), None, ops._chk(v, "viewdirs"), raw_t.data_ptr(), acts.data_ptr(),
+                        None if masks is None else masks.data_ptr(), ops._stream()), "nefes_field_fwd_train")
         if fused:
             ops._tap("masks", (masks, N, S, pk.width, mode))
             ctx.save_for_backward(raw_t, acts, o, d, v, zz, masks)
@@ -226,7 +235,7 @@ class FieldTrain(torch.autograd.Function):
         ctx.pk.check_generation(ctx.pk_gen)
         raw_t, acts = ctx.saved_tensors[:2]
         N, S = ctx.NS
-        with ops._timed("field_bwd_train"):
+        with ops._timed("field_bwd_train[h3]" if (ctx.fused and fp16_pipe(ctx.pk)) else "field_bwd_train"):
             g = weight_grads(ctx.net, ctx.pk, ctx.mode, N, S, raw_t, ops._f32(g_raw_t), acts,
                              fused=tuple(ctx.saved_tensors[2:]) if ctx.fused else None)
         names = param_names(ctx.net, ctx.mode)

@@ -38,11 +38,16 @@ def _relerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+@pytest.mark.parametrize("pipe", ["h3", "f32"])
 @pytest.mark.parametrize("Wd,C", [(256, 16), (128, 128)])
 @pytest.mark.parametrize("typ", ["coarse", "fine"])
-def test_field_train_weight_grads(Wd, C, typ):
+def test_field_train_weight_grads(Wd, C, typ, pipe, monkeypatch):
+    """pipe: the train-mode forward and the fused dX chain on the fp16 two-part instances (default) or on the fp32-MFMA ones."""
     from nefes_amd import lib as L
+    from nefes_amd import ops
     from nefes_amd import train as TR
+    monkeypatch.setattr(ops, "SPLIT", pipe)
+    monkeypatch.setattr(ops, "TIMERS", {})
     torch.manual_seed(11)
     N, S = 37, 24                                                   # 888 samples: 7 tiles, the last one ragged
     mode = L.FIELD_STATIC if typ == "coarse" else L.FIELD_FULL
@@ -78,10 +83,12 @@ def test_field_train_weight_grads(Wd, C, typ):
     # float64 pre-activations: every differing unit sits within fp32 rounding of zero.
     G = torch.randn(N, R, S, generator=g)
     (raw_t * G.to(DEV)).sum().backward()
+    tag = "[h3]" if pipe == "h3" else ""
+    assert set(ops.TIMERS) == {"field_fwd_train" + tag, "field_bwd_train" + tag}, set(ops.TIMERS)     # the pipe asked for ran
     pin = B.Pinned(tap, Wd)
     raw = O.query_field(p, pts, rays_d.double(), typ, typ == "fine", False, act=pin.act(True))          # [N,S,R]
     flips, units, worst_pre = pin.summary()
-    P.record(f"train_field[{Wd},{C},{typ}]", "relu branch flips vs float64", flips=flips, units=units, worst_preact_rel=worst_pre)
+    P.record(f"train_field[{Wd},{C},{typ},{pipe}]", "relu branch flips vs float64", flips=flips, units=units, worst_preact_rel=worst_pre)
     assert worst_pre < 2e-5 and flips <= max(8, units // 100000), (flips, units, worst_pre)
     assert _relerr(raw_t.permute(0, 2, 1), raw) < 2e-5
     (raw * G.permute(0, 2, 1).double()).sum().backward()
@@ -91,7 +98,7 @@ def test_field_train_weight_grads(Wd, C, typ):
         assert sd[n].grad is not None, n
         e_ = _relerr(sd[n].grad, p[n].grad)
         worst = max(worst, (n, e_), key=lambda t: t[1])
-    P.record(f"train_field[{Wd},{C},{typ}]", "worst parameter gradient [branch-pinned]", e_hip=worst[1], e_ref=None, bound=1e-4)
+    P.record(f"train_field[{Wd},{C},{typ},{pipe}]", "worst parameter gradient [branch-pinned]", e_hip=worst[1], e_ref=None, bound=1e-4)
     assert worst[1] < 1e-4, worst
 
 
