@@ -236,34 +236,43 @@ __global__ __launch_bounds__(64) void train_dw_x6_kernel(int n_tiles, int rows, 
     }
     const size_t go = (size_t)(g_row0 + 32 * NTO * ob + m) * 128 + 8 * kh;
     const size_t xo = (size_t)(x_row0 + 32 * NTI * ib + m) * 128 + 8 * kh;
-    // one wave per SIMD at most (256 accumulator registers for the 128 x 128 block): the loads of step s + 1 are requested before
-    // the MFMAs of step s issue -- the raw values wait in registers, the split happens when their step comes
-    float4 ra[NTO][2], rb[NTI][2];
-    auto request = [&](int tile, int grp) {
+    // one wave per SIMD at most (256 accumulator registers for the 128 x 128 block), so the memory latency is covered by requests
+    // in flight, not by other waves: two register sets, the loads of steps s + 1 and s + 2 are outstanding while the MFMAs of step s
+    // issue.  A set is free as soon as its raw values are split (tri_of), i.e. at the top of its step, and is re-requested there.
+    float4 ra[2][NTO][2], rb[2][NTI][2];
+    auto request = [&](int tile, int grp, int set) {
         const float* g = gbuf + (size_t)tile * rows * 128 + go + 16 * grp;
         const float* x = xbuf + (size_t)tile * rows * 128 + xo + 16 * grp;
 #pragma unroll
-        for (int to = 0; to < NTO; ++to) { ra[to][0] = *(const float4*)(g + (size_t)32 * to * 128); ra[to][1] = *(const float4*)(g + (size_t)32 * to * 128 + 4); }
+        for (int to = 0; to < NTO; ++to) { ra[set][to][0] = *(const float4*)(g + (size_t)32 * to * 128); ra[set][to][1] = *(const float4*)(g + (size_t)32 * to * 128 + 4); }
 #pragma unroll
-        for (int ti = 0; ti < NTI; ++ti) { rb[ti][0] = *(const float4*)(x + (size_t)32 * ti * 128); rb[ti][1] = *(const float4*)(x + (size_t)32 * ti * 128 + 4); }
+        for (int ti = 0; ti < NTI; ++ti) { rb[set][ti][0] = *(const float4*)(x + (size_t)32 * ti * 128); rb[set][ti][1] = *(const float4*)(x + (size_t)32 * ti * 128 + 4); }
     };
-    if (t_lo < t_hi) request(t_lo, 0);
-    for (int tile = t_lo; tile < t_hi; ++tile) {
-#pragma unroll 2
-        for (int grp = 0; grp < 8; ++grp) {                    // 16 samples per step
-            Tri A[NTO], B[NTI];
-            if (bias) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 bsum2[NTO];
 #pragma unroll
-                for (int to = 0; to < NTO; ++to)
-                    bsum[to] += ((ra[to][0].x + ra[to][0].y) + (ra[to][0].z + ra[to][0].w)) + ((ra[to][1].x + ra[to][1].y) + (ra[to][1].z + ra[to][1].w));
+    for (int to = 0; to < NTO; ++to) bsum2[to] = f32x2{0.f, 0.f};
+    if (t_lo < t_hi) { request(t_lo, 0, 0); request(t_lo, 1, 1); }
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+#pragma unroll
+        for (int grp = 0; grp < 8; ++grp) {                    // 16 samples per step
+            constexpr int kSets = 2;
+            const int set = grp % kSets;
+            Tri A[NTO], B[NTI];
+            if (bias) {                                        // packed adds: two row-sum lanes per instruction
+#pragma unroll
+                for (int to = 0; to < NTO; ++to) {
+                    const float4 u = ra[set][to][0], w = ra[set][to][1];
+                    bsum2[to] += (f32x2{u.x, u.y} + f32x2{u.z, u.w}) + (f32x2{w.x, w.y} + f32x2{w.z, w.w});
+                }
             }
 #pragma unroll
-            for (int to = 0; to < NTO; ++to) tri_of(A[to], ra[to][0], ra[to][1], false);
+            for (int to = 0; to < NTO; ++to) tri_of(A[to], ra[set][to][0], ra[set][to][1], false);
 #pragma unroll
-            for (int ti = 0; ti < NTI; ++ti) tri_of(B[ti], rb[ti][0], rb[ti][1], x_relu != 0);
+            for (int ti = 0; ti < NTI; ++ti) tri_of(B[ti], rb[set][ti][0], rb[set][ti][1], x_relu != 0);
             {
-                const int ng = grp + 1 < 8 ? grp + 1 : 0, nt = grp + 1 < 8 ? tile : tile + 1;
-                if (nt < t_hi) request(nt, ng);
+                const int ng = (grp + kSets) % 8, nt = tile + (grp + kSets) / 8;
+                if (nt < t_hi) request(nt, ng, set);
             }
 #pragma unroll
             for (int to = 0; to < NTO; ++to)
@@ -280,6 +289,8 @@ __global__ __launch_bounds__(64) void train_dw_x6_kernel(int n_tiles, int rows, 
                 }
         }
     }
+#pragma unroll
+    for (int to = 0; to < NTO; ++to) bsum[to] = bsum2[to].x + bsum2[to].y;
     float* out = partial + (size_t)sp * n_out_pad * ld + (size_t)(32 * NTO * ob + 4 * kh) * ld + 32 * NTI * ib + m;
 #pragma unroll
     for (int to = 0; to < NTO; ++to)
