@@ -361,8 +361,11 @@ static int train_dw_impl(int64_t n_tiles, int rows, const float* dacts, int g_ro
     const int ot = n_out / 32, it = n_in / 32;
     hipStream_t st = (hipStream_t)stream;
     static const bool f32_dw = [] { const char* e = getenv("NEFES_TRAIN_DW"); return e && e[0] == 'f'; }();
-    // bf16x6 kernel: a 128 x 128 block per wave where the shapes allow (every row of G and X is then read by ONE workgroup)
+    // bf16x6 kernel: a 128 x 128 block per wave where the shapes allow (every row of G and X is then read by ONE workgroup);
+    // likewise all five tiles of the rgb+feature head (3 + 128 channels) and all four of a Wd = 128 layer over a 64-wide input
     if (!f32_dw && ot % 4 == 0 && it % 4 == 0) return launch_dw<4, 4>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, partial, st);
+    if (!f32_dw && ot == 5 && it == 2) return launch_dw<5, 2>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, partial, st);
+    if (!f32_dw && ot % 4 == 0 && it == 2) return launch_dw<4, 2>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, partial, st);
     const int nto = ot % 2 == 0 ? 2 : 1, nti = it % 4 == 0 ? 4 : (it % 2 == 0 ? 2 : 1);
 #define NEFES_DW(O, I) \
     if (nto == O && nti == I) return launch_dw<O, I>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, partial, st);

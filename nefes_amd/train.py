@@ -55,6 +55,21 @@ def _pad_t(w, n_in_pad, k_pad):
     return wt
 
 
+def _dw_grid(ot, it):
+    """(workgroups per share of the sample tiles, waves wanted per launch) for an ot x it-tile weight gradient: mirrors the
+    block shapes nefes_train_dw picks (csrc/train.hip).  The big blocks hold 128-256 accumulator registers: one wave per SIMD,
+    1024 SIMDs; the small ones run two or three waves per SIMD."""
+    if ot % 4 == 0 and it % 4 == 0:
+        return (ot // 4) * (it // 4), 1024
+    if ot == 5 and it == 2:
+        return 1, 1024
+    if ot % 4 == 0 and it == 2:
+        return ot // 4, 1024
+    nto = 2 if ot % 2 == 0 else 1
+    nti = 4 if it % 4 == 0 else (2 if it % 2 == 0 else 1)
+    return (ot // nto) * (it // nti), 2048
+
+
 class _Pass:
     def __init__(self, net, desc, n_tiles, acts, dacts):
         self.lib, self.desc, self.n_tiles = L.load(), desc, n_tiles
@@ -63,7 +78,6 @@ class _Pass:
         self.offsets = [int(self.lib.nefes_train_row_offset(C.byref(desc), b)) for b in range(L.TB_END + 1)]
         self.stream = ops._stream()
         self.dev = acts.device
-        self.want = 2048                                              # waves per dW launch (1024 SIMDs x 2-3 resident)
         self.db = {}                                                  # block -> bias gradient (filled by dw)
 
     def off(self, block):                                             # (a method, not a closure: no reference cycle
@@ -81,8 +95,8 @@ class _Pass:
         """-> [n_out_pad, n_in_pad] = sum_s G[o][s] f(X[i][s]); bias: the row sums of G (the Linear's bias gradient) ride along as
         one more column of the partials and are kept in self.db[g_block]."""
         op, ip = (n_out + 31) // 32 * 32, (n_in + 31) // 32 * 32
-        blocks = max(1, (op // 32) * (ip // 32) // 8)
-        splits = max(1, min(self.n_tiles, self.want // blocks))
+        blocks, want = _dw_grid(op // 32, ip // 32)
+        splits = max(1, min(self.n_tiles, want // blocks))
         partial = torch.empty(splits, op, ip + (1 if bias else 0), device=self.dev)
         fn = self.lib.nefes_train_dw_bias if bias else self.lib.nefes_train_dw
         L.check(fn(self.n_tiles, self.rows, self.dacts.data_ptr(), self.off(g_block), op, self.acts.data_ptr(), self.off(x_block),
