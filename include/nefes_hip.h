@@ -232,7 +232,8 @@ int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, int N, int 
                        const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);
 
 /* ---- train mode: weight gradients (script/run_nefes.py:42-108 `loss.backward()` through models/nerfh_nff.py:525-576) ----
- * Buffers `acts` / `dacts`: fp32 [n_tiles = ceil(N*S/128)][rows][128 samples], rows = nefes_train_rows(desc); row blocks
+ * Buffers `acts` / `dacts`: fp32 [n_tiles = ceil(N*S/128)][rows x 128 samples], rows = nefes_train_rows(desc); inside a tile
+ * element (row, sample) sits at float offset [row / 32][sample / 16][row % 32][sample % 16] (csrc/layout.h nefes_train_off); row blocks
  * NEFES_TB_* (nefes_amd/csrc/layout.h): E, DV (embeddings, slot order), L1..L8, FINAL, DIR, T0..T2 (natural feature
  * order), RGB, SIG, TH (head gradients, padded to 32 rows).  `acts` holds PRE-activations, `dacts` their gradients. */
 size_t nefes_train_rows(const NefesNetDesc* desc);

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
         // TRAIN: this lane's column of a hidden block in the gradient buffer (first row + 4 rows for lane half 1)
         auto gptr = [&](int block) -> float* {
             if constexpr (!TRAIN) return nullptr;
-            else return a.dacts + ((size_t)tile * a.rows + nefes_train_row(W, 0, block) + 4 * h) * 128 + wave * 32 + j;
+            else return a.dacts + (size_t)tile * a.rows * 128 + (size_t)(nefes_train_row(W, 0, block) >> 5) * 4096 + nefes_train_lane_off(wave, j, h);
         };
         f32x16 G2[NTH], T3[NTH], T4[NTH];
         // ---- static_rgb^T: 3+C gradients in compact slots -> d(dir_encoding output) ----

@@ -51,8 +51,8 @@ struct StoringSplitH {
     __device__ __forceinline__ void stage_a(PairRegs& s, int q, int pp) const {
         in.stage_a(s, q, pp);
         const int e = 8 * q + 2 * pp;
-        __builtin_nontemporal_store(s.x0 * inv, &p[(32 * (e >> 4) + nefes_rho(0, e & 15)) * 128]);
-        __builtin_nontemporal_store(s.x1 * inv, &p[(32 * ((e + 1) >> 4) + nefes_rho(0, (e + 1) & 15)) * 128]);
+        __builtin_nontemporal_store(s.x0 * inv, &p[(e >> 4) * 4096 + nefes_rho(0, e & 15) * 16]);      // layout.h nefes_train_off
+        __builtin_nontemporal_store(s.x1 * inv, &p[((e + 1) >> 4) * 4096 + nefes_rho(0, (e + 1) & 15) * 16]);
     }
     __device__ __forceinline__ void stage_b(PairRegs& s) const { in.stage_b(s); }
     template <bool NOP>
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
         // TRAIN: this lane's column of a hidden block in the gradient buffer (first row + 4 rows for lane half 1)
         auto gptr = [&](int block) -> float* {
             if constexpr (!TRAIN) return nullptr;
-            else return a.dacts + ((size_t)tile * a.rows + nefes_train_row(W, 0, block) + 4 * h) * 128 + wave * 32 + j;
+            else return a.dacts + (size_t)tile * a.rows * 128 + (size_t)(nefes_train_row(W, 0, block) >> 5) * 4096 + nefes_train_lane_off(wave, j, h);
         };
         f32x16 G2[NTH], T3[NTH], T4[NTH];
         // ---- static_rgb^T (fp32): 3+C gradients in compact slots -> d(dir_encoding output), exponent 0 ----

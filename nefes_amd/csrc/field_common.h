@@ -240,7 +240,7 @@ struct Storing {
     template <bool NOP>
     __device__ __forceinline__ float get(int s) const {
         const float v = in.template get<NOP>(s);
-        p[(32 * (s >> 4) + nefes_rho(0, s & 15)) * 128] = v;
+        p[(s >> 4) * 4096 + nefes_rho(0, s & 15) * 16] = v;      // layout.h nefes_train_off
         return v;
     }
 };

@@ -32,11 +32,11 @@ struct FieldFwdArgs {
 // One accumulator register = two 128-byte row segments (lane halves hold rows rho and rho + 4): full-rate stores.
 template <int NT>
 __device__ __forceinline__ void train_save(float* tile_base, uint32_t voff, int row0, const f32x16 (&X)[NT]) {
-    float* p = tile_base + (size_t)row0 * 128 + voff;
+    float* p = tile_base + (size_t)(row0 >> 5) * 4096 + voff;      // layout.h nefes_train_off: voff = nefes_train_lane_off
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p[(32 * t + nefes_rho(0, r)) * 128] = X[t][r];
+        for (int r = 0; r < 16; ++r) p[t * 4096 + nefes_rho(0, r) * 16] = X[t][r];
 }
 
 // MODE: NEFES_FIELD_SIGMA / STATIC / FULL.  W: MLP width.  NTR: tiles of the rgb+feature head.
@@ -135,16 +135,17 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(FieldFwdArgs a) {
         const ArrayIn<ES> in_E{E};
         const ArrayIn<NEFES_D_STEPS> in_D{Dv};
         float* act_tile = nullptr;                                    // wave-uniform
-        const uint32_t act_voff = (uint32_t)(4 * h * 128 + wave * 32 + j);
+        const uint32_t act_voff = nefes_train_lane_off(wave, j, h);
         if constexpr (TRAIN) {
             act_tile = a.acts + (size_t)tile * a.rows * 128;
-            float* pe = act_tile + (size_t)nefes_train_row(W, 0, NEFES_TB_E) * 128 + (h * 128 + wave * 32 + j);
+            const uint32_t emb_off = (uint32_t)(((wave * 32 + j) >> 4) * 512 + h * 16 + (j & 15));   // row 2s+h of an embedding block
+            float* pe = act_tile + (size_t)(nefes_train_row(W, 0, NEFES_TB_E) >> 5) * 4096 + emb_off;
 #pragma unroll
-            for (int s = 0; s < ES; ++s) pe[2 * s * 128] = E[s];     // slot (s,h) -> row 2s+h
+            for (int s = 0; s < ES; ++s) pe[(s >> 4) * 4096 + 2 * (s & 15) * 16] = E[s];     // slot (s,h) -> row 2s+h
             if (MODE != NEFES_FIELD_SIGMA) {
-                float* pd = act_tile + (size_t)nefes_train_row(W, 0, NEFES_TB_DV) * 128 + (h * 128 + wave * 32 + j);
+                float* pd = act_tile + (size_t)(nefes_train_row(W, 0, NEFES_TB_DV) >> 5) * 4096 + emb_off;
 #pragma unroll
-                for (int s = 0; s < NEFES_D_STEPS; ++s) pd[2 * s * 128] = Dv[s];
+                for (int s = 0; s < NEFES_D_STEPS; ++s) pd[2 * s * 16] = Dv[s];
             }
         }
         auto save_trunk = [&](int layer, const f32x16 (&X)[NTW]) {   // layer 1..9 (9 = xyz_encoding_final)

@@ -46,11 +46,11 @@ struct FieldFwdH3Args {
 // the true values (inv = 2^-es).  One register = two 128-byte row segments (lane halves hold rows rho and rho + 4).
 template <int NT, int T0, int NX>
 __device__ __forceinline__ void train_save_h3(float* tile_base, uint32_t voff, int row0, const f32x16 (&X)[NX], float inv) {
-    float* p = tile_base + (size_t)row0 * 128 + voff;
+    float* p = tile_base + (size_t)(row0 >> 5) * 4096 + voff;      // layout.h nefes_train_off: voff = nefes_train_lane_off
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(X[T0 + t][r] * inv, &p[(32 * t + nefes_rho(0, r)) * 128]);
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(X[T0 + t][r] * inv, &p[t * 4096 + nefes_rho(0, r) * 16]);
 }
 
 // MODE: NEFES_FIELD_SIGMA, NEFES_FIELD_STATIC (static head only: the TRAIN instances of a coarse network) or NEFES_FIELD_FULL;
@@ -129,12 +129,13 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
 #pragma unroll
         for (int s = 0; s < ES; ++s) e_lds[s * 64] = E[s];          // own lane's column only: no barrier needed
         float* act_tile = nullptr;                                  // wave-uniform
-        const uint32_t act_voff = (uint32_t)(4 * h * 128 + wave * 32 + j);
+        const uint32_t act_voff = nefes_train_lane_off(wave, j, h);
+        const uint32_t emb_off = (uint32_t)(((wave * 32 + j) >> 4) * 512 + h * 16 + (j & 15));   // row 2s+h of an embedding block
         if constexpr (TRAIN) {
             act_tile = a.acts + (size_t)tile * a.rows * 128;
-            float* pe = act_tile + (size_t)nefes_train_row(W, 0, NEFES_TB_E) * 128 + (h * 128 + wave * 32 + j);
+            float* pe = act_tile + (size_t)(nefes_train_row(W, 0, NEFES_TB_E) >> 5) * 4096 + emb_off;
 #pragma unroll
-            for (int s = 0; s < ES; ++s) __builtin_nontemporal_store(E[s], &pe[2 * s * 128]);     // slot (s,h) -> row 2s+h
+            for (int s = 0; s < ES; ++s) __builtin_nontemporal_store(E[s], &pe[(s >> 4) * 4096 + 2 * (s & 15) * 16]);     // slot (s,h) -> row 2s+h
         }
         auto save_trunk = [&](int layer, const f32x16 (&X)[NTW], int es) {   // layer 1..9 (9 = xyz_encoding_final)
             if constexpr (TRAIN) train_save_h3<NTW, 0>(act_tile, act_voff, nefes_train_row(W, 0, NEFES_TB_L1) + (layer - 1) * W, X, pow2i(-es));
@@ -247,9 +248,9 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                 for (int s = 0; s < 16; ++s) Dv[s] = s < NEFES_D_STEPS ? d14[s] : 0.f;
             }
             if constexpr (TRAIN) {
-                float* pd = act_tile + (size_t)nefes_train_row(W, 0, NEFES_TB_DV) * 128 + (h * 128 + wave * 32 + j);
+                float* pd = act_tile + (size_t)(nefes_train_row(W, 0, NEFES_TB_DV) >> 5) * 4096 + emb_off;
 #pragma unroll
-                for (int s = 0; s < NEFES_D_STEPS; ++s) __builtin_nontemporal_store(Dv[s], &pd[2 * s * 128]);
+                for (int s = 0; s < NEFES_D_STEPS; ++s) __builtin_nontemporal_store(Dv[s], &pd[2 * s * 16]);
             }
             f32x16 dt[NDT];
             uint32_t bits2[WH];

@@ -118,8 +118,8 @@ struct StoringSplit {
         float x0, x1;
         in.vals(q, pp, x0, x1);
         const int s = 8 * q + 2 * pp;
-        p[(32 * (s >> 4) + nefes_rho(0, s & 15)) * 128] = x0;
-        p[(32 * ((s + 1) >> 4) + nefes_rho(0, (s + 1) & 15)) * 128] = x1;
+        p[(s >> 4) * 4096 + nefes_rho(0, s & 15) * 16] = x0;      // layout.h nefes_train_off
+        p[((s + 1) >> 4) * 4096 + nefes_rho(0, (s + 1) & 15) * 16] = x1;
         split_pair_n<NP>(o, pp, x0, x1);
     }
 };

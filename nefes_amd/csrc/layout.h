@@ -128,13 +128,24 @@ NEFES_HD int nefes_h3b_seg(int has_transient, int seg) { return (has_transient |
 NEFES_HD int nefes_mask_words(int W) { return 8 * (W / 64) + 4 * (W / 128); }
 
 // ---- train-mode activation / gradient buffers (field_fwd TRAIN instances, train.hip) ----
-// Tile-major: buf[tile128][row][128 samples] fp32.  One row map for both buffers:
+// Tile-major: buf[tile128][rows x 128 samples] fp32; inside a tile, blocks of 32 rows x 16 samples (2 KiB) are contiguous:
+//     element (row, sample) at float offset nefes_train_off(row, sample) = [row / 32][sample / 16][row % 32][sample % 16]
+// A 16-sample step of the weight-gradient kernels (train.hip) then reads whole contiguous 2 KiB blocks -- with plain
+// [row][128] rows every 128-byte line was shared by two steps issued a microsecond apart, and the HBM counters showed 1.4 x the
+// algorithmic bytes (the in-flight data of a launch is as large as the L2s).  Row blocks start at multiples of 32.
+// One row map for both buffers:
 //   `acts`  (forward):  E, DV = embeddings in slot order (row 2s+h); L1..L8, FINAL, DIR, T0..T2 = PRE-activations
 //   `dacts` (backward): L1..T2 = gradient w.r.t. those pre-activations; RGB, SIG, TH = head pre-activation gradients
 // Hidden blocks are in natural feature order.  Head blocks are padded to whole 32-row tiles.
 enum { NEFES_TB_E = 0, NEFES_TB_DV = 1, NEFES_TB_L1 = 2 /* .. L8 = 9 */, NEFES_TB_FINAL = 10, NEFES_TB_DIR = 11,
        NEFES_TB_T0 = 12, NEFES_TB_T1 = 13, NEFES_TB_T2 = 14, NEFES_TB_RGB = 15, NEFES_TB_SIG = 16, NEFES_TB_TH = 17,
        NEFES_TB_END = 18 };
+NEFES_HD size_t nefes_train_off(int row, int sample) {
+    return ((size_t)(row >> 5) * 8 + (size_t)(sample >> 4)) * 512 + (size_t)(row & 31) * 16 + (size_t)(sample & 15);
+}
+// the per-lane part of that offset for the kernels whose lane (j = lane % 32, h = lane / 32) of wave w holds sample 32 w + j and
+// rows 32 t + rho(0, r) + 4 h of a block: offset = (row0 / 32 + t) * 4096 + rho(0, r) * 16 + nefes_train_lane_off(w, j, h)
+NEFES_HD uint32_t nefes_train_lane_off(int wave, int j, int h) { return (uint32_t)(((wave * 32 + j) >> 4) * 512 + 4 * h * 16 + (j & 15)); }
 NEFES_HD int nefes_train_row(int W, int C, int block) {
     const int ntr = (3 + C + 31) / 32;
     int r = 0;

@@ -32,23 +32,21 @@ __global__ __launch_bounds__(128) void train_head_grad_kernel(int W, int C, int 
     const bool valid = m < M;
     const int ray = valid ? (int)(m / S) : 0, smp = valid ? (int)(m - (long long)ray * S) : 0;
     const size_t col = (size_t)ray * R * S + smp;
-    float* base = dacts + (size_t)tile * rows * 128 + s;
+    float* base = dacts + (size_t)tile * rows * 128;             // element (row, s) at base[nefes_train_off(row, s)] (layout.h)
     const int C3 = 3 + C, ntr = (C3 + 31) / 32;
-    float* rgb = base + (size_t)nefes_train_row(W, C, NEFES_TB_RGB) * 128;
-    for (int c = 0; c < 32 * ntr; ++c) rgb[(size_t)c * 128] = (valid && c < C3) ? g_raw_t[col + (size_t)c * S] : 0.f;
-    float* sig = base + (size_t)nefes_train_row(W, C, NEFES_TB_SIG) * 128;
+    const int r_rgb = nefes_train_row(W, C, NEFES_TB_RGB), r_sig = nefes_train_row(W, C, NEFES_TB_SIG), r_th = nefes_train_row(W, C, NEFES_TB_TH);
+    for (int c = 0; c < 32 * ntr; ++c) base[nefes_train_off(r_rgb + c, s)] = (valid && c < C3) ? g_raw_t[col + (size_t)c * S] : 0.f;
     float ds = 0.f;
     if (valid) ds = g_raw_t[col + (size_t)C3 * S] * (1.f - expf(-raw_t[col + (size_t)C3 * S]));
-    for (int c = 0; c < 32; ++c) sig[(size_t)c * 128] = c == 0 ? ds : 0.f;
+    for (int c = 0; c < 32; ++c) base[nefes_train_off(r_sig + c, s)] = c == 0 ? ds : 0.f;
     if (full) {
-        float* th = base + (size_t)nefes_train_row(W, C, NEFES_TB_TH) * 128;
         for (int c = 0; c < 32; ++c) {
             float v = 0.f;
             if (valid && c < 5) {
                 const float y = raw_t[col + (size_t)(C3 + 1 + c) * S], g = g_raw_t[col + (size_t)(C3 + 1 + c) * S];
                 v = c < 3 ? g * (y * (1.f - y)) : g * (1.f - expf(-y));
             }
-            th[(size_t)c * 128] = v;
+            base[nefes_train_off(r_th + c, s)] = v;
         }
     }
 }
@@ -63,7 +61,8 @@ __global__ __launch_bounds__(256, 2) void train_dx_kernel(int rows, const float*
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, kh = lane >> 5;
     const size_t tile_off = (size_t)blockIdx.x * rows * 128;
-    const float* g = gbuf + tile_off + (size_t)g_row0 * 128 + wave * 32 + j;
+    const float* g = gbuf + tile_off;                            // element (row, sample) at nefes_train_off (layout.h)
+    const int smp = wave * 32 + j;
     const float* wrow = wt + (size_t)j * ldw + 4 * kh;
     f32x16 acc[NT];
 #pragma unroll
@@ -77,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void train_dx_kernel(int rows, const float*
 #pragma unroll
     for (int t = 0; t < NT; ++t) a[t] = *(const float4*)(wrow + (size_t)32 * t * ldw);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) b[c] = g[(size_t)(4 * kh + c) * 128];
+    for (int c = 0; c < 4; ++c) b[c] = g[nefes_train_off(g_row0 + 4 * kh + c, smp)];
     for (int q = 0; q < nq; ++q) {
         float4 an[NT];
         float bn[4];
@@ -85,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void train_dx_kernel(int rows, const float*
 #pragma unroll
         for (int t = 0; t < NT; ++t) an[t] = *(const float4*)(wrow + (size_t)32 * t * ldw + 8 * qn);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bn[c] = g[(size_t)(8 * qn + 4 * kh + c) * 128];
+        for (int c = 0; c < 4; ++c) bn[c] = g[nefes_train_off(g_row0 + 8 * qn + 4 * kh + c, smp)];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             acc[t] = mfma2(a[t].x, b[0], acc[t]);
@@ -98,12 +97,11 @@ __global__ __launch_bounds__(256, 2) void train_dx_kernel(int rows, const float*
 #pragma unroll
         for (int c = 0; c < 4; ++c) b[c] = bn[c];
     }
-    const size_t o0 = tile_off + (size_t)(dst_row0 + 4 * kh) * 128 + wave * 32 + j;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const size_t o = o0 + (size_t)(32 * t + nefes_rho(0, r)) * 128;
+            const size_t o = tile_off + nefes_train_off(dst_row0 + 4 * kh + 32 * t + nefes_rho(0, r), smp);
             float v = acc[t][r];
             if (accumulate) v += dbuf[o];
             if (mask) v = acts[o] > 0.f ? v : 0.f;
@@ -132,8 +130,9 @@ __global__ __launch_bounds__(64) void train_dw_kernel(int n_tiles, int rows, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[to][ti][r] = 0.f;
     }
-    const size_t go = (size_t)(g_row0 + 32 * NTO * ob + m) * 128 + 4 * kh;
-    const size_t xo = (size_t)(x_row0 + 32 * NTI * ib + m) * 128 + 4 * kh;
+    // element (row, sample) at nefes_train_off (layout.h): row block rb, 16-sample group sg -> (rb * 8 + sg) * 512 + (row % 32) * 16 + sample % 16
+    const size_t go = (size_t)((g_row0 >> 5) + NTO * ob) * 4096 + m * 16;
+    const size_t xo = (size_t)((x_row0 >> 5) + NTI * ib) * 4096 + m * 16;
     for (int tile = t_lo; tile < t_hi; ++tile) {
         const float* g = gbuf + (size_t)tile * rows * 128 + go;
         const float* x = xbuf + (size_t)tile * rows * 128 + xo;
@@ -144,12 +143,12 @@ __global__ __launch_bounds__(64) void train_dw_kernel(int n_tiles, int rows, con
 #pragma unroll
             for (int to = 0; to < NTO; ++to)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) a[to][u] = *(const float4*)(g + (size_t)32 * to * 128 + 32 * line + 8 * u);
+                for (int u = 0; u < 4; ++u) a[to][u] = *(const float4*)(g + (size_t)to * 4096 + (2 * line + (u >> 1)) * 512 + 8 * (u & 1) + 4 * kh);
 #pragma unroll
             for (int ti = 0; ti < NTI; ++ti)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    float4 v = *(const float4*)(x + (size_t)32 * ti * 128 + 32 * line + 8 * u);
+                    float4 v = *(const float4*)(x + (size_t)ti * 4096 + (2 * line + (u >> 1)) * 512 + 8 * (u & 1) + 4 * kh);
                     if (x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     b[ti][u] = v;
                 }
@@ -234,19 +233,20 @@ __global__ __launch_bounds__(64) void train_dw_x6_kernel(int n_tiles, int rows, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[to][ti][r] = 0.f;
     }
-    const size_t go = (size_t)(g_row0 + 32 * NTO * ob + m) * 128 + 8 * kh;
-    const size_t xo = (size_t)(x_row0 + 32 * NTI * ib + m) * 128 + 8 * kh;
+    // element (row, sample) at nefes_train_off (layout.h): a step's operands are whole contiguous 2 KiB blocks (32 rows x 16 samples)
+    const size_t go = (size_t)((g_row0 >> 5) + NTO * ob) * 4096 + m * 16 + 8 * kh;
+    const size_t xo = (size_t)((x_row0 >> 5) + NTI * ib) * 4096 + m * 16 + 8 * kh;
     // one wave per SIMD at most (256 accumulator registers for the 128 x 128 block), so the memory latency is covered by requests
     // in flight, not by other waves: two register sets, the loads of steps s + 1 and s + 2 are outstanding while the MFMAs of step s
     // issue.  A set is free as soon as its raw values are split (tri_of), i.e. at the top of its step, and is re-requested there.
     float4 ra[2][NTO][2], rb[2][NTI][2];
     auto request = [&](int tile, int grp, int set) {
-        const float* g = gbuf + (size_t)tile * rows * 128 + go + 16 * grp;
-        const float* x = xbuf + (size_t)tile * rows * 128 + xo + 16 * grp;
+        const float* g = gbuf + (size_t)tile * rows * 128 + go + 512 * grp;
+        const float* x = xbuf + (size_t)tile * rows * 128 + xo + 512 * grp;
 #pragma unroll
-        for (int to = 0; to < NTO; ++to) { ra[set][to][0] = *(const float4*)(g + (size_t)32 * to * 128); ra[set][to][1] = *(const float4*)(g + (size_t)32 * to * 128 + 4); }
+        for (int to = 0; to < NTO; ++to) { ra[set][to][0] = *(const float4*)(g + (size_t)4096 * to); ra[set][to][1] = *(const float4*)(g + (size_t)4096 * to + 4); }
 #pragma unroll
-        for (int ti = 0; ti < NTI; ++ti) { rb[set][ti][0] = *(const float4*)(x + (size_t)32 * ti * 128); rb[set][ti][1] = *(const float4*)(x + (size_t)32 * ti * 128 + 4); }
+        for (int ti = 0; ti < NTI; ++ti) { rb[set][ti][0] = *(const float4*)(x + (size_t)4096 * ti); rb[set][ti][1] = *(const float4*)(x + (size_t)4096 * ti + 4); }
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 bsum2[NTO];

@@ -25,6 +25,13 @@ EMB_XYZ, EMB_DIR = 63, 27
 DEBUG = None          # tests may set this to a dict to receive the acts / dacts buffers of the last backward pass
 
 
+def rows_view(buf):
+    """[tiles, rows, 128] copy of an acts / dacts buffer in (row, sample) order.  The device layout stores, inside a tile, blocks
+    of 32 rows x 16 samples contiguously (csrc/layout.h nefes_train_off): [row / 32][sample / 16][row % 32][sample % 16]."""
+    T, rows, _ = buf.shape
+    return buf.reshape(T, rows // 32, 8, 32, 16).permute(0, 1, 3, 2, 4).reshape(T, rows, 128)
+
+
 def _emb_slot(n_freq, s, h):
     """layout.h nefes_emb_slot: embedding slot (s, h) -> index in the reference's embedding order, -1 = padding."""
     if s < 3 * n_freq:
@@ -200,7 +207,7 @@ def weight_grads(net, pk, mode, N, S, raw_t, g_raw_t, acts, fused=None):
         th = blk(L.TB_TH, 5)
         g["transient_rgb.0.bias"], g["transient_sigma.0.bias"], g["transient_beta.0.bias"] = th[:3], th[3:4], th[4:5]
     if DEBUG is not None:
-        DEBUG.update(acts=acts, dacts=dacts, rows=P.rows, off={b: P.off(b) for b in range(19)})
+        DEBUG.update(acts=rows_view(acts), dacts=rows_view(dacts), rows=P.rows, off={b: P.off(b) for b in range(19)})
     del keep
     return g
 
@@ -237,7 +244,7 @@ class FieldTrain(torch.autograd.Function):
             ctx.save_for_backward(raw_t, acts)
         ctx.fused = fused
         if DEBUG is not None:
-            DEBUG.update(acts=acts, rows=rows, off={b: int(lib.nefes_train_row_offset(C.byref(pk.desc), b)) for b in range(19)})
+            DEBUG.update(acts=rows_view(acts), rows=rows, off={b: int(lib.nefes_train_row_offset(C.byref(pk.desc), b)) for b in range(19)})
         ctx.net, ctx.pk, ctx.mode, ctx.NS, ctx.pk_gen = net, pk, mode, (N, S), pk.generation
         return raw_t
 

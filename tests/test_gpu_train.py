@@ -102,6 +102,34 @@ def test_field_train_weight_grads(Wd, C, typ, pipe, monkeypatch):
     assert worst[1] < 1e-4, worst
 
 
+@pytest.mark.parametrize("Wd,C,typ", [(128, 128, "coarse"), (128, 128, "fine"), (256, 16, "fine")])
+def test_layered_dx_chain_matches_fused(Wd, C, typ, monkeypatch):
+    """train.FUSED_DX = False (nefes_train_dx layer by layer: the fallback, e.g. for external embeddings) gives the gradients of
+    the fused backward launch; same fp32 forward for both, so only the dX chain differs."""
+    from nefes_amd import lib as L
+    from nefes_amd import ops
+    from nefes_amd import train as TR
+    monkeypatch.setattr(ops, "SPLIT", "f32")
+    torch.manual_seed(3)
+    net = _net(typ, Wd, C)
+    mode = L.FIELD_STATIC if typ == "coarse" else L.FIELD_FULL
+    N, S = 37, 24
+    o = torch.randn(N, 3, device=DEV) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(N, 3, device=DEV), dim=-1)
+    z = torch.sort(torch.rand(N, S, device=DEV) * 3.5 + 0.2, -1)[0]
+    grads, G = {}, None
+    for fused in (True, False):
+        monkeypatch.setattr(TR, "FUSED_DX", fused)
+        net.zero_grad()
+        raw = TR.field_train(net, mode, o, d, d, z)
+        G = torch.randn_like(raw) if G is None else G
+        (raw * G).sum().backward()
+        grads[fused] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    assert len(grads[True]) == len(grads[False]) >= 24
+    for n, b in grads[True].items():
+        assert _relerr(grads[False][n], b.cpu()) < 1e-5, n
+
+
 @pytest.mark.parametrize("Wd,C,Ni", [(128, 128, 0), (256, 16, 32)])
 def test_render_train_mode_weight_grads(Wd, C, Ni):
     """run_nefes.py-style step (test_time=False, trainable NeRF weights) through render(): loss on rgb, rgb0, features;
