@@ -272,9 +272,11 @@ int nefes_train_dw(int64_t n_tiles, int rows, const float* dacts, int g_row0, in
                    int n_in, int x_relu, int splits, float* partial, void* stream);
 /* The same with the bias gradient riding along: partial[sp][o][n_in + 1], column n_in = sum over the share's samples of
  * dacts[g_row0 + o][s] (the row sums autograd gives a Linear's bias; the operand is in registers for the product anyway, a
- * separate reduction would read the whole gradient buffer a second time). */
+ * separate reduction would read the whole gradient buffer a second time).  split_stride = floats between the partials of
+ * consecutive shares (0: n_out * (n_in + 1), back to back) -- a caller that gives every layer's launch the same `splits` and one
+ * wide buffer sums all layers' partials with a single reduction. */
 int nefes_train_dw_bias(int64_t n_tiles, int rows, const float* dacts, int g_row0, int n_out, const float* acts, int x_row0,
-                        int n_in, int x_relu, int splits, float* partial, void* stream);
+                        int n_in, int x_relu, int splits, int64_t split_stride, float* partial, void* stream);
 
 /* ---- bicubic up-sampling of the fused feature image (script/dm/DFM_APR_refine.py:114,118: torch.nn.Upsample(size,
  *      mode='bicubic'), align_corners=False, A=-0.75) ---- */

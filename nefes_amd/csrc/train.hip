@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void train_dx_kernel(int rows, const float*
 template <int NTO, int NTI>
 __global__ __launch_bounds__(64) void train_dw_kernel(int n_tiles, int rows, const float* __restrict__ gbuf, int g_row0,
                                                       const float* __restrict__ xbuf, int x_row0, int x_relu, int in_blocks,
-                                                      int splits, int ld, int with_bias, int n_out_pad, float* __restrict__ partial) {
+                                                      int splits, int ld, int with_bias, long long split_stride, float* __restrict__ partial) {
     const int lane = threadIdx.x, m = lane & 31, kh = lane >> 5;
     const int ib = blockIdx.x % in_blocks, ob = blockIdx.x / in_blocks, sp = blockIdx.y;
     const int t_lo = (int)((long long)n_tiles * sp / splits), t_hi = (int)((long long)n_tiles * (sp + 1) / splits);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) void train_dw_kernel(int n_tiles, int rows, con
                     }
         }
     }
-    float* out = partial + (size_t)sp * n_out_pad * ld + (size_t)(32 * NTO * ob + 4 * kh) * ld + 32 * NTI * ib + m;
+    float* out = partial + (size_t)sp * split_stride + (size_t)(32 * NTO * ob + 4 * kh) * ld + 32 * NTI * ib + m;
 #pragma unroll
     for (int to = 0; to < NTO; ++to)
 #pragma unroll
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void train_dw_kernel(int n_tiles, int rows, con
 #pragma unroll
         for (int to = 0; to < NTO; ++to) {
             const float t = bsum[to] + __shfl_xor(bsum[to], 32);
-            if (kh == 0) partial[(size_t)sp * n_out_pad * ld + (size_t)(32 * NTO * ob + 32 * to + m) * ld + ld - 1] = t;
+            if (kh == 0) partial[(size_t)sp * split_stride + (size_t)(32 * NTO * ob + 32 * to + m) * ld + ld - 1] = t;
         }
     }
 }
@@ -218,7 +218,7 @@ __device__ __forceinline__ void tri_of(Tri& o, float4 a, float4 b, bool relu) {
 template <int NTO, int NTI>
 __global__ __launch_bounds__(64) void train_dw_x6_kernel(int n_tiles, int rows, const float* __restrict__ gbuf, int g_row0,
                                                          const float* __restrict__ xbuf, int x_row0, int x_relu, int in_blocks,
-                                                         int splits, int ld, int with_bias, int n_out_pad, float* __restrict__ partial) {
+                                                         int splits, int ld, int with_bias, long long split_stride, float* __restrict__ partial) {
     const int lane = threadIdx.x, m = lane & 31, kh = lane >> 5;
     const int ib = blockIdx.x % in_blocks, ob = blockIdx.x / in_blocks, sp = blockIdx.y;
     const int t_lo = (int)((long long)n_tiles * sp / splits), t_hi = (int)((long long)n_tiles * (sp + 1) / splits);
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64) void train_dw_x6_kernel(int n_tiles, int rows, 
     }
 #pragma unroll
     for (int to = 0; to < NTO; ++to) bsum[to] = bsum2[to].x + bsum2[to].y;
-    float* out = partial + (size_t)sp * n_out_pad * ld + (size_t)(32 * NTO * ob + 4 * kh) * ld + 32 * NTI * ib + m;
+    float* out = partial + (size_t)sp * split_stride + (size_t)(32 * NTO * ob + 4 * kh) * ld + 32 * NTI * ib + m;
 #pragma unroll
     for (int to = 0; to < NTO; ++to)
 #pragma unroll
@@ -302,23 +302,24 @@ __global__ __launch_bounds__(64) void train_dw_x6_kernel(int n_tiles, int rows, 
 #pragma unroll
         for (int to = 0; to < NTO; ++to) {
             const float t = bsum[to] + __shfl_xor(bsum[to], 32);
-            if (kh == 0) partial[(size_t)sp * n_out_pad * ld + (size_t)(32 * NTO * ob + 32 * to + m) * ld + ld - 1] = t;
+            if (kh == 0) partial[(size_t)sp * split_stride + (size_t)(32 * NTO * ob + 32 * to + m) * ld + ld - 1] = t;
         }
     }
 }
 
 template <int NTO, int NTI>
 int launch_dw(int n_tiles, int rows, const float* g, int g_row0, int out_tiles, const float* x, int x_row0, int in_tiles,
-              int x_relu, int splits, int with_bias, float* partial, hipStream_t st) {
+              int x_relu, int splits, int with_bias, long long split_stride, float* partial, hipStream_t st) {
     const int ld = 32 * in_tiles + (with_bias ? 1 : 0);
+    if (split_stride <= 0) split_stride = (long long)32 * out_tiles * ld;      // partials of one launch back to back
     const int ob = out_tiles / NTO, ib = in_tiles / NTI;
     static const bool f32_path = [] { const char* e = getenv("NEFES_TRAIN_DW"); return e && e[0] == 'f'; }();   // "f32": the fp32-MFMA kernel
     if (f32_path)
         train_dw_kernel<NTO, NTI><<<dim3((unsigned)(ob * ib), (unsigned)splits), dim3(64), 0, st>>>(
-            n_tiles, rows, g, g_row0, x, x_row0, x_relu, ib, splits, ld, with_bias, 32 * out_tiles, partial);
+            n_tiles, rows, g, g_row0, x, x_row0, x_relu, ib, splits, ld, with_bias, split_stride, partial);
     else
         train_dw_x6_kernel<NTO, NTI><<<dim3((unsigned)(ob * ib), (unsigned)splits), dim3(64), 0, st>>>(
-            n_tiles, rows, g, g_row0, x, x_row0, x_relu, ib, splits, ld, with_bias, 32 * out_tiles, partial);
+            n_tiles, rows, g, g_row0, x, x_row0, x_relu, ib, splits, ld, with_bias, split_stride, partial);
     return (int)hipGetLastError();
 }
 
@@ -355,7 +356,7 @@ extern "C" int nefes_train_dx(int64_t n_tiles, int rows, const float* dacts_in, 
 }
 
 static int train_dw_impl(int64_t n_tiles, int rows, const float* dacts, int g_row0, int n_out, const float* acts,
-                         int x_row0, int n_in, int x_relu, int splits, int with_bias, float* partial, void* stream) {
+                         int x_row0, int n_in, int x_relu, int splits, int with_bias, long long split_stride, float* partial, void* stream) {
     if (n_tiles <= 0 || rows <= 0 || !dacts || !acts || !partial || splits <= 0 || splits > n_tiles) return NEFES_E_BADARG;
     if (n_out <= 0 || n_out % 32 || n_in <= 0 || n_in % 32 || g_row0 < 0 || x_row0 < 0) return NEFES_E_BADARG;
     const int ot = n_out / 32, it = n_in / 32;
@@ -363,12 +364,12 @@ static int train_dw_impl(int64_t n_tiles, int rows, const float* dacts, int g_ro
     static const bool f32_dw = [] { const char* e = getenv("NEFES_TRAIN_DW"); return e && e[0] == 'f'; }();
     // bf16x6 kernel: a 128 x 128 block per wave where the shapes allow (every row of G and X is then read by ONE workgroup);
     // likewise all five tiles of the rgb+feature head (3 + 128 channels) and all four of a Wd = 128 layer over a 64-wide input
-    if (!f32_dw && ot % 4 == 0 && it % 4 == 0) return launch_dw<4, 4>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, partial, st);
-    if (!f32_dw && ot == 5 && it == 2) return launch_dw<5, 2>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, partial, st);
-    if (!f32_dw && ot % 4 == 0 && it == 2) return launch_dw<4, 2>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, partial, st);
+    if (!f32_dw && ot % 4 == 0 && it % 4 == 0) return launch_dw<4, 4>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, split_stride, partial, st);
+    if (!f32_dw && ot == 5 && it == 2) return launch_dw<5, 2>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, split_stride, partial, st);
+    if (!f32_dw && ot % 4 == 0 && it == 2) return launch_dw<4, 2>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, split_stride, partial, st);
     const int nto = ot % 2 == 0 ? 2 : 1, nti = it % 4 == 0 ? 4 : (it % 2 == 0 ? 2 : 1);
 #define NEFES_DW(O, I) \
-    if (nto == O && nti == I) return launch_dw<O, I>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, partial, st);
+    if (nto == O && nti == I) return launch_dw<O, I>((int)n_tiles, rows, dacts, g_row0, ot, acts, x_row0, it, x_relu, splits, with_bias, split_stride, partial, st);
     NEFES_DW(2, 4) NEFES_DW(2, 2) NEFES_DW(2, 1) NEFES_DW(1, 4) NEFES_DW(1, 2) NEFES_DW(1, 1)
 #undef NEFES_DW
     return NEFES_E_UNSUPPORTED;
@@ -376,10 +377,11 @@ static int train_dw_impl(int64_t n_tiles, int rows, const float* dacts, int g_ro
 
 extern "C" int nefes_train_dw(int64_t n_tiles, int rows, const float* dacts, int g_row0, int n_out, const float* acts,
                               int x_row0, int n_in, int x_relu, int splits, float* partial, void* stream) {
-    return train_dw_impl(n_tiles, rows, dacts, g_row0, n_out, acts, x_row0, n_in, x_relu, splits, 0, partial, stream);
+    return train_dw_impl(n_tiles, rows, dacts, g_row0, n_out, acts, x_row0, n_in, x_relu, splits, 0, 0, partial, stream);
 }
 
 extern "C" int nefes_train_dw_bias(int64_t n_tiles, int rows, const float* dacts, int g_row0, int n_out, const float* acts,
-                                   int x_row0, int n_in, int x_relu, int splits, float* partial, void* stream) {
-    return train_dw_impl(n_tiles, rows, dacts, g_row0, n_out, acts, x_row0, n_in, x_relu, splits, 1, partial, stream);
+                                   int x_row0, int n_in, int x_relu, int splits, int64_t split_stride, float* partial, void* stream) {
+    if (split_stride != 0 && split_stride < (int64_t)n_out * (n_in + 1)) return NEFES_E_BADARG;
+    return train_dw_impl(n_tiles, rows, dacts, g_row0, n_out, acts, x_row0, n_in, x_relu, splits, 1, split_stride, partial, stream);
 }

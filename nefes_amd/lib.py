@@ -88,7 +88,7 @@ SIGNATURES = {
     "nefes_train_head_grad": (_i, [_desc, _i, _i, _i, _p, _p, _p, _p]),
     "nefes_train_dx": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
     "nefes_train_dw": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p]),
-    "nefes_train_dw_bias": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p]),
+    "nefes_train_dw_bias": (_i, [C.c_int64, _i, _p, _i, _i, _p, _i, _i, _i, _i, C.c_int64, _p, _p]),
     "nefes_bicubic_up_fwd": (_i, [C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "nefes_bicubic_up_bwd": (_i, [C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "nefes_pose_compose_fwd": (_i, [_i, _p, _p, _p, C.c_float, C.POINTER(C.c_float), C.c_float, _p, _p]),

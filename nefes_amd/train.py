@@ -85,7 +85,8 @@ class _Pass:
         self.offsets = [int(self.lib.nefes_train_row_offset(C.byref(desc), b)) for b in range(L.TB_END + 1)]
         self.stream = ops._stream()
         self.dev = acts.device
-        self.db = {}                                                  # block -> bias gradient (filled by dw)
+        self.db = {}                                                  # block -> bias gradient (filled by run)
+        self.jobs, self.cols = [], 0                                  # declared weight-gradient products, columns of the wide partial buffer
 
     def off(self, block):                                             # (a method, not a closure: no reference cycle
         return self.offsets[block]                                    #  may keep the multi-GB buffers alive)
@@ -99,20 +100,39 @@ class _Pass:
         return wt                                                     # kept alive by the caller until the stream is done
 
     def dw(self, g_block, n_out, x_block, n_in, relu, bias=True):
-        """-> [n_out_pad, n_in_pad] = sum_s G[o][s] f(X[i][s]); bias: the row sums of G (the Linear's bias gradient) ride along as
-        one more column of the partials and are kept in self.db[g_block]."""
+        """Declares sum_s G[o][s] f(X[i][s]) -> handle; handle.v = [n_out_pad, n_in_pad] after run().  The row sums of G (the
+        Linear's bias gradient) ride along as one more column of every product's partials; bias=True keeps them in
+        self.db[g_block]."""
         op, ip = (n_out + 31) // 32 * 32, (n_in + 31) // 32 * 32
-        blocks, want = _dw_grid(op // 32, ip // 32)
-        splits = max(1, min(self.n_tiles, want // blocks))
-        partial = torch.empty(splits, op, ip + (1 if bias else 0), device=self.dev)
-        fn = self.lib.nefes_train_dw_bias if bias else self.lib.nefes_train_dw
-        L.check(fn(self.n_tiles, self.rows, self.dacts.data_ptr(), self.off(g_block), op, self.acts.data_ptr(), self.off(x_block),
-                   ip, int(relu), splits, partial.data_ptr(), self.stream), "nefes_train_dw")
-        out = partial.sum(0)
-        if bias:
-            self.db[g_block] = out[:, ip]
-            out = out[:, :ip]
-        return out
+        h = _Product(g_block, op, x_block, ip, bool(relu), bool(bias), self.cols)
+        self.cols += op * (ip + 1)
+        self.jobs.append(h)
+        return h
+
+    def run(self):
+        """Launches every declared product into ONE wide partial buffer [splits][all products' columns] (same number of shares
+        for all, nefes_train_dw_bias' split_stride) and sums the shares with a single reduction, in a fixed order."""
+        big = [_dw_grid(h.op // 32, h.ip // 32)[0] for h in self.jobs if _dw_grid(h.op // 32, h.ip // 32)[1] == 1024]
+        splits = max(1, min(self.n_tiles, 1024 // max(big + [1])))
+        wide = torch.empty(splits, self.cols, device=self.dev)
+        for h in self.jobs:
+            L.check(self.lib.nefes_train_dw_bias(self.n_tiles, self.rows, self.dacts.data_ptr(), self.off(h.g_block), h.op,
+                                                 self.acts.data_ptr(), self.off(h.x_block), h.ip, int(h.relu), splits, self.cols,
+                                                 wide.data_ptr() + 4 * h.col, self.stream), "nefes_train_dw_bias")
+        red = wide.sum(0)
+        for h in self.jobs:
+            out = red[h.col:h.col + h.op * (h.ip + 1)].view(h.op, h.ip + 1)
+            h.v = out[:, :h.ip]
+            if h.bias:
+                self.db[h.g_block] = out[:, h.ip]
+        self.jobs = []
+
+
+class _Product:
+    __slots__ = ("g_block", "op", "x_block", "ip", "relu", "bias", "col", "v")
+
+    def __init__(self, g_block, op, x_block, ip, relu, bias, col):
+        self.g_block, self.op, self.x_block, self.ip, self.relu, self.bias, self.col, self.v = g_block, op, x_block, ip, relu, bias, col, None
 
 
 def param_names(net, mode):
@@ -177,23 +197,32 @@ def weight_grads(net, pk, mode, N, S, raw_t, g_raw_t, acts, fused=None):
     e_idx = _slot_rows(10, 64, EMB_XYZ, acts.device)
     d_idx = _slot_rows(4, 28, EMB_DIR, acts.device)
     g = {}
-    g["xyz_encoding_1.0.weight"] = P.dw(TB(1), W, L.TB_E, 64, False)[:W][:, e_idx]
-    for l in range(2, 9):
-        dh = P.dw(TB(l), W, TB(l - 1), W, True)[:W, :W]
-        if l == 5:
-            dh = torch.cat([P.dw(TB(5), W, L.TB_E, 64, False, bias=False)[:W][:, e_idx], dh], 1)
-        g[f"xyz_encoding_{l}.0.weight"] = dh
-    g["static_sigma.0.weight"] = P.dw(L.TB_SIG, 1, TB(8), W, True)[:1, :W]
-    g["xyz_encoding_final.weight"] = P.dw(L.TB_FINAL, W, TB(8), W, True)[:W, :W]
-    g["dir_encoding.0.weight"] = torch.cat([P.dw(L.TB_DIR, H2, L.TB_FINAL, W, False)[:H2, :W],
-                                            P.dw(L.TB_DIR, H2, L.TB_DV, 32, False, bias=False)[:H2][:, d_idx]], 1)
-    g["static_rgb.0.weight"] = P.dw(L.TB_RGB, C3, L.TB_DIR, H2, True)[:C3, :H2]
+    h1 = P.dw(TB(1), W, L.TB_E, 64, False)
+    hl = {l: P.dw(TB(l), W, TB(l - 1), W, True) for l in range(2, 9)}
+    h5e = P.dw(TB(5), W, L.TB_E, 64, False, bias=False)
+    hsig, hfin = P.dw(L.TB_SIG, 1, TB(8), W, True), P.dw(L.TB_FINAL, W, TB(8), W, True)
+    hdir, hdird = P.dw(L.TB_DIR, H2, L.TB_FINAL, W, False), P.dw(L.TB_DIR, H2, L.TB_DV, 32, False, bias=False)
+    hrgb = P.dw(L.TB_RGB, C3, L.TB_DIR, H2, True)
     if full:
-        g["transient_encoding.0.weight"] = torch.cat([P.dw(L.TB_T0, H2, L.TB_FINAL, W, False)[:H2, :W],
-                                                      P.dw(L.TB_T0, H2, L.TB_DV, 32, False, bias=False)[:H2][:, d_idx]], 1)
-        g["transient_encoding.2.weight"] = P.dw(L.TB_T1, H2, L.TB_T0, H2, True)[:H2, :H2]
-        g["transient_encoding.4.weight"] = P.dw(L.TB_T2, H2, L.TB_T1, H2, True)[:H2, :H2]
-        d_th = P.dw(L.TB_TH, 5, L.TB_T2, H2, True)[:5, :H2]
+        ht0, ht0d = P.dw(L.TB_T0, H2, L.TB_FINAL, W, False), P.dw(L.TB_T0, H2, L.TB_DV, 32, False, bias=False)
+        ht1, ht2 = P.dw(L.TB_T1, H2, L.TB_T0, H2, True), P.dw(L.TB_T2, H2, L.TB_T1, H2, True)
+        hth = P.dw(L.TB_TH, 5, L.TB_T2, H2, True)
+    P.run()
+    g["xyz_encoding_1.0.weight"] = h1.v[:W][:, e_idx]
+    for l in range(2, 9):
+        dh = hl[l].v[:W, :W]
+        if l == 5:
+            dh = torch.cat([h5e.v[:W][:, e_idx], dh], 1)
+        g[f"xyz_encoding_{l}.0.weight"] = dh
+    g["static_sigma.0.weight"] = hsig.v[:1, :W]
+    g["xyz_encoding_final.weight"] = hfin.v[:W, :W]
+    g["dir_encoding.0.weight"] = torch.cat([hdir.v[:H2, :W], hdird.v[:H2][:, d_idx]], 1)
+    g["static_rgb.0.weight"] = hrgb.v[:C3, :H2]
+    if full:
+        g["transient_encoding.0.weight"] = torch.cat([ht0.v[:H2, :W], ht0d.v[:H2][:, d_idx]], 1)
+        g["transient_encoding.2.weight"] = ht1.v[:H2, :H2]
+        g["transient_encoding.4.weight"] = ht2.v[:H2, :H2]
+        d_th = hth.v[:5, :H2]
         g["transient_rgb.0.weight"], g["transient_sigma.0.weight"], g["transient_beta.0.weight"] = d_th[:3], d_th[3:4], d_th[4:5]
     # ---- bias gradients: row sums of the gradient blocks over all samples, summed inside the dW launches ----
     blk = lambda b, n: P.db[b][:n]
