@@ -433,11 +433,38 @@ __device__ __forceinline__ void mask_store(float (&dst)[NOUT], const f32x16 (&ac
     for (int s = 0; s < NT * 16; ++s) dst[s] = mask_shift_out(w[s >> 5], acc[T0 + (s >> 4)][s & 15]);
 }
 
-// sin/cos of x*2^k for the frequency embedding.  x*2^k is exact in fp32 (the reference computes sin(x * 2^k)), so the
-// argument reduction can be done exactly in turns: t = x/(2 pi) in f64 (|error| < 1e-13 turns at |x*2^k| = 2048),
-// frac(t*2^k) by an exponent shift and a round; then a quadrant split and the classic fp32 minimax polynomials on
-// [-pi/4, pi/4] (abs error ~1e-7, like a 1-2 ulp libm).  ~26 instructions instead of the ~120 of ocml sincosf, which
-// carries a Payne-Hanek path.  VALU count matters: nothing overlaps with an fp32 MFMA of the same wave.
+// sin/cos of x*2^k for the frequency embedding.  x*2^k is exact in fp32 (the reference computes sin(x * 2^k)), so the argument
+// reduction can be done exactly in turns -- and in integers: t = x/(2 pi) in f64 (|error| < 1e-13 turns at |x*2^k| = 2048), its
+// fraction as a 64-bit fixed-point number hi.lo (once per coordinate: the only f64 instructions left, they issue at a quarter
+// of the fp32 rate), and frac(t 2^k) is that number shifted left by k: one v_alignbit_b32 per frequency for the top 32 bits.
+// Read as a signed integer the phase is already reduced to [-1/2, 1/2) turns; cos is sin a quarter turn later (an integer add),
+// so every lane evaluates ONE odd polynomial on the half turn folded onto [-1/4, 1/4] (sin(pi - th) = sin th): twelve fp32-rate
+// instructions per value instead of ~26 + four f64 (two polynomials, quadrant selects, f64 ldexp / rint / subtract / convert).
+// Fit of sin(2 pi r) / r in r^2 on [0, 1/4]: 3e-9; evaluated in fp32: 1.7e-7 abs, like a 1-2 ulp libm.  VALU count matters:
+// the embedding of a tile is not overlapped with that wave's MFMAs.
+__device__ __forceinline__ void turns_fixed(float x, uint32_t& hi, uint32_t& lo) {
+    const double t = (double)x * 0.15915494309189533577;
+    const double s = (t - __builtin_floor(t)) * 4294967296.0;      // frac(t) 2^32: [0, 2^32], exact scaling
+    hi = (uint32_t)s;                                              // truncating, saturating conversions
+    lo = (uint32_t)((s - (double)hi) * 4294967296.0);
+}
+__device__ __forceinline__ float sin_phase(uint32_t top) {         // sin(2 pi top / 2^32)
+    const float r = (float)(int32_t)top * 2.3283064365386963e-10f; // [-1/2, 1/2] turns
+    const float a = fabsf(r);
+    const float rr = __builtin_copysignf(fminf(a, 0.5f - a), r);   // folded onto [-1/4, 1/4]; 0.5 - a is exact where it is the smaller
+    const float z = rr * rr;
+    float p = 39.53672409057617f;
+    p = __builtin_fmaf(p, z, -76.5497817993164f);
+    p = __builtin_fmaf(p, z, 81.60100555419922f);
+    p = __builtin_fmaf(p, z, -41.34165573120117f);
+    p = __builtin_fmaf(p, z, 6.283185005187988f);
+    return rr * p;
+}
+__device__ __forceinline__ uint32_t phase_of(uint32_t hi, uint32_t lo, int k) {   // top 32 bits of frac(t 2^k), k < 32 (compile-time)
+    return k ? __builtin_amdgcn_alignbit(hi, lo, 32 - k) : hi;
+}
+// the round-1 form (f64 reduction per value, both polynomials): used by the experimental kernels of field_fwd_h4.hip and, with
+// -DNEFES_SINCOS_F64, by embed_slots / embed_slots_bwd for A/B timing
 __device__ __forceinline__ void sincos_turns(double t, int k, float& sn, float& cs) {
 #ifdef NEFES_DBG_OLD_SINCOS
     sincosf((float)(t * 6.283185307179586) * (float)(1 << k), &sn, &cs);
@@ -461,6 +488,7 @@ __device__ __forceinline__ void sincos_turns(double t, int k, float& sn, float& 
 template <int L, int NS>
 __device__ __forceinline__ void embed_slots(float (&e)[NS], const float (&x)[3], int h) {
     static_assert(NS >= 3 * L + 2, "embedding vector too small");
+#ifdef NEFES_SINCOS_F64
     double t[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) t[a] = (double)x[a] * 0.15915494309189533577;
@@ -472,6 +500,16 @@ __device__ __forceinline__ void embed_slots(float (&e)[NS], const float (&x)[3],
             sincos_turns(t[a], k, sn, cs);
             e[3 * k + a] = h ? cs : sn;
         }
+#else
+    uint32_t hi[3], lo[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) turns_fixed(x[a], hi[a], lo[a]);
+    const uint32_t quarter = h ? 0x40000000u : 0u;                  // half-1 lanes keep cos = sin a quarter turn later
+#pragma unroll
+    for (int k = 0; k < L; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) e[3 * k + a] = sin_phase(phase_of(hi[a], lo[a], k) + quarter);
+#endif
     e[3 * L] = h ? x[1] : x[0];
     e[3 * L + 1] = h ? 0.f : x[2];
 #pragma unroll
@@ -482,6 +520,7 @@ __device__ __forceinline__ void embed_slots(float (&e)[NS], const float (&x)[3],
 template <int L, int NS>
 __device__ __forceinline__ void embed_slots_bwd(float (&gx)[3], const float (&g)[NS], const float (&x)[3], int h) {
     gx[0] = gx[1] = gx[2] = 0.f;
+#ifdef NEFES_SINCOS_F64
     double t[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) t[a] = (double)x[a] * 0.15915494309189533577;
@@ -494,5 +533,18 @@ __device__ __forceinline__ void embed_slots_bwd(float (&gx)[3], const float (&g)
             sincos_turns(t[a], k, sn, cs);
             gx[a] += g[3 * k + a] * (h ? -(f * sn) : (f * cs));
         }
+#else
+    uint32_t hi[3], lo[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) turns_fixed(x[a], hi[a], lo[a]);
+    const uint32_t shift = h ? 0x80000000u : 0x40000000u;           // d sin = cos = sin(. + 1/4 turn); d cos = -sin = sin(. + 1/2 turn)
+#pragma unroll
+    for (int k = 0; k < L; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float f = (float)(1 << k);
+            gx[a] += g[3 * k + a] * (f * sin_phase(phase_of(hi[a], lo[a], k) + shift));
+        }
+#endif
     if (h) { gx[1] += g[3 * L]; } else { gx[0] += g[3 * L]; gx[2] += g[3 * L + 1]; }
 }
