@@ -19,6 +19,9 @@
 #include "../../include/nefes_hip.h"
 
 #include "field_x6.h"
+#if !(defined(NEFES_TU_PART) && (NEFES_TU_PART == 2 || NEFES_TU_PART == 4)) && !defined(H3_NO_ACC_READ_ASM)
+#define H3_ACC_READ_ASM        // Wd = 256 objects: source tiles are read out of their AGPRs inside the MFMA gaps (field_h3.h acc_read)
+#endif
 #include "field_h3.h"
 #define NEFES_H3_SLOTS 2   // 64 KiB ring (StagedRing: two slots)
 
@@ -193,23 +196,27 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
             M = rowb(NEFES_H3F_L1) * mE + bmax(NEFES_H3BB_L1);
             save_trunk(1, A, es_a);
         }
+        // even layers 2, 4, 6, 8 (A -> B); a macro so that the sigma-only kernel can run layer 8 behind the loop: with a `break` in
+        // the middle of the rolled loop hipcc copied a whole accumulator set between register classes at the loop head
+#define NEFES_FWD_EVEN_LAYER(L1_, SEG1_)                                                                                       \
+        clear_bits();                                                                                                          \
+        {                                                                                                                      \
+            const int ew = wexp(SEG1_), tau = tau_of(M, ew);                                                                   \
+            float mx = 0.f;                                                                                                    \
+            mma_run_h3<NTW, W / 16, 0, true>(ring, ring_lane, ReluSplitH<CAP, NTW, WT>{A, bits, pow2i(tau - es_a), mx},        \
+                                             bias_at(((L1_) - 1) * W, tau + ew), B);                                           \
+            M = rowb(SEG1_) * (pair_max(mx) * pow2i(-es_a)) + bmax((L1_) - 1);                                                 \
+            es_b = tau + ew;                                                                                                   \
+            save_trunk(L1_, B, es_b);                                                                                          \
+        }                                                                                                                      \
+        put_masks(bits, WT);                                                                      /* mask of layer l1-1 */
+        constexpr int NPAIRS = MODE == NEFES_FIELD_SIGMA ? 3 : 4;
 #pragma unroll 1
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NPAIRS; ++p) {
             const int l1 = 2 + 2 * p, l2 = l1 + 1;
             const int seg1 = l1 <= 5 ? l1 - 1 : l1;                                    // layout.h NEFES_H3F_*: L5 is two segments
             const int seg2 = l2 <= 5 ? l2 - 1 : (l2 <= 8 ? l2 : NEFES_H3F_FINAL);
-            clear_bits();
-            {
-                const int ew = wexp(seg1), tau = tau_of(M, ew);
-                float mx = 0.f;
-                mma_run_h3<NTW, W / 16, 0, true>(ring, ring_lane, ReluSplitH<CAP, NTW, WT>{A, bits, pow2i(tau - es_a), mx},
-                                                 bias_at((l1 - 1) * W, tau + ew), B);                 // layers 2, 4, 6, 8
-                M = rowb(seg1) * (pair_max(mx) * pow2i(-es_a)) + bmax(l1 - 1);
-                es_b = tau + ew;
-                save_trunk(l1, B, es_b);
-            }
-            put_masks(bits, WT);                                                                      // mask of layer l1-1
-            if (p == 3 && MODE == NEFES_FIELD_SIGMA) break;
+            NEFES_FWD_EVEN_LAYER(l1, seg1)
             clear_bits();
             {
                 const int ew = wexp(seg2);
@@ -227,6 +234,8 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
             }
             put_masks(bits, WT);                                                                      // mask of layer l1
         }
+        if constexpr (MODE == NEFES_FIELD_SIGMA) { NEFES_FWD_EVEN_LAYER(8, NEFES_H3F_L8) }
+#undef NEFES_FWD_EVEN_LAYER
         if constexpr (MODE == NEFES_FIELD_SIGMA) sigma_head(B, es_b, tau_of(M, wexp(NEFES_H3F_SIG)));
         if constexpr (MODE != NEFES_FIELD_SIGMA) {
             // FULL: dir_encoding and transient_encoding.0 as ONE stacked 2*NTH-tile product (pack.cpp add_heads_x6): tiles

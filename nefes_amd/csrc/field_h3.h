@@ -157,6 +157,19 @@ __device__ __forceinline__ void split_pair_h(Split2& o, int p, float x0, float x
 struct PairRegs {
     float x0, x1;
 };
+// One value of a source tile for the vector ALU.  H3_ACC_READ_ASM (the Wd = 256 forward objects, whose MFMAs are asm statements on
+// "+a" tiles): the tile stays in its AGPRs and the value is read HERE -- an explicit v_accvgpr_read_b32 inside the MFMA gap that
+// hosts the pair.  Left to itself hipcc moves the whole source set (128 registers) to VGPRs in one block at every layer boundary,
+// where the wave's matrix pipe idles: ~280 instructions between two runs, 7 % of the forward (seen in the disassembly).
+__device__ __forceinline__ float acc_read(const float& x) {
+#ifdef H3_ACC_READ_ASM
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(x));
+    return v;
+#else
+    return x;
+#endif
+}
 template <bool CAPTURE, int NX, int NWORDS, int T0 = 0>
 struct ReluSplitH {
     const f32x16 (&X)[NX];
@@ -164,8 +177,8 @@ struct ReluSplitH {
     float r;
     float& m;                   // running max of the consumed values (accumulator units), this lane
     __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
-        s.x0 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p];
-        s.x1 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1];
+        s.x0 = acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
+        s.x1 = acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
 #ifndef H3_ABL_NOMASK
         if (CAPTURE) {
             mask_shift_in(bits[(8 * q + 2 * p) >> 5], s.x0);
@@ -213,8 +226,8 @@ struct IdentSplitH {
     float r;
     float& m;
     __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
-        s.x0 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p];
-        s.x1 = X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1];
+        s.x0 = acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
+        s.x1 = acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
     }
     __device__ __forceinline__ void stage_b(PairRegs& s) const { absmax3_acc(m, s.x0, s.x1); }
     template <bool NOP>
