@@ -308,7 +308,9 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int cu = 32 * t + nefes_rho(0, r);
-                            if (cu + 4 * h < 3 + a.C) __builtin_nontemporal_store(ar[t][r] * inv, &ph[(size_t)cu * a.S]);
+                            // NTR = ceil((3 + C) / 32): every row of the tiles before the last one is a channel -- only the last
+                            // tile's stores carry a per-lane predicate (80 predicated stores per tile at C = 128 otherwise)
+                            if (t + 1 < NTR || cu + 4 * h < 3 + a.C) __builtin_nontemporal_store(ar[t][r] * inv, &ph[(size_t)cu * a.S]);
                         }
                 }
             }
