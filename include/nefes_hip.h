@@ -278,6 +278,16 @@ int nefes_train_dw(int64_t n_tiles, int rows, const float* dacts, int g_row0, in
 int nefes_train_dw_bias(int64_t n_tiles, int rows, const float* dacts, int g_row0, int n_out, const float* acts, int x_row0,
                         int n_in, int x_relu, int splits, int64_t split_stride, float* partial, void* stream);
 
+/* ---- FusionNet's convolutions (script/models/nerfh_nff.py:356-418; run on the rendered 60x80 image by run_fusion_net in
+ *      every refinement iteration, script/dm/DFM_APR_refine.py:112-120) ----
+ * y[b][co][p] = bias[co] + sum_{tap, ci} W[co][ci][tap] x[b][ci][p + tap - pad]  (stride 1, zero "same" padding, ksize 3 or 5;
+ * ReLU on the way out if relu).  NCHW fp32.  w_packed = [Cin rounded up to even][ksize*ksize][Cout rounded up to 32] =
+ * W[co][ci][ty][tx] at [ci][ty*ksize + tx][co], zero padded (the caller packs once per weight version).  mask (nullable,
+ * x's shape): x is read as zero where mask <= 0 -- the ReLU derivative of the layer in front, for the gradient pass: the gradient
+ * w.r.t. a layer's input is this call on the flipped, transposed weights (W'[ci][co][ty][tx] = W[co][ci][K-1-ty][K-1-tx]). */
+int nefes_conv2d_same(int B, int Cin, int Cout, int H, int W, int ksize, const float* x, const float* mask, const float* w_packed,
+                      const float* bias, int relu, float* y, void* stream);
+
 /* ---- bicubic up-sampling of the fused feature image (script/dm/DFM_APR_refine.py:114,118: torch.nn.Upsample(size,
  *      mode='bicubic'), align_corners=False, A=-0.75) ---- */
 /* in [planes,h,w] -> out [planes,CH,CW] = the window [oy0, oy0+CH) x [ox0, ox0+CW) of the OH x OW up-sampled image (planes =

@@ -23,7 +23,8 @@ FEATURE_DIM = 128        # nerfh_nff.py:21
 
 class FusionNet(nn.Module):
     """4-layer conv 'fusion' CNN on the rendered (rgb || feature) image (nerfh_nff.py:356-418).
-    Runs once per image after the path; plain torch (MIOpen) by design (SURVEY.md §2.1 #5)."""
+    Plain torch (MIOpen) where its weights train; in the refinement loop, where they are frozen and the net runs
+    on the 60x80 render every iteration, forward_parts takes the implicit-GEMM kernels of csrc/conv.hip."""
     mean = [0.485, 0.456, 0.406]
     std = [0.229, 0.224, 0.225]
 
@@ -49,6 +50,21 @@ class FusionNet(nn.Module):
         out = self.net(x)
         return x[:, 3:] + out if self.fusion_residule else out
 
+    HIP_CONVS = True      # frozen weights on a GPU: the four convolutions as csrc/conv.hip launches (ops.frozen_conv2d)
+
+    def _use_hip(self, x):
+        """The refinement loop's case: CUDA input, no convolution parameter requires grad (training them goes through torch)."""
+        return (self.HIP_CONVS and x.is_cuda and x.dtype == torch.float32
+                and not any(p.requires_grad for m in self.net[:7] for p in m.parameters()))
+
+    def _convs_hip(self, x):
+        from . import ops
+        c0, c1, c2, c3 = self.net[0], self.net[2], self.net[4], self.net[6]
+        x = ops.frozen_conv2d(x, c0.weight, c0.bias, relu=True)
+        x = ops.frozen_conv2d(x, c1.weight, c1.bias, relu=True)
+        x = ops.frozen_conv2d(x, c2.weight, c2.bias, relu=True)
+        return ops.frozen_conv2d(x, c3.weight, c3.bias, relu=False)
+
     def forward_parts(self, rgb_nchw, feat_nchw, per_image_norm=False):
         """forward(cat([rgb, feat], 1)) without the in-place slice assignment (whose autograd costs a fill and two copies):
         the colour channels are normalised before the concatenation -- same values, same order of operations.
@@ -58,11 +74,12 @@ class FusionNet(nn.Module):
         not updated on this path)."""
         mean, std = self._mean_std(rgb_nchw)
         x = torch.cat([(rgb_nchw - mean[:, None, None]) / std[:, None, None], feat_nchw], dim=1)
+        convs = self._convs_hip if self._use_hip(x) else self.net[:7]
         if per_image_norm and not self.no_BN and x.shape[0] > 1:
             bn = self.net[-1]
-            out = nn.functional.instance_norm(self.net[:-1](x), weight=bn.weight, bias=bn.bias, eps=bn.eps)
+            out = nn.functional.instance_norm(convs(x), weight=bn.weight, bias=bn.bias, eps=bn.eps)
         else:
-            out = self.net(x)
+            out = convs(x) if self.no_BN else self.net[-1](convs(x))
         return feat_nchw + out if self.fusion_residule else out
 
 

@@ -78,6 +78,7 @@ SIGNATURES = {
     "nefes_h4_sigma_blob_bytes": (_sz, [_desc]),
     "nefes_h4_sigma_pack": (_i, [_desc, _p, _i, _p, _sz]),
     "nefes_field_fwd_h4_sigma": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "nefes_conv2d_same": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p]),
     "nefes_probe_mfma_clock": (_i, [_i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), _p]),
     "nefes_train_rows": (_sz, [_desc]),
     "nefes_train_row_offset": (_i, [_desc, _i]),

@@ -614,6 +614,69 @@ class HashGridEncode(torch.autograd.Function):
         return g_x.reshape(ctx.shape), None
 
 
+_CONV_PACK = {}     # (id(weight), backward) -> (weakref to the weight, its version, packed [Cin even][K*K][Cout multiple of 32])
+
+
+def _pack_conv(w, backward):
+    """Packed A operands of nefes_conv2d_same for a frozen Conv2d weight [Cout, Cin, K, K]; backward: the flipped, transposed
+    weights (gradient w.r.t. the layer's input).  Cached per weight tensor and version (the entry holds a weak reference: an
+    address re-used by another tensor is not a hit)."""
+    import weakref
+    key = (id(w), backward)
+    hit = _CONV_PACK.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == w._version:
+        return hit[2]
+    wd = w.detach().to(torch.float32)
+    if backward:
+        wd = wd.flip(2, 3).transpose(0, 1)
+    co, ci, k, _ = wd.shape
+    pk = torch.zeros((ci + 1) // 2 * 2, k * k, (co + 31) // 32 * 32, device=w.device)
+    pk[:ci, :, :co] = wd.permute(1, 2, 3, 0).reshape(ci, k * k, co)
+    for dead in [kk for kk, v in _CONV_PACK.items() if v[0]() is None]:
+        del _CONV_PACK[dead]
+    _CONV_PACK[key] = (weakref.ref(w), w._version, pk)
+    return pk
+
+
+def _conv2d_same(x, wp, cout, ksize, bias, relu, mask=None):
+    B, cin, H, W = x.shape
+    y = torch.empty(B, cout, H, W, device=x.device)
+    with _timed("conv2d_same"):
+        L.check(L.load().nefes_conv2d_same(B, cin, cout, H, W, ksize, _chk(x, "x"), _chk(mask, "mask"), _chk(wp, "w_packed"),
+                                           _chk(bias, "bias"), int(relu), y.data_ptr(), _stream()), "nefes_conv2d_same")
+    return y
+
+
+class FrozenConv2d(torch.autograd.Function):
+    """Conv2d(stride 1, "same" zero padding, 3x3 or 5x5) [+ ReLU] with FROZEN weight and bias, differentiable w.r.t. its input:
+    FusionNet's layers in the refinement loop (nerfh_nff.py:356-418; weights carry no gradient there).  Forward and the input
+    gradient are the same implicit-GEMM kernel (csrc/conv.hip); the ReLU derivative is applied to the incoming gradient inside
+    the gradient launch (mask = this layer's output)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        xc = _f32(x)
+        k = weight.shape[-1]
+        y = _conv2d_same(xc, _pack_conv(weight, False), weight.shape[0], k, None if bias is None else _f32(bias.detach()), relu)
+        ctx.weight, ctx.relu = weight, relu
+        if relu:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        w = ctx.weight
+        y = ctx.saved_tensors[0] if ctx.relu else None
+        gx = _conv2d_same(_f32(g), _pack_conv(w, True), w.shape[1], w.shape[-1], None, False, mask=y)
+        return gx, None, None, None
+
+
+def frozen_conv2d(x, weight, bias, relu=False):
+    if weight.requires_grad or (bias is not None and bias.requires_grad):
+        raise ValueError("nefes_amd: frozen_conv2d is for weights without gradient (use torch's conv2d to train them)")
+    return FrozenConv2d.apply(x, weight, bias, relu)
+
+
 class BicubicUpsample(torch.autograd.Function):
     """torch.nn.Upsample(size=(OH, OW), mode='bicubic') on a contiguous [B,C,h,w] image (DFM_APR_refine.py:114,118), optionally
     only the window `crop` pixels inside every border (the loop's `[:, :, 10:-10, 10:-10]`, :115,119: the cropped-away pixels are

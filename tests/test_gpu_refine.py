@@ -255,3 +255,69 @@ def test_pose_refiner_option_matrix(golden, upsample, encode_hist, world):
     p2, l2 = mk(images=2).refine(init[None].repeat(2, 1, 1), tgt[None].repeat(2, 1, 1, 1), hist.repeat(2, 1), 3)
     assert l2.shape == (3, 2) and torch.isfinite(l2).all() and float(l2[-1].max()) < float(l2[0].min())
     assert rel(l2[:, 0].cpu().numpy(), l1.cpu().numpy()) < 5e-4 and rel(l2[:, 1].cpu().numpy(), l1.cpu().numpy()) < 5e-4
+
+
+@pytest.mark.parametrize("B,Cin,Cout,k,relu,H,W", [(1, 131, 64, 3, True, 60, 80), (1, 64, 64, 3, True, 60, 80), (1, 64, 128, 5, False, 60, 80),
+                                                   (3, 19, 64, 3, True, 17, 23), (2, 64, 16, 5, False, 9, 70)])
+def test_frozen_conv_matches_float64(B, Cin, Cout, k, relu, H, W):
+    """csrc/conv.hip (ops.frozen_conv2d): Conv2d(stride 1, same padding)[+ReLU] forward and input gradient against torch's
+    convolution in float64; torch's own fp32 GPU convolution (MIOpen) measured beside it.  Ragged sizes: odd channel counts,
+    channel counts that are no multiple of 32, a pixel count that is no multiple of 32, images narrower than a pixel tile."""
+    from nefes_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + Cin + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    gy = torch.randn(B, Cout, H, W, generator=g)
+
+    def ref(dt, dev):
+        xx = x.to(dev, dt).requires_grad_()
+        y = torch.nn.functional.conv2d(xx, w.to(dev, dt), b.to(dev, dt), padding=k // 2)
+        y = torch.relu(y) if relu else y
+        (y * gy.to(dev, dt)).sum().backward()
+        return y.detach().cpu().double(), xx.grad.cpu().double()
+    y64, g64 = ref(torch.float64, "cpu")
+    y32, g32 = ref(torch.float32, DEV)
+    xd = x.to(DEV).requires_grad_()
+    y = ops.frozen_conv2d(xd, w.to(DEV), b.to(DEV), relu=relu)
+    (y * gy.to(DEV)).sum().backward()
+    rel = lambda a_, t_: float((a_.cpu().double() - t_).abs().max() / t_.abs().max())
+    e_y, e_g, r_y, r_g = rel(y.detach(), y64), rel(xd.grad, g64), rel(y32, y64), rel(g32, g64)
+    P.record(f"frozen_conv[{B},{Cin},{Cout},{k}]", "output / input gradient vs float64", e_hip=max(e_y, e_g), e_ref=max(r_y, r_g), bound=1e-5)
+    assert e_y < 1e-5 and e_g < 1e-5, (e_y, e_g, r_y, r_g)
+
+
+def test_fusion_net_hip_convs_against_float64():
+    """FusionNet.forward_parts with frozen weights takes the HIP convolutions: fused features and the gradient to the render
+    against the same module in float64 on the CPU, with torch's fp32 GPU layers (MIOpen) measured beside it.  One image
+    (BatchNorm on its statistics) and three images (instance norm).  (MIOpen's fp32 backward-data kernels for this shape are
+    ~5e-3 away from float64; the implicit-GEMM kernels ~1e-6.)"""
+    import copy
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    torch.manual_seed(4)
+    net = NeRFH_NFF('coarse', W=128, f_dim=128).requires_grad_(False).to(DEV)
+    net64 = copy.deepcopy(net).cpu().double()
+    relm = lambda a_, t_: float((a_.cpu().double() - t_).abs().max() / t_.abs().max())
+    for B in (1, 3):
+        rgb = torch.rand(B * 4800, 3, device=DEV)
+        feat = torch.randn(B * 4800, 128, device=DEV)
+        wl = torch.randn(B, 128, 60, 80, device=DEV)
+        r, f = rgb.cpu().double().requires_grad_(), feat.cpu().double().requires_grad_()
+        _, _, fused = net64.run_fusion_net(r, f, 60, 80, B, per_image_norm=B > 1)
+        (fused * wl.cpu().double()).sum().backward()
+        truth = (fused.detach(), r.grad, f.grad)
+        err = {}
+        for hip in (True, False):
+            net.fusion_net.HIP_CONVS = hip
+            r, f = rgb.clone().requires_grad_(), feat.clone().requires_grad_()
+            ops.TIMERS = {}
+            _, _, fused = net.run_fusion_net(r, f, 60, 80, B, per_image_norm=B > 1)
+            assert ("conv2d_same" in ops.TIMERS) == hip
+            ops.TIMERS = None
+            (fused * wl).sum().backward()
+            err[hip] = [relm(a_, t_) for a_, t_ in zip((fused.detach(), r.grad, f.grad), truth)]
+        net.fusion_net.HIP_CONVS = True
+        for name, e_hip, e_ref in zip(("fused", "d rgb", "d feature"), err[True], err[False]):
+            P.record(f"fusion_net[{B}]", name + " vs float64 (e_ref = torch fp32 on the GPU)", e_hip=e_hip, e_ref=e_ref, bound=1e-4)
+            assert e_hip < 1e-4, (B, name, e_hip, e_ref)
