@@ -130,6 +130,36 @@ def test_layered_dx_chain_matches_fused(Wd, C, typ, monkeypatch):
         assert _relerr(grads[False][n], b.cpu()) < 1e-5, n
 
 
+@pytest.mark.parametrize("Wd,C", [(128, 128), (256, 16)])
+def test_static_head_of_a_transient_network_on_both_pipes(Wd, C, monkeypatch):
+    """NEFES_FIELD_STATIC on a network that HAS transient heads (a fine network evaluated with output_transient=False): the
+    static-head fp16 streams of such a network share dir_encoding's scale with transient_encoding.0 (pack.cpp).  Raw outputs and
+    every parameter gradient of the fp16 pipe against the fp32-MFMA pipe."""
+    from nefes_amd import lib as L
+    from nefes_amd import ops
+    from nefes_amd import train as TR
+    torch.manual_seed(8)
+    net = _net("fine", Wd, C)
+    N, S = 29, 20
+    o = torch.randn(N, 3, device=DEV) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(N, 3, device=DEV), dim=-1)
+    z = torch.sort(torch.rand(N, S, device=DEV) * 3.5 + 0.2, -1)[0]
+    res, G = {}, None
+    for pipe in ("f32", "h3"):
+        monkeypatch.setattr(ops, "SPLIT", pipe)
+        monkeypatch.setattr(ops, "TIMERS", {})
+        net.zero_grad()
+        raw = TR.field_train(net, L.FIELD_STATIC, o, d, d, z)
+        G = torch.randn_like(raw) if G is None else G
+        (raw * G).sum().backward()
+        assert ("field_fwd_train[h3]" in ops.TIMERS) == (pipe == "h3")
+        res[pipe] = (raw.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+    assert raw.shape[1] == 3 + C + 1 and len(res["h3"][1]) == 24
+    assert _relerr(res["h3"][0], res["f32"][0].cpu()) < 2e-5
+    for n, b in res["f32"][1].items():
+        assert _relerr(res["h3"][1][n], b.cpu()) < 1e-4, n
+
+
 @pytest.mark.parametrize("Wd,C,Ni", [(128, 128, 0), (256, 16, 32)])
 def test_render_train_mode_weight_grads(Wd, C, Ni):
     """run_nefes.py-style step (test_time=False, trainable NeRF weights) through render(): loss on rgb, rgb0, features;
