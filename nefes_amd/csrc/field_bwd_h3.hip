@@ -175,7 +175,28 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
             STASH(c) = a.pts ? in_o[c] : add_rn(in_o[c], mul_rn(in_d[c], in_z));
             STASH(3 + c) = v[c];
         }
-        STASH(6) = h == 0 ? g_sg * (1.f - expf(-y_sg)) : 0.f;
+        const float d_sigma = h == 0 ? g_sg * (1.f - expf(-y_sg)) : 0.f;
+        STASH(6) = d_sigma;
+        if constexpr (TRAIN) {
+            // The head blocks of the gradient buffer -- d raw for the rgb+feature channels, the sigma and transient-head
+            // pre-activation gradients, padded with zero rows to whole 32-row tiles -- are what the weight-gradient kernels read as
+            // G of static_rgb / static_sigma / the transient heads.  They are in registers here (compact slots: row 2s + h), so
+            // they are stored here: the separate head-gradient pass (train.hip train_head_grad_kernel) re-read d raw and raw_t.
+            float* dt_ = a.dacts + (size_t)tile * a.rows * 128 + (size_t)(((wave * 32 + j) >> 4) * 512 + h * 16 + (j & 15));
+            float* prgb = dt_ + (size_t)(nefes_train_row(W, C3 - 3, NEFES_TB_RGB) >> 5) * 4096;
+            constexpr int NTR_ = (C3 + 31) / 32;
+#pragma unroll
+            for (int s = 0; s < 16 * NTR_; ++s)
+                __builtin_nontemporal_store(s < KR ? dr[s < KR ? s : 0] : 0.f, &prgb[(s >> 4) * 4096 + 2 * (s & 15) * 16]);
+            float* psig = dt_ + (size_t)(nefes_train_row(W, C3 - 3, NEFES_TB_SIG) >> 5) * 4096;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) __builtin_nontemporal_store(s == 0 ? d_sigma : 0.f, &psig[2 * s * 16]);
+            if constexpr (HAS_T) {
+                float* pth = dt_ + (size_t)(nefes_train_row(W, C3 - 3, NEFES_TB_TH) >> 5) * 4096;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) __builtin_nontemporal_store(s < 3 ? dth[s < 3 ? s : 0] : 0.f, &pth[2 * s * 16]);
+            }
+        }
 
         auto load_bits = [&](uint32_t* b, int word0, int n) {
             for (int w = 0; w < n; ++w) b[w] = MASKW(word0 + w);

@@ -163,8 +163,9 @@ def weight_grads(net, pk, mode, N, S, raw_t, g_raw_t, acts, fused=None):
     full = mode == L.FIELD_FULL
     n_tiles = acts.shape[0]
     dacts = torch.empty_like(acts)
-    L.check(lib.nefes_train_head_grad(C.byref(desc), mode, N, S, raw_t.data_ptr(), g_raw_t.data_ptr(), dacts.data_ptr(),
-                                      ops._stream()), "nefes_train_head_grad")
+    if not (fused is not None and fp16_pipe(pk)):             # (the fp16 dX kernel writes the head blocks itself)
+        L.check(lib.nefes_train_head_grad(C.byref(desc), mode, N, S, raw_t.data_ptr(), g_raw_t.data_ptr(), dacts.data_ptr(),
+                                          ops._stream()), "nefes_train_head_grad")
     P = _Pass(net, desc, n_tiles, acts, dacts)
     sd = dict(net.named_parameters())
     w = lambda name: sd[name + ".weight"]
