@@ -53,7 +53,13 @@ __device__ __forceinline__ void train_save_h3(float* tile_base, uint32_t voff, i
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(X[T0 + t][r] * inv, &p[t * 4096 + nefes_rho(0, r) * 16]);
+        for (int r = 0; r < 16; ++r) {
+#ifdef H3_TRAIN_TEMPORAL      // A/B switch: ordinary (write-back) stores
+            p[t * 4096 + nefes_rho(0, r) * 16] = X[T0 + t][r] * inv;
+#else
+            __builtin_nontemporal_store(X[T0 + t][r] * inv, &p[t * 4096 + nefes_rho(0, r) * 16]);
+#endif
+        }
 }
 
 // MODE: NEFES_FIELD_SIGMA, NEFES_FIELD_STATIC (static head only: the TRAIN instances of a coarse network) or NEFES_FIELD_FULL;
