@@ -594,7 +594,7 @@ __device__ __forceinline__ void mma_run_h3_small(Ring& ring, const char* ring_la
     Bn = B;
     // FIRST: the C operand of a tile's first MFMA (bias x 2^es, or zero) is written straight into the tile's own registers,
     // one unit ahead of its first use -- the output tiles are dead until then -- rather than into a 16-register staging tile
-    // (this kernel family sits a handful of registers below its 512: DESIGN.md)
+    // (a 16-register staging tile per run was what this kernel family could not afford before the source tiles stayed in AGPRs)
 #ifdef H3_ABL_NOBIAS
     if (FIRST) acc[T0] = ZeroInit{}(0);
 #else
