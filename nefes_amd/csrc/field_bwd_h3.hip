@@ -72,6 +72,18 @@ __device__ __forceinline__ auto wrap_store_h3(const Inner& in, float* p, float i
     else return in;
 }
 
+// Streaming inputs of a tile (ReLU masks, raw outputs, upstream gradient: read once, 27 GB per headline launch) are loaded
+// non-temporally: as ordinary loads they pushed the 2.6 MB weight stream, which every workgroup re-reads per tile, out of the L2s --
+// the HBM counters showed 63 GB fetched per launch (FETCH_SIZE x 2 is exact for these load widths: tools/probe/fetch_probe.hip).
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+#ifdef H3_BWD_TEMPORAL_LOADS
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+
 // HAS_T = false: the static head only (NEFES_FIELD_STATIC forward: raw channels rgb+feature, sigma); the stream then is
 // NEFES_STREAM_BWD_STATIC_H3 and the transient segments are absent.  TRAIN: see StoringSplitH.
 template <int W, int C3, int ENC, bool HAS_T = true, bool TRAIN = false>   // C3 = 3 + C; ENC = NEFES_XYZ_*
@@ -131,24 +143,24 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
             for (int s = 0; s < 3; ++s) {            // compact slot (s,h) <-> transient-head row 2s+h (5 rows)
                 const int row = 2 * s + h;
                 const int ch = cT + (row < 5 ? row : 4);
-                y_th[s] = a.raw_t[chan0 + (size_t)ch * a.S];
-                g_th[s] = a.g_raw_t[chan0 + (size_t)ch * a.S];
+                y_th[s] = ld_stream(&a.raw_t[chan0 + (size_t)ch * a.S]);
+                g_th[s] = ld_stream(&a.g_raw_t[chan0 + (size_t)ch * a.S]);
             }
         }
-        y_sg = a.raw_t[chan0 + (size_t)C3 * a.S];
-        g_sg = a.g_raw_t[chan0 + (size_t)C3 * a.S];
+        y_sg = ld_stream(&a.raw_t[chan0 + (size_t)C3 * a.S]);
+        g_sg = ld_stream(&a.g_raw_t[chan0 + (size_t)C3 * a.S]);
 #pragma unroll
         for (int s = 0; s < KR; ++s) {               // compact slot (s,h) <-> static rgb/feature channel 2s+h
             const int ch = 2 * s + h;
-            dr[s] = a.g_raw_t[chan0 + (size_t)(ch < C3 ? ch : C3 - 1) * a.S];
+            dr[s] = ld_stream(&a.g_raw_t[chan0 + (size_t)(ch < C3 ? ch : C3 - 1) * a.S]);
         }
         uint4 mq[MW / 4];
         {
             const uint32_t* mk32 = a.masks + ((size_t)(m >> 5) * MW) * 64 + lane;
 #pragma unroll
             for (int q = 0; q < MW / 4; ++q) {
-                mq[q].x = mk32[(4 * q + 0) * 64]; mq[q].y = mk32[(4 * q + 1) * 64];
-                mq[q].z = mk32[(4 * q + 2) * 64]; mq[q].w = mk32[(4 * q + 3) * 64];
+                mq[q].x = ld_stream(&mk32[(4 * q + 0) * 64]); mq[q].y = ld_stream(&mk32[(4 * q + 1) * 64]);
+                mq[q].z = ld_stream(&mk32[(4 * q + 2) * 64]); mq[q].w = ld_stream(&mk32[(4 * q + 3) * 64]);
             }
         }
         // ======================================================================================================
