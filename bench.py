@@ -93,8 +93,38 @@ def cpu_baseline(Wd, C, Nc, Ni, n_rows, W, focal):
     dt = time.perf_counter() - t0
     n = n_rows * W
     return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{n} rays (first {n_rows} rows of the 480x640 frame), fwd+bwd to pose, {Nc}+{Ni} samples, "
-                      f"8x{Wd} MLP, C={C}, torch {torch.__version__} CPU, {dt:.1f} s"}
+            "sample": f"{n} rays (first {n_rows} rows of the 480x640 frame) in ONE chunk, fwd+bwd to pose, {Nc}+{Ni} samples, "
+                      f"8x{Wd} MLP, C={C}, torch {torch.__version__} CPU, {dt:.1f} s; SURVEY 8d names a 32 768-ray chunk "
+                      f"(~{32768 / (n / dt):.0f} s at this rate): bounded to the bench contract's 10-30 s of CPU work, rays/s is "
+                      f"per-ray work and does not depend on the chunk length"}
+
+
+def committed_traffic(backward, h3, x6):
+    """HBM-side bytes per launch of the dominant kernel, from the newest committed counter digest (profiles/rNN/pmc_per_launch.json:
+    separate rocprofv3 --pmc passes of this same command, tools/profile_round.sh).  A digest is only quoted while the kernel
+    sources it was measured on are the ones in this tree (`_meta.kernel_sources`, tools/pmc_aggregate.py); otherwise the line
+    carries traffic = null and says why.  Returns (bytes or None, source string)."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_aggregate import kernel_source_digest
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "pmc_per_launch.json")))
+    if not files:
+        return None, "no committed counter digest under profiles/"
+    path = files[-1]
+    rel = os.path.relpath(path, ROOT)
+    try:
+        pm = json.load(open(path))
+        have, want_src = pm.get("_meta", {}).get("kernel_sources"), kernel_source_digest(ROOT)
+        if have != want_src:
+            return None, f"{rel} is STALE: collected on kernel sources {have}, this tree is {want_src} (re-run tools/profile_round.sh)"
+        if backward:
+            want = "field_bwd_h3_kernel<256,19,0" if h3 else ("field_bwd_kernel<256,19,0,6," if x6 else "field_bwd_kernel<256,19,0,0,")
+        else:
+            want = "field_fwd_h3_kernel<2,0,256" if h3 else ("field_fwd_x6_kernel<2," if x6 else "field_fwd_kernel<256,1,2")
+        e = next(v for k, v in pm.items() if k.replace(" ", "").startswith(want))
+        return (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0, f"{rel} (kernel sources {have})"
+    except Exception as ex:
+        return None, f"{rel}: {ex}"
 
 
 def refinement_loop(dev, iters=50, graph=True, images=1):
@@ -220,7 +250,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--height", type=int, default=0, help="override the workload's frame height (debugging)")
     ap.add_argument("--width", type=int, default=0, help="override the workload's frame width (debugging)")
-    ap.add_argument("--cpu-rows", type=int, default=4, help="rows of the frame timed on the host cores (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=12, help="rows of the frame timed on the host cores (0 = skip)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["loop50", "train"], default="metric")
     a = ap.parse_args()
 
@@ -273,7 +303,7 @@ def main():
         sec_b, _ = refinement_loop(dev, graph=True, images=8)
         print(json.dumps({"metric": "rays/s (fwd+bwd), secondary workload 'loop50'", "value": rays / sec, "unit": "rays/s",
                           "n_gpus": 1, "higher_is_better": True,
-                          "dtype": "bf16x3 (16-bit operands, opt-in reduced precision)" if ops.X6_PRODUCTS == 3 and ops.USE_X6 else "f32",
+                          "dtype": "f32",
                           "data": "synthetic", "vs_baseline": None,
                           "ms_per_image_50_iterations": sec * 1e3, "ms_per_image_50_iterations_eager": sec_e * 1e3,
                           "ms_per_image_50_iterations_8_images_side_by_side": sec_b * 1e3,
@@ -351,42 +381,32 @@ def main():
         fwd_key = next(k for k in kern if k.startswith("field_fwd[full"))
         bwd_key = next(k for k in kern if k.startswith("field_bwd"))
         dom_key = max((fwd_key, bwd_key), key=lambda k: kern[k])
-        x3 = dom_key.endswith("x3]")                      # opt-in reduced-precision run (NEFES_X6_PRODUCTS=3): labelled as such
         h3 = dom_key.endswith("h3]")                      # fp16 two-part split products: three MFMAs per algorithmic product
-        x6 = dom_key.endswith("x6]") or x3
+        x6 = dom_key.endswith("x6]")
         ach = flop_fwd / (kern[dom_key] * 1e-3) / 1e12
         enc = int(wl['hashgrid'])
         if dom_key == bwd_key:
             dom_name = (f"field_bwd_h3_kernel<{Wd},{3 + C},{enc}>" if h3 else
-                        f"field_bwd_kernel<{Wd},{3 + C},{enc}{',X6=3' if x3 else ',X6' if x6 else ''}>")
+                        f"field_bwd_kernel<{Wd},{3 + C},{enc}{',X6' if x6 else ''}>")
         else:
             dom_name = (f"field_fwd_h3_kernel<FULL,{enc},{Wd},{(3 + C + 31) // 32}>" if h3 else
-                        ("field_fwd_x6_kernel<FULL,NP=3>" if x3 else "field_fwd_x6_kernel<FULL>") if x6
+                        "field_fwd_x6_kernel<FULL>" if x6
                         else f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{enc}>")
-        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if h3 else (PEAK_BF16_MFMA_TFLOPS / (3.0 if x3 else 6.0) if x6 else PEAK_F32_MFMA_TFLOPS)
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if h3 else (PEAK_BF16_MFMA_TFLOPS / 6.0 if x6 else PEAK_F32_MFMA_TFLOPS)
         flop_frame = 2.0 * (Nc * macs_sigma(Wd, in_xyz) + 2 * (Nc + Ni) * macs_full(Wd, C, in_xyz)) * n_total
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure
         # comes from the committed rocprofv3 passes of this same command (profiles/, 2*FETCH_SIZE + WRITE_SIZE in KiB,
         # gfx950 correction of MI355X_MICROARCH.md) and is quoted only for the workload it was measured on.
-        traffic = None
-        try:
-            if (a.workload, H, W, world) == ("metric", 480, 640, 1) and not x3:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02" if h3 else "r01", "pmc_per_launch.json")))
-                if dom_key == bwd_key:
-                    want = "field_bwd_h3_kernel<256,19,0" if h3 else ("field_bwd_kernel<256,19,0,6," if x6 else "field_bwd_kernel<256,19,0,0,")
-                else:
-                    want = "field_fwd_h3_kernel<2,0,256" if h3 else ("field_fwd_x6_kernel<2," if x6 else "field_fwd_kernel<256,1,2")
-                pm = next(v for k, v in pm.items() if k.replace(" ", "").startswith(want))
-                traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
-        except Exception:
-            traffic = None
+        traffic, traffic_source = None, None
+        if (a.workload, H, W, world) == ("metric", 480, 640, 1):
+            traffic, traffic_source = committed_traffic(dom_key == bwd_key, h3, x6)
         out = {
             "metric": "rays/s (fwd+bwd) at 640x480x(64+128) samples, 8x256 MLP" if a.workload == "metric"
                       else f"rays/s (fwd+bwd), secondary workload '{a.workload}'", "value": value, "unit": "rays/s",
             "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1,
             "collective_backend": (dist.get_backend() if world > 1 else None), "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16x3 (16-bit operands, NOT the headline precision)" if x3 else "f32",
-            "matrix_core_arithmetic": "fp16 two-part split (3 products)" if h3 else ("bf16x3" if x3 else "bf16x6" if x6 else "fp32 MFMA"),
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "matrix_core_arithmetic": "fp16 two-part split (3 products)" if h3 else ("bf16x6" if x6 else "fp32 MFMA"),
             "data": "synthetic",
             "config": {"workload": f"{wl['name']}; {W}x{H}, random seed-0 weights, fwd + bwd to the 3x4 pose",
                        "rays_per_step": n_total, "samples_per_ray": [Nc, Ni], "parallelism": f"rows/{world}",
@@ -394,9 +414,6 @@ def main():
                                       "scaled operands, 22 significant bits, three cross terms, fp32 accumulation: fp32-level accuracy, "
                                       "tests/test_gpu_h3.py); NEFES_SPLIT=x6 / f32 select the bf16x6 / fp32-MFMA kernels"
                                       if h3 else
-                                      "REDUCED PRECISION (opt-in NEFES_X6_PRODUCTS=3): three leading bf16 split products, operands "
-                                      "carried to 16 bits, ~5e-6 of the output scale (tests/test_gpu_x6.py); not the default"
-                                      if x3 else
                                       "fp32 in, fp32 out; matrix products as exact bf16x6 split products with fp32 accumulation "
                                       "(fp32-level accuracy, tests/test_gpu_x6.py); NEFES_X6=0 selects the fp32-MFMA kernels"
                                       if any(k.endswith("x6]") for k in kern) else "fp32 MFMA")},
@@ -404,11 +421,11 @@ def main():
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "peak_basis": ("dense fp16 MFMA peak 2500 / 3: fp16 two-part split, three products per algorithmic product, "
                                         "fp32-level accuracy" if h3 else
-                                        "dense bf16 MFMA peak 2500 / 3: three-product split, reduced precision" if x3 else
                                         "dense bf16 MFMA peak 2500 / 6: bf16x6 split products, fp32-level accuracy" if x6
                                         else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                          "vs_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch (HBM side: 2 x FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC passes, profiles/)",
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_unit": "bytes/launch (HBM side: 2 x FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC passes, profiles/)",
                          "end_to_end_frac": value * (flop_frame / n_total) / (PEAK_F32_MFMA_TFLOPS * 1e12 * world)},
             "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items())},
             "pose_grad_abs_max": float(g.abs().max()),
@@ -421,7 +438,7 @@ def main():
                 import ctypes as _C
                 ghz, tf = _C.c_double(), _C.c_double()
                 L.check(L.load().nefes_probe_mfma_clock(1, 40, _C.byref(ghz), _C.byref(tf), None), "nefes_probe_mfma_clock")
-                per = 3.0 if (h3 or x3) else 6.0
+                per = 3.0 if h3 else 6.0
                 out["roofline"]["sustained"] = {
                     "clock_ghz": round(ghz.value, 3), "dense_16bit_mfma_tflops": round(tf.value, 1),
                     "peak": tf.value / per, "frac": ach / (tf.value / per),

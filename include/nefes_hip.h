@@ -205,17 +205,6 @@ int nefes_field_bwd_x6(const NefesNetDesc* desc, const void* packed, int N, int 
                        const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
                        const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);
 
-/* Opt-in reduced-precision variants of the two calls above (same shapes): the three leading products
- * hi*hi + hi*mid + mid*hi of the same bf16 split, i.e. operands carried to 16 bits -- relative error ~5e-6 of the output
- * scale instead of ~5e-7, half the matrix-core work.  Same streams, same arguments, same mask-word format.  Never the
- * default: the callers select them explicitly (nefes_amd.ops.X6_PRODUCTS = 3). */
-int nefes_field_fwd_x3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
-                       const float* rays_d, const float* z, const float* pts, const float* xyz_enc, const float* viewdirs,
-                       float* raw_t, uint32_t* masks, void* stream);
-int nefes_field_bwd_x3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
-                       const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
-                       const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);
-
 /* The same two functions (nefes_field_fwd in NEFES_FIELD_SIGMA / NEFES_FIELD_FULL mode, nefes_field_bwd) with the products as
  * fp16 TWO-PART split products on v_mfma_f32_32x32x16_f16 -- (hi, lo) fp16 pairs of power-of-two scaled operands, three cross
  * terms hh + hl + lh, fp32 accumulation: 22 significant bits per operand, fp32-level accuracy at half the matrix-core work of
@@ -322,14 +311,6 @@ int nefes_cosine_loss_bwd(int C, int64_t P, const float* a, const float* b, cons
  *      v_mfma_f32_32x32x16_f16 back to back on every SIMD for ~ms_target milliseconds (operands all zero, or random bits) and
  *      returns the settled shader clock and the dense fp16 rate.  Synchronises the stream.  Not part of the render path. ---- */
 int nefes_probe_mfma_clock(int random_operands, int ms_target, double* clock_ghz, double* fp16_dense_tflops, void* stream);
-
-/* ---- EXPERIMENT (not reachable from render()): the sigma-only forward of the Wd = 256 coarse network on
- *      v_mfma_f32_16x16x32_f16 (8 waves x 16 samples, two waves per SIMD), with its own self-contained weight blob.
- *      tensors: the (weight, bias) table of nefes_pack_weights.  raw_t: [N][1][S] = softplus(sigma). ---- */
-size_t nefes_h4_sigma_blob_bytes(const NefesNetDesc* desc);                 /* 0 = unsupported description */
-int nefes_h4_sigma_pack(const NefesNetDesc* desc, const float* const* tensors, int n_tensors, void* blob, size_t blob_bytes);  /* host */
-int nefes_field_fwd_h4_sigma(const NefesNetDesc* desc, const void* blob, int N, int S, const float* rays_o, const float* rays_d,
-                             const float* z, float* raw_t, void* stream);
 
 #ifdef __cplusplus
 }

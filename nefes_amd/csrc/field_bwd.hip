@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(FieldBwdArgs a) {
     constexpr int MW_TRUNK = 8 * WT;
     constexpr int KR = (C3 + 1) / 2;
     static_assert(MW % 4 == 0, "mask words are staged as 16-byte groups");
-    constexpr int NP = X6 == 3 ? 3 : 6;
+    constexpr int NP = 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -280,7 +280,7 @@ static int launch_bwd(const FieldBwdArgs& a, hipStream_t st) {
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { BWD_X6_256 = 0, BWD_X6_256_EXT, BWD_X6_128, BWD_X3_256, BWD_X3_256_EXT, BWD_X3_128, BWD_STATIC_256, BWD_STATIC_128, BWD_TRAIN_256_FULL,
+enum { BWD_X6_256 = 0, BWD_X6_256_EXT, BWD_X6_128, BWD_STATIC_256, BWD_STATIC_128, BWD_TRAIN_256_FULL,
        BWD_TRAIN_256_STATIC, BWD_TRAIN_128_FULL, BWD_TRAIN_128_STATIC };
 int nefes_bwd_launch_part1(int which, const FieldBwdArgs& a, hipStream_t st);
 int nefes_bwd_launch_part2(int which, const FieldBwdArgs& a, hipStream_t st);
@@ -298,9 +298,6 @@ int nefes_bwd_launch_part1(int which, const FieldBwdArgs& a, hipStream_t st) {
 #elif NEFES_TU_PART == 2
 int nefes_bwd_launch_part2(int which, const FieldBwdArgs& a, hipStream_t st) {
     switch (which) {
-        case BWD_X3_256: return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 3>(a, st);
-        case BWD_X3_256_EXT: return launch_bwd<256, 19, NEFES_XYZ_EXTERNAL32, 3>(a, st);
-        case BWD_X3_128: return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 3>(a, st);
         case BWD_STATIC_256: return launch_bwd<256, 19, NEFES_XYZ_FREQ10, 0, false>(a, st);
         case BWD_STATIC_128: return launch_bwd<128, 131, NEFES_XYZ_FREQ10, 0, false>(a, st);
     }
@@ -360,12 +357,6 @@ static int field_bwd_impl(int x6, bool full, float* dacts, const NefesNetDesc* d
         if (desc->width == 128 && desc->feat_dim == 128 && !ext) return nefes_bwd_launch_part2(BWD_STATIC_128, a, st);
         return NEFES_E_UNSUPPORTED;
     }
-    if (x6 == 3) {   // three-product instances
-        if (desc->width == 128 && desc->feat_dim == 128 && !ext) return nefes_bwd_launch_part2(BWD_X3_128, a, st);
-        if (desc->width == 256 && desc->feat_dim == 16 && !ext) return nefes_bwd_launch_part2(BWD_X3_256, a, st);
-        if (desc->width == 256 && desc->feat_dim == 16 && ext) return nefes_bwd_launch_part2(BWD_X3_256_EXT, a, st);
-        return NEFES_E_UNSUPPORTED;
-    }
     if (x6) {
         if (desc->width == 256 && desc->feat_dim == 16 && !ext) return nefes_bwd_launch_part1(BWD_X6_256, a, st);
         if (desc->width == 256 && desc->feat_dim == 16 && ext) return nefes_bwd_launch_part1(BWD_X6_256_EXT, a, st);
@@ -391,14 +382,6 @@ extern "C" int nefes_field_bwd_x6(const NefesNetDesc* desc, const void* packed, 
                                   const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                                   float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
     return field_bwd_impl(6, true, nullptr, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
-                          g_viewdirs_s, stream);
-}
-
-extern "C" int nefes_field_bwd_x3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
-                                  const float* rays_d, const float* z, const float* pts, const float* viewdirs,
-                                  const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
-                                  float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
-    return field_bwd_impl(3, true, nullptr, desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc,
                           g_viewdirs_s, stream);
 }
 

@@ -35,7 +35,6 @@ struct FieldFwdX6Args {
 
 // MODE: NEFES_FIELD_SIGMA or NEFES_FIELD_FULL; ENC: NEFES_XYZ_FREQ10 or NEFES_XYZ_EXTERNAL32 (hash grid);
 // (W, NTR) = (256, 1) [C = 16] or (128, 5) [C = 128: the reference-default shape]
-// NP = 6 (default, fp32-level accuracy) or 3 (the three leading products only: 16-bit operands, nefes_field_fwd_x3)
 template <int MODE, int ENC, int W = 256, int NTR = 1, int NP = 6>
 __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
@@ -229,15 +228,13 @@ static int launch_x6(const FieldFwdX6Args& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// Kernel instances spread over three objects built from this one source (Makefile: -DNEFES_TU_PART=0..2): part 0 = entry points
-// + the Wd = 256 frequency-embedding instances, part 1 = hash-grid and Wd = 128 instances, part 2 = three-product instances.
+// Kernel instances spread over two objects built from this one source (Makefile: -DNEFES_TU_PART=0..1): part 0 = entry points
+// + the Wd = 256 frequency-embedding instances, part 1 = hash-grid and Wd = 128 instances.
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { FWD_EXT_SIGMA = 0, FWD_EXT_FULL, FWD_128_SIGMA, FWD_128_FULL, FWD_X3_SIGMA, FWD_X3_FULL, FWD_X3_EXT_SIGMA, FWD_X3_EXT_FULL,
-       FWD_X3_128_SIGMA, FWD_X3_128_FULL };
+enum { FWD_EXT_SIGMA = 0, FWD_EXT_FULL, FWD_128_SIGMA, FWD_128_FULL };
 int nefes_fwd_x6_launch_part1(int which, const FieldFwdX6Args& a, hipStream_t st);
-int nefes_fwd_x6_launch_part2(int which, const FieldFwdX6Args& a, hipStream_t st);
 
 #if NEFES_TU_PART == 1
 int nefes_fwd_x6_launch_part1(int which, const FieldFwdX6Args& a, hipStream_t st) {
@@ -249,21 +246,9 @@ int nefes_fwd_x6_launch_part1(int which, const FieldFwdX6Args& a, hipStream_t st
     }
     return NEFES_E_UNSUPPORTED;
 }
-#elif NEFES_TU_PART == 2
-int nefes_fwd_x6_launch_part2(int which, const FieldFwdX6Args& a, hipStream_t st) {
-    switch (which) {
-        case FWD_X3_SIGMA: return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 256, 1, 3>(a, st);
-        case FWD_X3_FULL: return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 256, 1, 3>(a, st);
-        case FWD_X3_EXT_SIGMA: return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32, 256, 1, 3>(a, st);
-        case FWD_X3_EXT_FULL: return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32, 256, 1, 3>(a, st);
-        case FWD_X3_128_SIGMA: return launch_x6<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5, 3>(a, st);
-        case FWD_X3_128_FULL: return launch_x6<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5, 3>(a, st);
-    }
-    return NEFES_E_UNSUPPORTED;
-}
 #else   // part 0
 
-static int field_fwd_x6_impl(int np, const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+static int field_fwd_x6_impl(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                              const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
                              const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
     if (!desc || !packed || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
@@ -287,11 +272,6 @@ static int field_fwd_x6_impl(int np, const NefesNetDesc* desc, const void* packe
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
-    if (np == 3) {   // three-product instances
-        if (small) return nefes_fwd_x6_launch_part2(mode == NEFES_FIELD_SIGMA ? FWD_X3_128_SIGMA : FWD_X3_128_FULL, a, st);
-        if (ext) return nefes_fwd_x6_launch_part2(mode == NEFES_FIELD_SIGMA ? FWD_X3_EXT_SIGMA : FWD_X3_EXT_FULL, a, st);
-        return nefes_fwd_x6_launch_part2(mode == NEFES_FIELD_SIGMA ? FWD_X3_SIGMA : FWD_X3_FULL, a, st);
-    }
     if (small) {
         if (mode == NEFES_FIELD_SIGMA) return nefes_fwd_x6_launch_part1(FWD_128_SIGMA, a, st);
         return nefes_fwd_x6_launch_part1(FWD_128_FULL, a, st);
@@ -307,12 +287,6 @@ static int field_fwd_x6_impl(int np, const NefesNetDesc* desc, const void* packe
 extern "C" int nefes_field_fwd_x6(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                                   const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
                                   const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
-    return field_fwd_x6_impl(6, desc, packed, mode, N, S, rays_o, rays_d, z, pts, xyz_enc, viewdirs, raw_t, masks, stream);
-}
-
-extern "C" int nefes_field_fwd_x3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
-                                  const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
-                                  const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
-    return field_fwd_x6_impl(3, desc, packed, mode, N, S, rays_o, rays_d, z, pts, xyz_enc, viewdirs, raw_t, masks, stream);
+    return field_fwd_x6_impl(desc, packed, mode, N, S, rays_o, rays_d, z, pts, xyz_enc, viewdirs, raw_t, masks, stream);
 }
 #endif   // NEFES_TU_PART

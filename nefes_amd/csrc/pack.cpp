@@ -66,7 +66,7 @@ struct Seg {
 
 // w = hi + mid + lo exactly, each a bf16: hi = RNE(w), mid = RNE(w - hi), lo = w - hi - mid (both residuals are exact in
 // fp32, the last one has at most 8 significant bits).  Round-to-nearest parts make hi + mid an unbiased 16-bit value of w,
-// which is what the three-product kernels (nefes_field_fwd_x3) consume; the six-product kernels see an exact triple either way.
+// (an earlier three-product experiment consumed that); the six-product kernels see an exact triple either way.
 static uint16_t rne_bf16(float f) {
     uint32_t b;
     memcpy(&b, &f, 4);

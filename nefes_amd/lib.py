@@ -71,13 +71,8 @@ SIGNATURES = {
     "nefes_field_bwd_static": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_bwd_x6": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_fwd_x6": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "nefes_field_bwd_x3": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "nefes_field_fwd_x3": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_bwd_h3": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_fwd_h3": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "nefes_h4_sigma_blob_bytes": (_sz, [_desc]),
-    "nefes_h4_sigma_pack": (_i, [_desc, _p, _i, _p, _sz]),
-    "nefes_field_fwd_h4_sigma": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p]),
     "nefes_conv2d_same": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p]),
     "nefes_probe_mfma_clock": (_i, [_i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), _p]),
     "nefes_train_rows": (_sz, [_desc]),

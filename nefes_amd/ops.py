@@ -287,16 +287,6 @@ SPLIT = os.environ.get("NEFES_SPLIT", "h3")
 # let re-packed networks run on the bf16x6 instances (the round-2 behaviour)
 REPACK_H3 = os.environ.get("NEFES_REPACK_H3", "1") != "0"
 USE_X6 = os.environ.get("NEFES_X6", "1") != "0"
-# Number of cross products of the split: 6 (default: fp32-level accuracy) or 3 (opt-in, NEFES_X6_PRODUCTS=3: operands carried
-# to 16 bits, ~5e-6 of the output scale, half the matrix-core work; the shapes with bf16x6 instances -- nefes_field_fwd_x3 / _bwd_x3).
-X6_PRODUCTS = int(os.environ.get("NEFES_X6_PRODUCTS", "6"))
-
-
-def _x3(pk):
-    if X6_PRODUCTS not in (3, 6):
-        raise ValueError("nefes_amd.ops.X6_PRODUCTS must be 6 or 3")
-    return X6_PRODUCTS == 3 and ((pk.width == 256 and pk.feat_dim == 16) or
-                                 (pk.width == 128 and pk.feat_dim == 128 and pk.xyz_encoding == L.XYZ_FREQ10))
 
 
 def x6_supported(pk: PackedField, mode, forward=True):
@@ -310,20 +300,18 @@ def _h3(pk):
     """fp16 two-part instances apply: selected, this network's fp16 streams are current, and M fits the kernels' 32-bit index."""
     if SPLIT not in ("h3", "x6", "f32"):
         raise ValueError("nefes_amd.ops.SPLIT must be 'h3', 'x6' or 'f32'")
-    return SPLIT == "h3" and pk.h3_valid and X6_PRODUCTS == 6
+    return SPLIT == "h3" and pk.h3_valid
 
 
 def field_fwd_x6(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, viewdirs=None, want_masks=False, xyz_enc=None,
                  pts=None):
-    """field_fwd on the split-product instances (same outputs, same mask words): fp16 two-part (default), bf16x6, or the
-    opt-in three-product bf16 variant."""
+    """field_fwd on the split-product instances (same outputs, same mask words): fp16 two-part (default) or bf16x6."""
     dev = pk.blob.device
     raw_t = torch.empty(N, pk.n_raw(mode), S, device=dev)
     masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=dev) if want_masks else None
-    x3 = _x3(pk)
     h3 = _h3(pk) and N * S < (1 << 31) - 256
-    fn = L.load().nefes_field_fwd_h3 if h3 else (L.load().nefes_field_fwd_x3 if x3 else L.load().nefes_field_fwd_x6)
-    with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]},{'h3' if h3 else 'x3' if x3 else 'x6'}]"):
+    fn = L.load().nefes_field_fwd_h3 if h3 else L.load().nefes_field_fwd_x6
+    with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]},{'h3' if h3 else 'x6'}]"):
         L.check(fn(pk.desc, _chk(pk.blob, "blob", torch.uint8), mode, N, S, _chk(rays_o, "rays_o"),
                                             _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(xyz_enc, "xyz_enc"),
                                             _chk(viewdirs, "viewdirs"),
@@ -350,10 +338,9 @@ def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=
     g_enc = torch.empty(N * S, 32, device=dev) if ext else None
     g_vs = torch.empty(N * S, 3, device=dev)
     if USE_X6 and SPLIT != "f32" and x6_supported(pk, L.FIELD_FULL, forward=False):
-        x3 = _x3(pk)
         h3 = _h3(pk)
-        fn = L.load().nefes_field_bwd_h3 if h3 else (L.load().nefes_field_bwd_x3 if x3 else L.load().nefes_field_bwd_x6)
-        with _timed("field_bwd[h3]" if h3 else "field_bwd[x3]" if x3 else "field_bwd[x6]"):
+        fn = L.load().nefes_field_bwd_h3 if h3 else L.load().nefes_field_bwd_x6
+        with _timed("field_bwd[h3]" if h3 else "field_bwd[x6]"):
             L.check(fn(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
                                                 _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),
                                                 _chk(raw_t, "raw_t"), _chk(g_raw_t, "g_raw_t"), _chk(masks, "masks", torch.int32),
@@ -784,33 +771,3 @@ def cosine_feature_loss(a, b, return_cos=False):
     per-channel similarities (float64, no gradient) -- per-image losses of a batch folded into the channel dimension."""
     loss, cos = CosineFeatureLoss.apply(a, b)
     return (loss, cos) if return_cos else loss
-
-
-# ---------------------------------------------------------------------------------------------
-# EXPERIMENT (DESIGN.md section 7 item 1): sigma-only forward on v_mfma_f32_16x16x32_f16.  Not used by render().
-# ---------------------------------------------------------------------------------------------
-class H4Sigma:
-    """The coarse network's sigma-only branch (run_network_NeRFH_NFF with typ='coarse', test_time=True) on the 16x16x32 kernel:
-    its own weight blob, packed on the host from the module's parameters."""
-
-    def __init__(self, net, device="cuda"):
-        lib = L.load()
-        self.desc = L.NefesNetDesc(int(net.W), int(net.W_features), 0, L.XYZ_FREQ10)
-        n = lib.nefes_h4_sigma_blob_bytes(self.desc)
-        if n == 0:
-            raise RuntimeError("nefes_amd: the 16x16x32 experiment is built for Wd = 256 / 128 with the frequency embedding")
-        sd = dict(net.named_parameters())
-        tens = [sd[name + s].detach().to("cpu", torch.float32).contiguous() for name in PackedField.LAYERS_COARSE for s in (".weight", ".bias")]
-        ptrs = (C.c_void_p * len(tens))(*[t.data_ptr() for t in tens])
-        host = torch.zeros(n, dtype=torch.uint8)
-        L.check(lib.nefes_h4_sigma_pack(self.desc, ptrs, len(tens), C.c_void_p(host.data_ptr()), n), "nefes_h4_sigma_pack")
-        self.blob = host.to(device)
-
-    def forward(self, N, S, rays_o, rays_d, z):
-        o, d, zz = _f32(rays_o), _f32(rays_d), _f32(z)
-        raw_t = torch.empty(N, 1, S, device=o.device)
-        with _timed("field_fwd[sigma,h4]"):
-            L.check(L.load().nefes_field_fwd_h4_sigma(self.desc, _chk(self.blob, "blob", torch.uint8), N, S, _chk(o, "rays_o"),
-                                                      _chk(d, "rays_d"), _chk(zz, "z"), _chk(raw_t, "raw_t"), _stream()),
-                    "nefes_field_fwd_h4_sigma")
-        return raw_t

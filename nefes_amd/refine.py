@@ -39,6 +39,34 @@ def feature_loss(feature_rgb, feature_target, img_in=True, per_pixel=False):
     return 1 - cos(feature_rgb, feature_target).mean()
 
 
+def svd_reg(pose):
+    """dm/DFM_pose_refine.py:119-129: the 3x3 block of a regressed [B,3,4] pose replaced by its nearest rotation U V^T.
+    Out of place (the reference writes into its argument)."""
+    u, _, v = torch.svd(pose[..., :3, :3])
+    return torch.cat([u @ v.transpose(-2, -1), pose[..., :3, 3:]], -1)
+
+
+def img2mse(x, y):
+    return torch.mean((x - y) ** 2)
+
+
+def mse2psnr(x):
+    """models/nerfh.py: -10 log10(mse)."""
+    return -10. * torch.log(x) / torch.log(torch.tensor([10.], device=x.device))
+
+
+def ssim_map(x, y):
+    """utils/utils.py:15-49 (`SSIM`): 7x7 mean filters on reflection-padded images, clamped to [0, 1]."""
+    F = nn.functional
+    x, y = F.pad(x, (3, 3, 3, 3), mode="reflect"), F.pad(y, (3, 3, 3, 3), mode="reflect")
+    pool = lambda t: F.avg_pool2d(t, 7, 1)
+    mx, my = pool(x), pool(y)
+    sx, sy, sxy = pool(x ** 2) - mx ** 2, pool(y ** 2) - my ** 2, pool(x * y) - mx * my
+    n = (2 * mx * my + 0.01 ** 2) * (2 * sxy + 0.03 ** 2)
+    d = (mx ** 2 + my ** 2 + 0.01 ** 2) * (sx + sy + 0.03 ** 2)
+    return torch.clamp(n / d, 0, 1)
+
+
 class FeatureLoss(nn.Module):
     """dm/DFM_pose_refine.py:236-255."""
 
@@ -57,11 +85,18 @@ class PoseRefiner:
     hwf: full-resolution (H, W, focal); the render runs at 1/tinyscale.  `upsample=True` is the APR variant (bicubic
     upsample of the fused features to (H, W) and a 10-pixel crop; `feature_target` is [C, H, W]); False is the
     DFM_pose_refine variant (`feature_target` is [C, H/ts, W/ts]).  `world_setup` = dict(pose_scale, pose_scale2,
-    move_all_cam_vec) or None.  `graph=True` replays one captured HIP graph per iteration."""
+    move_all_cam_vec) or None.  `graph=True` replays one captured HIP graph per iteration.
+
+    `pose_model=` selects `train_on_batch` proper (DFM_APR_refine.py:84-156, `pose_only=2`): the pose is what a regression
+    network predicts from the query image (`pose_model(img)` -> [1,12] or [1,3,4]; `svd_reg=True` as config_stairs_DFM.txt:22),
+    the optimizer is Adam(lr=`learning_rate`) over a deep copy of that network per image (:209-212), and `refine_apr` returns what
+    `DFM_post_processing` records for the image: the refined network's pose, or the initial one when the verification step
+    finds PSNR or SSIM of the up-sampled render lower after the loop than before (:233-250).  The network itself is the
+    caller's (a CNN outside this path); implies `upsample=True`."""
 
     def __init__(self, render_kwargs, args, hwf, near, far, tinyscale=4, lr_r=0.01, lr_t=0.1, lietorch=False,
                  upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda", adam_capturable=None,
-                 fused_glue=True, images=1):
+                 fused_glue=True, images=1, pose_model=None, svd_reg=False, learning_rate=1e-5):
         self.kw, self.args = dict(render_kwargs), args
         H, W, focal = hwf
         self.H, self.W = int(H), int(W)
@@ -79,6 +114,17 @@ class PoseRefiner:
         if self.B > 1 and (not fused_glue or lietorch or per_pixel):
             raise NotImplementedError("nefes_amd: batched refinement runs on the fused glue kernels (fused_glue=True, "
                                       "lietorch=False, per_pixel=False)")
+        self.apr = None
+        if pose_model is not None:
+            if self.B > 1 or per_pixel:
+                raise NotImplementedError("nefes_amd: the regression-network variant refines one image at a time")
+            import copy
+            self.upsample = upsample = True
+            self.apr_base, self.svd_reg = pose_model, bool(svd_reg)
+            self.apr = copy.deepcopy(pose_model).to(self.dev).train()           # DFM_post_processing :209 (`pp_model`)
+            self.photo = torch.zeros(1, 3, self.H, self.W, device=self.dev)
+            self.apr_opt = torch.optim.Adam(self.apr.parameters(), lr=learning_rate)
+            self._rgb = None
         self.model = LearnPose(self.B, True, True, init_c2w=torch.eye(4)[None].repeat(self.B, 1, 1), lietorch=lietorch).to(self.dev)
         # fused_glue: the pose chain, the crop and the feature loss as library kernels (ops.pose_compose, the windowed
         # ops.bicubic_upsample, ops.cosine_feature_loss) and one fused Adam launch -- ~80 launches per iteration instead of ~215.
@@ -99,7 +145,13 @@ class PoseRefiner:
         """DFM_optimization_NFF (:310-337): pose -> render -> affine colour transform -> fusion CNN -> feature loss.
         Returns (scalar to differentiate, per-image losses [B] or the same scalar)."""
         B = self.B
-        if self.fused_glue and not self.model.lietorch:
+        if self.apr is not None:                           # train_on_batch :91-97
+            c2w = self.apr(self.photo).reshape(1, 3, 4)
+            if self.svd_reg:
+                c2w = svd_reg(c2w)
+            if self.world_setup is not None:
+                c2w = fix_coord_supp(c2w, self.world_setup)
+        elif self.fused_glue and not self.model.lietorch:
             ws = self.world_setup or {"pose_scale": 1.0, "pose_scale2": 1.0, "move_all_cam_vec": (0., 0., 0.)}
             c2w = ops.pose_compose(self.model.r, self.model.t, self.model.init_c2w, ws["pose_scale"], ws["move_all_cam_vec"],
                                    ws["pose_scale2"])                                     # [B,3,4]
@@ -118,6 +170,8 @@ class PoseRefiner:
                 rgb = self.coarse.apply_affine(self._affine, rgb, B)
             else:
                 rgb = self.coarse.affine_color_transform(self.args, rgb, self.hist, B)
+        if self.apr is not None:
+            self._rgb = rgb.detach()                       # the verification step's image (:117-118)
         _, _, fused = self.coarse.run_fusion_net(rgb, feat, self.h, self.w, B, per_image_norm=B > 1)
         if self.upsample:
             if self.fused_glue:
@@ -208,3 +262,62 @@ class PoseRefiner:
             return self.model(torch.arange(self.B, device=self.dev)).detach().clone(), losses
 
     refine_batch = refine
+
+    # ---- train_on_batch / DFM_post_processing (pose_only=2) ------------------------------------------------------------
+    def apr_loss_and_grad(self):
+        """Loss at the working network's current parameters; gradients into their .grad (no optimizer step)."""
+        loss, _ = self._loss()
+        params = [p for p in self.apr.parameters() if p.requires_grad]
+        for p, g in zip(params, torch.autograd.grad(loss, params)):
+            p.grad = g
+        self.loss.copy_(loss.detach())
+        return self.loss
+
+    def _verification(self):
+        """PSNR and mean SSIM of the up-sampled, cropped render against the cropped query image (:117-128, :146-150)."""
+        img = self._rgb.reshape(1, self.h, self.w, 3).permute(0, 3, 1, 2)
+        img = nn.functional.interpolate(img, size=(self.H, self.W), mode="bicubic")[:, :, 10:-10, 10:-10]
+        gt = self.photo[:, :, 10:-10, 10:-10]
+        return float(mse2psnr(img2mse(img, gt))), float(ssim_map(img, gt).mean())
+
+    def predicted_pose(self, net=None):
+        """inference_pose_regression (DFM_pose_refine.py:131-160) of the working (or given) network on the query image: [3,4]."""
+        with torch.no_grad():
+            pose = (self.apr if net is None else net)(self.photo).reshape(1, 3, 4)
+            return (svd_reg(pose) if self.svd_reg else pose)[0]
+
+    def refine_apr(self, photo, feature_target, hist, iters=50, verification=True):
+        """One query image, `pose_only=2`: `photo` [1,3,H,W], `feature_target` [C,H,W] (the query image's features at full
+        resolution; cropped here as :125 does).  Returns (pose [3,4] in the regression network's coordinates, losses [iters],
+        info = dict(psnr=(first, last), ssim=(first, last), retreat=bool))."""
+        if self.apr is None:
+            raise RuntimeError("nefes_amd: PoseRefiner was built without pose_model=")
+        dev = self.dev
+        with torch.no_grad():
+            self.photo.copy_(photo.to(dev).reshape(self.photo.shape))
+            self.target.copy_(feature_target.to(dev).reshape(self.C, self.H, self.W)[:, 10:-10, 10:-10])
+            for pw, pb in zip(self.apr.parameters(), self.apr_base.parameters()):
+                pw.copy_(pb.to(dev))                                       # a fresh copy of the network per image (:209)
+            self.hist.copy_(hist.to(dev).reshape(1, 10))
+            expo = getattr(self.coarse, "exposure_embedding", None)
+            if (self.fused_glue and getattr(self.args, "encode_hist", False) and expo is not None
+                    and not any(p.requires_grad for p in expo.parameters())):
+                self._affine = self.coarse.exposure_coefficients(self.hist).clone()
+        self.apr_opt = torch.optim.Adam(self.apr.parameters(), lr=self.apr_opt.param_groups[0]["lr"])      # :212
+        first = self.predicted_pose()
+        losses = torch.empty(iters, device=dev)
+        checks = []
+        for i in range(iters):
+            self.apr_loss_and_grad()
+            self.apr_opt.step()
+            losses[i] = self.loss
+            if verification and (i == 0 or i == iters - 1):
+                checks.append(self._verification())
+        pose = self.predicted_pose()
+        info = {"retreat": False}
+        if verification and len(checks) == 2:
+            (p0, s0), (p1, s1) = checks
+            info = {"psnr": (p0, p1), "ssim": (s0, s1), "retreat": bool(p1 < p0) or bool(s1 < s0)}       # :242-250
+            if info["retreat"]:
+                pose = first
+        return pose.detach().clone(), losses, info

@@ -213,83 +213,3 @@ def test_x6_ragged_shapes_against_fp32_kernel(N, S, seed):
             ops.USE_X6 = old
     for a, b in zip(outs[True], outs[False]):
         assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) < 2e-5
-
-
-@pytest.mark.parametrize("xyz,Wd,C", [(63, 256, 16), (32, 256, 16), (63, 128, 128)])
-def test_three_product_variant_within_north_star_tolerance(xyz, Wd, C):
-    """Opt-in ops.X6_PRODUCTS = 3 (nefes_field_fwd_x3 / nefes_field_bwd_x3: hi*hi + hi*mid + mid*hi, 16-bit operands):
-    raw outputs within 5e-5 of the float64 oracle per channel scale (BASELINE.json north_star tolerance: 1e-4; the six-product
-    kernels: <3e-6), input gradients within 5e-5 of the six-product backward on the same forward state, never the default."""
-    from nefes_amd import lib as L
-    from nefes_amd import ops
-    from nefes_amd.field import NeRFH_NFF
-    assert ops.X6_PRODUCTS == 6 or "NEFES_X6_PRODUCTS" in __import__("os").environ
-    N, S = 300, 64
-    net = NeRFH_NFF('fine', W=Wd, f_dim=C, in_channels_xyz=xyz, encode_appearance=True, encode_transient=True).requires_grad_(False).to(DEV)
-    pk = net.packed()
-    g = torch.Generator().manual_seed(11)
-    o = torch.randn(N, 3, generator=g) * 0.3
-    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
-    z = torch.sort(torch.rand(N, S, generator=g) * 3.8 + 0.1, -1)[0]
-    enc = torch.randn(N * S, 32, generator=g) * 0.5
-    od, dd, zd, ed = o.to(DEV), d.to(DEV), z.to(DEV), enc.to(DEV)
-    kw = dict(viewdirs=dd, want_masks=True)
-    kw.update(dict(xyz_enc=ed) if xyz == 32 else dict(rays_o=od, rays_d=dd, z=zd))
-    out, fwd = {}, {}
-    bk = dict(viewdirs=dd) if xyz == 32 else dict(rays_o=od, rays_d=dd, z=zd, viewdirs=dd)
-    for prod in (6, 3):
-        old, ops.X6_PRODUCTS = ops.X6_PRODUCTS, prod
-        old_use, ops.USE_X6 = ops.USE_X6, True              # (the suite also runs under NEFES_X6=0)
-        try:
-            fwd[prod] = ops.field_fwd_x6(pk, L.FIELD_FULL, N, S, **kw)
-            # both backward variants on the SAME forward state (six-product outputs and mask words): a ReLU unit whose
-            # pre-activation is within rounding of zero may take the other branch in the other forward, which moves that
-            # sample's gradient by a kink, not by arithmetic error
-            g_raw = torch.randn(fwd[6][0].shape, generator=torch.Generator().manual_seed(12)).to(DEV)
-            gx, gv = ops.field_bwd(pk, N, S, fwd[6][0], g_raw, fwd[6][1], **bk)
-            out[prod] = (fwd[prod][0].cpu().double(), gx.cpu().double(), gv.cpu().double())
-        finally:
-            ops.X6_PRODUCTS, ops.USE_X6 = old, old_use
-    if xyz == 63:
-        p = {k: v.detach().cpu().double() for k, v in net.named_parameters()}
-        pts = o[:, None, :] + d[:, None, :] * z[..., None]
-        ref = O.query_field(p, pts.double(), d.double(), "fine", True, True)            # [N,S,25] float64
-        sc = ref.abs().amax((0, 1)).clamp_min(1e-30)
-        e3 = float(((out[3][0].permute(0, 2, 1) - ref).abs().amax((0, 1)) / sc).max())
-        e6 = float(((out[6][0].permute(0, 2, 1) - ref).abs().amax((0, 1)) / sc).max())
-        print(f"[x3] Wd={Wd}: raw ({9 + C} ch) vs float64: three products {e3:.2e}  six products {e6:.2e}")
-        assert e3 < 5e-5 and e6 < 3e-6
-    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
-    e_raw, e_gx, e_gv = rel(out[3][0], out[6][0]), rel(out[3][1], out[6][1]), rel(out[3][2], out[6][2])
-    print(f"[x3] vs six products: raw {e_raw:.2e}  d inputs {e_gx:.2e}  d viewdirs {e_gv:.2e}")
-    assert 0 < e_raw < 5e-5 and 0 < e_gx < 5e-5 and 0 < e_gv < 5e-5
-
-
-def test_render_three_product_variant_end_to_end():
-    """render() at the headline shape per ray with ops.X6_PRODUCTS = 3 against the six-product run: maps within 1e-4
-    (north-star tolerance), pose gradient within 1e-3 (it also moves through ReLU units that take the other branch)."""
-    import types
-    from nefes_amd import ops
-    from nefes_amd.field import NeRFH_NFF
-    from nefes_amd.render import render
-    coarse = NeRFH_NFF('coarse', W=256, f_dim=16).requires_grad_(False).to(DEV)
-    fine = NeRFH_NFF('fine', W=256, f_dim=16, encode_appearance=True, encode_transient=True).requires_grad_(False).to(DEV)
-    args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True)
-    kw = dict(network_query_fn=None, perturb=False, N_importance=128, N_samples=64, network_fn=coarse, network_fine=fine,
-              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=True, args=args, ndc=False, lindisp=False)
-    H, W, f = 12, 16, 525.505 * 16 / 640.
-    res = {}
-    for prod in (6, 3):
-        old, ops.X6_PRODUCTS = ops.X6_PRODUCTS, prod
-        old_use, ops.USE_X6 = ops.USE_X6, True
-        try:
-            c2w = O.bench_pose().to(DEV).requires_grad_()
-            rgb, disp, acc, ex = render(H, W, f, c2w=c2w, near=0., far=4., **kw)
-            O.bench_loss(rgb, ex["feat_map"]).backward()
-            res[prod] = (rgb.detach().cpu().double(), ex["feat_map"].detach().cpu().double(), c2w.grad.cpu().double())
-        finally:
-            ops.X6_PRODUCTS, ops.USE_X6 = old, old_use
-    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
-    e = [rel(res[3][i], res[6][i]) for i in range(3)]
-    print(f"[x3] render vs six products: rgb {e[0]:.2e}  feat {e[1]:.2e}  d c2w {e[2]:.2e}")
-    assert 0 < e[0] < 1e-4 and 0 < e[1] < 1e-4 and e[2] < 1e-3

@@ -7,10 +7,25 @@ dispatches of a kernel and divided by the number of dispatches, so every figure 
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_digest(root=ROOT):
+    """sha256 over the kernel sources (nefes_amd/csrc: *.hip, *.h, *.cpp, Makefile), 16 hex digits.  Stored with every counter
+    digest; bench.py quotes `roofline.traffic` from a committed digest only while this still matches the tree it runs from."""
+    d = os.path.join(root, "nefes_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def short(name):
@@ -37,7 +52,9 @@ def main():
                 a["_dispatches"] = n
                 for c, v in e["sums"].items():
                     a[c] = v / n
-    json.dump(dict(sorted(agg.items())), open(out, "w"), indent=1)
+    res = dict(sorted(agg.items()))
+    res["_meta"] = {"kernel_sources": kernel_source_digest()}
+    json.dump(res, open(out, "w"), indent=1)
 
 
 if __name__ == "__main__":

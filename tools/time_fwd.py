@@ -22,7 +22,7 @@ for mode, name in ((L.FIELD_SIGMA, 'sigma'), (L.FIELD_FULL, 'full')):
     ms = e0.elapsed_time(e1)
     mac = {('sigma', 256): 491264, ('full', 256): 665088, ('sigma', 128): 130944, ('full', 128): 184064}[(name, Wd)]
     print(f"{name}: {ms:.2f} ms  {2 * mac * N * S / ms / 1e9:.1f} TFLOP/s  checksum {float(raw.double().sum()):.6f}")
-# bf16 split-product instances (six products; NEFES_X6_PRODUCTS=3 selects the opt-in three-product variant)
+# bf16 split-product instances (six products)
 for mode, name in ((L.FIELD_SIGMA, 'sigma'), (L.FIELD_FULL, 'full')):
     if not ops.x6_supported(pk, mode):
         continue
@@ -34,5 +34,5 @@ for mode, name in ((L.FIELD_SIGMA, 'sigma'), (L.FIELD_FULL, 'full')):
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     mac = {('sigma', 256): 491264, ('full', 256): 665088, ('sigma', 128): 130944, ('full', 128): 184064}[(name, Wd)]
-    print(f"{name} bf16x{ops.X6_PRODUCTS}: {ms:.2f} ms  {2 * mac * N * S / ms / 1e9:.1f} TFLOP/s (algorithmic fp32 FLOPs)  "
+    print(f"{name} bf16x6: {ms:.2f} ms  {2 * mac * N * S / ms / 1e9:.1f} TFLOP/s (algorithmic fp32 FLOPs)  "
           f"checksum {float(raw.double().sum()):.6f}")
