@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEFES_ABI_VERSION 9
+#define NEFES_ABI_VERSION 10
 
 #define NEFES_E_BADARG (-1)     /* null pointer / non-positive size */
 #define NEFES_E_UNSUPPORTED (-2) /* width / feat_dim / sample count outside the compiled set */
@@ -47,7 +47,7 @@ typedef struct NefesNetDesc {
 /* where each weight stream lives inside a packed blob (all offsets in bytes from the blob start) */
 typedef struct NefesStreamInfo {
     uint64_t slab_off;   /* first slab */
-    uint32_t n_slabs;    /* 32 KiB each (nefes_amd/csrc/layout.h: NEFES_FWD_SLAB_KIB / NEFES_BWD_SLAB_KIB) */
+    uint32_t n_slabs;    /* nefes_stream_slab_bytes(desc, stream) bytes each (16 / 32 / 48 KiB: nefes_amd/csrc/layout.h) */
     uint32_t bias_floats;
     uint64_t bias_off;   /* bias block (fp32, natural row order per layer); 0 if none */
     uint32_t scale_off;  /* _H3 streams: word index, inside the bias block, of the weight-scale exponent table (int32 per
@@ -76,6 +76,8 @@ int nefes_version(void);
 /* ---- weights ------------------------------------------------------------------------------- */
 /* Blob geometry for a network description. */
 int nefes_blob_info(const NefesNetDesc* desc, NefesBlobInfo* info);
+/* bytes of one slab of weight stream `stream` (NEFES_STREAM_*) for this network description; 0 for an unknown stream */
+size_t nefes_stream_slab_bytes(const NefesNetDesc* desc, int stream);
 /* Host-side layout transform of a NeRFH_NFF state_dict into the MFMA fragment streams the kernels
  * consume.  `tensors` = host fp32 pointers, (weight, bias) per layer in the reference's construction
  * order (nerfh_nff.py:452-505): xyz_encoding_1..8, xyz_encoding_final, dir_encoding.0,

@@ -303,6 +303,383 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs p) {
     }
 }
 
+
+// =====================================================================================================================
+// Four samples per lane (S a multiple of 64): the kernels above move 4 bytes per lane and load instruction and walk a ray's
+// samples in S/64 passes of scans; here a lane owns FOUR CONSECUTIVE samples, so every row of a ray (768 B at S = 192) is one
+// 16-byte load per lane, the transmittance scan is four in-lane products plus ONE cross-lane scan, and a ray occupies RW = S/64
+// rows of 16 lanes -- 4 / RW rays share a wave (four coarse rays of 64 samples, two 128-sample rays, one ray of 192 or 256).
+// Same arithmetic as above: f64 running products / sums rounded to f32 per element, division-free backward.
+// =====================================================================================================================
+template <int RW> struct Seg {
+    static constexpr int LPR = 16 * RW;              // lanes per ray
+    static constexpr int RPW = 4 / RW;               // rays per wave (RW = 3: one ray, the fourth row idles)
+};
+// sum over the lanes of this lane's ray (RW rows of 16 lanes), on every lane of the ray
+template <int RW>
+__device__ __forceinline__ double seg_sum(double v, int lane) {
+    v += dpp_move<0xb1>(v);
+    v += dpp_move<0x4e>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);                         // every lane holds its row's sum
+    if (RW == 1) return v;
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    if (RW == 2) return lane < 32 ? r0 + r1 : r2 + r3;
+    if (RW == 3) return (r0 + r1) + r2;
+    return ((r0 + r1) + r2) + r3;
+}
+// inclusive prefix product over the lanes of a ray (sl = lane index inside the ray)
+template <int RW>
+__device__ __forceinline__ double seg_incl_prod(double v, int sl) {
+#pragma unroll
+    for (int o = 1; o < 16 * RW; o <<= 1) {
+        const double u = __shfl_up(v, o);
+        if (sl >= o) v *= u;
+    }
+    return v;
+}
+// reverse scan of affine maps over the lanes of a ray: lane i ends with F_i o F_{i+1} o ... o F_last
+template <int RW>
+__device__ __forceinline__ void seg_rev_affine(double& m, double& a, int sl) {
+#pragma unroll
+    for (int o = 1; o < 16 * RW; o <<= 1) {
+        const double m2 = __shfl_down(m, o), a2 = __shfl_down(a, o);
+        if (sl + o < 16 * RW) {
+            a = a + m * a2;
+            m = m * m2;
+        }
+    }
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ float el(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+
+struct Ray4 {
+    float zz[4], dl[4], a_c[4], a_s[4], a_t[4], T[4], Ts[4], e_c[4], e_s[4], e_t[4];
+};
+template <int RW>
+__device__ __forceinline__ void ray_forward4(const CompArgs& p, const float* raw, const float* zr, int sl, Ray4& r) {
+    const bool transient = p.flags & NEFES_COMP_TRANSIENT, sigma_only = p.flags & NEFES_COMP_SIGMA_ONLY;
+    const bool static_only = p.flags & NEFES_COMP_STATIC_ONLY;
+    const int S = p.S, C3 = 3 + p.C;
+    const int chS = sigma_only ? 0 : C3, chT = C3 + 4;
+    const int s0 = 4 * sl;
+    const float4 z4 = ld4(zr + s0);
+    const float4 ss4 = ld4(raw + (size_t)chS * S + s0);
+    float4 st4 = {0.f, 0.f, 0.f, 0.f};
+    if (transient) st4 = ld4(raw + (size_t)chT * S + s0);
+    const float z_next = __shfl_down(z4.x, 1);                     // first depth of the next lane's group
+    double om[4], oms[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float z0 = el(z4, k);
+        const float z1 = k < 3 ? el(z4, k + 1) : z_next;
+        r.zz[k] = z0;
+        r.dl[k] = (s0 + k == S - 1) ? 1e2f : (z1 - z0);
+        const float ss = el(ss4, k), st = el(st4, k);
+        r.e_c[k] = expf(-(r.dl[k] * (ss + st)));
+        r.a_c[k] = 1.f - r.e_c[k];
+        if (transient) {
+            r.e_s[k] = expf(-(r.dl[k] * ss));
+            r.e_t[k] = expf(-(r.dl[k] * st));
+            r.a_s[k] = 1.f - r.e_s[k];
+            r.a_t[k] = 1.f - r.e_t[k];
+        } else {
+            r.e_s[k] = r.e_c[k]; r.e_t[k] = 1.f; r.a_s[k] = r.a_c[k]; r.a_t[k] = 0.f;
+        }
+        om[k] = (double)(1.f - r.a_c[k]);
+        oms[k] = (double)(1.f - r.a_s[k]);
+    }
+    {   // exclusive cumprod: the lane's own running product, times the product of everything in front of the lane
+        const double p0 = om[0], p1 = p0 * om[1], p2 = p1 * om[2], p3 = p2 * om[3];
+        const double inc = seg_incl_prod<RW>(p3, sl);
+        const double prev = __shfl_up(inc, 1);
+        const double E = sl == 0 ? 1.0 : prev;
+        r.T[0] = (float)E; r.T[1] = (float)(E * p0); r.T[2] = (float)(E * p1); r.T[3] = (float)(E * p2);
+    }
+    if (static_only) {
+        const double p0 = oms[0], p1 = p0 * oms[1], p2 = p1 * oms[2], p3 = p2 * oms[3];
+        const double inc = seg_incl_prod<RW>(p3, sl);
+        const double prev = __shfl_up(inc, 1);
+        const double E = sl == 0 ? 1.0 : prev;
+        r.Ts[0] = (float)E; r.Ts[1] = (float)(E * p0); r.Ts[2] = (float)(E * p1); r.Ts[3] = (float)(E * p2);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.Ts[k] = r.T[k];
+    }
+}
+
+template <int RW>
+__global__ __launch_bounds__(256) void composite_fwd4_kernel(CompArgs p) {
+    constexpr int LPR = Seg<RW>::LPR, RPW = Seg<RW>::RPW;
+    const int lane = threadIdx.x & 63;
+    const int seg = lane / LPR, sl = lane - seg * LPR;
+    const int ray_raw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + seg;
+    const bool live = seg < RPW && ray_raw < p.N;
+    const int ray = live ? ray_raw : p.N - 1;            // idle lanes shadow the last ray (loads stay in bounds, nothing is stored)
+    const int S = p.S, C = p.C, C3 = 3 + C;
+    const float* raw = p.raw_t + (size_t)ray * p.R * S;
+    const float* zr = p.z + (size_t)ray * S;
+    const bool transient = p.flags & NEFES_COMP_TRANSIENT, sigma_only = p.flags & NEFES_COMP_SIGMA_ONLY;
+    const bool static_only = p.flags & NEFES_COMP_STATIC_ONLY;
+    const bool both = transient && !static_only;
+    const int split = blockIdx.y, n_split = gridDim.y;
+    const bool lead = split == 0;
+    const int s0 = 4 * sl;
+    Ray4 r;
+    ray_forward4<RW>(p, raw, zr, sl, r);
+
+    float w[4], ws[4], wt[4], wo[4];
+    double s_acc = 0, s_dep = 0, s_wo = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        w[k] = r.a_c[k] * r.T[k];
+        ws[k] = static_only ? r.a_s[k] * r.Ts[k] : (transient ? r.a_s[k] * r.T[k] : w[k]);
+        wt[k] = both ? r.a_t[k] * r.T[k] : 0.f;
+        wo[k] = static_only ? ws[k] : w[k];
+        s_acc += w[k];
+        s_wo += wo[k];
+        s_dep += (double)(wo[k] * r.zz[k]);
+    }
+    if (p.weights && lead && live) *(float4*)(p.weights + (size_t)ray * S + s0) = make_float4(wo[0], wo[1], wo[2], wo[3]);
+    const float acc = (float)seg_sum<RW>(s_acc, lane);
+    if (sl == 0 && p.acc && lead && live) p.acc[ray] = acc;
+    if (sigma_only) return;
+    if (lead) {
+        const float depth = (float)seg_sum<RW>(s_dep, lane);
+        const float sum_wo = static_only ? (float)seg_sum<RW>(s_wo, lane) : acc;
+        if (sl == 0 && live) {
+            if (p.depth) p.depth[ray] = depth;
+            if (p.disp) p.disp[ray] = 1.f / max_nan(1e-10f, depth / sum_wo);
+        }
+        float4 c4[3], t4[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            c4[c] = ld4(raw + (size_t)c * S + s0);
+            if (both) t4[c] = ld4(raw + (size_t)(C3 + 1 + c) * S + s0);
+        }
+        float rgb_keep = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double a = 0, b = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a += (double)(ws[k] * el(c4[c], k));
+                if (both) b += (double)(wt[k] * el(t4[c], k));
+            }
+            float v = (float)seg_sum<RW>(a, lane);
+            if ((p.flags & NEFES_COMP_WHITE_BKGD) && both) v = v + (1.f - acc);
+            if (both) v = v + (float)seg_sum<RW>(b, lane);
+            if (sl == c) rgb_keep = v;
+        }
+        if (sl < 3 && p.rgb && live) p.rgb[(size_t)ray * 3 + sl] = rgb_keep;
+    }
+    if (p.feat) {
+        const int per = ((C + n_split - 1) / n_split + 31) / 32 * 32;
+        const int c_lo = split * per, c_hi = (c_lo + per) < C ? (c_lo + per) : C;
+        for (int c0 = c_lo; c0 < c_hi; c0 += LPR) {
+            float keep = 0.f;
+            const int nc = (c_hi - c0) < LPR ? (c_hi - c0) : LPR;
+            for (int cb = 0; cb < nc; cb += 4) {                         // four rows requested before the first is consumed
+                float4 f4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = cb + i < nc ? cb + i : nc - 1;
+                    f4[i] = ld4(raw + (size_t)(3 + c0 + c) * S + s0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double a = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a += (double)(ws[k] * el(f4[i], k));
+                    const float v = (float)seg_sum<RW>(a, lane);
+                    if (sl == cb + i) keep = v;
+                }
+            }
+            if (sl < nc && live) p.feat[(size_t)ray * C + c0 + sl] = keep;
+        }
+    }
+    if (p.beta && lead) {
+        float bv = 0.f;
+        if (both) {
+            const float4 b4 = ld4(raw + (size_t)(C3 + 5) * S + s0);
+            double sb = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sb += (double)(wt[k] * el(b4, k));
+            bv = (float)seg_sum<RW>(sb, lane) + p.beta_min;
+        }
+        if (sl == 0 && live) p.beta[ray] = bv;
+    }
+}
+
+template <int RW>
+__global__ __launch_bounds__(256) void composite_bwd4_kernel(CompArgs p) {
+    constexpr int LPR = Seg<RW>::LPR, RPW = Seg<RW>::RPW;
+    const int lane = threadIdx.x & 63;
+    const int seg = lane / LPR, sl = lane - seg * LPR;
+    const int ray_raw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + seg;
+    const bool live = seg < RPW && ray_raw < p.N;
+    const int ray = live ? ray_raw : p.N - 1;
+    const int S = p.S, C = p.C, C3 = 3 + C;
+    const float* raw = p.raw_t + (size_t)ray * p.R * S;
+    float* graw = p.g_raw_t + (size_t)ray * p.R * S;
+    const float* zr = p.z + (size_t)ray * S;
+    const bool transient = p.flags & NEFES_COMP_TRANSIENT, sigma_only = p.flags & NEFES_COMP_SIGMA_ONLY;
+    const bool static_only = p.flags & NEFES_COMP_STATIC_ONLY;
+    const bool both = transient && !static_only;
+    const int s0 = 4 * sl;
+    // rows the per-sample weight gradients need, requested before the scans
+    float4 c4[3], t4[3], b4 = {0.f, 0.f, 0.f, 0.f}, gw4 = {0.f, 0.f, 0.f, 0.f};
+    if (!sigma_only) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            c4[c] = ld4(raw + (size_t)c * S + s0);
+            if (both) t4[c] = ld4(raw + (size_t)(C3 + 1 + c) * S + s0);
+        }
+        if (both) b4 = ld4(raw + (size_t)(C3 + 5) * S + s0);
+    }
+    if (p.g_weights) gw4 = ld4(p.g_weights + (size_t)ray * S + s0);
+    Ray4 r;
+    ray_forward4<RW>(p, raw, zr, sl, r);
+
+    float w[4], ws[4], wt[4], wo[4];
+    double s_acc = 0, s_dep = 0, s_wo = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        w[k] = r.a_c[k] * r.T[k];
+        ws[k] = static_only ? r.a_s[k] * r.Ts[k] : (transient ? r.a_s[k] * r.T[k] : w[k]);
+        wt[k] = both ? r.a_t[k] * r.T[k] : 0.f;
+        wo[k] = static_only ? ws[k] : w[k];
+        s_acc += w[k]; s_wo += wo[k]; s_dep += (double)(wo[k] * r.zz[k]);
+    }
+    const float acc = (float)seg_sum<RW>(s_acc, lane);
+    const float depth = (float)seg_sum<RW>(s_dep, lane);
+    const float sum_wo = static_only ? (float)seg_sum<RW>(s_wo, lane) : acc;
+
+    float g_rgb[3] = {0.f, 0.f, 0.f};
+    if (p.g_rgb && !sigma_only)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g_rgb[c] = p.g_rgb[(size_t)ray * 3 + c];
+    float g_acc = p.g_acc ? p.g_acc[ray] : 0.f;
+    float g_dep = (p.g_depth && !sigma_only) ? p.g_depth[ray] : 0.f;
+    const float g_beta = (p.g_beta && both) ? p.g_beta[ray] : 0.f;
+    float g_sumwo = 0.f;
+    if (p.g_disp && !sigma_only) {
+        const float gd = p.g_disp[ray];
+        const float ratio = depth / sum_wo;
+        if (ratio > 1e-10f || ratio != ratio) {
+            const float disp = 1.f / ratio;
+            const float g_ratio = -gd * disp * disp;
+            g_dep += g_ratio / sum_wo;
+            g_sumwo += -g_ratio * ratio / sum_wo;
+        }
+    }
+    if ((p.flags & NEFES_COMP_WHITE_BKGD) && both) g_acc -= (g_rgb[0] + g_rgb[1] + g_rgb[2]);
+    if (!static_only) { g_acc += g_sumwo; g_sumwo = 0.f; }
+
+    float Gs[4], Gt[4], Gc[4], G1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        Gs[k] = Gt[k] = Gc[k] = G1[k] = 0.f;
+        const float gw = el(gw4, k);
+        float col_s = 0.f, col_t = 0.f;
+        if (!sigma_only) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                col_s += g_rgb[c] * el(c4[c], k);
+                if (both) col_t += g_rgb[c] * el(t4[c], k);
+            }
+        }
+        if (both) {
+            Gs[k] = col_s;
+            Gt[k] = col_t + g_beta * el(b4, k);
+            Gc[k] = g_acc + g_dep * r.zz[k] + gw;
+        } else if (static_only) {
+            G1[k] = col_s + g_dep * r.zz[k] + g_sumwo + gw;
+            Gc[k] = g_acc;
+        } else {
+            Gc[k] = col_s + g_acc + g_dep * r.zz[k] + gw;
+        }
+    }
+    // X_i = A_i + (1 - alpha_i) X_{i+1} over the ray: the lane's four maps composed, one reverse scan across lanes, then the
+    // lane's own elements by back-substitution from the next lane's X.  B_i = X_{i+1}.
+    double Bc[4], B1[4];
+    {
+        double mk[4], ak[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mk[k] = (double)(1.f - r.a_c[k]);
+            ak[k] = (double)Gs[k] * r.a_s[k] * (both ? 1.0 : 0.0) + (double)Gt[k] * r.a_t[k] + (double)Gc[k] * r.a_c[k];
+        }
+        double m = ((mk[0] * mk[1]) * mk[2]) * mk[3];
+        double a = ak[0] + mk[0] * (ak[1] + mk[1] * (ak[2] + mk[2] * ak[3]));
+        seg_rev_affine<RW>(m, a, sl);
+        const double nxt = __shfl_down(a, 1);
+        double X = sl + 1 < LPR ? nxt : 0.0;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) { Bc[k] = X; X = ak[k] + mk[k] * X; }
+    }
+    if (static_only) {
+        double mk[4], ak[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { mk[k] = (double)(1.f - r.a_s[k]); ak[k] = (double)G1[k] * r.a_s[k]; }
+        double m = ((mk[0] * mk[1]) * mk[2]) * mk[3];
+        double a = ak[0] + mk[0] * (ak[1] + mk[1] * (ak[2] + mk[2] * ak[3]));
+        seg_rev_affine<RW>(m, a, sl);
+        const double nxt = __shfl_down(a, 1);
+        double X = sl + 1 < LPR ? nxt : 0.0;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) { B1[k] = X; X = ak[k] + mk[k] * X; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) B1[k] = 0.0;
+    }
+    if (!live) return;
+    float gss[4], gst[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double T = r.T[k], Ts = r.Ts[k];
+        const double d_ac = (double)Gc[k] * T - T * Bc[k];
+        double d_as = 0.0, d_at = 0.0;
+        if (both) { d_as = (double)Gs[k] * T; d_at = (double)Gt[k] * T; }
+        if (static_only) d_as = (double)G1[k] * Ts - Ts * B1[k];
+        const double dl = r.dl[k];
+        gss[k] = (float)(transient ? d_as * dl * r.e_s[k] + d_ac * dl * r.e_c[k] : d_ac * dl * r.e_c[k]);
+        gst[k] = (float)(d_at * dl * r.e_t[k] + d_ac * dl * r.e_c[k]);
+    }
+    auto store_row = [&](int ch, const float (&v)[4]) { *(float4*)(graw + (size_t)ch * S + s0) = make_float4(v[0], v[1], v[2], v[3]); };
+    if (sigma_only) { store_row(0, gss); return; }
+    store_row(C3, gss);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v[4] = {ws[0] * g_rgb[c], ws[1] * g_rgb[c], ws[2] * g_rgb[c], ws[3] * g_rgb[c]};
+        store_row(c, v);
+    }
+    const float* gf = p.g_feat ? p.g_feat + (size_t)ray * C : nullptr;
+    for (int c = 0; c < C; ++c) {
+        const float gfc = gf ? gf[c] : 0.f;
+        const float v[4] = {gf ? ws[0] * gfc : 0.f, gf ? ws[1] * gfc : 0.f, gf ? ws[2] * gfc : 0.f, gf ? ws[3] * gfc : 0.f};
+        store_row(3 + c, v);
+    }
+    if (transient) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v[4] = {wt[0] * g_rgb[c], wt[1] * g_rgb[c], wt[2] * g_rgb[c], wt[3] * g_rgb[c]};
+            store_row(C3 + 1 + c, v);
+        }
+        store_row(C3 + 4, gst);
+        const float v[4] = {wt[0] * g_beta, wt[1] * g_beta, wt[2] * g_beta, wt[3] * g_beta};
+        store_row(C3 + 5, v);
+    }
+}
+
+#ifndef NEFES_COMPOSITE_LEGACY
+#define NEFES_COMPOSITE_LEGACY 0      /* 1: one sample per lane for every S (A/B builds) */
+#endif
+static bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 static int comp_args(CompArgs& a, int N, int S, int C, uint32_t flags) {
     if (N <= 0 || S <= 1 || C < 0) return NEFES_E_BADARG;
     if (S > 256) return NEFES_E_UNSUPPORTED;
@@ -324,6 +701,17 @@ extern "C" int nefes_composite_fwd(int N, int S, int C, uint32_t flags, float be
     const int n_split = (feat && C >= 64 && N < 40000) ? ((C + 31) / 32 < 4 ? (C + 31) / 32 : 4) : 1;
     const dim3 grid((N + 3) / 4, n_split), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (S % 64 == 0 && !NEFES_COMPOSITE_LEGACY && aligned16(raw_t) && aligned16(z) && aligned16(weights)) {   // four samples per lane
+        const int rw = S / 64, rpw = 4 / rw;
+        const dim3 grid4((N + 4 * rpw - 1) / (4 * rpw), n_split);
+        switch (rw) {
+            case 1: hipLaunchKernelGGL(composite_fwd4_kernel<1>, grid4, block, 0, st, a); break;
+            case 2: hipLaunchKernelGGL(composite_fwd4_kernel<2>, grid4, block, 0, st, a); break;
+            case 3: hipLaunchKernelGGL(composite_fwd4_kernel<3>, grid4, block, 0, st, a); break;
+            default: hipLaunchKernelGGL(composite_fwd4_kernel<4>, grid4, block, 0, st, a); break;
+        }
+        return (int)hipGetLastError();
+    }
     switch ((S + 63) / 64) {
         case 1: hipLaunchKernelGGL(composite_fwd_kernel<1>, grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL(composite_fwd_kernel<2>, grid, block, 0, st, a); break;
@@ -345,6 +733,17 @@ extern "C" int nefes_composite_bwd(int N, int S, int C, uint32_t flags, const fl
     a.g_depth = g_depth; a.g_weights = g_weights; a.g_beta = g_beta; a.g_raw_t = g_raw_t;
     const dim3 grid((N + 3) / 4), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (S % 64 == 0 && !NEFES_COMPOSITE_LEGACY && aligned16(raw_t) && aligned16(z) && aligned16(g_raw_t) && aligned16(g_weights)) {
+        const int rw = S / 64, rpw = 4 / rw;
+        const dim3 grid4((N + 4 * rpw - 1) / (4 * rpw));
+        switch (rw) {
+            case 1: hipLaunchKernelGGL(composite_bwd4_kernel<1>, grid4, block, 0, st, a); break;
+            case 2: hipLaunchKernelGGL(composite_bwd4_kernel<2>, grid4, block, 0, st, a); break;
+            case 3: hipLaunchKernelGGL(composite_bwd4_kernel<3>, grid4, block, 0, st, a); break;
+            default: hipLaunchKernelGGL(composite_bwd4_kernel<4>, grid4, block, 0, st, a); break;
+        }
+        return (int)hipGetLastError();
+    }
     switch ((S + 63) / 64) {
         case 1: hipLaunchKernelGGL(composite_bwd_kernel<1>, grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL(composite_bwd_kernel<2>, grid, block, 0, st, a); break;

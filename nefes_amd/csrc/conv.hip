@@ -58,8 +58,9 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a) {
         const int iy = py + tap / KS - PAD, ix = px + tap % KS - PAD;
         if (pin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) vbits |= 1u << tap;
     }
-    const float* xp = xb + p - (PAD * a.W + PAD);            // tap (ty, tx) of channel ci: xp[ci * HW + ty * W + tx]
-    const float* mp = mb ? mb + p - (PAD * a.W + PAD) : nullptr;
+    const int pa = pin ? p : HW - 1;                         // lanes past the last pixel address the last one (their loads are unused)
+    const float* xp = xb + pa - (PAD * a.W + PAD);           // tap (ty, tx) of channel ci: xp[ci * HW + ty * W + tx]
+    const float* mp = mb ? mb + pa - (PAD * a.W + PAD) : nullptr;
     const float* wl = a.wp + cot * 32 + n;                   // wl[(ci * TAPS + tap) * cout_pad]
     auto fetch = [&](int s0, float (&av)[NST], float (&bv)[NST]) __attribute__((always_inline)) {
 #pragma unroll

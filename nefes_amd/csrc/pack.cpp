@@ -511,6 +511,11 @@ void fill_info(const Stream (&st)[NEFES_N_STREAMS], int width, NefesBlobInfo* in
 
 extern "C" int nefes_version(void) { return NEFES_ABI_VERSION; }
 
+extern "C" size_t nefes_stream_slab_bytes(const NefesNetDesc* desc, int stream) {
+    if (!desc || stream < 0 || stream >= 13) return 0;
+    return (size_t)nefes_stream_slab_kib(stream, desc->width) * 1024;
+}
+
 extern "C" int nefes_blob_info(const NefesNetDesc* desc, NefesBlobInfo* info) {
     if (!desc || !info) return NEFES_E_BADARG;
     Net n;

@@ -71,11 +71,12 @@ class FusionNet(nn.Module):
         per_image_norm: B independent images in one batch (PoseRefiner(images=B)).  The reference runs this net on one image at
         a time with BatchNorm in train mode, i.e. normalised by that image's own statistics; for a batch the same arithmetic is
         an instance norm with the BatchNorm's affine parameters (the running statistics, which train mode never reads, are
-        not updated on this path)."""
+        not updated on this path).  A BatchNorm put into eval() normalises every image by its running statistics instead --
+        per image already -- so the batch then goes through the module itself, like a single image does."""
         mean, std = self._mean_std(rgb_nchw)
         x = torch.cat([(rgb_nchw - mean[:, None, None]) / std[:, None, None], feat_nchw], dim=1)
         convs = self._convs_hip if self._use_hip(x) else self.net[:7]
-        if per_image_norm and not self.no_BN and x.shape[0] > 1:
+        if per_image_norm and not self.no_BN and x.shape[0] > 1 and self.net[-1].training:
             bn = self.net[-1]
             out = nn.functional.instance_norm(convs(x), weight=bn.weight, bias=bn.bias, eps=bn.eps)
         else:
@@ -177,9 +178,9 @@ class NeRFH_NFF(nn.Module):
             key += (float(sum(p.detach().double().sum() for p in prm)),)
         if (self._pk is not None and key != self._pk_key and any(p.requires_grad for p in prm)
                 and all(p.is_cuda and p.device == self._pk.blob.device for p in prm)):
-            # a trainable network after an optimizer step: re-packed on the device, no host copy, no sync (the fp16 two-part
-            # streams are not produced there -- the train path runs on the bf16x6 / fp32 instances).  A FROZEN network whose
-            # values changed (load_state_dict, an in-place edit) takes the host packer below and keeps its fp16 streams.
+            # a trainable network after an optimizer step: re-packed on the device, no host copy, no sync -- every stream, the
+            # fp16 two-part ones and their scale tables included (ops.REPACK_H3; bit-identical to the host packer).  A FROZEN
+            # network whose values changed (load_state_dict, an in-place edit) takes the host packer below.
             self._pk.repack(prm)
             self._pk_key = key
         elif self._pk is None or key != self._pk_key:

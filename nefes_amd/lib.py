@@ -32,7 +32,7 @@ class NefesHashGridDesc(C.Structure):
                 ("base_resolution", C.c_int32), ("per_level_scale", C.c_float), ("bound", C.c_float)]
 
 
-ABI_VERSION = 9        # NEFES_ABI_VERSION of include/nefes_hip.h
+ABI_VERSION = 10       # NEFES_ABI_VERSION of include/nefes_hip.h
 STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6, STREAM_BWD_FULL_X6, STREAM_BWD_STATIC = 0, 1, 2, 3, 4, 5, 6, 7
 STREAM_FWD_SIGMA_H3, STREAM_FWD_FULL_H3, STREAM_BWD_FULL_H3, STREAM_FWD_STATIC_H3, STREAM_BWD_STATIC_H3 = 8, 9, 10, 11, 12
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
@@ -48,6 +48,7 @@ _desc = C.POINTER(NefesNetDesc)
 SIGNATURES = {
     "nefes_version": (_i, []),
     "nefes_blob_info": (_i, [_desc, C.POINTER(NefesBlobInfo)]),
+    "nefes_stream_slab_bytes": (_sz, [_desc, _i]),
     "nefes_pack_weights": (_i, [_desc, C.POINTER(_p), _i, _p, _sz]),
     "nefes_pack_map": (_i, [_desc, _p, _sz, _p]),
     "nefes_pack_h3_plan": (_i, [_desc, _p, _sz, C.POINTER(_sz)]),

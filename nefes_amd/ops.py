@@ -241,12 +241,11 @@ class PackedField:
         """[(begin, end)] byte ranges of the fp16 two-part units and their scale tables (refreshed by repack() only with the
         fp16 plan, REPACK_H3)."""
         out = []
-        fwd_kib = 16 if int(self.desc.width) == 128 else 32            # csrc/layout.h: NEFES_H3_{FWD,BWD}_SLAB_KIB_128 / NEFES_H3_{FWD,BWD}_SLAB_KIB
-        for k, kib in ((L.STREAM_FWD_SIGMA_H3, fwd_kib), (L.STREAM_FWD_FULL_H3, fwd_kib), (L.STREAM_BWD_FULL_H3, fwd_kib),
-                       (L.STREAM_FWD_STATIC_H3, fwd_kib), (L.STREAM_BWD_STATIC_H3, fwd_kib)):
+        for k in (L.STREAM_FWD_SIGMA_H3, L.STREAM_FWD_FULL_H3, L.STREAM_BWD_FULL_H3, L.STREAM_FWD_STATIC_H3, L.STREAM_BWD_STATIC_H3):
             si = self.info.stream[k]
             if si.n_slabs:
-                out.append((int(si.slab_off), int(si.slab_off + si.n_slabs * kib * 1024)))
+                slab = int(L.load().nefes_stream_slab_bytes(self.desc, k))        # per stream: forward and backward rings differ
+                out.append((int(si.slab_off), int(si.slab_off + si.n_slabs * slab)))
                 out.append((int(si.bias_off + 4 * si.scale_off), int(si.bias_off + 4 * si.bias_floats)))
         return out
 

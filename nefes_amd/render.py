@@ -11,7 +11,7 @@ Kernel sequence of one render() at test time (perturb=0, test_time=True; SURVEY.
     Composite variant A/B                        -> rgb, feat, disp, acc               [grad -> raw_t]
 The ray batch is processed in one launch per kernel (no Python chunk loop over 32 768-ray chunks as in
 rendering.py:182-195): the batch is split only when its intermediates (raw_t, its gradient, the ReLU masks, train-mode
-activations) would not fit the free device memory -- see `rays_per_launch` -- or at MAX_RAYS_PER_LAUNCH.  `netchunk` is
+activations) would not fit the device memory -- see `rays_per_launch` -- or at MAX_RAYS_PER_LAUNCH.  `netchunk` is
 accepted and ignored (the fused kernel tiles internally).
 """
 import types
@@ -26,24 +26,34 @@ MAX_RAYS_PER_LAUNCH = 1 << 22
 MEMORY_FRACTION = 0.6          # share of the free device memory one launch sequence may plan for
 
 
+_STEP = {}
+
+
 def rays_per_launch(cfg, network_fn, network_fine, device, train=False):
     """Largest ray count whose per-launch intermediates fit: per ray and fine sample 2 x R floats (raw_t and its gradient),
     the 1-bit ReLU masks, d pts / d viewdirs, and in train mode the saved pre-activations (layout.h row map); plus the
-    depth / weight rows.  Bounded by MAX_RAYS_PER_LAUNCH."""
+    depth / weight rows.  Bounded by MAX_RAYS_PER_LAUNCH.  Planned once per (network shape, sample counts, mode, device) against
+    the device's TOTAL memory, so that where a batch is split -- and with it the order in which jitter / noise is drawn -- does
+    not depend on what else happens to be allocated at the moment of a call (a plan that no longer fits fails in the allocator
+    with torch's out-of-memory error)."""
     net = network_fine if (network_fine is not None and cfg.N_importance > 0) else network_fn
     S = cfg.N_samples + cfg.N_importance if not cfg.use_fine_only or cfg.N_importance == 0 else cfg.N_importance
     Wd, C = net.W, net.W_features
+    dev = torch.device(device)
+    key = (Wd, C, S, cfg.N_samples, bool(train), dev.type, dev.index)
+    if key in _STEP:
+        return _STEP[key]
     R = 3 + C + 6
     per_sample = 2 * R * 4 + (8 * (Wd // 64) + 4 * (Wd // 128)) * 4 * 2 + 24 + 16
     if train:
         per_sample += 4 * (64 + 32 + 9 * Wd + 2 * Wd + 32 * ((3 + C + 31) // 32) + 64) * 2
     per_ray = per_sample * S + (cfg.N_samples * 4) * 4 + 256
     try:
-        free, _ = torch.cuda.mem_get_info(device)
-        free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)      # cached blocks are reusable
+        total = torch.cuda.get_device_properties(dev).total_memory
     except Exception:
         return MAX_RAYS_PER_LAUNCH
-    return int(max(1024, min(MAX_RAYS_PER_LAUNCH, (free * MEMORY_FRACTION) // per_ray)))
+    _STEP[key] = int(max(1024, min(MAX_RAYS_PER_LAUNCH, (total * MEMORY_FRACTION) // per_ray)))
+    return _STEP[key]
 
 
 def _cfg(kwargs):
@@ -169,7 +179,7 @@ def _cat_parts(outs):
 
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     """Reference signature (rendering.py:182-195).  The reference's `chunk` exists to bound memory; here that bound is
-    computed from the free device memory (rays_per_launch) and the batch is split only when it would not fit."""
+    planned against the device memory (rays_per_launch) and the batch is split only when it would not fit."""
     cfg = _cfg(dict(kwargs, N_samples=kwargs.get("N_samples", 64)))
     rays_flat = rays_flat.to(_DEV)
     step = rays_per_launch(cfg, kwargs["network_fn"], kwargs.get("network_fine", None), rays_flat.device,
@@ -188,7 +198,12 @@ def _rays_for(H, W, focal, c2w, c2w_staticcam, row_range):
 def _render_batch(rays_o, rays_d, viewdirs, near, far, chunk, kwargs, cfg):
     network_fn, network_fine = kwargs["network_fn"], kwargs.get("network_fine", None)
     N = rays_o.shape[0]
-    step = rays_per_launch(cfg, network_fn, network_fine, rays_o.device, train=not cfg.test_time)
+    trains = any(p.requires_grad for net in (network_fn, network_fine) if net is not None for p in net.parameters())
+    step = rays_per_launch(cfg, network_fn, network_fine, rays_o.device, train=trains)
+    if trains and N > step:
+        # every slice's saved activations live until backward(): slicing would not bound the peak, so say it instead of dying later
+        raise RuntimeError(f"nefes_amd: a train-mode batch of {N} rays needs more than {MEMORY_FRACTION:.0%} of the device memory for "
+                           f"its saved activations (at most {step} rays at this network shape); render fewer rays per step")
     if N <= step:       # the usual case: no slicing (a slice of a differentiable tensor costs a fill and a copy in its backward)
         return _render_core(rays_o, rays_d, viewdirs, float(near), float(far), network_fn, network_fine, cfg)
     outs = []

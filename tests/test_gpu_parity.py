@@ -140,6 +140,63 @@ def test_composite_matches_reference(golden, ops, tag):
     np.testing.assert_allclose(got[fin], want[fin], rtol=1e-4, atol=1e-5 * scale)
 
 
+@pytest.mark.parametrize("S", [64, 128, 192, 256])
+@pytest.mark.parametrize("tag", ["A", "B", "C", "D"])
+def test_composite_four_samples_per_lane_matches_oracle(ops, tag, S):
+    """S a multiple of 64 takes the four-samples-per-lane kernels (csrc/composite.hip: composite_fwd4 / bwd4; 4 / (S/64) rays
+    share a wave): every map and d raw against the float64 oracle (raw2outputs_NeRFH_NFF restated, oracle/ref_cpu.py) with the
+    fp32 oracle beside it (three-way rule), on rays that include saturated alphas, zero density, and a ray count that fills
+    neither the last wave nor the last workgroup."""
+    flags, _ = VARIANTS[tag]
+    N, C = 37, 5
+    g = torch.Generator().manual_seed(100 * S + ord(tag))
+    R = 1 if tag == "D" else 3 + C + (6 if tag in ("A", "B") else 1)
+    raw = torch.randn(N, S, R, generator=g)
+    i_s = 0 if tag == "D" else 3 + C
+    raw[..., i_s] = torch.nn.functional.softplus(3 * torch.randn(N, S, generator=g))
+    raw[3, :, i_s] *= 40.                                  # alpha saturates to 1 early on this ray
+    raw[5, S // 2:, i_s] = 0.                              # empty second half
+    if tag in ("A", "B"):
+        raw[..., i_s + 4] = torch.nn.functional.softplus(torch.randn(N, S, generator=g) - 1)
+        raw[..., i_s + 1:i_s + 4] = torch.sigmoid(raw[..., i_s + 1:i_s + 4])
+    z = torch.sort(torch.rand(N, S, generator=g) * 4, -1)[0]
+    ups = {k: torch.randn(N, *sh, generator=g) for k, sh in (("rgb", (3,)), ("feat", (C,)), ("acc", ()), ("depth", ()), ("w", (S,)), ("beta", ()))}
+
+    def run(dt):
+        r = raw.detach().clone().to(dt).requires_grad_()
+        o = O.composite(r, z.to(dt), output_transient=tag in ("A", "B"), test_time=tag in ("B", "D"), typ="coarse" if tag == "D" else "fine",
+                        transient_at_test=tag == "A")
+        loss = (o.acc * ups["acc"].to(dt)).sum() + (o.weights * ups["w"].to(dt)).sum()
+        if tag != "D":
+            loss = loss + (o.rgb * ups["rgb"].to(dt)).sum() + (o.feat * ups["feat"].to(dt)).sum() + (o.depth * ups["depth"].to(dt)).sum()
+            if tag == "A":
+                loss = loss + (o.beta * ups["beta"].to(dt)).sum()
+        loss.backward()
+        maps = {"acc": o.acc, "weights": o.weights}
+        if tag != "D":
+            maps.update(rgb=o.rgb, feat=o.feat, depth=o.depth)
+            if tag == "A":
+                maps["beta"] = o.beta
+        return {k: v.detach().double() for k, v in maps.items()}, r.grad.double()
+    m64, g64 = run(torch.float64)
+    m32, g32 = run(torch.float32)
+    raw_t = raw.permute(0, 2, 1).contiguous().to(DEV).requires_grad_()
+    rgb, feat, disp, acc, depth, w, beta = ops.Composite.apply(raw_t, z.to(DEV), C, flags, 0.1)
+    loss = (acc * ups["acc"].to(DEV)).sum() + (w * ups["w"].to(DEV)).sum()
+    got = {"acc": acc, "weights": w}
+    if tag != "D":
+        loss = loss + (rgb * ups["rgb"].to(DEV)).sum() + (feat * ups["feat"].to(DEV)).sum() + (depth * ups["depth"].to(DEV)).sum()
+        got.update(rgb=rgb, feat=feat, depth=depth)
+        if tag == "A":
+            loss = loss + (beta * ups["beta"].to(DEV)).sum()
+            got["beta"] = beta
+    loss.backward()
+    relm = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    for k, v in got.items():
+        P.check(f"composite4[{tag},S={S}]", k, relm(v.detach().cpu().double(), m64[k]), relm(m32[k], m64[k]), tol=2e-6)
+    P.check(f"composite4[{tag},S={S}]", "d raw", relm(raw_t.grad.permute(0, 2, 1).cpu().double(), g64), relm(g32, g64), tol=5e-6)
+
+
 def test_composite_rejects_cpu_tensors(ops):
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.composite_fwd(torch.zeros(2, 1, 8), torch.zeros(2, 8), 0, 4)

@@ -276,8 +276,8 @@ def test_render_poses_batches_into_one_launch_sequence():
 
 
 def test_memory_bounded_batching_gives_the_same_maps(monkeypatch):
-    """the per-launch ray count follows the free device memory; a forced tiny budget splits the batch and the
-    maps are unchanged bit for bit."""
+    """the per-launch ray count is planned once per network shape against the device memory; a forced tiny budget
+    splits the batch and the maps are unchanged bit for bit; a train-mode batch that cannot be held at once is refused."""
     R, M, _ = dropin()
     import nefes_amd.render as NR
     coarse, fine = nets(128, 128)
@@ -294,6 +294,11 @@ def test_memory_bounded_batching_gives_the_same_maps(monkeypatch):
     per_ray = (2 * 137 * 4 + 80 + 40) * 128
     free, _ = torch.cuda.mem_get_info()
     assert 1024 <= cap <= NR.MAX_RAYS_PER_LAUNCH and cap * per_ray <= free + torch.cuda.memory_reserved()
+    assert NR.rays_per_launch(cfg, coarse, fine, torch.device(DEV)) == cap                 # planned once, not per call
+    coarse.requires_grad_(True)
+    monkeypatch.setattr(NR, "rays_per_launch", lambda *args, **k: 1024)
+    with pytest.raises(RuntimeError, match="train-mode batch"):
+        R.render(H, W, focal, c2w=c2w, near=0., far=4., **dict(kw, test_time=False, perturb=1.))
 
 
 def test_merge_with_nans_fills_every_slot():
