@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEFES_ABI_VERSION 10
+#define NEFES_ABI_VERSION 11
 
 #define NEFES_E_BADARG (-1)     /* null pointer / non-positive size */
 #define NEFES_E_UNSUPPORTED (-2) /* width / feat_dim / sample count outside the compiled set */
@@ -308,6 +308,21 @@ int nefes_cosine_loss_fwd(int C, int64_t P, const float* a, const float* b, doub
 /* g_a [C,P] = g_loss[0] * d loss / d a (g_loss: dev scalar). */
 int nefes_cosine_loss_bwd(int C, int64_t P, const float* a, const float* b, const double* scratch, const float* g_loss, float* g_a,
                           void* stream);
+
+/* ---- FusionNet's input from the rendered maps, one launch each way (script/models/nerfh_nff.py:605-626 affine_color_transform
+ *      with the image's 12 exposure coefficients given, :578-603 run_fusion_net's reshape / permute / cat, :395-402 the colour
+ *      normalisation):  y = sigmoid(K rgb + b) (affine == NULL: y = rgb);  x[b, 0:3] = (y - mean) / std;  x[b, 3:] = feat^T.
+ *      rgb [B*HW,3], feat [B*HW,C], affine [B,12] (dev), mean3 / std3 HOST pointers -> x [B,3+C,HW], y [B*HW,3] (saved). ---- */
+int nefes_fusion_input_fwd(int B, int HW, int C, const float* rgb, const float* feat, const float* affine, const float* mean3,
+                           const float* std3, float* x, float* y, void* stream);
+/* g_x [B,3+C,HW] -> g_rgb [B*HW,3], g_feat [B*HW,C] (either may be NULL); the exposure coefficients carry no gradient here. */
+int nefes_fusion_input_bwd(int B, int HW, int C, const float* g_x, const float* affine, const float* y, const float* std3, float* g_rgb,
+                           float* g_feat, void* stream);
+/* torch.optim.Adam's update (no weight decay, no amsgrad) for n <= 1024 fp32 numbers with a learning rate per element (dev array
+ * of doubles; bias corrections and step size in float64 like the Python scalars of torch/optim/adam.py): the refinement loop's
+ * (r, t) with (lr_r, lr_t) in one launch.  step: dev scalar (float), incremented. */
+int nefes_adam_step(int n, float* p, const float* g, float* m, float* v, float* step, const double* lr, double beta1, double beta2,
+                    double eps, void* stream);
 
 /* ---- measurement aid (bench.py's roofline): the matrix-core rate this GPU SUSTAINS under its power management.  Runs
  *      v_mfma_f32_32x32x16_f16 back to back on every SIMD for ~ms_target milliseconds (operands all zero, or random bits) and

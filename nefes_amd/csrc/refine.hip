@@ -216,3 +216,162 @@ extern "C" int nefes_cosine_loss_bwd(int C, int64_t P, const float* a, const flo
                        scratch, g_loss, g_a);
     return (int)hipGetLastError();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+//   fusion_input      what the loop does between compositing and FusionNet's first convolution (script/models/nerfh_nff.py:
+//                     605-626 affine_color_transform with the image's 12 exposure coefficients already known, :578-603
+//                     run_fusion_net's reshape / permute / cat, FusionNet.forward's colour normalisation :395-402):
+//                         y = sigmoid(K rgb + b);  x[b, 0:3] = (y - mean) / std;  x[b, 3:] = feat^T           ([B, 3+C, H*W])
+//                     In torch: a GEMM, five element-wise passes and a transposing cat forward, five passes backward -- eleven
+//                     launches of 4-8 us around 4800 pixels.  Here one launch each way; y is kept for the backward.
+//   adam              torch.optim.Adam's update (defaults, no weight decay / amsgrad) for a handful of numbers with a learning
+//                     rate per element: the refinement loop's (r, t) with (lr_r, lr_t) are two parameter groups = four launches.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct FusionInArgs {
+    int HW, C, has_affine;
+    const float* rgb;      // [B*HW, 3]
+    const float* feat;     // [B*HW, C]
+    const float* affine;   // [B, 12] (3x3 kernel row-major, 3 bias) or null
+    float mean[3], stdv[3];
+    float* x;              // [B, 3+C, HW]
+    float* y;              // [B*HW, 3] colours after the transform (saved for the backward)
+    const float* g_x;      // backward: [B, 3+C, HW]
+    float* g_rgb;          // [B*HW, 3]
+    float* g_feat;         // [B*HW, C]
+};
+
+__global__ __launch_bounds__(256) void fusion_input_fwd_kernel(FusionInArgs a) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.y, n0 = blockIdx.x * 64, t = threadIdx.x;
+    const int HW = a.HW, C = a.C;
+    const size_t pix0 = (size_t)b * HW + n0;
+    float* xb = a.x + (size_t)b * (3 + C) * HW;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = r * 4 + (t >> 6), col = t & 63;
+            tile[row][col] = (n0 + row < HW && c0 + col < C) ? a.feat[(pix0 + row) * C + c0 + col] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = r * 4 + (t >> 6), px = t & 63;
+            if (n0 + px < HW && c0 + ch < C) xb[(size_t)(3 + c0 + ch) * HW + n0 + px] = tile[px][ch];
+        }
+        __syncthreads();
+    }
+    if (t < 64 && n0 + t < HW) {
+        const float* p = a.rgb + (pix0 + t) * 3;
+        float v[3] = {p[0], p[1], p[2]};
+        if (a.has_affine) {
+            const float* k = a.affine + b * 12;
+            float o[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float lin = ((k[3 * c] * v[0] + k[3 * c + 1] * v[1]) + k[3 * c + 2] * v[2]) + k[9 + c];
+                o[c] = 1.f / (1.f + expf(-lin));
+            }
+            v[0] = o[0]; v[1] = o[1]; v[2] = o[2];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (a.y) a.y[(pix0 + t) * 3 + c] = v[c];
+            xb[(size_t)c * HW + n0 + t] = (v[c] - a.mean[c]) / a.stdv[c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fusion_input_bwd_kernel(FusionInArgs a) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.y, n0 = blockIdx.x * 64, t = threadIdx.x;
+    const int HW = a.HW, C = a.C;
+    const size_t pix0 = (size_t)b * HW + n0;
+    const float* gb = a.g_x + (size_t)b * (3 + C) * HW;
+    if (a.g_feat) {
+        for (int c0 = 0; c0 < C; c0 += 64) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = r * 4 + (t >> 6), px = t & 63;
+                tile[px][ch] = (n0 + px < HW && c0 + ch < C) ? gb[(size_t)(3 + c0 + ch) * HW + n0 + px] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r * 4 + (t >> 6), col = t & 63;
+                if (n0 + row < HW && c0 + col < C) a.g_feat[(pix0 + row) * C + c0 + col] = tile[row][col];
+            }
+            __syncthreads();
+        }
+    }
+    if (a.g_rgb && t < 64 && n0 + t < HW) {
+        float gy[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gy[c] = gb[(size_t)c * HW + n0 + t] / a.stdv[c];
+        float o[3] = {gy[0], gy[1], gy[2]};
+        if (a.has_affine) {
+            const float* k = a.affine + b * 12;
+            const float* y = a.y + (pix0 + t) * 3;
+            float gl[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gl[c] = gy[c] * ((1.f - y[c]) * y[c]);          // sigmoid_backward: g * (1 - y) * y
+#pragma unroll
+            for (int j = 0; j < 3; ++j) o[j] = (k[j] * gl[0] + k[3 + j] * gl[1]) + k[6 + j] * gl[2];
+        }
+        float* g = a.g_rgb + (pix0 + t) * 3;
+        g[0] = o[0]; g[1] = o[1]; g[2] = o[2];
+    }
+}
+
+// torch.optim.Adam, single-tensor formulas of torch/optim/adam.py as the CPU reference evaluates them: the bias corrections and
+// the step size are Python floats (float64) rounded to the tensor's dtype when they enter an operation:
+//   m.lerp_(g, 1 - b1);  v.mul_(b2).addcmul_(g, g, value=1 - b2);  denom = (v.sqrt() / sqrt(1 - b2^t)).add_(eps);
+//   p.addcdiv_(m, denom, value=-(lr / (1 - b1^t)))
+__global__ void adam_kernel(int n, float* p, const float* g, float* m, float* v, float* step, const double* lr, double b1, double b2,
+                            double eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float t = step[0] + 1.f;
+    if (i < n) {
+        const float gi = g[i];
+        const float mi = m[i] + (float)(1.0 - b1) * (gi - m[i]);                 // torch.lerp, weight < 0.5
+        const float vi = v[i] * (float)b2 + ((float)(1.0 - b2) * gi) * gi;
+        m[i] = mi; v[i] = vi;
+        const double c1 = 1.0 - pow(b1, (double)t), c2s = sqrt(1.0 - pow(b2, (double)t));
+        const float denom = sqrtf(vi) / (float)c2s + (float)eps;
+        p[i] = p[i] + (float)(-(lr[i] / c1)) * (mi / denom);
+    }
+    __syncthreads();
+    if (i == 0) step[0] = t;
+}
+
+}  // namespace
+
+extern "C" int nefes_fusion_input_fwd(int B, int HW, int C, const float* rgb, const float* feat, const float* affine, const float* mean3,
+                                      const float* std3, float* x, float* y, void* stream) {
+    if (B <= 0 || HW <= 0 || C < 0 || !rgb || !x || (C > 0 && !feat) || !mean3 || !std3 || (affine && !y)) return NEFES_E_BADARG;
+    FusionInArgs a = {};
+    a.HW = HW; a.C = C; a.has_affine = affine ? 1 : 0; a.rgb = rgb; a.feat = feat; a.affine = affine; a.x = x; a.y = y;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
+    hipLaunchKernelGGL(fusion_input_fwd_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_fusion_input_bwd(int B, int HW, int C, const float* g_x, const float* affine, const float* y, const float* std3,
+                                      float* g_rgb, float* g_feat, void* stream) {
+    if (B <= 0 || HW <= 0 || C < 0 || !g_x || !std3 || (affine && !y) || (!g_rgb && !g_feat)) return NEFES_E_BADARG;
+    FusionInArgs a = {};
+    a.HW = HW; a.C = C; a.has_affine = affine ? 1 : 0; a.affine = affine; a.y = const_cast<float*>(y); a.g_x = g_x; a.g_rgb = g_rgb;
+    a.g_feat = C > 0 ? g_feat : nullptr;
+    for (int c = 0; c < 3; ++c) a.stdv[c] = std3[c];
+    hipLaunchKernelGGL(fusion_input_bwd_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_adam_step(int n, float* p, const float* g, float* m, float* v, float* step, const double* lr, double beta1,
+                               double beta2, double eps, void* stream) {
+    if (n <= 0 || n > 1024 || !p || !g || !m || !v || !step || !lr) return NEFES_E_BADARG;
+    hipLaunchKernelGGL(adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, p, g, m, v, step, lr, beta1, beta2, eps);
+    return (int)hipGetLastError();
+}

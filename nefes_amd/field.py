@@ -75,6 +75,11 @@ class FusionNet(nn.Module):
         per image already -- so the batch then goes through the module itself, like a single image does."""
         mean, std = self._mean_std(rgb_nchw)
         x = torch.cat([(rgb_nchw - mean[:, None, None]) / std[:, None, None], feat_nchw], dim=1)
+        return self.forward_prepared(x, per_image_norm)
+
+    def forward_prepared(self, x, per_image_norm=False):
+        """forward_parts from the concatenated, colour-normalised input [B,3+C,H,W] on (ops.fusion_input builds it in one launch)."""
+        feat_nchw = x[:, 3:]
         convs = self._convs_hip if self._use_hip(x) else self.net[:7]
         if per_image_norm and not self.no_BN and x.shape[0] > 1 and self.net[-1].training:
             bn = self.net[-1]

@@ -702,8 +702,9 @@ class PoseCompose(torch.autograd.Function):
     launch each way: (r [n,3], t [n,3]) -> c2w [n,3,4] in NeRF coordinates.  `init_c2w` [n,4,4] on the device, no gradient."""
 
     @staticmethod
-    def forward(ctx, r, t, init_c2w, pose_scale, move, pose_scale2):
+    def forward(ctx, r, t, init_c2w, pose_scale, move, pose_scale2, grad_into=None):
         rf, tf, i0 = _f32(r).reshape(-1, 3), _f32(t).reshape(-1, 3), _f32(init_c2w).reshape(-1, 4, 4)
+        ctx.grad_into = grad_into             # (g_r, g_t) buffers the backward writes (the parameters' .grad: no copy afterwards)
         n = rf.shape[0]
         if tf.shape[0] != n or i0.shape[0] != n:
             raise ValueError("nefes_amd: pose_compose needs as many translations and initial poses as rotations")
@@ -720,16 +721,19 @@ class PoseCompose(torch.autograd.Function):
         rf, tf, i0 = ctx.saved_tensors
         sc, mv, sc2, r_shape, t_shape = ctx.consts
         gf = _f32(g)
-        g_r, g_t = torch.empty_like(rf), torch.empty_like(tf)
+        if ctx.grad_into is not None:
+            g_r, g_t = (b.reshape(rf.shape) for b in ctx.grad_into)
+        else:
+            g_r, g_t = torch.empty_like(rf), torch.empty_like(tf)
         L.check(L.load().nefes_pose_compose_bwd(rf.shape[0], _chk(rf, "r"), _chk(tf, "t"), _chk(i0, "init_c2w"), sc, mv, sc2,
                                                 _chk(gf, "g_c2w"), _chk(g_r, "g_r"), _chk(g_t, "g_t"), _stream()),
                 "nefes_pose_compose_bwd")
-        return g_r.reshape(r_shape), g_t.reshape(t_shape), None, None, None, None
+        return g_r.reshape(r_shape), g_t.reshape(t_shape), None, None, None, None, None
 
 
-def pose_compose(r, t, init_c2w, pose_scale=1.0, move=(0., 0., 0.), pose_scale2=1.0):
-    """[n,3,4] for n cameras; [3,4] when r is a single 3-vector."""
-    out = PoseCompose.apply(r, t, init_c2w, pose_scale, move, pose_scale2)
+def pose_compose(r, t, init_c2w, pose_scale=1.0, move=(0., 0., 0.), pose_scale2=1.0, grad_into=None):
+    """[n,3,4] for n cameras; [3,4] when r is a single 3-vector.  grad_into = (g_r, g_t): buffers the backward writes."""
+    out = PoseCompose.apply(r, t, init_c2w, pose_scale, move, pose_scale2, grad_into)
     return out[0] if r.dim() == 1 else out
 
 
@@ -770,3 +774,72 @@ def cosine_feature_loss(a, b, return_cos=False):
     per-channel similarities (float64, no gradient) -- per-image losses of a batch folded into the channel dimension."""
     loss, cos = CosineFeatureLoss.apply(a, b)
     return (loss, cos) if return_cos else loss
+
+
+class FusionInput(torch.autograd.Function):
+    """The rendered maps -> FusionNet's input in one launch (csrc/refine.hip fusion_input): affine colour transform with the image's
+    12 exposure coefficients (or none), colour normalisation, [N,3] / [N,C] -> [B,3+C,H,W].  Gradients to rgb and feat; the
+    coefficients are constants here (a trainable exposure network takes the torch path)."""
+
+    @staticmethod
+    def forward(ctx, rgb, feat, affine, B, H, W, mean, std):
+        rgb, feat = _f32(rgb).reshape(-1, 3), _f32(feat)
+        Cf = feat.shape[-1]
+        feat = feat.reshape(-1, Cf)
+        HW = int(H) * int(W)
+        x = torch.empty(B, 3 + Cf, int(H), int(W), device=rgb.device)
+        y = torch.empty_like(rgb) if affine is not None else None
+        m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+        L.check(L.load().nefes_fusion_input_fwd(B, HW, Cf, _chk(rgb, "rgb"), _chk(feat, "feat"), _chk(affine, "affine"), m3, s3,
+                                                _chk(x, "x"), _chk(y, "y"), _stream()), "nefes_fusion_input_fwd")
+        ctx.save_for_backward(affine, y)
+        ctx.cfg = (B, HW, Cf, s3)
+        return x
+
+    @staticmethod
+    def backward(ctx, g_x):
+        affine, y = ctx.saved_tensors
+        B, HW, Cf, s3 = ctx.cfg
+        g = _f32(g_x)
+        g_rgb = torch.empty(B * HW, 3, device=g.device) if ctx.needs_input_grad[0] else None
+        g_feat = torch.empty(B * HW, Cf, device=g.device) if ctx.needs_input_grad[1] else None
+        L.check(L.load().nefes_fusion_input_bwd(B, HW, Cf, _chk(g, "g_x"), _chk(affine, "affine"), _chk(y, "y"), s3, _chk(g_rgb, "g_rgb"),
+                                                _chk(g_feat, "g_feat"), _stream()), "nefes_fusion_input_bwd")
+        return g_rgb, g_feat, None, None, None, None, None, None
+
+
+def fusion_input(rgb, feat, affine, B, H, W, mean, std):
+    return FusionInput.apply(rgb, feat, affine, int(B), int(H), int(W), tuple(mean), tuple(std))
+
+
+class FusedAdam:
+    """torch.optim.Adam (defaults: no weight decay, no amsgrad) over a few small fp32 parameters with a learning rate per
+    parameter, as ONE launch per step (csrc/refine.hip adam_kernel): the parameters are views into one flat buffer, so are their
+    .grad tensors, and the state (m, v, step) lives on the device -- capturable in a HIP graph by construction."""
+
+    def __init__(self, params_and_lrs, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p, _ in params_and_lrs]
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, device=dev)
+        self.grad = torch.zeros(n, device=dev)
+        self.m, self.v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        self.step_t = torch.zeros(1, device=dev)
+        self.lr = torch.cat([torch.full((p.numel(),), float(lr), dtype=torch.float64) for p, lr in params_and_lrs]).to(dev)
+        self.betas, self.eps = betas, eps
+        off = 0
+        with torch.no_grad():
+            for p in self.params:                     # re-home each parameter (and its gradient) as a view of the flat buffers
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat[off:off + k].view(p.shape)
+                p.grad = self.grad[off:off + k].view(p.shape)
+                off += k
+
+    def zero_state(self):
+        self.m.zero_(); self.v.zero_(); self.step_t.zero_(); self.grad.zero_()
+
+    def step(self):
+        L.check(L.load().nefes_adam_step(self.flat.numel(), self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                         self.step_t.data_ptr(), self.lr.data_ptr(), float(self.betas[0]), float(self.betas[1]),
+                                         float(self.eps), _stream()), "nefes_adam_step")

@@ -124,15 +124,20 @@ class PoseRefiner:
             self.apr = copy.deepcopy(pose_model).to(self.dev).train()           # DFM_post_processing :209 (`pp_model`)
             self.photo = torch.zeros(1, 3, self.H, self.W, device=self.dev)
             self.apr_opt = torch.optim.Adam(self.apr.parameters(), lr=learning_rate)
-            self._rgb = None
+            self._rgb = self._x_rgb = None
         self.model = LearnPose(self.B, True, True, init_c2w=torch.eye(4)[None].repeat(self.B, 1, 1), lietorch=lietorch).to(self.dev)
         # fused_glue: the pose chain, the crop and the feature loss as library kernels (ops.pose_compose, the windowed
         # ops.bicubic_upsample, ops.cosine_feature_loss) and one fused Adam launch -- ~80 launches per iteration instead of ~215.
         # False keeps the torch expressions (the tests compare the two).
         self.fused_glue = bool(fused_glue)
-        self.opt = torch.optim.Adam([{"params": [self.model.r], "lr": lr_r}, {"params": [self.model.t], "lr": lr_t}],
-                                    capturable=bool(graph) if adam_capturable is None else bool(adam_capturable),
-                                    fused=True if self.fused_glue else None)
+        # fused glue: Adam over (r, t) with (lr_r, lr_t) as ONE launch (ops.FusedAdam: the two parameters and their gradients are
+        # views of flat buffers, the pose kernel's backward writes the gradients there); otherwise torch.optim.Adam, two groups
+        if self.fused_glue and not lietorch:
+            self.opt = ops.FusedAdam([(self.model.r, lr_r), (self.model.t, lr_t)])
+        else:
+            self.opt = torch.optim.Adam([{"params": [self.model.r], "lr": lr_r}, {"params": [self.model.t], "lr": lr_t}],
+                                        capturable=bool(graph) if adam_capturable is None else bool(adam_capturable),
+                                        fused=True if self.fused_glue else None)
         th, tw = (self.H - 20, self.W - 20) if upsample else (self.h, self.w)
         self.target = torch.zeros(self.C, th, tw, device=self.dev) if self.B == 1 else torch.zeros(self.B, self.C, th, tw, device=self.dev)
         self.hist = torch.zeros(self.B, 10, device=self.dev)
@@ -153,26 +158,37 @@ class PoseRefiner:
                 c2w = fix_coord_supp(c2w, self.world_setup)
         elif self.fused_glue and not self.model.lietorch:
             ws = self.world_setup or {"pose_scale": 1.0, "pose_scale2": 1.0, "move_all_cam_vec": (0., 0., 0.)}
+            into = (self.model.r.grad, self.model.t.grad) if isinstance(self.opt, ops.FusedAdam) else None
             c2w = ops.pose_compose(self.model.r, self.model.t, self.model.init_c2w, ws["pose_scale"], ws["move_all_cam_vec"],
-                                   ws["pose_scale2"])                                     # [B,3,4]
+                                   ws["pose_scale2"], grad_into=into)                     # [B,3,4]
         else:
             c2w = self.model(0)[None, :3, :4]
             if self.world_setup is not None:
                 c2w = fix_coord_supp(c2w, self.world_setup)
         if B == 1:
-            rgb, _, _, ex = render(self.h, self.w, self.focal, c2w=c2w[0], near=self.near, far=self.far, img_idx=self.hist, **self.kw)
+            # (a view, not c2w[0]: indexing costs a zero fill and a copy in the backward)
+            rgb, _, _, ex = render(self.h, self.w, self.focal, c2w=c2w.reshape(3, 4), near=self.near, far=self.far, img_idx=self.hist, **self.kw)
             feat = ex["feat_map"]
         else:
             rgb, _, _, ex = render_poses(self.h, self.w, self.focal, c2w, near=self.near, far=self.far, **self.kw)
             rgb, feat = rgb.reshape(-1, 3), ex["feat_map"].reshape(-1, self.C)
-        if getattr(self.args, "encode_hist", False):
-            if self._affine is not None:                   # frozen exposure network: its 12 numbers were computed once per image
-                rgb = self.coarse.apply_affine(self._affine, rgb, B)
-            else:
-                rgb = self.coarse.affine_color_transform(self.args, rgb, self.hist, B)
-        if self.apr is not None:
-            self._rgb = rgb.detach()                       # the verification step's image (:117-118)
-        _, _, fused = self.coarse.run_fusion_net(rgb, feat, self.h, self.w, B, per_image_norm=B > 1)
+        enc = bool(getattr(self.args, "encode_hist", False))
+        fnet = self.coarse.fusion_net
+        if self.fused_glue and (not enc or self._affine is not None) and fnet._use_hip(rgb):
+            # colour transform + normalisation + the NCHW concatenation as one launch each way (ops.fusion_input)
+            x = ops.fusion_input(rgb, feat, self._affine if enc else None, B, self.h, self.w, fnet.mean, fnet.std)
+            if self.apr is not None:
+                self._x_rgb = x.detach()[:, :3]            # the verification step's image, still normalised (:117-118)
+            fused = fnet.forward_prepared(x, per_image_norm=B > 1)
+        else:
+            if enc:
+                if self._affine is not None:               # frozen exposure network: its 12 numbers were computed once per image
+                    rgb = self.coarse.apply_affine(self._affine, rgb, B)
+                else:
+                    rgb = self.coarse.affine_color_transform(self.args, rgb, self.hist, B)
+            if self.apr is not None:
+                self._rgb, self._x_rgb = rgb.detach(), None
+            _, _, fused = self.coarse.run_fusion_net(rgb, feat, self.h, self.w, B, per_image_norm=B > 1)
         if self.upsample:
             if self.fused_glue:
                 fused = ops.bicubic_upsample(fused, (self.H, self.W), crop=10)
@@ -182,10 +198,12 @@ class PoseRefiner:
             # sum over images of (1 - mean_c cos) = B x (1 - mean over all B*C channels): one launch pair for the whole batch
             mean_loss, cos = ops.cosine_feature_loss(fused.reshape(B * self.C, -1), self.target.reshape(B * self.C, -1), return_cos=True)
             return mean_loss * float(B), (1.0 - cos.view(B, self.C).mean(1)).float()
+        # (a view where possible: fused[0] costs a 34 MB zero fill and a copy in the backward)
+        fused = fused.view(fused.shape[1:]) if fused.is_contiguous() else fused[0]
         if self.fused_glue and not self.per_pixel:
-            loss = ops.cosine_feature_loss(fused[0], self.target)
+            loss = ops.cosine_feature_loss(fused, self.target)
         else:
-            loss = feature_loss(fused[0], self.target, per_pixel=self.per_pixel)
+            loss = feature_loss(fused, self.target, per_pixel=self.per_pixel)
         return loss, loss.detach()
 
     def loss_and_grad(self):
@@ -196,7 +214,8 @@ class PoseRefiner:
         for p, g in ((self.model.r, gr), (self.model.t, gt)):
             if p.grad is None:
                 p.grad = torch.empty_like(p)
-            p.grad.copy_(g)
+            if g.data_ptr() != p.grad.data_ptr():          # (the fused pose kernel writes the parameters' .grad itself)
+                p.grad.copy_(g)
         self.loss.copy_(per_image)
         return self.loss
 
@@ -219,13 +238,16 @@ class PoseRefiner:
                     self._affine = a.clone()
                 else:
                     self._affine.copy_(a)                  # in place: a captured graph keeps reading the same buffer
-            for st in self.opt.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
-            for p in (self.model.r, self.model.t):
-                if p.grad is not None:
-                    p.grad.zero_()
+            if isinstance(self.opt, ops.FusedAdam):
+                self.opt.zero_state()
+            else:
+                for st in self.opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+                for p in (self.model.r, self.model.t):
+                    if p.grad is not None:
+                        p.grad.zero_()
 
     def _capture(self):
         """Warm up on a side stream (allocator, MIOpen plans, Adam state), then capture one iteration."""
@@ -275,7 +297,12 @@ class PoseRefiner:
 
     def _verification(self):
         """PSNR and mean SSIM of the up-sampled, cropped render against the cropped query image (:117-128, :146-150)."""
-        img = self._rgb.reshape(1, self.h, self.w, 3).permute(0, 3, 1, 2)
+        if self._x_rgb is not None:                        # de-normalise FusionNet's colour channels
+            fnet = self.coarse.fusion_net
+            mean, std = fnet._mean_std(self._x_rgb)
+            img = self._x_rgb * std[:, None, None] + mean[:, None, None]
+        else:
+            img = self._rgb.reshape(1, self.h, self.w, 3).permute(0, 3, 1, 2)
         img = nn.functional.interpolate(img, size=(self.H, self.W), mode="bicubic")[:, :, 10:-10, 10:-10]
         gt = self.photo[:, :, 10:-10, 10:-10]
         return float(mse2psnr(img2mse(img, gt))), float(ssim_map(img, gt).mean())
