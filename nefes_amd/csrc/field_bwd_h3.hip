@@ -8,6 +8,15 @@
 #define NEFES_SLAB_KIB 16      // the Wd = 128 instances (layout.h NEFES_H3_BWD_SLAB_KIB_128)
 #else
 #define NEFES_SLAB_KIB 32
+// H3B_WIDE_EXPERIMENT (round 3, not shipped: DESIGN.md section 4.1b "the backward on the gap schedule"): the Wd = 256 objects with
+// their 8-/10-tile runs on field_h3.h's gap-by-gap schedule -- 2 x NTW hidden tiles in the 256 AGPRs, the three embedding tiles in
+// VGPRs.  Fits without spills (228 VGPRs) and runs ~1.2 % faster, but with the accumulator file fully subscribed hipcc relocates
+// whole tiles with v_accvgpr_mov in the middle of the asm runs (it cannot know an issued asm MFMA has not written them yet): wrong
+// gradients.  Build with -DH3B_WIDE_EXPERIMENT -UNEFES_H3_WIDE_MIN to reproduce; tools/ab_bwd.py compares two builds.
+#ifdef H3B_WIDE_EXPERIMENT
+#define H3_ACC_READ_ASM        // source tiles are read out of their AGPRs inside the MFMA gaps (field_h3.h acc_read)
+#define H3_WIDE_ENTRY_FENCE    // wide runs follow compiler-scheduled segments here (field_h3.h mma_run_h3_wide)
+#endif
 #endif
 #define NEFES_B_BATCH 2
 #define NEFES_B_BATCH_NT8 4
@@ -15,6 +24,9 @@
 #include "field_x6.h"
 #include "field_h3.h"
 #include "../../include/nefes_hip.h"
+#ifndef H3B_WIDE_LAYERS
+#define H3B_WIDE_LAYERS 0x1ff   /* bit L: layer L's transposed product on the gap-by-gap schedule; bit 0: xyz_encoding_final's (debugging) */
+#endif
 #define NEFES_H3B_SLOTS 2   // 64 KiB ring (StagedRing: two slots) + the tile's ReLU masks and the scale table
 
 struct FieldBwdH3Args {
@@ -261,7 +273,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
         }
         }
         // Full-width accumulators, ping-pong.  Tiles [2, NTW+2) hold a layer's d hidden; XA tile 1 = d dir-embedding;
-        // XB tiles 0,1 = d xyz-embedding (written by layer 5, accumulated by layer 1).
+        // XB tiles 0,1 = d xyz-embedding (written by layer 5, accumulated by layer 1).  In the Wd = 256 objects the 2 x NTW hidden
+        // tiles fill the 256 AGPRs (asm MFMAs, gap-by-gap schedule of field_h3.h) and the three embedding tiles live in VGPRs.
         f32x16 XA[NTW + 2], XB[NTW + 2];
         // ---- [transient_encoding.0 ; dir_encoding]^T -> d dir-embedding (tile 1) + d final (tiles 2..): both products
         //      accumulate into the same tiles, so both operands are brought to one common exponent ----
@@ -279,13 +292,19 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
             mma_run_h3<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{G2, bh, pow2i(tau), mg}, gptr(NEFES_TB_DIR), 1.f), ZeroInit{}, XA);
             M = (HAS_T ? rowb(NEFES_H3B_T0) * (pair_max(mt) * pow2i(-es3)) : 0.f) + rowb(NEFES_H3B_DIR) * pair_max(mg);
         }
+#ifdef H3B_WIDE_EXPERIMENT
+        // From here on the 2 x NTW hidden tiles own the 256 AGPRs (asm MFMAs with "+a" operands): the d dir-embedding tile must
+        // not sit there too.  Left in an AGPR it over-subscribes the file and hipcc shuffles whole tiles with v_accvgpr_mov in the
+        // middle of the asm runs -- copying registers an issued MFMA has not written yet (seen in the disassembly; wrong gradients).
+        asm volatile("" : "+v"(XA[1]));
+#endif
         // ---- xyz_encoding_final^T (no ReLU on its output) + static_sigma^T (one extra fp32 k-step) -> d h8 ----
         int es_b;
         {
             const int ew = wexp(NEFES_H3B_FINAL), tau = tau_of(M, ew);
             float mx = 0.f;
             es_b = tau + ew;
-            mma_run_h3<NTW, W / 16, 2, true>(ring, ring_lane, wrap_store_h3<TRAIN>(IdentSplitH<NTW + 2, 2>{XA, pow2i(tau - es_dt), mx}, gptr(NEFES_TB_FINAL), pow2i(-es_dt)), ZeroInit{}, XB);
+            mma_run_h3<NTW, W / 16, 2, true, 2, (H3B_WIDE_LAYERS & 1) != 0>(ring, ring_lane, wrap_store_h3<TRAIN>(IdentSplitH<NTW + 2, 2>{XA, pow2i(tau - es_dt), mx}, gptr(NEFES_TB_FINAL), pow2i(-es_dt)), ZeroInit{}, XB);
             const float dsig = STASH(6);
             float dsg[1];
             dsg[0] = dsig * pow2i(es_b);
@@ -301,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
             const int ew = wexp(NEFES_H3B_L8 + 8 - (L)), tau = tau_of(M, ew);                                       \
             float mx = 0.f;                                                                                         \
             ES_DST = tau + ew;                                                                                      \
-            mma_run_h3<NTILES, W / 16, T0, true>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTW + 2, WT, 2>{SRC, bt, pow2i(tau - ES_SRC), mx}, gptr(NEFES_TB_L1 + (L) - 1), pow2i(-(ES_SRC))), ZeroInit{}, DST); \
+            mma_run_h3<NTILES, W / 16, T0, true, 2, ((H3B_WIDE_LAYERS >> (L)) & 1) != 0>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTW + 2, WT, 2>{SRC, bt, pow2i(tau - ES_SRC), mx}, gptr(NEFES_TB_L1 + (L) - 1), pow2i(-(ES_SRC))), ZeroInit{}, DST); \
             M = rowb(NEFES_H3B_L8 + 8 - (L)) * (pair_max(mx) * pow2i(-(ES_SRC)));                                   \
         }
         NEFES_BWD_LAYER(8, XB, XA, es_b, es_a, NTW, 2)

@@ -26,6 +26,9 @@
 #ifndef NEFES_H3_WIDE_MIN
 #define NEFES_H3_WIDE_MIN 8   /* segments with at least this many tiles take the gap-by-gap schedule (mma_run_h3_wide) */
 #endif
+#ifndef NEFES_H3_WIDE_MAX
+#define NEFES_H3_WIDE_MAX 64
+#endif
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -162,7 +165,7 @@ struct PairRegs {
 // hosts the pair.  Left to itself hipcc moves the whole source set (128 registers) to VGPRs in one block at every layer boundary,
 // where the wave's matrix pipe idles: ~280 instructions between two runs, 7 % of the forward (seen in the disassembly).
 __device__ __forceinline__ float acc_read(const float& x) {
-#ifdef H3_ACC_READ_ASM
+#if defined(H3_ACC_READ_ASM) && !defined(H3_DBG_PLAINREAD)
     float v;
     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(x));
     return v;
@@ -206,8 +209,8 @@ struct MaskedSplitH {
     float r;
     float& m;
     __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
-        s.x0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
-        s.x1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
+        s.x0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]));
+        s.x1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]));
     }
     __device__ __forceinline__ void stage_b(PairRegs& s) const {
 #ifndef H3_ABL_NOMAX3
@@ -401,6 +404,15 @@ __device__ __forceinline__ void mfma_h3_asm(f32x16& c, const f32x4& a, const u32
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 #endif
 }
+// The same MFMA on a tile that lives in VGPRs: the backward's wide runs keep 16 tiles (source + destination set) in the 256 AGPRs
+// and the few extra output tiles of a run (the d embedding tiles riding on layer 5) in vector registers.
+__device__ __forceinline__ void mfma_h3_asm_v(f32x16& c, const f32x4& a, const u32x4& b) {
+#ifdef H3_BUILTIN_MFMA
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(a), as_f16x8(b), c, 0, 0, 0);
+#else
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#endif
+}
 #ifdef H3_STAMP   // diagnostic build (tools/stamp_h3.sh): cycles inside the wide runs / inside ring acquires, per wave
 __device__ unsigned long long h3_stamp_run = 0, h3_stamp_acq = 0, h3_stamp_n = 0, h3_stamp_total = 0;
 static __device__ __forceinline__ unsigned long long h3_now() {
@@ -409,10 +421,12 @@ static __device__ __forceinline__ unsigned long long h3_now() {
     return t;
 }
 #endif
-template <int NT, int KS16, int T0, bool FIRST = true, class SrcFn, class InitFn, int NACC, class Ring>
+// VT: tiles acc[0 .. VT) live in VGPRs ("+v" MFMAs), the rest in AGPRs.
+template <int NT, int KS16, int T0, bool FIRST = true, int VT = 0, class SrcFn, class InitFn, int NACC, class Ring>
 __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lane, const SrcFn& src, const InitFn& init,
                                                 f32x16 (&acc)[NACC]) {
     static_assert(T0 + NT <= NACC, "accumulator array too small");
+    static_assert(T0 + NT - 2 >= VT, "the run's last two tiles must be AGPR tiles (end-of-run wait states)");
     static_assert(NT >= 8 && NT % 2 == 0, "the gap schedule below pairs tiles: an even tile hosts a pair, the odd one a ring piece");
 #ifdef H3_STAMP
     const unsigned long long stamp0 = h3_now();
@@ -427,6 +441,19 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
     // everything is selected at compile time (the loops are fully unrolled).
     Split2 B0, B1;
     auto BQ = [&](int k) -> Split2& { return (k & 1) ? B1 : B0; };
+#ifdef H3_WIDE_ENTRY_FENCE
+    // The run's first operand is read out of the source tiles' AGPRs by asm statements, which hipcc schedules freely among its OWN
+    // MFMAs: when the previous segment ran on compiler-placed MFMAs (narrow runs, the fp32 sigma step) it hoisted these reads to
+    // right behind the MFMA that writes the register -- inside that MFMA's 16 passes, where the read returns the old value (seen in
+    // the disassembly of the backward; wrong gradients).  Nothing crosses this point, and the youngest result is 18 wait states old.
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef H3_DBG_BIGFENCE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#else
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1" ::: "memory");
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // H3_ABL_* macros: timing ablations only (tools/ablate_h3.sh, tools/stamp_h3.sh build side libraries with them; results are garbage)
     {
         PairRegs s0;
@@ -466,17 +493,22 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
             if (uu < nu) {
                 const int u = sl * UPS + uu, q = u / NT, t = u % NT;
                 const bool make = q + 1 < KS16;            // this step produces the next step's operand
-                const bool host = make && (t % 2 == 0);    // pair t/2: stages A, B, C1 here, C2 in the next (odd) unit
-                const bool tail = make && (t % 2 == 1);
                 const int pp = t / 2;
+                const bool host = make && (t % 2 == 0) && pp < 4;    // pair t/2: stages A, B, C1 here, C2 in the next (odd) unit
+                const bool tail = make && (t % 2 == 1) && pp < 4;    // (a k-step has four pairs; a ten-tile run's last two tiles host none)
                 const char* pn = p + (2 * uu + 4) * 1024;  // unit u + 2's hi group (lo: + 1 KiB)
                 Split2& B = BQ(q);
                 Split2& Bn = BQ(q + 1);
                 f32x4 &h0 = HA(u), &l0 = LA(u), &h2 = HA(u + 2), &l2 = LA(u + 2);
                 __builtin_amdgcn_sched_barrier(0);
                 // the tile's C operand was written by the vector ALU (bias tile): materialise it in its AGPRs HERE, then two wait states
-                if (FIRST && q == 0) asm volatile("s_nop 1" : "+a"(acc[T0 + t]));
-                mfma_h3_asm(acc[T0 + t], l0, B.h);                                                  // M1 (small terms first)
+                const bool vt = T0 + t < VT;               // (folds: the loops are fully unrolled)
+                if (FIRST && q == 0) {
+                    if (vt) asm volatile("s_nop 1" : "+v"(acc[T0 + t]));
+                    else asm volatile("s_nop 1" : "+a"(acc[T0 + t]));
+                }
+                if (vt) mfma_h3_asm_v(acc[T0 + t], l0, B.h);
+                else mfma_h3_asm(acc[T0 + t], l0, B.h);                                             // M1 (small terms first)
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- gap 1 ----
 #ifndef H3_ABL_NOSPLIT
@@ -491,7 +523,8 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
                 // empty uses the registers are handed to the gap's instructions and overwritten under the MFMA (seen in the
                 // disassembly as conversions writing the previous MFMA's operand registers; the results were garbage).
                 asm volatile("" ::"v"(l0), "v"(B.h));
-                mfma_h3_asm(acc[T0 + t], h0, B.l);                                                  // M2
+                if (vt) mfma_h3_asm_v(acc[T0 + t], h0, B.l);
+                else mfma_h3_asm(acc[T0 + t], h0, B.l);                                             // M2
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- gap 2 ----
 #ifndef H3_ABL_NOSPLIT
@@ -514,7 +547,8 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("" ::"v"(B.l));
-                mfma_h3_asm(acc[T0 + t], h0, B.h);                                                  // M3
+                if (vt) mfma_h3_asm_v(acc[T0 + t], h0, B.h);
+                else mfma_h3_asm(acc[T0 + t], h0, B.h);                                             // M3
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- gap 3 ----
 #ifndef H3_ABL_NOSPLIT
@@ -558,7 +592,12 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
     // The layer's functor reads the tiles with the vector ALU: 18 wait states between an MFMA and such a read of its result are the
     // program's to provide (the compiler pads them for its own MFMAs only).  Tying the two youngest tiles to the statement keeps their
     // reads behind it; the older tiles' last MFMAs are at least six MFMAs back.
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1" : "+a"(acc[T0 + NT - 1]), "+a"(acc[T0 + NT - 2]));
+    // The same statement holds the LAST MFMA's A and B operand registers: an issued asm MFMA is still reading them, and once the
+    // unit's empty use is behind it hipcc hands them out again -- the very next instruction overwrote the B operand (seen in the
+    // disassembly of the backward: v_mfma ... v[14:17] followed by v_mov_b32 v14; the last tile's last k-step came out wrong).
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1"
+                 : "+a"(acc[T0 + NT - 1]), "+a"(acc[T0 + NT - 2])
+                 : "v"(HA(NU - 1)), "v"(BQ(KS16 - 1).h), "v"(BQ(KS16 - 1).l));
 #endif
 #ifdef H3_STAMP
     if (threadIdx.x == 0) {      // wave 0 of every workgroup
@@ -679,9 +718,9 @@ __device__ __forceinline__ void mma_run_h3_small(Ring& ring, const char* ring_la
     ring.pf = ah;
 }
 
-template <int NT, int KS16, int T0, bool FIRST = true, class SrcFn, class InitFn, int NACC, class Ring>
+template <int NT, int KS16, int T0, bool FIRST = true, int VT = 0, bool ALLOW_WIDE = true, class SrcFn, class InitFn, int NACC, class Ring>
 __device__ __forceinline__ void mma_run_h3(Ring& ring, const char* ring_lane, const SrcFn& src, const InitFn& init,
                                            f32x16 (&acc)[NACC]) {
-    if constexpr (NT >= NEFES_H3_WIDE_MIN) mma_run_h3_wide<NT, KS16, T0, FIRST>(ring, ring_lane, src, init, acc);
+    if constexpr (ALLOW_WIDE && NT >= NEFES_H3_WIDE_MIN && NT % 2 == 0 && NT <= NEFES_H3_WIDE_MAX) mma_run_h3_wide<NT, KS16, T0, FIRST, VT>(ring, ring_lane, src, init, acc);
     else mma_run_h3_small<NT, KS16, T0, FIRST>(ring, ring_lane, src, init, acc);
 }
