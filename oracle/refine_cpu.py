@@ -212,11 +212,13 @@ class Problem:
         self.cfg, self.near, self.far, self.world, self.dtype = cfg, near, far, world, dtype
         self.upsample = upsample
 
-    def loss_at_pose(self, pose: Tensor, want_rgb: bool = False):
-        """From the 3x4 pose in APR/COLMAP coordinates on: DFM_optimization_NFF (:311-337) / train_on_batch (:97-131)."""
+    def loss_at_pose(self, pose: Tensor, want_rgb: bool = False, **pin):
+        """From the 3x4 pose in APR/COLMAP coordinates on: DFM_optimization_NFF (:311-337) / train_on_batch (:97-131).
+        `pin` (tests only): fine_act / z_fine / coarse_act of ref_cpu.render -- the oracle on a GIVEN ReLU branch pattern and
+        GIVEN sample depths (those a HIP forward pass took: tests/branch.py)."""
         pose = fix_coord_supp(pose, self.world["pose_scale"], self.world["move_all_cam_vec"], self.world["pose_scale2"])
         rgb, _, _, extras = O.render(self.h, self.w, self.f, self.p_coarse, self.p_fine, self.cfg, c2w=pose, near=self.near,
-                                     far=self.far, hist=self.hist)
+                                     far=self.far, hist=self.hist, **pin)
         rgb = affine_color_transform(self.exposure_params, rgb, self.hist, 1)
         fused = fusion_net(self.fusion_sd, rgb, extras["feat_map"], self.h, self.w, 1)
         target = self.target
@@ -229,15 +231,15 @@ class Problem:
             return loss, F.interpolate(img, size=self.upsample, mode="bicubic")[:, :, 10:-10, 10:-10]
         return loss
 
-    def loss(self, r: Tensor, t: Tensor) -> Tensor:
+    def loss(self, r: Tensor, t: Tensor, **pin) -> Tensor:
         """DFM_optimization_NFF (:310-337)."""
-        return self.loss_at_pose(learn_pose(r, t, self.init_c2w))
+        return self.loss_at_pose(learn_pose(r, t, self.init_c2w), **pin)
 
-    def loss_and_grad(self, r, t):
+    def loss_and_grad(self, r, t, **pin):
         """(loss, d loss / d [r, t] as one 6-vector) at the given pose parameters."""
         r = torch.as_tensor(r, dtype=self.dtype).clone().requires_grad_()
         t = torch.as_tensor(t, dtype=self.dtype).clone().requires_grad_()
-        loss = self.loss(r, t)
+        loss = self.loss(r, t, **pin)
         gr, gt = torch.autograd.grad(loss, [r, t])
         return loss.detach(), torch.cat([gr, gt])
 
