@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEFES_ABI_VERSION 11
+#define NEFES_ABI_VERSION 13
 
 #define NEFES_E_BADARG (-1)     /* null pointer / non-positive size */
 #define NEFES_E_UNSUPPORTED (-2) /* width / feat_dim / sample count outside the compiled set */
@@ -308,6 +308,21 @@ int nefes_cosine_loss_fwd(int C, int64_t P, const float* a, const float* b, doub
 /* g_a [C,P] = g_loss[0] * d loss / d a (g_loss: dev scalar). */
 int nefes_cosine_loss_bwd(int C, int64_t P, const float* a, const float* b, const double* scratch, const float* g_loss, float* g_a,
                           void* stream);
+
+/* feature_loss ON the bicubically up-sampled, cropped feature image without materialising it (DFM_APR_refine.py:114,125-131):
+ * x [C,h,w] is up-sampled to (OH, OW) as nefes_bicubic_up_fwd does, `crop` pixels are dropped on every side, and the loss is
+ * nefes_cosine_loss_fwd against target [C, OH-2crop, OW-2crop] -- each up-sampled value interpolated where it is consumed.
+ * scratch: nefes_cosine_loss_scratch_doubles(C) doubles, kept for the backward; tmp: [C, OH-2crop, w] floats. */
+int nefes_upcos_loss_fwd(int C, int h, int w, int OH, int OW, int crop, const float* x, const float* target, double* scratch, float* loss,
+                         void* stream);
+/* tx_* / ty_*: gather tables of the x and y axes (nefes_bicubic_gather_table with (w, OW, crop, OW-2crop) and (h, OH, crop, OH-2crop)). */
+int nefes_upcos_loss_bwd(int C, int h, int w, int OH, int OW, int crop, const float* x, const float* target, const double* scratch,
+                         const float* g_loss, const int* tx_first, const int* tx_count, const float* tx_wt, const int* ty_first,
+                         const int* ty_count, const float* ty_wt, int T, float* tmp, float* g_x, void* stream);
+/* Which up-sampled positions of the window [o0, o0 + n_win) of an axis (n_in -> n_out, bicubic) reach source index y, and with what
+ * weight: first[y] (relative to o0), count[y], wt[y * T .. + count[y]) -- the transpose of the interpolation, a function of the sizes
+ * only; T >= 4 n_out / n_in + 8. */
+int nefes_bicubic_gather_table(int n_in, int n_out, int o0, int n_win, int T, int* first, int* count, float* wt, void* stream);
 
 /* ---- FusionNet's input from the rendered maps, one launch each way (script/models/nerfh_nff.py:605-626 affine_color_transform
  *      with the image's 12 exposure coefficients given, :578-603 run_fusion_net's reshape / permute / cat, :395-402 the colour

@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "../../include/nefes_hip.h"
+#include "bicubic.h"
 
 namespace {
 
@@ -180,7 +181,167 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(int C, long P, double e
     g_a[idx] = (float)(k * v);
 }
 
+// ---- feature loss ON the up-sampled image, without the up-sampled image (DFM_APR_refine.py:114-131): the loop up-samples the
+// fused [C,h,w] features bicubically to (H, W), crops 10 px and takes the cosine loss against the query image's features.  As
+// separate kernels that is 34 MB written and read again each way (up-sampled features; their gradient) around 2.4 MB of data.
+// Here every up-sampled value is interpolated where it is consumed -- same expression, same order as bicubic_up_fwd_kernel -- from
+// the channel's low-resolution plane (forward: staged in LDS) or its four source rows (backward), and the target is the only
+// large tensor that moves.
+struct UpCosArgs {
+    int C, h, w, OH, OW, o0, CH, CW;
+    float sy, sx;
+    const float* x;        // [C, h, w]
+    const float* target;   // [C, CH, CW]
+};
+
+__device__ __forceinline__ float up_value(const float* plane, int w, int h, const nefes_bicubic::Taps& ty, const nefes_bicubic::Taps& tx) {
+    using namespace nefes_bicubic;
+    int xs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xs[j] = clampi(tx.base - 1 + j, w);
+    float rows[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float* r = plane + (long)clampi(ty.base - 1 + i, h) * w;
+        rows[i] = r[xs[0]] * tx.w[0] + r[xs[1]] * tx.w[1] + r[xs[2]] * tx.w[2] + r[xs[3]] * tx.w[3];
+    }
+    return rows[0] * ty.w[0] + rows[1] * ty.w[1] + rows[2] * ty.w[2] + rows[3] * ty.w[3];
+}
+
+__global__ __launch_bounds__(256) void upcos_partial_kernel(UpCosArgs a, double* __restrict__ part) {      // part [C][kParts][3]
+    using namespace nefes_bicubic;
+    extern __shared__ float plane[];
+    const int c = blockIdx.x / kParts, q = blockIdx.x % kParts;
+    const float* src = a.x + (long)c * a.h * a.w;
+    for (int i = threadIdx.x; i < a.h * a.w; i += 256) plane[i] = src[i];
+    __syncthreads();
+    // part q = a band of up-sampled rows; a thread owns columns (its x taps and clamped source columns are computed once)
+    const int per = (a.CH + kParts - 1) / kParts, r_lo = q * per, r_hi = r_lo + per < a.CH ? r_lo + per : a.CH;
+    double dab = 0, daa = 0, dbb = 0;
+    for (int j = threadIdx.x; j < a.CW; j += 256) {
+        const Taps tx = taps_of(a.sx, j + a.o0);
+        int xs[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xs[m] = clampi(tx.base - 1 + m, a.w);
+        const float* pb = a.target + (long)c * a.CH * a.CW + j;
+        for (int r = r_lo; r < r_hi; ++r) {
+            const Taps ty = taps_of(a.sy, r + a.o0);
+            float rows[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* rr = plane + clampi(ty.base - 1 + i, a.h) * a.w;
+                rows[i] = rr[xs[0]] * tx.w[0] + rr[xs[1]] * tx.w[1] + rr[xs[2]] * tx.w[2] + rr[xs[3]] * tx.w[3];
+            }
+            const double xv = rows[0] * ty.w[0] + rows[1] * ty.w[1] + rows[2] * ty.w[2] + rows[3] * ty.w[3];
+            const double yv = pb[(long)r * a.CW];
+            dab += xv * yv;
+            daa += xv * xv;
+            dbb += yv * yv;
+        }
+    }
+    __shared__ double sh[3][256];
+    sh[0][threadIdx.x] = dab; sh[1][threadIdx.x] = daa; sh[2][threadIdx.x] = dbb;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+            sh[2][threadIdx.x] += sh[2][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double* o = part + ((long)c * kParts + q) * 3;
+        o[0] = sh[0][0]; o[1] = sh[1][0]; o[2] = sh[2][0];
+    }
+}
+
+// One workgroup per (channel, up-sampled row of the window): the row's gradient d loss / d up[c][oy][:] is formed in LDS from the
+// interpolated values and the target row, and gathered along x onto the w source columns: tmp[c][oy - o0][0..w).  The gather
+// along y (bicubic_gather_kernel of upsample.hip, inner = w) finishes the job.
+__global__ __launch_bounds__(128) void upcos_bwd_rows_kernel(UpCosArgs a, double eps, const double* __restrict__ stats,
+                                                             const float* __restrict__ g_loss, nefes_bicubic::GatherTable gx,
+                                                             float* __restrict__ tmp) {
+    using namespace nefes_bicubic;
+    extern __shared__ float lds[];
+    float* rows = lds;                 // [4][w] the four source rows of this up-sampled row
+    float* gs = lds + 4 * a.w;         // [CW]
+    const int c = blockIdx.x / a.CH, r = blockIdx.x % a.CH, oy = r + a.o0;
+    const Taps ty = taps_of(a.sy, oy);
+    const float* src = a.x + (long)c * a.h * a.w;
+    for (int i = threadIdx.x; i < 4 * a.w; i += 128) rows[i] = src[(long)clampi(ty.base - 1 + i / a.w, a.h) * a.w + i % a.w];
+    __syncthreads();
+    const double dab = stats[c * 4 + 0], na = stats[c * 4 + 1], nb = stats[c * 4 + 2];
+    const double nbc = nb > eps ? nb : eps;
+    const double k = -(double)g_loss[0] / a.C;
+    // d cos / d a = b / (|a||b|) - (a.b) a / (|a|^3 |b|)  (a clamped norm is a constant): two factors per channel, not per pixel
+    const double k1 = na > eps ? k / (na * nbc) : k / (eps * nbc), k2 = na > eps ? k * dab / (na * na * na * nbc) : 0.0;
+    const float* pb = a.target + ((long)c * a.CH + r) * a.CW;
+    for (int j = threadIdx.x; j < a.CW; j += 128) {
+        const Taps tx = taps_of(a.sx, j + a.o0);
+        int xs[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xs[m] = clampi(tx.base - 1 + m, a.w);
+        float rv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* rr = rows + i * a.w;
+            rv[i] = rr[xs[0]] * tx.w[0] + rr[xs[1]] * tx.w[1] + rr[xs[2]] * tx.w[2] + rr[xs[3]] * tx.w[3];
+        }
+        const double av = rv[0] * ty.w[0] + rv[1] * ty.w[1] + rv[2] * ty.w[2] + rv[3] * ty.w[3];
+        gs[j] = (float)(k1 * (double)pb[j] - k2 * av);
+    }
+    __syncthreads();
+    float* out = tmp + ((long)c * a.CH + r) * a.w;
+    for (int xi = threadIdx.x; xi < a.w; xi += 128) out[xi] = gather_axis_table(gx, xi, gs, 1);
+}
+
+__global__ __launch_bounds__(256) void upcos_gather_rows_kernel(long outer, int n_in, int n_win, long inner, nefes_bicubic::GatherTable gy,
+                                                                const float* __restrict__ src, float* __restrict__ dst) {
+    using namespace nefes_bicubic;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= outer * n_in * inner) return;
+    const long q = idx % inner;
+    const int y = (int)((idx / inner) % n_in);
+    const long p = idx / (inner * n_in);
+    dst[idx] = gather_axis_table(gy, y, src + p * n_win * inner + q, inner);
+}
+
 }  // namespace
+
+extern "C" int nefes_upcos_loss_fwd(int C, int h, int w, int OH, int OW, int crop, const float* x, const float* target, double* scratch,
+                                    float* loss, void* stream) {
+    const int CH = OH - 2 * crop, CW = OW - 2 * crop;
+    if (C <= 0 || h <= 0 || w <= 0 || crop < 0 || CH <= 0 || CW <= 0 || !x || !target || !scratch || !loss) return NEFES_E_BADARG;
+    if ((size_t)h * w * 4 > 96 * 1024) return NEFES_E_UNSUPPORTED;           // the channel's plane is staged in LDS
+    UpCosArgs a{C, h, w, OH, OW, crop, CH, CW, (float)h / OH, (float)w / OW, x, target};
+    double* part = scratch + (size_t)C * 4;
+    const size_t lds = (size_t)h * w * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)upcos_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(upcos_partial_kernel, dim3(C * kParts), dim3(256), lds, (hipStream_t)stream, a, part);
+    hipLaunchKernelGGL(cosine_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, C, 1e-6, (const double*)part, scratch, loss);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_upcos_loss_bwd(int C, int h, int w, int OH, int OW, int crop, const float* x, const float* target, const double* scratch,
+                                    const float* g_loss, const int* tx_first, const int* tx_count, const float* tx_wt, const int* ty_first,
+                                    const int* ty_count, const float* ty_wt, int T, float* tmp, float* g_x, void* stream) {
+    const int CH = OH - 2 * crop, CW = OW - 2 * crop;
+    if (C <= 0 || h <= 0 || w <= 0 || crop < 0 || CH <= 0 || CW <= 0 || !x || !target || !scratch || !g_loss || !tmp || !g_x) return NEFES_E_BADARG;
+    if (!tx_first || !tx_count || !tx_wt || !ty_first || !ty_count || !ty_wt || T <= 0) return NEFES_E_BADARG;
+    const nefes_bicubic::GatherTable gx{tx_first, tx_count, tx_wt, T}, gy{ty_first, ty_count, ty_wt, T};
+    UpCosArgs a{C, h, w, OH, OW, crop, CH, CW, (float)h / OH, (float)w / OW, x, target};
+    const size_t lds = (size_t)(4 * w + CW) * 4;
+    if (lds > 96 * 1024) return NEFES_E_UNSUPPORTED;
+    hipError_t e = hipFuncSetAttribute((const void*)upcos_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(upcos_bwd_rows_kernel, dim3((unsigned)((long)C * CH)), dim3(128), lds, (hipStream_t)stream, a, 1e-6, scratch, g_loss, gx, tmp);
+    const long n = (long)C * h * w;                    // g_x[c][y][x] = sum over the window's rows oy of Wy(oy -> y) tmp[c][oy - o0][x]
+    hipLaunchKernelGGL(upcos_gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)C, h, CH, (long)w, gy,
+                       (const float*)tmp, g_x);
+    return (int)hipGetLastError();
+}
 
 extern "C" int nefes_pose_compose_fwd(int n_poses, const float* r, const float* t, const float* init_c2w, float pose_scale,
                                       const float* move, float pose_scale2, float* c2w, void* stream) {

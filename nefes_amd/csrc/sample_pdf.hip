@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(int N, int Nc, in
     __shared__ float s_cdf[4][SP_MAX_NC];
     __shared__ float s_bins[4][SP_MAX_NC];
     __shared__ float s_all[4][SP_MAX_S];
+    __shared__ float s_sorted[4][SP_MAX_S];    // the merged depths by rank, so that z_fine leaves as whole rows (a scattered 4-byte store per sample before)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wv;
     if (ray >= N) return;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(int N, int Nc, in
         for (int k0 = 0; k0 < np; k0 += 64) {
             const int k = k0 + lane;
             const double pdf = k < np ? (double)__fdiv_rn(__fadd_rn(w[k + 1], 1e-5f), total) : 0.0;   // :27
-            const double inc = wave_incl_sum(pdf, lane) + carry;                                   // :28 (f64 accumulate)
+            const double inc = wave_incl_sum_dpp(pdf, lane) + carry;                               // :28 (f64 accumulate)
             if (k < np) cdf[k + 1] = (float)inc;
             carry = lane_bcast(inc, 63);
         }
@@ -85,21 +86,48 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(int N, int Nc, in
 
     // a cumulative sum of positive terms is non-decreasing; a caller-supplied CDF is checked rather than trusted
     const bool cdf_sorted = wave_sorted(cdf, nb, lane);
-    for (int i = lane; i < Ni; i += 64) {
-        const float uu = u_per_ray ? u[(size_t)ray * Ni + i] : u[i];
-        int cnt = 0;                                      // searchsorted(..., right=True): #{k : cdf[k] <= u}  (:51)
-        if (cdf_sorted && uu == uu) cnt = count_less_equal(cdf, nb, uu);
-        else for (int k = 0; k < nb; ++k) cnt += (cdf[k] <= uu) ? 1 : 0;
-        const int below = cnt - 1 > 0 ? cnt - 1 : 0;      // :52-53
-        const int above = cnt < nb - 1 ? cnt : nb - 1;
-        const float c_lo = cdf[below], c_hi = cdf[above], b_lo = bins[below], b_hi = bins[above];
-        float denom = __fsub_rn(c_hi, c_lo);              // :60-64
-        denom = denom < 1e-5f ? 1.f : denom;
-        const float t = __fdiv_rn(__fsub_rn(uu, c_lo), denom);
-        const float smp = __fadd_rn(b_lo, __fmul_rn(t, __fsub_rn(b_hi, b_lo)));
-        all[Nc + i] = smp;
-        if (z_samples) z_samples[(size_t)ray * Ni + i] = smp;
-        if (inds_out) inds_out[(size_t)ray * Ni + i] = cnt;
+    // two samples per lane per pass: their binary searches are independent chains of LDS reads, issued side by side
+    for (int i0 = lane; i0 < Ni; i0 += 128) {
+        const int ii[2] = {i0, i0 + 64};
+        float uu[2];
+        int cnt[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = ii[e] < Ni ? ii[e] : Ni - 1;
+            uu[e] = u_per_ray ? u[(size_t)ray * Ni + i] : u[i];
+        }
+        if (cdf_sorted && uu[0] == uu[0] && uu[1] == uu[1]) {          // searchsorted(..., right=True): #{k : cdf[k] <= u}  (:51)
+            int lo0 = 0, hi0 = nb, lo1 = 0, hi1 = nb;
+            while (lo0 < hi0 || lo1 < hi1) {
+                const int m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+                const float c0 = cdf[m0 < nb ? m0 : nb - 1], c1 = cdf[m1 < nb ? m1 : nb - 1];
+                if (lo0 < hi0) { if (c0 <= uu[0]) lo0 = m0 + 1; else hi0 = m0; }
+                if (lo1 < hi1) { if (c1 <= uu[1]) lo1 = m1 + 1; else hi1 = m1; }
+            }
+            cnt[0] = lo0; cnt[1] = lo1;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                cnt[e] = 0;
+                if (cdf_sorted && uu[e] == uu[e]) cnt[e] = count_less_equal(cdf, nb, uu[e]);
+                else for (int k = 0; k < nb; ++k) cnt[e] += (cdf[k] <= uu[e]) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (ii[e] >= Ni) continue;
+            const int i = ii[e];
+            const int below = cnt[e] - 1 > 0 ? cnt[e] - 1 : 0;      // :52-53
+            const int above = cnt[e] < nb - 1 ? cnt[e] : nb - 1;
+            const float c_lo = cdf[below], c_hi = cdf[above], b_lo = bins[below], b_hi = bins[above];
+            float denom = __fsub_rn(c_hi, c_lo);              // :60-64
+            denom = denom < 1e-5f ? 1.f : denom;
+            const float t = __fdiv_rn(__fsub_rn(uu[e], c_lo), denom);
+            const float smp = __fadd_rn(b_lo, __fmul_rn(t, __fsub_rn(b_hi, b_lo)));
+            all[Nc + i] = smp;
+            if (z_samples) z_samples[(size_t)ray * Ni + i] = smp;
+            if (inds_out) inds_out[(size_t)ray * Ni + i] = cnt[e];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
@@ -126,8 +154,11 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(int N, int Nc, in
                     rank += before ? 1 : 0;
                 }
             }
-            z_fine[(size_t)ray * S + rank] = v;
+            s_sorted[wv][rank] = v;
         }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (int i = lane; i < S; i += 64) z_fine[(size_t)ray * S + i] = s_sorted[wv][i];
     }
 }
 

@@ -8,31 +8,10 @@
 #include "../../include/nefes_hip.h"
 #include <hip/hip_runtime.h>
 
+#include "bicubic.h"
+
 namespace {
-
-__device__ __forceinline__ float cc1(float x) { return ((-0.75f + 2.f) * x - (-0.75f + 3.f)) * x * x + 1.f; }
-__device__ __forceinline__ float cc2(float x) { return ((-0.75f * x - 5.f * -0.75f) * x + 8.f * -0.75f) * x - 4.f * -0.75f; }
-
-struct Taps {
-    int base;        // floor(src): taps are base-1 .. base+2 (to be clamped)
-    float w[4];
-};
-
-__device__ __forceinline__ Taps taps_of(float scale, int dst) {
-    const float src = scale * ((float)dst + 0.5f) - 0.5f;
-    const float fl = floorf(src);
-    const float t = src - fl;
-    Taps r;
-    r.base = (int)fl;
-    r.w[0] = cc2(t + 1.f);
-    r.w[1] = cc1(t);
-    const float u = 1.f - t;
-    r.w[2] = cc1(u);
-    r.w[3] = cc2(u + 1.f);
-    return r;
-}
-
-__device__ __forceinline__ int clampi(int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); }
+using namespace nefes_bicubic;
 
 // out = the window [oy0, oy0+CH) x [ox0, ox0+CW) of the up-sampled OH x OW image (the loop crops 10 pixels per side right after
 // up-sampling, DFM_APR_refine.py:115,119: only the window is ever computed, stored, or differentiated)
@@ -66,13 +45,21 @@ __global__ __launch_bounds__(256) void bicubic_gather_kernel(long outer, int n_i
     const long q = idx % inner;
     const int y = (int)((idx / inner) % n_in);
     const long p = idx / (inner * n_in);
+    (void)n_out;
+    const float acc = gather_axis(y, n_in, o0, n_win, scale, inv_scale, src + p * n_win * inner + q, inner);
+    dst[idx] = acc;
+}
+
+// first / count / wt of GatherTable for one axis: one thread per source index.  Positions whose taps miss y inside [lo, hi] get
+// weight 0 (the span is contiguous up to such holes at the clamped borders).
+__global__ void gather_table_kernel(int n_in, int o0, int n_win, float scale, float inv_scale, int T, int* first, int* count, float* wt) {
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= n_in) return;
     int lo = (int)floorf(((float)y - 1.5f) * inv_scale - 0.5f) - 1;
     int hi = (int)ceilf(((float)y + 2.5f) * inv_scale - 0.5f) + 1;
     lo = lo < o0 ? o0 : lo;
     hi = hi > o0 + n_win - 1 ? o0 + n_win - 1 : hi;
-    (void)n_out;
-    const float* s = src + p * n_win * inner + q - (long)o0 * inner;
-    float acc = 0.f;
+    int f = -1, n = 0;
     for (int o = lo; o <= hi; ++o) {
         const Taps t = taps_of(scale, o);
         float wsum = 0.f;
@@ -80,12 +67,24 @@ __global__ __launch_bounds__(256) void bicubic_gather_kernel(long outer, int n_i
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (clampi(t.base - 1 + k, n_in) == y) { wsum += t.w[k]; hit = true; }
-        if (hit) acc += wsum * s[(long)o * inner];
+        if (hit && f < 0) f = o;
+        if (f >= 0 && o - f < T) {
+            wt[(long)y * T + (o - f)] = hit ? wsum : 0.f;
+            if (hit) n = o - f + 1;
+        }
     }
-    dst[idx] = acc;
+    first[y] = f < 0 ? 0 : f - o0;
+    count[y] = n;
 }
 
 }   // namespace
+
+extern "C" int nefes_bicubic_gather_table(int n_in, int n_out, int o0, int n_win, int T, int* first, int* count, float* wt, void* stream_) {
+    if (n_in <= 0 || n_out <= 0 || o0 < 0 || n_win <= 0 || o0 + n_win > n_out || T <= 0 || !first || !count || !wt) return NEFES_E_BADARG;
+    if (T < (int)(4.f * n_out / n_in) + 8) return NEFES_E_BADARG;         // a source index is hit from at most ~4 scale + a few positions
+    gather_table_kernel<<<dim3((n_in + 63) / 64), dim3(64), 0, (hipStream_t)stream_>>>(n_in, o0, n_win, (float)n_in / n_out, (float)n_out / n_in, T, first, count, wt);
+    return (int)hipGetLastError();
+}
 
 static bool window_ok(int O, int o0, int n) { return o0 >= 0 && n > 0 && o0 + n <= O; }
 

@@ -46,6 +46,29 @@ __device__ __forceinline__ double wave_incl_sum(double v, int lane) {
     }
     return v;
 }
+// The same scan on DPP (register to register: no LDS crossbar round trip per step): row_shr 1, 2, 4, 8 inside the rows of 16
+// lanes -- a lane that has no source keeps its value, the shifted-in operand reads as zero -- then the rows' totals are added
+// across rows (v_readlane of lanes 15, 31, 47).  Adds the same terms in a different association than the ds_bpermute form.
+template <int CTRL>
+__device__ __forceinline__ double dpp_shr_zero(double v) {      // lane i <- lane i - k of its row, 0 where there is none
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_incl_sum_dpp(double v, int lane) {
+    v += dpp_shr_zero<0x111>(v);     // row_shr:1
+    v += dpp_shr_zero<0x112>(v);     // row_shr:2
+    v += dpp_shr_zero<0x114>(v);     // row_shr:4
+    v += dpp_shr_zero<0x118>(v);     // row_shr:8
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
+    const int row = lane >> 4;
+    const double base = row == 0 ? 0.0 : (row == 1 ? r0 : (row == 2 ? r0 + r1 : (r0 + r1) + r2));
+    return base + v;
+}
 // Reverse scan of affine maps f_i(x) = a_i + m_i * x over lanes: on return lane i holds the
 // composition F_i = f_i o f_{i+1} o ... o f_63  as (m, a).
 __device__ __forceinline__ void wave_rev_affine(double& m, double& a, int lane) {

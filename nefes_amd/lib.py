@@ -32,7 +32,7 @@ class NefesHashGridDesc(C.Structure):
                 ("base_resolution", C.c_int32), ("per_level_scale", C.c_float), ("bound", C.c_float)]
 
 
-ABI_VERSION = 11       # NEFES_ABI_VERSION of include/nefes_hip.h
+ABI_VERSION = 13       # NEFES_ABI_VERSION of include/nefes_hip.h
 STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6, STREAM_BWD_FULL_X6, STREAM_BWD_STATIC = 0, 1, 2, 3, 4, 5, 6, 7
 STREAM_FWD_SIGMA_H3, STREAM_FWD_FULL_H3, STREAM_BWD_FULL_H3, STREAM_FWD_STATIC_H3, STREAM_BWD_STATIC_H3 = 8, 9, 10, 11, 12
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
@@ -51,6 +51,9 @@ SIGNATURES = {
     "nefes_stream_slab_bytes": (_sz, [_desc, _i]),
     "nefes_fusion_input_fwd": (_i, [_i, _i, _i, _p, _p, _p, C.POINTER(_f), C.POINTER(_f), _p, _p, _p]),
     "nefes_fusion_input_bwd": (_i, [_i, _i, _i, _p, _p, _p, C.POINTER(_f), _p, _p, _p]),
+    "nefes_upcos_loss_fwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "nefes_upcos_loss_bwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "nefes_bicubic_gather_table": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "nefes_adam_step": (_i, [_i, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]),
     "nefes_pack_weights": (_i, [_desc, C.POINTER(_p), _i, _p, _sz]),
     "nefes_pack_map": (_i, [_desc, _p, _sz, _p]),

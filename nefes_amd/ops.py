@@ -776,6 +776,69 @@ def cosine_feature_loss(a, b, return_cos=False):
     return (loss, cos) if return_cos else loss
 
 
+_GATHER_TABLES = {}
+
+
+def bicubic_gather_table(n_in, n_out, o0, n_win, device):
+    """(first, count, wt, T) of one axis (include/nefes_hip.h nefes_bicubic_gather_table), built once per geometry and device."""
+    key = (int(n_in), int(n_out), int(o0), int(n_win), str(device))
+    t = _GATHER_TABLES.get(key)
+    if t is None:
+        T = 4 * ((n_out + n_in - 1) // n_in) + 8
+        first = torch.zeros(n_in, dtype=torch.int32, device=device)
+        count = torch.zeros(n_in, dtype=torch.int32, device=device)
+        wt = torch.zeros(n_in, T, device=device)
+        L.check(L.load().nefes_bicubic_gather_table(n_in, n_out, o0, n_win, T, first.data_ptr(), count.data_ptr(), wt.data_ptr(), _stream()),
+                "nefes_bicubic_gather_table")
+        t = _GATHER_TABLES[key] = (first, count, wt, T)
+    return t
+
+
+class UpsampledCosineLoss(torch.autograd.Function):
+    """cosine_feature_loss(bicubic_upsample(x, size, crop), target) for x [C,h,w] (or [1,C,h,w]) without the up-sampled image:
+    csrc/refine.hip upcos kernels.  Returns (loss, per-channel cosine similarities) like CosineFeatureLoss."""
+
+    @staticmethod
+    def forward(ctx, x, target, OH, OW, crop):
+        xf = _f32(x)
+        Cc, h, w = xf.shape[-3:]
+        xf = xf.reshape(Cc, h, w)
+        tf = _f32(target).reshape(Cc, OH - 2 * crop, OW - 2 * crop)
+        lib = L.load()
+        scratch = torch.empty(lib.nefes_cosine_loss_scratch_doubles(Cc), dtype=torch.float64, device=xf.device)
+        loss = torch.empty((), device=xf.device)
+        with _timed("upcos_loss_fwd"):
+            L.check(lib.nefes_upcos_loss_fwd(Cc, h, w, OH, OW, crop, _chk(xf, "x"), _chk(tf, "target"), _chk(scratch, "scratch", torch.float64),
+                                             _chk(loss, "loss"), _stream()), "nefes_upcos_loss_fwd")
+        ctx.save_for_backward(xf, tf, scratch)
+        ctx.cfg = (x.shape, OH, OW, crop)
+        cos = scratch[:4 * Cc].view(Cc, 4)[:, 3]
+        ctx.mark_non_differentiable(cos)
+        return loss, cos
+
+    @staticmethod
+    def backward(ctx, g, _g_cos):
+        xf, tf, scratch = ctx.saved_tensors
+        shape, OH, OW, crop = ctx.cfg
+        Cc, h, w = xf.shape
+        gf = _f32(g).reshape(1)
+        tmp = torch.empty(Cc, OH - 2 * crop, w, device=xf.device)
+        g_x = torch.empty_like(xf)
+        fx, cx, wx, T = bicubic_gather_table(w, OW, crop, OW - 2 * crop, xf.device)
+        fy, cy, wy, _ = bicubic_gather_table(h, OH, crop, OH - 2 * crop, xf.device)
+        with _timed("upcos_loss_bwd"):
+            L.check(L.load().nefes_upcos_loss_bwd(Cc, h, w, OH, OW, crop, _chk(xf, "x"), _chk(tf, "target"), _chk(scratch, "scratch", torch.float64),
+                                                  _chk(gf, "g_loss"), fx.data_ptr(), cx.data_ptr(), wx.data_ptr(), fy.data_ptr(), cy.data_ptr(),
+                                                  wy.data_ptr(), T, _chk(tmp, "tmp"), _chk(g_x, "g_x"), _stream()), "nefes_upcos_loss_bwd")
+        return g_x.reshape(shape), None, None, None, None
+
+
+def upsampled_cosine_loss(x, target, size, crop=0, return_cos=False):
+    """1 - mean over channels of the cosine similarity (over pixels) between the bicubically up-sampled, cropped x and target."""
+    loss, cos = UpsampledCosineLoss.apply(x, target, int(size[0]), int(size[1]), int(crop))
+    return (loss, cos) if return_cos else loss
+
+
 class FusionInput(torch.autograd.Function):
     """The rendered maps -> FusionNet's input in one launch (csrc/refine.hip fusion_input): affine colour transform with the image's
     12 exposure coefficients (or none), colour normalisation, [N,3] / [N,C] -> [B,3+C,H,W].  Gradients to rgb and feat; the

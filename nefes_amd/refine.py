@@ -79,6 +79,7 @@ class FeatureLoss(nn.Module):
 
 
 class PoseRefiner:
+    FUSED_UPSAMPLED_LOSS = True      # False: bicubic up-sampling and cosine loss as separate kernels (the tests compare the two)
     """`refine(init_c2w, feature_target, hist, iters)` -> (refined 4x4 c2w, losses [iters]) for one query image, or for
     `images=B` of them side by side (see refine()).
 
@@ -189,6 +190,13 @@ class PoseRefiner:
             if self.apr is not None:
                 self._rgb, self._x_rgb = rgb.detach(), None
             _, _, fused = self.coarse.run_fusion_net(rgb, feat, self.h, self.w, B, per_image_norm=B > 1)
+        if self.upsample and self.fused_glue and not self.per_pixel and self.FUSED_UPSAMPLED_LOSS:
+            # up-sampling, crop and feature loss in one pass each way: the 34 MB up-sampled image is never written (ops.upsampled_cosine_loss)
+            mean_loss, cos = ops.upsampled_cosine_loss(fused.reshape(B * self.C, self.h, self.w), self.target.reshape(B * self.C, self.H - 20, self.W - 20),
+                                                       (self.H, self.W), crop=10, return_cos=True)
+            if B > 1:
+                return mean_loss * float(B), (1.0 - cos.view(B, self.C).mean(1)).float()
+            return mean_loss, mean_loss.detach()
         if self.upsample:
             if self.fused_glue:
                 fused = ops.bicubic_upsample(fused, (self.H, self.W), crop=10)

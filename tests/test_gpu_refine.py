@@ -170,6 +170,31 @@ def test_bicubic_upsample_window_equals_cropped_full_image():
     assert torch.allclose(xa.grad, xb.grad, rtol=0, atol=2e-6 * float(xb.grad.abs().max()))
 
 
+@pytest.mark.parametrize("C,h,w,ts", [(128, 60, 80, 4), (5, 15, 20, 4), (3, 30, 40, 4)])
+def test_upsampled_cosine_loss_equals_separate_kernels(C, h, w, ts):
+    """ops.upsampled_cosine_loss (up-sampling, 10 px crop and feature loss in one pass each way; the up-sampled image is never
+    written) == ops.cosine_feature_loss(ops.bicubic_upsample(x, crop=10), target): the same loss to 1e-7 (same interpolation
+    expression, float64 sums in another order), the same gradient to 1e-6 (the gather runs along x first instead of y first), and
+    both against torch's own Upsample + CosineSimilarity in float64."""
+    from nefes_amd import ops
+    from nefes_amd.refine import feature_loss
+    g = torch.Generator().manual_seed(C + h)
+    H, W = h * ts, w * ts
+    x = torch.randn(1, C, h, w, generator=g)
+    tgt = torch.randn(C, H - 20, W - 20, generator=g) + 0.5 * torch.nn.functional.interpolate(x, size=(H, W), mode="bicubic")[0, :, 10:-10, 10:-10]
+    xa, xb = x.to(DEV).requires_grad_(), x.to(DEV).requires_grad_()
+    la, cos = ops.upsampled_cosine_loss(xa, tgt.to(DEV), (H, W), crop=10, return_cos=True)
+    lb = ops.cosine_feature_loss(ops.bicubic_upsample(xb, (H, W), crop=10)[0], tgt.to(DEV))
+    (2.0 * la).backward()
+    (2.0 * lb).backward()
+    assert abs(float(la) - float(lb)) < 1e-7 and cos.shape == (C,)
+    assert rel(xa.grad.cpu().numpy(), xb.grad.cpu().numpy()) < 1e-6
+    xd = x.double().requires_grad_()
+    ld = feature_loss(torch.nn.functional.interpolate(xd, size=(H, W), mode="bicubic")[0, :, 10:-10, 10:-10], tgt.double())
+    (2.0 * ld).backward()
+    assert abs(float(la) - float(ld)) < 3e-7 and rel(xa.grad.cpu().numpy(), xd.grad.numpy()) < 2e-6
+
+
 def test_fused_glue_iteration_equals_torch_glue(golden):
     """One PoseRefiner iteration with the glue kernels == the same iteration with the torch expressions (APR variant: bicubic
     up-sampling + 10 px crop; DFM variant without): loss and (r, t) gradient."""

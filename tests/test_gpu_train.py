@@ -268,7 +268,20 @@ def test_train_mode_vs_reference_golden(golden, tag):
         loss = loss + ((ex["rgb0"] - t_rgb) ** 2).mean()
     assert abs(float(loss.detach()) - float(g[f"{tag}.loss"])) < 1e-5 * float(g[f"{tag}.loss"])
     loss.backward()
+    # the float64 oracle on ITS OWN branches (unpinned) for the three-way record: how far the reference's own fp32 gradients are
+    # from float64 on this problem is what the 3e-2 below has to be read against (the branch-pinned twin above holds 2e-4)
+    from nefes_amd import lib as L
+    from nefes_amd import train as TR
+    pc = _oracle_params(coarse, TR.param_names(coarse, L.FIELD_STATIC))
+    pf = _oracle_params(fine, TR.param_names(fine, L.FIELD_FULL))
+    cfg = O.RenderCfg(N_samples=Nc, N_importance=Ni, perturb=0., test_time=False, transient_at_test=True, NeRFW=True)
+    rgb_r, _, _, ex_r = O.render(H, W, float(focal), pc, pf, cfg, rays=(rays_o.double(), rays_d.double()), near=0., far=4.)
+    loss_r = ((rgb_r - t_rgb.cpu().double()) ** 2).mean() + ((ex_r["feat_map"] - t_feat.cpu().double()) ** 2).mean()
+    if Ni > 0:
+        loss_r = loss_r + ((ex_r["rgb0"] - t_rgb.cpu().double()) ** 2).mean()
+    loss_r.backward()
     n = 0
+    worst = {"e_hip": 0., "e_ref": 0., "direct": 0.}
     for k in [k for k in g if k.startswith(f"{tag}.grad.")]:
         _, _, net, name = k.split(".", 3)
         got = dict((coarse if net == "coarse" else fine).named_parameters())[name].grad
@@ -277,9 +290,18 @@ def test_train_mode_vs_reference_golden(golden, tag):
         if float(b.abs().max()) == 0.:                                # e.g. transient_beta: beta is not in this loss
             assert float(a.abs().max()) == 0., k
             continue
-        assert float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) < 3e-2, k
+        direct = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        t64 = (pc if net == "coarse" else pf)[name].grad
+        if t64 is not None and float(t64.abs().max()) > 0:
+            t64 = t64.reshape(-1)
+            sc = t64.abs().max()
+            worst["e_hip"] = max(worst["e_hip"], float((a - t64).abs().max() / sc))
+            worst["e_ref"] = max(worst["e_ref"], float((b - t64).abs().max() / sc))
+        worst["direct"] = max(worst["direct"], direct)
+        assert direct < 3e-2, k
         assert float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30)) > 0.9995, k
         n += 1
+    P.record(f"train_golden[{tag}]", "worst parameter gradient, UNPINNED: hip / reference fp32 vs float64 on its own branches", bound=3e-2, **worst)
     assert n >= 19
 
 
