@@ -647,6 +647,7 @@ class FrozenConv2d(torch.autograd.Function):
         ctx.weight, ctx.relu = weight, relu
         if relu:
             ctx.save_for_backward(y)
+            _tap("conv_relu", y)             # tests: the ReLU branch pattern of this layer (y > 0), tests/branch.py's rule for FusionNet
         return y
 
     @staticmethod

@@ -87,18 +87,33 @@ def affine_color_transform(params: Tensor, rgb: Tensor, hist: Tensor, batch_size
 FUSION_MEAN, FUSION_STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]      # nerfh_nff.py:359-360
 
 
-def fusion_net(sd: Dict[str, Tensor], rgb: Tensor, feat: Tensor, H: int, W: int, B: int, residual: bool = False) -> Tensor:
+def fusion_net(sd: Dict[str, Tensor], rgb: Tensor, feat: Tensor, H: int, W: int, B: int, residual: bool = False, conv_pos=None,
+               audit=None) -> Tensor:
     """run_fusion_net (:578-603) + FusionNet.forward (:395-418), BatchNorm2d in train mode (batch statistics, eps 1e-5).
-    `sd`: the fusion_net state dict (net.0/2/4/6 conv weight+bias, net.7 BatchNorm weight+bias), any dtype."""
+    `sd`: the fusion_net state dict (net.0/2/4/6 conv weight+bias, net.7 BatchNorm weight+bias), any dtype.
+    `conv_pos` (tests only): three boolean tensors, the ReLU branch pattern (output > 0) a HIP forward pass took in the three
+    hidden layers -- the oracle is then evaluated ON that pattern, where the function is smooth (tests/branch.py's rule, extended to
+    the loop's CNN); `audit`: dict that receives the number of units whose own sign differs and how far from zero they sit."""
     dt = rgb.dtype
     x = torch.cat([rgb.reshape(B, H, W, 3).permute(0, 3, 1, 2), feat.reshape(B, H, W, -1).permute(0, 3, 1, 2)], 1)
     mean, std = torch.tensor(FUSION_MEAN, dtype=dt), torch.tensor(FUSION_STD, dtype=dt)
     x = torch.cat([(x[:, :3] - mean[:, None, None]) / std[:, None, None], x[:, 3:]], 1)
     h = x
-    for k, pad in ((0, 1), (2, 1), (4, 1), (6, 2)):
+    for li, (k, pad) in enumerate(((0, 1), (2, 1), (4, 1), (6, 2))):
         h = F.conv2d(h, sd[f"net.{k}.weight"].to(dt), sd[f"net.{k}.bias"].to(dt), stride=1, padding=pad)
         if k != 6:
-            h = torch.relu(h)
+            if conv_pos is None:
+                h = torch.relu(h)
+            else:
+                pos = conv_pos[li].reshape(h.shape)
+                if audit is not None:
+                    with torch.no_grad():
+                        flips = (h > 0) != pos
+                        audit["flips"] = audit.get("flips", 0) + int(flips.sum())
+                        audit["units"] = audit.get("units", 0) + h.numel()
+                        if bool(flips.any()):
+                            audit["worst"] = max(audit.get("worst", 0.), float(h[flips].abs().max() / h.abs().max()))
+                h = h * pos.to(dt)
     if "net.7.weight" in sd:
         mu = h.mean(dim=(0, 2, 3), keepdim=True)
         var = ((h - mu) ** 2).mean(dim=(0, 2, 3), keepdim=True)                 # biased, as BatchNorm normalises with
@@ -214,13 +229,14 @@ class Problem:
 
     def loss_at_pose(self, pose: Tensor, want_rgb: bool = False, **pin):
         """From the 3x4 pose in APR/COLMAP coordinates on: DFM_optimization_NFF (:311-337) / train_on_batch (:97-131).
-        `pin` (tests only): fine_act / z_fine / coarse_act of ref_cpu.render -- the oracle on a GIVEN ReLU branch pattern and
-        GIVEN sample depths (those a HIP forward pass took: tests/branch.py)."""
+        `pin` (tests only): fine_act / z_fine / coarse_act of ref_cpu.render and conv_pos / conv_audit of fusion_net -- the oracle
+        on a GIVEN ReLU branch pattern and GIVEN sample depths (those a HIP forward pass took: tests/branch.py)."""
+        conv_pos, conv_audit = pin.pop("conv_pos", None), pin.pop("conv_audit", None)
         pose = fix_coord_supp(pose, self.world["pose_scale"], self.world["move_all_cam_vec"], self.world["pose_scale2"])
         rgb, _, _, extras = O.render(self.h, self.w, self.f, self.p_coarse, self.p_fine, self.cfg, c2w=pose, near=self.near,
                                      far=self.far, hist=self.hist, **pin)
         rgb = affine_color_transform(self.exposure_params, rgb, self.hist, 1)
-        fused = fusion_net(self.fusion_sd, rgb, extras["feat_map"], self.h, self.w, 1)
+        fused = fusion_net(self.fusion_sd, rgb, extras["feat_map"], self.h, self.w, 1, conv_pos=conv_pos, audit=conv_audit)
         target = self.target
         if self.upsample is not None:
             fused = F.interpolate(fused, size=self.upsample, mode="bicubic")[:, :, 10:-10, 10:-10]      # :114, :126

@@ -21,6 +21,13 @@ from tests.test_refine50_oracle import photo_of, problem, rel
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# Tolerance of the LOOP's gradient on pinned branches.  1e-4 is the north star for the render path's pose gradient and is held
+# there (tests/test_gpu_parity.py, test_gpu_edges.py, smoke()).  The loop's gradient additionally runs through FusionNet's four fp32
+# convolutions forward and backward, the up-sampling and the cosine loss, and along a converging trajectory it becomes a small
+# remainder of cancelling terms: the fp32 CPU oracle itself is 6e-6 ... 1.4e-4 from float64 on identical branches between iteration 20
+# and 49 (recorded beside every check).  Measured for the HIP loop: 7e-6 ... 1.3e-4.  What it does to the refined poses is the
+# population test below: medians within 0.05 % of the reference's.
+LOOP_TOL = 2e-4
 T = lambda a: torch.from_numpy(np.asarray(a))
 
 
@@ -75,6 +82,15 @@ def target_full(g):
     return torch.nn.functional.interpolate(T(g["target_low"])[None], size=(int(H), int(W)), mode="bicubic")[0]     # CPU: as the generator
 
 
+def conv_audit(tag, aud):
+    """FusionNet's ReLU units whose float64 sign differs from the branch the HIP convolutions took must sit within fp32 rounding of
+    zero (relative to the layer's largest pre-activation), like the field's units in tests/branch.py."""
+    flips, units, worst = aud.get("flips", 0), aud.get("units", 0), aud.get("worst", 0.)
+    print(f"[{tag}] FusionNet ReLU pattern vs float64: {flips} of {units} units differ, worst |pre-activation| / layer max {worst:.1e}")
+    P.record(tag, "FusionNet relu branch flips vs float64", flips=flips, units=units, worst_preact_rel=worst)
+    assert worst < 2e-5 and flips <= max(8, units // 20000), (flips, units, worst)
+
+
 def errors(g, poses):
     return np.array([RC.pose_error(g["true_c2w"], np.asarray(p)) for p in poses])
 
@@ -111,8 +127,11 @@ def test_mode3_iterations_match_reference_along_its_trajectory(golden):
                      e_ref=rel(g["m3_grad"][k, i], g64.numpy()), direct=direct, bound=None)
             P.check(f"refine50_mode3_iteration[{i}]", "loss", abs(loss - float(l64)) / float(l64),
                     abs(float(g["m3_loss"][k, i]) - float(l64)) / float(l64), dl, tol=2e-4, factor=3.0)
+            conv_pos, aud = [(y > 0).cpu() for y in tap["conv_relu"][-3:]], {}
             B.pinned_gradients(f"refine50_mode3_iteration[{i}]", {"d loss / d (r, t)": grad}, tap, Wd,
-                               lambda dt, act, zf: {"d loss / d (r, t)": probs[dt].loss_and_grad(r0, t0, fine_act=act, z_fine=zf)[1]}, audit_tol=1e-4)
+                               lambda dt, act, zf: {"d loss / d (r, t)": probs[dt].loss_and_grad(r0, t0, fine_act=act, z_fine=zf, conv_pos=conv_pos,
+                                                                                          conv_audit=aud if dt == torch.float64 else None)[1]}, audit_tol=1e-4, tol=LOOP_TOL)
+            conv_audit(f"refine50_mode3_iteration[{i}]", aud)
     P.record("refine50_mode3_iteration[all]", "worst over 50 iterations: gradient, loss vs the reference's fp32", direct=worst_g, e_hip=worst_l, e_ref=None, bound=5e-3)
     assert worst_g < 5e-3 and worst_l < 1e-3, (worst_g, worst_l)
 
@@ -149,16 +168,18 @@ def test_mode2_iterations_match_reference_along_its_trajectory(golden, k):
         if i in (0, 20, 49):
             def oracle(dt, act=None, zf=None):
                 raw = (T(Wn).to(dt) @ desc.to(dt) + T(bn).to(dt)).requires_grad_()
-                pin = {} if act is None else dict(fine_act=act, z_fine=zf)
+                pin = {} if act is None else dict(fine_act=act, z_fine=zf, conv_pos=conv_pos, conv_audit=aud if dt == torch.float64 else None)
                 l = probs[dt].loss_at_pose(RC.svd_reg(raw.reshape(3, 4)), **pin)
                 return l.detach(), torch.autograd.grad(l, raw)[0]
+            conv_pos, aud = [(y > 0).cpu() for y in tap["conv_relu"][-3:]], {}
             l64, g64 = oracle(torch.float64)
             P.record(f"refine50_mode2_iteration[{k},{i}]", "d loss / d (12 regressed numbers), UNPINNED", e_hip=rel(grad, g64.numpy()),
                      e_ref=rel(g["m2_grad"][k, i], g64.numpy()), direct=direct, bound=None)
             P.check(f"refine50_mode2_iteration[{k},{i}]", "loss", abs(lossf - float(l64)) / float(l64),
                     abs(float(g["m2_loss"][k, i]) - float(l64)) / float(l64), dl, tol=2e-4, factor=3.0)
             B.pinned_gradients(f"refine50_mode2_iteration[{k},{i}]", {"d loss / d (12 regressed numbers)": torch.from_numpy(grad)}, tap, Wd,
-                               lambda dt, act, zf: {"d loss / d (12 regressed numbers)": oracle(dt, act, zf)[1]}, audit_tol=1e-4)
+                               lambda dt, act, zf: {"d loss / d (12 regressed numbers)": oracle(dt, act, zf)[1]}, audit_tol=1e-4, tol=LOOP_TOL)
+            conv_audit(f"refine50_mode2_iteration[{k},{i}]", aud)
             ps, ss = ref._verification()
             assert abs(ps - g["m2_psnr"][k, i]) < 2e-3 and abs(ss - g["m2_ssim"][k, i]) < 2e-5, (ps, ss)
     P.record(f"refine50_mode2_iteration[{k},all]", "worst over 50 iterations: gradient, loss vs the reference's fp32", direct=worst_g, e_hip=worst_l, e_ref=None, bound=5e-3)
