@@ -8,14 +8,18 @@
 #define NEFES_SLAB_KIB 16      // the Wd = 128 instances (layout.h NEFES_H3_BWD_SLAB_KIB_128)
 #else
 #define NEFES_SLAB_KIB 32
-// H3B_WIDE_EXPERIMENT (round 3, not shipped: DESIGN.md section 4.1b "the backward on the gap schedule"): the Wd = 256 objects with
-// their 8-/10-tile runs on field_h3.h's gap-by-gap schedule -- 2 x NTW hidden tiles in the 256 AGPRs, the three embedding tiles in
-// VGPRs.  Fits without spills (228 VGPRs) and runs ~1.2 % faster, but with the accumulator file fully subscribed hipcc relocates
-// whole tiles with v_accvgpr_mov in the middle of the asm runs (it cannot know an issued asm MFMA has not written them yet): wrong
-// gradients.  Build with -DH3B_WIDE_EXPERIMENT -UNEFES_H3_WIDE_MIN to reproduce; tools/ab_bwd.py compares two builds.
-#ifdef H3B_WIDE_EXPERIMENT
+// The Wd = 256 inference objects (parts 0, 1) run their 8-/10-tile products on field_h3.h's gap-by-gap schedule (asm MFMAs on AGPR
+// tiles, source tiles read out of their AGPRs inside the gaps), like the forward.  That needs the accumulator file to hold EXACTLY
+// the 2 x NTW ping-pong tiles: with a seventeenth tile alive hipcc relocates whole tiles with v_accvgpr_mov in the middle of the asm
+// runs -- behind an MFMA that has not written them yet.  So the three embedding-gradient tiles are consumed
+// where they are produced (below), layer 5's two extra output tiles live in VGPRs for the length of that run, and
+// tests/test_pack_stream.py disassembles the library and fails if a v_accvgpr_mov shows up in these kernels.
+#if !defined(NEFES_TU_PART) || NEFES_TU_PART == 0 || NEFES_TU_PART == 1
+#define H3B_WIDE
 #define H3_ACC_READ_ASM        // source tiles are read out of their AGPRs inside the MFMA gaps (field_h3.h acc_read)
 #define H3_WIDE_ENTRY_FENCE    // wide runs follow compiler-scheduled segments here (field_h3.h mma_run_h3_wide)
+#else
+#define NEFES_H3_WIDE_MIN 99   // TRAIN instances: block-per-pair form for every segment
 #endif
 #endif
 #define NEFES_B_BATCH 2
@@ -27,6 +31,10 @@
 #ifndef H3B_WIDE_LAYERS
 #define H3B_WIDE_LAYERS 0x1ff   /* bit L: layer L's transposed product on the gap-by-gap schedule; bit 0: xyz_encoding_final's (debugging) */
 #endif
+#ifndef NEFES_H3B_WG128
+#define NEFES_H3B_WG128 1      /* workgroups per CU of the Wd = 128 instances; 2 fits only with ~100 registers spilled to scratch and measured no gain (0.744 vs 0.741 ms on the 80x60 frame) */
+#endif
+#define NEFES_H3B_WG_PER_CU(W) ((W) == 128 ? NEFES_H3B_WG128 : 1)
 #define NEFES_H3B_SLOTS 2   // 64 KiB ring (StagedRing: two slots) + the tile's ReLU masks and the scale table
 
 struct FieldBwdH3Args {
@@ -99,7 +107,7 @@ __device__ __forceinline__ T ld_stream(const T* p) {
 // HAS_T = false: the static head only (NEFES_FIELD_STATIC forward: raw channels rgb+feature, sigma); the stream then is
 // NEFES_STREAM_BWD_STATIC_H3 and the transient segments are absent.  TRAIN: see StoringSplitH.
 template <int W, int C3, int ENC, bool HAS_T = true, bool TRAIN = false>   // C3 = 3 + C; ENC = NEFES_XYZ_*
-__global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) {
+__global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kernel(FieldBwdH3Args a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
     constexpr int WT = (NTW + 1) / 2, WH = (NTH + 1) / 2;   // mask words per trunk / half-width layer
@@ -292,12 +300,19 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
             mma_run_h3<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{G2, bh, pow2i(tau), mg}, gptr(NEFES_TB_DIR), 1.f), ZeroInit{}, XA);
             M = (HAS_T ? rowb(NEFES_H3B_T0) * (pair_max(mt) * pow2i(-es3)) : 0.f) + rowb(NEFES_H3B_DIR) * pair_max(mg);
         }
-#ifdef H3B_WIDE_EXPERIMENT
-        // From here on the 2 x NTW hidden tiles own the 256 AGPRs (asm MFMAs with "+a" operands): the d dir-embedding tile must
-        // not sit there too.  Left in an AGPR it over-subscribes the file and hipcc shuffles whole tiles with v_accvgpr_mov in the
-        // middle of the asm runs -- copying registers an issued MFMA has not written yet (seen in the disassembly; wrong gradients).
-        asm volatile("" : "+v"(XA[1]));
-#endif
+        // The d dir-embedding tile (XA tile 1) is complete here and nothing else reads it: its embedding backward runs NOW and three
+        // numbers per lane stay, instead of a 16-register tile riding along through all nine full-width layers (round 3: with the two
+        // d xyz-embedding tiles treated the same way below, the layer chain holds exactly the 2 x NTW ping-pong tiles).
+        float gv[3];
+        {
+            float dDv[16], v3[3];
+            const float inv = pow2i(-es_dt);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dDv[r] = XA[1][r] * inv;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v3[c] = STASH(3 + c);
+            embed_slots_bwd<NEFES_N_FREQ_DIR>(gv, dDv, v3, h);
+        }
         // ---- xyz_encoding_final^T (no ReLU on its output) + static_sigma^T (one extra fp32 k-step) -> d h8 ----
         int es_b;
         {
@@ -328,54 +343,61 @@ __global__ __launch_bounds__(256, 1) void field_bwd_h3_kernel(FieldBwdH3Args a) 
         NEFES_BWD_LAYER(6, XB, XA, es_b, es_a, NTW, 2)
         NEFES_BWD_LAYER(5, XA, XB, es_a, es_b, NTW + 2, 0)
         es_e = es_b;                                                         // exponent of the d xyz-embedding tiles XB[0], XB[1]
+        // the skip connection's share of d xyz-embedding (XB tiles 0, 1), consumed at once (see the d dir-embedding tile above)
+        float gx[3] = {0.f, 0.f, 0.f};
+        float ge[ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : 1];
+        {
+            const float inv = pow2i(-es_e);
+            if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+#pragma unroll
+                for (int s_ = 0; s_ < NEFES_X_STEPS; ++s_) ge[s_] = XB[0][s_] * inv;
+            } else {
+                float dE[32], x3[3];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dE[t * 16 + r] = XB[t][r] * inv;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) x3[c] = STASH(c);
+                embed_slots_bwd<NEFES_N_FREQ_XYZ>(gx, dE, x3, h);
+                ge[0] = 0.f;
+            }
+        }
         NEFES_BWD_LAYER(4, XB, XA, es_b, es_a, NTW, 2)
         NEFES_BWD_LAYER(3, XA, XB, es_a, es_b, NTW, 2)
         NEFES_BWD_LAYER(2, XB, XA, es_b, es_a, NTW, 2)
 #undef NEFES_BWD_LAYER
-        // ---- xyz_encoding_1^T accumulates onto the skip's d embedding: bring those two tiles to the new product's exponent ----
+        // ---- xyz_encoding_1^T -> layer 1's share of d xyz-embedding, into fresh tiles (the skip's share is already consumed) ----
         int es_1;
         {
             load_bits(bt, 0, WT);
             const int ew = wexp(NEFES_H3B_L1), tau = tau_of(M, ew);
             float mx = 0.f;
             es_1 = tau + ew;
-            const float resc = pow2i(es_1 - es_e);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) XB[t][r] *= resc;
-            mma_run_h3<2, W / 16, 0, false>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTW + 2, WT, 2>{XA, bt, pow2i(tau - es_a), mx}, gptr(NEFES_TB_L1), pow2i(-es_a)), ZeroInit{}, XB);
+            mma_run_h3<2, W / 16, 0, true>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTW + 2, WT, 2>{XA, bt, pow2i(tau - es_a), mx}, gptr(NEFES_TB_L1), pow2i(-es_a)), ZeroInit{}, XB);
         }
-        float dDv[16];
-        {
-            const float inv = pow2i(-es_dt);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dDv[r] = XA[1][r] * inv;
-        }
-
-        // ---- embedding backward (Embedder.embed :257-267) ----
-        float x[3], gx[3] = {0.f, 0.f, 0.f}, gv[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { x[c] = STASH(c); v[c] = STASH(3 + c); }
+        // ---- embedding backward (Embedder.embed :257-267): layer 1's share; the other two were taken where they were produced ----
         const float inv1 = pow2i(-es_1);
         if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
-            float ge[NEFES_X_STEPS];
 #pragma unroll
-            for (int s = 0; s < NEFES_X_STEPS; ++s) ge[s] = XB[0][s] * inv1;
+            for (int s_ = 0; s_ < NEFES_X_STEPS; ++s_) ge[s_] += XB[0][s_] * inv1;
             if (valid) {
                 float* gp = a.g_enc + m * 32 + h;
 #pragma unroll
-                for (int s = 0; s < NEFES_X_STEPS; ++s) gp[2 * s] = ge[s];
+                for (int s_ = 0; s_ < NEFES_X_STEPS; ++s_) gp[2 * s_] = ge[s_];
             }
         } else {
-            float dE[32];
+            float dE[32], x3[3], g1[3];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dE[t * 16 + r] = XB[t][r] * inv1;
-            embed_slots_bwd<NEFES_N_FREQ_XYZ>(gx, dE, x, h);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x3[c] = STASH(c);
+            embed_slots_bwd<NEFES_N_FREQ_XYZ>(g1, dE, x3, h);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gx[c] += g1[c];
         }
-        embed_slots_bwd<NEFES_N_FREQ_DIR>(gv, dDv, v, h);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             gx[c] += __shfl_xor(gx[c], 32);
@@ -401,7 +423,8 @@ static int launch_bwd_h3(const FieldBwdH3Args& a, hipStream_t st) {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int grid = a.n_tiles < cus ? a.n_tiles : cus;
+    const int slots = cus * NEFES_H3B_WG_PER_CU(W);            // Wd = 128: two workgroups share a CU (61 KiB of LDS each)
+    int grid = a.n_tiles < slots ? a.n_tiles : slots;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
     return (int)hipGetLastError();

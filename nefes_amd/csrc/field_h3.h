@@ -441,6 +441,9 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
     // everything is selected at compile time (the loops are fully unrolled).
     Split2 B0, B1;
     auto BQ = [&](int k) -> Split2& { return (k & 1) ? B1 : B0; };
+    // (`s_nop 13` here and `s_nop 12` in the end-of-run statement occur nowhere else in the library: tests/test_pack_stream.py
+    // finds the asm-scheduled stretches of the disassembly by them and checks that no accumulator tile is moved inside one)
+    asm volatile("s_nop 13" ::: "memory");
 #ifdef H3_WIDE_ENTRY_FENCE
     // The run's first operand is read out of the source tiles' AGPRs by asm statements, which hipcc schedules freely among its OWN
     // MFMAs: when the previous segment ran on compiler-placed MFMAs (narrow runs, the fp32 sigma step) it hoisted these reads to
@@ -595,7 +598,7 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
     // The same statement holds the LAST MFMA's A and B operand registers: an issued asm MFMA is still reading them, and once the
     // unit's empty use is behind it hipcc hands them out again -- the very next instruction overwrote the B operand (seen in the
     // disassembly of the backward: v_mfma ... v[14:17] followed by v_mov_b32 v14; the last tile's last k-step came out wrong).
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1"
+    asm volatile("s_nop 12\n\ts_nop 4"
                  : "+a"(acc[T0 + NT - 1]), "+a"(acc[T0 + NT - 2])
                  : "v"(HA(NU - 1)), "v"(BQ(KS16 - 1).h), "v"(BQ(KS16 - 1).l));
 #endif

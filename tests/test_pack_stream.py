@@ -603,6 +603,63 @@ def test_m0_only_written_by_the_dma_helper(tmp_path):
     assert n_dma > 1000                                      # the unrolled weight-stream pieces of the field kernels
 
 
+def test_no_accumulator_tile_is_relocated_inside_the_asm_scheduled_kernels(tmp_path):
+    """The kernels whose MFMAs are asm statements (field_h3.h mma_run_h3_wide: the Wd = 256 fp16 forward instances and the Wd = 256
+    inference instances of the backward) rely on the register allocator never moving an accumulator tile while a run is under
+    way: an asm statement is instantaneous to hipcc, so a `v_accvgpr_mov` it places behind an issued MFMA copies registers the
+    MFMA has not written yet (seen with a seventeenth tile alive; wrong gradients).  Disassemble the
+    library, find the asm-scheduled stretches by their entry / exit markers (`s_nop 13` ... `s_nop 12`, used nowhere else) and
+    require that none contains an AGPR-to-AGPR move."""
+    import os, re, subprocess
+    from nefes_amd import lib as L
+    bindir = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(bindir, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not installed")
+    fat = tmp_path / "fatbin.bin"
+    subprocess.check_call([tools[0], "-O", "binary", "--only-section=.hip_fatbin", L.LIB_PATH, str(fat)])
+    data = fat.read_bytes()
+    starts = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), data)]
+    checked = {}
+    for i, a in enumerate(starts):
+        piece = tmp_path / f"bundle{i}.bin"
+        piece.write_bytes(data[a:starts[i + 1] if i + 1 < len(starts) else len(data)])
+        co = tmp_path / f"code{i}.o"
+        subprocess.check_call([tools[1], "--unbundle", "--type=o", f"--input={piece}", f"--output={co}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], stderr=subprocess.DEVNULL)
+        if co.stat().st_size == 0:
+            continue
+        dis = subprocess.run([tools[2], "-d", "-C", "--no-show-raw-insn", str(co)], capture_output=True, text=True, check=True).stdout
+        name = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                name = m.group(1)
+                continue
+            if name is None:
+                continue
+            # forward: field_fwd_h3_kernel<MODE, ENC, 256, ...> (inference); backward: field_bwd_h3_kernel<256, C3, ENC, HAS_T, false>
+            wide = (re.match(r"void field_fwd_h3_kernel<\d+, \d+, 256, \d+, false>", name) or
+                    re.match(r"void field_bwd_h3_kernel<256, \d+, \d+, true, false>", name))
+            if not wide:
+                continue
+            c = checked.setdefault(name, {"mfma": 0, "mov": 0, "runs": 0, "inside": False})
+            ins = line.split("//")[0].strip()
+            if ins == "s_nop 13":                                   # entry of an asm-scheduled run (field_h3.h mma_run_h3_wide)
+                c["inside"] = True
+                c["runs"] += 1
+            elif ins == "s_nop 12":                                 # its end-of-run statement
+                c["inside"] = False
+            elif c["inside"]:
+                if "v_mfma_f32_32x32x16_f16" in ins:
+                    c["mfma"] += 1
+                if "v_accvgpr_mov_b32" in ins:
+                    c["mov"] += 1
+    assert len(checked) >= 5, list(checked)                        # sigma / full x two encodings forward, two encodings backward
+    for name, c in checked.items():
+        assert c["runs"] >= 1 and not c["inside"] and c["mfma"] > 1000 and c["mov"] == 0, (name, c)
+
+
 # ---- fp16 two-part streams (layout.h NEFES_STREAM_*_H3, pack.cpp h3 segments, field_h3.h) -------------------------------------
 H3F = dict(L1=0, L2=1, L3=2, L4=3, L5H=4, L5E=5, L6=6, L7=7, L8=8, SIG=9, FINAL=10, DT_H=11, DT_D=12, RGB=13, T1=14, T2=15, TH=16)
 H3B = dict(RGB=0, TH=1, T2=2, T1=3, T0=4, DIR=5, FINAL=6, SIG=7, L8=8, L7=9, L6=10, L5=11, L4=12, L3=13, L2=14, L1=15)
