@@ -413,6 +413,16 @@ __device__ __forceinline__ void mfma_h3_asm_v(f32x16& c, const f32x4& a, const u
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 #endif
 }
+// First MFMA of a tile whose C operand is zero (the backward's transposed products): the inline constant 0 as srcC, the tile is an
+// output only -- no sixteen v_accvgpr_write per tile and layer to zero it (a third of a VALU instruction per MFMA in the backward).
+__device__ __forceinline__ void mfma_h3_asm_c0(f32x16& c, const f32x4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_h3_asm_v_c0(f32x16& c, const f32x4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+}
+template <class T> struct h3_is_zero_init { static constexpr bool value = false; };
+template <> struct h3_is_zero_init<ZeroInit> { static constexpr bool value = true; };
 #ifdef H3_STAMP   // diagnostic build (tools/stamp_h3.sh): cycles inside the wide runs / inside ring acquires, per wave
 __device__ unsigned long long h3_stamp_run = 0, h3_stamp_acq = 0, h3_stamp_n = 0, h3_stamp_total = 0;
 static __device__ __forceinline__ unsigned long long h3_now() {
@@ -470,10 +480,15 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
     }
     // FIRST: the C operand of a tile's first MFMA (bias x 2^es, or zero) is written straight into the tile's own registers,
     // one unit ahead of its first use -- the output tiles are dead until then -- rather than into a 16-register staging tile
+    constexpr bool C0 = FIRST && h3_is_zero_init<InitFn>::value
+#ifdef H3_BUILTIN_MFMA
+                        && false
+#endif
+        ;                                                  // zero C operand: the first MFMA of every tile takes the constant
 #ifdef H3_ABL_NOBIAS
-    if (FIRST) acc[T0] = ZeroInit{}(0);
+    if (FIRST && !C0) acc[T0] = ZeroInit{}(0);
 #else
-    if (FIRST) acc[T0] = init(0);
+    if (FIRST && !C0) acc[T0] = init(0);
 #endif
     // A operands are requested TWO units (six MFMAs) ahead of their use; (h0,l0), (h1,l1) = this and the next unit's, the reads
     // in flight are the unit's after that.  ring.pf carries the first unit's hi group across segments.
@@ -506,12 +521,17 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
                 __builtin_amdgcn_sched_barrier(0);
                 // the tile's C operand was written by the vector ALU (bias tile): materialise it in its AGPRs HERE, then two wait states
                 const bool vt = T0 + t < VT;               // (folds: the loops are fully unrolled)
-                if (FIRST && q == 0) {
-                    if (vt) asm volatile("s_nop 1" : "+v"(acc[T0 + t]));
-                    else asm volatile("s_nop 1" : "+a"(acc[T0 + t]));
+                if (C0 && q == 0) {
+                    if (vt) mfma_h3_asm_v_c0(acc[T0 + t], l0, B.h);
+                    else mfma_h3_asm_c0(acc[T0 + t], l0, B.h);
+                } else {
+                    if (FIRST && q == 0) {
+                        if (vt) asm volatile("s_nop 1" : "+v"(acc[T0 + t]));
+                        else asm volatile("s_nop 1" : "+a"(acc[T0 + t]));
+                    }
+                    if (vt) mfma_h3_asm_v(acc[T0 + t], l0, B.h);
+                    else mfma_h3_asm(acc[T0 + t], l0, B.h);                                         // M1 (small terms first)
                 }
-                if (vt) mfma_h3_asm_v(acc[T0 + t], l0, B.h);
-                else mfma_h3_asm(acc[T0 + t], l0, B.h);                                             // M1 (small terms first)
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- gap 1 ----
 #ifndef H3_ABL_NOSPLIT
@@ -542,9 +562,9 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
                         if (piece_unit(qq) == uu) ring.store_piece(qq);
                 }
 #ifdef H3_ABL_NOBIAS
-                if (FIRST && q == 0 && t + 1 < NT) acc[T0 + t + 1] = ZeroInit{}(0);
+                if (FIRST && !C0 && q == 0 && t + 1 < NT) acc[T0 + t + 1] = ZeroInit{}(0);
 #else
-                if (FIRST && q == 0 && t + 1 < NT) {
+                if (FIRST && !C0 && q == 0 && t + 1 < NT) {
                     acc[T0 + t + 1] = init(t + 1);
                 }
 #endif
