@@ -15,6 +15,9 @@
 #endif
 #include <stdlib.h>
 
+#ifndef NEFES_FWD_CONSUMER_BIAS
+#define NEFES_FWD_CONSUMER_BIAS 1   /* 0: bias tiles written by the producing run (A/B builds) */
+#endif
 #include "field_common.h"
 #include "../../include/nefes_hip.h"
 
@@ -164,6 +167,11 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
             return a.raw_t + ((size_t)rr * a.R * a.S + ss);
         };
         auto bias_at = [&](int off_floats, int es) { return BiasInitScaled{bias_half + off_floats * 4, pow2i(es)}; };
+        // CB (inference instances): the trunk layers 1..8 start their tiles from the constant 0 and their consumers add the bias
+        // (field_h3.h ReluBiasSplitH) -- sixteen vector instructions less per tile and layer.  TRAIN instances store the tiles as
+        // pre-activations and keep the bias in the producer.
+        constexpr bool CB = !TRAIN && W == 256 && NEFES_FWD_CONSUMER_BIAS;     // (Wd = 128, block-per-pair runs: measured 1-2 % slower)
+        float2 nbias;
         f32x16 A[NTW], B[NTW];
         uint32_t bits[WT];
         auto clear_bits = [&]() {
@@ -185,6 +193,12 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
             f32x16 sg[1];
             float mdummy = 0.f;
             const int es = tau_x + wexp(NEFES_H3F_SIG);
+            if constexpr (CB) {
+                const char* bp8 = bias_half + 7 * W * 4;                                  // the tiles are layer 8's, without its bias
+                nbias = ReluBiasSplitH<false, NTW, WT>::prime(bp8);
+                mma_run_h3<1, W / 16, 0, true>(ring, ring_lane, ReluBiasSplitH<false, NTW, WT>{X, bits, pow2i(tau_x - es_x), mdummy, bp8, pow2i(es_x), nbias},
+                                               bias_at(B_SIG, es), sg);
+            } else
             mma_run_h3<1, W / 16, 0, true>(ring, ring_lane, ReluSplitH<false, NTW, WT>{X, bits, pow2i(tau_x - es_x), mdummy},
                                            bias_at(B_SIG, es), sg);
             float* col = raw_col();
@@ -198,7 +212,8 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
         {
             const int tau = tau_of(mE, wexp(NEFES_H3F_L1));
             es_a = tau + wexp(NEFES_H3F_L1);
-            mma_run_h3<NTW, ES / 8, 0, true>(ring, ring_lane, LdsSplitH{e_lds, pow2i(tau)}, bias_at(0, es_a), A);            // layer 1
+            if constexpr (CB) mma_run_h3<NTW, ES / 8, 0, true>(ring, ring_lane, LdsSplitH{e_lds, pow2i(tau)}, ZeroInit{}, A);    // layer 1 (bias: consumer)
+            else mma_run_h3<NTW, ES / 8, 0, true>(ring, ring_lane, LdsSplitH{e_lds, pow2i(tau)}, bias_at(0, es_a), A);            // layer 1
             M = rowb(NEFES_H3F_L1) * mE + bmax(NEFES_H3BB_L1);
             save_trunk(1, A, es_a);
         }
@@ -209,6 +224,12 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
         {                                                                                                                      \
             const int ew = wexp(SEG1_), tau = tau_of(M, ew);                                                                   \
             float mx = 0.f;                                                                                                    \
+            if constexpr (CB) {                                                                                                \
+                const char* bps = bias_half + ((L1_) - 2) * W * 4;                          /* bias block of the source layer */ \
+                nbias = ReluBiasSplitH<CAP, NTW, WT>::prime(bps);                                                              \
+                mma_run_h3<NTW, W / 16, 0, true>(ring, ring_lane, ReluBiasSplitH<CAP, NTW, WT>{A, bits, pow2i(tau - es_a), mx, bps, pow2i(es_a), nbias}, \
+                                                 ZeroInit{}, B);                                                               \
+            } else                                                                                                             \
             mma_run_h3<NTW, W / 16, 0, true>(ring, ring_lane, ReluSplitH<CAP, NTW, WT>{A, bits, pow2i(tau - es_a), mx},        \
                                              bias_at(((L1_) - 1) * W, tau + ew), B);                                           \
             M = rowb(SEG1_) * (pair_max(mx) * pow2i(-es_a)) + bmax((L1_) - 1);                                                 \
@@ -230,6 +251,12 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                 const int tau = tau_of(p == 1 ? fmaxf(M, mE) : M, ew);
                 if (p == 3) sigma_head(B, es_b, tau_of(M, wexp(NEFES_H3F_SIG)));   // static_sigma reads the same relu(h8)
                 float mx = 0.f;
+                if constexpr (CB) {
+                    const char* bps = bias_half + (l1 - 1) * W * 4;                        // bias block of the source layer l1
+                    nbias = ReluBiasSplitH<CAP, NTW, WT>::prime(bps);
+                    const ReluBiasSplitH<CAP, NTW, WT> src{B, bits, pow2i(tau - es_b), mx, bps, pow2i(es_b), nbias};
+                    mma_run_h3<NTW, W / 16, 0, true>(ring, ring_lane, src, ZeroInit{}, A);       // 3, 5, 7, final: zero start, bias at the consumers
+                } else
                 mma_run_h3<NTW, W / 16, 0, true>(ring, ring_lane, ReluSplitH<CAP, NTW, WT>{B, bits, pow2i(tau - es_b), mx},
                                                  bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL, tau + ew), A);   // 3, 5, 7, final
                 if (p == 1) mma_run_h3<NTW, ES / 8, 0, false>(ring, ring_lane, LdsSplitH{e_lds, pow2i(tau)}, ZeroInit{}, A);   // skip: + W5[:, :63] e
@@ -284,7 +311,13 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                 const int tau = tau_of(fmaxf(M, mD), ew);                            // common exponent of both parts
                 float mx = 0.f;
                 es_dt = tau + ew;
-                if constexpr (FULL)
+                if constexpr (CB) {
+                    const char* bpf = bias_half + B_FINAL * 4;                          // xyz_encoding_final's tiles come without its bias
+                    nbias = ReluBiasSplitH<false, 1, 1>::prime(bpf);
+                    const IdentBiasSplitH<NTW> srcf{A, pow2i(tau - es_a), mx, bpf, pow2i(es_a), nbias};
+                    if constexpr (FULL) mma_run_h3<NDT, W / 16, 0, true>(ring, ring_lane, srcf, Bias2{bias_at(B_DIR, es_dt), bias_at(B_T0, es_dt)}, dt);
+                    else mma_run_h3<NDT, W / 16, 0, true>(ring, ring_lane, srcf, bias_at(B_DIR, es_dt), dt);
+                } else if constexpr (FULL)
                     mma_run_h3<NDT, W / 16, 0, true>(ring, ring_lane, IdentSplitH<NTW, 0>{A, pow2i(tau - es_a), mx},
                                                      Bias2{bias_at(B_DIR, es_dt), bias_at(B_T0, es_dt)}, dt);
                 else

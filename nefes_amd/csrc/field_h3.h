@@ -202,6 +202,75 @@ struct ReluSplitH {
     template <bool NOP>
     __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
 };
+// ReluSplitH whose source tiles do NOT contain their layer's bias yet: the producing run started every tile from the constant 0
+// (mma_run_h3_wide C0) instead of writing sixteen bias x 2^es values into its accumulators (a v_mul and a v_accvgpr_write each), and
+// the bias is added HERE, where the value is in a VGPR anyway: x = fma(b, 2^es, acc) -- one instruction per value instead of two, and
+// one rounding of the sum.  bp: the source layer's bias block (this lane half's +16 bytes included), bs = 2^es of the source set.
+// The two bias values of a pair are one 8-byte LDS read, requested one pair ahead (`nb` carries it from call to call: the pairs of
+// a run are visited in order, k-step by k-step), so its latency is a unit or more old when the fma needs it.
+template <bool CAPTURE, int NX, int NWORDS>
+struct ReluBiasSplitH {
+    const f32x16 (&X)[NX];
+    uint32_t (&bits)[NWORDS];
+    float r;
+    float& m;
+    const char* bp;
+    float bs;
+    float2& nb;                 // bias pair of the NEXT stage_a call (primed by the caller with pair (0, 0))
+    static __device__ __forceinline__ int pair_off(int q, int p) {             // byte offset of the pair's two floats in the block
+        const int r0 = (q & 1) * 8 + 2 * p;
+        return ((q >> 1) * 32 + 8 * (r0 >> 2) + (r0 & 3)) * 4;
+    }
+    static __device__ __forceinline__ float2 prime(const char* bp_) { return *(const float2*)(bp_ + pair_off(0, 0)); }
+    __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
+        const float2 b = nb;
+        const int qn = p == 3 ? q + 1 : q, pn = p == 3 ? 0 : p + 1;
+        nb = *(const float2*)(bp + pair_off(qn, pn));                          // (past the last pair: the next block's first floats, unused)
+        s.x0 = __builtin_fmaf(b.x, bs, acc_read(X[q >> 1][(q & 1) * 8 + 2 * p]));
+        s.x1 = __builtin_fmaf(b.y, bs, acc_read(X[q >> 1][(q & 1) * 8 + 2 * p + 1]));
+#ifndef H3_ABL_NOMASK
+        if (CAPTURE) {
+            mask_shift_in(bits[(8 * q + 2 * p) >> 5], s.x0);
+            mask_shift_in(bits[(8 * q + 2 * p + 1) >> 5], s.x1);
+        }
+#endif
+    }
+    __device__ __forceinline__ void stage_b(PairRegs& s) const {
+        s.x0 = relu1<false>(s.x0);
+        s.x1 = relu1<false>(s.x1);
+#ifndef H3_ABL_NOMAX3
+        max3_acc(m, s.x0, s.x1);
+#endif
+    }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
+    __device__ __forceinline__ void stage_c1(Split2& o, int p, const PairRegs& s) const { split_pair_hi(o, p, s.x0, s.x1, r); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
+};
+// IdentSplitH with the source layer's bias added on the way in (see ReluBiasSplitH): xyz_encoding_final read by the heads.
+template <int NX>
+struct IdentBiasSplitH {
+    const f32x16 (&X)[NX];
+    float r;
+    float& m;
+    const char* bp;
+    float bs;
+    float2& nb;
+    __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
+        const float2 b = nb;
+        const int qn = p == 3 ? q + 1 : q, pn = p == 3 ? 0 : p + 1;
+        nb = *(const float2*)(bp + ReluBiasSplitH<false, 1, 1>::pair_off(qn, pn));
+        s.x0 = __builtin_fmaf(b.x, bs, acc_read(X[q >> 1][(q & 1) * 8 + 2 * p]));
+        s.x1 = __builtin_fmaf(b.y, bs, acc_read(X[q >> 1][(q & 1) * 8 + 2 * p + 1]));
+    }
+    __device__ __forceinline__ void stage_b(PairRegs& s) const { absmax3_acc(m, s.x0, s.x1); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
+    __device__ __forceinline__ void stage_c1(Split2& o, int p, const PairRegs& s) const { split_pair_hi(o, p, s.x0, s.x1, r); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
+};
 template <int NX, int NWORDS, int T0>
 struct MaskedSplitH {
     const f32x16 (&X)[NX];

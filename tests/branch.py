@@ -114,7 +114,18 @@ class tapped:
         return False
 
 
-def pinned_gradients(tag, hip, tap, Wd, oracle_run, tol=P.NORTH_STAR_TOL, audit_tol=2e-5):
+# The branch audit's bound is not a call-site number: a test names one of these classes.  The value is how far (relative to the
+# layer's largest pre-activation) a float64 pre-activation may sit from zero and still land on the other side in fp32.
+AUDIT_CLASSES = {
+    # identical fp32 inputs on both sides: rounding of one network evaluation
+    "same_inputs": 2e-5,
+    # the float64 oracle warps the rays to NDC in float64; the fp32 inputs differ from it by rounding UPSTREAM of the network,
+    # amplified 2^9 by the embedding (measured worst 3.4e-5, 27 flips of 3.3 M)
+    "ndc_inputs_f64": 2e-4,
+}
+
+
+def pinned_gradients(tag, hip, tap, Wd, oracle_run, tol=P.NORTH_STAR_TOL, audit="same_inputs"):
     """Gradient parity on the kernels' own ReLU branch pattern: `oracle_run(dtype, act, z_fine)` -> {name: gradient} of the
     oracle evaluated with the activation hook `act` (and, for render-level runs, at the kernels' depths `z_fine`);
     `hip` = the same dict from the kernels.  Also audits the branch pattern against the float64 pre-activations."""
@@ -124,9 +135,7 @@ def pinned_gradients(tag, hip, tap, Wd, oracle_run, tol=P.NORTH_STAR_TOL, audit_
     flips, units, worst = pin.summary()
     print(f"[{tag}] ReLU branch pattern vs float64: {flips} of {units} units differ, worst |pre-activation| / layer max {worst:.1e}")
     P.record(tag, "relu branch flips vs float64", flips=flips, units=units, worst_preact_rel=worst)
-    # audit_tol: how far (relative to the layer's largest pre-activation) a float64 pre-activation may sit from zero and
-    # still land on the other side in fp32: ~1e-5 for identical inputs; more where the float64 oracle's INPUTS differ from
-    # the fp32 ones by rounding upstream of the network (e.g. an NDC warp evaluated in float64), amplified by 2^9 in the embedding
+    audit_tol = AUDIT_CLASSES[audit]
     assert worst < audit_tol and flips <= max(8, units // 100000) * (audit_tol / 2e-5), (flips, units, worst)
     out = {}
     for name in hip:

@@ -133,7 +133,7 @@ def test_explicit_rays_and_ndc():
             return {"d rays_o": oc.grad, "d rays_d": dc.grad}
 
         B.pinned_gradients(f"explicit_rays[ndc={int(ndc)}]", {"d rays_o": oh.grad, "d rays_d": dh.grad}, tap, 128, oracle_run,
-                           audit_tol=2e-4 if ndc else 2e-5)     # NDC: the float64 oracle warps the rays in float64
+                           audit="ndc_inputs_f64" if ndc else "same_inputs")
 
 
 def test_stratified_jitter_path_runs_and_is_sorted():

@@ -132,7 +132,7 @@ def test_mode3_iterations_match_reference_along_its_trajectory(golden):
             conv_pos, aud = [(y > 0).cpu() for y in tap["conv_relu"][-3:]], {}
             B.pinned_gradients(f"refine50_mode3_iteration[{i}]", {"d loss / d (r, t)": grad}, tap, Wd,
                                lambda dt, act, zf: {"d loss / d (r, t)": probs[dt].loss_and_grad(r0, t0, fine_act=act, z_fine=zf, conv_pos=conv_pos,
-                                                                                          conv_audit=aud if dt == torch.float64 else None)[1]}, audit_tol=1e-4, tol=LOOP_TOL)
+                                                                                          conv_audit=aud if dt == torch.float64 else None)[1]}, tol=LOOP_TOL)
             conv_audit(f"refine50_mode3_iteration[{i}]", aud)
     P.record("refine50_mode3_iteration[all]", "worst over 50 iterations: gradient, loss vs the reference's fp32", direct=worst_g, e_hip=worst_l, e_ref=None, bound=5e-3)
     assert worst_g < 5e-3 and worst_l < 1e-3, (worst_g, worst_l)
@@ -180,7 +180,7 @@ def test_mode2_iterations_match_reference_along_its_trajectory(golden, k):
             P.check(f"refine50_mode2_iteration[{k},{i}]", "loss", abs(lossf - float(l64)) / float(l64),
                     abs(float(g["m2_loss"][k, i]) - float(l64)) / float(l64), dl, tol=2e-4, factor=3.0)
             B.pinned_gradients(f"refine50_mode2_iteration[{k},{i}]", {"d loss / d (12 regressed numbers)": torch.from_numpy(grad)}, tap, Wd,
-                               lambda dt, act, zf: {"d loss / d (12 regressed numbers)": oracle(dt, act, zf)[1]}, audit_tol=1e-4, tol=LOOP_TOL)
+                               lambda dt, act, zf: {"d loss / d (12 regressed numbers)": oracle(dt, act, zf)[1]}, tol=LOOP_TOL)
             conv_audit(f"refine50_mode2_iteration[{k},{i}]", aud)
             ps, ss = ref._verification()
             assert abs(ps - g["m2_psnr"][k, i]) < 2e-3 and abs(ss - g["m2_ssim"][k, i]) < 2e-5, (ps, ss)
