@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
     constexpr int WT = (NTW + 1) / 2, WH = (NTH + 1) / 2;   // mask words per trunk / half-width layer
     constexpr int MW_TRUNK = 8 * WT;
-    constexpr int KR = (C3 + 1) / 2;
+    constexpr int NTR = (C3 + 31) / 32, KR16 = (C3 + 15) / 16;      // static rgb/feature head^T: 3+C upstream channels as fp16 k-steps
     static_assert(MW % 4 == 0, "mask words are staged as 16-byte groups");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[ray * 3 + c];
         const int cT = C3 + 1;                       // transient rgb channels start
-        float y_th[3] = {0.f, 0.f, 0.f}, g_th[3] = {0.f, 0.f, 0.f}, y_sg, g_sg, dr[KR];
+        float y_th[3] = {0.f, 0.f, 0.f}, g_th[3] = {0.f, 0.f, 0.f}, y_sg, g_sg, dr[8 * KR16];
         if constexpr (HAS_T) {
 #pragma unroll
             for (int s = 0; s < 3; ++s) {            // compact slot (s,h) <-> transient-head row 2s+h (5 rows)
@@ -169,10 +169,13 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
         }
         y_sg = ld_stream(&a.raw_t[chan0 + (size_t)C3 * a.S]);
         g_sg = ld_stream(&a.g_raw_t[chan0 + (size_t)C3 * a.S]);
+        // element e of this lane <-> static rgb/feature channel 32 (e / 16) + rho_h(e % 16): the natural slot order of the fp16 operands
 #pragma unroll
-        for (int s = 0; s < KR; ++s) {               // compact slot (s,h) <-> static rgb/feature channel 2s+h
-            const int ch = 2 * s + h;
-            dr[s] = ld_stream(&a.g_raw_t[chan0 + (size_t)(ch < C3 ? ch : C3 - 1) * a.S]);
+        for (int e = 0; e < 8 * KR16; ++e) {
+            const int ch0 = 32 * (e >> 4) + nefes_rho(0, e & 15);              // lane half 1: + 4
+            if (ch0 >= C3) { dr[e] = 0.f; continue; }
+            const int ch = ch0 + 4 * h;
+            dr[e] = ld_stream(&a.g_raw_t[chan0 + (size_t)(ch < C3 ? ch : C3 - 1) * a.S]);
         }
         uint4 mq[MW / 4];
         {
@@ -191,10 +194,10 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
             for (int s = 0; s < 3; ++s) g_th[s] = 0.f;
             g_sg = 0.f;
 #pragma unroll
-            for (int s = 0; s < KR; ++s) dr[s] = 0.f;
+            for (int e = 0; e < 8 * KR16; ++e) dr[e] = 0.f;
         }
 #pragma unroll
-        for (int s = 0; s < KR; ++s) dr[s] = (2 * s + h < C3) ? dr[s] : 0.f;
+        for (int e = 0; e < 8 * KR16; ++e) dr[e] = (32 * (e >> 4) + nefes_rho(h, e & 15) < C3) ? dr[e] : 0.f;
         // head activation derivatives from the outputs: sigmoid' = y(1-y), softplus' = 1 - exp(-y)
         float dth[3];
         if (h == 0) {   // rows 0 (rgb_t0), 2 (rgb_t2), 4 (beta)
@@ -220,11 +223,10 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
             // G of static_rgb / static_sigma / the transient heads.  They are in registers here (compact slots: row 2s + h), so
             // they are stored here: the separate head-gradient pass (train.hip train_head_grad_kernel) re-read d raw and raw_t.
             float* dt_ = a.dacts + (size_t)tile * a.rows * 128 + (size_t)(((wave * 32 + j) >> 4) * 512 + h * 16 + (j & 15));
-            float* prgb = dt_ + (size_t)(nefes_train_row(W, C3 - 3, NEFES_TB_RGB) >> 5) * 4096;
-            constexpr int NTR_ = (C3 + 31) / 32;
+            float* prgb = a.dacts + (size_t)tile * a.rows * 128 + (size_t)(nefes_train_row(W, C3 - 3, NEFES_TB_RGB) >> 5) * 4096 + nefes_train_lane_off(wave, j, h);
 #pragma unroll
-            for (int s = 0; s < 16 * NTR_; ++s)
-                __builtin_nontemporal_store(s < KR ? dr[s < KR ? s : 0] : 0.f, &prgb[(s >> 4) * 4096 + 2 * (s & 15) * 16]);
+            for (int e = 0; e < 16 * NTR; ++e)      // row 32 (e / 16) + rho_h(e % 16)
+                __builtin_nontemporal_store(e < 8 * KR16 ? dr[e < 8 * KR16 ? e : 0] : 0.f, &prgb[(e >> 4) * 4096 + nefes_rho(0, e & 15) * 16]);
             float* psig = dt_ + (size_t)(nefes_train_row(W, C3 - 3, NEFES_TB_SIG) >> 5) * 4096;
 #pragma unroll
             for (int s = 0; s < 16; ++s) __builtin_nontemporal_store(s == 0 ? d_sigma : 0.f, &psig[2 * s * 16]);
@@ -252,9 +254,17 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
             else return a.dacts + (size_t)tile * a.rows * 128 + (size_t)(nefes_train_row(W, 0, block) >> 5) * 4096 + nefes_train_lane_off(wave, j, h);
         };
         f32x16 G2[NTH], T3[NTH], T4[NTH];
-        // ---- static_rgb^T (fp32): 3+C gradients in compact slots -> d(dir_encoding output), exponent 0 ----
-        mma_run<NTH, KR, 0, true>(ring, ring_lane, ArrayIn<KR>{dr}, ZeroInit{}, G2);
-        const float M_g2 = rowb(NEFES_H3B_RGB) * pair_max(array_max(dr));
+        // ---- static_rgb^T: 3+C gradients -> d(dir_encoding output).  An fp16 two-part product like the hidden layers' since round 3
+        //      (KR16 k-steps of v_mfma_f32_32x32x16_f16 x 3; it was (3+C)/2 k-steps of the 64-cycle fp32 MFMA: a fifth of the matrix
+        //      time at C = 128).  The operand's exact maximum is known here, so its exponent is picked from it. ----
+        const float M_dr = pair_max(array_max(dr));
+        int es_g2;
+        {
+            const int ew = wexp(NEFES_H3B_RGB), tau = tau_of(M_dr, ew);
+            es_g2 = tau + ew;
+            mma_run_h3<NTH, KR16, 0, true>(ring, ring_lane, ArraySplitH<8 * KR16>{dr, pow2i(tau)}, ZeroInit{}, G2);
+        }
+        const float M_g2 = rowb(NEFES_H3B_RGB) * M_dr;
         float M = 0.f;
         int es3 = 0;
         if constexpr (HAS_T) {
@@ -297,8 +307,8 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
                 mma_run_h3<NTW + 1, GS / 8, 1, true>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{T3, bh, pow2i(tau - es3), mt}, gptr(NEFES_TB_T0), pow2i(-es3)), ZeroInit{}, XA);
             }
             load_bits(bh, MW_TRUNK, WH);
-            mma_run_h3<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{G2, bh, pow2i(tau), mg}, gptr(NEFES_TB_DIR), 1.f), ZeroInit{}, XA);
-            M = (HAS_T ? rowb(NEFES_H3B_T0) * (pair_max(mt) * pow2i(-es3)) : 0.f) + rowb(NEFES_H3B_DIR) * pair_max(mg);
+            mma_run_h3<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{G2, bh, pow2i(tau - es_g2), mg}, gptr(NEFES_TB_DIR), pow2i(-es_g2)), ZeroInit{}, XA);
+            M = (HAS_T ? rowb(NEFES_H3B_T0) * (pair_max(mt) * pow2i(-es3)) : 0.f) + rowb(NEFES_H3B_DIR) * (pair_max(mg) * pow2i(-es_g2));
         }
         // The d dir-embedding tile (XA tile 1) is complete here and nothing else reads it: its embedding backward runs NOW and three
         // numbers per lane stay, instead of a 16-register tile riding along through all nine full-width layers (round 3: with the two

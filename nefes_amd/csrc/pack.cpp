@@ -327,8 +327,16 @@ void add_backward(const Net& n, Stream& st, int x6 = 0, bool transient = true) {
     const int W = n.W, W2 = n.W2, NTW = n.NTW, NTH = n.NTH;
     // static rgb/feature head^T first (its 3+C upstream values are consumed straight after the tile's loads):
     // in = 3+C grads (compact slots), out = d g
-    const int kr = (3 + n.C + 1) / 2;
-    st.segs.push_back(seg(NTH, kr, k_compact(kr, 3 + n.C), rows_natural(NTH, W2), n.w(L_RGB), W2, true));
+    if (x6 == 2) {   // fp16 stream: natural slots, ceil((3+C)/16) k-steps of 16 (channels past 3+C are zero columns)
+        const int ks = 8 * ((3 + n.C + 15) / 16);
+        std::vector<int> k = k_natural(ks, 0);
+        for (auto& v : k) if (v >= 3 + n.C) v = -1;
+        st.segs.push_back(seg(NTH, ks, k, rows_natural(NTH, W2), n.w(L_RGB), W2, true));
+        mark(st.segs.back(), 2);
+    } else {
+        const int kr = (3 + n.C + 1) / 2;
+        st.segs.push_back(seg(NTH, kr, k_compact(kr, 3 + n.C), rows_natural(NTH, W2), n.w(L_RGB), W2, true));
+    }
     if (transient) {
     // transient heads^T: in = 5 pre-activation grads (compact slots), out = d t2
     st.segs.push_back(seg(NTH, 3, k_compact(3, 5), rows_natural(NTH, W2), n.th_w.data(), W2, true));

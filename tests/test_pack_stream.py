@@ -899,13 +899,24 @@ def test_h3_streams_reproduce_the_mlp(Wd, Cf):
              "t_sigma": gr[:, C3 + 4] * (1 - np.exp(-r[:, C3 + 4])), "t_beta": gr[:, C3 + 5] * (1 - np.exp(-r[:, C3 + 5]))}
     st = StreamH3(blob_f, info_f.stream[L.STREAM_BWD_FULL_H3], _h3_slab_kib("BWD", Wd), 16)
     w, rb = st.wexp, st.rowb
-    assert st.bias.size == 0 and w[H3B["T0"]] == w[H3B["DIR"]] and all(w[H3B[k]] == 0 for k in ("RGB", "TH", "SIG"))
+    assert st.bias.size == 0 and w[H3B["T0"]] == w[H3B["DIR"]] and all(w[H3B[k]] == 0 for k in ("TH", "SIG"))
     Z = lambda nt: np.zeros((nt, 32, n), np.float64)
     f32v = lambda v: v.astype(np.float32)
     G2 = Z(NTH)
-    st.mma32(NTH, compact([d_pre["rgbfeat"][:, k] for k in range(C3)], (C3 + 1) // 2), G2)
-    M_g2 = rb[H3B["RGB"]] * np.abs(d_pre["rgbfeat"]).max(1).astype(np.float32)
-    assert np.all(abs_max(G2, zeros) <= M_g2)
+    # static_rgb^T: an fp16 product too (round 3): ceil(C3 / 16) k-steps, natural slots, exponent from the operand's exact maximum
+    KR16 = (C3 + 15) // 16
+    dr = np.zeros((8 * KR16, 2, n), np.float32)
+    for e in range(8 * KR16):
+        for h in range(2):
+            ch = 32 * (e >> 4) + rho(h, e & 15)
+            if ch < C3:
+                dr[e, h] = d_pre["rgbfeat"][:, ch]
+    M_dr = np.abs(d_pre["rgbfeat"]).max(1).astype(np.float32)
+    tau = tau_of(M_dr, w[H3B["RGB"]])
+    es_g2 = tau + w[H3B["RGB"]]
+    st.mma(NTH, dr, tau, G2)
+    M_g2 = rb[H3B["RGB"]] * M_dr
+    assert np.all(abs_max(G2, es_g2) <= M_g2)
     T3 = Z(NTH)
     dth = [d_pre["t_rgb"][:, 0], d_pre["t_rgb"][:, 1], d_pre["t_rgb"][:, 2], d_pre["t_sigma"], d_pre["t_beta"]]
     st.mma32(NTH, compact(dth, 3), T3)
@@ -922,9 +933,9 @@ def test_h3_streams_reproduce_the_mlp(Wd, Cf):
     tau = tau_of(np.maximum(M, M_g2), w[H3B["T0"]])
     es_dt = tau + w[H3B["T0"]]
     a9 = Z(NTW + 1)
-    mt, mg = abs_max(src * masks["T0"], es), abs_max(G2 * masks["DIR"], zeros)
+    mt, mg = abs_max(src * masks["T0"], es), abs_max(G2 * masks["DIR"], es_g2)
     st.mma(NTW + 1, acc_to_vec(f32v(src * masks["T0"])), tau - es, a9)
-    st.mma(NTW + 1, acc_to_vec(f32v(G2 * masks["DIR"])), tau, a9)
+    st.mma(NTW + 1, acc_to_vec(f32v(G2 * masks["DIR"])), tau - es_g2, a9)
     M = rb[H3B["T0"]] * mt + rb[H3B["DIR"]] * mg
     assert np.all(abs_max(a9, es_dt) <= M)
     dD = acc_to_vec(f32v(a9), 0, 1) * np.exp2(-es_dt)[None, None, :]
