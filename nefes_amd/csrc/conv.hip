@@ -27,11 +27,23 @@ struct ConvArgs {
     int B, Cin, Cout, H, W, relu, cin_pad, cout_pad;
 };
 
-template <int KS>
+// One k-step = one tap of one pair of input channels (lane half kh holds channel 2s + kh).  What keeps the matrix pipe fed is the
+// instruction count per 64-cycle MFMA, so everything a load needs is hoisted out of the K loop:
+//   * the byte offset of every tap is a per-lane constant (own pixel where the tap falls outside the image, so that every load
+//     has a valid address), relative to the plane of channel 2s: the loads are `global_load_dword v, v_off, s[base]` with a
+//     wave-uniform base that advances by two planes per channel pair -- no vector address arithmetic in the loop;
+//   * zero padding is one AND of the loaded value with a per-tap, per-lane word (`vm`);
+//   * the ReLU derivative of the gradient launches (HAS_MASK) is a compare + select on the value loaded from `mask` at the same offset.
+// A stage = one tap ROW of a channel pair (KS k-steps).  Register sets for two channel pairs x KS rows: the loads of pair s + 2,
+// row ty are issued as soon as the MFMAs of pair s, row ty have consumed the set, i.e. 2 KS - 1 stages ahead (every operand
+// comes from L2; with about one wave per SIMD that latency is covered by the loads in flight, not by other waves).  The K order
+// (channel pair, tap row, tap column) and the split of the channel pairs over the four waves are those of the first version of
+// this kernel: results are bit-identical to it.
+template <int KS, bool HAS_MASK>
 __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a) {
     constexpr int PAD = KS / 2, TAPS = KS * KS;
     __shared__ float red[3][16][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, kh = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, kh = lane >> 5;
     const int HW = a.H * a.W, px_tiles = (HW + 31) / 32, co_tiles = a.cout_pad / 32;
     int bid = blockIdx.x;
     const int ptile = bid % px_tiles;
@@ -42,56 +54,82 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a) {
     const int py = pin ? p / a.W : 0, px = pin ? p - py * a.W : 0;
     const int pairs = a.cin_pad / 2;
     const int s_lo = pairs * wave / 4, s_hi = pairs * (wave + 1) / 4;          // this wave's share of the input-channel pairs
-    const float* xb = a.x + (size_t)b * a.Cin * HW;
-    const float* mb = a.mask ? a.mask + (size_t)b * a.Cin * HW : nullptr;
+    const char* xb = (const char*)(a.x + (size_t)b * a.Cin * HW);
+    const char* mb = HAS_MASK ? (const char*)(a.mask + (size_t)b * a.Cin * HW) : nullptr;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // K runs channel-pair-major: for a pair of input channels, all taps.  A stage = CPS channel pairs x TAPS k-steps, fully unrolled
-    // (no branches inside): its 2 x CPS x TAPS loads are requested while the previous stage's MFMAs issue -- every operand comes from
-    // L2 (~1 us), and with one or two waves per SIMD that latency is covered by the loads in flight, not by other waves.  The taps
-    // of one channel read neighbouring addresses of one plane; validity of a tap (zero padding) is one bit per lane, computed once.
-    constexpr int CPS = KS == 3 ? 2 : 1, NST = CPS * TAPS;      // (twice as many per stage: 119.5 -> 125 ms per 50 iterations)
-    uint32_t vbits = 0;
+    const int pa = pin ? p : HW - 1;                         // lanes past the last pixel address the last one (their loads are unused)
+    uint32_t vm[TAPS], boff[TAPS];      // vm: all ones where the tap lies inside the image (zero padding = one AND per k-step)
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
         const int iy = py + tap / KS - PAD, ix = px + tap % KS - PAD;
-        if (pin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) vbits |= 1u << tap;
+        const bool use = pin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        vm[tap] = use ? 0xffffffffu : 0u;
+        asm volatile("" : "+v"(vm[tap]));      // a vector register, not a lane mask in two scalar ones: 25 of those spill at 5x5
+        boff[tap] = (uint32_t)(kh * HW + (use ? iy * a.W + ix : pa)) * 4u;
     }
-    const int pa = pin ? p : HW - 1;                         // lanes past the last pixel address the last one (their loads are unused)
-    const float* xp = xb + pa - (PAD * a.W + PAD);           // tap (ty, tx) of channel ci: xp[ci * HW + ty * W + tx]
-    const float* mp = mb ? mb + pa - (PAD * a.W + PAD) : nullptr;
-    const float* wl = a.wp + cot * 32 + n;                   // wl[(ci * TAPS + tap) * cout_pad]
-    auto fetch = [&](int s0, float (&av)[NST], float (&bv)[NST]) __attribute__((always_inline)) {
+    // an odd channel count: the upper lane half of the last pair has no channel (its weights are zero rows of the packed array);
+    // it reads the pair's first channel instead of the plane behind the image
+    const uint32_t tail_sub = (a.Cin & 1) ? (uint32_t)(kh * HW) * 4u : 0u;
+    const uint32_t woff = (uint32_t)(kh * TAPS * a.cout_pad + cot * 32 + n) * 4u;     // + ((2 s) TAPS + tap) cout_pad floats
+    const size_t plane2 = (size_t)2 * HW * 4, wpair = (size_t)2 * TAPS * a.cout_pad * 4, wtap = (size_t)a.cout_pad * 4;
+
+    float xv[2][KS][KS], wv[2][KS][KS], mv[2][KS][KS];
+    // xs / ms / wrow: wave-uniform bases (plane of channel 2s; first weight of the tap row), every load = base + a per-lane offset
+    auto load_row = [&](const char* xs, const char* ms, const char*& wrow, uint32_t sub, int ty, float (&xr)[KS], float (&wr)[KS],
+                        float (&mr)[KS]) __attribute__((always_inline)) {
+        uint32_t wo = woff;
+        asm volatile("" : "+v"(wo));            // keeps the zero-extension next to the loads: base in SGPRs + 32-bit lane offset
 #pragma unroll
-        for (int c = 0; c < CPS; ++c) {
-            const int s = s0 + c;
-            const bool live = s < s_hi;
-            const int ci = 2 * (live ? s : s_lo) + kh;
-            const bool chan = live && ci < a.Cin;
-            const float* xc = xp + (size_t)(chan ? ci : 0) * HW;
-            const float* mc = mp ? mp + (size_t)(chan ? ci : 0) * HW : nullptr;
-            const float* wc = wl + (size_t)ci * TAPS * a.cout_pad;
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const bool use = chan && ((vbits >> tap) & 1u);
-                const int o = use ? (tap / KS) * a.W + tap % KS : PAD * a.W + PAD;      // (unused: the lane's own pixel, a valid address)
-                float v = xc[o];
-                if (mc) v = mc[o] > 0.f ? v : 0.f;
-                bv[c * TAPS + tap] = use ? v : 0.f;
-                av[c * TAPS + tap] = wc[(size_t)tap * a.cout_pad];
-            }
+        for (int tx = 0; tx < KS; ++tx) {
+            const uint32_t o = boff[ty * KS + tx] - sub;
+            xr[tx] = *(const float*)(xs + o);
+            if (HAS_MASK) mr[tx] = *(const float*)(ms + o);
+            wr[tx] = *(const float*)(wrow + wo);
+            wrow += wtap;
         }
     };
-    float a0[NST], b0[NST], a1[NST], b1[NST];
-    fetch(s_lo, a0, b0);
-    for (int s = s_lo; s < s_hi; s += 2 * CPS) {
-        fetch(s + CPS, a1, b1);
+    auto mma_row = [&](int ty, const float (&xr)[KS], const float (&wr)[KS], const float (&mr)[KS]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < NST; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
-        fetch(s + 2 * CPS, a0, b0);
+        for (int tx = 0; tx < KS; ++tx) {
+            uint32_t v = __float_as_uint(xr[tx]) & vm[ty * KS + tx];
+            if (HAS_MASK) v = mr[tx] > 0.f ? v : 0u;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[tx], __uint_as_float(v), acc, 0, 0, 0);
+        }
+    };
+    // bases of channel pair sn (wave-uniform): plane of channel 2 sn, first weight of the pair
+    auto pair_bases = [&](int sn, const char*& xs, const char*& ms, const char*& wrow, uint32_t& sub) __attribute__((always_inline)) {
+        const size_t so = (size_t)sn * plane2;
+        xs = xb + so;
+        ms = HAS_MASK ? mb + so : nullptr;
+        wrow = (const char*)a.wp + (size_t)sn * wpair;
+        sub = sn == pairs - 1 ? tail_sub : 0u;
+    };
 #pragma unroll
-        for (int u = 0; u < NST; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0);   // (past the end: zeros)
+    for (int pr = 0; pr < 2; ++pr)
+        if (s_lo + pr < s_hi) {                                                  // wave-uniform
+            const char *xs, *ms, *wrow;
+            uint32_t sub;
+            pair_bases(s_lo + pr, xs, ms, wrow, sub);
+#pragma unroll
+            for (int ty = 0; ty < KS; ++ty) load_row(xs, ms, wrow, sub, ty, xv[pr][ty], wv[pr][ty], mv[pr][ty]);
+        }
+    for (int s = s_lo; s < s_hi; s += 2) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            if (s + pr < s_hi) {                                                 // wave-uniform
+                const bool nxt = s + pr + 2 < s_hi;
+                const char *xs, *ms, *wrow;
+                uint32_t sub;
+                pair_bases(nxt ? s + pr + 2 : s + pr, xs, ms, wrow, sub);
+#pragma unroll
+                for (int ty = 0; ty < KS; ++ty) {
+                    mma_row(ty, xv[pr][ty], wv[pr][ty], mv[pr][ty]);
+                    if (nxt) load_row(xs, ms, wrow, sub, ty, xv[pr][ty], wv[pr][ty], mv[pr][ty]);
+                }
+            }
+        }
     }
     if (wave > 0) {
 #pragma unroll
@@ -127,7 +165,9 @@ extern "C" int nefes_conv2d_same(int B, int Cin, int Cout, int H, int W, int ksi
     const long long blocks = (long long)B * (a.cout_pad / 32) * (((long long)H * W + 31) / 32);
     if (blocks > 0x7fffffffll) return NEFES_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (ksize == 3) hipLaunchKernelGGL(conv2d_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(conv2d_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (ksize == 3 && !mask) hipLaunchKernelGGL((conv2d_kernel<3, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else if (ksize == 3) hipLaunchKernelGGL((conv2d_kernel<3, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else if (!mask) hipLaunchKernelGGL((conv2d_kernel<5, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv2d_kernel<5, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
