@@ -283,11 +283,13 @@ def test_pose_refiner_option_matrix(golden, upsample, encode_hist, world):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,k,relu,H,W", [(1, 131, 64, 3, True, 60, 80), (1, 64, 64, 3, True, 60, 80), (1, 64, 128, 5, False, 60, 80),
-                                                   (3, 19, 64, 3, True, 17, 23), (2, 64, 16, 5, False, 9, 70)])
+                                                   (3, 19, 64, 3, True, 17, 23), (2, 64, 16, 5, False, 9, 70),
+                                                   (1, 1, 1, 5, True, 3, 3), (3, 9, 33, 5, True, 7, 11), (2, 7, 5, 3, False, 13, 9)])
 def test_frozen_conv_matches_float64(B, Cin, Cout, k, relu, H, W):
     """csrc/conv.hip (ops.frozen_conv2d): Conv2d(stride 1, same padding)[+ReLU] forward and input gradient against torch's
     convolution in float64; torch's own fp32 GPU convolution (MIOpen) measured beside it.  Ragged sizes: odd channel counts,
-    channel counts that are no multiple of 32, a pixel count that is no multiple of 32, images narrower than a pixel tile."""
+    channel counts that are no multiple of 32, a pixel count that is no multiple of 32, images narrower than a pixel tile; a single
+    channel, fewer channel pairs than the four waves that split them, an image smaller than the 5x5 kernel."""
     from nefes_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + Cin + k)
     x = torch.randn(B, Cin, H, W, generator=g)
