@@ -79,7 +79,6 @@ class FeatureLoss(nn.Module):
 
 
 class PoseRefiner:
-    FUSED_UPSAMPLED_LOSS = True      # False: bicubic up-sampling and cosine loss as separate kernels (the tests compare the two)
     """`refine(init_c2w, feature_target, hist, iters)` -> (refined 4x4 c2w, losses [iters]) for one query image, or for
     `images=B` of them side by side (see refine()).
 
@@ -94,6 +93,8 @@ class PoseRefiner:
     `DFM_post_processing` records for the image: the refined network's pose, or the initial one when the verification step
     finds PSNR or SSIM of the up-sampled render lower after the loop than before (:233-250).  The network itself is the
     caller's (a CNN outside this path); implies `upsample=True`."""
+
+    FUSED_UPSAMPLED_LOSS = True      # False: bicubic up-sampling and cosine loss as separate kernels (the tests compare the two)
 
     def __init__(self, render_kwargs, args, hwf, near, far, tinyscale=4, lr_r=0.01, lr_t=0.1, lietorch=False,
                  upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda", adam_capturable=None,
@@ -298,7 +299,9 @@ class PoseRefiner:
         """Loss at the working network's current parameters; gradients into their .grad (no optimizer step)."""
         loss, _ = self._loss()
         params = [p for p in self.apr.parameters() if p.requires_grad]
-        for p, g in zip(params, torch.autograd.grad(loss, params)):
+        # loss.backward() in the reference (train_on_batch, DFM_pose_refine.py:318) tolerates parameters the loss never touches --
+        # DFNet's adaptation_layers with return_feature=False (feature/dfnet.py:142): their .grad stays None and Adam skips them
+        for p, g in zip(params, torch.autograd.grad(loss, params, allow_unused=True)):
             p.grad = g
         self.loss.copy_(loss.detach())
         return self.loss
@@ -333,6 +336,8 @@ class PoseRefiner:
             self.target.copy_(feature_target.to(dev).reshape(self.C, self.H, self.W)[:, 10:-10, 10:-10])
             for pw, pb in zip(self.apr.parameters(), self.apr_base.parameters()):
                 pw.copy_(pb.to(dev))                                       # a fresh copy of the network per image (:209)
+            for bw, bb in zip(self.apr.buffers(), self.apr_base.buffers()):
+                bw.copy_(bb.to(dev))                                       # deepcopy resets BatchNorm statistics too
             self.hist.copy_(hist.to(dev).reshape(1, 10))
             expo = getattr(self.coarse, "exposure_embedding", None)
             if (self.fused_glue and getattr(self.args, "encode_hist", False) and expo is not None

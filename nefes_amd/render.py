@@ -27,6 +27,7 @@ MEMORY_FRACTION = 0.6          # share of the free device memory one launch sequ
 
 
 _STEP = {}
+_PER_RAY = {}
 
 
 def rays_per_launch(cfg, network_fn, network_fine, device, train=False):
@@ -48,12 +49,31 @@ def rays_per_launch(cfg, network_fn, network_fine, device, train=False):
     if train:
         per_sample += 4 * (64 + 32 + 9 * Wd + 2 * Wd + 32 * ((3 + C + 31) // 32) + 64) * 2
     per_ray = per_sample * S + (cfg.N_samples * 4) * 4 + 256
+    _PER_RAY[key] = per_ray
     try:
         total = torch.cuda.get_device_properties(dev).total_memory
     except Exception:
         return MAX_RAYS_PER_LAUNCH
     _STEP[key] = int(max(1024, min(MAX_RAYS_PER_LAUNCH, (total * MEMORY_FRACTION) // per_ray)))
     return _STEP[key]
+
+
+def _clamp_to_free_memory(step, cfg, network_fn, network_fine, device):
+    """Inference without jitter or noise draws nothing from the RNG, so where the batch is split changes no result: there the
+    deterministic plan is additionally bounded by what is FREE right now (the feature extractor, APR copies, graph pools or
+    another rank may share the device), instead of handing the allocator one launch it cannot serve."""
+    net = network_fine if (network_fine is not None and cfg.N_importance > 0) else network_fn
+    S = cfg.N_samples + cfg.N_importance if not cfg.use_fine_only or cfg.N_importance == 0 else cfg.N_importance
+    dev = torch.device(device)
+    per_ray = _PER_RAY.get((net.W, net.W_features, S, cfg.N_samples, False, dev.type, dev.index))
+    if per_ray is None:
+        return step
+    try:
+        free, _ = torch.cuda.mem_get_info(dev)
+        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # torch's own cache is reusable
+    except Exception:
+        return step
+    return int(max(1024, min(step, (free * 0.8) // per_ray)))
 
 
 def _cfg(kwargs):
@@ -68,6 +88,14 @@ def _cfg(kwargs):
         transient_at_test=bool(g("transient_at_test", False)),
         # BASELINE config 4: a hash-grid (ops.HashGrid) in front of the same MLP instead of the frequency embedding
         xyz_encoder=kwargs.get("xyz_encoder", None))
+
+
+def _trainable(net):
+    """True when a render would run the train-mode instances for `net`: autograd is recording AND one of the field's own weights
+    asks for a gradient (the FusionNet / exposure sub-modules hang off the same nn.Module but are not part of the field)."""
+    return (torch.is_grad_enabled() and net is not None
+            and any(p.requires_grad for n, p in net.named_parameters()
+                    if not n.startswith(("fusion_net", "exposure_embedding"))))
 
 
 def _field(pk, mode, rays_o, rays_d, viewdirs, z, xyz_encoder):
@@ -87,10 +115,7 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
     # Trainable NeRF weights (run_nefes.py) go through the train-mode instances: forward with saved pre-activations and
     # the weight-gradient kernels of csrc/train.hip.  Frozen weights (refinement loop, DFM_APR_refine.py:192-193) use the
     # fused backward-to-rays path.
-    def trainable(net):
-        return (torch.is_grad_enabled() and net is not None
-                and any(p.requires_grad for n, p in net.named_parameters()
-                        if not n.startswith(("fusion_net", "exposure_embedding"))))
+    trainable = _trainable
 
     def field(net, pk, mode, z_):
         if trainable(net) and mode != L.FIELD_SIGMA:
@@ -183,7 +208,7 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     cfg = _cfg(dict(kwargs, N_samples=kwargs.get("N_samples", 64)))
     rays_flat = rays_flat.to(_DEV)
     step = rays_per_launch(cfg, kwargs["network_fn"], kwargs.get("network_fine", None), rays_flat.device,
-                           train=not cfg.test_time)
+                           train=_trainable(kwargs["network_fn"]) or _trainable(kwargs.get("network_fine", None)))
     return _cat_parts([render_rays(rays_flat[i:i + step], **kwargs) for i in range(0, rays_flat.shape[0], step)])
 
 
@@ -198,8 +223,12 @@ def _rays_for(H, W, focal, c2w, c2w_staticcam, row_range):
 def _render_batch(rays_o, rays_d, viewdirs, near, far, chunk, kwargs, cfg):
     network_fn, network_fine = kwargs["network_fn"], kwargs.get("network_fine", None)
     N = rays_o.shape[0]
-    trains = any(p.requires_grad for net in (network_fn, network_fine) if net is not None for p in net.parameters())
+    # the same predicate _render_core dispatches on: a validation render under torch.no_grad() with trainable networks
+    # (run_nefes.py:427,467 -> render_path, rendering.py:350,588) saves nothing and is sliced like any inference batch
+    trains = _trainable(network_fn) or _trainable(network_fine)
     step = rays_per_launch(cfg, network_fn, network_fine, rays_o.device, train=trains)
+    if not trains and cfg.perturb == 0. and cfg.raw_noise_std == 0.:
+        step = _clamp_to_free_memory(step, cfg, network_fn, network_fine, rays_o.device)
     if trains and N > step:
         # every slice's saved activations live until backward(): slicing would not bound the peak, so say it instead of dying later
         raise RuntimeError(f"nefes_amd: a train-mode batch of {N} rays needs more than {MEMORY_FRACTION:.0%} of the device memory for "

@@ -242,3 +242,34 @@ def test_mode2_population_of_50_iteration_runs(golden):
         assert abs(info["psnr"][0] - g["m2_psnr"][k, 0]) < 2e-3 and abs(info["psnr"][1] - g["m2_psnr"][k, -1]) < 5e-2, (info, g["m2_psnr"][k, [0, -1]])
         assert rel(losses.cpu().numpy(), g["m2_loss"][k]) < 2e-3
     population_check("refine50_mode2", g, poses, g["m2_final"], g["m2_final_f64"])
+
+
+class AprWithUnusedHead(TinyAPR):
+    """DFNet-shaped in the two ways ADVICE r3 names: a sub-module the pose output never touches (DFNet's adaptation_layers with
+    return_feature=False, feature/dfnet.py:142) and a buffer the forward updates (BatchNorm statistics in train mode)."""
+
+    def __init__(self, weight, bias):
+        super().__init__(weight, bias)
+        self.adaptation = torch.nn.Linear(12, 4)
+        self.register_buffer("calls", torch.zeros((), dtype=torch.int64))
+
+    def forward(self, x):
+        self.calls += 1
+        return super().forward(x)
+
+
+def test_apr_with_unused_parameters_and_buffers(golden):
+    """`train_on_batch` uses loss.backward(): parameters outside the loss keep .grad None and Adam skips them; every query image
+    starts from deepcopy(model) (DFM_APR_refine.py:209), buffers included."""
+    g = golden("refine50")
+    photo, tgt = photo_of(g), target_full(g)
+    apr = AprWithUnusedHead(g["m2_weight"][0], g["m2_bias"][0])
+    ref = refiner(g, apr=apr)
+    w0 = apr.adaptation.weight.detach().clone()
+    pose_a, losses_a, _ = ref.refine_apr(photo, tgt, T(g["hist"]), 3)
+    calls_a = int(ref.apr.calls)
+    assert ref.apr.adaptation.weight.grad is None and torch.equal(ref.apr.adaptation.weight.detach().cpu(), w0)
+    assert rel(losses_a.cpu().numpy(), g["m2_loss"][0, :3]) < 2e-3
+    pose_b, losses_b, _ = ref.refine_apr(photo, tgt, T(g["hist"]), 3)
+    assert int(ref.apr.calls) == calls_a and int(ref.apr_base.calls) == 0                  # not carried over from image to image
+    assert torch.equal(pose_a, pose_b) and torch.equal(losses_a, losses_b)

@@ -301,6 +301,41 @@ def test_memory_bounded_batching_gives_the_same_maps(monkeypatch):
         R.render(H, W, focal, c2w=c2w, near=0., far=4., **dict(kw, test_time=False, perturb=1.))
 
 
+def test_no_grad_render_with_trainable_networks_is_sliced_not_refused(monkeypatch):
+    """the validation renders of a training run (run_nefes.py:427,467 -> render_path under torch.no_grad(), networks still
+    requiring grad) are inference: planned with the inference budget, sliced when larger than it, bit-identical to one launch."""
+    R, M, _ = dropin()
+    import nefes_amd.render as NR
+    coarse, fine = nets(128, 128)
+    coarse.requires_grad_(True)
+    fine.requires_grad_(True)
+    kw = dict(kwargs(M, coarse, fine, 64), use_viewdirs=True, ndc=False)
+    H, W, focal = 40, 64, 50.0
+    c2w = O.bench_pose().to(DEV)
+    seen = []
+
+    def plan(cfg, a, b, dev, train=False):
+        seen.append(train)
+        return 1024
+    with torch.no_grad():
+        a = R.render(H, W, focal, c2w=c2w, near=0., far=4., **kw)
+        monkeypatch.setattr(NR, "rays_per_launch", plan)
+        b = R.render(H, W, focal, c2w=c2w, near=0., far=4., **kw)                      # 2560 rays > 1024: three slices
+        c = R.render(H, W, focal, c2w=c2w, near=0., far=4., **dict(kw, test_time=False))
+    assert seen == [False, False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[3]["feat_map"], b[3]["feat_map"]) and c[0].shape == a[0].shape
+    assert not a[0].requires_grad
+    # free-memory clamp of the inference plan: never above the deterministic plan, never below the floor
+    monkeypatch.undo()
+    cfg = NR._cfg(kw)
+    cap = NR.rays_per_launch(cfg, coarse, fine, torch.device(DEV))
+    assert 1024 <= NR._clamp_to_free_memory(cap, cfg, coarse, fine, torch.device(DEV)) <= cap
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a: (1 << 20, 1 << 38))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda *a: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda *a: 0)
+    assert NR._clamp_to_free_memory(cap, cfg, coarse, fine, torch.device(DEV)) == 1024
+
+
 def test_merge_with_nans_fills_every_slot():
     """NaN depths take the all-pairs rank; torch.sort puts NaNs last and fills every slot -- so must the kernel."""
     from nefes_amd import ops
