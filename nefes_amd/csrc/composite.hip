@@ -679,10 +679,11 @@ __global__ __launch_bounds__(256) void composite_bwd4_kernel(CompArgs p) {
 #ifndef NEFES_COMPOSITE_LEGACY
 #define NEFES_COMPOSITE_LEGACY 0      /* 1: one sample per lane for every S (A/B builds) */
 #endif
+#define NEFES_COMP_MAX_S 512           /* one sample per lane in up to eight passes; four per lane (S % 64 == 0) up to 256 */
 static bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 static int comp_args(CompArgs& a, int N, int S, int C, uint32_t flags) {
     if (N <= 0 || S <= 1 || C < 0) return NEFES_E_BADARG;
-    if (S > 256) return NEFES_E_UNSUPPORTED;
+    if (S > NEFES_COMP_MAX_S) return NEFES_E_UNSUPPORTED;      // (the sampler's bound too: sample_pdf.hip SP_MAX_S)
     a.N = N; a.S = S; a.C = C; a.flags = flags;
     a.R = (flags & NEFES_COMP_SIGMA_ONLY) ? 1 : ((flags & NEFES_COMP_TRANSIENT) ? 3 + C + 6 : 3 + C + 1);
     return 0;
@@ -701,7 +702,7 @@ extern "C" int nefes_composite_fwd(int N, int S, int C, uint32_t flags, float be
     const int n_split = (feat && C >= 64 && N < 40000) ? ((C + 31) / 32 < 4 ? (C + 31) / 32 : 4) : 1;
     const dim3 grid((N + 3) / 4, n_split), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (S % 64 == 0 && !NEFES_COMPOSITE_LEGACY && aligned16(raw_t) && aligned16(z) && aligned16(weights)) {   // four samples per lane
+    if (S % 64 == 0 && S <= 256 && !NEFES_COMPOSITE_LEGACY && aligned16(raw_t) && aligned16(z) && aligned16(weights)) {   // four samples per lane
         const int rw = S / 64, rpw = 4 / rw;
         const dim3 grid4((N + 4 * rpw - 1) / (4 * rpw), n_split);
         switch (rw) {
@@ -716,7 +717,11 @@ extern "C" int nefes_composite_fwd(int N, int S, int C, uint32_t flags, float be
         case 1: hipLaunchKernelGGL(composite_fwd_kernel<1>, grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL(composite_fwd_kernel<2>, grid, block, 0, st, a); break;
         case 3: hipLaunchKernelGGL(composite_fwd_kernel<3>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(composite_fwd_kernel<4>, grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(composite_fwd_kernel<4>, grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL(composite_fwd_kernel<5>, grid, block, 0, st, a); break;      // 64 + 256 samples
+        case 6: hipLaunchKernelGGL(composite_fwd_kernel<6>, grid, block, 0, st, a); break;      // 128 + 256
+        case 7: hipLaunchKernelGGL(composite_fwd_kernel<7>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(composite_fwd_kernel<8>, grid, block, 0, st, a); break;
     }
     return (int)hipGetLastError();
 }
@@ -733,7 +738,7 @@ extern "C" int nefes_composite_bwd(int N, int S, int C, uint32_t flags, const fl
     a.g_depth = g_depth; a.g_weights = g_weights; a.g_beta = g_beta; a.g_raw_t = g_raw_t;
     const dim3 grid((N + 3) / 4), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (S % 64 == 0 && !NEFES_COMPOSITE_LEGACY && aligned16(raw_t) && aligned16(z) && aligned16(g_raw_t) && aligned16(g_weights)) {
+    if (S % 64 == 0 && S <= 256 && !NEFES_COMPOSITE_LEGACY && aligned16(raw_t) && aligned16(z) && aligned16(g_raw_t) && aligned16(g_weights)) {
         const int rw = S / 64, rpw = 4 / rw;
         const dim3 grid4((N + 4 * rpw - 1) / (4 * rpw));
         switch (rw) {
@@ -748,7 +753,11 @@ extern "C" int nefes_composite_bwd(int N, int S, int C, uint32_t flags, const fl
         case 1: hipLaunchKernelGGL(composite_bwd_kernel<1>, grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL(composite_bwd_kernel<2>, grid, block, 0, st, a); break;
         case 3: hipLaunchKernelGGL(composite_bwd_kernel<3>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(composite_bwd_kernel<4>, grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(composite_bwd_kernel<4>, grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL(composite_bwd_kernel<5>, grid, block, 0, st, a); break;      // 64 + 256 samples
+        case 6: hipLaunchKernelGGL(composite_bwd_kernel<6>, grid, block, 0, st, a); break;      // 128 + 256
+        case 7: hipLaunchKernelGGL(composite_bwd_kernel<7>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(composite_bwd_kernel<8>, grid, block, 0, st, a); break;
     }
     return (int)hipGetLastError();
 }

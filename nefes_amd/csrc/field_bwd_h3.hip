@@ -4,8 +4,8 @@
 // (field_bwd.hip); the transposed products of transient_encoding.{4,2,0}, dir_encoding, xyz_encoding_final and layers 8..1 run on
 // v_mfma_f32_32x32x16_f16 as hh + hl + lh of power-of-two scaled (hi, lo) fp16 pairs; the three narrow head products (3+C, 5 and
 // 1 k-values) stay on the fp32 MFMA.  Every gradient vector carries a per-lane scale exponent (field_h3.h).
-#if defined(NEFES_TU_PART) && (NEFES_TU_PART == 2 || NEFES_TU_PART == 4)
-#define NEFES_SLAB_KIB 16      // the Wd = 128 instances (layout.h NEFES_H3_BWD_SLAB_KIB_128)
+#if defined(NEFES_TU_PART) && NEFES_TU_PART >= 2 && NEFES_TU_PART % 2 == 0
+#define NEFES_SLAB_KIB 16      // even parts from 2 on: the Wd = 128 instances (layout.h NEFES_H3_BWD_SLAB_KIB_128)
 #else
 #define NEFES_SLAB_KIB 32
 // The Wd = 256 inference objects (parts 0, 1) run their 8-/10-tile products on field_h3.h's gap-by-gap schedule (asm MFMAs on AGPR
@@ -14,7 +14,7 @@
 // runs -- behind an MFMA that has not written them yet.  So the three embedding-gradient tiles are consumed
 // where they are produced (below), layer 5's two extra output tiles live in VGPRs for the length of that run, and
 // tests/test_pack_stream.py disassembles the library and fails if a v_accvgpr_mov shows up in these kernels.
-#if !defined(NEFES_TU_PART) || NEFES_TU_PART == 0 || NEFES_TU_PART == 1
+#if !defined(NEFES_TU_PART) || NEFES_TU_PART == 0 || NEFES_TU_PART == 1 || NEFES_TU_PART == 5
 #define H3B_WIDE
 #define H3_ACC_READ_ASM        // source tiles are read out of their AGPRs inside the MFMA gaps (field_h3.h acc_read)
 #define H3_WIDE_ENTRY_FENCE    // wide runs follow compiler-scheduled segments here (field_h3.h mma_run_h3_wide)
@@ -32,7 +32,12 @@
 #define H3B_WIDE_LAYERS 0x1ff   /* bit L: layer L's transposed product on the gap-by-gap schedule; bit 0: xyz_encoding_final's (debugging) */
 #endif
 #ifndef NEFES_H3B_WG128
-#define NEFES_H3B_WG128 1      /* workgroups per CU of the Wd = 128 instances; 2 fits only with ~100 registers spilled to scratch and measured no gain (0.744 vs 0.741 ms on the 80x60 frame) */
+// Workgroups per CU of the Wd = 128 instances.  Rounds 2-3: 2 needed ~100 registers spilled to scratch and measured no gain.  Round 4:
+// with C a run-time value the per-channel row offsets and channel tests of the tile's loads are recomputed per tile by the scalar ALU
+// instead of being hoisted into ~150 (spilled) registers, the kernel needs 232-242 VGPRs, and two workgroups per CU -- one wave's
+// vector work under the other's MFMAs, as in the forward -- measure 0.618 vs 0.684 ms on the 80x60 frame (A/B on one box against the
+// round-3 library; the same source at one workgroup per CU: 0.72).
+#define NEFES_H3B_WG128 2
 #endif
 #define NEFES_H3B_WG_PER_CU(W) ((W) == 128 ? NEFES_H3B_WG128 : 1)
 #define NEFES_H3B_SLOTS 2   // 64 KiB ring (StagedRing: two slots) + the tile's ReLU masks and the scale table
@@ -106,13 +111,17 @@ __device__ __forceinline__ T ld_stream(const T* p) {
 
 // HAS_T = false: the static head only (NEFES_FIELD_STATIC forward: raw channels rgb+feature, sigma); the stream then is
 // NEFES_STREAM_BWD_STATIC_H3 and the transient segments are absent.  TRAIN: see StoringSplitH.
-template <int W, int C3, int ENC, bool HAS_T = true, bool TRAIN = false>   // C3 = 3 + C; ENC = NEFES_XYZ_*
+// KR16 = k-steps of 16 upstream channels of static_rgb^T = the head class of layout.h (2: 3 + C <= 32; 9: 3 + C <= 144); C itself is
+// a run-time argument (a.C).  ENC = NEFES_XYZ_*
+template <int W, int KR16, int ENC, bool HAS_T = true, bool TRAIN = false>
 __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kernel(FieldBwdH3Args a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
     constexpr int WT = (NTW + 1) / 2, WH = (NTH + 1) / 2;   // mask words per trunk / half-width layer
     constexpr int MW_TRUNK = 8 * WT;
-    constexpr int NTR = (C3 + 31) / 32, KR16 = (C3 + 15) / 16;      // static rgb/feature head^T: 3+C upstream channels as fp16 k-steps
+    constexpr int NTR = KR16 <= 2 ? 1 : 5;                          // tiles of the rgb+feature head block in `dacts` (TRAIN)
+    static_assert(KR16 == 2 || KR16 == 9, "head classes of layout.h (nefes_head_kr16 / nefes_head_ntr)");
+    const int C3 = 3 + a.C;                                         // static rgb/feature head^T: 3+C upstream channels as fp16 k-steps
     static_assert(MW % 4 == 0, "mask words are staged as 16-byte groups");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -169,13 +178,26 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
         }
         y_sg = ld_stream(&a.raw_t[chan0 + (size_t)C3 * a.S]);
         g_sg = ld_stream(&a.g_raw_t[chan0 + (size_t)C3 * a.S]);
-        // element e of this lane <-> static rgb/feature channel 32 (e / 16) + rho_h(e % 16): the natural slot order of the fp16 operands
+        // element e of this lane <-> static rgb/feature channel 32 (e / 16) + rho_h(e % 16): the natural slot order of the fp16 operands.
+        // Addressing: the channel's row offset ch0 * S is wave-uniform (scalar ALU), the lane half's + 4 rows is one per-lane pointer.
+        // S passes through an opaque asm once per tile: with C a run-time value hipcc otherwise hoists the 8 * KR16 per-lane 64-bit
+        // row offsets out of the tile loop (144 registers at KR16 = 9, spilled to scratch -- seen in the disassembly).
+        // (the same for 3 + C, whose 2 x 8 KR16 wave-uniform comparisons would be hoisted into spilled scalar registers)
+        {
+            int S_t = a.S, c3 = C3;
+            asm volatile("" : "+s"(S_t), "+s"(c3));
+            const float* g0 = a.g_raw_t + chan0;
+            const float* g4 = g0 + (size_t)(4 * h) * S_t;
 #pragma unroll
-        for (int e = 0; e < 8 * KR16; ++e) {
-            const int ch0 = 32 * (e >> 4) + nefes_rho(0, e & 15);              // lane half 1: + 4
-            if (ch0 >= C3) { dr[e] = 0.f; continue; }
-            const int ch = ch0 + 4 * h;
-            dr[e] = ld_stream(&a.g_raw_t[chan0 + (size_t)(ch < C3 ? ch : C3 - 1) * a.S]);
+            for (int e = 0; e < 8 * KR16; ++e) {
+                const int ch0 = 32 * (e >> 4) + nefes_rho(0, e & 15);          // lane half 1: + 4
+                if (ch0 >= c3) dr[e] = 0.f;
+                else if (ch0 + 4 < c3) dr[e] = ld_stream(g4 + (size_t)ch0 * S_t);
+                else {                                                         // row ch0 + 4 lies past the last channel
+                    const float lo = ld_stream(g0 + (size_t)ch0 * S_t);
+                    dr[e] = h == 0 ? lo : 0.f;
+                }
+            }
         }
         uint4 mq[MW / 4];
         {
@@ -196,8 +218,6 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
 #pragma unroll
             for (int e = 0; e < 8 * KR16; ++e) dr[e] = 0.f;
         }
-#pragma unroll
-        for (int e = 0; e < 8 * KR16; ++e) dr[e] = (32 * (e >> 4) + nefes_rho(h, e & 15) < C3) ? dr[e] : 0.f;
         // head activation derivatives from the outputs: sigmoid' = y(1-y), softplus' = 1 - exp(-y)
         float dth[3];
         if (h == 0) {   // rows 0 (rgb_t0), 2 (rgb_t2), 4 (beta)
@@ -223,15 +243,15 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
             // G of static_rgb / static_sigma / the transient heads.  They are in registers here (compact slots: row 2s + h), so
             // they are stored here: the separate head-gradient pass (train.hip train_head_grad_kernel) re-read d raw and raw_t.
             float* dt_ = a.dacts + (size_t)tile * a.rows * 128 + (size_t)(((wave * 32 + j) >> 4) * 512 + h * 16 + (j & 15));
-            float* prgb = a.dacts + (size_t)tile * a.rows * 128 + (size_t)(nefes_train_row(W, C3 - 3, NEFES_TB_RGB) >> 5) * 4096 + nefes_train_lane_off(wave, j, h);
+            float* prgb = a.dacts + (size_t)tile * a.rows * 128 + (size_t)(nefes_train_row(W, a.C, NEFES_TB_RGB) >> 5) * 4096 + nefes_train_lane_off(wave, j, h);
 #pragma unroll
             for (int e = 0; e < 16 * NTR; ++e)      // row 32 (e / 16) + rho_h(e % 16)
                 __builtin_nontemporal_store(e < 8 * KR16 ? dr[e < 8 * KR16 ? e : 0] : 0.f, &prgb[(e >> 4) * 4096 + nefes_rho(0, e & 15) * 16]);
-            float* psig = dt_ + (size_t)(nefes_train_row(W, C3 - 3, NEFES_TB_SIG) >> 5) * 4096;
+            float* psig = dt_ + (size_t)(nefes_train_row(W, a.C, NEFES_TB_SIG) >> 5) * 4096;
 #pragma unroll
             for (int s = 0; s < 16; ++s) __builtin_nontemporal_store(s == 0 ? d_sigma : 0.f, &psig[2 * s * 16]);
             if constexpr (HAS_T) {
-                float* pth = dt_ + (size_t)(nefes_train_row(W, C3 - 3, NEFES_TB_TH) >> 5) * 4096;
+                float* pth = dt_ + (size_t)(nefes_train_row(W, a.C, NEFES_TB_TH) >> 5) * 4096;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) __builtin_nontemporal_store(s < 3 ? dth[s < 3 ? s : 0] : 0.f, &pth[2 * s * 16]);
             }
@@ -424,10 +444,10 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
     ring.drain();
 }
 
-template <int W, int C3, int ENC, bool HAS_T = true, bool TRAIN = false>
+template <int W, int KR16, int ENC, bool HAS_T = true, bool TRAIN = false>
 static int launch_bwd_h3(const FieldBwdH3Args& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_H3B_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (8 * (W / 64) + 4 * (W / 128) + 8) * 256 + 256;
-    auto k = field_bwd_h3_kernel<W, C3, ENC, HAS_T, TRAIN>;
+    auto k = field_bwd_h3_kernel<W, KR16, ENC, HAS_T, TRAIN>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -440,37 +460,64 @@ static int launch_bwd_h3(const FieldBwdH3Args& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// Instances spread over three objects built from this one source (Makefile: -DNEFES_TU_PART=0..2): part 0 = entry point + the
-// Wd = 256 frequency-embedding instance, part 1 = hash-grid instance, part 2 = Wd = 128 instance.
+// Instances spread over nine objects built from this one source (Makefile: -DNEFES_TU_PART=0..8; even parts from 2 on are the
+// Wd = 128 objects): part 0 = entry points + Wd = 256 / head class 0, part 1 = hash-grid instance, part 2 = Wd = 128 / class 1,
+// parts 3 / 4 = their TRAIN instances, parts 5 / 6 = Wd = 256 / class 1 and Wd = 128 / class 0, parts 7 / 8 = their TRAIN instances.
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { BWD_H3_256_EXT = 0, BWD_H3_128, BWD_H3_TRAIN_STATIC, BWD_H3_TRAIN_FULL };
+enum { BWD_H3_EXT = 0, BWD_H3_FULL, BWD_H3_TRAIN_STATIC, BWD_H3_TRAIN_FULL };
 int nefes_bwd_h3_launch_part1(int which, const FieldBwdH3Args& a, hipStream_t st);
 int nefes_bwd_h3_launch_part2(int which, const FieldBwdH3Args& a, hipStream_t st);
-int nefes_bwd_h3_launch_part3(int which, const FieldBwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256
-int nefes_bwd_h3_launch_part4(int which, const FieldBwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 128
+int nefes_bwd_h3_launch_part3(int which, const FieldBwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256, class 0
+int nefes_bwd_h3_launch_part4(int which, const FieldBwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 128, class 1
+int nefes_bwd_h3_launch_part5(int which, const FieldBwdH3Args& a, hipStream_t st);   // Wd = 256, class 1
+int nefes_bwd_h3_launch_part6(int which, const FieldBwdH3Args& a, hipStream_t st);   // Wd = 128, class 0
+int nefes_bwd_h3_launch_part7(int which, const FieldBwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256, class 1
+int nefes_bwd_h3_launch_part8(int which, const FieldBwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 128, class 0
 
 #if NEFES_TU_PART == 1
 int nefes_bwd_h3_launch_part1(int which, const FieldBwdH3Args& a, hipStream_t st) {
-    if (which == BWD_H3_256_EXT) return launch_bwd_h3<256, 19, NEFES_XYZ_EXTERNAL32>(a, st);
+    if (which == BWD_H3_EXT) return launch_bwd_h3<256, 2, NEFES_XYZ_EXTERNAL32>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 2      // built with -mllvm -amdgpu-mfma-vgpr-form: see field_fwd_h3.hip
 int nefes_bwd_h3_launch_part2(int which, const FieldBwdH3Args& a, hipStream_t st) {
-    if (which == BWD_H3_128) return launch_bwd_h3<128, 131, NEFES_XYZ_FREQ10>(a, st);
+    if (which == BWD_H3_FULL) return launch_bwd_h3<128, 9, NEFES_XYZ_FREQ10>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 3
 int nefes_bwd_h3_launch_part3(int which, const FieldBwdH3Args& a, hipStream_t st) {
-    if (which == BWD_H3_TRAIN_STATIC) return launch_bwd_h3<256, 19, NEFES_XYZ_FREQ10, false, true>(a, st);
-    if (which == BWD_H3_TRAIN_FULL) return launch_bwd_h3<256, 19, NEFES_XYZ_FREQ10, true, true>(a, st);
+    if (which == BWD_H3_TRAIN_STATIC) return launch_bwd_h3<256, 2, NEFES_XYZ_FREQ10, false, true>(a, st);
+    if (which == BWD_H3_TRAIN_FULL) return launch_bwd_h3<256, 2, NEFES_XYZ_FREQ10, true, true>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 4      // (built like part 2)
 int nefes_bwd_h3_launch_part4(int which, const FieldBwdH3Args& a, hipStream_t st) {
-    if (which == BWD_H3_TRAIN_STATIC) return launch_bwd_h3<128, 131, NEFES_XYZ_FREQ10, false, true>(a, st);
-    if (which == BWD_H3_TRAIN_FULL) return launch_bwd_h3<128, 131, NEFES_XYZ_FREQ10, true, true>(a, st);
+    if (which == BWD_H3_TRAIN_STATIC) return launch_bwd_h3<128, 9, NEFES_XYZ_FREQ10, false, true>(a, st);
+    if (which == BWD_H3_TRAIN_FULL) return launch_bwd_h3<128, 9, NEFES_XYZ_FREQ10, true, true>(a, st);
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 5      // (gap-by-gap schedule, like part 0)
+int nefes_bwd_h3_launch_part5(int which, const FieldBwdH3Args& a, hipStream_t st) {
+    if (which == BWD_H3_FULL) return launch_bwd_h3<256, 9, NEFES_XYZ_FREQ10>(a, st);
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 6      // (built like part 2)
+int nefes_bwd_h3_launch_part6(int which, const FieldBwdH3Args& a, hipStream_t st) {
+    if (which == BWD_H3_FULL) return launch_bwd_h3<128, 2, NEFES_XYZ_FREQ10>(a, st);
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 7
+int nefes_bwd_h3_launch_part7(int which, const FieldBwdH3Args& a, hipStream_t st) {
+    if (which == BWD_H3_TRAIN_STATIC) return launch_bwd_h3<256, 9, NEFES_XYZ_FREQ10, false, true>(a, st);
+    if (which == BWD_H3_TRAIN_FULL) return launch_bwd_h3<256, 9, NEFES_XYZ_FREQ10, true, true>(a, st);
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 8      // (built like part 2)
+int nefes_bwd_h3_launch_part8(int which, const FieldBwdH3Args& a, hipStream_t st) {
+    if (which == BWD_H3_TRAIN_STATIC) return launch_bwd_h3<128, 2, NEFES_XYZ_FREQ10, false, true>(a, st);
+    if (which == BWD_H3_TRAIN_FULL) return launch_bwd_h3<128, 2, NEFES_XYZ_FREQ10, true, true>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #else   // part 0
@@ -486,8 +533,8 @@ extern "C" int nefes_field_bwd_train_h3(const NefesNetDesc* desc, const void* pa
     if (mode != NEFES_FIELD_STATIC && mode != NEFES_FIELD_FULL) return NEFES_E_BADARG;
     const bool full = mode == NEFES_FIELD_FULL;
     if (full && !desc->has_transient) return NEFES_E_UNSUPPORTED;
-    const bool big = desc->width == 256 && desc->feat_dim == 16, small = desc->width == 128 && desc->feat_dim == 128;
-    if (!(big || small) || desc->xyz_encoding != NEFES_XYZ_FREQ10) return NEFES_E_UNSUPPORTED;
+    const int cls = nefes_head_class(desc->feat_dim);
+    if ((desc->width != 256 && desc->width != 128) || cls < 0 || desc->xyz_encoding != NEFES_XYZ_FREQ10) return NEFES_E_UNSUPPORTED;
     NefesBlobInfo info;
     int rc = nefes_blob_info(desc, &info);
     if (rc) return rc;
@@ -505,7 +552,9 @@ extern "C" int nefes_field_bwd_train_h3(const NefesNetDesc* desc, const void* pa
     a.dacts = dacts;
     a.rows = nefes_train_row(desc->width, desc->feat_dim, NEFES_TB_END);
     const int which = full ? BWD_H3_TRAIN_FULL : BWD_H3_TRAIN_STATIC;
-    return small ? nefes_bwd_h3_launch_part4(which, a, (hipStream_t)stream) : nefes_bwd_h3_launch_part3(which, a, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (desc->width == 256) return cls == 0 ? nefes_bwd_h3_launch_part3(which, a, st) : nefes_bwd_h3_launch_part7(which, a, st);
+    return cls == 1 ? nefes_bwd_h3_launch_part4(which, a, st) : nefes_bwd_h3_launch_part8(which, a, st);
 }
 
 extern "C" int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
@@ -533,9 +582,11 @@ extern "C" int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, 
     a.n_tiles = (int)((a.M + 127) / 128);
     a.dacts = nullptr; a.rows = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (desc->width == 256 && desc->feat_dim == 16 && !ext) return launch_bwd_h3<256, 19, NEFES_XYZ_FREQ10>(a, st);
-    if (desc->width == 256 && desc->feat_dim == 16 && ext) return nefes_bwd_h3_launch_part1(BWD_H3_256_EXT, a, st);
-    if (desc->width == 128 && desc->feat_dim == 128 && !ext) return nefes_bwd_h3_launch_part2(BWD_H3_128, a, st);
+    const int cls = nefes_head_class(desc->feat_dim);          // compiled set: as nefes_field_fwd_h3
+    if (cls < 0) return NEFES_E_UNSUPPORTED;
+    if (desc->width == 256 && ext) return cls == 0 ? nefes_bwd_h3_launch_part1(BWD_H3_EXT, a, st) : NEFES_E_UNSUPPORTED;
+    if (desc->width == 256) return cls == 0 ? launch_bwd_h3<256, 2, NEFES_XYZ_FREQ10>(a, st) : nefes_bwd_h3_launch_part5(BWD_H3_FULL, a, st);
+    if (desc->width == 128 && !ext) return cls == 1 ? nefes_bwd_h3_launch_part2(BWD_H3_FULL, a, st) : nefes_bwd_h3_launch_part6(BWD_H3_FULL, a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #endif   // NEFES_TU_PART

@@ -8,8 +8,9 @@
 // in LDS between layer 1 and the skip at layer 5 instead of in registers: with one accumulator set in VGPRs (the compiler keeps
 // the set the vector ALU reads there) the kernel has no 32 registers to spare.
 // (layout.h is included below; the two sizes are repeated there as NEFES_H3_FWD_SLAB_KIB / _128 and checked against these)
-#if defined(NEFES_TU_PART) && (NEFES_TU_PART == 2 || NEFES_TU_PART == 4)
-#define NEFES_SLAB_KIB 16      // the Wd = 128 instances: 2 x 16 KiB of ring, two workgroups per CU (see launch_h3)
+#if defined(NEFES_TU_PART) && NEFES_TU_PART >= 2 && NEFES_TU_PART % 2 == 0
+#define NEFES_TU_W128          // even parts from 2 on hold the Wd = 128 instances
+#define NEFES_SLAB_KIB 16      // 2 x 16 KiB of ring, two workgroups per CU (see launch_h3)
 #else
 #define NEFES_SLAB_KIB 32
 #endif
@@ -22,7 +23,7 @@
 #include "../../include/nefes_hip.h"
 
 #include "field_x6.h"
-#if !(defined(NEFES_TU_PART) && (NEFES_TU_PART == 2 || NEFES_TU_PART == 4)) && !defined(H3_NO_ACC_READ_ASM)
+#if !defined(NEFES_TU_W128) && !defined(H3_NO_ACC_READ_ASM)
 #define H3_ACC_READ_ASM        // Wd = 256 objects: source tiles are read out of their AGPRs inside the MFMA gaps (field_h3.h acc_read)
 #endif
 #include "field_h3.h"
@@ -66,8 +67,9 @@ __device__ __forceinline__ void train_save_h3(float* tile_base, uint32_t voff, i
 }
 
 // MODE: NEFES_FIELD_SIGMA, NEFES_FIELD_STATIC (static head only: the TRAIN instances of a coarse network) or NEFES_FIELD_FULL;
-// ENC: NEFES_XYZ_FREQ10 or NEFES_XYZ_EXTERNAL32 (hash grid); (W, NTR) = (256, 1) [C = 16] or (128, 5) [C = 128: the
-// reference-default shape].  TRAIN: every hidden layer's pre-activation and both embeddings also go to a.acts (weight gradients).
+// ENC: NEFES_XYZ_FREQ10 or NEFES_XYZ_EXTERNAL32 (hash grid); W = 128 or 256; NTR = tiles of the rgb+feature head = the head class
+// of layout.h (1: 3 + C <= 32, e.g. BASELINE's C = 16; 5: 3 + C <= 144, e.g. the reference's FEATURE_DIM = 128) -- C itself is a
+// run-time argument.  TRAIN: every hidden layer's pre-activation and both embeddings also go to a.acts (weight gradients).
 template <int MODE, int ENC, int W = 256, int NTR = 1, bool TRAIN = false>
 __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(FieldFwdH3Args a) {
     static_assert(NEFES_SLAB_KIB == (W == 128 ? NEFES_H3_FWD_SLAB_KIB_128 : NEFES_H3_FWD_SLAB_KIB), "ring slab size != the packer's for this width");
@@ -342,15 +344,26 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                 if (col) {
                     float* ph = col + (size_t)(4 * h) * a.S;
                     const float inv = pow2i(-es);
+                    // C is a run-time value inside the head class: tiles whose 32 rows are all channels store unpredicated (a
+                    // wave-uniform test per tile), the tile that holds row 3 + C carries a per-lane predicate, the padding tiles
+                    // behind it store nothing (80 predicated stores per tile at C = 128 otherwise)
+                    int S_t = a.S, c3 = 3 + a.C;                  // opaque per tile: the 16 NTR row offsets cu * S and the channel tests
+                    asm volatile("" : "+s"(S_t), "+s"(c3));      // are recomputed by the scalar ALU here instead of being hoisted out
+                    const int full = c3 >> 5;                     // of the tile loop into (spilled) registers
 #pragma unroll
-                    for (int t = 0; t < NTR; ++t)
+                    for (int t = 0; t < NTR; ++t) {
+                        if (t < full) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int cu = 32 * t + nefes_rho(0, r);
-                            // NTR = ceil((3 + C) / 32): every row of the tiles before the last one is a channel -- only the last
-                            // tile's stores carry a per-lane predicate (80 predicated stores per tile at C = 128 otherwise)
-                            if (t + 1 < NTR || cu + 4 * h < 3 + a.C) __builtin_nontemporal_store(ar[t][r] * inv, &ph[(size_t)cu * a.S]);
+                            for (int r = 0; r < 16; ++r)
+                                __builtin_nontemporal_store(ar[t][r] * inv, &ph[(size_t)(32 * t + nefes_rho(0, r)) * S_t]);
+                        } else if (32 * t < c3) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int cu = 32 * t + nefes_rho(0, r);
+                                if (cu + 4 * h < c3) __builtin_nontemporal_store(ar[t][r] * inv, &ph[(size_t)cu * S_t]);
+                            }
                         }
+                    }
                 }
             }
             if constexpr (FULL) {
@@ -441,16 +454,21 @@ static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// Kernel instances spread over three objects built from this one source (Makefile: -DNEFES_TU_PART=0..2): part 0 = entry point +
-// the Wd = 256 frequency-embedding instances, part 1 = hash-grid instances, part 2 = Wd = 128 instances.
+// Kernel instances spread over nine objects built from this one source (Makefile: -DNEFES_TU_PART=0..8; even parts from 2 on are
+// the Wd = 128 objects): part 0 = entry points + Wd = 256 / head class 0, part 1 = hash-grid instances, part 2 = Wd = 128 / class 1,
+// parts 3 / 4 = their TRAIN instances, parts 5 / 6 = Wd = 256 / class 1 and Wd = 128 / class 0, parts 7 / 8 = their TRAIN instances.
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_128_SIGMA, H3_128_FULL, H3_TRAIN_STATIC, H3_TRAIN_FULL };
+enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_SIGMA, H3_FULL, H3_TRAIN_STATIC, H3_TRAIN_FULL };
 int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st);
 int nefes_fwd_h3_launch_part2(int which, const FieldFwdH3Args& a, hipStream_t st);
-int nefes_fwd_h3_launch_part3(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256
-int nefes_fwd_h3_launch_part4(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 128
+int nefes_fwd_h3_launch_part3(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256, class 0
+int nefes_fwd_h3_launch_part4(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 128, class 1
+int nefes_fwd_h3_launch_part5(int which, const FieldFwdH3Args& a, hipStream_t st);   // Wd = 256, class 1 (the reference's FEATURE_DIM at netwidth 256)
+int nefes_fwd_h3_launch_part6(int which, const FieldFwdH3Args& a, hipStream_t st);   // Wd = 128, class 0
+int nefes_fwd_h3_launch_part7(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256, class 1
+int nefes_fwd_h3_launch_part8(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 128, class 0
 
 #if defined(H3_STAMP) && defined(H3_STAMP_READER)   // exactly one translation unit of a diagnostic build (tools/stamp_h3.sh)
 extern "C" int nefes_debug_h3_stamps(unsigned long long* out3) {
@@ -484,8 +502,8 @@ int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st
 // backward 0.77 -> 0.73 ms on the 80x60 refinement frame.
 int nefes_fwd_h3_launch_part2(int which, const FieldFwdH3Args& a, hipStream_t st) {
     switch (which) {
-        case H3_128_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5>(a, st);
-        case H3_128_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5>(a, st);
+        case H3_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5>(a, st);       // (the sigma-only pass has no rgb head: one instance per width)
+        case H3_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5>(a, st);
     }
     return NEFES_E_UNSUPPORTED;
 }
@@ -505,6 +523,32 @@ int nefes_fwd_h3_launch_part4(int which, const FieldFwdH3Args& a, hipStream_t st
     }
     return NEFES_E_UNSUPPORTED;
 }
+#elif NEFES_TU_PART == 5
+int nefes_fwd_h3_launch_part5(int which, const FieldFwdH3Args& a, hipStream_t st) {
+    if (which == H3_FULL) return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 256, 5>(a, st);
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 6      // (built like part 2)
+int nefes_fwd_h3_launch_part6(int which, const FieldFwdH3Args& a, hipStream_t st) {
+    if (which == H3_FULL) return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 1>(a, st);
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 7
+int nefes_fwd_h3_launch_part7(int which, const FieldFwdH3Args& a, hipStream_t st) {
+    switch (which) {
+        case H3_TRAIN_STATIC: return launch_h3<NEFES_FIELD_STATIC, NEFES_XYZ_FREQ10, 256, 5, true>(a, st);
+        case H3_TRAIN_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 256, 5, true>(a, st);
+    }
+    return NEFES_E_UNSUPPORTED;
+}
+#elif NEFES_TU_PART == 8      // (built like part 2)
+int nefes_fwd_h3_launch_part8(int which, const FieldFwdH3Args& a, hipStream_t st) {
+    switch (which) {
+        case H3_TRAIN_STATIC: return launch_h3<NEFES_FIELD_STATIC, NEFES_XYZ_FREQ10, 128, 1, true>(a, st);
+        case H3_TRAIN_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 1, true>(a, st);
+    }
+    return NEFES_E_UNSUPPORTED;
+}
 #else   // part 0
 
 // Train-mode forward on the fp16 pipe: as nefes_field_fwd_train (field_fwd.hip), same `acts` rows, same masks, same raw_t.
@@ -515,8 +559,8 @@ extern "C" int nefes_field_fwd_train_h3(const NefesNetDesc* desc, const void* pa
     if (!pts && !(rays_o && rays_d && z)) return NEFES_E_BADARG;
     if (mode != NEFES_FIELD_STATIC && mode != NEFES_FIELD_FULL) return NEFES_E_UNSUPPORTED;
     if (mode == NEFES_FIELD_FULL && !desc->has_transient) return NEFES_E_BADARG;
-    const bool big = desc->width == 256 && desc->feat_dim == 16, small = desc->width == 128 && desc->feat_dim == 128;
-    if (!(big || small) || desc->xyz_encoding != NEFES_XYZ_FREQ10) return NEFES_E_UNSUPPORTED;
+    const int cls = nefes_head_class(desc->feat_dim);
+    if ((desc->width != 256 && desc->width != 128) || cls < 0 || desc->xyz_encoding != NEFES_XYZ_FREQ10) return NEFES_E_UNSUPPORTED;
     NefesBlobInfo info;
     int rc = nefes_blob_info(desc, &info);
     if (rc) return rc;
@@ -535,7 +579,9 @@ extern "C" int nefes_field_fwd_train_h3(const NefesNetDesc* desc, const void* pa
     a.rows = nefes_train_row(desc->width, desc->feat_dim, NEFES_TB_END);
     magic_div((uint32_t)S, a.s_magic, a.s_shift);
     const int which = mode == NEFES_FIELD_STATIC ? H3_TRAIN_STATIC : H3_TRAIN_FULL;
-    return small ? nefes_fwd_h3_launch_part4(which, a, (hipStream_t)stream) : nefes_fwd_h3_launch_part3(which, a, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (desc->width == 256) return cls == 0 ? nefes_fwd_h3_launch_part3(which, a, st) : nefes_fwd_h3_launch_part7(which, a, st);
+    return cls == 1 ? nefes_fwd_h3_launch_part4(which, a, st) : nefes_fwd_h3_launch_part8(which, a, st);
 }
 
 extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
@@ -546,8 +592,11 @@ extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, 
     if (ext ? !xyz_enc : (!pts && !(rays_o && rays_d && z))) return NEFES_E_BADARG;
     if (mode != NEFES_FIELD_SIGMA && mode != NEFES_FIELD_FULL) return NEFES_E_UNSUPPORTED;
     if (mode == NEFES_FIELD_FULL && (!viewdirs || !desc->has_transient)) return NEFES_E_BADARG;
-    const bool big = desc->width == 256 && desc->feat_dim == 16, small = desc->width == 128 && desc->feat_dim == 128 && !ext;
-    if (!(big || small) || (desc->xyz_encoding != NEFES_XYZ_FREQ10 && !ext)) return NEFES_E_UNSUPPORTED;
+    // compiled set: widths 128 / 256 x head classes 0 / 1 (layout.h) with the frequency embedding; width 256 / class 0 with an
+    // external 32-feature embedding
+    const int cls = nefes_head_class(desc->feat_dim);
+    const bool big = desc->width == 256, small = desc->width == 128 && !ext;
+    if (!(big || small) || cls < 0 || (ext && cls != 0) || (desc->xyz_encoding != NEFES_XYZ_FREQ10 && !ext)) return NEFES_E_UNSUPPORTED;
     NefesBlobInfo info;
     int rc = nefes_blob_info(desc, &info);
     if (rc) return rc;
@@ -565,9 +614,12 @@ extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, 
     a.n_tiles = (int)((a.M + 127) / 128);
     magic_div((uint32_t)S, a.s_magic, a.s_shift);
     hipStream_t st = (hipStream_t)stream;
-    if (small) return nefes_fwd_h3_launch_part2(mode == NEFES_FIELD_SIGMA ? H3_128_SIGMA : H3_128_FULL, a, st);
     if (ext) return nefes_fwd_h3_launch_part1(mode == NEFES_FIELD_SIGMA ? H3_EXT_SIGMA : H3_EXT_FULL, a, st);
+    if (small) {
+        if (mode == NEFES_FIELD_SIGMA) return nefes_fwd_h3_launch_part2(H3_SIGMA, a, st);
+        return cls == 1 ? nefes_fwd_h3_launch_part2(H3_FULL, a, st) : nefes_fwd_h3_launch_part6(H3_FULL, a, st);
+    }
     if (mode == NEFES_FIELD_SIGMA) return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10>(a, st);
-    return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10>(a, st);
+    return cls == 0 ? launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10>(a, st) : nefes_fwd_h3_launch_part5(H3_FULL, a, st);
 }
 #endif   // NEFES_TU_PART

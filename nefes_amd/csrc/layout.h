@@ -66,6 +66,15 @@ NEFES_HD int nefes_emb_slot(int L, int s, int h) {
     if (s == 3 * L + 1) return h == 0 ? 2 : -1;
     return -1;
 }
+// Head classes.  The static rgb+feature head (3 + C output rows, nerfh_nff.py:487-490; C = FEATURE_DIM, :21) is a compile-time
+// shape in the fp16 two-part field kernels: NTR output tiles forward, KR16 k-steps of 16 upstream channels backward.  Two classes
+// are compiled per width and the packer pads a network's head to its class (zero rows / zero columns), so that C is a run-time
+// parameter: class 0 serves 3 + C <= 32 (C = 16: BASELINE configs[1]), class 1 serves 3 + C <= 144 (C = 128: the reference's own
+// FEATURE_DIM).  -1: no instance.
+NEFES_HD int nefes_head_class(int C) { return C < 0 ? -1 : (3 + C <= 32 ? 0 : (3 + C <= 144 ? 1 : -1)); }
+NEFES_HD int nefes_head_ntr(int C) { return 3 + C <= 32 ? 1 : 5; }
+NEFES_HD int nefes_head_kr16(int C) { return 3 + C <= 32 ? 2 : 9; }
+#define NEFES_HEAD_MAX_C 141
 // k-steps per slab for a segment with NT accumulator tiles
 NEFES_HD int nefes_steps_per_slab(int nt, int slab_frags) { return slab_frags / nt; }
 NEFES_HD int nefes_segment_slabs(int nt, int ks, int slab_frags) {
@@ -147,7 +156,7 @@ NEFES_HD size_t nefes_train_off(int row, int sample) {
 // rows 32 t + rho(0, r) + 4 h of a block: offset = (row0 / 32 + t) * 4096 + rho(0, r) * 16 + nefes_train_lane_off(w, j, h)
 NEFES_HD uint32_t nefes_train_lane_off(int wave, int j, int h) { return (uint32_t)(((wave * 32 + j) >> 4) * 512 + 4 * h * 16 + (j & 15)); }
 NEFES_HD int nefes_train_row(int W, int C, int block) {
-    const int ntr = (3 + C + 31) / 32;
+    const int ntr = nefes_head_ntr(C);
     int r = 0;
     if (block == NEFES_TB_E) return r;
     r += 2 * NEFES_E_STEPS;

@@ -327,8 +327,8 @@ void add_backward(const Net& n, Stream& st, int x6 = 0, bool transient = true) {
     const int W = n.W, W2 = n.W2, NTW = n.NTW, NTH = n.NTH;
     // static rgb/feature head^T first (its 3+C upstream values are consumed straight after the tile's loads):
     // in = 3+C grads (compact slots), out = d g
-    if (x6 == 2) {   // fp16 stream: natural slots, ceil((3+C)/16) k-steps of 16 (channels past 3+C are zero columns)
-        const int ks = 8 * ((3 + n.C + 15) / 16);
+    if (x6 == 2) {   // fp16 stream: natural slots, the head class's k-steps of 16 (channels past 3+C are zero columns)
+        const int ks = 8 * nefes_head_kr16(n.C);
         std::vector<int> k = k_natural(ks, 0);
         for (auto& v : k) if (v >= 3 + n.C) v = -1;
         st.segs.push_back(seg(NTH, ks, k, rows_natural(NTH, W2), n.w(L_RGB), W2, true));
@@ -429,9 +429,9 @@ static int group_of(const Net& n, const float* Wm) {
 bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&st)[NEFES_N_STREAMS]) {
     if (!d) return false;
     if (d->width != 128 && d->width != 256) return false;
-    if (d->feat_dim < 0 || 3 + d->feat_dim > 160) return false;
+    if (nefes_head_class(d->feat_dim) < 0) return false;          // 0 <= C <= NEFES_HEAD_MAX_C (layout.h: head classes)
     n.W = d->width; n.W2 = n.W / 2; n.C = d->feat_dim;
-    n.NTW = n.W / 32; n.NTH = n.W2 / 32; n.NTR = (3 + n.C + 31) / 32;
+    n.NTW = n.W / 32; n.NTH = n.W2 / 32; n.NTR = nefes_head_ntr(n.C);
     n.transient = d->has_transient != 0;
     n.ext = d->xyz_encoding == NEFES_XYZ_EXTERNAL32;
     if (d->xyz_encoding != NEFES_XYZ_FREQ10 && !n.ext) return false;
@@ -468,21 +468,26 @@ bool build(const NefesNetDesc* d, const float* const* tensors, Net& n, Stream (&
         add_transient_head(n, st[NEFES_STREAM_FWD_FULL]);
         add_backward(n, st[NEFES_STREAM_BWD_FULL]);
     }
-    const bool big = n.W == 256, small = n.W == 128 && n.C == 128 && !n.ext;   // shapes with bf16x6 instances (layout.h)
-    if (big || small) {
-        add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_X6], 1);
+    // bf16x6 instances exist for the two canonical shapes only (and the sigma-only pass at every Wd = 256 network); the fp16 two-part
+    // instances for both widths x both head classes (frequency embedding), and for Wd = 256 / class 0 with an external embedding
+    const bool big = n.W == 256, small = n.W == 128 && n.C == 128 && !n.ext;
+    const bool h3_shape = !n.ext || (n.W == 256 && nefes_head_class(n.C) == 0);
+    if (big || small) add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_X6], 1);
+    if (n.transient && (big || small) && (small || n.C == 16)) {
+        add_trunk(n, st[NEFES_STREAM_FWD_FULL_X6], 1);
+        add_heads_x6(n, st[NEFES_STREAM_FWD_FULL_X6]);
+        add_backward(n, st[NEFES_STREAM_BWD_FULL_X6], 1);
+    }
+    if (h3_shape) {
         add_trunk(n, st[NEFES_STREAM_FWD_SIGMA_H3], 2);
         st[NEFES_STREAM_FWD_SIGMA_H3].h3 = true;
-        if (!n.ext && (small || n.C == 16)) {          // static head only: what a coarse network runs in train mode
+        if (!n.ext) {                                   // static head only: what a coarse network runs in train mode
             add_trunk(n, st[NEFES_STREAM_FWD_STATIC_H3], 2);
             add_static_head_h3(n, st[NEFES_STREAM_FWD_STATIC_H3]);
             add_backward(n, st[NEFES_STREAM_BWD_STATIC_H3], 2, false);
             st[NEFES_STREAM_FWD_STATIC_H3].h3 = st[NEFES_STREAM_BWD_STATIC_H3].h3 = true;
         }
-        if (n.transient && (small || n.C == 16)) {
-            add_trunk(n, st[NEFES_STREAM_FWD_FULL_X6], 1);
-            add_heads_x6(n, st[NEFES_STREAM_FWD_FULL_X6]);
-            add_backward(n, st[NEFES_STREAM_BWD_FULL_X6], 1);
+        if (n.transient) {
             add_trunk(n, st[NEFES_STREAM_FWD_FULL_H3], 2);
             add_heads_x6(n, st[NEFES_STREAM_FWD_FULL_H3], 2);
             add_backward(n, st[NEFES_STREAM_BWD_FULL_H3], 2);

@@ -160,7 +160,8 @@ class NeRFH_NFF(nn.Module):
     # -- the HIP path ---------------------------------------------------------------------------
     def _supported(self):
         return (self.D == 8 and self.skips == [4] and self.in_channels_xyz in (63, 32) and self.in_channels_dir == 27
-                and self.W in (128, 256) and self.out_ch_size != 3)
+                and self.W in (128, 256) and self.out_ch_size != 3 and 0 < self.W_features <= ops.HEAD_MAX_C
+                and (self.in_channels_xyz == 63 or (self.W == 256 and ops.head_class(self.W_features) == 0)))
 
     def invalidate_packed(self):
         """Force a re-pack on the next render.  The cache key is (data_ptr, _version, device) per parameter, which sees
@@ -173,8 +174,9 @@ class NeRFH_NFF(nn.Module):
         """Fragment streams for the fused kernels; re-packed when any path parameter changes (see invalidate_packed for
         the one kind of change this cannot see)."""
         if not self._supported():
-            raise RuntimeError("nefes_amd: the HIP field kernels are built for D=8, skips=[4], 63/27 encodings, "
-                               "W in {128,256} and a feature head (f_dim>0); got an unsupported NeRFH_NFF configuration")
+            raise RuntimeError(f"nefes_amd: the HIP field kernels are built for D=8, skips=[4], 63/27 encodings and a feature head "
+                               f"(f_dim>0); got D={self.D}, skips={self.skips}, W={self.W}, f_dim={self.W_features}, "
+                               f"in_channels_xyz={self.in_channels_xyz}.  Compiled: {ops.COMPILED_SET}")
         names = ops.PackedField.LAYERS_FINE if self.encode_transient else ops.PackedField.LAYERS_COARSE
         sd = dict(self.named_parameters())
         prm = [sd[n + s] for n in names for s in (".weight", ".bias")]

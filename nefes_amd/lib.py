@@ -125,7 +125,12 @@ def load():
     return lib
 
 
+COMPILED_SET = ("fp16 two-part instances (default): widths 128 / 256 x feature heads of 0..29 or 30..141 channels with the frequency "
+                "embedding, width 256 x 0..29 channels with an external 32-feature embedding; bf16x6 and fp32-MFMA instances "
+                "(NEFES_SPLIT=x6 / f32): width 256 x 16 channels and width 128 x 128 channels only")
+
+
 def check(rc, what):
     if rc != 0:
         kind = {-1: "bad argument", -2: "unsupported configuration", -3: "bad weight blob"}.get(rc, f"hipError {rc}")
-        raise RuntimeError(f"{what} failed: {kind}")
+        raise RuntimeError(f"{what} failed: {kind}" + (f".  Compiled: {COMPILED_SET}" if rc == -2 else ""))

@@ -264,6 +264,10 @@ class PackedField:
 def field_fwd(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, pts=None, viewdirs=None, want_masks=False,
               xyz_enc=None):
     dev = pk.blob.device
+    if not canonical_shape(pk):
+        raise RuntimeError(f"nefes_amd: the {('sigma', 'static', 'full')[mode]} forward of W={pk.width}, f_dim={pk.feat_dim} was routed to "
+                           f"the fp32-MFMA instances (NEFES_SPLIT={SPLIT}; or a frozen network's static head with test_time=False), "
+                           f"which exist for the canonical shapes only.  Compiled: {COMPILED_SET}")
     raw_t = torch.empty(N, pk.n_raw(mode), S, device=dev)
     masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=dev) if want_masks else None
     with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]}]"):
@@ -288,10 +292,33 @@ REPACK_H3 = os.environ.get("NEFES_REPACK_H3", "1") != "0"
 USE_X6 = os.environ.get("NEFES_X6", "1") != "0"
 
 
+HEAD_MAX_C = 141          # csrc/layout.h NEFES_HEAD_MAX_C: the larger head class serves 3 + C <= 144
+COMPILED_SET = L.COMPILED_SET
+
+
+def head_class(C):
+    """csrc/layout.h nefes_head_class: the rgb+feature head's compile-time shape class (0: 3+C <= 32, 1: 3+C <= 144, -1: none)."""
+    return -1 if C < 0 else (0 if 3 + C <= 32 else (1 if 3 + C <= 144 else -1))
+
+
+def canonical_shape(pk: PackedField):
+    """Shapes that ALSO have bf16x6 and fp32-MFMA instances: width 256 / C = 16 (either xyz encoding) and the reference-default
+    width 128 / C = 128 (frequency embedding)."""
+    return (pk.width == 256 and pk.feat_dim == 16) or (pk.width == 128 and pk.feat_dim == 128 and pk.xyz_encoding == L.XYZ_FREQ10)
+
+
+def h3_shape(pk: PackedField):
+    """Shapes with fp16 two-part instances (csrc/field_fwd_h3.hip nefes_field_fwd_h3): both widths x both head classes with the
+    frequency embedding; width 256 / class 0 with an external embedding."""
+    cls = head_class(pk.feat_dim)
+    if pk.width not in (128, 256) or cls < 0:
+        return False
+    return True if pk.xyz_encoding == L.XYZ_FREQ10 else (pk.width == 256 and cls == 0)
+
+
 def x6_supported(pk: PackedField, mode, forward=True):
-    """bf16x6 instances: width 256 / C = 16 (either xyz encoding) and the reference-default width 128 / C = 128
-    (frequency embedding); sigma-only or full mode, forward and backward."""
-    ok = (pk.width == 256 and pk.feat_dim == 16) or (pk.width == 128 and pk.feat_dim == 128 and pk.xyz_encoding == L.XYZ_FREQ10)
+    """A split-product instance (fp16 two-part or bf16x6) serves this network and mode: sigma-only or full, forward and backward."""
+    ok = canonical_shape(pk) or (_h3(pk) and h3_shape(pk))
     return ok and (mode == L.FIELD_SIGMA or (mode == L.FIELD_FULL and pk.has_transient))
 
 
@@ -302,13 +329,25 @@ def _h3(pk):
     return SPLIT == "h3" and pk.h3_valid
 
 
+def require_instance(pk: PackedField, what):
+    """Fail loudly, naming the compiled set, before a launch that no kernel instance serves."""
+    if canonical_shape(pk) or (_h3(pk) and h3_shape(pk)):
+        return
+    raise RuntimeError(f"nefes_amd: no kernel instance serves {what} for W={pk.width}, f_dim={pk.feat_dim}, "
+                       f"xyz_encoding={pk.xyz_encoding} with NEFES_SPLIT={SPLIT}"
+                       f"{'' if pk.h3_valid else ' (fp16 streams stale: NEFES_REPACK_H3=0)'}.  Compiled: {COMPILED_SET}")
+
+
 def field_fwd_x6(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, viewdirs=None, want_masks=False, xyz_enc=None,
                  pts=None):
     """field_fwd on the split-product instances (same outputs, same mask words): fp16 two-part (default) or bf16x6."""
     dev = pk.blob.device
     raw_t = torch.empty(N, pk.n_raw(mode), S, device=dev)
     masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=dev) if want_masks else None
-    h3 = _h3(pk) and N * S < (1 << 31) - 256
+    h3 = _h3(pk) and h3_shape(pk) and N * S < (1 << 31) - 256
+    if not h3 and not canonical_shape(pk):
+        raise RuntimeError(f"nefes_amd: {N * S} samples in one launch exceed the fp16 two-part kernels' 32-bit sample index and "
+                           f"W={pk.width}, f_dim={pk.feat_dim} has no other instance; render fewer rays per launch")
     fn = L.load().nefes_field_fwd_h3 if h3 else L.load().nefes_field_fwd_x6
     with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]},{'h3' if h3 else 'x6'}]"):
         L.check(fn(pk.desc, _chk(pk.blob, "blob", torch.uint8), mode, N, S, _chk(rays_o, "rays_o"),

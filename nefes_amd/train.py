@@ -146,9 +146,8 @@ def param_names(net, mode):
 
 def fp16_pipe(pk):
     """The train-mode forward (and the fused dX chain) run on the fp16 two-part instances when ops.SPLIT selects them, the
-    network's fp16 streams are current, and the shape has them (Wd = 256 / C = 16, Wd = 128 / C = 128, frequency embedding)."""
-    shape = (pk.width == 256 and pk.feat_dim == 16) or (pk.width == 128 and pk.feat_dim == 128)
-    return ops._h3(pk) and shape and pk.xyz_encoding == L.XYZ_FREQ10
+    network's fp16 streams are current, and the shape has them (both widths x both head classes, frequency embedding)."""
+    return ops._h3(pk) and ops.h3_shape(pk) and pk.xyz_encoding == L.XYZ_FREQ10
 
 
 FUSED_DX = True       # one fused backward launch (nefes_field_bwd_train) instead of the layer-by-layer nefes_train_dx chain
@@ -262,6 +261,11 @@ class FieldTrain(torch.autograd.Function):
         fused = FUSED_DX and pk.xyz_encoding == L.XYZ_FREQ10
         masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=zz.device) if fused else None
         h3 = fused and fp16_pipe(pk)
+        if not h3:
+            ops.require_instance(pk, "the fp32-MFMA train-mode forward")
+            if not ops.canonical_shape(pk):
+                raise RuntimeError(f"nefes_amd: train mode for W={pk.width}, f_dim={pk.feat_dim} runs on the fused fp16 two-part "
+                                   f"instances only (train.FUSED_DX, NEFES_SPLIT=h3).  Compiled: {ops.COMPILED_SET}")
         fwd = lib.nefes_field_fwd_train_h3 if h3 else lib.nefes_field_fwd_train
         with ops._timed("field_fwd_train[h3]" if h3 else "field_fwd_train"):
             L.check(fwd(C.byref(pk.desc), pk.blob.data_ptr(), mode, N, S, ops._chk(o, "rays_o"), ops._chk(d, "rays_d"),

@@ -396,12 +396,18 @@ def _kwargs(M, coarse, fine, Ni, tat):
 
 @pytest.mark.parametrize("tag", ["ref_default", "metric", "metric_B", "surface", "ref_default_B"])
 def test_render_end_to_end_vs_reference(golden, tag):
-    R, M = _dropin()
     g = golden("end_to_end")
     Wd, C, Ni, tat, sscale, H, W, focal = g[f"{tag}.cfg"]
-    Wd, C, Ni, H, W = int(Wd), int(C), int(Ni), int(H), int(W)
+    check_end_to_end(g, tag, int(Wd), int(C), 64, int(Ni), bool(tat), float(sscale), int(H), int(W), float(focal))
+
+
+def check_end_to_end(g, tag, Wd, C, Nc, Ni, tat, sscale, H, W, focal):
+    """render() through the drop-in modules against a fixture captured from the reference (keys `{tag}.rgb` ...): maps within 1e-4,
+    pose gradients by the branch-pinned rule and, unpinned, against the reference's own fp32 gradient (shared by
+    tests/test_gpu_shapes.py for the round-4 fixtures)."""
+    R, M = _dropin()
     coarse, fine = _modules(Wd, C, float(sscale))
-    kw = _kwargs(M, coarse, fine, Ni, bool(tat))
+    kw = dict(_kwargs(M, coarse, fine, Ni, bool(tat)), N_samples=Nc)
     c2w = T(g[f"{tag}.c2w"]).to(DEV).clone().requires_grad_()
     with B.tapped() as tap:
         rgb, disp, acc, ex = R.render(H, W, float(focal), chunk=32768, c2w=c2w, near=0., far=4.,
@@ -419,7 +425,7 @@ def test_render_end_to_end_vs_reference(golden, tag):
         p["static_sigma.0.weight"] = p["static_sigma.0.weight"] * float(sscale)
         p["static_sigma.0.bias"] = p["static_sigma.0.bias"] * float(sscale)
     c64 = T(g[f"{tag}.c2w"]).double().requires_grad_()
-    cfg = O.RenderCfg(N_samples=64, N_importance=Ni, transient_at_test=bool(tat))
+    cfg = O.RenderCfg(N_samples=Nc, N_importance=Ni, transient_at_test=bool(tat))
     r64, _, _, e64 = O.render(H, W, float(focal), pc, pf, cfg, c2w=c64, near=0., far=4.)
     (t1,) = torch.autograd.grad(O.bench_loss(r64, e64["feat_map"]), c64, retain_graph=True)
     (t2,) = torch.autograd.grad((r64 * T(g[f"{tag}.g_rgb"]).double()).sum() + (e64["feat_map"] * T(g[f"{tag}.g_feat"]).double()).sum(), c64)

@@ -43,6 +43,10 @@ def _relerr(a, b):
 @pytest.mark.parametrize("typ", ["coarse", "fine"])
 def test_field_train_weight_grads(Wd, C, typ, pipe, monkeypatch):
     """pipe: the train-mode forward and the fused dX chain on the fp16 two-part instances (default) or on the fp32-MFMA ones."""
+    check_field_train_weight_grads(Wd, C, typ, pipe, monkeypatch)
+
+
+def check_field_train_weight_grads(Wd, C, typ, pipe, monkeypatch):
     from nefes_amd import lib as L
     from nefes_amd import ops
     from nefes_amd import train as TR
@@ -247,9 +251,12 @@ def test_training_steps_reduce_loss():
 def test_train_mode_vs_reference_golden(golden, tag):
     """The HIP train path against tensors captured from the reference itself (tools/make_goldens.py, train.npz):
     maps and train extras within 2e-5; weight gradients with the kink-tolerant bound (see above)."""
+    check_train_golden(golden("train"), tag)
+
+
+def check_train_golden(g, tag):
     import numpy as np
     from nefes_amd.render import render
-    g = golden("train")
     Wd, C, Nc, Ni, H, W, focal = g[f"{tag}.cfg"]
     Wd, C, Nc, Ni, H, W = int(Wd), int(C), int(Nc), int(Ni), int(H), int(W)
     coarse, fine = _net("coarse", Wd, C), _net("fine", Wd, C)
@@ -283,7 +290,7 @@ def test_train_mode_vs_reference_golden(golden, tag):
     n = 0
     worst = {"e_hip": 0., "e_ref": 0., "direct": 0.}
     for k in [k for k in g if k.startswith(f"{tag}.grad.")]:
-        _, _, net, name = k.split(".", 3)
+        net, name = k[len(f"{tag}.grad."):].split(".", 1)
         got = dict((coarse if net == "coarse" else fine).named_parameters())[name].grad
         assert got is not None, k
         a, b = got.detach().cpu().double().reshape(-1), torch.from_numpy(g[k]).double().reshape(-1)

@@ -177,3 +177,72 @@ def test_train_mode(golden, tag):
         assert np.abs(got.numpy() - g[k]).max() <= 2e-5 * max(np.abs(g[k]).max(), 1e-12), k
         n += 1
     assert n >= 19
+
+
+# ---- round-4 fixtures (tools/make_golden_shapes.py -> shapes.npz): W = 256 with the reference's FEATURE_DIM = 128, W = 128 with 16
+# ---- feature channels, and more than 256 samples per ray ---------------------------------------------------------------------
+@pytest.mark.parametrize("Wd,C", [(256, 128), (128, 16)])
+def test_shapes_param_recipe_and_mlp(golden, Wd, C):
+    g = golden("shapes")
+    tag = f"mlp.w{Wd}c{C}"
+    for typ in ("coarse", "fine"):
+        for k, v in O.make_field_params(typ, Wd, C).items():
+            got = np.array([v.double().sum().item(), v.double().abs().sum().item(), float(v.flatten()[0])])
+            np.testing.assert_allclose(got, g[f"{tag}.{typ}.{k}"], rtol=0, atol=0, err_msg=f"{typ}.{k}")
+    pf, pc = O.make_field_params("fine", Wd, C), O.make_field_params("coarse", Wd, C)
+    emb = torch.cat([O.freq_encode(T(g[f"{tag}.pts"]), 10), O.freq_encode(T(g[f"{tag}.dirs"]), 4)], 1).requires_grad_()
+    raw = O.field_forward(pf, emb, output_transient=True)
+    close(raw, g[f"{tag}.raw_full"], rtol=1e-5, atol=1e-6)
+    (ge,) = torch.autograd.grad(raw, emb, T(g[f"{tag}.g_raw"]))
+    close(ge, g[f"{tag}.g_emb"], rtol=1e-4, atol=1e-5)
+    close(O.field_forward(pc, emb.detach(), output_transient=False), g[f"{tag}.raw_static"], rtol=1e-5, atol=1e-6)
+    close(O.field_forward(pc, emb.detach()[:, :63], sigma_only=True), g[f"{tag}.sigma"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["w256c128", "w128c16", "w256c128_B", "s320", "s384"])
+def test_shapes_end_to_end(golden, tag):
+    g = golden("shapes")
+    t = f"e2e.{tag}"
+    Wd, C, Nc, Ni, tat, H, W, focal = g[f"{t}.cfg"]
+    Wd, C, Nc, Ni, H, W = int(Wd), int(C), int(Nc), int(Ni), int(H), int(W)
+    pc, pf = O.make_field_params("coarse", Wd, C), O.make_field_params("fine", Wd, C)
+    cfg = O.RenderCfg(N_samples=Nc, N_importance=Ni, transient_at_test=bool(tat))
+    c2w = T(g[f"{t}.c2w"]).clone().requires_grad_()
+    rgb, disp, acc, ex = O.render(H, W, float(focal), pc, pf, cfg, c2w=c2w, near=0., far=4., hist=torch.full((1, 10), 10.))
+    feat = ex["feat_map"]
+    close(rgb, g[f"{t}.rgb"], rtol=1e-5, atol=1e-6)
+    close(feat, g[f"{t}.feat"], rtol=1e-5, atol=1e-6)
+    close(disp, g[f"{t}.disp"], rtol=1e-5)
+    close(acc, g[f"{t}.acc"], rtol=1e-5)
+    (g1,) = torch.autograd.grad(O.bench_loss(rgb, feat), c2w, retain_graph=True)
+    (g2,) = torch.autograd.grad((rgb * T(g[f"{t}.g_rgb"])).sum() + (feat * T(g[f"{t}.g_feat"])).sum(), c2w)
+    assert np.abs(g1.numpy() - g[f"{t}.g_c2w_loss"]).max() <= 2e-5 * np.abs(g[f"{t}.g_c2w_loss"]).max()
+    assert np.abs(g2.numpy() - g[f"{t}.g_c2w_lin"]).max() <= 2e-5 * np.abs(g[f"{t}.g_c2w_lin"]).max()
+
+
+@pytest.mark.parametrize("tag", ["w256c128", "w128c16"])
+def test_shapes_train_mode(golden, tag):
+    g = golden("shapes")
+    t = f"train.{tag}"
+    Wd, C, Nc, Ni, H, W, focal = g[f"{t}.cfg"]
+    Wd, C, Nc, Ni, H, W = int(Wd), int(C), int(Nc), int(Ni), int(H), int(W)
+    pc = {k: v.requires_grad_() for k, v in O.make_field_params("coarse", Wd, C).items()}
+    pf = {k: v.requires_grad_() for k, v in O.make_field_params("fine", Wd, C).items()}
+    cfg = O.RenderCfg(N_samples=Nc, N_importance=Ni, perturb=0., test_time=False, transient_at_test=True)
+    rays_o, rays_d = O.ray_bundle(H, W, float(focal), T(g[f"{t}.c2w"])[:3, :4])
+    rgb, disp, acc, ex = O.render(H, W, float(focal), pc, pf, cfg, rays=(rays_o, rays_d), near=0., far=4., hist=torch.full((1, 10), 10.))
+    close(rgb, g[f"{t}.rgb"], rtol=1e-5, atol=1e-6)
+    for k in [k for k in g if k.startswith(f"{t}.ex.")]:
+        close(ex[k.split(".ex.")[1]], g[k], rtol=2e-5, atol=2e-6)
+    t_rgb, t_feat = T(g[f"{t}.t_rgb"]), T(g[f"{t}.t_feat"])
+    loss = ((rgb - t_rgb) ** 2).mean() + ((ex["feat_map"] - t_feat) ** 2).mean() + ((ex["rgb0"] - t_rgb) ** 2).mean()
+    assert abs(float(loss.detach()) - float(g[f"{t}.loss"])) < 1e-6 * float(g[f"{t}.loss"])
+    loss.backward()
+    n = 0
+    for k in [k for k in g if k.startswith(f"{t}.grad.")]:
+        _, _, _, net, name = k.split(".", 4)
+        got = (pc if net == "coarse" else pf)[name].grad
+        assert got is not None, k
+        assert np.abs(got.numpy() - g[k]).max() <= 2e-5 * max(np.abs(g[k]).max(), 1e-12), k
+        n += 1
+    assert n >= 19

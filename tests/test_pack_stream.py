@@ -471,7 +471,8 @@ def test_x6_full_stream_reproduces_the_mlp(Wd, Cf):
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("Wd,C,tr,enc", [(128, 128, False, 0), (128, 128, True, 0), (256, 16, True, 0), (256, 16, True, 1)])
+@pytest.mark.parametrize("Wd,C,tr,enc", [(128, 128, False, 0), (128, 128, True, 0), (256, 16, True, 0), (256, 16, True, 1),
+                                         (256, 128, True, 0), (128, 16, False, 0), (256, 77, True, 0)])
 def test_pack_map_reproduces_host_pack(Wd, C, tr, enc):
     """nefes_pack_map: expanding the slot -> (parameter, part) codes in numpy exactly as pack_device_kernel does gives the
     blob nefes_pack_weights writes, for every stream (fp32 and bf16x6) and the bias blocks."""
@@ -759,9 +760,11 @@ def abs_max(acc, es):
     return (np.abs(acc).max((0, 1)) * np.exp2(-es.astype(np.float64))).astype(np.float32)
 
 
-@pytest.mark.parametrize("Wd,Cf", [(256, 16), (128, 128)])
+@pytest.mark.parametrize("Wd,Cf", [(256, 16), (128, 128), (256, 128), (128, 16), (256, 64), (128, 141)])
 def test_h3_streams_reproduce_the_mlp(Wd, Cf):
-    """The fp16 two-part streams consumed in kernel order with the kernels' scale bookkeeping (field_fwd_h3.hip /
+    """(Wd, C) beyond the two canonical shapes: the head CLASSES of layout.h -- the rgb+feature head padded to 1 or 5 output tiles and
+    to 2 or 9 k-steps of its transposed product -- so that C is a run-time parameter of the compiled instances.
+    The fp16 two-part streams consumed in kernel order with the kernels' scale bookkeeping (field_fwd_h3.hip /
     field_bwd_h3.hip): operand exponents from BOUNDS of the largest magnitude (the packer's row bounds x the exactly measured
     maximum of the previous operand + max |b|), per-matrix weight exponents from the table, common exponents where two products
     share accumulators, bias x 2^es, outputs x 2^-es.  No operand may overflow fp16 (asserted in StreamH3.mma); forward against
@@ -773,7 +776,7 @@ def test_h3_streams_reproduce_the_mlp(Wd, Cf):
     pts[1] *= 6.                                                   # and one far out (|x| ~ 15)
     dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
     e63, e27 = O.freq_encode(pts, 10), O.freq_encode(dirs, 4)
-    NTW, NTH, NTR = Wd // 32, Wd // 64, (3 + Cf + 31) // 32
+    NTW, NTH, NTR = Wd // 32, Wd // 64, (1 if 3 + Cf <= 32 else 5)          # layout.h nefes_head_ntr
     E, D = emb_vector(e63.numpy(), 10, 32), emb_vector(e27.numpy(), 4, 16)
     mE = np.maximum(1.0, np.abs(pts.numpy()).max(1)).astype(np.float32)
     zeros = np.zeros(n, np.int64)
@@ -903,8 +906,9 @@ def test_h3_streams_reproduce_the_mlp(Wd, Cf):
     Z = lambda nt: np.zeros((nt, 32, n), np.float64)
     f32v = lambda v: v.astype(np.float32)
     G2 = Z(NTH)
-    # static_rgb^T: an fp16 product too (round 3): ceil(C3 / 16) k-steps, natural slots, exponent from the operand's exact maximum
-    KR16 = (C3 + 15) // 16
+    # static_rgb^T: an fp16 product too (round 3): the head class's k-steps of 16 (layout.h nefes_head_kr16), natural slots, exponent
+    # from the operand's exact maximum
+    KR16 = 2 if C3 <= 32 else 9
     dr = np.zeros((8 * KR16, 2, n), np.float32)
     for e in range(8 * KR16):
         for h in range(2):

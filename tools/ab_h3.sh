@@ -1,27 +1,18 @@
 #!/bin/bash
 # A/B of a compile-time switch of the fp16 two-part field kernels on one box: a side library that differs from the shipped one
-# only in field_fwd_h3 / field_bwd_h3 (parts 0, 2 and 4: the Wd = 256 and Wd = 128 frequency-embedding instances, the Wd = 128 train
-# instances; AB_WORKLOADS="train" times the training step).
+# only in the objects of field_fwd_h3.hip / field_bwd_h3.hip (all parts; AB_WORKLOADS="train" times the training step).
 #   tools/ab_h3.sh build NAME "-DFLAG ..."   (CPU container)  ->  nefes_amd/abl/libnefes_NAME.so
 #   tools/ab_h3.sh run NAME [NAME ...]       (GPU box)        ->  shipped library and each NAME, twice, headline + ref workloads
 # Switches: -DNEFES_SINCOS_F64 (round-1 f64 argument reduction of the embedding: 453.4 vs 446.8 ms per headline frame).
 # (Tried this way and dropped: requesting the next tile's ray inputs during the current tile's last layers -- no difference.)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd); CS=$ROOT/nefes_amd/csrc; OUT=$ROOT/nefes_amd/abl
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-gpu-rdc -Wno-unused-function -Wno-unused-variable -mllvm -pragma-unroll-threshold=65536"
 if [ "$1" = "build" ]; then
-  NAME=$2; DEFS=$3; mkdir -p $OUT
-  OTHERS=$(ls $CS/build/*.o | grep -v "field_fwd_h3.hip.o\|field_fwd_h3.p2.o\|field_fwd_h3.p4.o\|field_bwd_h3.hip.o\|field_bwd_h3.p2.o\|field_bwd_h3.p4.o")
-  ( cd $CS
-    /opt/rocm/bin/hipcc $FLAGS $DEFS -c field_fwd_h3.hip -o $OUT/f0_$NAME.o &
-    /opt/rocm/bin/hipcc $FLAGS $DEFS -mllvm -amdgpu-mfma-vgpr-form -DNEFES_TU_PART=2 -c field_fwd_h3.hip -o $OUT/f2_$NAME.o &
-    /opt/rocm/bin/hipcc $FLAGS $DEFS -DNEFES_H3_WIDE_MIN=99 -c field_bwd_h3.hip -o $OUT/b0_$NAME.o &
-    /opt/rocm/bin/hipcc $FLAGS $DEFS -DNEFES_H3_WIDE_MIN=99 -mllvm -amdgpu-mfma-vgpr-form -DNEFES_TU_PART=2 -c field_bwd_h3.hip -o $OUT/b2_$NAME.o &
-    /opt/rocm/bin/hipcc $FLAGS $DEFS -mllvm -amdgpu-mfma-vgpr-form -DNEFES_TU_PART=4 -c field_fwd_h3.hip -o $OUT/f4_$NAME.o &
-    /opt/rocm/bin/hipcc $FLAGS $DEFS -DNEFES_H3_WIDE_MIN=99 -mllvm -amdgpu-mfma-vgpr-form -DNEFES_TU_PART=4 -c field_bwd_h3.hip -o $OUT/b4_$NAME.o &
-    wait
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libnefes_$NAME.so $OTHERS $OUT/f0_$NAME.o $OUT/f2_$NAME.o $OUT/b0_$NAME.o $OUT/b2_$NAME.o $OUT/f4_$NAME.o $OUT/b4_$NAME.o )
-  rm -f $OUT/f0_$NAME.o $OUT/f2_$NAME.o $OUT/b0_$NAME.o $OUT/b2_$NAME.o $OUT/f4_$NAME.o $OUT/b4_$NAME.o
+  # the shipped objects are copied, the fp16 field kernels' are rebuilt by the library's own Makefile with the extra flags
+  NAME=$2; DEFS=$3; mkdir -p $OUT/$NAME
+  cp -p $CS/build/*.o $OUT/$NAME/ && rm -f $OUT/$NAME/field_fwd_h3.* $OUT/$NAME/field_bwd_h3.*
+  make -C $CS -j${JOBS:-7} BUILD=../abl/$NAME OUT=../abl/libnefes_$NAME.so EXTRA_H3="$DEFS" > $OUT/$NAME.log 2>&1 || { tail -20 $OUT/$NAME.log; exit 1; }
+  rm -rf $OUT/$NAME
   echo built $NAME
 else
   shift
