@@ -36,6 +36,9 @@ def macs_full(W, C, in_xyz=63):
 WORKLOADS = {
     "metric": dict(H=480, W=640, focal=525.505, near=0., far=4., Wd=256, C=16, Nc=64, Ni=128, hashgrid=False,
                    name="BASELINE configs[1]: 7-Scenes-stairs geometry, 64+128 samples, 8x256 MLP + 16-ch feature head"),
+    "metric128": dict(H=480, W=640, focal=525.505, near=0., far=4., Wd=256, C=128, Nc=64, Ni=128, hashgrid=False,
+                      name="the BASELINE frame with the network the reference itself builds at --netwidth 256: FEATURE_DIM = 128 is a "
+                           "module constant (nerfh_nff.py:21,427), so 8x256 MLP + 128-ch feature head, 64+128 samples"),
     "cam": dict(H=480, W=854, focal=744., near=0., far=20., Wd=256, C=16, Nc=64, Ni=128, hashgrid=True,
                 name="BASELINE configs[3]: Cambridge ShopFacade geometry 854x480, hash-grid (L=16,F=2,T=2^19, bound 25) in "
                      "front of the 8x256 MLP + 16-ch feature head (hash-grid arithmetic: parity unpinned)"),
@@ -60,7 +63,7 @@ def bench_pose():
 def cpu_baseline(Wd, C, Nc, Ni, n_rows, W, focal):
     """The CPU oracle (same torch op sequence as the reference) on a bounded slice of the same workload."""
     from oracle import ref_cpu as O
-    cores = os.cpu_count() or 1
+    cores = host_cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     pc, pf = O.make_field_params("coarse", Wd, C), O.make_field_params("fine", Wd, C)
     cfg = O.RenderCfg(N_samples=Nc, N_importance=Ni)
@@ -92,11 +95,13 @@ def cpu_baseline(Wd, C, Nc, Ni, n_rows, W, focal):
     once()
     dt = time.perf_counter() - t0
     n = n_rows * W
-    return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "rays/s", "cores": cores, "threads": cores, "host_cores": host_cores, "kind": "port",
             "sample": f"{n} rays (first {n_rows} rows of the 480x640 frame) in ONE chunk, fwd+bwd to pose, {Nc}+{Ni} samples, "
                       f"8x{Wd} MLP, C={C}, torch {torch.__version__} CPU, {dt:.1f} s; SURVEY 8d names a 32 768-ray chunk "
                       f"(~{32768 / (n / dt):.0f} s at this rate): bounded to the bench contract's 10-30 s of CPU work, rays/s is "
-                      f"per-ray work and does not depend on the chunk length"}
+                      f"per-ray work and does not depend on the chunk length; `cores` = `threads` = the torch thread count used "
+                      f"(calibrated on a quarter-size run: every hardware thread of a many-core host is slower on 256-wide "
+                      f"GEMMs), `host_cores` = os.cpu_count()"}
 
 
 def committed_traffic(backward, h3, x6):
@@ -118,7 +123,7 @@ def committed_traffic(backward, h3, x6):
         if have != want_src:
             return None, f"{rel} is STALE: collected on kernel sources {have}, this tree is {want_src} (re-run tools/profile_round.sh)"
         if backward:
-            want = "field_bwd_h3_kernel<256,19,0" if h3 else ("field_bwd_kernel<256,19,0,6," if x6 else "field_bwd_kernel<256,19,0,0,")
+            want = "field_bwd_h3_kernel<256,2,0" if h3 else ("field_bwd_kernel<256,19,0,6," if x6 else "field_bwd_kernel<256,19,0,0,")
         else:
             want = "field_fwd_h3_kernel<2,0,256" if h3 else ("field_fwd_x6_kernel<2," if x6 else "field_fwd_kernel<256,1,2")
         e = next(v for k, v in pm.items() if k.replace(" ", "").startswith(want))
@@ -363,8 +368,12 @@ def main():
     if trace:
         print(f"enqueue {t_enq:.4f} s, with the final sync {dt:.4f} s", file=sys.stderr, flush=True)
     timers, ops.TIMERS = ops.TIMERS, None
+    rank_ms = [dt / a.steps * 1e3]
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(every, tmax)                                  # per-rank step time (min / max over ranks in the line)
+        rank_ms = [float(t.item()) / a.steps * 1e3 for t in every]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -386,10 +395,10 @@ def main():
         ach = flop_fwd / (kern[dom_key] * 1e-3) / 1e12
         enc = int(wl['hashgrid'])
         if dom_key == bwd_key:
-            dom_name = (f"field_bwd_h3_kernel<{Wd},{3 + C},{enc}>" if h3 else
+            dom_name = (f"field_bwd_h3_kernel<{Wd},{2 if 3 + C <= 32 else 9},{enc}>" if h3 else
                         f"field_bwd_kernel<{Wd},{3 + C},{enc}{',X6' if x6 else ''}>")
         else:
-            dom_name = (f"field_fwd_h3_kernel<FULL,{enc},{Wd},{(3 + C + 31) // 32}>" if h3 else
+            dom_name = (f"field_fwd_h3_kernel<FULL,{enc},{Wd},{1 if 3 + C <= 32 else 5}>" if h3 else
                         "field_fwd_x6_kernel<FULL>" if x6
                         else f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{enc}>")
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if h3 else (PEAK_BF16_MFMA_TFLOPS / 6.0 if x6 else PEAK_F32_MFMA_TFLOPS)
@@ -429,6 +438,10 @@ def main():
                          "end_to_end_frac": value * (flop_frame / n_total) / (PEAK_F32_MFMA_TFLOPS * 1e12 * world)},
             "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items())},
             "pose_grad_abs_max": float(g.abs().max()),
+            # the all-reduced 3x4 pose gradient itself (row-major), so that an N-rank run can be compared with the 1-rank run number
+            # by number (tests/test_gpu_a_bench_launch.py), and each rank's own step time
+            "pose_grad": [float(v) for v in g.detach().reshape(-1).cpu().tolist()],
+            "ms_per_step_by_rank": {"min": min(rank_ms), "max": max(rank_ms), "all": [round(t, 4) for t in rank_ms]},
         }
         if h3 or x6:
             # The 2 500 TFLOP/s data-sheet peak is a 2.4 GHz figure; under sustained MFMA issue with operands whose bits toggle
@@ -446,7 +459,7 @@ def main():
                              "(power-limited clock; the data-sheet peak assumes 2.4 GHz)"}
             except Exception as e:                       # the probe is an aid, never a reason to lose the bench line
                 out["roofline"]["sustained"] = {"error": str(e)}
-        if world == 1 and a.cpu_rows > 0 and a.workload == "metric":
+        if world == 1 and a.cpu_rows > 0 and a.workload in ("metric", "metric128"):
             out["cpu_baseline"] = cpu_baseline(Wd, C, Nc, Ni, a.cpu_rows, W, focal)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

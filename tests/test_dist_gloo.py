@@ -89,3 +89,78 @@ def test_row_shard_covers_every_row_once():
                 row0, n = row_shard(H, r, world)
                 rows += list(range(row0, row0 + n))
             assert rows == list(range(H))
+
+
+# ---- a SHARDED refinement iteration (SURVEY.md section 8e's caveat; DFM_APR_refine.py:113-126): the fusion CNN and the feature loss need
+# ---- the whole image, so the ranks' row shards of (rgb, feat) are gathered, every rank evaluates the replicated whole-image tail, and
+# ---- gather_maps' backward hands each rank the slice of d loss / d maps that belongs to its rows; the pose gradients of the shards are
+# ---- then summed by the one all-reduce.  world_size 2 and 3 (3 does not divide the 8 rows: unequal shards, broadcast path).
+def _iteration_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from nefes_amd import dist as D
+    r = _sharded_iteration(D, rank, world)
+    q.put((rank, r[0], r[1].numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _iteration_problem():
+    from nefes_amd.field import NeRFH_NFF
+    from oracle import ref_cpu as O
+    from oracle import refine_cpu as RC
+    Wd, C, h, w, focal = 128, 16, 8, 6, 5.0
+    pc, pf = O.make_field_params("coarse", Wd, C), O.make_field_params("fine", Wd, C)
+    for p in (pc, pf):
+        RC.structure_scene(p, 3.0, 1.0, 4.0)
+    net = NeRFH_NFF('coarse', W=Wd, f_dim=C)                                     # seed-0 FusionNet / exposure parameters
+    fsd = {k: v.detach().clone() for k, v in net.fusion_net.state_dict().items()}
+    expo = net.exposure_embedding.params.detach().clone()
+    gen = torch.Generator().manual_seed(3)
+    target = torch.nn.functional.normalize(torch.randn(C, h, w, generator=gen), dim=0)
+    hist = torch.full((1, 10), 10.)
+    cfg = O.RenderCfg(N_samples=12, N_importance=12)
+    return pc, pf, fsd, expo, target, hist, cfg, (h, w, focal, C)
+
+
+def _sharded_iteration(D, rank, world):
+    """One iteration's loss and pose gradient with the rows of the render sharded over `world` ranks (world = 1: unsharded)."""
+    from oracle import ref_cpu as O
+    from oracle import refine_cpu as RC
+    pc, pf, fsd, expo, target, hist, cfg, (h, w, focal, C) = _iteration_problem()
+    c2w = O.bench_pose().requires_grad_()
+    pose = D.replicate_pose(c2w) if world > 1 else c2w
+    row0, n = D.row_shard(h, rank, world)
+    o, d = O.ray_bundle(h, w, focal, pose)
+    rgb, _, _, ex = O.render(h, w, focal, pc, pf, cfg, rays=(o[row0:row0 + n], d[row0:row0 + n]), near=0., far=4., hist=hist)
+    feat = ex["feat_map"]
+    if world > 1:
+        rgb, feat = D.gather_maps(rgb, h, W=w), D.gather_maps(feat, h, W=w)      # differentiable: backward = this rank's slice
+    rgb = RC.affine_color_transform(expo, rgb, hist, 1)
+    fused = RC.fusion_net(fsd, rgb, feat, h, w, 1)
+    loss = RC.feature_loss(fused[0], target)
+    loss.backward()                                                              # the pose-gradient all-reduce happens in here
+    return float(loss.detach()), c2w.grad.detach().clone()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_refinement_iteration_equals_unsharded(world):
+    from nefes_amd import dist as D
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_iteration_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=480) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    loss1, g1 = _sharded_iteration(D, 0, 1)
+    assert float(g1.abs().max()) > 0
+    for rank, loss, g in got:
+        assert abs(loss - loss1) <= 1e-6 * abs(loss1), (rank, loss, loss1)       # every rank holds the whole-image loss
+        g = torch.from_numpy(g)
+        assert float((g - g1).abs().max()) <= 2e-5 * float(g1.abs().max()), (rank, g, g1)      # and the full pose gradient

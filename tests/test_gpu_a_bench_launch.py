@@ -26,20 +26,29 @@ def bench(extra, env_extra, timeout=900):
     return r, (json.loads(lines[-1]) if lines else None)
 
 
-def test_two_ranks_through_the_self_launcher_match_one_rank():
-    """--gpus 2 as a fresh child: torch.distributed.run starts two ranks, each renders its half of the rows, the 48-byte pose
-    gradient is all-reduced; the JSON line says so and the reduced gradient equals the single-rank run's."""
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_ranks_through_the_self_launcher_match_one_rank(ranks):
+    """--gpus N as a fresh child: torch.distributed.run starts N ranks, each renders its share of the rows, the 48-byte pose
+    gradient is all-reduced; the JSON line says so and ALL TWELVE numbers of the reduced gradient equal the single-rank run's
+    (fp32 sums in a different order: 1e-6 of the gradient's largest entry)."""
     one_gpu = {"NEFES_BENCH_ONE_GPU": "1", "NEFES_BENCH_BACKEND": "gloo"}
     r1, j1 = bench(["--gpus", "1"] + SMALL, {})
     assert r1.returncode == 0 and j1 is not None, r1.stderr[-2000:]
-    r2, j2 = bench(["--gpus", "2"] + SMALL, one_gpu)
-    assert r2.returncode == 0 and j2 is not None, r2.stderr[-2000:]
+    rn, jn = bench(["--gpus", str(ranks)] + SMALL, one_gpu)
+    assert rn.returncode == 0 and jn is not None, rn.stderr[-2000:]
     assert j1["n_gpus"] == 1 and j1["world_size"] == 1 and j1["collective_backend"] is None
-    assert j2["n_gpus"] == 2 and j2["world_size"] == 2 and j2["collective_backend"] == "gloo"
-    assert j2["config"]["parallelism"] == "rows/2" and j2["config"]["rays_per_step"] == 48 * 64
-    assert j2["steps"] == 1 and j2["warmup"] == 1 and j2["value"] > 0 and j2["scaling"] == "strong"
-    g1, g2 = j1["pose_grad_abs_max"], j2["pose_grad_abs_max"]
-    assert g1 > 0 and abs(g1 - g2) <= 1e-6 * g1, (g1, g2)          # row shards + all-reduce == the whole frame on one rank
+    assert jn["n_gpus"] == ranks and jn["world_size"] == ranks and jn["collective_backend"] == "gloo"
+    assert jn["config"]["parallelism"] == f"rows/{ranks}" and jn["config"]["rays_per_step"] == 48 * 64
+    assert jn["steps"] == 1 and jn["warmup"] == 1 and jn["value"] > 0 and jn["scaling"] == "strong"
+    g1, gn = j1["pose_grad"], jn["pose_grad"]
+    assert len(g1) == 12 and len(gn) == 12
+    scale = max(abs(v) for v in g1)
+    assert scale > 0 and abs(scale - j1["pose_grad_abs_max"]) <= 1e-12 * scale
+    worst = max(abs(a - b) for a, b in zip(g1, gn))
+    assert worst <= 1e-6 * scale, (g1, gn)                         # row shards + all-reduce == the whole frame on one rank
+    by_rank = jn["ms_per_step_by_rank"]
+    assert len(by_rank["all"]) == ranks and 0 < by_rank["min"] <= by_rank["max"]
+    assert abs(by_rank["max"] - jn["ms_per_step"]) <= 1e-6 * jn["ms_per_step"]      # the line's time is the slowest rank's
 
 
 def test_launcher_started_ranks_must_match_gpus():

@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--k", type=int, default=K, help="dry runs only: fewer starts")
     ap.add_argument("--iters", type=int, default=ITERS, help="dry runs only: fewer iterations")
     ap.add_argument("--out", default=os.path.join(OUT, "refine50.npz"))
+    ap.add_argument("--hw", type=float, nargs=3, default=[120, 160, 150.0], metavar=("H", "W", "FOCAL"),
+                    help="full-resolution image; the loop renders (H/4) x (W/4) rays.  240 320 300 = the 60 x 80 rays of the reference's own "
+                         "loop (DFM_APR_refine.py:107, seven_scenes_colmap.py:264-276): `--hw 240 320 300 --k 1 --out tests/golden/refine50_60x80.npz`")
     a = ap.parse_args()
     globals().update(K=a.k, ITERS=a.iters)
     torch.set_num_threads(a.threads)
@@ -101,7 +104,7 @@ def main():
     torch.set_default_device = lambda *args_, **kw_: None                         # see the module docstring
 
     Wd, C, Nc, Ni = 128, 128, 64, 64          # the refinement shape of the reference (8x128 MLP, 128 feature channels, 64+64)
-    H, W, focal, ts = 120, 160, 150.0, 4      # 30x40 rays
+    H, W, focal, ts = int(a.hw[0]), int(a.hw[1]), float(a.hw[2]), 4      # 30x40 rays by default
     near, far = 0.0, 4.0                      # data/7Scenes/stairs/world_setup.json:2-3
     coarse = M.NeRFH_NFF('coarse', D=8, W=Wd, skips=[4], in_channels_xyz=63, in_channels_dir=27, f_dim=C)
     fine = M.NeRFH_NFF('fine', D=8, W=Wd, skips=[4], in_channels_xyz=63, in_channels_dir=27, encode_appearance=True,
@@ -259,7 +262,7 @@ def main():
 
     if a.skip_f64:
         return
-    add_f64(a.out)
+    add_f64(a.out, a.iters)
 
 
 def problem(g, dtype, k, mode):
@@ -286,8 +289,9 @@ def problem(g, dtype, k, mode):
                       upsample=(int(H), int(W)) if mode == 2 else None)
 
 
-def add_f64(path):
+def add_f64(path, iters=ITERS):
     """The float64 oracle's run from the same starts: `m3_*_f64`, `m2_*_f64` (ORACLE output, the tests' truth)."""
+    ITERS = iters
     g = dict(np.load(path))
     K_ = len(g["init_c2w"])
     photo = torch.from_numpy(g["photo_u8"]).float()[None] / 255.
