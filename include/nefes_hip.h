@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEFES_ABI_VERSION 13
+#define NEFES_ABI_VERSION 14
 
 #define NEFES_E_BADARG (-1)     /* null pointer / non-positive size */
 #define NEFES_E_UNSUPPORTED (-2) /* width / feat_dim / sample count outside the compiled set */
@@ -167,6 +167,14 @@ int nefes_composite_bwd(int N, int S, int C, uint32_t flags, const float* raw_t,
 int nefes_sample_pdf_merge(int N, int Nc, int Ni, int layout, const float* z_coarse, const float* weights,
                            const float* u, int u_per_ray, const float* cdf_in, float* z_fine, float* z_samples,
                            int32_t* inds, float* cdf_out, void* stream);
+/* The coarse pass behind its field kernel as ONE launch: compositing variant D (the sigma-only coarse pass' weights,
+ * nerfh_nff.py:83-89) + sample_pdf (rendering.py:23-66) + sort(cat[z_vals, z_samples]) (:132-141), Nc = 64 / 128 / 256, Nc + Ni <= 512.
+ * sigma [N,Nc] = raw_t of nefes_field_fwd* in NEFES_FIELD_SIGMA mode; z = [N,Nc] depths, or ONE row [Nc] shared by every ray
+ * (z_shared_row = 1); u as in nefes_sample_pdf_merge.  Outputs: z_fine [N,Nc+Ni]; optional z_samples [N,Ni] and weights_out [N,Nc]
+ * (= nefes_composite_fwd's `weights`).  Bit-identical to nefes_composite_fwd(NEFES_COMP_SIGMA_ONLY) + nefes_sample_pdf_merge.
+ * NEFES_E_UNSUPPORTED for other Nc (use those two calls). */
+int nefes_coarse_sample(int N, int Nc, int Ni, const float* sigma, const float* z, int z_shared_row, const float* u, int u_per_ray,
+                        float* z_fine, float* z_samples, float* weights_out, void* stream);
 
 /* ---- multiresolution hash-grid encoding (script/models/nerfh_tcnn.py:60-75,151-156; tiny-cuda-nn semantics) ---- */
 /* PARITY UNPINNED: the reference delegates this to tiny-cuda-nn (not vendored, not version-pinned) and its own model
@@ -212,12 +220,21 @@ int nefes_field_bwd_x6(const NefesNetDesc* desc, const void* packed, int N, int 
  * terms hh + hl + lh, fp32 accumulation: 22 significant bits per operand, fp32-level accuracy at half the matrix-core work of
  * the _x6 calls (nefes_amd/csrc/field_h3.h; replaces script/models/nerfh_nff.py:168-231,525-576 + autograd like they do).
  * Weights are scaled per matrix by the packer (exponent table in the NEFES_STREAM_*_H3 streams), activations / gradient vectors
- * per sample and product inside the kernels.  Shapes: width 256 / C = 16 (either xyz encoding) and width 128 / C = 128.
+ * per sample and product inside the kernels.  Shapes (round 4): widths 128 / 256 x the two head CLASSES of csrc/layout.h --
+ * nefes_head_class: C <= 29 (e.g. BASELINE's 16 channels) and 30 <= C <= 141 (the reference's FEATURE_DIM = 128, nerfh_nff.py:21) --
+ * with the frequency embedding, C itself a run-time value (desc->feat_dim); width 256 / C <= 29 with an external embedding.
+ * NEFES_E_UNSUPPORTED otherwise (nefes_blob_info refuses C > 141 and widths other than 128 / 256 up front).
  * Same arguments, outputs and ReLU-mask words as the calls above, so forward and backward kernels of every kind combine.
  * nefes_pack_device refreshes the fp16 streams when it is given the plan of nefes_pack_h3_plan. */
 int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                        const float* rays_d, const float* z, const float* pts, const float* xyz_enc, const float* viewdirs,
                        float* raw_t, uint32_t* masks, void* stream);
+/* nefes_field_fwd_h3 with ONE row of S depths shared by every ray (z_row [S], frequency embedding): the coarse pass at test time
+ * with scalar near / far and no jitter (rendering.py:96-100: z_vals = near (1 - t) + far t, then expand) -- the [N, S] tensor is
+ * never materialised. */
+int nefes_field_fwd_h3_zrow(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                            const float* rays_d, const float* z_row, const float* viewdirs, float* raw_t, uint32_t* masks,
+                            void* stream);
 int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
                        const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
                        const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);

@@ -47,6 +47,7 @@ struct FieldFwdH3Args {
     uint32_t s_magic, s_shift;   // m / S == mulhi(m, s_magic) >> s_shift for every m < 2^31 (host: magic_div)
     float* acts;             // TRAIN instances: [n_tiles][rows][128] pre-activations + embeddings (layout.h row map)
     int rows;
+    int z_row;               // 1: `z` is ONE row of S depths shared by every ray (scalar near / far, no jitter: rendering.py:96-100)
 };
 
 // TRAIN: tiles X[T0 .. T0+NT) hold a layer's pre-activations times 2^es; rows [row0, row0 + 32 NT) of this tile of `acts` get
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
 #pragma unroll
             for (int c = 0; c < 3; ++c) in_o[c] = a.pts[(size_t)m * 3 + c];
         } else {
-            in_z = a.z[m];
+            in_z = a.z[a.z_row ? smp : m];
 #pragma unroll
             for (int c = 0; c < 3; ++c) { in_o[c] = a.rays_o[ray * 3 + c]; in_d[c] = a.rays_d[ray * 3 + c]; }
         }
@@ -577,6 +578,7 @@ extern "C" int nefes_field_fwd_train_h3(const NefesNetDesc* desc, const void* pa
     a.n_tiles = (int)((a.M + 127) / 128);
     a.acts = acts;
     a.rows = nefes_train_row(desc->width, desc->feat_dim, NEFES_TB_END);
+    a.z_row = 0;
     magic_div((uint32_t)S, a.s_magic, a.s_shift);
     const int which = mode == NEFES_FIELD_STATIC ? H3_TRAIN_STATIC : H3_TRAIN_FULL;
     hipStream_t st = (hipStream_t)stream;
@@ -584,9 +586,9 @@ extern "C" int nefes_field_fwd_train_h3(const NefesNetDesc* desc, const void* pa
     return cls == 1 ? nefes_fwd_h3_launch_part4(which, a, st) : nefes_fwd_h3_launch_part8(which, a, st);
 }
 
-extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
-                                  const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
-                                  const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
+static int field_fwd_h3_impl(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                             const float* rays_d, const float* z, int z_row, const float* pts, const float* xyz_enc,
+                             const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
     if (!desc || !packed || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
     const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
     if (ext ? !xyz_enc : (!pts && !(rays_o && rays_d && z))) return NEFES_E_BADARG;
@@ -607,7 +609,7 @@ extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, 
     a.bias = (const float*)((const char*)packed + si.bias_off);
     a.n_slabs = si.n_slabs; a.bias_floats = si.bias_floats; a.scale_off = si.scale_off;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.xyz_enc = xyz_enc; a.viewdirs = viewdirs; a.raw_t = raw_t; a.masks = masks;
-    a.acts = nullptr; a.rows = 0;
+    a.acts = nullptr; a.rows = 0; a.z_row = z_row;
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = mode == NEFES_FIELD_SIGMA ? 1 : 3 + a.C + 6;
     a.M = (long long)N * S;
     if (a.M >= (1ll << 31) - 256) return NEFES_E_UNSUPPORTED;      // the kernel indexes samples with 32 bits
@@ -621,5 +623,21 @@ extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, 
     }
     if (mode == NEFES_FIELD_SIGMA) return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10>(a, st);
     return cls == 0 ? launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10>(a, st) : nefes_fwd_h3_launch_part5(H3_FULL, a, st);
+}
+
+extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                                  const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
+                                  const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
+    return field_fwd_h3_impl(desc, packed, mode, N, S, rays_o, rays_d, z, 0, pts, xyz_enc, viewdirs, raw_t, masks, stream);
+}
+
+// The same pass with ONE row of S depths shared by every ray (`z_row` [S]): the coarse pass at test time with scalar near / far
+// (rendering.py:96-100) -- the [N, S] depth tensor is then never materialised (79 MB at the headline shape, and a launch).
+extern "C" int nefes_field_fwd_h3_zrow(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                                       const float* rays_d, const float* z_row, const float* viewdirs, float* raw_t, uint32_t* masks,
+                                       void* stream) {
+    if (!rays_o || !rays_d || !z_row) return NEFES_E_BADARG;
+    if (desc && desc->xyz_encoding != NEFES_XYZ_FREQ10) return NEFES_E_UNSUPPORTED;
+    return field_fwd_h3_impl(desc, packed, mode, N, S, rays_o, rays_d, z_row, 1, nullptr, nullptr, viewdirs, raw_t, masks, stream);
 }
 #endif   // NEFES_TU_PART

@@ -162,6 +162,201 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(int N, int Nc, in
     }
 }
 
+
+// =====================================================================================================================
+// The coarse pass behind its field kernel as ONE launch (round 4): compositing variant D (weights of the sigma-only coarse pass,
+// nerfh_nff.py:83-89 / composite.hip composite_fwd4_kernel) + sample_pdf + sort(cat[z_vals, z_samples]) per ray, for
+// Nc = 64 RW coarse samples (RW = 1, 2, 4).  A ray occupies 16 RW lanes with four consecutive coarse samples each, as in
+// composite.hip's four-samples-per-lane kernels -- 4 / RW rays per wave, 16 / RW per workgroup -- so the coarse weights never
+// travel to HBM and back (79 MB written by one launch and read by the next at the headline shape) and a 64-entry CDF no longer
+// leaves three quarters of a wave idle.  `z` is one row of Nc depths per ray (z_stride = Nc) or one row shared by every ray
+// (z_stride = 0: scalar near / far without jitter, rendering.py:96-100 -- the row is then never materialised per ray at all).
+// Same arithmetic, statement for statement, as composite_fwd4_kernel (transmittance: f64 running products in the same association)
+// and sample_pdf_merge_kernel (f64 sums are exact here, so their association does not matter): z_fine is bit-identical to the three
+// launches it replaces (tests/test_gpu_surface.py).
+// =====================================================================================================================
+template <int RW>
+__global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const float* __restrict__ sigma, const float* __restrict__ z,
+                                                            size_t z_stride, const float* __restrict__ u, int u_per_ray, float* z_fine,
+                                                            float* z_samples, float* weights_out) {
+    constexpr int LPR = Seg<RW>::LPR, RPW = Seg<RW>::RPW, Nc = 64 * RW, nb = Nc - 1, np_ = Nc - 2;
+    extern __shared__ float smem_cs[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane / LPR, sl = lane - sub * LPR;
+    const int S = Nc + Ni;
+    const int slot = wv * RPW + sub;                              // ray slot inside the workgroup
+    const int ray_raw = (blockIdx.x * 4 + wv) * RPW + sub;
+    const bool live = ray_raw < N;
+    const int ray = live ? ray_raw : N - 1;                       // idle lanes shadow the last ray (loads in bounds, nothing stored)
+    float* cdf = smem_cs + (size_t)slot * (2 * Nc + 2 * S);
+    float* bins = cdf + Nc;
+    float* all = bins + Nc;
+    float* sorted = all + S;
+    const uint64_t seg_mask = LPR == 64 ? ~0ull : (((1ull << LPR) - 1ull) << (sub * LPR));
+
+    // ---- compositing, variant D: weights w_k = alpha_k * prod_{j<k} (1 - alpha_j)  (composite.hip ray_forward4, sigma_only) ----
+    const int s0 = 4 * sl;
+    const float4 z4 = ld4(z + (size_t)ray * z_stride + s0);
+    const float4 ss4 = ld4(sigma + (size_t)ray * Nc + s0);
+    const float z_next = __shfl_down(z4.x, 1);
+    float a_c[4], w[4], zz[4];
+    double om[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float z0 = el(z4, k);
+        const float z1 = k < 3 ? el(z4, k + 1) : z_next;
+        zz[k] = z0;
+        const float dl = (s0 + k == Nc - 1) ? 1e2f : (z1 - z0);
+        const float e_c = expf(-(dl * (el(ss4, k) + 0.f)));
+        a_c[k] = 1.f - e_c;
+        om[k] = (double)(1.f - a_c[k]);
+    }
+    {
+        const double p0 = om[0], p1 = p0 * om[1], p2 = p1 * om[2], p3 = p2 * om[3];
+        const double inc = seg_incl_prod<RW>(p3, sl);
+        const double prev = __shfl_up(inc, 1);
+        const double E = sl == 0 ? 1.0 : prev;
+        w[0] = a_c[0] * (float)E; w[1] = a_c[1] * (float)(E * p0); w[2] = a_c[2] * (float)(E * p1); w[3] = a_c[3] * (float)(E * p2);
+    }
+    if (weights_out && live) *(float4*)(weights_out + (size_t)ray * Nc + s0) = make_float4(w[0], w[1], w[2], w[3]);
+
+    // ---- bins = z_mid, cdf = [0, cumsum((w[1:-1] + 1e-5) / sum)]  (rendering.py:26-29,132-134; sample_pdf_merge_kernel) ----
+    double part = 0.0;
+    float pw[4];                                                  // w + 1e-5 of this lane's samples that are pdf entries (k in 1 .. Nc-2)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int kk = s0 + k;
+        all[kk] = zz[k];
+        if (kk < nb) bins[kk] = __fmul_rn(.5f, __fadd_rn(k < 3 ? zz[k + 1] : z_next, zz[k]));
+        pw[k] = __fadd_rn(w[k], 1e-5f);
+        if (kk >= 1 && kk <= np_) part += (double)pw[k];
+    }
+    const float total = (float)seg_sum<RW>(part, lane);
+    {
+        double run[4], acc_ = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int kk = s0 + k;
+            if (kk >= 1 && kk <= np_) acc_ += (double)__fdiv_rn(pw[k], total);
+            run[k] = acc_;
+        }
+        const double incl = seg_incl_sum<RW>(acc_, sl);
+        const double base = incl - acc_;                          // everything in front of this lane (exact: see the header comment)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int kk = s0 + k;
+            if (kk == 0) cdf[0] = 0.f;
+            else if (kk <= np_) cdf[kk] = (float)(base + run[k]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+
+    // ---- inverse-CDF samples (rendering.py:31-64): searchsorted(cdf, u, right=True) = #{k : cdf[k] <= u} ----
+    bool okc = true;
+    for (int k = sl; k + 1 < nb; k += LPR) okc = okc && (cdf[k] <= cdf[k + 1]);
+    const bool cdf_sorted = (__ballot(!okc) & seg_mask) == 0ull;
+    for (int i0 = sl; i0 < Ni; i0 += 2 * LPR) {
+        const int ii[2] = {i0, i0 + LPR};
+        float uu[2];
+        int cnt[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = ii[e] < Ni ? ii[e] : Ni - 1;
+            uu[e] = u_per_ray ? u[(size_t)ray * Ni + i] : u[i];
+        }
+        if (cdf_sorted && uu[0] == uu[0] && uu[1] == uu[1]) {
+            int lo0 = 0, hi0 = nb, lo1 = 0, hi1 = nb;
+            while (lo0 < hi0 || lo1 < hi1) {
+                const int m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+                const float c0 = cdf[m0 < nb ? m0 : nb - 1], c1 = cdf[m1 < nb ? m1 : nb - 1];
+                if (lo0 < hi0) { if (c0 <= uu[0]) lo0 = m0 + 1; else hi0 = m0; }
+                if (lo1 < hi1) { if (c1 <= uu[1]) lo1 = m1 + 1; else hi1 = m1; }
+            }
+            cnt[0] = lo0; cnt[1] = lo1;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                cnt[e] = 0;
+                if (cdf_sorted && uu[e] == uu[e]) cnt[e] = count_less_equal(cdf, nb, uu[e]);
+                else for (int k = 0; k < nb; ++k) cnt[e] += (cdf[k] <= uu[e]) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (ii[e] >= Ni) continue;
+            const int i = ii[e];
+            const int below = cnt[e] - 1 > 0 ? cnt[e] - 1 : 0;
+            const int above = cnt[e] < nb - 1 ? cnt[e] : nb - 1;
+            const float c_lo = cdf[below], c_hi = cdf[above], b_lo = bins[below], b_hi = bins[above];
+            float denom = __fsub_rn(c_hi, c_lo);
+            denom = denom < 1e-5f ? 1.f : denom;
+            const float t = __fdiv_rn(__fsub_rn(uu[e], c_lo), denom);
+            const float smp = __fadd_rn(b_lo, __fmul_rn(t, __fsub_rn(b_hi, b_lo)));
+            all[Nc + i] = smp;
+            if (z_samples && live) z_samples[(size_t)ray * Ni + i] = smp;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+
+    // ---- stable rank sort of cat[z_coarse, z_samples] (rendering.py:141), as sample_pdf_merge_kernel ----
+    bool oka = true;
+    for (int k = sl; k + 1 < Nc; k += LPR) oka = oka && (all[k] <= all[k + 1]);
+    for (int k = sl; k + 1 < Ni; k += LPR) oka = oka && (all[Nc + k] <= all[Nc + k + 1]);
+    const bool ordered = (__ballot(!oka) & seg_mask) == 0ull;
+    for (int i = sl; i < S; i += LPR) {
+        const float v = all[i];
+        int rank = 0;
+        if (ordered) {
+            rank = i < Nc ? i + count_less(all + Nc, Ni, v) : (i - Nc) + count_less_equal(all, Nc, v);
+        } else {
+            const bool v_nan = v != v;
+            for (int k = 0; k < S; ++k) {
+                const float o = all[k];
+                const bool o_nan = o != o;
+                const bool before = v_nan ? (!o_nan || k < i) : (!o_nan && (o < v || (o == v && k < i)));
+                rank += before ? 1 : 0;
+            }
+        }
+        sorted[rank] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (live)
+        for (int i = sl; i < S; i += LPR) z_fine[(size_t)ray * S + i] = sorted[i];
+}
+
+template <int RW>
+static int launch_coarse_sample(int N, int Ni, const float* sigma, const float* z, size_t z_stride, const float* u, int u_per_ray,
+                                float* z_fine, float* z_samples, float* weights_out, hipStream_t st) {
+    constexpr int RPW = Seg<RW>::RPW, Nc = 64 * RW;
+    const size_t lds = (size_t)4 * RPW * (2 * Nc + 2 * (Nc + Ni)) * sizeof(float);
+    auto k = coarse_sample_kernel<RW>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, dim3((N + 4 * RPW - 1) / (4 * RPW)), dim3(256), lds, st, N, Ni, sigma, z, z_stride, u, u_per_ray, z_fine,
+                       z_samples, weights_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_coarse_sample(int N, int Nc, int Ni, const float* sigma, const float* z, int z_shared_row, const float* u,
+                                   int u_per_ray, float* z_fine, float* z_samples, float* weights_out, void* stream) {
+    if (!sigma || !z || !u || !z_fine || N <= 0 || Ni <= 0) return NEFES_E_BADARG;
+    if (Nc + Ni > SP_MAX_S) return NEFES_E_UNSUPPORTED;
+    if (((uintptr_t)sigma | (uintptr_t)z | (uintptr_t)weights_out) & 15) return NEFES_E_BADARG;      // 16-byte row loads
+    const size_t zs = z_shared_row ? 0 : (size_t)Nc;
+    hipStream_t st = (hipStream_t)stream;
+    switch (Nc) {
+        case 64: return launch_coarse_sample<1>(N, Ni, sigma, z, zs, u, u_per_ray, z_fine, z_samples, weights_out, st);
+        case 128: return launch_coarse_sample<2>(N, Ni, sigma, z, zs, u, u_per_ray, z_fine, z_samples, weights_out, st);
+        case 256: return launch_coarse_sample<4>(N, Ni, sigma, z, zs, u, u_per_ray, z_fine, z_samples, weights_out, st);
+    }
+    return NEFES_E_UNSUPPORTED;                                   // other coarse counts: composite D + nefes_sample_pdf_merge
+}
+
 extern "C" int nefes_sample_pdf_merge(int N, int Nc, int Ni, int layout, const float* z_coarse, const float* weights,
                                       const float* u, int u_per_ray, const float* cdf_in, float* z_fine, float* z_samples,
                                       int32_t* inds, float* cdf_out, void* stream) {

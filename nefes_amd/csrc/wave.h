@@ -82,3 +82,61 @@ __device__ __forceinline__ void wave_rev_affine(double& m, double& a, int lane) 
     }
 }
 __device__ __forceinline__ double lane_bcast(double v, int src) { return __shfl(v, src); }
+
+// ---- rays that occupy RW rows of 16 lanes, four consecutive samples per lane (composite.hip's four-samples-per-lane kernels and
+// ---- the fused coarse-pass sampler of sample_pdf.hip): 4 / RW rays share a wave -----------------------------------------------
+template <int RW> struct Seg {
+    static constexpr int LPR = 16 * RW;              // lanes per ray
+    static constexpr int RPW = 4 / RW;               // rays per wave (RW = 3: one ray, the fourth row idles)
+};
+// sum over the lanes of this lane's ray (RW rows of 16 lanes), on every lane of the ray
+template <int RW>
+__device__ __forceinline__ double seg_sum(double v, int lane) {
+    v += dpp_move<0xb1>(v);
+    v += dpp_move<0x4e>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);                         // every lane holds its row's sum
+    if (RW == 1) return v;
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    if (RW == 2) return lane < 32 ? r0 + r1 : r2 + r3;
+    if (RW == 3) return (r0 + r1) + r2;
+    return ((r0 + r1) + r2) + r3;
+}
+// inclusive prefix product over the lanes of a ray (sl = lane index inside the ray)
+template <int RW>
+__device__ __forceinline__ double seg_incl_prod(double v, int sl) {
+#pragma unroll
+    for (int o = 1; o < 16 * RW; o <<= 1) {
+        const double u = __shfl_up(v, o);
+        if (sl >= o) v *= u;
+    }
+    return v;
+}
+// reverse scan of affine maps over the lanes of a ray: lane i ends with F_i o F_{i+1} o ... o F_last
+template <int RW>
+__device__ __forceinline__ void seg_rev_affine(double& m, double& a, int sl) {
+#pragma unroll
+    for (int o = 1; o < 16 * RW; o <<= 1) {
+        const double m2 = __shfl_down(m, o), a2 = __shfl_down(a, o);
+        if (sl + o < 16 * RW) {
+            a = a + m * a2;
+            m = m * m2;
+        }
+    }
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ float el(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+// inclusive prefix sum over the lanes of a ray (sl = lane index inside the ray)
+template <int RW>
+__device__ __forceinline__ double seg_incl_sum(double v, int sl) {
+#pragma unroll
+    for (int o = 1; o < 16 * RW; o <<= 1) {
+        const double u = __shfl_up(v, o);
+        if (sl >= o) v += u;
+    }
+    return v;
+}

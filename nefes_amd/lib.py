@@ -32,7 +32,7 @@ class NefesHashGridDesc(C.Structure):
                 ("base_resolution", C.c_int32), ("per_level_scale", C.c_float), ("bound", C.c_float)]
 
 
-ABI_VERSION = 13       # NEFES_ABI_VERSION of include/nefes_hip.h
+ABI_VERSION = 14       # NEFES_ABI_VERSION of include/nefes_hip.h
 STREAM_FWD_SIGMA, STREAM_FWD_STATIC, STREAM_FWD_FULL, STREAM_BWD_FULL, STREAM_FWD_SIGMA_X6, STREAM_FWD_FULL_X6, STREAM_BWD_FULL_X6, STREAM_BWD_STATIC = 0, 1, 2, 3, 4, 5, 6, 7
 STREAM_FWD_SIGMA_H3, STREAM_FWD_FULL_H3, STREAM_BWD_FULL_H3, STREAM_FWD_STATIC_H3, STREAM_BWD_STATIC_H3 = 8, 9, 10, 11, 12
 FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
@@ -80,6 +80,8 @@ SIGNATURES = {
     "nefes_field_fwd_x6": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_bwd_h3": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_fwd_h3": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_field_fwd_h3_zrow": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_coarse_sample": (_i, [_i, _i, _i, _p, _p, _i, _p, _i, _p, _p, _p, _p]),
     "nefes_conv2d_same": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p]),
     "nefes_probe_mfma_clock": (_i, [_i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), _p]),
     "nefes_train_rows": (_sz, [_desc]),

@@ -173,6 +173,64 @@ def coarse_depths(N, Nc, near, far, lindisp=False, t_rand=None, device="cuda", b
     return z
 
 
+_ZROW = {}
+
+
+def coarse_depth_row(Nc, near, far, lindisp=False, device="cuda"):
+    """The ONE row of coarse depths every ray shares when near / far are scalars and nothing is jittered (rendering.py:96-100:
+    z_vals = near (1 - t) + far t, expanded to [N_rays, N_samples]): [Nc], computed once per (Nc, near, far, lindisp, device) by the
+    same kernel as coarse_depths, so the expanded tensor never exists (field_sigma_row, coarse_sample)."""
+    key = (int(Nc), float(near), float(far), bool(lindisp), str(device))
+    z = _ZROW.get(key)
+    if z is None:
+        z = _ZROW[key] = coarse_depths(1, Nc, near, far, lindisp, None, device=device).reshape(-1)
+    return z
+
+
+def fused_coarse_pass_ok(pk, Nc, Ni):
+    """The coarse pass as two launches (sigma-only field kernel on a shared depth row + coarse_sample) instead of four: fp16 two-part
+    instances, frequency embedding, Nc = 64 / 128 / 256, Nc + Ni <= 512 (csrc/sample_pdf.hip coarse_sample_kernel)."""
+    return (FUSED_COARSE and _h3(pk) and h3_shape(pk) and pk.xyz_encoding == L.XYZ_FREQ10 and Nc in (64, 128, 256)
+            and Ni > 0 and Nc + Ni <= 512)
+
+
+def field_sigma_row(pk, rays_o, rays_d, z_row):
+    """sigma [N,1,Nc] of the coarse network along rays whose depths are ONE shared row (no gradient: nerfh_nff.py:192-202)."""
+    rays_o, rays_d = _f32(rays_o), _f32(rays_d)
+    N, S = rays_o.shape[0], z_row.numel()
+    if N * S >= (1 << 31) - 256:
+        raise RuntimeError("nefes_amd: too many samples for one launch of the fp16 two-part kernels (32-bit sample index)")
+    raw_t = torch.empty(N, 1, S, device=rays_o.device)
+    with _timed("field_fwd[sigma,h3]"):
+        L.check(L.load().nefes_field_fwd_h3_zrow(pk.desc, _chk(pk.blob, "blob", torch.uint8), L.FIELD_SIGMA, N, S, _chk(rays_o, "rays_o"),
+                                                 _chk(rays_d, "rays_d"), _chk(z_row, "z_row"), None, _chk(raw_t, "raw_t"), None, _stream()),
+                "nefes_field_fwd_h3_zrow")
+    return raw_t
+
+
+def coarse_sample(sigma, z, Ni, u=None, want_samples=True, want_weights=False):
+    """Compositing variant D + sample_pdf + sort(cat) of the coarse pass in ONE launch (csrc/sample_pdf.hip coarse_sample_kernel;
+    nerfh_nff.py:83-89, rendering.py:23-66,132-141).  sigma [N,1,Nc] or [N,Nc]; z [N,Nc], or [Nc] = one row shared by every ray.
+    -> (z_fine [N,Nc+Ni], z_samples [N,Ni] or None[, weights [N,Nc]]); bit-identical to composite_fwd(COMP_SIGMA_ONLY) +
+    sample_pdf_merge."""
+    sigma, z = _f32(sigma), _f32(z)
+    N, Nc = sigma.shape[0], sigma.shape[-1]
+    dev = sigma.device
+    if u is None:
+        u = _linspace01(Ni, dev)
+    u = _f32(u)
+    z_fine = torch.empty(N, Nc + Ni, device=dev)
+    z_samples = torch.empty(N, Ni, device=dev) if want_samples else None
+    weights = torch.empty(N, Nc, device=dev) if want_weights else None
+    with _timed("coarse_sample"):
+        L.check(L.load().nefes_coarse_sample(N, Nc, Ni, _chk(sigma, "sigma"), _chk(z, "z"), 1 if z.dim() == 1 else 0, _chk(u, "u"),
+                                             1 if u.dim() == 2 else 0, _chk(z_fine, "z_fine"), _chk(z_samples, "z_samples"),
+                                             _chk(weights, "weights"), _stream()), "nefes_coarse_sample")
+    _tap("z_fine", z_fine)
+    _tap("z_samples", z_samples)
+    return (z_fine, z_samples, weights) if want_weights else (z_fine, z_samples)
+
+
 # ---------------------------------------------------------------------------------------------
 # field MLP
 # ---------------------------------------------------------------------------------------------
@@ -290,6 +348,9 @@ SPLIT = os.environ.get("NEFES_SPLIT", "h3")
 # let re-packed networks run on the bf16x6 instances (the round-2 behaviour)
 REPACK_H3 = os.environ.get("NEFES_REPACK_H3", "1") != "0"
 USE_X6 = os.environ.get("NEFES_X6", "1") != "0"
+# the coarse pass at test time as two launches instead of four (coarse_depth_row / field_sigma_row / coarse_sample); "0": the separate
+# coarse_depths, sigma field, composite D and sample_pdf_merge launches (the tests compare the two bit for bit)
+FUSED_COARSE = os.environ.get("NEFES_FUSED_COARSE", "1") != "0"
 
 
 HEAD_MAX_C = 141          # csrc/layout.h NEFES_HEAD_MAX_C: the larger head class serves 3 + C <= 144

@@ -125,11 +125,21 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
             return T.field_train(net, mode, rays_o, rays_d, viewdirs, z_)
         return _field(pk, mode, rays_o, rays_d, viewdirs, z_, cfg.xyz_encoder)
 
-    t_rand = torch.rand(N, Nc, device=dev) if cfg.perturb > 0. else None            # :110 (RNG stays in torch)
-    z = ops.coarse_depths(N, Nc, near, far, cfg.lindisp, t_rand, device=dev, bounds=bounds)
-    store_rgb = (Ni == 0)
     pk_c = network_fn.packed()
     C = pk_c.feat_dim
+    store_rgb = (Ni == 0)
+    if (cfg.test_time and cfg.perturb == 0. and cfg.raw_noise_std == 0. and bounds is None and cfg.xyz_encoder is None
+            and not cfg.use_fine_only and ops.fused_coarse_pass_ok(pk_c, Nc, Ni)):
+        # The coarse pass at test time (:96-141, nerfh_nff.py:192-202) as TWO launches: every ray shares one row of depths, which is
+        # computed once per (near, far, Nc) and never expanded; the sigma-only field kernel reads it; compositing variant D,
+        # sample_pdf and the sort run per ray in one kernel, the coarse weights stay in registers.
+        with torch.no_grad():
+            z_row = ops.coarse_depth_row(Nc, near, far, cfg.lindisp, dev)
+            raw_c = ops.field_sigma_row(pk_c, rays_o.detach(), rays_d.detach(), z_row)
+            z_fine, z_samples = ops.coarse_sample(raw_c, z_row, Ni, want_samples=False)
+        return _fine_pass(rays_o, rays_d, viewdirs, z_fine, z_samples, network_fine, cfg, C, field, None)
+    t_rand = torch.rand(N, Nc, device=dev) if cfg.perturb > 0. else None            # :110 (RNG stays in torch)
+    z = ops.coarse_depths(N, Nc, near, far, cfg.lindisp, t_rand, device=dev, bounds=bounds)
     if cfg.test_time:
         # coarse + test_time: sigma-only branch, nothing differentiable (nerfh_nff.py:192-202)
         with torch.no_grad():
@@ -156,6 +166,13 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
     # hierarchical sampling (:132-141); z_samples are detached in the reference
     u = None if cfg.perturb == 0. else torch.rand(N, Ni, device=dev)
     z_fine, z_samples = ops.sample_pdf_merge(z, w0.detach(), Ni, u=u)
+    return _fine_pass(rays_o, rays_d, viewdirs, z_fine, z_samples, network_fine, cfg, C, field, (rgb0, feat0, disp0, acc0))
+
+
+def _fine_pass(rays_o, rays_d, viewdirs, z_fine, z_samples, network_fine, cfg, C, field, coarse_maps):
+    """rendering.py:142-180: the fine network at the merged depths, compositing, and the reference's `ret` dict.  coarse_maps =
+    (rgb0, feat0, disp0, acc0) of a differentiable coarse pass, or None (test time)."""
+    rgb0, feat0, disp0, acc0 = coarse_maps if coarse_maps is not None else (None, None, None, None)
     z_f = z_samples if cfg.use_fine_only else z_fine
     pk_f = network_fine.packed()
     mode = L.FIELD_FULL if cfg.NeRFW else L.FIELD_STATIC

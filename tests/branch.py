@@ -85,16 +85,19 @@ class Pinned:
 
 
 # ---- shared comparison helpers of the GPU tests (and of __graft_entry__.smoke) ---------------------------------------
-def rel(a, b):
+def rel(a, b, scale=None):
+    """max |a - b| relative to max |b| -- or to a given `scale` (an absolute statement: e.g. a late iteration's gradient error in
+    units of the FIRST iteration's gradient norm, where the loop's gradient has shrunk tenfold into a remainder of cancelling
+    terms and its own norm is no longer the natural unit)."""
     a = a.detach().cpu().double() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)).double()
     b = b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).double()
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    return float((a - b).abs().max() / (b.abs().max().clamp_min(1e-30) if scale is None else float(scale)))
 
 
-def three_way(test, name, got, ref32, truth, tol=P.NORTH_STAR_TOL, factor=P.REF_FACTOR):
+def three_way(test, name, got, ref32, truth, tol=P.NORTH_STAR_TOL, factor=P.REF_FACTOR, scale=None):
     """hip vs float64, fp32 oracle vs float64, hip vs fp32 oracle; recorded (tests/parity_log.py) and asserted with the
     shared rule e_hip <= max(tol, factor * e_ref)."""
-    e_hip, e_ref, direct = rel(got, truth), rel(ref32, truth), rel(got, ref32)
+    e_hip, e_ref, direct = rel(got, truth, scale), rel(ref32, truth, scale), rel(got, ref32, scale)
     print(f"[{test}] {name}: hip-vs-f64 {e_hip:.2e}  fp32-oracle-vs-f64 {e_ref:.2e}  hip-vs-fp32-oracle {direct:.2e}")
     P.check(test, name, e_hip, e_ref, direct, tol=tol, factor=factor)
     return e_hip, e_ref, direct
@@ -125,7 +128,7 @@ AUDIT_CLASSES = {
 }
 
 
-def pinned_gradients(tag, hip, tap, Wd, oracle_run, tol=P.NORTH_STAR_TOL, audit="same_inputs"):
+def pinned_gradients(tag, hip, tap, Wd, oracle_run, tol=P.NORTH_STAR_TOL, audit="same_inputs", scale=None, suffix=" [branch-pinned]"):
     """Gradient parity on the kernels' own ReLU branch pattern: `oracle_run(dtype, act, z_fine)` -> {name: gradient} of the
     oracle evaluated with the activation hook `act` (and, for render-level runs, at the kernels' depths `z_fine`);
     `hip` = the same dict from the kernels.  Also audits the branch pattern against the float64 pre-activations."""
@@ -139,5 +142,8 @@ def pinned_gradients(tag, hip, tap, Wd, oracle_run, tol=P.NORTH_STAR_TOL, audit=
     assert worst < audit_tol and flips <= max(8, units // 100000) * (audit_tol / 2e-5), (flips, units, worst)
     out = {}
     for name in hip:
-        out[name] = three_way(tag, name + " [branch-pinned]", hip[name], g32[name], g64[name], tol=tol)
+        out[name] = three_way(tag, name + suffix, hip[name], g32[name], g64[name], tol=tol, scale=scale)
+        if scale is not None:      # the same three numbers relative to the gradient's own norm: recorded, not bounded
+            P.record(tag, name + " [branch-pinned, relative to its own norm]", e_hip=rel(hip[name], g64[name]), e_ref=rel(g32[name], g64[name]),
+                     direct=rel(hip[name], g32[name]), bound=None)
     return out

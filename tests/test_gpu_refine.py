@@ -63,30 +63,27 @@ def test_refinement_iteration_matches_reference_along_its_trajectory(golden):
     assert worst < 1e-3
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_refinement_loop_tracks_the_reference(golden, graph):
-    """Free-running, eager and as one replayed HIP graph per iteration.  The first iterations coincide with the reference's.
-    After twelve, the well-conditioned outputs agree: rotation block within 2e-3 (it moves by 0.1), loss curve within 2e-3 of
-    its largest value (measured 1e-3; the reference's own fp32 curve is 8e-4 from the float64 one).  The translation is driven by a noise-level gradient that Adam amplifies (tests/test_refine_oracle.py:
-    the reference's own fp32 run ends 0.03 from the float64 run): it is held to 1.5 x that distance, the shared rule."""
+def test_refinement_loop_graph_equals_eager_and_follows_the_loss_curve(golden):
+    """Free-running on the round-2 fixture (default-init scene), eager and as one replayed HIP graph per iteration: the two are the
+    same arithmetic (poses and loss curves bit for bit), the first iterations coincide with the reference's, and the loss curve obeys
+    the shared rule against the float64 oracle loop.  This scene's translation is driven by a noise-level gradient that Adam
+    amplifies (the reference's own fp32 run ends 0.03 from the float64 run: tests/test_refine_oracle.py), so its refined POSE is not
+    a parity statement and is not asserted here (round 3 held it to 1.5 x that distance, a 0.047 bound that proved nothing); the
+    free-running pose statements live on the conditioned scene of tests/test_gpu_refine50.py."""
     g = golden("refine")
     n = len(g["losses"])
-    ref = refiner(g, graph=graph)
-    pose, losses = ref.refine(T(g["init_c2w"]), T(g["target"]), T(g["hist"]), n)
-    losses, pose = losses.cpu().numpy(), pose[:3, :4].cpu().numpy()
-    tag = f"refine_loop[{'graph' if graph else 'eager'}]"
+    out = {}
+    for graph in (False, True):
+        ref = refiner(g, graph=graph)
+        pose, losses = ref.refine(T(g["init_c2w"]), T(g["target"]), T(g["hist"]), n)
+        out[graph] = (pose[:3, :4].cpu().numpy(), losses.cpu().numpy())
+    assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
+    pose, losses = out[True]
     b = RC.refine(problem(g, torch.float64), float(g["lr"][0]), float(g["lr"][1]), n)
-    truth, gold = b["poses"][-1].numpy(), g["poses"][-1]
-    P.check(tag, "refined rotation block (abs)", float(np.abs(pose[:, :3] - truth[:, :3]).max()),
-            float(np.abs(gold[:, :3] - truth[:, :3]).max()), float(np.abs(pose[:, :3] - gold[:, :3]).max()), tol=2e-3, factor=1.5)
-    P.check(tag, "refined translation (abs)", float(np.abs(pose[:, 3] - truth[:, 3]).max()),
-            float(np.abs(gold[:, 3] - truth[:, 3]).max()), float(np.abs(pose[:, 3] - gold[:, 3]).max()), tol=2e-3, factor=1.5)
     assert rel(losses[:2], g["losses"][:2]) < 2e-4
-    el = rel(losses, g["losses"])
-    P.record(tag, "loss curve", e_hip=rel(losses, b["losses"].numpy()), e_ref=rel(g["losses"], b["losses"].numpy()), direct=el, bound=2e-3)
-    assert el < 2e-3
+    P.check("refine_loop", "loss curve", rel(losses, b["losses"].numpy()), rel(g["losses"], b["losses"].numpy()), rel(losses, g["losses"]),
+            tol=1e-3, factor=1.5)
     assert losses[-1] < 0.2 * losses[0]
-    assert float(np.abs(gold[:, :3] - g["init_c2w"][:3, :3]).max()) > 0.05          # the motion the 2e-3 are measured against
 
 
 def test_fusion_net_and_affine_transform_on_the_gpu(golden):

@@ -394,3 +394,60 @@ def test_every_shipped_config_runs_on_the_hip_path():
             g = [p.grad for n, p in fine.named_parameters() if p.grad is not None]
             assert g and all(torch.isfinite(x).all() for x in g), name
             optimizer.step()
+
+
+@pytest.mark.parametrize("Nc,Ni", [(64, 128), (64, 64), (128, 128), (256, 256), (64, 37)])
+def test_fused_coarse_sampler_is_bit_identical_to_the_three_launches(Nc, Ni):
+    """csrc/sample_pdf.hip coarse_sample_kernel (compositing variant D + sample_pdf + sort in one launch, several rays per wave)
+    against nefes_composite_fwd(COMP_SIGMA_ONLY) + nefes_sample_pdf_merge: weights, samples and merged depths bit for bit -- with
+    per-ray depths and with one shared row, with the deterministic u and with per-ray jittered u, on rays that are empty, saturated
+    (alpha = 1), carry a NaN, and on a ray count that fills neither the last wave nor the last workgroup."""
+    from nefes_amd import lib as L
+    from nefes_amd import ops
+    gen = torch.Generator().manual_seed(100 + Nc + Ni)
+    N = 37
+    sigma = torch.nn.functional.softplus(torch.randn(N, Nc, generator=gen) * 3) * 0.5
+    sigma[1] = 0.
+    sigma[2] = 3000.
+    sigma[3, Nc // 2:Nc // 2 + 3] = 5000.
+    sigma[4, 7] = float("nan")
+    sigma[5] = 1e-12
+    z_row = ops.coarse_depth_row(Nc, 0.25, 5.0, False, DEV)
+    z_rays = torch.sort(z_row[None].cpu() + (torch.rand(N, Nc, generator=gen) - .5) * 0.02, -1)[0].to(DEV).contiguous()
+    u_ray = torch.rand(N, Ni, generator=gen).to(DEV)
+    sg = sigma.to(DEV).reshape(N, 1, Nc).contiguous()
+    for z, tag in ((z_rays, "per-ray depths"), (z_row, "shared row")):
+        z_full = z if z.dim() == 2 else z[None].expand(N, Nc).contiguous()
+        _, _, _, acc, _, w_ref, _ = ops.composite_fwd(sg, z_full, 16, L.COMP_SIGMA_ONLY)
+        for u in (None, u_ray):
+            zf_ref, zs_ref = ops.sample_pdf_merge(z_full, w_ref, Ni, u=u)
+            zf, zs, w = ops.coarse_sample(sg, z, Ni, u=u, want_weights=True)
+            same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=-7.), torch.nan_to_num(b, nan=-7.)) and torch.equal(torch.isnan(a), torch.isnan(b))
+            assert same(w, w_ref), (tag, "weights")
+            assert same(zs, zs_ref), (tag, "z_samples", (zs != zs_ref).nonzero()[:4])
+            assert same(zf, zf_ref), (tag, "z_fine")
+            ok = torch.ones(N, dtype=torch.bool)
+            ok[4] = False
+            assert bool((zf[ok.to(DEV)].diff(dim=-1) >= 0).all())
+
+
+def test_render_with_the_fused_coarse_pass_equals_the_separate_launches(monkeypatch):
+    """render() at test time through the two-launch coarse pass (shared depth row, fused sampler: the default) and through the four
+    separate launches (NEFES_FUSED_COARSE=0): every map and the pose gradient bit for bit, at both canonical shapes."""
+    R, M, _ = dropin()
+    from nefes_amd import ops
+    for Wd, C, Ni in ((128, 128, 64), (256, 16, 128)):
+        coarse, fine = nets(Wd, C)
+        kw = dict(kwargs(M, coarse, fine, Ni), use_viewdirs=True, ndc=False)
+        H, W, focal = 12, 20, 16.0
+        out = {}
+        for fused in (True, False):
+            monkeypatch.setattr(ops, "FUSED_COARSE", fused)
+            monkeypatch.setattr(ops, "TIMERS", {})
+            c2w = O.bench_pose().to(DEV).requires_grad_()
+            rgb, disp, acc, ex = R.render(H, W, focal, c2w=c2w, near=0., far=4., **kw)
+            O.bench_loss(rgb, ex["feat_map"]).backward()
+            out[fused] = (rgb.detach(), disp.detach(), acc.detach(), ex["feat_map"].detach(), c2w.grad.clone())
+            assert ("coarse_sample" in ops.TIMERS) == fused and ("sample_pdf_merge" in ops.TIMERS) == (not fused)
+        for a, b in zip(out[True], out[False]):
+            assert torch.equal(a, b)

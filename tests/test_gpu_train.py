@@ -305,10 +305,14 @@ def check_train_golden(g, tag):
             worst["e_hip"] = max(worst["e_hip"], float((a - t64).abs().max() / sc))
             worst["e_ref"] = max(worst["e_ref"], float((b - t64).abs().max() / sc))
         worst["direct"] = max(worst["direct"], direct)
-        assert direct < 3e-2, k
+        assert direct < 1e-3, k                                       # against the reference's own fp32 gradient (measured <= 6e-5)
         assert float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30)) > 0.9995, k
         n += 1
-    P.record(f"train_golden[{tag}]", "worst parameter gradient, UNPINNED: hip / reference fp32 vs float64 on its own branches", bound=3e-2, **worst)
+    # unpinned: both fp32 runs sit the same few 1e-3 from the float64 oracle on ITS branches (kink noise); the HIP run is held to the
+    # shared rule against the reference's own distance, and to 1e-3 of the reference's gradient directly (above)
+    bound = P.bound(worst["e_ref"], tol=1e-3)
+    P.record(f"train_golden[{tag}]", "worst parameter gradient, UNPINNED: hip / reference fp32 vs float64 on its own branches", bound=bound, **worst)
+    assert worst["e_hip"] <= bound, worst
     assert n >= 19
 
 
