@@ -76,13 +76,8 @@ struct StoringSplitH {
     __device__ __forceinline__ void stage_a(PairRegs& s, int q, int pp) const {
         in.stage_a(s, q, pp);
         const int e = 8 * q + 2 * pp;
-#ifdef H3_TRAIN_TEMPORAL      // A/B switch: ordinary (write-back) stores
-        p[(e >> 4) * 4096 + nefes_rho(0, e & 15) * 16] = s.x0 * inv;
-        p[((e + 1) >> 4) * 4096 + nefes_rho(0, (e + 1) & 15) * 16] = s.x1 * inv;
-#else
         __builtin_nontemporal_store(s.x0 * inv, &p[(e >> 4) * 4096 + nefes_rho(0, e & 15) * 16]);      // layout.h nefes_train_off
         __builtin_nontemporal_store(s.x1 * inv, &p[((e + 1) >> 4) * 4096 + nefes_rho(0, (e + 1) & 15) * 16]);
-#endif
     }
     __device__ __forceinline__ void stage_b(PairRegs& s) const { in.stage_b(s); }
     template <bool NOP>
@@ -102,11 +97,7 @@ __device__ __forceinline__ auto wrap_store_h3(const Inner& in, float* p, float i
 // the HBM counters showed 63 GB fetched per launch (FETCH_SIZE x 2 is exact for these load widths: tools/probe/fetch_probe.hip).
 template <typename T>
 __device__ __forceinline__ T ld_stream(const T* p) {
-#ifdef H3_BWD_TEMPORAL_LOADS
-    return *p;
-#else
     return __builtin_nontemporal_load(p);
-#endif
 }
 
 // HAS_T = false: the static head only (NEFES_FIELD_STATIC forward: raw channels rgb+feature, sigma); the stream then is

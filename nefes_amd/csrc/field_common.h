@@ -32,16 +32,7 @@ __device__ __forceinline__ float sigmoid_ref(float x) { return 1.f / (1.f + expf
 // Source address = wave-uniform 64-bit base (SGPR pair, advanced by scalar ALU) + a constant 32-bit per-lane offset:
 // the refill costs no vector ALU instruction (VALU ops are never hidden behind an fp32 MFMA of the same wave).
 __device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, uint32_t lds_dst) {
-#ifdef H3_ABL_NODMA     // timing ablation (tools/ablate_h3.sh): no transfer; the consumers read whatever the LDS holds
-    asm volatile("" :: "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
-    return;
-#endif
     uint32_t keep;
-#ifdef NEFES_DBG_OLD_DMA
-    const char* gsrc = (const char*)gbase + lane_off;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-#else
     // The SGPR base may have just been written by a VALU instruction (v_readlane restoring a spilled SGPR,
     // v_readfirstlane), and a VMEM instruction reading such an SGPR needs 5 wait states the compiler does not insert for
     // inline asm.  Instead of padding (s_nop 4 = 20 cycles, a large part of a 32-cycle bf16 MFMA gap) the base is copied
@@ -63,7 +54,6 @@ __device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, 
         : "=&s"(base2)
         : "v"(lane_off), "s"(gbase), "s"(lds_dst)
         : "memory");
-#endif
 }
 // 1-instruction ReLU (fmaxf() costs a canonicalising v_max in front of the real one)
 // NOP = true: the result feeds an MFMA as srcB straight away.  A VALU write -> MFMA operand read needs 2 wait states that
@@ -72,14 +62,10 @@ __device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t lane_off, 
 // MFMA issues between this instruction and the consumer (mma_run computes the operand one k-step ahead).
 template <bool NOP = true>
 __device__ __forceinline__ float relu1(float v) {
-#ifdef NEFES_DBG_OLD_RELU
-    return fmaxf(v, 0.f);
-#else
     float r;
     if (NOP) asm volatile("v_max_f32 %0, 0, %1\n\ts_nop 1" : "=v"(r) : "v"(v));
     else asm volatile("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
     return r;
-#endif
 }
 // ReLU-mask words are built by shifting, one VALU instruction per activation on either side of a word's life:
 // forward shifts the SIGN bit of the pre-activation in from the right (v_alignbit_b32: {word, v} >> 31 = word<<1 | sign),
@@ -149,28 +135,9 @@ struct WeightRing {
     }
     // Synchronisation point before consuming the next slab; returns its LDS byte offset (relative to the ring base).
     // After it the slot of the slab consumed before is free: its refill = the 4 issue_piece() calls that follow.
-#ifdef NEFES_STAMP   // diagnostic build only: cycles parked in the counted wait and in the barrier
-    unsigned long long dbg_wait = 0, dbg_barrier = 0;
-    static __device__ __forceinline__ unsigned long long now() {
-        unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
-#endif
     __device__ __forceinline__ uint32_t acquire() {
-#ifdef NEFES_STAMP
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long t0 = now();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEFES_SLAB_PIECES * (SLOTS - 2)) : "memory");
-        const unsigned long long t1 = now();
-        __builtin_amdgcn_s_barrier();
-        const unsigned long long t2 = now();
-        dbg_wait += t1 - t0; dbg_barrier += t2 - t1;
-#else
-#ifdef H3_ABL_NOBARRIER
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NEFES_SLAB_PIECES * (SLOTS - 2)) : "memory");
         __builtin_amdgcn_s_barrier();
-#endif
-#endif
         const uint32_t off = c_slot * NEFES_SLAB_BYTES;
         c_slot = (c_slot + 1 == SLOTS) ? 0 : c_slot + 1;
         return off;
@@ -466,10 +433,6 @@ __device__ __forceinline__ uint32_t phase_of(uint32_t hi, uint32_t lo, int k) { 
 // the round-1 form (f64 reduction per value, both polynomials): used by the experimental kernels of field_fwd_h4.hip and, with
 // -DNEFES_SINCOS_F64, by embed_slots / embed_slots_bwd for A/B timing
 __device__ __forceinline__ void sincos_turns(double t, int k, float& sn, float& cs) {
-#ifdef NEFES_DBG_OLD_SINCOS
-    sincosf((float)(t * 6.283185307179586) * (float)(1 << k), &sn, &cs);
-    return;
-#endif
     const double tk = __builtin_ldexp(t, k);
     const float r = (float)(tk - __builtin_rint(tk));          // [-0.5, 0.5] turns, exact difference
     const float q = __builtin_rintf(r * 4.f);                  // quadrant -2..2
@@ -488,19 +451,6 @@ __device__ __forceinline__ void sincos_turns(double t, int k, float& sn, float& 
 template <int L, int NS>
 __device__ __forceinline__ void embed_slots(float (&e)[NS], const float (&x)[3], int h) {
     static_assert(NS >= 3 * L + 2, "embedding vector too small");
-#ifdef NEFES_SINCOS_F64
-    double t[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) t[a] = (double)x[a] * 0.15915494309189533577;
-#pragma unroll
-    for (int k = 0; k < L; ++k)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            float sn, cs;
-            sincos_turns(t[a], k, sn, cs);
-            e[3 * k + a] = h ? cs : sn;
-        }
-#else
     uint32_t hi[3], lo[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) turns_fixed(x[a], hi[a], lo[a]);
@@ -509,7 +459,6 @@ __device__ __forceinline__ void embed_slots(float (&e)[NS], const float (&x)[3],
     for (int k = 0; k < L; ++k)
 #pragma unroll
         for (int a = 0; a < 3; ++a) e[3 * k + a] = sin_phase(phase_of(hi[a], lo[a], k) + quarter);
-#endif
     e[3 * L] = h ? x[1] : x[0];
     e[3 * L + 1] = h ? 0.f : x[2];
 #pragma unroll
@@ -520,20 +469,6 @@ __device__ __forceinline__ void embed_slots(float (&e)[NS], const float (&x)[3],
 template <int L, int NS>
 __device__ __forceinline__ void embed_slots_bwd(float (&gx)[3], const float (&g)[NS], const float (&x)[3], int h) {
     gx[0] = gx[1] = gx[2] = 0.f;
-#ifdef NEFES_SINCOS_F64
-    double t[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) t[a] = (double)x[a] * 0.15915494309189533577;
-#pragma unroll
-    for (int k = 0; k < L; ++k)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            float sn, cs;
-            const float f = (float)(1 << k);
-            sincos_turns(t[a], k, sn, cs);
-            gx[a] += g[3 * k + a] * (h ? -(f * sn) : (f * cs));
-        }
-#else
     uint32_t hi[3], lo[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) turns_fixed(x[a], hi[a], lo[a]);
@@ -545,6 +480,5 @@ __device__ __forceinline__ void embed_slots_bwd(float (&gx)[3], const float (&g)
             const float f = (float)(1 << k);
             gx[a] += g[3 * k + a] * (f * sin_phase(phase_of(hi[a], lo[a], k) + shift));
         }
-#endif
     if (h) { gx[1] += g[3 * L]; } else { gx[0] += g[3 * L]; gx[2] += g[3 * L + 1]; }
 }

@@ -59,11 +59,7 @@ __device__ __forceinline__ void train_save_h3(float* tile_base, uint32_t voff, i
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-#ifdef H3_TRAIN_TEMPORAL      // A/B switch: ordinary (write-back) stores
-            p[t * 4096 + nefes_rho(0, r) * 16] = X[T0 + t][r] * inv;
-#else
             __builtin_nontemporal_store(X[T0 + t][r] * inv, &p[t * 4096 + nefes_rho(0, r) * 16]);
-#endif
         }
 }
 
@@ -101,9 +97,6 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
     // bias block offsets (floats), in stream order: L1..L8, SIG, FINAL, DIR, RGB, T0, T1, T2, TH (as in field_fwd.hip)
     constexpr int B_SIG = 8 * W, B_FINAL = B_SIG + 32, B_DIR = B_FINAL + W, B_RGB = B_DIR + W / 2,
                   B_T0 = B_RGB + 32 * NTR, B_T1 = B_T0 + W / 2, B_T2 = B_T1 + W / 2, B_TH = B_T2 + W / 2;
-#ifdef H3_STAMP
-    const unsigned long long stamp_k0 = h3_now();
-#endif
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         // sample / ray indices are recomputed where they are needed (loads here, three output points below) rather than kept
@@ -418,9 +411,6 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
             }
         }
     }
-#ifdef H3_STAMP
-    if (threadIdx.x == 0) atomicAdd(&h3_stamp_total, h3_now() - stamp_k0);
-#endif
 }
 
 // magic multiplier for unsigned division by d, exact for dividends below 2^31: q = mulhi(n, magic) >> shift
@@ -471,21 +461,6 @@ int nefes_fwd_h3_launch_part6(int which, const FieldFwdH3Args& a, hipStream_t st
 int nefes_fwd_h3_launch_part7(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256, class 1
 int nefes_fwd_h3_launch_part8(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 128, class 0
 
-#if defined(H3_STAMP) && defined(H3_STAMP_READER)   // exactly one translation unit of a diagnostic build (tools/stamp_h3.sh)
-extern "C" int nefes_debug_h3_stamps(unsigned long long* out3) {
-    unsigned long long v[4] = {0, 0, 0, 0};
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(&v[3], HIP_SYMBOL(h3_stamp_total), 8);
-    hipMemcpyFromSymbol(&v[0], HIP_SYMBOL(h3_stamp_run), 8);
-    hipMemcpyFromSymbol(&v[1], HIP_SYMBOL(h3_stamp_acq), 8);
-    hipMemcpyFromSymbol(&v[2], HIP_SYMBOL(h3_stamp_n), 8);
-    out3[0] = v[0]; out3[1] = v[1]; out3[2] = v[2]; out3[3] = v[3];
-    const unsigned long long z = 0;
-    hipMemcpyToSymbol(HIP_SYMBOL(h3_stamp_total), &z, 8);
-    hipMemcpyToSymbol(HIP_SYMBOL(h3_stamp_run), &z, 8); hipMemcpyToSymbol(HIP_SYMBOL(h3_stamp_acq), &z, 8); hipMemcpyToSymbol(HIP_SYMBOL(h3_stamp_n), &z, 8);
-    return 0;
-}
-#endif
 
 #if NEFES_TU_PART == 1
 int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st) {

@@ -50,9 +50,6 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
     WeightRing<NEFES_X6_SLOTS> ring;
     ring.init(a.stream, a.n_slabs, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_base, wave, lane);
     __syncthreads();
-#ifdef NEFES_STAMP
-    const unsigned long long stamp_t0 = ring.now();
-#endif
     const char* ring_lane = ring_base + lane * 16;
     const char* bias_half = (const char*)bias_lds + 16 * h;
     ring.prime(ring_lane);
@@ -205,13 +202,6 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(FieldFwdX6Args a) 
         }
     }
     ring.drain();
-#ifdef NEFES_STAMP   // diagnostic build: per workgroup [cycles in counted waits, cycles in barriers, total cycles, tiles] of wave 0
-    if (a.masks && MODE != NEFES_FIELD_FULL && threadIdx.x == 0) {
-        unsigned long long* o = (unsigned long long*)a.masks + (size_t)blockIdx.x * 4;
-        o[0] = ring.dbg_wait; o[1] = ring.dbg_barrier; o[2] = ring.now() - stamp_t0;
-        o[3] = (a.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
-    }
-#endif
 }
 
 template <int MODE, int ENC, int W = 256, int NTR = 1, int NP = 6>

@@ -122,11 +122,6 @@ __device__ __forceinline__ void split_pair_lo(Split2& o, int p, float x0, float 
 }
 template <bool NOP>
 __device__ __forceinline__ void split_pair_h(Split2& o, int p, float x0, float x1, float r) {
-#ifdef H3_ABL_CHEAPSPLIT      // timing ablation: one VALU per pair instead of four, dataflow kept
-    o.h[p] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-    o.l[p] = __float_as_uint(r);
-    return;
-#endif
     uint32_t h, l;
     if (NOP)
         asm volatile(
@@ -165,7 +160,7 @@ struct PairRegs {
 // hosts the pair.  Left to itself hipcc moves the whole source set (128 registers) to VGPRs in one block at every layer boundary,
 // where the wave's matrix pipe idles: ~280 instructions between two runs, 7 % of the forward (seen in the disassembly).
 __device__ __forceinline__ float acc_read(const float& x) {
-#if defined(H3_ACC_READ_ASM) && !defined(H3_DBG_PLAINREAD)
+#if defined(H3_ACC_READ_ASM)
     float v;
     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(x));
     return v;
@@ -182,19 +177,15 @@ struct ReluSplitH {
     __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
         s.x0 = acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
         s.x1 = acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
-#ifndef H3_ABL_NOMASK
         if (CAPTURE) {
             mask_shift_in(bits[(8 * q + 2 * p) >> 5], s.x0);
             mask_shift_in(bits[(8 * q + 2 * p + 1) >> 5], s.x1);
         }
-#endif
     }
     __device__ __forceinline__ void stage_b(PairRegs& s) const {
         s.x0 = relu1<false>(s.x0);
         s.x1 = relu1<false>(s.x1);
-#ifndef H3_ABL_NOMAX3
         max3_acc(m, s.x0, s.x1);
-#endif
     }
     template <bool NOP>
     __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
@@ -228,19 +219,15 @@ struct ReluBiasSplitH {
         nb = *(const float2*)(bp + pair_off(qn, pn));                          // (past the last pair: the next block's first floats, unused)
         s.x0 = __builtin_fmaf(b.x, bs, acc_read(X[q >> 1][(q & 1) * 8 + 2 * p]));
         s.x1 = __builtin_fmaf(b.y, bs, acc_read(X[q >> 1][(q & 1) * 8 + 2 * p + 1]));
-#ifndef H3_ABL_NOMASK
         if (CAPTURE) {
             mask_shift_in(bits[(8 * q + 2 * p) >> 5], s.x0);
             mask_shift_in(bits[(8 * q + 2 * p + 1) >> 5], s.x1);
         }
-#endif
     }
     __device__ __forceinline__ void stage_b(PairRegs& s) const {
         s.x0 = relu1<false>(s.x0);
         s.x1 = relu1<false>(s.x1);
-#ifndef H3_ABL_NOMAX3
         max3_acc(m, s.x0, s.x1);
-#endif
     }
     template <bool NOP>
     __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
@@ -282,9 +269,7 @@ struct MaskedSplitH {
         s.x1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]));
     }
     __device__ __forceinline__ void stage_b(PairRegs& s) const {
-#ifndef H3_ABL_NOMAX3
         absmax3_acc(m, s.x0, s.x1);
-#endif
     }
     template <bool NOP>
     __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
@@ -346,11 +331,7 @@ struct BiasInitScaled {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 b = *(const f32x4*)(p + (t * 32 + 8 * q) * 4);
-#ifdef H3_DBG_NOBIASMUL
-            c[4 * q + 0] = b[0]; c[4 * q + 1] = b[1]; c[4 * q + 2] = b[2]; c[4 * q + 3] = b[3];
-#else
             c[4 * q + 0] = b[0] * s; c[4 * q + 1] = b[1] * s; c[4 * q + 2] = b[2] * s; c[4 * q + 3] = b[3] * s;
-#endif
         }
         return c;
     }
@@ -396,42 +377,21 @@ struct StagedRing {
     }
     // the two halves of issue_piece for callers that place them in different MFMA gaps (mma_run_h3_wide)
     __device__ __forceinline__ void store_piece(int q) {
-#if !defined(H3_ABL_NODMA) && !defined(H3_ABL_NOSTORE)
         *(f32x4*)(my_lds + (c_slot ^ 1u) * NEFES_SLAB_BYTES + q * 1024) = stage[q];
-#endif
     }
     __device__ __forceinline__ void fetch_piece(int q) {
-#if !defined(H3_ABL_NODMA) && !defined(H3_ABL_NOLOAD)
         load_piece(q);
-#endif
         if (q == NEFES_SLAB_PIECES - 1) g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
     }
     // piece q of the next slab: registers -> the idle slot; then request the same piece of the slab after it
     __device__ __forceinline__ void issue_piece(int q) {
-#ifdef H3_ABL_NODMA
-        return;
-#endif
-#ifndef H3_ABL_NOSTORE
-#if defined(H3_STORE_B64)      // experiment: two 8-byte stores instead of one 16-byte store
-        {
-            const uint32_t a_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(my_lds + (c_slot ^ 1u) * NEFES_SLAB_BYTES + q * 1024);
-            const float2 lo_ = {stage[q][0], stage[q][1]}, hi_ = {stage[q][2], stage[q][3]};
-            asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8" ::"v"(a_), "v"(lo_), "v"(hi_) : "memory");
-        }
-#else
         *(f32x4*)(my_lds + (c_slot ^ 1u) * NEFES_SLAB_BYTES + q * 1024) = stage[q];
-#endif
-#endif
-#ifndef H3_ABL_NOLOAD
         load_piece(q);
-#endif
         if (q == NEFES_SLAB_PIECES - 1) g_next = (g_next + 1 == n_slabs) ? 0 : g_next + 1;
     }
     __device__ __forceinline__ uint32_t acquire() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef H3_ABL_NOBARRIER
         __builtin_amdgcn_s_barrier();
-#endif
         c_slot ^= 1u;
         return c_slot * NEFES_SLAB_BYTES;
     }
@@ -467,20 +427,12 @@ struct StagedRing {
 // read of a tile follows the tile's last MFMA by a whole layer, a VALU write of a bias tile precedes its first MFMA by a unit;
 // operands returned by LDS reads are waited for by the compiler's own s_waitcnt (it tracks asm operands).
 __device__ __forceinline__ void mfma_h3_asm(f32x16& c, const f32x4& a, const u32x4& b) {
-#ifdef H3_BUILTIN_MFMA     // debugging: the compiler's MFMA (its own hazard padding, its own placement)
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(a), as_f16x8(b), c, 0, 0, 0);
-#else
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-#endif
 }
 // The same MFMA on a tile that lives in VGPRs: the backward's wide runs keep 16 tiles (source + destination set) in the 256 AGPRs
 // and the few extra output tiles of a run (the d embedding tiles riding on layer 5) in vector registers.
 __device__ __forceinline__ void mfma_h3_asm_v(f32x16& c, const f32x4& a, const u32x4& b) {
-#ifdef H3_BUILTIN_MFMA
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(a), as_f16x8(b), c, 0, 0, 0);
-#else
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-#endif
 }
 // First MFMA of a tile whose C operand is zero (the backward's transposed products): the inline constant 0 as srcC, the tile is an
 // output only -- no sixteen v_accvgpr_write per tile and layer to zero it (a third of a VALU instruction per MFMA in the backward).
@@ -492,14 +444,6 @@ __device__ __forceinline__ void mfma_h3_asm_v_c0(f32x16& c, const f32x4& a, cons
 }
 template <class T> struct h3_is_zero_init { static constexpr bool value = false; };
 template <> struct h3_is_zero_init<ZeroInit> { static constexpr bool value = true; };
-#ifdef H3_STAMP   // diagnostic build (tools/stamp_h3.sh): cycles inside the wide runs / inside ring acquires, per wave
-__device__ unsigned long long h3_stamp_run = 0, h3_stamp_acq = 0, h3_stamp_n = 0, h3_stamp_total = 0;
-static __device__ __forceinline__ unsigned long long h3_now() {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-}
-#endif
 // VT: tiles acc[0 .. VT) live in VGPRs ("+v" MFMAs), the rest in AGPRs.
 template <int NT, int KS16, int T0, bool FIRST = true, int VT = 0, class SrcFn, class InitFn, int NACC, class Ring>
 __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lane, const SrcFn& src, const InitFn& init,
@@ -507,10 +451,6 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
     static_assert(T0 + NT <= NACC, "accumulator array too small");
     static_assert(T0 + NT - 2 >= VT, "the run's last two tiles must be AGPR tiles (end-of-run wait states)");
     static_assert(NT >= 8 && NT % 2 == 0, "the gap schedule below pairs tiles: an even tile hosts a pair, the odd one a ring piece");
-#ifdef H3_STAMP
-    const unsigned long long stamp0 = h3_now();
-    unsigned long long stamp_acq = 0;
-#endif
     constexpr int UPS = (NEFES_SLAB_FRAGS / 4) / 2;       // units per slab
     constexpr int NU = KS16 * NT;
     constexpr int NSLAB = (NU + UPS - 1) / UPS;
@@ -529,14 +469,9 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
     // right behind the MFMA that writes the register -- inside that MFMA's 16 passes, where the read returns the old value (seen in
     // the disassembly of the backward; wrong gradients).  Nothing crosses this point, and the youngest result is 18 wait states old.
     __builtin_amdgcn_sched_barrier(0);
-#ifdef H3_DBG_BIGFENCE
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-#else
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1" ::: "memory");
-#endif
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    // H3_ABL_* macros: timing ablations only (tools/ablate_h3.sh, tools/stamp_h3.sh build side libraries with them; results are garbage)
     {
         PairRegs s0;
 #pragma unroll
@@ -550,15 +485,8 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
     // FIRST: the C operand of a tile's first MFMA (bias x 2^es, or zero) is written straight into the tile's own registers,
     // one unit ahead of its first use -- the output tiles are dead until then -- rather than into a 16-register staging tile
     constexpr bool C0 = FIRST && h3_is_zero_init<InitFn>::value
-#ifdef H3_BUILTIN_MFMA
-                        && false
-#endif
         ;                                                  // zero C operand: the first MFMA of every tile takes the constant
-#ifdef H3_ABL_NOBIAS
-    if (FIRST && !C0) acc[T0] = ZeroInit{}(0);
-#else
     if (FIRST && !C0) acc[T0] = init(0);
-#endif
     // A operands are requested TWO units (six MFMAs) ahead of their use; (h0,l0), (h1,l1) = this and the next unit's, the reads
     // in flight are the unit's after that.  ring.pf carries the first unit's hi group across segments.
     const char* p = ring_lane + ring.cur_off;
@@ -603,13 +531,9 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- gap 1 ----
-#ifndef H3_ABL_NOSPLIT
                 if (host) src.stage_a(ps[pp], q + 1, pp);
                 if (tail) src.template stage_c2<false>(Bn, pp, ps[pp]);
-#endif
-#ifndef H3_ABL_NOAREAD
                 if (!host && uu != acq_u) h2 = *(const f32x4*)(pn);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 // An asm's inputs are dead to the compiler once it has issued, but the MFMA is still reading them: without these
                 // empty uses the registers are handed to the gap's instructions and overwritten under the MFMA (seen in the
@@ -619,33 +543,23 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
                 else mfma_h3_asm(acc[T0 + t], h0, B.l);                                             // M2
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- gap 2 ----
-#ifndef H3_ABL_NOSPLIT
                 if (host) src.stage_b(ps[pp]);
-#endif
-#ifndef H3_ABL_NOAREAD
                 if (host && uu != acq_u) h2 = *(const f32x4*)(pn);
-#endif
                 if (!host) {
 #pragma unroll
                     for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
                         if (piece_unit(qq) == uu) ring.store_piece(qq);
                 }
-#ifdef H3_ABL_NOBIAS
-                if (FIRST && !C0 && q == 0 && t + 1 < NT) acc[T0 + t + 1] = ZeroInit{}(0);
-#else
                 if (FIRST && !C0 && q == 0 && t + 1 < NT) {
                     acc[T0 + t + 1] = init(t + 1);
                 }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("" ::"v"(B.l));
                 if (vt) mfma_h3_asm_v(acc[T0 + t], h0, B.h);
                 else mfma_h3_asm(acc[T0 + t], h0, B.h);                                             // M3
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- gap 3 ----
-#ifndef H3_ABL_NOSPLIT
                 if (host) src.stage_c1(Bn, pp, ps[pp]);
-#endif
                 if (!host) {
 #pragma unroll
                     for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
@@ -655,24 +569,12 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
 #pragma unroll
                     for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
                         if (piece_unit(qq) == uu && host) { ring.store_piece(qq); ring.fetch_piece(qq); }
-#ifdef H3_STAMP
-                    const unsigned long long ta = h3_now();
                     ring.cur_off = ring.acquire();
-                    stamp_acq += h3_now() - ta;
-#else
-                    ring.cur_off = ring.acquire();
-#endif
                     p = ring_lane + ring.cur_off - (size_t)nu * 2048;      // so that unit index uu + 2 >= nu addresses the new slab
                     pn = p + (2 * uu + 4) * 1024;
-#ifndef H3_ABL_NOAREAD
                     h2 = *(const f32x4*)(pn);
-#endif
                 }
-#ifndef H3_ABL_NOAREAD
                 l2 = *(const f32x4*)(pn + 1024);
-#else
-                h2 = HA(u + 1); l2 = LA(u + 1);
-#endif
                 if (uu + 1 == nu) p = ring_lane + ring.cur_off;            // plain addressing again from the new slab's unit 0
                 asm volatile("" ::"v"(h0), "v"(B.h));                      // M3's operands stay untouched through its gap
                 __builtin_amdgcn_sched_barrier(0);
@@ -680,7 +582,6 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
         }
     }
     ring.pf = HA(NU);
-#ifndef H3_BUILTIN_MFMA
     // The layer's functor reads the tiles with the vector ALU: 18 wait states between an MFMA and such a read of its result are the
     // program's to provide (the compiler pads them for its own MFMAs only).  Tying the two youngest tiles to the statement keeps their
     // reads behind it; the older tiles' last MFMAs are at least six MFMAs back.
@@ -690,14 +591,6 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
     asm volatile("s_nop 12\n\ts_nop 4"
                  : "+a"(acc[T0 + NT - 1]), "+a"(acc[T0 + NT - 2])
                  : "v"(HA(NU - 1)), "v"(BQ(KS16 - 1).h), "v"(BQ(KS16 - 1).l));
-#endif
-#ifdef H3_STAMP
-    if (threadIdx.x == 0) {      // wave 0 of every workgroup
-        atomicAdd(&h3_stamp_run, h3_now() - stamp0);
-        atomicAdd(&h3_stamp_acq, stamp_acq);
-        atomicAdd(&h3_stamp_n, (unsigned long long)(3 * NT * KS16));
-    }
-#endif
 }
 
 // Narrow segments (fewer than eight tiles: the half-width layers and the heads, a few per cent of the MFMAs): the operand of the
@@ -711,7 +604,6 @@ __device__ __forceinline__ void mma_run_h3_small(Ring& ring, const char* ring_la
     constexpr int NU = KS16 * NT;
     constexpr int NSLAB = (NU + UPS - 1) / UPS;
     Split2 B, Bn;
-    // H3_ABL_* macros: timing ablations only (tools/ablate_h3.sh builds side libraries with them; results are garbage)
     {
         PairRegs s0;
 #pragma unroll
@@ -726,11 +618,7 @@ __device__ __forceinline__ void mma_run_h3_small(Ring& ring, const char* ring_la
     // FIRST: the C operand of a tile's first MFMA (bias x 2^es, or zero) is written straight into the tile's own registers,
     // one unit ahead of its first use -- the output tiles are dead until then -- rather than into a 16-register staging tile
     // (a 16-register staging tile per run was what this kernel family could not afford before the source tiles stayed in AGPRs)
-#ifdef H3_ABL_NOBIAS
-    if (FIRST) acc[T0] = ZeroInit{}(0);
-#else
     if (FIRST) acc[T0] = init(0);
-#endif
     const char* p = ring_lane + ring.cur_off;
     f32x4 ah = ring.pf, al = *(const f32x4*)(p + 1024);
 #pragma unroll
@@ -745,11 +633,7 @@ __device__ __forceinline__ void mma_run_h3_small(Ring& ring, const char* ring_la
                 f32x4 nh;
                 const bool last = !(uu + 1 < nu);
                 if (!last) {
-#ifdef H3_ABL_NOAREAD
-                    nh = ah;
-#else
                     nh = *(const f32x4*)(p + (2 * uu + 2) * 1024);
-#endif
                 } else {
 #pragma unroll
                     for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
@@ -764,14 +648,8 @@ __device__ __forceinline__ void mma_run_h3_small(Ring& ring, const char* ring_la
                 const f16x8 Bh = as_f16x8(B.h), Bl = as_f16x8(B.l);
                 f32x16 c = acc[T0 + t];
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, c, 0, 0, 0);          // small terms first
-#ifndef H3_ABL_NOAREAD
                 al = *(const f32x4*)(p + (last ? 1 : 2 * uu + 3) * 1024);
-#endif
-#ifdef H3_ABL_NOBIAS
-                if (FIRST && q == 0 && t + 1 < NT) acc[T0 + t + 1] = ZeroInit{}(0);
-#else
                 if (FIRST && q == 0 && t + 1 < NT) acc[T0 + t + 1] = init(t + 1);
-#endif
                 if (uu + 1 < nu) {
 #pragma unroll
                     for (int qq = 0; qq < NEFES_SLAB_PIECES; ++qq)
@@ -789,13 +667,11 @@ __device__ __forceinline__ void mma_run_h3_small(Ring& ring, const char* ring_la
 #pragma unroll
                     for (int pp = 0; pp < 4; ++pp)
                         if (NT >= 4 ? (t == pp * STRIDE + STRIDE - 1) : (t == (pp * NT) / 4)) {
-#ifndef H3_ABL_NOSPLIT
                             PairRegs s1;
                             src.stage_a(s1, q + 1, pp);
                             src.stage_b(s1);
                             if (pp == 3) src.template stage_c<true>(Bn, pp, s1);
                             else src.template stage_c<false>(Bn, pp, s1);
-#endif
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {                     // interleave: one MFMA, then up to four VALU
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
