@@ -175,12 +175,15 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(int N, int Nc, in
 // and sample_pdf_merge_kernel (f64 sums are exact here, so their association does not matter): z_fine is bit-identical to the three
 // launches it replaces (tests/test_gpu_surface.py).
 // =====================================================================================================================
+// LDS floats per ray: cdf [Nc], bins [Nc], all [S], sorted [S], histogram [Nc + 4], the samples' counts [Ni] (16-byte aligned rows)
+__host__ __device__ inline int coarse_sample_lds_floats(int Nc, int Ni) { return (3 * Nc + 4 + 2 * (Nc + Ni) + Ni + 3) / 4 * 4; }
+
 template <int RW>
 __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const float* __restrict__ sigma, const float* __restrict__ z,
                                                             size_t z_stride, const float* __restrict__ u, int u_per_ray, float* z_fine,
                                                             float* z_samples, float* weights_out) {
     constexpr int LPR = Seg<RW>::LPR, RPW = Seg<RW>::RPW, Nc = 64 * RW, nb = Nc - 1, np_ = Nc - 2;
-    extern __shared__ float smem_cs[];
+    extern __shared__ __attribute__((aligned(16))) float smem_cs[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane / LPR, sl = lane - sub * LPR;
     const int S = Nc + Ni;
@@ -188,10 +191,18 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const
     const int ray_raw = (blockIdx.x * 4 + wv) * RPW + sub;
     const bool live = ray_raw < N;
     const int ray = live ? ray_raw : N - 1;                       // idle lanes shadow the last ray (loads in bounds, nothing stored)
-    float* cdf = smem_cs + (size_t)slot * (2 * Nc + 2 * S);
+    float* cdf = smem_cs + (size_t)slot * coarse_sample_lds_floats(Nc, Ni);
     float* bins = cdf + Nc;
     float* all = bins + Nc;
     float* sorted = all + S;
+    int* hist = (int*)(sorted + S);                               // [Nc + 4] (merge)
+    int* cnt_of = hist + Nc + 4;                                  // [Ni]: #{k : cdf_k <= u_i} of every sample, kept for the merge
+    // the shared u row, staged once per workgroup: the searches below read it in dependent chains (an L2 round trip each otherwise)
+    float* u_lds = smem_cs + (size_t)4 * RPW * coarse_sample_lds_floats(Nc, Ni);
+    if (!u_per_ray) {
+        for (int i = threadIdx.x; i < Ni; i += 256) u_lds[i] = u[i];
+        __syncthreads();
+    }
     const uint64_t seg_mask = LPR == 64 ? ~0ull : (((1ull << LPR) - 1ull) << (sub * LPR));
 
     // ---- compositing, variant D: weights w_k = alpha_k * prod_{j<k} (1 - alpha_j)  (composite.hip ray_forward4, sigma_only) ----
@@ -256,45 +267,129 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const
     bool okc = true;
     for (int k = sl; k + 1 < nb; k += LPR) okc = okc && (cdf[k] <= cdf[k + 1]);
     const bool cdf_sorted = (__ballot(!okc) & seg_mask) == 0ull;
-    for (int i0 = sl; i0 < Ni; i0 += 2 * LPR) {
-        const int ii[2] = {i0, i0 + LPR};
-        float uu[2];
-        int cnt[2];
+    // Test time: ONE ascending u row for every ray (linspace, :33).  A lane then owns PL CONSECUTIVE samples: a binary search for
+    // its first one and a forward walk for the rest (the counts are non-decreasing in u) -- ~6 + 4 + PL dependent LDS reads instead
+    // of 6 PL -- and its samples leave as whole 16-byte groups.  `cnt_of[]` keeps each sample's count for the merge below.
+    const int PL = (Ni + LPR - 1) / LPR;                          // samples per lane
+    bool u_asc = !u_per_ray && cdf_sorted;
+    if (u_asc) {
+        bool oku = true;
+        for (int i = sl; i + 1 < Ni; i += LPR) oku = oku && (u_lds[i] <= u_lds[i + 1]);
+        u_asc = (__ballot(!oku) & seg_mask) == 0ull;
+    }
+    auto sample_at = [&](int i, float uu, int cnt) {
+        const int below = cnt - 1 > 0 ? cnt - 1 : 0;               // :52-53
+        const int above = cnt < nb - 1 ? cnt : nb - 1;
+        const float c_lo = cdf[below], c_hi = cdf[above], b_lo = bins[below], b_hi = bins[above];
+        float denom = __fsub_rn(c_hi, c_lo);                       // :60-64
+        denom = denom < 1e-5f ? 1.f : denom;
+        const float t = __fdiv_rn(__fsub_rn(uu, c_lo), denom);
+        const float smp = __fadd_rn(b_lo, __fmul_rn(t, __fsub_rn(b_hi, b_lo)));
+        all[Nc + i] = smp;
+        cnt_of[i] = cnt;
+        return smp;
+    };
+    if (u_asc) {
+        // The search turned around: each lane takes its own four CDF entries (k = 4 sl ..) and finds j_k = #{i : u_i < cdf_k} -- for
+        // an evenly spaced u an arithmetic guess, corrected against the actual u values (a walk of zero or one step; any ascending u
+        // stays correct, only slower) -- and cnt_i = #{k : cdf_k <= u_i} = #{k : j_k <= i} is the prefix sum of the histogram of the
+        // j's.  No data-dependent search chains: four guesses, 4 + PL LDS atomics / reads and one scan per lane, the same for every
+        // lane, where a binary search per sample was 6 dependent LDS reads x PL.
+        int* H = (int*)sorted;                                     // [Ni + 1] counters (the row is free until the merge)
+        for (int i = sl; i < Ni + 1; i += LPR) H[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const float span = (float)(Ni - 1);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int i = ii[e] < Ni ? ii[e] : Ni - 1;
-            uu[e] = u_per_ray ? u[(size_t)ray * Ni + i] : u[i];
+        for (int k = 0; k < 4; ++k) {
+            const int kk = s0 + k;
+            if (kk >= nb) continue;
+            const float c = cdf[kk];
+            int j = (int)ceilf(c * span);
+            j = j < 0 ? 0 : (j > Ni ? Ni : j);
+            while (j < Ni && u_lds[j] < c) ++j;
+            while (j > 0 && !(u_lds[j - 1] < c)) --j;
+            atomicAdd(&H[j], 1);
         }
-        if (cdf_sorted && uu[0] == uu[0] && uu[1] == uu[1]) {
-            int lo0 = 0, hi0 = nb, lo1 = 0, hi1 = nb;
-            while (lo0 < hi0 || lo1 < hi1) {
-                const int m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
-                const float c0 = cdf[m0 < nb ? m0 : nb - 1], c1 = cdf[m1 < nb ? m1 : nb - 1];
-                if (lo0 < hi0) { if (c0 <= uu[0]) lo0 = m0 + 1; else hi0 = m0; }
-                if (lo1 < hi1) { if (c1 <= uu[1]) lo1 = m1 + 1; else hi1 = m1; }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const int i_lo = sl * PL, i_hi = (i_lo + PL) < Ni ? (i_lo + PL) : Ni;
+        int run = 0;
+        for (int i = i_lo; i < i_hi; ++i) run += H[i];
+        int incl = run;
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (sl >= o) incl += t;
+        }
+        int cnt = incl - run;
+        // four samples at a time: their counts, then all sixteen table reads, then the arithmetic, then the stores -- written out so
+        // that the LDS reads of a group are in flight together (a loop over single samples waits for every read in turn)
+        for (int i0 = i_lo; i0 < i_hi; i0 += 4) {
+            int cn[4], bl[4], ab[4];
+            float uu[4], c_lo[4], c_hi[4], b_lo[4], b_hi[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e < Ni ? i0 + e : Ni - 1;
+                cnt += i0 + e < i_hi ? H[i] : 0;
+                cn[e] = cnt;
+                uu[e] = u_lds[i];
             }
-            cnt[0] = lo0; cnt[1] = lo1;
-        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bl[e] = cn[e] - 1 > 0 ? cn[e] - 1 : 0;              // :52-53
+                ab[e] = cn[e] < nb - 1 ? cn[e] : nb - 1;
+                c_lo[e] = cdf[bl[e]]; c_hi[e] = cdf[ab[e]]; b_lo[e] = bins[bl[e]]; b_hi[e] = bins[ab[e]];
+            }
+            float smp[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float denom = __fsub_rn(c_hi[e], c_lo[e]);         // :60-64
+                denom = denom < 1e-5f ? 1.f : denom;
+                const float t = __fdiv_rn(__fsub_rn(uu[e], c_lo[e]), denom);
+                smp[e] = __fadd_rn(b_lo[e], __fmul_rn(t, __fsub_rn(b_hi[e], b_lo[e])));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i0 + e < i_hi) {
+                    all[Nc + i0 + e] = smp[e];
+                    cnt_of[i0 + e] = cn[e];
+                    if (z_samples && live) z_samples[(size_t)ray * Ni + i0 + e] = smp[e];
+                }
+        }
+    } else {
+        for (int i0 = sl; i0 < Ni; i0 += 2 * LPR) {               // two samples per lane and pass, searched side by side
+            const int ii[2] = {i0, i0 + LPR};
+            float uu[2];
+            int cnt[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                cnt[e] = 0;
-                if (cdf_sorted && uu[e] == uu[e]) cnt[e] = count_less_equal(cdf, nb, uu[e]);
-                else for (int k = 0; k < nb; ++k) cnt[e] += (cdf[k] <= uu[e]) ? 1 : 0;
+                const int i = ii[e] < Ni ? ii[e] : Ni - 1;
+                uu[e] = u_per_ray ? u[(size_t)ray * Ni + i] : u[i];
             }
-        }
+            if (cdf_sorted && uu[0] == uu[0] && uu[1] == uu[1]) {
+                int lo0 = 0, hi0 = nb, lo1 = 0, hi1 = nb;
+                while (lo0 < hi0 || lo1 < hi1) {
+                    const int m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+                    const float c0 = cdf[m0 < nb ? m0 : nb - 1], c1 = cdf[m1 < nb ? m1 : nb - 1];
+                    if (lo0 < hi0) { if (c0 <= uu[0]) lo0 = m0 + 1; else hi0 = m0; }
+                    if (lo1 < hi1) { if (c1 <= uu[1]) lo1 = m1 + 1; else hi1 = m1; }
+                }
+                cnt[0] = lo0; cnt[1] = lo1;
+            } else {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if (ii[e] >= Ni) continue;
-            const int i = ii[e];
-            const int below = cnt[e] - 1 > 0 ? cnt[e] - 1 : 0;
-            const int above = cnt[e] < nb - 1 ? cnt[e] : nb - 1;
-            const float c_lo = cdf[below], c_hi = cdf[above], b_lo = bins[below], b_hi = bins[above];
-            float denom = __fsub_rn(c_hi, c_lo);
-            denom = denom < 1e-5f ? 1.f : denom;
-            const float t = __fdiv_rn(__fsub_rn(uu[e], c_lo), denom);
-            const float smp = __fadd_rn(b_lo, __fmul_rn(t, __fsub_rn(b_hi, b_lo)));
-            all[Nc + i] = smp;
-            if (z_samples && live) z_samples[(size_t)ray * Ni + i] = smp;
+                for (int e = 0; e < 2; ++e) {
+                    cnt[e] = 0;
+                    if (cdf_sorted && uu[e] == uu[e]) cnt[e] = count_less_equal(cdf, nb, uu[e]);
+                    else for (int k = 0; k < nb; ++k) cnt[e] += (cdf[k] <= uu[e]) ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (ii[e] >= Ni) continue;
+                const float smp = sample_at(ii[e], uu[e], cnt[e]);
+                if (z_samples && live) z_samples[(size_t)ray * Ni + ii[e]] = smp;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -305,33 +400,86 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const
     for (int k = sl; k + 1 < Nc; k += LPR) oka = oka && (all[k] <= all[k + 1]);
     for (int k = sl; k + 1 < Ni; k += LPR) oka = oka && (all[Nc + k] <= all[Nc + k + 1]);
     const bool ordered = (__ballot(!oka) & seg_mask) == 0ull;
-    for (int i = sl; i < S; i += LPR) {
-        const float v = all[i];
-        int rank = 0;
-        if (ordered) {
-            rank = i < Nc ? i + count_less(all + Nc, Ni, v) : (i - Nc) + count_less_equal(all, Nc, v);
-        } else {
+    if (ordered) {
+        // Both halves ascending.  A sample's rank is its index + c = #{coarse <= sample}; the sample was interpolated between the
+        // midpoints around coarse depth `c`, so a walk of a step or two from the previous sample's c finds it (instead of a 6-step
+        // binary search per element).  A coarse depth's rank is its index + #{samples < z_k} = #{samples : c <= k} (z ascending):
+        // a histogram of the c's (LDS atomics) and its prefix sum over the ray's lanes.
+        for (int k = sl; k < Nc + 4; k += LPR) hist[k] = 0;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const int i_lo = sl * PL, i_hi = (i_lo + PL) < Ni ? (i_lo + PL) : Ni;
+        for (int i0 = i_lo; i0 < i_hi; i0 += 4) {                  // groups of four, reads first (as above)
+            float v[4], z_at[4];
+            int c[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e < Ni ? i0 + e : Ni - 1;
+                v[e] = all[Nc + i];
+                // the sample was interpolated between bins[below] >= z[below] and bins[above] <= z[below + 2]: c is below + 1 or + 2
+                c[e] = cnt_of[i] > 1 ? cnt_of[i] : 1;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z_at[e] = all[c[e] < Nc ? c[e] : Nc - 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (c[e] < Nc && z_at[e] <= v[e]) {
+                    ++c[e];
+                    while (c[e] < Nc && all[c[e]] <= v[e]) ++c[e];     // (not taken for a sample between its two midpoints)
+                }
+                while (c[e] > 0 && !(all[c[e] - 1] <= v[e])) --c[e];   // (one read: confirms the lower side)
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i0 + e < i_hi) {
+                    sorted[i0 + e + c[e]] = v[e];
+                    atomicAdd(&hist[c[e]], 1);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        int h4[4], run = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { run += hist[s0 + k]; h4[k] = run; }
+        int incl = run;                                            // inclusive scan of the lanes' totals over the ray
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (sl >= o) incl += t;
+        }
+        const int base = incl - run;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sorted[s0 + k + base + h4[k]] = zz[k];
+    } else {
+        for (int i = sl; i < S; i += LPR) {
+            const float v = all[i];
             const bool v_nan = v != v;
+            int rank = 0;
             for (int k = 0; k < S; ++k) {
                 const float o = all[k];
                 const bool o_nan = o != o;
                 const bool before = v_nan ? (!o_nan || k < i) : (!o_nan && (o < v || (o == v && k < i)));
                 rank += before ? 1 : 0;
             }
+            sorted[rank] = v;
         }
-        sorted[rank] = v;
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    if (live)
-        for (int i = sl; i < S; i += LPR) z_fine[(size_t)ray * S + i] = sorted[i];
+    if (live) {
+        if ((S & 3) == 0) {                                        // whole 16-byte groups: 16 LPR bytes of a ray's row per instruction
+            for (int i = 4 * sl; i < S; i += 4 * LPR) *(float4*)(z_fine + (size_t)ray * S + i) = *(const float4*)(sorted + i);
+        } else {
+            for (int i = sl; i < S; i += LPR) z_fine[(size_t)ray * S + i] = sorted[i];
+        }
+    }
 }
 
 template <int RW>
 static int launch_coarse_sample(int N, int Ni, const float* sigma, const float* z, size_t z_stride, const float* u, int u_per_ray,
                                 float* z_fine, float* z_samples, float* weights_out, hipStream_t st) {
     constexpr int RPW = Seg<RW>::RPW, Nc = 64 * RW;
-    const size_t lds = (size_t)4 * RPW * (2 * Nc + 2 * (Nc + Ni)) * sizeof(float);
+    const size_t lds = ((size_t)4 * RPW * coarse_sample_lds_floats(Nc, Ni) + (size_t)(Ni + 3) / 4 * 4) * sizeof(float);
     auto k = coarse_sample_kernel<RW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -195,7 +195,8 @@ def test_mode2_iterations_match_reference_along_its_trajectory(golden, k):
     assert worst_abs < 1e-3 and worst_l < 1e-3, (worst_abs, worst_g, worst_l)
 
 
-STAGES = ["default", "field_fp32_mfma", "torch_convs", "separate_upsample_and_loss", "torch_glue", "svd_on_host", "svd_float64"]
+STAGES = ["default", "field_fp32_mfma", "torch_convs", "separate_upsample_and_loss", "torch_glue", "svd_on_host", "svd_float64", "torch_upsample_and_loss",
+          "torch_upsample_and_loss_float64", "fusion_net_float64", "render_maps_to_float64_tail"]
 
 
 @pytest.mark.parametrize("variant", STAGES)
@@ -228,8 +229,36 @@ def test_loop_gradient_error_by_stage(golden, variant, monkeypatch):
             u, _, v = torch.svd(m)
             return torch.cat([(u @ v.transpose(-2, -1)).to(pose.device, pose.dtype), pose[..., :3, 3:]], -1)
         monkeypatch.setattr(NRF, "svd_reg", svd_reg_alt)
+    if variant.startswith("torch_upsample_and_loss"):
+        # bicubic up-sampling, crop and cosine loss through torch's own operators on the device (fp32, or float64 in between)
+        import nefes_amd.refine as NRF
+        f64 = variant.endswith("float64")
+        monkeypatch.setattr(ops, "bicubic_upsample", lambda x, size, crop=0: torch.nn.functional.interpolate(
+            x.double() if f64 else x, size=size, mode="bicubic"))
+        if f64:
+            monkeypatch.setattr(NRF, "feature_loss", lambda a, b, per_pixel=False: (
+                1 - torch.nn.functional.cosine_similarity(a.reshape(a.shape[0], -1), b.double().reshape(b.shape[0], -1), dim=1).mean()).float())
     apr = TinyAPR(g["m2_weight"][k], g["m2_bias"][k])
     coarse, fine = nets(g)
+    if variant in ("fusion_net_float64", "render_maps_to_float64_tail"):
+        # FusionNet (four convolutions + train-mode BatchNorm) evaluated in float64 by torch on the device; the second variant also
+        # runs the colour transform, up-sampling, crop and loss in float64: everything behind the rendered maps
+        import copy
+        import nefes_amd.refine as NRF
+        fnet = coarse.fusion_net
+        net64 = copy.deepcopy(fnet.net).double()
+        relu_tap = []
+        for j in (1, 3, 5):
+            net64[j].register_forward_hook(lambda m, a, out: relu_tap.append(out.detach()))
+
+        def forward_prepared64(x, per_image_norm=False):
+            return net64(x.double()).float() if variant == "fusion_net_float64" else net64(x.double())
+        monkeypatch.setattr(fnet, "forward_prepared", forward_prepared64)
+        monkeypatch.setattr(type(fnet), "_use_hip", lambda self, x: False)
+        if variant == "render_maps_to_float64_tail":
+            monkeypatch.setattr(ops, "bicubic_upsample", lambda x, size, crop=0: torch.nn.functional.interpolate(x.double(), size=size, mode="bicubic"))
+            monkeypatch.setattr(NRF, "feature_loss", lambda a, b, per_pixel=False: (
+                1 - torch.nn.functional.cosine_similarity(a.reshape(a.shape[0], -1), b.double().reshape(b.shape[0], -1), dim=1).mean()).float())
     args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True, encode_hist=True)
     kw = dict(network_query_fn=None, perturb=0., N_importance=int(g["Ni"]), N_samples=int(g["Nc"]), network_fn=coarse,
               network_fine=fine, use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=True, args=args, ndc=False, lindisp=False)
@@ -237,7 +266,8 @@ def test_loop_gradient_error_by_stage(golden, variant, monkeypatch):
     H, W, focal = g["hwf"].tolist()
     ref = PoseRefiner(kw, args, (H, W, focal), float(g["near"]), float(g["far"]), tinyscale=int(g["tinyscale"]), lr_r=float(g["lr"][0]),
                       lr_t=float(g["lr"][1]), world_setup=world, graph=False, device=DEV, pose_model=apr, svd_reg=True,
-                      learning_rate=float(g["m2_lr"]), fused_glue=(variant != "torch_glue"))
+                      learning_rate=float(g["m2_lr"]), fused_glue=variant not in ("torch_glue", "torch_upsample_and_loss", "torch_upsample_and_loss_float64", "fusion_net_float64",
+                                                 "render_maps_to_float64_tail"))
     photo, tgt = photo_of(g), target_full(g)
     ref.refine_apr(photo, tgt, T(g["hist"]), iters=0, verification=False)
     Wn, bn = g["m2_w_traj"][k, i - 1], g["m2_b_traj"][k, i - 1]
@@ -254,7 +284,7 @@ def test_loop_gradient_error_by_stage(golden, variant, monkeypatch):
     for h in hooks:
         h.remove()
     grad = ref.apr.raw.grad[0].cpu().numpy()
-    conv_src = relu_out if variant == "torch_convs" else tap["conv_relu"]
+    conv_src = relu_out if variant == "torch_convs" else (relu_tap if variant in ("fusion_net_float64", "render_maps_to_float64_tail") else tap["conv_relu"])
     conv_pos, aud = [(y > 0).cpu() for y in conv_src[-3:]], {}
     probs = {dt: problem(g, dt, k, 2) for dt in (torch.float64, torch.float32)}
     desc = RC.image_descriptor(photo.double())

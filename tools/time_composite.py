@@ -49,7 +49,14 @@ for name, N, S, C, Nc in (("G-metric 640x480, 64+128, C=16", 307200, 192, 16, 64
     w = torch.rand(N, Nc, device=dev)
     t_s = timed(lambda: ops.sample_pdf_merge(zc, w, S - Nc))
     b_s = N * (Nc * 8 + S * 4)
+    # the coarse pass behind its field kernel as one launch (csrc/sample_pdf.hip coarse_sample_kernel): sigma in, merged depths out,
+    # on a depth row shared by every ray (what render() does at test time) -- realistic weights: a density bump along each ray
+    sig = (4.0 * torch.exp(-0.5 * ((torch.arange(Nc, device=dev)[None] - torch.rand(N, 1, device=dev, generator=g) * Nc) / 3.0) ** 2)).contiguous()
+    z_row = ops.coarse_depth_row(Nc, 0., 4., False, dev)
+    t_c = timed(lambda: ops.coarse_sample(sig, z_row, S - Nc, want_samples=False))
+    b_c = N * (Nc * 4 + S * 4)
     chk = [float(t.double().abs().sum()) for t in (outs[0], outs[1], outs[5], g_raw)]
     print("   checksums (|rgb|, |feat|, |weights|, |d raw|):", " ".join(f"{c:.9e}" for c in chk))
     print(f"{name}: composite_fwd {t_f:.3f} ms = {b_f / t_f / 1e9:.2f} TB/s | composite_bwd {t_b:.3f} ms = {b_b / t_b / 1e9:.2f} TB/s | "
-          f"composite_fwd[D] {t_d:.3f} ms = {b_d / t_d / 1e9:.2f} TB/s | sample_pdf_merge {t_s:.3f} ms = {b_s / t_s / 1e9:.2f} TB/s")
+          f"composite_fwd[D] {t_d:.3f} ms = {b_d / t_d / 1e9:.2f} TB/s | sample_pdf_merge {t_s:.3f} ms = {b_s / t_s / 1e9:.2f} TB/s | "
+          f"coarse_sample (D + sample_pdf + merge, one launch) {t_c:.3f} ms = {b_c / t_c / 1e9:.2f} TB/s")
