@@ -132,39 +132,112 @@ def committed_traffic(backward, h3, x6):
         return None, f"{rel}: {ex}"
 
 
-def refinement_loop(dev, iters=50, graph=True, images=1):
-    """BASELINE configs[4] without the DFNet CNN (out of scope): per query image `iters` iterations of
-    LearnPose -> render(80x60) -> affine colour transform -> FusionNet -> bicubic upsample + crop -> cosine feature loss
-    against a fixed target -> backward -> Adam  (script/dm/DFM_APR_refine.py:84-156, DFM_pose_refine.py:290-348),
-    driven by nefes_amd.refine.PoseRefiner (one captured HIP graph per iteration when graph=True).
-    Returns (seconds per image, rays rendered per image)."""
+def _structure_scene(named, gain, decay, sigma_gain):
+    """The synthetic scene of tests/golden/refine50*.npz (tools/make_golden_refine50.py applies the same deterministic edit to the
+    reference's seed-0 modules): hidden weights x gain, the positional columns of frequency band k of the two layers that read the
+    xyz embedding x 2^(-decay k), density head x sigma_gain -- a field with spatial structure instead of a nearly constant one."""
+    with torch.no_grad():
+        for name, p in named.items():
+            if name.startswith(("xyz_encoding_", "dir_encoding", "transient_encoding")) and name.endswith("weight"):
+                p.mul_(gain)
+        for lname in ("xyz_encoding_1.0.weight", "xyz_encoding_5.0.weight"):
+            w = named[lname]
+            for k in range(10):
+                w[:, 3 + 6 * k: 9 + 6 * k] *= float(2.0 ** (-decay * k))
+        named["static_sigma.0.weight"].mul_(sigma_gain)
+
+
+def _pose_error(gt, pred):
+    """(|t - t'| in metres, rotation angle of R' R^T in degrees): the reference's metric (dm/pose_model.py:75-92 == eval.py:34-51)."""
+    import numpy as np
+    a, b = np.asarray(gt, dtype=np.float64), np.asarray(pred, dtype=np.float64)
+    R = b[:3, :3] @ a[:3, :3].T
+    s_ = 0.5 * np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return [float(np.linalg.norm(a[:3, 3] - b[:3, 3])), float(np.degrees(np.arctan2(s_, 0.5 * (np.trace(R) - 1.0))))]
+
+
+class _TinyAPR(torch.nn.Module):
+    """The fixture's stand-in for the absolute-pose-regression CNN (out of scope): Linear(12, 12) on the 2x2 average-pooled image."""
+
+    def __init__(self, weight, bias):
+        super().__init__()
+        self.fc = torch.nn.Linear(12, 12)
+        with torch.no_grad():
+            self.fc.weight.copy_(torch.from_numpy(weight))
+            self.fc.bias.copy_(torch.from_numpy(bias))
+
+    def forward(self, x):
+        return self.fc(torch.nn.functional.adaptive_avg_pool2d(x, 2).reshape(x.shape[0], -1))
+
+
+def refinement_loop(dev, iters=50, graph=True, images=1, mode="upsampled"):
+    """BASELINE configs[4] without the DFNet CNN (out of scope) on the scene of tests/golden/refine50_60x80.npz --
+    the 60 x 80 rays the reference's own loop renders (DFM_APR_refine.py:107), one perturbed start, the reference's 50-iteration
+    results beside it.  Per query image `iters` iterations of pose -> render(80x60) -> affine colour transform -> FusionNet ->
+    feature loss -> backward -> Adam, driven by nefes_amd.refine.PoseRefiner:
+      mode "3"          DFM_optimization_NFF (DFM_pose_refine.py:290-348): LearnPose, loss at 1/4 resolution -- the fixture's mode 3
+      mode "2"          train_on_batch (DFM_APR_refine.py:84-156, the shipped default): the pose is a small regression network's output,
+                        loss on the bicubically up-sampled, cropped features -- the fixture's mode 2
+      mode "upsampled"  LearnPose with mode 2's up-sampled loss: the timing line of rounds 1-3 (one captured HIP graph per iteration)
+    Returns (seconds per image, rays rendered per image, pose errors or None)."""
+    import numpy as np
     from nefes_amd.field import NeRFH_NFF
     from nefes_amd.refine import PoseRefiner
-    wl = WORKLOADS["ref"]
-    H, W, focal, Wd, C = wl["H"], wl["W"], wl["focal"], wl["Wd"], wl["C"]
-    coarse = NeRFH_NFF('coarse', W=Wd, f_dim=C).requires_grad_(False).to(dev)
-    fine = NeRFH_NFF('fine', W=Wd, f_dim=C, encode_appearance=True, encode_transient=True).requires_grad_(False).to(dev)
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "refine50_60x80.npz")))
+    T = lambda a_: torch.from_numpy(np.asarray(a_))
+    Wd, C = int(g["Wd"]), int(g["C"])
+    H, W, focal = (float(v) for v in g["hwf"])
+    H, W, ts = int(H), int(W), int(g["tinyscale"])
+    coarse = NeRFH_NFF('coarse', W=Wd, f_dim=C)
+    fine = NeRFH_NFF('fine', W=Wd, f_dim=C, encode_appearance=True, encode_transient=True)
+    gain, decay, sg = (float(v) for v in g["scene"])
+    with torch.no_grad():
+        coarse.exposure_embedding.params.copy_(T(g["exposure_params"]))
+    for n_ in (coarse, fine):
+        _structure_scene(dict(n_.named_parameters()), gain, decay, sg)
+    coarse, fine = coarse.requires_grad_(False).to(dev), fine.requires_grad_(False).to(dev)
     args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True, netchunk=1 << 21,
                                  encode_hist=True)
-    kw = dict(network_query_fn=None, perturb=False, N_importance=wl["Ni"], N_samples=wl["Nc"], network_fn=coarse,
+    kw = dict(network_query_fn=None, perturb=False, N_importance=int(g["Ni"]), N_samples=int(g["Nc"]), network_fn=coarse,
               network_fine=fine, use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=True, args=args, ndc=False,
               lindisp=False)
-    init = torch.eye(4, device=dev)
-    init[:3, :4] = bench_pose().to(dev)
-    hist = torch.full((1, 10), 10., device=dev)
-    target = torch.nn.functional.normalize(torch.randn(C, 4 * H - 20, 4 * W - 20, device=dev), dim=0)
-    if images > 1:        # `images` query images refined side by side (PoseRefiner(images=B)); time is reported per image
-        init, hist, target = init[None].repeat(images, 1, 1), hist.repeat(images, 1), target[None].repeat(images, 1, 1, 1)
-    ref = PoseRefiner(kw, args, (4 * H, 4 * W, 4 * focal), 0., 4., tinyscale=4, upsample=True, graph=graph, device=dev,
-                      images=images)
-    ref.refine(init, target, hist, iters)                      # packs weights, warms MIOpen, captures the graph
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    world = dict(pose_scale=float(g["pose_scale"]), pose_scale2=float(g["pose_scale2"]), move_all_cam_vec=g["move_all_cam_vec"].tolist())
+    init, hist = T(g["init_c2w"][0]).to(dev), T(g["hist"]).to(dev)
+    low = T(g["target_low"])
+    full = torch.nn.functional.interpolate(low[None], size=(H, W), mode="bicubic")[0]            # what mode 2 matches against
+    common = dict(tinyscale=ts, lr_r=float(g["lr"][0]), lr_t=float(g["lr"][1]), world_setup=world, device=dev)
     n_img = 3
-    for _ in range(n_img):
-        ref.refine(init, target, hist, iters)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n_img / images, iters * H * W
+    if mode == "2":
+        photo = T(g["photo_u8"]).float()[None] / 255.
+        ref = PoseRefiner(kw, args, (H, W, focal), float(g["near"]), float(g["far"]), graph=False, pose_model=_TinyAPR(g["m2_weight"][0], g["m2_bias"][0]),
+                          svd_reg=True, learning_rate=float(g["m2_lr"]), **common)
+        pose, _, _ = ref.refine_apr(photo, full, hist, iters)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_img):
+            pose, _, _ = ref.refine_apr(photo, full, hist, iters)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / n_img
+        err = {"hip": _pose_error(g["true_c2w"], pose.cpu().numpy()), "reference": [float(v) for v in g["m2_err"][0]]}
+    else:
+        up = mode == "upsampled"
+        target = (full[:, 10:-10, 10:-10] if up else low).to(dev)
+        if images > 1:    # `images` query images refined side by side (PoseRefiner(images=B)); time is reported per image
+            init, hist, target = init[None].repeat(images, 1, 1), hist.repeat(images, 1), target[None].repeat(images, 1, 1, 1)
+        ref = PoseRefiner(kw, args, (H, W, focal), float(g["near"]), float(g["far"]), upsample=up, graph=graph, images=images, **common)
+        pose, _ = ref.refine(init, target, hist, iters)               # packs weights, warms MIOpen, captures the graph
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_img):
+            pose, _ = ref.refine(init, target, hist, iters)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / n_img / images
+        p0 = (pose if images == 1 else pose[0])[:3, :4].cpu().numpy()
+        err = {"hip": _pose_error(g["true_c2w"], p0)}
+        if mode == "3":
+            err["reference"] = [float(v) for v in g["m3_err"][0]]
+    err["initial"] = [float(v) for v in g["init_err"][0]]
+    return sec, iters * (H // ts) * (W // ts), err
 
 
 def train_steps(dev, steps=10, warmup=2):
@@ -303,17 +376,23 @@ def main():
                                                  "perturb=1, img2mse, backward to weights, Adam"}}), flush=True)
         return
     if a.workload == "loop50":
-        sec_e, rays = refinement_loop(dev, graph=False)
-        sec, rays = refinement_loop(dev, graph=True)
-        sec_b, _ = refinement_loop(dev, graph=True, images=8)
+        sec_e, rays, _ = refinement_loop(dev, graph=False)
+        sec, rays, err_up = refinement_loop(dev, graph=True)
+        sec_b, _, _ = refinement_loop(dev, graph=True, images=8)
+        sec3, _, err3 = refinement_loop(dev, graph=True, mode="3")
+        sec2, _, err2 = refinement_loop(dev, mode="2")
         print(json.dumps({"metric": "rays/s (fwd+bwd), secondary workload 'loop50'", "value": rays / sec, "unit": "rays/s",
                           "n_gpus": 1, "higher_is_better": True,
                           "dtype": "f32",
                           "data": "synthetic", "vs_baseline": None,
                           "ms_per_image_50_iterations": sec * 1e3, "ms_per_image_50_iterations_eager": sec_e * 1e3,
                           "ms_per_image_50_iterations_8_images_side_by_side": sec_b * 1e3,
-                          "config": {"workload": "BASELINE configs[4] minus the DFNet CNN: 50 x [LearnPose -> render 80x60 "
-                                                 "(64+64, 8x128, C=128) -> affine colour -> FusionNet -> bicubic x4 -> cosine "
+                          "ms_per_image_50_iterations_mode3": sec3 * 1e3, "ms_per_image_50_iterations_mode2_eager": sec2 * 1e3,
+                          "pose_error_m_deg_after_50_iterations": {"mode3": err3, "mode2": err2, "upsampled_loss_learnpose": err_up,
+                                                                   "reference_from": "tests/golden/refine50_60x80.npz: the reference's own DFM_optimization_NFF / "
+                                                                                     "train_on_batch on the CPU from the same start"},
+                          "config": {"workload": "BASELINE configs[4] minus the DFNet CNN, on the scene of tests/golden/refine50_60x80.npz: 50 x "
+                                                 "[pose -> render 80x60 (64+64, 8x128, C=128) -> affine colour -> FusionNet -> bicubic x4 -> cosine "
                                                  "feature loss -> backward -> Adam]"}}), flush=True)
         return
     wl = WORKLOADS[a.workload]

@@ -175,8 +175,11 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(int N, int Nc, in
 // and sample_pdf_merge_kernel (f64 sums are exact here, so their association does not matter): z_fine is bit-identical to the three
 // launches it replaces (tests/test_gpu_surface.py).
 // =====================================================================================================================
-// LDS floats per ray: cdf [Nc], bins [Nc], all [S], sorted [S], histogram [Nc + 4], the samples' counts [Ni] (16-byte aligned rows)
-__host__ __device__ inline int coarse_sample_lds_floats(int Nc, int Ni) { return (3 * Nc + 4 + 2 * (Nc + Ni) + Ni + 3) / 4 * 4; }
+// LDS floats per ray (16-byte aligned rows): cb [2 Nc] = {cdf_k, bins_k} pairs; zp [Nc + 8] = the coarse depths behind four -inf and
+// in front of +inf sentinels; s2 [2 Ni] = {sample_i, count_i} pairs; sorted [S] (the counters of the inverse-CDF histogram live
+// here until the merge); hist [Nc + 4].  Per workgroup: up [Ni + 8] = the shared u row, padded the same way.
+__host__ __device__ inline int coarse_sample_lds_floats(int Nc, int Ni) { return 2 * Nc + (Nc + 8) + (2 * Ni + 3) / 4 * 4 + (Nc + Ni + 3) / 4 * 4 + (Nc + 4); }
+__host__ __device__ inline int coarse_sample_u_floats(int Ni) { return (Ni + 8 + 3) / 4 * 4; }
 
 template <int RW>
 __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const float* __restrict__ sigma, const float* __restrict__ z,
@@ -186,21 +189,26 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const
     extern __shared__ __attribute__((aligned(16))) float smem_cs[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane / LPR, sl = lane - sub * LPR;
-    const int S = Nc + Ni;
+    const int S = Nc + Ni, S4 = (S + 3) / 4 * 4;
     const int slot = wv * RPW + sub;                              // ray slot inside the workgroup
     const int ray_raw = (blockIdx.x * 4 + wv) * RPW + sub;
     const bool live = ray_raw < N;
     const int ray = live ? ray_raw : N - 1;                       // idle lanes shadow the last ray (loads in bounds, nothing stored)
-    float* cdf = smem_cs + (size_t)slot * coarse_sample_lds_floats(Nc, Ni);
-    float* bins = cdf + Nc;
-    float* all = bins + Nc;
-    float* sorted = all + S;
-    int* hist = (int*)(sorted + S);                               // [Nc + 4] (merge)
-    int* cnt_of = hist + Nc + 4;                                  // [Ni]: #{k : cdf_k <= u_i} of every sample, kept for the merge
-    // the shared u row, staged once per workgroup: the searches below read it in dependent chains (an L2 round trip each otherwise)
-    float* u_lds = smem_cs + (size_t)4 * RPW * coarse_sample_lds_floats(Nc, Ni);
-    if (!u_per_ray) {
-        for (int i = threadIdx.x; i < Ni; i += 256) u_lds[i] = u[i];
+    float* cb = smem_cs + (size_t)slot * coarse_sample_lds_floats(Nc, Ni);
+    float* zp = cb + 2 * Nc;                                      // z_k at zp[4 + k]
+    float* s2 = zp + Nc + 8;
+    float* sorted = s2 + (2 * Ni + 3) / 4 * 4;
+    int* hist = (int*)(sorted + S4);
+    int* H = (int*)sorted;                                        // [Ni + 1] counters of the inverse-CDF histogram (free until the merge)
+    float* up = smem_cs + (size_t)4 * RPW * coarse_sample_lds_floats(Nc, Ni);      // u_i at up[4 + i]
+    auto cdfv = [&](int k) -> float { return cb[2 * k]; };
+    auto binv = [&](int k) -> float { return cb[2 * k + 1]; };
+    auto zv = [&](int k) -> float { return zp[4 + k]; };
+    auto allv = [&](int i) -> float { return i < Nc ? zp[4 + i] : s2[2 * (i - Nc)]; };      // cat[z_vals, z_samples]
+    const float inf = __builtin_huge_valf();
+    if (!u_per_ray) {     // the shared u row, staged once per workgroup: the searches read it in dependent chains (an L2 round trip each otherwise)
+        for (int i = threadIdx.x; i < Ni; i += 256) up[4 + i] = u[i];
+        if (threadIdx.x < 4) { up[threadIdx.x] = -inf; up[4 + Ni + threadIdx.x] = inf; }
         __syncthreads();
     }
     const uint64_t seg_mask = LPR == 64 ? ~0ull : (((1ull << LPR) - 1ull) << (sub * LPR));
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const
     const int s0 = 4 * sl;
     const float4 z4 = ld4(z + (size_t)ray * z_stride + s0);
     const float4 ss4 = ld4(sigma + (size_t)ray * Nc + s0);
-    const float z_next = __shfl_down(z4.x, 1);
+    const float z_next = RW == 1 ? row_next(z4.x) : __shfl_down(z4.x, 1);     // (unused by a ray's last lane)
     float a_c[4], w[4], zz[4];
     double om[4];
 #pragma unroll
@@ -224,8 +232,8 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const
     }
     {
         const double p0 = om[0], p1 = p0 * om[1], p2 = p1 * om[2], p3 = p2 * om[3];
-        const double inc = seg_incl_prod<RW>(p3, sl);
-        const double prev = __shfl_up(inc, 1);
+        const double inc = RW == 1 ? row_incl_prod(p3) : seg_incl_prod<RW>(p3, sl);
+        const double prev = RW == 1 ? row_prev(inc, 1.0) : __shfl_up(inc, 1);
         const double E = sl == 0 ? 1.0 : prev;
         w[0] = a_c[0] * (float)E; w[1] = a_c[1] * (float)(E * p0); w[2] = a_c[2] * (float)(E * p1); w[3] = a_c[3] * (float)(E * p2);
     }
@@ -233,12 +241,11 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const
 
     // ---- bins = z_mid, cdf = [0, cumsum((w[1:-1] + 1e-5) / sum)]  (rendering.py:26-29,132-134; sample_pdf_merge_kernel) ----
     double part = 0.0;
-    float pw[4];                                                  // w + 1e-5 of this lane's samples that are pdf entries (k in 1 .. Nc-2)
+    float pw[4], cd[4], bn[4];                                    // this lane's four (cdf_k, bins_k): kept in registers too
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int kk = s0 + k;
-        all[kk] = zz[k];
-        if (kk < nb) bins[kk] = __fmul_rn(.5f, __fadd_rn(k < 3 ? zz[k + 1] : z_next, zz[k]));
+        bn[k] = __fmul_rn(.5f, __fadd_rn(k < 3 ? zz[k + 1] : z_next, zz[k]));
         pw[k] = __fadd_rn(w[k], 1e-5f);
         if (kk >= 1 && kk <= np_) part += (double)pw[k];
     }
@@ -251,109 +258,113 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const
             if (kk >= 1 && kk <= np_) acc_ += (double)__fdiv_rn(pw[k], total);
             run[k] = acc_;
         }
-        const double incl = seg_incl_sum<RW>(acc_, sl);
-        const double base = incl - acc_;                          // everything in front of this lane (exact: see the header comment)
+        const double incl = RW == 1 ? row_incl_sum(acc_) : seg_incl_sum<RW>(acc_, sl);
+        const double base = incl - acc_;                          // everything in front of this lane (the f64 sums are exact here)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int kk = s0 + k;
-            if (kk == 0) cdf[0] = 0.f;
-            else if (kk <= np_) cdf[kk] = (float)(base + run[k]);
-        }
+        for (int k = 0; k < 4; ++k) cd[k] = s0 + k == 0 ? 0.f : (float)(base + run[k]);      // (entry Nc - 1 is never read)
     }
+    *(float4*)(cb + 2 * s0) = make_float4(cd[0], bn[0], cd[1], bn[1]);
+    *(float4*)(cb + 2 * s0 + 4) = make_float4(cd[2], bn[2], cd[3], bn[3]);
+    *(float4*)(zp + 4 + s0) = z4;
+    if (sl == 0) *(float4*)zp = make_float4(-inf, -inf, -inf, -inf);
+    if (sl == LPR - 1) *(float4*)(zp + 4 + Nc) = make_float4(inf, inf, inf, inf);
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
 
     // ---- inverse-CDF samples (rendering.py:31-64): searchsorted(cdf, u, right=True) = #{k : cdf[k] <= u} ----
     bool okc = true;
-    for (int k = sl; k + 1 < nb; k += LPR) okc = okc && (cdf[k] <= cdf[k + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float nxt = k < 3 ? cd[k + 1] : (RW == 1 ? row_next(cd[0]) : __shfl_down(cd[0], 1));
+        if (s0 + k + 1 < nb) okc = okc && (cd[k] <= nxt);
+    }
     const bool cdf_sorted = (__ballot(!okc) & seg_mask) == 0ull;
-    // Test time: ONE ascending u row for every ray (linspace, :33).  A lane then owns PL CONSECUTIVE samples: a binary search for
-    // its first one and a forward walk for the rest (the counts are non-decreasing in u) -- ~6 + 4 + PL dependent LDS reads instead
-    // of 6 PL -- and its samples leave as whole 16-byte groups.  `cnt_of[]` keeps each sample's count for the merge below.
+    // Test time: ONE ascending u row for every ray (linspace, :33).  A lane then owns PL CONSECUTIVE samples and the search is
+    // turned around: each lane takes its own four CDF entries and finds j_k = #{i : u_i < cdf_k} -- for an evenly spaced u an
+    // arithmetic guess confirmed against the two neighbouring u values (any ascending u stays correct, only slower) -- and
+    // cnt_i = #{k : cdf_k <= u_i} = #{k : j_k <= i} is the prefix sum of the histogram of the j's.  No search chains, the same
+    // work on every lane, and every table is read and written in 8- and 16-byte groups: the kernel is bound by LDS instructions.
     const int PL = (Ni + LPR - 1) / LPR;                          // samples per lane
+    const bool vec = (PL & 3) == 0 && PL * LPR == Ni;             // whole 16-byte groups per lane (Ni = 64, 128, 256 ...)
     bool u_asc = !u_per_ray && cdf_sorted;
     if (u_asc) {
         bool oku = true;
-        for (int i = sl; i + 1 < Ni; i += LPR) oku = oku && (u_lds[i] <= u_lds[i + 1]);
+        for (int i = sl; i + 1 < Ni; i += LPR) oku = oku && (up[4 + i] <= up[5 + i]);
         u_asc = (__ballot(!oku) & seg_mask) == 0ull;
     }
-    auto sample_at = [&](int i, float uu, int cnt) {
+    auto sample_of = [&](float uu, int cnt) {
         const int below = cnt - 1 > 0 ? cnt - 1 : 0;               // :52-53
         const int above = cnt < nb - 1 ? cnt : nb - 1;
-        const float c_lo = cdf[below], c_hi = cdf[above], b_lo = bins[below], b_hi = bins[above];
-        float denom = __fsub_rn(c_hi, c_lo);                       // :60-64
+        // above is below + 1 except at the two ends, where it equals below: ONE paired read of entries (below, below + 1)
+        const float2 lo = *(const float2*)(cb + 2 * below), nx = *(const float2*)(cb + 2 * below + 2);
+        const float2 hi = above == below ? lo : nx;
+        float denom = __fsub_rn(hi.x, lo.x);                       // :60-64
         denom = denom < 1e-5f ? 1.f : denom;
-        const float t = __fdiv_rn(__fsub_rn(uu, c_lo), denom);
-        const float smp = __fadd_rn(b_lo, __fmul_rn(t, __fsub_rn(b_hi, b_lo)));
-        all[Nc + i] = smp;
-        cnt_of[i] = cnt;
-        return smp;
+        const float t = __fdiv_rn(__fsub_rn(uu, lo.x), denom);
+        return __fadd_rn(lo.y, __fmul_rn(t, __fsub_rn(hi.y, lo.y)));
     };
+    const int i_lo = sl * PL, i_hi = (i_lo + PL) < Ni ? (i_lo + PL) : Ni;
     if (u_asc) {
-        // The search turned around: each lane takes its own four CDF entries (k = 4 sl ..) and finds j_k = #{i : u_i < cdf_k} -- for
-        // an evenly spaced u an arithmetic guess, corrected against the actual u values (a walk of zero or one step; any ascending u
-        // stays correct, only slower) -- and cnt_i = #{k : cdf_k <= u_i} = #{k : j_k <= i} is the prefix sum of the histogram of the
-        // j's.  No data-dependent search chains: four guesses, 4 + PL LDS atomics / reads and one scan per lane, the same for every
-        // lane, where a binary search per sample was 6 dependent LDS reads x PL.
-        int* H = (int*)sorted;                                     // [Ni + 1] counters (the row is free until the merge)
-        for (int i = sl; i < Ni + 1; i += LPR) H[i] = 0;
+        if (vec) { for (int i = i_lo; i < i_hi; i += 4) *(int4*)(H + i) = make_int4(0, 0, 0, 0); if (sl == 0) H[Ni] = 0; }
+        else for (int i = sl; i < Ni + 1; i += LPR) H[i] = 0;
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
         const float span = (float)(Ni - 1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int kk = s0 + k;
-            if (kk >= nb) continue;
-            const float c = cdf[kk];
+            if (s0 + k >= nb) continue;
+            const float c = cd[k];
             int j = (int)ceilf(c * span);
             j = j < 0 ? 0 : (j > Ni ? Ni : j);
-            while (j < Ni && u_lds[j] < c) ++j;
-            while (j > 0 && !(u_lds[j - 1] < c)) --j;
+            for (;;) {                                             // j = #{i : u_i < c}  <=>  u_{j-1} < c and not u_j < c  (sentinels at both ends)
+                const float below = up[3 + j], at = up[4 + j];
+                if (at < c) ++j; else if (!(below < c)) --j; else break;
+            }
             atomicAdd(&H[j], 1);
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-        const int i_lo = sl * PL, i_hi = (i_lo + PL) < Ni ? (i_lo + PL) : Ni;
         int run = 0;
-        for (int i = i_lo; i < i_hi; ++i) run += H[i];
+        if (vec) for (int i = i_lo; i < i_hi; i += 4) { const int4 h = *(const int4*)(H + i); run += (h.x + h.y) + (h.z + h.w); }
+        else for (int i = i_lo; i < i_hi; ++i) run += H[i];
         int incl = run;
+        if (RW == 1) incl = row_incl_sum(run);
+        else {
 #pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (sl >= o) incl += t;
+            for (int o = 1; o < LPR; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (sl >= o) incl += t;
+            }
         }
         int cnt = incl - run;
-        // four samples at a time: their counts, then all sixteen table reads, then the arithmetic, then the stores -- written out so
-        // that the LDS reads of a group are in flight together (a loop over single samples waits for every read in turn)
-        for (int i0 = i_lo; i0 < i_hi; i0 += 4) {
-            int cn[4], bl[4], ab[4];
-            float uu[4], c_lo[4], c_hi[4], b_lo[4], b_hi[4];
+        for (int i0 = i_lo; i0 < i_hi; i0 += 4) {                  // four samples at a time: counts, table reads, arithmetic, one 32-byte store
+            int cn[4];
+            float uu[4], smp[4];
+            if (vec) {
+                const int4 h = *(const int4*)(H + i0);
+                const float4 u4 = *(const float4*)(up + 4 + i0);
+                cn[0] = cnt + h.x; cn[1] = cn[0] + h.y; cn[2] = cn[1] + h.z; cn[3] = cn[2] + h.w;
+                uu[0] = u4.x; uu[1] = u4.y; uu[2] = u4.z; uu[3] = u4.w;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = i0 + e < Ni ? i0 + e : Ni - 1;
-                cnt += i0 + e < i_hi ? H[i] : 0;
-                cn[e] = cnt;
-                uu[e] = u_lds[i];
+                for (int e = 0; e < 4; ++e) {
+                    const int i = i0 + e < Ni ? i0 + e : Ni - 1;
+                    cnt += i0 + e < i_hi ? H[i] : 0;
+                    cn[e] = cnt;
+                    uu[e] = up[4 + i];
+                }
             }
+            cnt = cn[3];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bl[e] = cn[e] - 1 > 0 ? cn[e] - 1 : 0;              // :52-53
-                ab[e] = cn[e] < nb - 1 ? cn[e] : nb - 1;
-                c_lo[e] = cdf[bl[e]]; c_hi[e] = cdf[ab[e]]; b_lo[e] = bins[bl[e]]; b_hi[e] = bins[ab[e]];
-            }
-            float smp[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float denom = __fsub_rn(c_hi[e], c_lo[e]);         // :60-64
-                denom = denom < 1e-5f ? 1.f : denom;
-                const float t = __fdiv_rn(__fsub_rn(uu[e], c_lo[e]), denom);
-                smp[e] = __fadd_rn(b_lo[e], __fmul_rn(t, __fsub_rn(b_hi[e], b_lo[e])));
+            for (int e = 0; e < 4; ++e) smp[e] = sample_of(uu[e], cn[e]);
+            if (vec) {
+                *(float4*)(s2 + 2 * i0) = make_float4(smp[0], __int_as_float(cn[0]), smp[1], __int_as_float(cn[1]));
+                *(float4*)(s2 + 2 * i0 + 4) = make_float4(smp[2], __int_as_float(cn[2]), smp[3], __int_as_float(cn[3]));
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (i0 + e < i_hi) {
-                    all[Nc + i0 + e] = smp[e];
-                    cnt_of[i0 + e] = cn[e];
+                    if (!vec) { s2[2 * (i0 + e)] = smp[e]; s2[2 * (i0 + e) + 1] = __int_as_float(cn[e]); }
                     if (z_samples && live) z_samples[(size_t)ray * Ni + i0 + e] = smp[e];
                 }
         }
@@ -365,13 +376,13 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int i = ii[e] < Ni ? ii[e] : Ni - 1;
-                uu[e] = u_per_ray ? u[(size_t)ray * Ni + i] : u[i];
+                uu[e] = u_per_ray ? u[(size_t)ray * Ni + i] : up[4 + i];
             }
             if (cdf_sorted && uu[0] == uu[0] && uu[1] == uu[1]) {
                 int lo0 = 0, hi0 = nb, lo1 = 0, hi1 = nb;
                 while (lo0 < hi0 || lo1 < hi1) {
                     const int m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
-                    const float c0 = cdf[m0 < nb ? m0 : nb - 1], c1 = cdf[m1 < nb ? m1 : nb - 1];
+                    const float c0 = cdfv(m0 < nb ? m0 : nb - 1), c1 = cdfv(m1 < nb ? m1 : nb - 1);
                     if (lo0 < hi0) { if (c0 <= uu[0]) lo0 = m0 + 1; else hi0 = m0; }
                     if (lo1 < hi1) { if (c1 <= uu[1]) lo1 = m1 + 1; else hi1 = m1; }
                 }
@@ -380,14 +391,15 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     cnt[e] = 0;
-                    if (cdf_sorted && uu[e] == uu[e]) cnt[e] = count_less_equal(cdf, nb, uu[e]);
-                    else for (int k = 0; k < nb; ++k) cnt[e] += (cdf[k] <= uu[e]) ? 1 : 0;
+                    for (int k = 0; k < nb; ++k) cnt[e] += (cdfv(k) <= uu[e]) ? 1 : 0;
                 }
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 if (ii[e] >= Ni) continue;
-                const float smp = sample_at(ii[e], uu[e], cnt[e]);
+                const float smp = sample_of(uu[e], cnt[e]);
+                s2[2 * ii[e]] = smp;
+                s2[2 * ii[e] + 1] = __int_as_float(cnt[e]);
                 if (z_samples && live) z_samples[(size_t)ray * Ni + ii[e]] = smp;
             }
         }
@@ -397,37 +409,46 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const
 
     // ---- stable rank sort of cat[z_coarse, z_samples] (rendering.py:141), as sample_pdf_merge_kernel ----
     bool oka = true;
-    for (int k = sl; k + 1 < Nc; k += LPR) oka = oka && (all[k] <= all[k + 1]);
-    for (int k = sl; k + 1 < Ni; k += LPR) oka = oka && (all[Nc + k] <= all[Nc + k + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (s0 + k + 1 < Nc) oka = oka && (zz[k] <= (k < 3 ? zz[k + 1] : z_next));
+    for (int k = sl; k + 1 < Ni; k += LPR) oka = oka && (s2[2 * k] <= s2[2 * k + 2]);
     const bool ordered = (__ballot(!oka) & seg_mask) == 0ull;
     if (ordered) {
-        // Both halves ascending.  A sample's rank is its index + c = #{coarse <= sample}; the sample was interpolated between the
-        // midpoints around coarse depth `c`, so a walk of a step or two from the previous sample's c finds it (instead of a 6-step
-        // binary search per element).  A coarse depth's rank is its index + #{samples < z_k} = #{samples : c <= k} (z ascending):
-        // a histogram of the c's (LDS atomics) and its prefix sum over the ray's lanes.
-        for (int k = sl; k < Nc + 4; k += LPR) hist[k] = 0;
+        // Both halves ascending.  A sample's rank is its index + c, c = #{coarse <= sample}: the sample was interpolated between the
+        // midpoints bins[below] >= z[below] and bins[above] <= z[below + 2], so c is below + 1 or below + 2 -- one paired read of
+        // (z[c - 1], z[c]) decides, a walk covers the rest.  A coarse depth's rank is its index + #{samples < z_k} =
+        // #{samples : c <= k} (z ascending): a histogram of the c's and its prefix sum over the ray's lanes.
+        *(int4*)(hist + s0) = make_int4(0, 0, 0, 0);
+        if (sl == 0) *(int4*)(hist + Nc) = make_int4(0, 0, 0, 0);
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-        const int i_lo = sl * PL, i_hi = (i_lo + PL) < Ni ? (i_lo + PL) : Ni;
-        for (int i0 = i_lo; i0 < i_hi; i0 += 4) {                  // groups of four, reads first (as above)
-            float v[4], z_at[4];
+        for (int i0 = i_lo; i0 < i_hi; i0 += 4) {
+            float v[4];
             int c[4];
+            if (vec) {
+                const float4 a4 = *(const float4*)(s2 + 2 * i0), b4 = *(const float4*)(s2 + 2 * i0 + 4);
+                v[0] = a4.x; v[1] = a4.z; v[2] = b4.x; v[3] = b4.z;
+                c[0] = __float_as_int(a4.y); c[1] = __float_as_int(a4.w); c[2] = __float_as_int(b4.y); c[3] = __float_as_int(b4.w);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = i0 + e < Ni ? i0 + e : Ni - 1;
+                    v[e] = s2[2 * i];
+                    c[e] = __float_as_int(s2[2 * i + 1]);
+                }
+            }
+            float lo[4], hi[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int i = i0 + e < Ni ? i0 + e : Ni - 1;
-                v[e] = all[Nc + i];
-                // the sample was interpolated between bins[below] >= z[below] and bins[above] <= z[below + 2]: c is below + 1 or + 2
-                c[e] = cnt_of[i] > 1 ? cnt_of[i] : 1;
+                c[e] = c[e] > 1 ? c[e] : 1;
+                lo[e] = zp[3 + c[e]];                              // z[c - 1]
+                hi[e] = zp[4 + c[e]];                              // z[c]  (+inf behind the last one)
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) z_at[e] = all[c[e] < Nc ? c[e] : Nc - 1];
-#pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (c[e] < Nc && z_at[e] <= v[e]) {
-                    ++c[e];
-                    while (c[e] < Nc && all[c[e]] <= v[e]) ++c[e];     // (not taken for a sample between its two midpoints)
-                }
-                while (c[e] > 0 && !(all[c[e] - 1] <= v[e])) --c[e];   // (one read: confirms the lower side)
+                if (hi[e] <= v[e]) { ++c[e]; while (zp[4 + c[e]] <= v[e]) ++c[e]; }
+                else if (!(lo[e] <= v[e])) { --c[e]; while (c[e] > 0 && !(zp[3 + c[e]] <= v[e])) --c[e]; }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -438,25 +459,29 @@ __global__ __launch_bounds__(256) void coarse_sample_kernel(int N, int Ni, const
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-        int h4[4], run = 0;
+        const int4 h4 = *(const int4*)(hist + s0);
+        const int r0 = h4.x, r1 = r0 + h4.y, r2 = r1 + h4.z, r3 = r2 + h4.w;
+        int incl = r3;                                             // inclusive scan of the lanes' totals over the ray
+        if (RW == 1) incl = row_incl_sum(r3);
+        else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { run += hist[s0 + k]; h4[k] = run; }
-        int incl = run;                                            // inclusive scan of the lanes' totals over the ray
-#pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (sl >= o) incl += t;
+            for (int o = 1; o < LPR; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (sl >= o) incl += t;
+            }
         }
-        const int base = incl - run;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sorted[s0 + k + base + h4[k]] = zz[k];
+        const int base = incl - r3;
+        sorted[s0 + base + r0] = zz[0];
+        sorted[s0 + 1 + base + r1] = zz[1];
+        sorted[s0 + 2 + base + r2] = zz[2];
+        sorted[s0 + 3 + base + r3] = zz[3];
     } else {
         for (int i = sl; i < S; i += LPR) {
-            const float v = all[i];
+            const float v = allv(i);
             const bool v_nan = v != v;
             int rank = 0;
             for (int k = 0; k < S; ++k) {
-                const float o = all[k];
+                const float o = allv(k);
                 const bool o_nan = o != o;
                 const bool before = v_nan ? (!o_nan || k < i) : (!o_nan && (o < v || (o == v && k < i)));
                 rank += before ? 1 : 0;
@@ -479,7 +504,7 @@ template <int RW>
 static int launch_coarse_sample(int N, int Ni, const float* sigma, const float* z, size_t z_stride, const float* u, int u_per_ray,
                                 float* z_fine, float* z_samples, float* weights_out, hipStream_t st) {
     constexpr int RPW = Seg<RW>::RPW, Nc = 64 * RW;
-    const size_t lds = ((size_t)4 * RPW * coarse_sample_lds_floats(Nc, Ni) + (size_t)(Ni + 3) / 4 * 4) * sizeof(float);
+    const size_t lds = ((size_t)4 * RPW * coarse_sample_lds_floats(Nc, Ni) + (size_t)coarse_sample_u_floats(Ni)) * sizeof(float);
     auto k = coarse_sample_kernel<RW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -140,3 +140,39 @@ __device__ __forceinline__ double seg_incl_sum(double v, int sl) {
     }
     return v;
 }
+
+// ---- the same scans for a ray that occupies exactly ONE row of 16 lanes (RW = 1), on DPP row shifts: register to register, no
+// ---- ds_bpermute round trips (the fused coarse-pass sampler is bound by LDS instructions).  Same Hillis-Steele tree, same results.
+template <int CTRL>
+__device__ __forceinline__ double dpp_shr_keep(double v, double keep) {      // lane i <- lane i - k of its row; `keep` where there is none
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(keep), lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_incl_prod(double v) {
+    v *= dpp_shr_keep<0x111>(v, 1.0);
+    v *= dpp_shr_keep<0x112>(v, 1.0);
+    v *= dpp_shr_keep<0x114>(v, 1.0);
+    v *= dpp_shr_keep<0x118>(v, 1.0);
+    return v;
+}
+__device__ __forceinline__ double row_incl_sum(double v) {
+    v += dpp_shr_zero<0x111>(v);
+    v += dpp_shr_zero<0x112>(v);
+    v += dpp_shr_zero<0x114>(v);
+    v += dpp_shr_zero<0x118>(v);
+    return v;
+}
+__device__ __forceinline__ int row_incl_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    return v;
+}
+// previous / next lane of the row (`keep` at the row's first / last lane)
+__device__ __forceinline__ double row_prev(double v, double keep) { return dpp_shr_keep<0x111>(v, keep); }
+__device__ __forceinline__ float row_next(float v) {             // row_shl:1; the row's last lane keeps its own value
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x101, 0xf, 0xf, false));
+}

@@ -118,3 +118,23 @@ def test_oracle_free_running_loops_track_the_reference(golden):
                       photo_of(g), float(g["m2_lr"]), n)
     assert np.abs(b["poses"].numpy() - g["m2_pose"][k, :n]).max() < 2e-5
     assert rel(b["losses"].numpy(), g["m2_loss"][k, :n]) < 2e-4
+
+
+# ---- the reference's own loop resolution: 60 x 80 rays (DFM_APR_refine.py:107, seven_scenes_colmap.py:264-276), one start x 50
+# ---- iterations x both modes (tests/golden/refine50_60x80.npz; `tools/make_golden_refine50.py --hw 240 320 300 --k 1`) ----------
+def test_oracle_matches_reference_at_60x80(golden):
+    g = golden("refine50_60x80")
+    assert tuple(int(v) // int(g["tinyscale"]) for v in g["hwf"][:2]) == (60, 80) and len(g["init_c2w"]) == 1
+    p = problem(g, torch.float32, 0, 3)
+    for i in (0, 49):
+        r0 = np.zeros(3, np.float32) if i == 0 else g["m3_r"][0, i - 1]
+        t0 = np.zeros(3, np.float32) if i == 0 else g["m3_t"][0, i - 1]
+        loss, grad = p.loss_and_grad(r0, t0)
+        ref_l = float(g["m3_loss"][0, i])
+        assert abs(float(loss) - ref_l) < 2e-4 * ref_l + 2e-7, (i, float(loss), ref_l)
+        assert rel(grad.numpy(), g["m3_grad"][0, i]) < 5e-4, (i, grad.numpy(), g["m3_grad"][0, i])
+    # the loop converges at this resolution too, in both modes, and the float64 oracle ends where the reference ends
+    for tag, key in (("m3", "m3_pose"), ("m2", "m2_final")):
+        assert g[tag + "_err"][0, 0] < g["init_err"][0, 0] / 3
+        e64 = RC.pose_error(g["true_c2w"], g[key + "_f64"][0])
+        assert abs(e64[0] - g[tag + "_err"][0, 0]) < 0.01 * g[tag + "_err"][0, 0], (tag, e64, g[tag + "_err"][0])
