@@ -331,8 +331,8 @@ def test_mode3_population_of_50_iteration_runs(golden, graph):
         curves.append(losses.cpu().numpy())
     tag = f"refine50_mode3[{'graph' if graph else 'eager'}]"
     el = max(rel(c, r) for c, r in zip(curves, g["m3_loss"]))
-    P.record(tag, "loss curves (50 iterations x 8 starts) vs the reference's", direct=el, e_hip=None, e_ref=None, bound=2e-3)
-    assert el < 2e-3
+    P.record(tag, "loss curves (50 iterations x 8 starts) vs the reference's", direct=el, e_hip=None, e_ref=None, bound=1e-3)
+    assert el < 1e-3
     population_check(tag, g, poses, g["m3_pose"], g["m3_pose_f64"])
 
 
@@ -400,8 +400,8 @@ def test_both_modes_at_60x80_rays(golden):
     ref = refiner(g, graph=True)
     pose, losses = ref.refine(T(g["init_c2w"][0]), T(g["target_low"]), T(g["hist"]), n)
     el = rel(losses.cpu().numpy(), g["m3_loss"][0])
-    P.record("refine50_60x80_mode3", "loss curve (50 iterations) vs the reference's", direct=el, e_hip=None, e_ref=None, bound=2e-3)
-    assert el < 2e-3
+    P.record("refine50_60x80_mode3", "loss curve (50 iterations) vs the reference's", direct=el, e_hip=None, e_ref=None, bound=1e-3)
+    assert el < 1e-3
     population_check("refine50_60x80_mode3", g, [pose[:3, :4].cpu().numpy()], g["m3_pose"], g["m3_pose_f64"])
     photo, tgt = photo_of(g), target_full(g)
     apr = TinyAPR(g["m2_weight"][0], g["m2_bias"][0])
@@ -424,7 +424,8 @@ def test_both_modes_at_60x80_rays(golden):
         with B.tapped() as tap:
             loss = float(ref3.loss_and_grad())
         grad = torch.cat([ref3.model.r.grad[0], ref3.model.t.grad[0]]).cpu()
-        assert abs(loss - float(g["m3_loss"][0, i])) < 2e-4 * float(g["m3_loss"][0, i])
+        # (1 - mean cosine: at convergence the loss is 3e-4, i.e. one fp32 ulp of the cosine is 2e-4 of it -- hence the absolute term)
+        assert abs(loss - float(g["m3_loss"][0, i])) < 2e-4 * float(g["m3_loss"][0, i]) + 2e-7
         conv_pos, aud = [(y > 0).cpu() for y in tap["conv_relu"][-3:]], {}
         B.pinned_gradients(f"refine50_60x80_mode3_iteration[{i}]", {"d loss / d (r, t)": grad}, tap, int(g["Wd"]),
                            lambda dt, act, zf: {"d loss / d (r, t)": probs[dt].loss_and_grad(r0, t0, fine_act=act, z_fine=zf, conv_pos=conv_pos,
