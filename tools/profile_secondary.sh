@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel stats of the secondary workloads:  tools/profile_secondary.sh r01  -> gpurun_out/<round>/<workload>_*
 R=${1:-r01}; ROOT=$(pwd); OUT=$ROOT/gpurun_out/$R; mkdir -p $OUT; export TMPDIR=/tmp
-for wl in ref cam loop50 train; do
+for wl in ref cam loop50 train metric128; do
   EXTRA=""; [ $wl = ref ] && EXTRA="--steps 50 --warmup 5"     # a 2 ms step: three steps after one warm-up still carry one-off host work
   python bench.py --workload $wl --cpu-rows 0 $EXTRA 2>/dev/null | tail -1 > $OUT/bench_$wl.json
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_$wl -- python3 $ROOT/bench.py --workload $wl --cpu-rows 0 > $OUT/st_$wl.log 2>&1)
