@@ -238,6 +238,8 @@ def weight_grads(net, pk, mode, N, S, raw_t, g_raw_t, acts, fused=None):
     if DEBUG is not None:
         DEBUG.update(acts=rows_view(acts), dacts=rows_view(dacts), rows=P.rows, off={b: P.off(b) for b in range(19)})
     del keep
+    if fused is not None:
+        g["__rays__"] = (g_pts, g_vs)          # per-sample d pts / d viewdirs of the fused dX chain (joint pose + weight gradients)
     return g
 
 
@@ -284,9 +286,10 @@ class FieldTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_raw_t):
-        if any(ctx.needs_input_grad[:4]):
-            raise NotImplementedError("nefes_amd: the train-mode pass produces weight gradients only; gradients w.r.t. the "
-                                      "rays come from the refinement path (frozen weights, ops.FieldFromRays)")
+        want_rays = any(ctx.needs_input_grad[:3])
+        if ctx.needs_input_grad[3] or (want_rays and not ctx.fused):
+            raise NotImplementedError("nefes_amd: gradients w.r.t. the rays in train mode come from the fused dX chain "
+                                      "(train.FUSED_DX, frequency embedding); the depths z carry no gradient (rendering.py:139 detaches them)")
         ctx.pk.check_generation(ctx.pk_gen)
         raw_t, acts = ctx.saved_tensors[:2]
         N, S = ctx.NS
@@ -294,7 +297,13 @@ class FieldTrain(torch.autograd.Function):
             g = weight_grads(ctx.net, ctx.pk, ctx.mode, N, S, raw_t, ops._f32(g_raw_t), acts,
                              fused=tuple(ctx.saved_tensors[2:]) if ctx.fused else None)
         names = param_names(ctx.net, ctx.mode)
-        return (None,) * 6 + tuple(g[n].contiguous() for n in names)
+        g_rays = (None, None, None)
+        if want_rays:
+            # joint pose + weight gradients (e.g. BARF-style training): the fused dX chain wrote d pts / d viewdirs per sample anyway
+            zz = ctx.saved_tensors[5]
+            g_pts, g_vs = g["__rays__"]
+            g_rays = ops.ray_grad_reduce(N, S, zz, g_pts, g_vs)
+        return g_rays + (None,) * 3 + tuple(g[n].contiguous() for n in names)
 
 
 def field_train(net, mode, rays_o, rays_d, viewdirs, z):

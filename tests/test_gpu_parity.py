@@ -453,16 +453,32 @@ def check_end_to_end(g, tag, Wd, C, Nc, Ni, tat, sscale, H, W, focal):
         assert direct <= max(1e-4, 4 * e_ref)
 
 
-def test_joint_pose_and_weight_gradients_fail_loudly():
-    """Trainable weights take the train-mode path (weight gradients, tests/test_gpu_train.py); asking for the pose
-    gradient through it as well is not built and must raise instead of silently returning no gradient."""
+def test_joint_pose_and_weight_gradients():
+    """Trainable weights take the train-mode path; its fused dX chain also yields d pts / d viewdirs per sample, so the pose gradient
+    comes along (round 4; rounds 1-3 raised): equal to the frozen-weight path's pose gradient on the same frame, with the weight
+    gradients unchanged by asking for it."""
     R, M = _dropin()
     coarse, fine = _modules(128, 128)
+    kw = _kwargs(M, coarse, fine, 64, True)
+    H, W, focal = 6, 8, 5.0
+    c0 = O.bench_pose().to(DEV).requires_grad_()
+    rgb, _, _, ex = R.render(H, W, focal, c2w=c0, near=0., far=4., **kw)
+    (g_frozen,) = torch.autograd.grad(O.bench_loss(rgb, ex["feat_map"]), c0)
     fine.requires_grad_(True)
-    c2w = O.bench_pose().to(DEV).requires_grad_()
-    rgb, _, _, _ = R.render(4, 4, 3.0, c2w=c2w, near=0., far=4., **_kwargs(M, coarse, fine, 64, True))
-    with pytest.raises(NotImplementedError, match="weight gradients only"):
-        rgb.sum().backward()
+    names = [n for n, p in fine.named_parameters() if not n.startswith(("fusion_net", "exposure_embedding"))]
+    rgb, _, _, ex = R.render(H, W, focal, c2w=O.bench_pose().to(DEV), near=0., far=4., **kw)       # weights only
+    O.bench_loss(rgb, ex["feat_map"]).backward()
+    gw = {n: p.grad.clone() for n, p in fine.named_parameters() if n in names and p.grad is not None}
+    assert len(gw) >= 30
+    fine.zero_grad()
+    c1 = O.bench_pose().to(DEV).requires_grad_()
+    rgb, _, _, ex = R.render(H, W, focal, c2w=c1, near=0., far=4., **kw)                             # weights AND pose
+    O.bench_loss(rgb, ex["feat_map"]).backward()
+    e = rel(c1.grad, g_frozen)
+    P.record("joint_pose_and_weights", "d c2w through the train-mode dX chain vs the frozen-weight backward", direct=e, e_hip=None, e_ref=None, bound=1e-5)
+    assert e < 1e-5, e
+    for n, g0 in gw.items():
+        assert torch.equal(dict(fine.named_parameters())[n].grad, g0), n
 
 
 def test_full_size_properties(ops, L):

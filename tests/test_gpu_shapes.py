@@ -174,3 +174,40 @@ def test_composite_above_256_samples_matches_oracle():
         _, _, _, acc_d, _, w_d, _ = ops.composite_fwd(rt.detach()[:, 3 + C:3 + C + 1, :].contiguous(), z.to(DEV), C, L.COMP_SIGMA_ONLY)
         ref_d = O.composite(raw[..., 3 + C:3 + C + 1].double(), z.double(), output_transient=False, test_time=True, typ="coarse")
         assert rel(w_d, ref_d.weights) < 2e-6 and rel(acc_d, ref_d.acc) < 2e-6
+
+
+def test_full_frame_640x480_properties_at_w256_c128():
+    """The BASELINE frame (640x480, 64+128 samples) with the network the reference builds at --netwidth 256 (C = 128: 59 M fine samples,
+    ~90 GB resident): the size-independent properties of tests/test_gpu_parity.py::test_full_frame_640x480_properties -- finite maps,
+    compositing weights a sub-probability, bit-identical rerun, row shards equal the rows of the full frame bit for bit, pose gradient
+    linear in the loss and additive over shards."""
+    from nefes_amd import dist as D
+    from tests.test_gpu_parity import _dropin, _kwargs
+    R, M = _dropin()
+    coarse, fine = _modules(256, 128)
+    kw = _kwargs(M, coarse, fine, 128, True)
+    H, W, f = 480, 640, 525.505
+    c2w = O.bench_pose().to(DEV).requires_grad_()
+    rgb, disp, acc, ex = R.render(H, W, f, c2w=c2w, near=0., far=4., **kw)
+    feat = ex["feat_map"]
+    assert rgb.shape == (H * W, 3) and feat.shape == (H * W, 128)
+    assert torch.isfinite(rgb).all() and torch.isfinite(feat).all() and torch.isfinite(disp).all()
+    assert (acc > 0).all() and (acc <= 1 + 1e-5).all()
+    loss = O.bench_loss(rgb, feat)
+    (g1,) = torch.autograd.grad(loss, c2w, retain_graph=True)
+    (g3,) = torch.autograd.grad(3.0 * loss, c2w)
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0 and rel(g3, 3.0 * g1) < 1e-6
+    chk = (float(rgb.double().sum()), float(feat.double().sum()))
+    del rgb, disp, acc, ex, loss
+    torch.cuda.empty_cache()
+    rgb2, _, _, ex2 = R.render(H, W, f, c2w=c2w, near=0., far=4., **kw)
+    assert (float(rgb2.double().sum()), float(ex2["feat_map"].double().sum())) == chk
+    acc_g = torch.zeros_like(g1)
+    for rank in range(2):
+        row0, n = D.row_shard(H, rank, 2)
+        r, _, _, e = R.render(H, W, f, c2w=c2w, near=0., far=4., row_range=(row0, n), **kw)
+        assert torch.equal(r, rgb2[row0 * W:(row0 + n) * W]) and torch.equal(e["feat_map"], ex2["feat_map"][row0 * W:(row0 + n) * W])
+        part = (e["feat_map"] ** 2).sum() / (H * W * 128) + (r ** 2).sum() / (H * W * 3)
+        acc_g += torch.autograd.grad(part, c2w)[0]
+        del r, e, part
+    assert rel(acc_g, g1) < 1e-5
