@@ -148,12 +148,14 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
         auto save_trunk = [&](int layer, const f32x16 (&X)[NTW], int es) {   // layer 1..9 (9 = xyz_encoding_final)
             if constexpr (TRAIN) train_save_h3<NTW, 0>(act_tile, act_voff, nefes_train_row(W, 0, NEFES_TB_L1) + (layer - 1) * W, X, pow2i(-es));
         };
-        int mask_word = 0;
+        // this lane's column of the tile's mask words: a running pointer, so that a layer's words leave at constant offsets
+        // (a word index kept as an integer cost three vector instructions of 64-bit address arithmetic per store, at every layer
+        // boundary, where the matrix pipe idles)
+        uint32_t* mask_ptr = (MODE != NEFES_FIELD_SIGMA && a.masks) ? a.masks + ((size_t)((long long)tile * 4 + wave) * MW) * 64 + lane : nullptr;
         auto put_masks = [&](const uint32_t* bits, int n) {
-            if (MODE != NEFES_FIELD_SIGMA && a.masks) {
-                uint32_t* mask_tile = a.masks + ((size_t)((long long)tile * 4 + wave) * MW) * 64;      // wave-uniform
-                for (int w = 0; w < n; ++w) __builtin_nontemporal_store(bits[w], &mask_tile[(mask_word + w) * 64 + lane]);   // written once, read once by the backward: keep it out of the way of the weight stream in L2
-                mask_word += n;
+            if (MODE != NEFES_FIELD_SIGMA && mask_ptr) {
+                for (int w = 0; w < n; ++w) __builtin_nontemporal_store(bits[w], &mask_ptr[w * 64]);   // written once, read once by the backward: keep it out of the way of the weight stream in L2
+                mask_ptr += n * 64;
             }
         };
         // column of this lane's sample in raw_t (null for the padding lanes of the last tile)
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
         clear_bits();                                                                                                          \
         {                                                                                                                      \
             const int ew = wexp(SEG1_), tau = tau_of(M, ew);                                                                   \
+            const float rb_ = rowb(SEG1_), bm_ = bmax((L1_) - 1);       /* table reads in front of the run, not behind it */    \
             float mx = 0.f;                                                                                                    \
             if constexpr (CB) {                                                                                                \
                 const char* bps = bias_half + ((L1_) - 2) * W * 4;                          /* bias block of the source layer */ \
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
             } else                                                                                                             \
             mma_run_h3<NTW, W / 16, 0, true>(ring, ring_lane, ReluSplitH<CAP, NTW, WT>{A, bits, pow2i(tau - es_a), mx},        \
                                              bias_at(((L1_) - 1) * W, tau + ew), B);                                           \
-            M = rowb(SEG1_) * (pair_max(mx) * pow2i(-es_a)) + bmax((L1_) - 1);                                                 \
+            M = rb_ * (pair_max(mx) * pow2i(-es_a)) + bm_;                                                                     \
             es_b = tau + ew;                                                                                                   \
             save_trunk(L1_, B, es_b);                                                                                          \
         }                                                                                                                      \
@@ -246,6 +249,8 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                 // skip layer: its xyz part accumulates into the same tiles, so the common exponent must suit the embedding too
                 const int tau = tau_of(p == 1 ? fmaxf(M, mE) : M, ew);
                 if (p == 3) sigma_head(B, es_b, tau_of(M, wexp(NEFES_H3F_SIG)));   // static_sigma reads the same relu(h8)
+                const float rb_ = rowb(seg2), bm_ = bmax(l2 <= 8 ? l2 - 1 : NEFES_H3BB_FINAL);      // (table reads in front of the run)
+                const float rbe_ = p == 1 ? rowb(NEFES_H3F_L5E) : 0.f;
                 float mx = 0.f;
                 if constexpr (CB) {
                     const char* bps = bias_half + (l1 - 1) * W * 4;                        // bias block of the source layer l1
@@ -256,8 +261,7 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                 mma_run_h3<NTW, W / 16, 0, true>(ring, ring_lane, ReluSplitH<CAP, NTW, WT>{B, bits, pow2i(tau - es_b), mx},
                                                  bias_at(l2 <= 8 ? (l2 - 1) * W : B_FINAL, tau + ew), A);   // 3, 5, 7, final
                 if (p == 1) mma_run_h3<NTW, ES / 8, 0, false>(ring, ring_lane, LdsSplitH{e_lds, pow2i(tau)}, ZeroInit{}, A);   // skip: + W5[:, :63] e
-                M = rowb(seg2) * (pair_max(mx) * pow2i(-es_b)) + (p == 1 ? rowb(NEFES_H3F_L5E) * mE : 0.f)
-                    + bmax(l2 <= 8 ? l2 - 1 : NEFES_H3BB_FINAL);
+                M = rb_ * (pair_max(mx) * pow2i(-es_b)) + (p == 1 ? rbe_ * mE : 0.f) + bm_;
                 es_a = tau + ew;
                 save_trunk(l2, A, es_a);
             }
