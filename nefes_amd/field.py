@@ -159,9 +159,44 @@ class NeRFH_NFF(nn.Module):
 
     # -- the HIP path ---------------------------------------------------------------------------
     def _supported(self):
-        return (self.D == 8 and self.skips == [4] and self.in_channels_xyz in (63, 32) and self.in_channels_dir == 27
+        # Encodings: the kernels compute the 10 / 4-frequency embeddings (63 / 27 features).  A network built on FEWER frequencies
+        # -- `multires` < 10, `multires_views` < 4, or the reference's reduce_embedding modes 0 (half the frequencies) and 1 (none:
+        # the raw 3-vector), nerfh_nff.py:307-330 -- reads a PREFIX of those features (x, then sin / cos per frequency in ascending
+        # order), so it runs on the same kernels with zero weight columns for the frequencies it does not have (_kernel_params).
+        freq_xyz = self.in_channels_xyz in range(3, 64, 6)
+        return (self.D == 8 and self.skips == [4] and (freq_xyz or self.in_channels_xyz == 32) and self.in_channels_dir in range(3, 28, 6)
                 and self.W in (128, 256) and self.out_ch_size != 3 and 0 < self.W_features <= ops.HEAD_MAX_C
-                and (self.in_channels_xyz == 63 or (self.W == 256 and ops.head_class(self.W_features) == 0)))
+                and (freq_xyz or (self.W == 256 and ops.head_class(self.W_features) == 0)))
+
+    # layers whose input holds an embedding: (name, column where the embedding starts, its width here, its width in the kernels)
+    def _embedding_columns(self):
+        ex, ed, W = self.in_channels_xyz, self.in_channels_dir, self.W
+        cols = []
+        if ex != 32 and ex < 63:
+            cols += [("xyz_encoding_1.0.weight", 0, ex, 63), ("xyz_encoding_5.0.weight", 0, ex, 63)]
+        if ed < 27:
+            cols += [("dir_encoding.0.weight", W, ed, 27)]
+            if self.encode_transient:
+                cols += [("transient_encoding.0.weight", W, ed, 27)]
+        return cols
+
+    def _kernel_params(self, sd):
+        """Parameters in the shapes the kernels are built for: zero columns appended to a shorter embedding's weight block."""
+        cols = self._embedding_columns()
+        if not cols:
+            return sd
+        out = dict(sd)
+        for name, at, have, want in cols:
+            w = sd[name]
+            out[name] = torch.cat([w[:, :at + have], w.new_zeros(w.shape[0], want - have), w[:, at + have:]], 1)
+        return out
+
+    def shrink_grads(self, g):
+        """Inverse of _kernel_params on a {name: gradient} dict of the train-mode kernels (drops the padded columns)."""
+        for name, at, have, want in self._embedding_columns():
+            if name in g:
+                g[name] = torch.cat([g[name][:, :at + have], g[name][:, at + want:]], 1)
+        return g
 
     def invalidate_packed(self):
         """Force a re-pack on the next render.  The cache key is (data_ptr, _version, device) per parameter, which sees
@@ -174,13 +209,15 @@ class NeRFH_NFF(nn.Module):
         """Fragment streams for the fused kernels; re-packed when any path parameter changes (see invalidate_packed for
         the one kind of change this cannot see)."""
         if not self._supported():
-            raise RuntimeError(f"nefes_amd: the HIP field kernels are built for D=8, skips=[4], 63/27 encodings and a feature head "
-                               f"(f_dim>0); got D={self.D}, skips={self.skips}, W={self.W}, f_dim={self.W_features}, "
-                               f"in_channels_xyz={self.in_channels_xyz}.  Compiled: {ops.COMPILED_SET}")
+            raise RuntimeError(f"nefes_amd: the HIP field kernels are built for D=8, skips=[4], frequency encodings of up to 10 / 4 "
+                               f"octaves (3 + 6k inputs, k <= 10 / 4) and a feature head (f_dim>0); got D={self.D}, skips={self.skips}, "
+                               f"W={self.W}, f_dim={self.W_features}, in_channels_xyz={self.in_channels_xyz}, "
+                               f"in_channels_dir={self.in_channels_dir}.  Compiled: {ops.COMPILED_SET}")
         names = ops.PackedField.LAYERS_FINE if self.encode_transient else ops.PackedField.LAYERS_COARSE
         sd = dict(self.named_parameters())
         prm = [sd[n + s] for n in names for s in (".weight", ".bias")]
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in prm)
+        pad = bool(self._embedding_columns())
         if os.environ.get("NEFES_DEBUG_PACK_CHECKSUM", "0") == "1":      # debug: also key on the values (one sync per call)
             key += (float(sum(p.detach().double().sum() for p in prm)),)
         if (self._pk is not None and key != self._pk_key and any(p.requires_grad for p in prm)
@@ -188,12 +225,17 @@ class NeRFH_NFF(nn.Module):
             # a trainable network after an optimizer step: re-packed on the device, no host copy, no sync -- every stream, the
             # fp16 two-part ones and their scale tables included (ops.REPACK_H3; bit-identical to the host packer).  A FROZEN
             # network whose values changed (load_state_dict, an in-place edit) takes the host packer below.
-            self._pk.repack(prm)
+            if pad:
+                ksd = self._kernel_params(sd)
+                self._pk.repack([ksd[n + s_] for n in names for s_ in (".weight", ".bias")])
+            else:
+                self._pk.repack(prm)
             self._pk_key = key
         elif self._pk is None or key != self._pk_key:
             dev = prm[0].device if prm[0].is_cuda else torch.device("cuda")
             enc = L.XYZ_EXTERNAL32 if self.in_channels_xyz == 32 else L.XYZ_FREQ10      # 32 = externally encoded (hash grid)
-            self._pk = ops.PackedField({n: p for n, p in sd.items()}, self.W, self.W_features, self.encode_transient, dev, enc)
+            self._pk = ops.PackedField(self._kernel_params({n: p.detach() for n, p in sd.items()}), self.W, self.W_features,
+                                       self.encode_transient, dev, enc)
             self._pk_key = key
         return self._pk
 
@@ -264,11 +306,15 @@ def run_network_NeRFH_NFF(inputs, viewdirs, ts, fn, embed_fn=None, embeddirs_fn=
 class _Embedder:
     """Embedder (nerfh_nff.py:234-270), kept because create_nerf returns embed fns inside the query lambda."""
 
-    def __init__(self, multires, include_input=True):
-        self.N_freqs, self.out_dim = multires, 3 * (1 + 2 * multires)
-        self.freq_bands = 2. ** torch.linspace(0., multires - 1, steps=multires) if multires > 0 else torch.zeros(0)
+    def __init__(self, num_freqs, max_freq_log2=None):
+        max_freq_log2 = num_freqs - 1 if max_freq_log2 is None else max_freq_log2
+        self.N_freqs, self.max_freq_log2 = num_freqs, max_freq_log2
+        self.freq_bands = 2. ** torch.linspace(0., max_freq_log2, steps=num_freqs) if num_freqs > 0 else torch.zeros(0)
+        self.out_dim = 3 * (1 + 2 * num_freqs)
 
     def embed(self, x):
+        if self.max_freq_log2 == 0:             # nerfh_nff.py:264-268: "max_freq_log2 != 0 ? cat(...) : inputs" -- also for multires = 1
+            return x
         parts = [x]
         for f in self.freq_bands:
             parts += [torch.sin(x * f), torch.cos(x * f)]
@@ -276,10 +322,22 @@ class _Embedder:
 
 
 def get_embedder(multires, i=0, reduce_mode=-1, epochToMaxFreq=-1):
-    """nerfh_nff.py:303-354.  Only the paper-default encoding (reduce_mode=-1) is built into the kernels."""
+    """nerfh_nff.py:303-354.  The kernels compute the paper-default embedding; modes 0 (half the octaves) and 1 (no embedding) and
+    smaller `multires` are prefixes of it and run on the same kernels (NeRFH_NFF._supported).  Mode 2 (the Nerfies-style window) does
+    not run in the reference's own NFF path -- run_network_NeRFH_NFF calls `embed_fn(x)` without the epoch the mode-2 lambda requires
+    (nerfh_nff.py:197,211,226 vs :351) -- and is not built."""
     if i == -1:
         return nn.Identity(), 3
-    if reduce_mode not in (-1,):
-        raise NotImplementedError("nefes_amd: reduce_embedding modes 0/1/2 are not built into the HIP field kernels")
-    eo = _Embedder(multires)
+    if reduce_mode == 2:
+        raise NotImplementedError("nefes_amd: reduce_embedding=2 (DNeRF window) is not built; the reference's NeRFH_NFF path cannot "
+                                  "run it either (embed_fn is called without the epoch argument, nerfh_nff.py:197)")
+    if reduce_mode == 0:
+        eo = _Embedder(multires // 2, (multires - 1) // 2)
+    elif reduce_mode == 1:
+        eo = _Embedder(0, 0)
+    else:
+        eo = _Embedder(multires)
+    if eo.N_freqs > 0 and not torch.equal(eo.freq_bands, 2. ** torch.arange(eo.N_freqs, dtype=eo.freq_bands.dtype)):
+        raise NotImplementedError(f"nefes_amd: {eo.N_freqs} frequencies up to 2^{eo.max_freq_log2} (multires = {multires}, mode {reduce_mode}) are not the octaves 1, 2, 4, ...: "
+                                  f"not a prefix of the embedding the kernels compute")
     return (lambda x, eo=eo: eo.embed(x)), eo.out_dim, eo

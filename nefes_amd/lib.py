@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must precede dlopen of libnefes_hip.so, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NEFES_HIP_LIB", os.path.join(_HERE, "libnefes_hip.so"))   # override = debugging builds only
+LIB_PATH = os.environ.get("NEFES_HIP_LIB") or os.path.join(_HERE, "libnefes_hip.so")   # override = debugging builds only
 
 
 class NefesNetDesc(C.Structure):

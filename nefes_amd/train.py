@@ -297,6 +297,7 @@ class FieldTrain(torch.autograd.Function):
             g = weight_grads(ctx.net, ctx.pk, ctx.mode, N, S, raw_t, ops._f32(g_raw_t), acts,
                              fused=tuple(ctx.saved_tensors[2:]) if ctx.fused else None)
         names = param_names(ctx.net, ctx.mode)
+        g = ctx.net.shrink_grads(g)            # a network on fewer embedding octaves: drop the columns the kernels padded (field.py)
         g_rays = (None, None, None)
         if want_rays:
             # joint pose + weight gradients (e.g. BARF-style training): the fused dX chain wrote d pts / d viewdirs per sample anyway

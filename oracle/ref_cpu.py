@@ -71,6 +71,8 @@ def ndc_warp(H: int, W: int, focal: float, near: float, rays_o: Tensor, rays_d: 
 def freq_encode(x: Tensor, n_freqs: int) -> Tensor:
     """[x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)], each term
     over the whole 3-vector (nerfh_nff.py:247-267; log-sampled bands :253)."""
+    if n_freqs == 0:                                                    # reduce_embedding = 1: the inputs themselves (:264-268, :318-326)
+        return x
     bands = 2. ** torch.linspace(0., n_freqs - 1, steps=n_freqs)
     parts = [x]
     for f in bands:
@@ -103,13 +105,14 @@ def field_param_shapes(typ: str, Wd: int, C: int, in_xyz: int = 63, in_dir: int 
     return spec
 
 
-def make_field_params(typ: str, Wd: int = 256, C: int = 16, seed: int = 0, dtype=torch.float32, in_xyz: int = 63) -> Dict[str, Tensor]:
+def make_field_params(typ: str, Wd: int = 256, C: int = 16, seed: int = 0, dtype=torch.float32, in_xyz: int = 63,
+                      in_dir: int = 27) -> Dict[str, Tensor]:
     """Random-init parameters with the reference's key names.  Like the ctor
     (nerfh_nff.py:446) this reseeds the global generator, then draws each
     nn.Linear in construction order (default kaiming-uniform init)."""
     torch.manual_seed(seed)
     out: Dict[str, Tensor] = {}
-    for name, n_out, n_in in field_param_shapes(typ, Wd, C, in_xyz=in_xyz):
+    for name, n_out, n_in in field_param_shapes(typ, Wd, C, in_xyz=in_xyz, in_dir=in_dir):
         lin = torch.nn.Linear(n_in, n_out)
         out[name + ".weight"] = lin.weight.detach().to(dtype).clone()
         out[name + ".bias"] = lin.bias.detach().to(dtype).clone()
@@ -196,10 +199,11 @@ def query_field(p: Dict[str, Tensor], pts: Tensor, viewdirs: Optional[Tensor], t
         e = freq_encode(flat[i:i + netchunk], n_freq_xyz)
         a = None if act is None else (lambda tag, pre, i=i: act(tag, pre, i))
         if sigma_only:
-            outs.append(field_forward(p, e, sigma_only=True, act=a))
+            outs.append(field_forward(p, e, sigma_only=True, in_xyz=e.shape[1], act=a))
         else:
             ed = freq_encode(dirs[i:i + netchunk], n_freq_dir)
-            outs.append(field_forward(p, torch.cat([e, ed], 1), output_transient=output_transient, act=a))
+            outs.append(field_forward(p, torch.cat([e, ed], 1), output_transient=output_transient, in_xyz=e.shape[1], in_dir=ed.shape[1],
+                                      act=a))
     out = torch.cat(outs, 0)
     return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
 
@@ -336,6 +340,10 @@ class RenderCfg:
     NeRFW: bool = True
     use_fine_only: bool = False
     netchunk: int = 1 << 21
+    # octaves of the two embeddings (get_embedder, nerfh_nff.py:303-354): multires / multires_views by default; half of them with
+    # reduce_embedding = 0 (:307-316: num_freqs = multires // 2 up to 2^((multires - 1) // 2)), none with reduce_embedding = 1
+    n_freq_xyz: int = 10
+    n_freq_dir: int = 4
 
 
 def coarse_depths(near: Tensor, far: Tensor, n: int, lindisp: bool, t_rand: Optional[Tensor] = None) -> Tensor:
@@ -365,7 +373,8 @@ def render_rays(ray_batch: Tensor, p_coarse, p_fine, cfg: RenderCfg, t_rand: Opt
     z = coarse_depths(near, far, cfg.N_samples, cfg.lindisp, t_rand if cfg.perturb > 0. else None)
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]          # :114
     store_rgb = (cfg.N_importance == 0)
-    raw = query_field(p_coarse, pts, viewdirs, "coarse", False, cfg.test_time, cfg.netchunk, act=coarse_act)      # :122
+    raw = query_field(p_coarse, pts, viewdirs, "coarse", False, cfg.test_time, cfg.netchunk, cfg.n_freq_xyz, cfg.n_freq_dir,
+                      act=coarse_act)                                                                            # :122
     c0 = composite(raw, z, cfg.raw_noise_std, white_bkgd=cfg.white_bkgd, test_time=cfg.test_time, typ="coarse",
                    store_rgb=store_rgb)
     out = c0
@@ -380,7 +389,8 @@ def render_rays(ray_batch: Tensor, p_coarse, p_fine, cfg: RenderCfg, t_rand: Opt
         if z_fine is not None:
             z = z_fine.to(z.dtype)
         pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]       # :142
-        raw = query_field(p_fine, pts, viewdirs, "fine", cfg.NeRFW, cfg.test_time, cfg.netchunk, act=fine_act)
+        raw = query_field(p_fine, pts, viewdirs, "fine", cfg.NeRFW, cfg.test_time, cfg.netchunk, cfg.n_freq_xyz, cfg.n_freq_dir,
+                          act=fine_act)
         out = composite(raw, z, cfg.raw_noise_std, output_transient=cfg.NeRFW, beta_min=0.1, white_bkgd=cfg.white_bkgd,
                         test_time=cfg.test_time, typ="fine", transient_at_test=cfg.transient_at_test)
         if debug is not None:

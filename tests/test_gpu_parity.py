@@ -236,11 +236,11 @@ def test_sample_pdf_indices_bit_exact(golden, ops, tag, det, Ni):
 
 
 # ---- a6/a7/a8 field MLP ---------------------------------------------------------------------------------------
-def _modules(Wd, C, sigma_scale=1.0):
+def _modules(Wd, C, sigma_scale=1.0, in_xyz=63, in_dir=27):
     from nefes_amd.field import NeRFH_NFF
-    coarse = NeRFH_NFF('coarse', D=8, W=Wd, skips=[4], f_dim=C)
+    coarse = NeRFH_NFF('coarse', D=8, W=Wd, skips=[4], f_dim=C, in_channels_xyz=in_xyz, in_channels_dir=in_dir)
     fine = NeRFH_NFF('fine', D=8, W=Wd, skips=[4], encode_appearance=True, encode_transient=True,
-                     in_channels_a=50, in_channels_t=20, f_dim=C)
+                     in_channels_a=50, in_channels_t=20, f_dim=C, in_channels_xyz=in_xyz, in_channels_dir=in_dir)
     with torch.no_grad():
         for m in (coarse, fine):
             m.static_sigma[0].weight.mul_(sigma_scale)
@@ -401,12 +401,13 @@ def test_render_end_to_end_vs_reference(golden, tag):
     check_end_to_end(g, tag, int(Wd), int(C), 64, int(Ni), bool(tat), float(sscale), int(H), int(W), float(focal))
 
 
-def check_end_to_end(g, tag, Wd, C, Nc, Ni, tat, sscale, H, W, focal):
+def check_end_to_end(g, tag, Wd, C, Nc, Ni, tat, sscale, H, W, focal, in_xyz=63, in_dir=27):
     """render() through the drop-in modules against a fixture captured from the reference (keys `{tag}.rgb` ...): maps within 1e-4,
     pose gradients by the branch-pinned rule and, unpinned, against the reference's own fp32 gradient (shared by
-    tests/test_gpu_shapes.py for the round-4 fixtures)."""
+    tests/test_gpu_shapes.py for the round-4 fixtures and by tests/test_gpu_reduced.py: networks on fewer embedding octaves)."""
     R, M = _dropin()
-    coarse, fine = _modules(Wd, C, float(sscale))
+    coarse, fine = _modules(Wd, C, float(sscale), in_xyz, in_dir)
+    enc = dict(in_xyz=in_xyz, in_dir=in_dir)
     kw = dict(_kwargs(M, coarse, fine, Ni, bool(tat)), N_samples=Nc)
     c2w = T(g[f"{tag}.c2w"]).to(DEV).clone().requires_grad_()
     with B.tapped() as tap:
@@ -420,18 +421,18 @@ def check_end_to_end(g, tag, Wd, C, Nc, Ni, tat, sscale, H, W, focal):
     (g1,) = torch.autograd.grad(O.bench_loss(rgb, feat), c2w, retain_graph=True)
     (g2,) = torch.autograd.grad((rgb * T(g[f"{tag}.g_rgb"]).to(DEV)).sum() + (feat * T(g[f"{tag}.g_feat"]).to(DEV)).sum(), c2w)
     # ground truth for the pose gradient: the oracle evaluated in float64 (SURVEY.md §7 hard part 10)
-    pc, pf = O.make_field_params("coarse", Wd, C, dtype=torch.float64), O.make_field_params("fine", Wd, C, dtype=torch.float64)
+    pc, pf = O.make_field_params("coarse", Wd, C, dtype=torch.float64, **enc), O.make_field_params("fine", Wd, C, dtype=torch.float64, **enc)
     for p in (pc, pf):
         p["static_sigma.0.weight"] = p["static_sigma.0.weight"] * float(sscale)
         p["static_sigma.0.bias"] = p["static_sigma.0.bias"] * float(sscale)
     c64 = T(g[f"{tag}.c2w"]).double().requires_grad_()
-    cfg = O.RenderCfg(N_samples=Nc, N_importance=Ni, transient_at_test=bool(tat))
+    cfg = O.RenderCfg(N_samples=Nc, N_importance=Ni, transient_at_test=bool(tat), n_freq_xyz=(in_xyz - 3) // 6, n_freq_dir=(in_dir - 3) // 6)
     r64, _, _, e64 = O.render(H, W, float(focal), pc, pf, cfg, c2w=c64, near=0., far=4.)
     (t1,) = torch.autograd.grad(O.bench_loss(r64, e64["feat_map"]), c64, retain_graph=True)
     (t2,) = torch.autograd.grad((r64 * T(g[f"{tag}.g_rgb"]).double()).sum() + (e64["feat_map"] * T(g[f"{tag}.g_feat"]).double()).sum(), c64)
     # (1) the north-star statement, on the kernels' own ReLU branch pattern (tests/branch.py): 1e-4 of the float64 gradient
     def oracle_run(dt, act, zf):
-        p_c, p_f = O.make_field_params("coarse", Wd, C, dtype=dt), O.make_field_params("fine", Wd, C, dtype=dt)
+        p_c, p_f = O.make_field_params("coarse", Wd, C, dtype=dt, **enc), O.make_field_params("fine", Wd, C, dtype=dt, **enc)
         for p in (p_c, p_f):
             p["static_sigma.0.weight"] = p["static_sigma.0.weight"] * float(sscale)
             p["static_sigma.0.bias"] = p["static_sigma.0.bias"] * float(sscale)

@@ -246,3 +246,63 @@ def test_shapes_train_mode(golden, tag):
         assert np.abs(got.numpy() - g[k]).max() <= 2e-5 * max(np.abs(g[k]).max(), 1e-12), k
         n += 1
     assert n >= 19
+
+
+# ---- embeddings with fewer octaves (tools/make_golden_reduced.py -> reduced.npz): --reduce_embedding 0 / 1 and smaller --multires
+# ---- (nerfh_nff.py:303-354); the networks are sized by the embedder's out_dim (:633-659) ------------------------------------------
+def _reduced_cfg(g, t):
+    Wd, C, mr, mrv, mode, Nc, Ni, H, W, focal, in_xyz, in_dir = g[f"{t}.cfg"]
+    n_xyz, n_dir = (int(in_xyz) - 3) // 6, (int(in_dir) - 3) // 6
+    # the reference's rule for the octave counts (get_embedder): mode 0 halves, mode 1 drops them, otherwise multires itself
+    assert n_xyz == {0: int(mr) // 2, 1: 0}.get(int(mode), int(mr)) and n_dir == {0: int(mrv) // 2, 1: 0}.get(int(mode), int(mrv))
+    return int(Wd), int(C), int(Nc), int(Ni), int(H), int(W), float(focal), int(in_xyz), int(in_dir), n_xyz, n_dir
+
+
+@pytest.mark.parametrize("tag", ["mode0", "mode1", "m6v2", "mode0_w256"])
+def test_reduced_embedding_end_to_end(golden, tag):
+    g = golden("reduced")
+    t = f"e2e.{tag}"
+    Wd, C, Nc, Ni, H, W, focal, in_xyz, in_dir, n_xyz, n_dir = _reduced_cfg(g, t)
+    pc, pf = O.make_field_params("coarse", Wd, C, in_xyz=in_xyz, in_dir=in_dir), O.make_field_params("fine", Wd, C, in_xyz=in_xyz, in_dir=in_dir)
+    for typ, p in (("coarse", pc), ("fine", pf)):
+        for k, v in p.items():
+            got = np.array([v.double().sum().item(), v.double().abs().sum().item(), float(v.flatten()[0])])
+            np.testing.assert_allclose(got, g[f"{t}.{typ}.{k}"], rtol=0, atol=0, err_msg=f"{typ}.{k}")
+    cfg = O.RenderCfg(N_samples=Nc, N_importance=Ni, n_freq_xyz=n_xyz, n_freq_dir=n_dir)
+    c2w = T(g[f"{t}.c2w"]).clone().requires_grad_()
+    rgb, disp, acc, ex = O.render(H, W, focal, pc, pf, cfg, c2w=c2w, near=0., far=4., hist=torch.full((1, 10), 10.))
+    feat = ex["feat_map"]
+    close(rgb, g[f"{t}.rgb"], rtol=1e-5, atol=1e-6)
+    close(feat, g[f"{t}.feat"], rtol=1e-5, atol=1e-6)
+    close(disp, g[f"{t}.disp"], rtol=1e-5)
+    close(acc, g[f"{t}.acc"], rtol=1e-5)
+    (g1,) = torch.autograd.grad(O.bench_loss(rgb, feat), c2w, retain_graph=True)
+    (g2,) = torch.autograd.grad((rgb * T(g[f"{t}.g_rgb"])).sum() + (feat * T(g[f"{t}.g_feat"])).sum(), c2w)
+    assert np.abs(g1.numpy() - g[f"{t}.g_c2w_loss"]).max() <= 2e-5 * np.abs(g[f"{t}.g_c2w_loss"]).max()
+    assert np.abs(g2.numpy() - g[f"{t}.g_c2w_lin"]).max() <= 2e-5 * np.abs(g[f"{t}.g_c2w_lin"]).max()
+
+
+def test_reduced_embedding_train_mode(golden):
+    g = golden("reduced")
+    t = "train.mode0"
+    Wd, C, Nc, Ni, H, W, focal, in_xyz, in_dir = g[f"{t}.cfg"]
+    Wd, C, Nc, Ni, H, W, in_xyz, in_dir = (int(v) for v in (Wd, C, Nc, Ni, H, W, in_xyz, in_dir))
+    pc = {k: v.requires_grad_() for k, v in O.make_field_params("coarse", Wd, C, in_xyz=in_xyz, in_dir=in_dir).items()}
+    pf = {k: v.requires_grad_() for k, v in O.make_field_params("fine", Wd, C, in_xyz=in_xyz, in_dir=in_dir).items()}
+    cfg = O.RenderCfg(N_samples=Nc, N_importance=Ni, perturb=0., test_time=False, n_freq_xyz=(in_xyz - 3) // 6, n_freq_dir=(in_dir - 3) // 6)
+    rays_o, rays_d = O.ray_bundle(H, W, float(focal), T(g[f"{t}.c2w"])[:3, :4])
+    rgb, disp, acc, ex = O.render(H, W, float(focal), pc, pf, cfg, rays=(rays_o, rays_d), near=0., far=4., hist=torch.full((1, 10), 10.))
+    close(rgb, g[f"{t}.rgb"], rtol=1e-5, atol=1e-6)
+    close(ex["feat_map"], g[f"{t}.feat"], rtol=1e-5, atol=1e-6)
+    t_rgb, t_feat = T(g[f"{t}.t_rgb"]), T(g[f"{t}.t_feat"])
+    loss = ((rgb - t_rgb) ** 2).mean() + ((ex["feat_map"] - t_feat) ** 2).mean() + ((ex["rgb0"] - t_rgb) ** 2).mean()
+    assert abs(float(loss.detach()) - float(g[f"{t}.loss"])) < 1e-6 * float(g[f"{t}.loss"])
+    loss.backward()
+    n = 0
+    for k in [k for k in g if k.startswith(f"{t}.grad.")]:
+        _, _, _, net, name = k.split(".", 4)
+        got = (pc if net == "coarse" else pf)[name].grad
+        assert got is not None and tuple(got.shape) == g[k].shape, k
+        assert np.abs(got.numpy() - g[k]).max() <= 2e-5 * max(np.abs(g[k]).max(), 1e-12), k
+        n += 1
+    assert n >= 19

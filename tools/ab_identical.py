@@ -1,6 +1,6 @@
 """Digest of the fp16 two-part field kernels' outputs on fixed inputs, for A/B builds that must not change a bit.
     NEFES_HIP_LIB=<lib> python tools/ab_identical.py [Wd C]
-prints one sha256 per output of the forward kernels (sigma-only raw; full and static raw + ReLU masks).  Run it once per
+prints one sha256 per output of the forward kernels (sigma-only raw; full raw + ReLU masks).  Run it once per
 library (tools/ab_h3.sh builds side libraries) and compare the lines: a re-scheduling of the same arithmetic gives the same digests."""
 import hashlib, os, sys
 import torch
@@ -27,9 +27,9 @@ def dig(t):
     return hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()[:16]
 
 
-print("lib", os.environ.get("NEFES_HIP_LIB", "shipped"))
+print("lib", os.environ.get("NEFES_HIP_LIB") or "shipped")
 raw, _ = ops.field_fwd_x6(pk, L.FIELD_SIGMA, N, S, rays_o=o, rays_d=d, z=z, viewdirs=d, want_masks=False)
 print("sigma raw  ", dig(raw))
-for mode, name in ((L.FIELD_FULL, "full"), (L.FIELD_STATIC, "static")):
+for mode, name in ((L.FIELD_FULL, "full"),):
     raw, m = ops.field_fwd_x6(pk, mode, N, S, rays_o=o, rays_d=d, z=z, viewdirs=d, want_masks=True)
     print(f"{name} raw   ", dig(raw), " masks", dig(m), " finite", bool(torch.isfinite(raw).all()))
