@@ -179,14 +179,29 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
             asm volatile("" : "+s"(S_t), "+s"(c3));
             const float* g0 = a.g_raw_t + chan0;
             const float* g4 = g0 + (size_t)(4 * h) * S_t;
+            // Per GROUP of sixteen elements (32 channels), not per element: a test per element put every load into its own basic block
+            // with a select right behind it, i.e. 8 KR16 memory round trips one after the other at the top of every tile (72 at
+            // KR16 = 9: seen in the disassembly as load / s_waitcnt vmcnt(0) / v_cndmask triplets).  A group whose 32 channels all
+            // exist -- every group but the network's last -- is sixteen plain loads in flight together; the last, partial group reads
+            // rows past the last channel as the last row (valid memory) and zeroes them once all its loads are out.
+            const int h4 = 4 * h;
 #pragma unroll
-            for (int e = 0; e < 8 * KR16; ++e) {
-                const int ch0 = 32 * (e >> 4) + nefes_rho(0, e & 15);          // lane half 1: + 4
-                if (ch0 >= c3) dr[e] = 0.f;
-                else if (ch0 + 4 < c3) dr[e] = ld_stream(g4 + (size_t)ch0 * S_t);
-                else {                                                         // row ch0 + 4 lies past the last channel
-                    const float lo = ld_stream(g0 + (size_t)ch0 * S_t);
-                    dr[e] = h == 0 ? lo : 0.f;
+            for (int grp = 0; grp < (8 * KR16 + 15) / 16; ++grp) {
+                const int e0 = 16 * grp, e1 = e0 + 16 < 8 * KR16 ? e0 + 16 : 8 * KR16;
+                if (32 * grp + 32 <= c3) {
+#pragma unroll
+                    for (int e = e0; e < e1; ++e) dr[e] = ld_stream(g4 + (size_t)(32 * grp + nefes_rho(0, e & 15)) * S_t);
+                } else if (32 * grp < c3) {
+#pragma unroll
+                    for (int e = e0; e < e1; ++e) {
+                        const int row = 32 * grp + nefes_rho(0, e & 15) + h4;
+                        dr[e] = ld_stream(g0 + (size_t)(row < c3 ? row : c3 - 1) * S_t);
+                    }
+#pragma unroll
+                    for (int e = e0; e < e1; ++e) dr[e] = (32 * grp + nefes_rho(0, e & 15) + h4 < c3) ? dr[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = e0; e < e1; ++e) dr[e] = 0.f;
                 }
             }
         }

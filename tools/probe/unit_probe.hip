@@ -6,7 +6,8 @@
 // through registers (global_load_dwordx4 -> ds_write_b128, one piece per odd unit), both A groups read with ds_read_b128 two units
 // ahead, lgkmcnt(0) + s_barrier per slab, 128 accumulator registers in AGPRs.  VALU > 0 adds that many independent v_fma_f32 per
 // unit, spread over the gaps (the kernels carry about 12: operand split, ReLU, masks, exponents).  Operands are random fp16.
-// REFILL: 3 = as the kernels, 1 = the global loads only, 2 = the ds_writes only (stale registers), 0 = neither (slot 0 re-read).
+// REFILL: 3 = as the kernels, 1 = the global loads only, 2 = the ds_writes only (stale registers), 0 = neither (slot 0 re-read);
+// +4 = no s_barrier per slab, +8 = only the hi group of a unit is read from LDS (half the A-operand traffic).
 // The MI355X runs this against its power limit, not its clock limit: the figure of merit is ns per unit.
 //   hipcc --offload-arch=gfx950 -O2 tools/probe/unit_probe.hip -o tools/probe/unit_probe && tools/probe/unit_probe
 #include <hip/hip_runtime.h>
@@ -103,15 +104,15 @@ __global__ __launch_bounds__(256, 1) void walk(const char* stream, const f32x4* 
             }
             __builtin_amdgcn_sched_barrier(0);
             if ((uu & 1) && (REFILL & 1)) stage[q] = *(const f32x4*)(stream + (size_t)g_next * SLAB + my_off + q * 1024);
-            if (uu + 2 < UNITS) l2 = *(const f32x4*)(p + (2 * uu + 5) * 1024);
+            if (uu + 2 < UNITS && !(REFILL & 8)) l2 = *(const f32x4*)(p + (2 * uu + 5) * 1024);
             Fma<G3>::run(v, kf);
             asm volatile("" ::"v"(h0), "v"(Bh0), "v"(Bh1));
             __builtin_amdgcn_sched_barrier(0);
         }
         g_next = g_next + 1 == (uint32_t)n_slabs ? 0 : g_next + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (REFILL == 3) c_slot ^= 1u;
+        if (!(REFILL & 4)) __builtin_amdgcn_s_barrier();
+        if ((REFILL & 3) == 3) c_slot ^= 1u;
     }
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]));
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(a16[30]), "+a"(a16[31]), "+a"(a16[28]), "+a"(a16[29]));
@@ -148,7 +149,8 @@ static double run(const char* stream, const f32x4* bsrc, int n_slabs, int rounds
     for (int i = 0; i < cus; ++i) mean += (double)h[i];
     mean /= cus;
     const double n_units = (double)rounds * UNITS;
-    static const char* rf[4] = {"no refill         ", "loads only        ", "ds_writes only    ", "refill            "};
+    static const char* rf[16] = {"no refill         ", "loads only        ", "ds_writes only    ", "refill            ",
+                                 "no refill, no barrier", "", "", "refill, no barrier (racy)", "no refill, half the A reads", "", "", "", "no refill/barrier, half A", "", "", ""};
     printf("%dx%d, %2d VALU per unit, %s(%2d slabs) %7.1f ms  %6.1f cycles/unit  clock %.2f GHz  %6.2f ns/unit  %7.1f TFLOP/s fp16  (%s)\n", SHAPE, SHAPE, VALU, rf[REFILL], n_slabs, ms,
            mean / n_units, mean / ms / 1e6, ms * 1e6 / n_units, n_units * 3 * 32768 * 4 * cus / (ms * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
     free(h); (void)hipFree(cyc); (void)hipFree(sink);
@@ -179,6 +181,11 @@ int main() {
         run<32, 12, 1>(stream, bsrc, n_slabs, rounds);
         run<32, 12, 2>(stream, bsrc, n_slabs, rounds);
         run<32, 12, 3>(stream, bsrc, 1, rounds);
+        // the other parts of the skeleton: the barrier per slab, and the A-operand reads (bit 3: the lo group is not re-read)
+        run<32, 12, 4>(stream, bsrc, n_slabs, rounds);
+        run<32, 12, 8>(stream, bsrc, n_slabs, rounds);
+        run<32, 12, 12>(stream, bsrc, n_slabs, rounds);
+        run<32, 0, 12>(stream, bsrc, n_slabs, rounds);
     }
     return 0;
 }
