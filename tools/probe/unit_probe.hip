@@ -1,6 +1,7 @@
 // One 2 KiB weight unit (A_hi | A_lo) against 32 samples, in the two MFMA shapes gfx950 offers for fp16:
 //     SHAPE 32: three v_mfma_f32_32x32x16_f16 (A = 32 rows x 16 k, B = 16 k x 32 samples)            -- the field kernels' unit
 //     SHAPE 16: six   v_mfma_f32_16x16x32_f16 (A = 16 rows x 32 k, B = 32 k x 16 samples, two sample blocks per A fragment)
+//     SHAPE 64: six   v_mfma_f32_32x32x16_f16 against TWO 32-sample blocks (twice the work per weight unit: a Wd = 128 kernel at 64 samples per wave)
 // Both do 3 x 16 384 multiply-adds per unit on 1 KiB + 1 KiB of weights read from LDS; everything around the MFMAs is the field
 // kernels' (tools/probe/ring_probe.hip): one workgroup of four waves per CU, 32 KiB slabs of sixteen units, two LDS slots refilled
 // through registers (global_load_dwordx4 -> ds_write_b128, one piece per odd unit), both A groups read with ds_read_b128 two units
@@ -53,6 +54,11 @@ __global__ __launch_bounds__(256, 1) void walk(const char* stream, const f32x4* 
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x16 acc2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
     f32x4 a16[32];
 #pragma unroll
     for (int t = 0; t < 32; ++t) a16[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -76,6 +82,9 @@ __global__ __launch_bounds__(256, 1) void walk(const char* stream, const f32x4* 
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (SHAPE == 32) {
                 asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[uu % 8]) : "v"(l0), "v"(Bh0));
+            } else if constexpr (SHAPE == 64) {
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[uu % 8]) : "v"(l0), "v"(Bh0));
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc2[uu % 8]) : "v"(l0), "v"(Bh1));
             } else {
                 asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(a16[2 * uu]) : "v"(l0), "v"(Bh0));
                 asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(a16[2 * uu + 1]) : "v"(l0), "v"(Bh1));
@@ -87,6 +96,9 @@ __global__ __launch_bounds__(256, 1) void walk(const char* stream, const f32x4* 
             asm volatile("" ::"v"(l0), "v"(Bh0), "v"(Bh1));
             if constexpr (SHAPE == 32) {
                 asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[uu % 8]) : "v"(h0), "v"(Bl0));
+            } else if constexpr (SHAPE == 64) {
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[uu % 8]) : "v"(h0), "v"(Bl0));
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc2[uu % 8]) : "v"(h0), "v"(Bl1));
             } else {
                 asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(a16[2 * uu]) : "v"(h0), "v"(Bl0));
                 asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(a16[2 * uu + 1]) : "v"(h0), "v"(Bl1));
@@ -98,6 +110,9 @@ __global__ __launch_bounds__(256, 1) void walk(const char* stream, const f32x4* 
             asm volatile("" ::"v"(Bl0), "v"(Bl1));
             if constexpr (SHAPE == 32) {
                 asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[uu % 8]) : "v"(h0), "v"(Bh0));
+            } else if constexpr (SHAPE == 64) {
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[uu % 8]) : "v"(h0), "v"(Bh0));
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc2[uu % 8]) : "v"(h0), "v"(Bh1));
             } else {
                 asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(a16[2 * uu]) : "v"(h0), "v"(Bh0));
                 asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(a16[2 * uu + 1]) : "v"(h0), "v"(Bh1));
@@ -116,11 +131,12 @@ __global__ __launch_bounds__(256, 1) void walk(const char* stream, const f32x4* 
     }
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]));
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(a16[30]), "+a"(a16[31]), "+a"(a16[28]), "+a"(a16[29]));
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(acc2[0]), "+a"(acc2[1]), "+a"(acc2[2]), "+a"(acc2[3]), "+a"(acc2[4]), "+a"(acc2[5]), "+a"(acc2[6]), "+a"(acc2[7]));
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
     float s = stage[0][0];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) s += acc[t][0] + v[t];
+    for (int t = 0; t < 8; ++t) s += acc[t][0] + v[t] + acc2[t][0];
 #pragma unroll
     for (int t = 0; t < 32; ++t) s += a16[t][0];
     sink[blockIdx.x * 256 + threadIdx.x] = s;
@@ -152,7 +168,7 @@ static double run(const char* stream, const f32x4* bsrc, int n_slabs, int rounds
     static const char* rf[16] = {"no refill         ", "loads only        ", "ds_writes only    ", "refill            ",
                                  "no refill, no barrier", "", "", "refill, no barrier (racy)", "no refill, half the A reads", "", "", "", "no refill/barrier, half A", "", "", ""};
     printf("%dx%d, %2d VALU per unit, %s(%2d slabs) %7.1f ms  %6.1f cycles/unit  clock %.2f GHz  %6.2f ns/unit  %7.1f TFLOP/s fp16  (%s)\n", SHAPE, SHAPE, VALU, rf[REFILL], n_slabs, ms,
-           mean / n_units, mean / ms / 1e6, ms * 1e6 / n_units, n_units * 3 * 32768 * 4 * cus / (ms * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
+           mean / n_units, mean / ms / 1e6, ms * 1e6 / n_units, n_units * (SHAPE == 64 ? 6 : 3) * 32768 * 4 * cus / (ms * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
     free(h); (void)hipFree(cyc); (void)hipFree(sink);
     return ms;
 }
@@ -186,6 +202,10 @@ int main() {
         run<32, 12, 8>(stream, bsrc, n_slabs, rounds);
         run<32, 12, 12>(stream, bsrc, n_slabs, rounds);
         run<32, 0, 12>(stream, bsrc, n_slabs, rounds);
+        // "64": the 32x32x16 unit against TWO 32-sample blocks per wave (six MFMAs per A pair: what a Wd = 128 kernel with 64 samples per
+        // wave would run; its side work per unit doubles with the samples).  Compare per MFMA with the 18-VALU line above.
+        run<64, 24>(stream, bsrc, n_slabs, rounds);
+        run<64, 36>(stream, bsrc, n_slabs, rounds);
     }
     return 0;
 }
