@@ -74,6 +74,17 @@ def test_single_ray_and_ragged_tiles():
         B.pinned_gradients(f"ragged[{H}x{W}]", {"d c2w": c2w.grad}, tap, 128, oracle_run)
 
 
+def test_an_empty_ray_batch_fails_loudly_as_in_the_reference():
+    """rendering.py:186-195: batchify_rays over zero rays builds an empty dict and `torch.cat` / the key lookups that follow raise;
+    here the C ABI refuses N <= 0 (NEFES_E_BADARG) before any launch -- an error either way, never a launch with an empty grid."""
+    from nefes_amd.render import render
+    coarse, fine = nets(128, 16)
+    kw = kwargs(coarse, fine)
+    e = torch.zeros(0, 3, device=DEV)
+    with pytest.raises((RuntimeError, ValueError, IndexError)):
+        render(4, 6, 5.0, rays=(e, e), near=0., far=4., **kw)
+
+
 def test_unsupported_sizes_fail_loudly():
     from nefes_amd import ops, lib as L
     with pytest.raises(RuntimeError, match="unsupported"):
