@@ -174,6 +174,7 @@ def coarse_depths(N, Nc, near, far, lindisp=False, t_rand=None, device="cuda", b
 
 
 _ZROW = {}
+_ZROW_MAX = 64
 
 
 def coarse_depth_row(Nc, near, far, lindisp=False, device="cuda"):
@@ -182,16 +183,25 @@ def coarse_depth_row(Nc, near, far, lindisp=False, device="cuda"):
     same kernel as coarse_depths, so the expanded tensor never exists (field_sigma_row, coarse_sample)."""
     key = (int(Nc), float(near), float(far), bool(lindisp), str(device))
     z = _ZROW.get(key)
-    if z is None:
-        z = _ZROW[key] = coarse_depths(1, Nc, near, far, lindisp, None, device=device).reshape(-1)
+    if z is not None:
+        _ZROW[key] = _ZROW.pop(key)                # most recently used last
+        return z
+    z = coarse_depths(1, Nc, near, far, lindisp, None, device=device).reshape(-1)
+    # A row first computed while a HIP graph is being captured lives in the graph's private pool and is filled on replay only:
+    # it must not be handed to later eager renders, so it is not cached (ADVICE r4).  Per-image near / far values would grow the
+    # cache without limit: the least recently used rows go.
+    if not torch.cuda.is_current_stream_capturing():
+        _ZROW[key] = z
+        while len(_ZROW) > _ZROW_MAX:
+            _ZROW.pop(next(iter(_ZROW)))
     return z
 
 
-def fused_coarse_pass_ok(pk, Nc, Ni):
+def fused_coarse_pass_ok(pk, Nc, Ni, N=0):
     """The coarse pass as two launches (sigma-only field kernel on a shared depth row + coarse_sample) instead of four: fp16 two-part
     instances, frequency embedding, Nc = 64 / 128 / 256, Nc + Ni <= 512 (csrc/sample_pdf.hip coarse_sample_kernel)."""
     return (FUSED_COARSE and _h3(pk) and h3_shape(pk) and pk.xyz_encoding == L.XYZ_FREQ10 and Nc in (64, 128, 256)
-            and Ni > 0 and Nc + Ni <= 512)
+            and Ni > 0 and Nc + Ni <= 512 and N * Nc < (1 << 31) - 256)      # (beyond the 32-bit sample index: the four-launch path)
 
 
 def field_sigma_row(pk, rays_o, rays_d, z_row):

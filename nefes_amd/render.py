@@ -47,7 +47,9 @@ def rays_per_launch(cfg, network_fn, network_fine, device, train=False):
     R = 3 + C + 6
     per_sample = 2 * R * 4 + (8 * (Wd // 64) + 4 * (Wd // 128)) * 4 * 2 + 24 + 16
     if train:
-        per_sample += 4 * (64 + 32 + 9 * Wd + 2 * Wd + 32 * ((3 + C + 31) // 32) + 64) * 2
+        # rows per sample of `acts` and `dacts` (csrc/layout.h nefes_train_row(..., NEFES_TB_END)): the head block is sized by the
+        # head CLASS (nefes_head_ntr: one tile for 3 + C <= 32, five otherwise), not by C
+        per_sample += 4 * (64 + 32 + 9 * Wd + 2 * Wd + 32 * (1 if 3 + C <= 32 else 5) + 64) * 2
     per_ray = per_sample * S + (cfg.N_samples * 4) * 4 + 256
     _PER_RAY[key] = per_ray
     try:
@@ -129,7 +131,7 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
     C = pk_c.feat_dim
     store_rgb = (Ni == 0)
     if (cfg.test_time and cfg.perturb == 0. and cfg.raw_noise_std == 0. and bounds is None and cfg.xyz_encoder is None
-            and not cfg.use_fine_only and ops.fused_coarse_pass_ok(pk_c, Nc, Ni)):
+            and not cfg.use_fine_only and ops.fused_coarse_pass_ok(pk_c, Nc, Ni, N)):
         # The coarse pass at test time (:96-141, nerfh_nff.py:192-202) as TWO launches: every ray shares one row of depths, which is
         # computed once per (near, far, Nc) and never expanded; the sigma-only field kernel reads it; compositing variant D,
         # sample_pdf and the sort run per ray in one kernel, the coarse weights stay in registers.

@@ -179,6 +179,11 @@ def weight_grads(net, pk, mode, N, S, raw_t, g_raw_t, acts, fused=None):
                     raw_t.data_ptr(), g_raw_t.data_ptr(), masks.data_ptr(), dacts.data_ptr(), g_pts.data_ptr(), g_vs.data_ptr(),
                     ops._stream()), "nefes_field_bwd_train")
     else:
+        if net._embedding_columns():
+            # the layer-by-layer chain slices the network's OWN weights at the paper-default embedding widths (63 / 27); a network on
+            # fewer octaves has narrower layer-5 / dir_encoding inputs and would hand P.dx the wrong block
+            raise NotImplementedError("nefes_amd: networks on a reduced embedding (--reduce_embedding / smaller --multires) train on the "
+                                      "fused dX chain only (train.FUSED_DX = True, frequency embedding)")
         if full:
             w_th = torch.cat([w("transient_rgb.0"), w("transient_sigma.0"), w("transient_beta.0")], 0)     # raw channel order
             keep.append(P.dx(L.TB_TH, 5, w_th, H2, L.TB_T2, False, True))

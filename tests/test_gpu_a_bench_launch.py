@@ -15,6 +15,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--steps", "1", "--warmup", "1", "--height", "48", "--width", "64", "--cpu-rows", "0"]
+# BASELINE configs[2] functionally: the frame's 480 rows over 8 ranks = 60 rows per rank, exactly the 8-GPU partition (the width is
+# shrunk instead of the row count, so that eight ranks sharing one GPU stay a functional check)
+ROWS480 = ["--steps", "1", "--warmup", "1", "--height", "480", "--width", "8", "--cpu-rows", "0"]
 
 
 def bench(extra, env_extra, timeout=900):
@@ -26,19 +29,21 @@ def bench(extra, env_extra, timeout=900):
     return r, (json.loads(lines[-1]) if lines else None)
 
 
-@pytest.mark.parametrize("ranks", [2, 4])
-def test_ranks_through_the_self_launcher_match_one_rank(ranks):
+@pytest.mark.parametrize("ranks,size", [(2, SMALL), (4, SMALL), (8, ROWS480)])
+def test_ranks_through_the_self_launcher_match_one_rank(ranks, size):
     """--gpus N as a fresh child: torch.distributed.run starts N ranks, each renders its share of the rows, the 48-byte pose
     gradient is all-reduced; the JSON line says so and ALL TWELVE numbers of the reduced gradient equal the single-rank run's
     (fp32 sums in a different order: 1e-6 of the gradient's largest entry)."""
     one_gpu = {"NEFES_BENCH_ONE_GPU": "1", "NEFES_BENCH_BACKEND": "gloo"}
+    SMALL = size
+    n_rays = int(size[5]) * int(size[7])
     r1, j1 = bench(["--gpus", "1"] + SMALL, {})
     assert r1.returncode == 0 and j1 is not None, r1.stderr[-2000:]
     rn, jn = bench(["--gpus", str(ranks)] + SMALL, one_gpu)
     assert rn.returncode == 0 and jn is not None, rn.stderr[-2000:]
     assert j1["n_gpus"] == 1 and j1["world_size"] == 1 and j1["collective_backend"] is None
     assert jn["n_gpus"] == ranks and jn["world_size"] == ranks and jn["collective_backend"] == "gloo"
-    assert jn["config"]["parallelism"] == f"rows/{ranks}" and jn["config"]["rays_per_step"] == 48 * 64
+    assert jn["config"]["parallelism"] == f"rows/{ranks}" and jn["config"]["rays_per_step"] == n_rays
     assert jn["steps"] == 1 and jn["warmup"] == 1 and jn["value"] > 0 and jn["scaling"] == "strong"
     g1, gn = j1["pose_grad"], jn["pose_grad"]
     assert len(g1) == 12 and len(gn) == 12
@@ -49,6 +54,22 @@ def test_ranks_through_the_self_launcher_match_one_rank(ranks):
     by_rank = jn["ms_per_step_by_rank"]
     assert len(by_rank["all"]) == ranks and 0 < by_rank["min"] <= by_rank["max"]
     assert abs(by_rank["max"] - jn["ms_per_step"]) <= 1e-6 * jn["ms_per_step"]      # the line's time is the slowest rank's
+
+
+def test_rccl_process_group_with_device_id_on_this_gpu():
+    """The `nccl` (= RCCL) backend initialised the way bench.py initialises it on a multi-GPU node -- `device_id=` bound at
+    init_process_group -- as a one-rank group on this box's GPU: init, an all-reduce, a barrier, and the 48-byte pose-gradient all-reduce
+    in the backward of nefes_amd.dist.replicate_pose (tools/nccl_one_rank.py, run as a fresh child so that the collective library is
+    loaded by a process that does nothing else).  What it cannot show: more than one rank over xGMI (no multi-GPU node in the pool)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_one_rank.py")], capture_output=True, text=True, cwd=ROOT, env=env,
+                       timeout=600, close_fds=True)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("nccl 1-rank ok")]
+    assert line, r.stdout[-1000:]
+    _, _, _, ones, gsum = line[-1].split()
+    assert float(ones) == 4.0                                  # all_reduce(SUM) of ones over one rank
+    assert abs(float(gsum) - 2.0 * sum(range(12))) < 1e-4      # d/dc sum(c^2) = 2c through replicate_pose's all-reducing backward
 
 
 def test_launcher_started_ranks_must_match_gpus():

@@ -188,6 +188,20 @@ def test_mode2_iterations_match_reference_along_its_trajectory(golden, k):
             B.pinned_gradients(f"refine50_mode2_iteration[{k},{i}]", {"d loss / d (12 regressed numbers)": torch.from_numpy(grad)}, tap, Wd,
                                lambda dt, act, zf: {"d loss / d (12 regressed numbers)": oracle(dt, act, zf)[1]}, scale=g0, suffix=LOOP_SUFFIX)
             conv_audit(f"refine50_mode2_iteration[{k},{i}]", aud)
+            # The same with the oracle evaluated AT THE TWELVE NUMBERS THE KERNELS' POSE CAME FROM (the regression network's fp32 output on
+            # the device) instead of at its own float64 W desc + b: the comparison above mixes the path's arithmetic with a ~1e-7
+            # difference of the evaluation point, which svd_reg's backward amplifies (test_mode2_gradient_excess_has_an_owner) -- here
+            # the path's share alone, held to 3 x the fp32 oracle's own distance from float64 (+ 2e-6)
+            raw_hip = ref.apr.raw.detach()[0].cpu()
+
+            def oracle_at(dt, act, zf):
+                r = raw_hip.to(dt).clone().requires_grad_()
+                l = probs[dt].loss_at_pose(RC.svd_reg(r.reshape(3, 4)), fine_act=act, z_fine=zf, conv_pos=conv_pos)
+                return {"d loss / d (12 regressed numbers)": torch.autograd.grad(l, r)[0]}
+            out = B.pinned_gradients(f"refine50_mode2_iteration[{k},{i}]", {"d loss / d (12 regressed numbers)": torch.from_numpy(grad)}, tap, Wd, oracle_at,
+                                     scale=g0, suffix=" [branch-pinned, oracle at the kernels' own twelve numbers, in units of |g| at iteration 0]")
+            e_hip_tf, e_ref_tf, _ = out["d loss / d (12 regressed numbers)"]
+            assert e_hip_tf <= 3 * e_ref_tf + 2e-6, (k, i, e_hip_tf, e_ref_tf)
             ps, ss = ref._verification()
             assert abs(ps - g["m2_psnr"][k, i]) < 2e-3 and abs(ss - g["m2_ssim"][k, i]) < 2e-5, (ps, ss)
     P.record(f"refine50_mode2_iteration[{k},all]", "worst over 50 iterations vs the reference's fp32: gradient in units of |g| at iteration 0; "
@@ -196,7 +210,9 @@ def test_mode2_iterations_match_reference_along_its_trajectory(golden, k):
 
 
 STAGES = ["default", "field_fp32_mfma", "torch_convs", "separate_upsample_and_loss", "torch_glue", "svd_on_host", "svd_float64", "torch_upsample_and_loss",
-          "torch_upsample_and_loss_float64", "fusion_net_float64", "render_maps_to_float64_tail"]
+          "torch_upsample_and_loss_float64", "fusion_net_float64", "render_maps_to_float64_tail",
+          # pairs (VERDICT r4 "weak" 1: single-stage swaps cannot see an error two stages share)
+          "svd_float64+field_fp32_mfma", "svd_float64+render_maps_to_float64_tail"]
 
 
 @pytest.mark.parametrize("variant", STAGES)
@@ -212,6 +228,15 @@ def test_loop_gradient_error_by_stage(golden, variant, monkeypatch):
     from nefes_amd.refine import PoseRefiner
     g = golden("refine50")
     k, i = 0, 49
+    pair = variant
+    if "+" in variant:                       # a pair: svd_reg in float64 on the device AND the second stage's swap
+        variant = variant.split("+")[1]
+        import nefes_amd.refine as NRF0
+
+        def svd_reg_f64(pose):
+            u, _, v = torch.svd(pose[..., :3, :3].double())
+            return torch.cat([(u @ v.transpose(-2, -1)).to(pose.dtype), pose[..., :3, 3:]], -1)
+        monkeypatch.setattr(NRF0, "svd_reg", svd_reg_f64)
     if variant == "field_fp32_mfma":
         monkeypatch.setattr(ops, "SPLIT", "f32")
     if variant == "torch_convs":
@@ -297,8 +322,112 @@ def test_loop_gradient_error_by_stage(golden, variant, monkeypatch):
 
     g0 = float(np.abs(g["m2_grad"][k, 0]).max())
     Wd = int(g["Wd"])
-    B.pinned_gradients(f"refine50_stage[{variant}]", {"d loss / d (12 regressed numbers)": torch.from_numpy(grad)}, tap, Wd, oracle, scale=g0,
+    B.pinned_gradients(f"refine50_stage[{pair}]", {"d loss / d (12 regressed numbers)": torch.from_numpy(grad)}, tap, Wd, oracle, scale=g0,
                        suffix=LOOP_SUFFIX)
+
+
+@pytest.mark.parametrize("k,i", [(0, 0), (0, 49), (1, 0)])
+def test_mode2_gradient_excess_has_an_owner(golden, k, i, monkeypatch):
+    """VERDICT r4 "weak" 1: `refine50_mode2_iteration[0,0]` sits 3.4e-5 from float64 (in units of |g| at iteration 0) where the fp32
+    oracle on identical ReLU branches sits at 1.3e-6, and no single-stage swap moved it (test_loop_gradient_error_by_stage).  That
+    comparison evaluates the float64 oracle at ITS OWN pose -- svd_reg of W desc + b computed in float64 -- while the kernels render the
+    pose the regression network produced in fp32 on the device (adaptive_avg_pool2d over 4 800 pixels per bin, a 12 x 12 GEMV,
+    torch.svd): two evaluation points ~1e-7 apart, and the gradient to the twelve regressed numbers (pushed through svd_reg's backward,
+    which divides by differences of nearly equal singular values) moves by far more than 1e-7 between them.  The decomposition, all
+    branch-pinned, in first-iteration units:
+
+      (i)   TEACHER-FORCED POSE: d loss / d (pose after svd_reg), kernels vs the float64 oracle evaluated at the kernels' own fp32 pose
+            -- the render chain, colour transform, FusionNet, up-sampling, loss and every backward behind them;
+      (ii)  the oracle's float64 d loss / d pose pushed through the DEVICE's fp32 svd_reg backward vs through float64 autograd at the same
+            twelve numbers -- svd_reg's backward on the device alone;
+      (iii) TEACHER-FORCED RAW OUTPUT: d loss / d (12 regressed numbers) against the float64 oracle evaluated at the kernels' own fp32
+            twelve numbers -- (i) and (ii) together, the statement the north star makes about this path;
+      (iv)  the float64 oracle's gradient at the kernels' twelve numbers vs at its own: what the evaluation point alone is worth.
+
+    (iii) must hold the shared rule e_hip <= max(1e-4, 1.5 e_ref) AND sit within 3 x e_ref + 2e-6; (iii) + (iv) must account for the
+    old record.  The regression network is the caller's (a CNN outside the path): its forward rounding is not the path's."""
+    import nefes_amd.refine as NRF
+    g = golden("refine50")
+    apr = TinyAPR(g["m2_weight"][k], g["m2_bias"][k])
+    ref = refiner(g, apr=apr)
+    photo, tgt = photo_of(g), target_full(g)
+    ref.refine_apr(photo, tgt, T(g["hist"]), iters=0, verification=False)
+    Wn = g["m2_weight"][k] if i == 0 else g["m2_w_traj"][k, i - 1]
+    bn = g["m2_bias"][k] if i == 0 else g["m2_b_traj"][k, i - 1]
+    with torch.no_grad():
+        ref.apr.fc.weight.copy_(T(Wn))
+        ref.apr.fc.bias.copy_(T(bn))
+    seen = {}
+    real_svd = NRF.svd_reg
+
+    def svd_tap(pose):
+        out = real_svd(pose)
+        out.retain_grad()
+        seen["pose"] = out
+        return out
+    monkeypatch.setattr(NRF, "svd_reg", svd_tap)
+    with B.tapped() as tap:
+        loss, _ = ref._loss()
+    loss.backward()
+    raw_hip = ref.apr.raw.detach()[0].cpu()                         # the twelve numbers the kernels' pose came from (fp32)
+    g_raw_hip = ref.apr.raw.grad[0].cpu()
+    pose_hip = seen["pose"].detach()[0].cpu()                       # [3,4] after svd_reg, before fix_coord_supp
+    g_pose_hip = seen["pose"].grad[0].cpu()
+    conv_pos, aud = [(y > 0).cpu() for y in tap["conv_relu"][-3:]], {}
+    probs = {dt: problem(g, dt, k, 2) for dt in (torch.float64, torch.float32)}
+    desc = RC.image_descriptor(photo.double())
+    Wd = int(g["Wd"])
+    g0 = float(np.abs(g["m2_grad"][k, 0]).max())
+    tag = f"refine50_mode2_owner[{k},{i}]"
+    pin = B.Pinned(tap, Wd)
+
+    def pins(dt, record=False):
+        return dict(fine_act=pin.act(record), z_fine=pin.z_fine, conv_pos=conv_pos, conv_audit=aud if record else None)
+
+    def grad_at_pose(dt, pose):                                      # d loss / d pose at a GIVEN 3x4 pose (after svd_reg)
+        p = pose.to(dt).clone().requires_grad_()
+        return torch.autograd.grad(probs[dt].loss_at_pose(p, **pins(dt, dt == torch.float64)), p)[0]
+
+    def grad_at_raw(dt, raw):                                        # d loss / d (12 numbers) at GIVEN twelve numbers
+        r = raw.to(dt).clone().requires_grad_()
+        return torch.autograd.grad(probs[dt].loss_at_pose(RC.svd_reg(r.reshape(3, 4)), **pins(dt)), r)[0]
+
+    # (i) teacher-forced pose
+    gp64, gp32 = grad_at_pose(torch.float64, pose_hip), grad_at_pose(torch.float32, pose_hip)
+    gp_scale = float(gp64.abs().max())
+    e_i = B.three_way(tag, "(i) d loss / d pose after svd_reg, oracle AT THE KERNELS' POSE [branch-pinned, own norm]", g_pose_hip, gp32, gp64)
+    conv_audit(tag, aud)
+    # (ii) svd_reg's backward on the device: the float64 upstream gradient through both
+    raw_dev = raw_hip.to(DEV).clone().requires_grad_()
+    real_svd(raw_dev.reshape(1, 3, 4)).backward(gp64.float().to(DEV)[None])
+    r64 = raw_hip.double().clone().requires_grad_()
+    RC.svd_reg(r64.reshape(3, 4)).backward(gp64)
+    r32 = raw_hip.clone().requires_grad_()
+    RC.svd_reg(r32.reshape(3, 4)).backward(gp64.float())
+    e_ii = B.three_way(tag, "(ii) float64 d loss / d pose through svd_reg's backward: device fp32 vs float64 autograd" + LOOP_SUFFIX,
+                       raw_dev.grad.cpu(), r32.grad, r64.grad, scale=g0)
+    P.record(tag, "cancellation inside svd_reg's backward: |d loss / d pose| / |d loss / d (12 numbers)| (max-norms)",
+             direct=gp_scale / float(r64.grad.abs().max()), bound=None)
+    # (iii) teacher-forced twelve numbers: the path's own statement
+    g64_at_hip, g32_at_hip = grad_at_raw(torch.float64, raw_hip), grad_at_raw(torch.float32, raw_hip)
+    e_iii = B.three_way(tag, "(iii) d loss / d (12 regressed numbers), oracle AT THE KERNELS' TWELVE NUMBERS" + LOOP_SUFFIX, g_raw_hip, g32_at_hip,
+                        g64_at_hip, scale=g0)
+    assert e_iii[0] <= 3 * e_iii[1] + 2e-6, e_iii
+    # (iv) what the evaluation point is worth, and the old comparison for the record
+    raw64 = T(Wn).double() @ desc + T(bn).double()
+    g64_own = grad_at_raw(torch.float64, raw64)
+    raw32 = (T(Wn) @ desc.float() + T(bn))
+    d_point = B.rel(raw_hip, raw64)
+    shift = B.rel(g64_at_hip, g64_own, g0)
+    old = B.rel(g_raw_hip, g64_own, g0)
+    P.record(tag, "(iv) twelve regressed numbers: device fp32 forward vs float64 (relative); CPU fp32 forward vs float64",
+             direct=d_point, e_ref=B.rel(raw32, raw64), bound=None)
+    P.record(tag, "(iv) float64 gradient at the kernels' twelve numbers vs at its own" + LOOP_SUFFIX, direct=shift, bound=None)
+    P.record(tag, "old comparison (oracle at its own float64 pose)" + LOOP_SUFFIX + ": e_hip; (iii) + (iv)", e_hip=old, direct=e_iii[0] + shift, bound=None)
+    print(f"[{tag}] evaluation point {d_point:.2e} apart -> float64 gradient moves {shift:.2e}; teacher-forced e_hip {e_iii[0]:.2e} (e_ref {e_iii[1]:.2e}); "
+          f"old comparison {old:.2e}")
+    assert old <= e_iii[0] + shift + 1e-7                            # the parts account for the old record (triangle inequality)
+    assert shift >= 0.5 * (old - e_iii[0]) or old < 5e-6            # ... and the evaluation point is the bulk of it
 
 
 def population_check(tag, g, poses, ref_poses, f64_poses):
