@@ -52,7 +52,17 @@
     X(24, "v_pk_ashrrev_i16", "v_pk_ashrrev_i16 %0, 15, %6", "v_pk_ashrrev_i16 %1, 15, %6", "v_pk_ashrrev_i16 %2, 15, %6",                \
       "v_pk_ashrrev_i16 %3, 15, %6")                                                                                                      \
     X(25, "v_pk_mad_u16", "v_pk_mad_u16 %0, %0, %6, %6", "v_pk_mad_u16 %1, %1, %6, %6", "v_pk_mad_u16 %2, %2, %6, %6",                    \
-      "v_pk_mad_u16 %3, %3, %6, %6")
+      "v_pk_mad_u16 %3, %3, %6, %6") \
+    X(26, "SEQ bwd mask: v_add_co + v_cndmask (production)", "v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, %4, 0, vcc", "v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %2, %5, 0, vcc", "v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %3, %4, 0, vcc", "v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, %5, 0, vcc") \
+    X(27, "SEQ bwd mask: v_bfe_i32 + v_bfi_b32", "v_bfe_i32 %1, %0, 31, 1\n\tv_bfi_b32 %1, %1, 0, %4", "v_bfe_i32 %2, %0, 30, 1\n\tv_bfi_b32 %2, %2, 0, %5", "v_bfe_i32 %3, %0, 29, 1\n\tv_bfi_b32 %3, %3, 0, %4", "v_bfe_i32 %1, %0, 28, 1\n\tv_bfi_b32 %1, %1, 0, %5") \
+    X(28, "SEQ fwd: v_alignbit + v_max (production)", "v_alignbit_b32 %0, %0, %4, 31\n\tv_max_f32 %1, 0, %4", "v_alignbit_b32 %0, %0, %5, 31\n\tv_max_f32 %2, 0, %5", "v_alignbit_b32 %0, %0, %4, 31\n\tv_max_f32 %3, 0, %4", "v_alignbit_b32 %0, %0, %5, 31\n\tv_max_f32 %1, 0, %5") \
+    X(29, "SEQ split pair: 4 v_fma_mix (production)", "v_fma_mixlo_f16 %0, %4, %5, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %5, %5, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixlo_f16 %1, %4, %5, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %1, %5, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]", "v_fma_mixlo_f16 %2, %4, %5, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %2, %5, %5, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixlo_f16 %3, %4, %5, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %3, %5, %5, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]", "v_fma_mixlo_f16 %0, %4, %5, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %5, %5, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixlo_f16 %1, %4, %5, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %1, %5, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]", "v_fma_mixlo_f16 %2, %4, %5, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %2, %5, %5, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixlo_f16 %3, %4, %5, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %3, %5, %5, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]") \
+    X(30, "SEQ split pair: 2 mul, cvt_pk, 2 fma_mix_f32, cvt_pk", "v_mul_f32 %2, %4, %5\n\tv_mul_f32 %3, %5, %5\n\tv_cvt_pk_f16_f32 %0, %2, %3\n\tv_fma_mix_f32 %2, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %3, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_cvt_pk_f16_f32 %1, %2, %3", "v_mul_f32 %2, %4, %5\n\tv_mul_f32 %3, %5, %5\n\tv_cvt_pk_f16_f32 %0, %2, %3\n\tv_fma_mix_f32 %2, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %3, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_cvt_pk_f16_f32 %1, %2, %3", "v_mul_f32 %2, %4, %5\n\tv_mul_f32 %3, %5, %5\n\tv_cvt_pk_f16_f32 %0, %2, %3\n\tv_fma_mix_f32 %2, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %3, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_cvt_pk_f16_f32 %1, %2, %3", "v_mul_f32 %2, %4, %5\n\tv_mul_f32 %3, %5, %5\n\tv_cvt_pk_f16_f32 %0, %2, %3\n\tv_fma_mix_f32 %2, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %3, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_cvt_pk_f16_f32 %1, %2, %3") \
+    X(31, "v_bfe_i32", "v_bfe_i32 %0, %4, 31, 1", "v_bfe_i32 %1, %4, 30, 1", "v_bfe_i32 %2, %4, 29, 1", "v_bfe_i32 %3, %4, 28, 1") \
+    X(32, "v_bfi_b32", "v_bfi_b32 %0, %4, 0, %5", "v_bfi_b32 %1, %4, 0, %5", "v_bfi_b32 %2, %4, 0, %5", "v_bfi_b32 %3, %4, 0, %5") \
+    X(33, "v_add_co_u32 (vcc)", "v_add_co_u32 %0, vcc, %0, %0", "v_add_co_u32 %1, vcc, %1, %1", "v_add_co_u32 %2, vcc, %2, %2", "v_add_co_u32 %3, vcc, %3, %3") \
+    X(34, "v_cndmask_b32 (sgpr pair mask, e64)", "v_cndmask_b32_e64 %0, %4, %5, s[20:21]", "v_cndmask_b32_e64 %1, %4, %5, s[20:21]", "v_cndmask_b32_e64 %2, %4, %5, s[20:21]", "v_cndmask_b32_e64 %3, %4, %5, s[20:21]") \
+    X(35, "v_accvgpr_read_b32", "v_accvgpr_read_b32 %0, a0", "v_accvgpr_read_b32 %1, a1", "v_accvgpr_read_b32 %2, a2", "v_accvgpr_read_b32 %3, a3")
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -69,7 +79,7 @@ __global__ __launch_bounds__(512) void alone(unsigned long long* out, float* sin
             REP32(asm volatile(I0 "\n\t" I1 "\n\t" I2 "\n\t" I3                                                                           \
                                : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)                                                                   \
                                : "v"(a), "v"(b), "v"(h), "v"(p0), "v"(pa), "v"(pb), "v"(p1)                                               \
-                               : "vcc");)                                                                                                 \
+                               : "vcc", "s20", "s21", "a0", "a1", "a2", "a3");)                                                                                                 \
         }
         KINDS(X)
 #undef X
