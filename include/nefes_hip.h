@@ -215,7 +215,8 @@ int nefes_field_bwd_x6(const NefesNetDesc* desc, const void* packed, int N, int 
                        const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
                        const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);
 
-/* The same two functions (nefes_field_fwd in NEFES_FIELD_SIGMA / NEFES_FIELD_FULL mode, nefes_field_bwd) with the products as
+/* The same two functions (nefes_field_fwd in NEFES_FIELD_SIGMA / NEFES_FIELD_FULL -- and, frequency embedding only, NEFES_FIELD_STATIC --
+ * mode, nefes_field_bwd) with the products as
  * fp16 TWO-PART split products on v_mfma_f32_32x32x16_f16 -- (hi, lo) fp16 pairs of power-of-two scaled operands, three cross
  * terms hh + hl + lh, fp32 accumulation: 22 significant bits per operand, fp32-level accuracy at half the matrix-core work of
  * the _x6 calls (nefes_amd/csrc/field_h3.h; replaces script/models/nerfh_nff.py:168-231,525-576 + autograd like they do).
@@ -238,6 +239,13 @@ int nefes_field_fwd_h3_zrow(const NefesNetDesc* desc, const void* packed, int mo
 int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
                        const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
                        const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);
+/* nefes_field_bwd_static on the fp16 two-part pipe (round 5): backward-to-inputs of a NEFES_FIELD_STATIC forward
+ * (nefes_field_fwd_h3 accepts that mode for the frequency embedding) for every compiled (width, head class) pair -- a frozen coarse
+ * network with test_time False (script/models/rendering.py:116-125) or a fine network with NeRFW off
+ * (script/models/nerfh_nff.py:217-231, output_transient False).  Same arguments as nefes_field_bwd_static. */
+int nefes_field_bwd_static_h3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
+                              const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
+                              const uint32_t* masks, float* g_pts, float* g_viewdirs_s, void* stream);
 
 /* ---- train mode: weight gradients (script/run_nefes.py:42-108 `loss.backward()` through models/nerfh_nff.py:525-576) ----
  * Buffers `acts` / `dacts`: fp32 [n_tiles = ceil(N*S/128)][rows x 128 samples], rows = nefes_train_rows(desc); inside a tile

@@ -472,7 +472,7 @@ static int launch_bwd_h3(const FieldBwdH3Args& a, hipStream_t st) {
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { BWD_H3_EXT = 0, BWD_H3_FULL, BWD_H3_TRAIN_STATIC, BWD_H3_TRAIN_FULL };
+enum { BWD_H3_EXT = 0, BWD_H3_FULL, BWD_H3_TRAIN_STATIC, BWD_H3_TRAIN_FULL, BWD_H3_STATIC };
 int nefes_bwd_h3_launch_part1(int which, const FieldBwdH3Args& a, hipStream_t st);
 int nefes_bwd_h3_launch_part2(int which, const FieldBwdH3Args& a, hipStream_t st);
 int nefes_bwd_h3_launch_part3(int which, const FieldBwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256, class 0
@@ -485,11 +485,13 @@ int nefes_bwd_h3_launch_part8(int which, const FieldBwdH3Args& a, hipStream_t st
 #if NEFES_TU_PART == 1
 int nefes_bwd_h3_launch_part1(int which, const FieldBwdH3Args& a, hipStream_t st) {
     if (which == BWD_H3_EXT) return launch_bwd_h3<256, 2, NEFES_XYZ_EXTERNAL32>(a, st);
+    if (which == BWD_H3_STATIC) return launch_bwd_h3<256, 2, NEFES_XYZ_FREQ10, false>(a, st);     // static head alone, inference (round 5)
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 2      // built with -mllvm -amdgpu-mfma-vgpr-form: see field_fwd_h3.hip
 int nefes_bwd_h3_launch_part2(int which, const FieldBwdH3Args& a, hipStream_t st) {
     if (which == BWD_H3_FULL) return launch_bwd_h3<128, 9, NEFES_XYZ_FREQ10>(a, st);
+    if (which == BWD_H3_STATIC) return launch_bwd_h3<128, 9, NEFES_XYZ_FREQ10, false>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 3
@@ -507,11 +509,13 @@ int nefes_bwd_h3_launch_part4(int which, const FieldBwdH3Args& a, hipStream_t st
 #elif NEFES_TU_PART == 5      // (gap-by-gap schedule, like part 0)
 int nefes_bwd_h3_launch_part5(int which, const FieldBwdH3Args& a, hipStream_t st) {
     if (which == BWD_H3_FULL) return launch_bwd_h3<256, 9, NEFES_XYZ_FREQ10>(a, st);
+    if (which == BWD_H3_STATIC) return launch_bwd_h3<256, 9, NEFES_XYZ_FREQ10, false>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 6      // (built like part 2)
 int nefes_bwd_h3_launch_part6(int which, const FieldBwdH3Args& a, hipStream_t st) {
     if (which == BWD_H3_FULL) return launch_bwd_h3<128, 2, NEFES_XYZ_FREQ10>(a, st);
+    if (which == BWD_H3_STATIC) return launch_bwd_h3<128, 2, NEFES_XYZ_FREQ10, false>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 7
@@ -561,6 +565,37 @@ extern "C" int nefes_field_bwd_train_h3(const NefesNetDesc* desc, const void* pa
     hipStream_t st = (hipStream_t)stream;
     if (desc->width == 256) return cls == 0 ? nefes_bwd_h3_launch_part3(which, a, st) : nefes_bwd_h3_launch_part7(which, a, st);
     return cls == 1 ? nefes_bwd_h3_launch_part4(which, a, st) : nefes_bwd_h3_launch_part8(which, a, st);
+}
+
+// nefes_field_bwd_static on the fp16 pipe: backward-to-inputs of a NEFES_FIELD_STATIC forward with frozen weights (round 5: every
+// compiled (width, head class) pair; the fp32-MFMA nefes_field_bwd_static serves the two canonical shapes only).
+extern "C" int nefes_field_bwd_static_h3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+                                         const float* rays_d, const float* z, const float* pts, const float* viewdirs,
+                                         const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
+                                         float* g_viewdirs_s, void* stream) {
+    if (!desc || !packed || !viewdirs || !raw_t || !g_raw_t || !masks || !g_pts || !g_viewdirs_s || N <= 0 || S <= 0)
+        return NEFES_E_BADARG;
+    if (!pts && !(rays_o && rays_d && z)) return NEFES_E_BADARG;
+    const int cls = nefes_head_class(desc->feat_dim);
+    if ((desc->width != 256 && desc->width != 128) || cls < 0 || desc->xyz_encoding != NEFES_XYZ_FREQ10) return NEFES_E_UNSUPPORTED;
+    NefesBlobInfo info;
+    int rc = nefes_blob_info(desc, &info);
+    if (rc) return rc;
+    const NefesStreamInfo& si = info.stream[NEFES_STREAM_BWD_STATIC_H3];
+    if (si.n_slabs == 0 || si.scale_count < 2 * (uint32_t)NEFES_H3B_N_STATIC) return NEFES_E_UNSUPPORTED;
+    FieldBwdH3Args a;
+    a.stream = (const char*)packed + si.slab_off;
+    a.tab = (const int*)((const char*)packed + si.bias_off) + si.scale_off;
+    a.n_slabs = si.n_slabs;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.viewdirs = viewdirs;
+    a.raw_t = raw_t; a.g_raw_t = g_raw_t; a.masks = masks; a.g_pts = g_pts; a.g_enc = nullptr; a.g_vs = g_viewdirs_s;
+    a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + 1;
+    a.M = (long long)N * S;
+    a.n_tiles = (int)((a.M + 127) / 128);
+    a.dacts = nullptr; a.rows = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (desc->width == 256) return cls == 0 ? nefes_bwd_h3_launch_part1(BWD_H3_STATIC, a, st) : nefes_bwd_h3_launch_part5(BWD_H3_STATIC, a, st);
+    return cls == 1 ? nefes_bwd_h3_launch_part2(BWD_H3_STATIC, a, st) : nefes_bwd_h3_launch_part6(BWD_H3_STATIC, a, st);
 }
 
 extern "C" int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,

@@ -455,7 +455,7 @@ static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_SIGMA, H3_FULL, H3_TRAIN_STATIC, H3_TRAIN_FULL };
+enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_SIGMA, H3_FULL, H3_TRAIN_STATIC, H3_TRAIN_FULL, H3_STATIC };
 int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st);
 int nefes_fwd_h3_launch_part2(int which, const FieldFwdH3Args& a, hipStream_t st);
 int nefes_fwd_h3_launch_part3(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256, class 0
@@ -471,6 +471,7 @@ int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st
     switch (which) {
         case H3_EXT_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32>(a, st);
         case H3_EXT_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32>(a, st);
+        case H3_STATIC: return launch_h3<NEFES_FIELD_STATIC, NEFES_XYZ_FREQ10, 256, 1>(a, st);    // static head alone, inference (round 5)
     }
     return NEFES_E_UNSUPPORTED;
 }
@@ -484,6 +485,7 @@ int nefes_fwd_h3_launch_part2(int which, const FieldFwdH3Args& a, hipStream_t st
     switch (which) {
         case H3_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_FREQ10, 128, 5>(a, st);       // (the sigma-only pass has no rgb head: one instance per width)
         case H3_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 5>(a, st);
+        case H3_STATIC: return launch_h3<NEFES_FIELD_STATIC, NEFES_XYZ_FREQ10, 128, 5>(a, st);
     }
     return NEFES_E_UNSUPPORTED;
 }
@@ -506,11 +508,13 @@ int nefes_fwd_h3_launch_part4(int which, const FieldFwdH3Args& a, hipStream_t st
 #elif NEFES_TU_PART == 5
 int nefes_fwd_h3_launch_part5(int which, const FieldFwdH3Args& a, hipStream_t st) {
     if (which == H3_FULL) return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 256, 5>(a, st);
+    if (which == H3_STATIC) return launch_h3<NEFES_FIELD_STATIC, NEFES_XYZ_FREQ10, 256, 5>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 6      // (built like part 2)
 int nefes_fwd_h3_launch_part6(int which, const FieldFwdH3Args& a, hipStream_t st) {
     if (which == H3_FULL) return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 1>(a, st);
+    if (which == H3_STATIC) return launch_h3<NEFES_FIELD_STATIC, NEFES_XYZ_FREQ10, 128, 1>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 7
@@ -571,8 +575,9 @@ static int field_fwd_h3_impl(const NefesNetDesc* desc, const void* packed, int m
     if (!desc || !packed || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
     const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
     if (ext ? !xyz_enc : (!pts && !(rays_o && rays_d && z))) return NEFES_E_BADARG;
-    if (mode != NEFES_FIELD_SIGMA && mode != NEFES_FIELD_FULL) return NEFES_E_UNSUPPORTED;
+    if (mode != NEFES_FIELD_SIGMA && mode != NEFES_FIELD_FULL && mode != NEFES_FIELD_STATIC) return NEFES_E_UNSUPPORTED;
     if (mode == NEFES_FIELD_FULL && (!viewdirs || !desc->has_transient)) return NEFES_E_BADARG;
+    if (mode == NEFES_FIELD_STATIC && (!viewdirs || ext)) return ext ? NEFES_E_UNSUPPORTED : NEFES_E_BADARG;   // (frequency embedding only)
     // compiled set: widths 128 / 256 x head classes 0 / 1 (layout.h) with the frequency embedding; width 256 / class 0 with an
     // external 32-feature embedding
     const int cls = nefes_head_class(desc->feat_dim);
@@ -581,7 +586,8 @@ static int field_fwd_h3_impl(const NefesNetDesc* desc, const void* packed, int m
     NefesBlobInfo info;
     int rc = nefes_blob_info(desc, &info);
     if (rc) return rc;
-    const NefesStreamInfo& si = info.stream[mode == NEFES_FIELD_SIGMA ? NEFES_STREAM_FWD_SIGMA_H3 : NEFES_STREAM_FWD_FULL_H3];
+    const NefesStreamInfo& si = info.stream[mode == NEFES_FIELD_SIGMA ? NEFES_STREAM_FWD_SIGMA_H3
+                                            : (mode == NEFES_FIELD_STATIC ? NEFES_STREAM_FWD_STATIC_H3 : NEFES_STREAM_FWD_FULL_H3)];
     if (si.n_slabs == 0) return NEFES_E_UNSUPPORTED;
     FieldFwdH3Args a;
     a.stream = (const char*)packed + si.slab_off;
@@ -589,12 +595,19 @@ static int field_fwd_h3_impl(const NefesNetDesc* desc, const void* packed, int m
     a.n_slabs = si.n_slabs; a.bias_floats = si.bias_floats; a.scale_off = si.scale_off;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.xyz_enc = xyz_enc; a.viewdirs = viewdirs; a.raw_t = raw_t; a.masks = masks;
     a.acts = nullptr; a.rows = 0; a.z_row = z_row;
-    a.N = N; a.S = S; a.C = desc->feat_dim; a.R = mode == NEFES_FIELD_SIGMA ? 1 : 3 + a.C + 6;
+    a.N = N; a.S = S; a.C = desc->feat_dim; a.R = mode == NEFES_FIELD_SIGMA ? 1 : 3 + a.C + (mode == NEFES_FIELD_STATIC ? 1 : 6);
     a.M = (long long)N * S;
     if (a.M >= (1ll << 31) - 256) return NEFES_E_UNSUPPORTED;      // the kernel indexes samples with 32 bits
     a.n_tiles = (int)((a.M + 127) / 128);
     magic_div((uint32_t)S, a.s_magic, a.s_shift);
     hipStream_t st = (hipStream_t)stream;
+    if (mode == NEFES_FIELD_STATIC) {
+        // The static head alone at inference (round 5): what a frozen coarse network runs when test_time is False (rendering.py:116-125)
+        // and a fine network with NeRFW off (nerfh_nff.py:217-231 with output_transient False) -- the TRAIN instances' kernel without
+        // the activation stores.
+        if (big) return cls == 0 ? nefes_fwd_h3_launch_part1(H3_STATIC, a, st) : nefes_fwd_h3_launch_part5(H3_STATIC, a, st);
+        return cls == 1 ? nefes_fwd_h3_launch_part2(H3_STATIC, a, st) : nefes_fwd_h3_launch_part6(H3_STATIC, a, st);
+    }
     if (ext) return nefes_fwd_h3_launch_part1(mode == NEFES_FIELD_SIGMA ? H3_EXT_SIGMA : H3_EXT_FULL, a, st);
     if (small) {
         if (mode == NEFES_FIELD_SIGMA) return nefes_fwd_h3_launch_part2(H3_SIGMA, a, st);

@@ -388,9 +388,19 @@ def h3_shape(pk: PackedField):
 
 
 def x6_supported(pk: PackedField, mode, forward=True):
-    """A split-product instance (fp16 two-part or bf16x6) serves this network and mode: sigma-only or full, forward and backward."""
+    """A split-product instance (fp16 two-part or bf16x6) serves this network and mode: sigma-only or full, forward and backward --
+    and, on the fp16 two-part instances with the frequency embedding, the static head alone (round 5: a frozen coarse network with
+    test_time False, a fine network with NeRFW off)."""
+    if mode == L.FIELD_STATIC:
+        return static_h3(pk)
     ok = canonical_shape(pk) or (_h3(pk) and h3_shape(pk))
     return ok and (mode == L.FIELD_SIGMA or (mode == L.FIELD_FULL and pk.has_transient))
+
+
+def static_h3(pk: PackedField):
+    """The static-head inference instances of the fp16 two-part kernels apply (csrc/field_fwd_h3.hip H3_STATIC,
+    nefes_field_bwd_static_h3): every compiled (width, head class) pair with the frequency embedding."""
+    return _h3(pk) and h3_shape(pk) and pk.xyz_encoding == L.XYZ_FREQ10
 
 
 def _h3(pk):
@@ -416,6 +426,8 @@ def field_fwd_x6(pk: PackedField, mode, N, S, rays_o=None, rays_d=None, z=None, 
     raw_t = torch.empty(N, pk.n_raw(mode), S, device=dev)
     masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=dev) if want_masks else None
     h3 = _h3(pk) and h3_shape(pk) and N * S < (1 << 31) - 256
+    if mode == L.FIELD_STATIC and not h3:
+        return field_fwd(pk, mode, N, S, rays_o=rays_o, rays_d=rays_d, z=z, pts=pts, viewdirs=viewdirs, want_masks=want_masks, xyz_enc=xyz_enc)
     if not h3 and not canonical_shape(pk):
         raise RuntimeError(f"nefes_amd: {N * S} samples in one launch exceed the fp16 two-part kernels' 32-bit sample index and "
                            f"W={pk.width}, f_dim={pk.feat_dim} has no other instance; render fewer rays per launch")
@@ -435,7 +447,18 @@ def field_bwd(pk: PackedField, N, S, raw_t, g_raw_t, masks, rays_o=None, rays_d=
               mode=L.FIELD_FULL):
     dev = pk.blob.device
     ext = pk.xyz_encoding == L.XYZ_EXTERNAL32
-    if mode == L.FIELD_STATIC:                      # static head only (coarse network in train mode)
+    if mode == L.FIELD_STATIC and USE_X6 and SPLIT != "f32" and static_h3(pk) and N * S < (1 << 31) - 256:
+        g_pts, g_vs = torch.empty(N * S, 3, device=dev), torch.empty(N * S, 3, device=dev)
+        with _timed("field_bwd[static,h3]"):
+            L.check(L.load().nefes_field_bwd_static_h3(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
+                                                       _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(pts, "pts"), _chk(viewdirs, "viewdirs"),
+                                                       _chk(raw_t, "raw_t"), _chk(g_raw_t, "g_raw_t"), _chk(masks, "masks", torch.int32),
+                                                       _chk(g_pts, "g_pts"), _chk(g_vs, "g_vs"), _stream()), "nefes_field_bwd_static_h3")
+        return g_pts, g_vs
+    if mode == L.FIELD_STATIC:                      # static head only on the fp32 MFMA (canonical shapes)
+        if not canonical_shape(pk):
+            raise RuntimeError(f"nefes_amd: the static-head backward of W={pk.width}, f_dim={pk.feat_dim} was routed to the fp32-MFMA "
+                               f"instances (NEFES_SPLIT={SPLIT}), which exist for the canonical shapes only.  Compiled: {COMPILED_SET}")
         g_pts, g_vs = torch.empty(N * S, 3, device=dev), torch.empty(N * S, 3, device=dev)
         with _timed("field_bwd[static]"):
             L.check(L.load().nefes_field_bwd_static(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
@@ -516,7 +539,7 @@ class FieldFromPoints(torch.autograd.Function):
         if viewdirs is None:
             viewdirs = torch.zeros(N, 3, device=pts.device)
         viewdirs = _f32(viewdirs)
-        need = mode == L.FIELD_FULL and any(ctx.needs_input_grad[:2])
+        need = mode in (L.FIELD_FULL, L.FIELD_STATIC) and any(ctx.needs_input_grad[:2])
         if USE_X6 and SPLIT != "f32" and x6_supported(pk, mode) and pk.xyz_encoding == L.XYZ_FREQ10:
             raw_t, masks = field_fwd_x6(pk, mode, N, S, pts=pts.reshape(-1, 3), viewdirs=viewdirs, want_masks=need)
         else:
@@ -529,11 +552,11 @@ class FieldFromPoints(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_raw_t):
         if not ctx.have:
-            raise NotImplementedError("nefes_amd: field backward is built for the FULL (fine) mode only")
+            raise NotImplementedError("nefes_amd: the sigma-only field pass has no backward (nerfh_nff.py:192-202 runs it without gradients)")
         pts, viewdirs, raw_t, masks = ctx.saved_tensors
         N, S = pts.shape[0], pts.shape[1]
         ctx.pk.check_generation(ctx.pk_gen)
-        g_pts, g_vs = field_bwd(ctx.pk, N, S, raw_t, _f32(g_raw_t), masks, pts=pts.reshape(-1, 3), viewdirs=viewdirs)
+        g_pts, g_vs = field_bwd(ctx.pk, N, S, raw_t, _f32(g_raw_t), masks, pts=pts.reshape(-1, 3), viewdirs=viewdirs, mode=ctx.mode)
         zeros = torch.zeros(N, S, device=pts.device)
         _, _, g_v = ray_grad_reduce(N, S, zeros, g_pts, g_vs)
         return g_pts.reshape(N, S, 3), g_v, None, None

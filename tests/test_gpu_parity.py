@@ -338,12 +338,20 @@ def test_field_from_rays_vs_oracle(ops, L, Wd, C, S):
         P.record(tag, f"d {name} [unpinned]", e_hip=rel(got, res[torch.float64][i]), e_ref=rel(res[torch.float32][i], res[torch.float64][i]))
 
 
-@pytest.mark.parametrize("Wd,C,S", [(256, 16, 64), (128, 128, 40)])
-def test_static_mode_field_backward_vs_oracle(ops, L, Wd, C, S):
-    """NEFES_FIELD_STATIC (the coarse network in train mode, rendering.py:116-125 with test_time=False): forward and the
-    gradient w.r.t. the rays through nefes_field_bwd_static against the oracle."""
+@pytest.mark.parametrize("Wd,C,S,net", [(256, 16, 64, "coarse"), (128, 128, 40, "coarse"),
+                                        # round 5: every compiled (width, head class) pair has a static-head INFERENCE instance on the fp16
+                                        # pipe (nefes_field_fwd_h3 mode STATIC, nefes_field_bwd_static_h3): the reference's own network at
+                                        # --netwidth 256 (FEATURE_DIM 128), the narrow class at width 128, sizes inside the classes, and a
+                                        # FINE network evaluated without its transient head (NeRFW off: nerfh_nff.py:217-231)
+                                        (256, 128, 40, "coarse"), (128, 16, 64, "coarse"), (128, 64, 33, "coarse"), (256, 5, 40, "coarse"),
+                                        (256, 128, 33, "fine"), (128, 128, 64, "fine")])
+def test_static_mode_field_backward_vs_oracle(ops, L, Wd, C, S, net):
+    """NEFES_FIELD_STATIC (a frozen coarse network with test_time=False, rendering.py:116-125; a fine network with NeRFW off): forward
+    and the gradient w.r.t. the rays against the oracle -- nefes_field_fwd_h3 / nefes_field_bwd_static_h3 on the default pipe."""
     coarse, fine = _modules(Wd, C)
-    pc = O.make_field_params("coarse", Wd, C)
+    if net == "fine":
+        coarse = fine
+    pc = O.make_field_params(net, Wd, C)
     gen = torch.Generator().manual_seed(21)
     N = 9
     o = (torch.rand(N, 3, generator=gen) - .5)
@@ -355,20 +363,25 @@ def test_static_mode_field_backward_vs_oracle(ops, L, Wd, C, S):
     for dt in (torch.float64, torch.float32):
         oo, dd, vv = (t.to(dt).clone().requires_grad_() for t in (o, d, v))
         pts = oo[:, None, :] + dd[:, None, :] * z.to(dt)[..., None]
-        raw = O.query_field({k: w.to(dt) for k, w in pc.items()}, pts, vv, "coarse", False, False)
+        raw = O.query_field({k: w.to(dt) for k, w in pc.items()}, pts, vv, net, False, False)
         raw.backward(g_raw.to(dt))
         res[dt] = (raw.detach(), oo.grad, dd.grad, vv.grad)
     oh, dh, vh = (t.to(DEV).clone().requires_grad_() for t in (o, d, v))
-    with B.tapped() as tap:
-        raw_t = ops.FieldFromRays.apply(oh, dh, vh, z.to(DEV), coarse.packed(), L.FIELD_STATIC)
-    raw_t.backward(g_raw.permute(0, 2, 1).contiguous().to(DEV))
-    tag = f"field_static[{Wd},{C},{S}]"
+    ops.TIMERS = timers = {}
+    try:
+        with B.tapped() as tap:
+            raw_t = ops.FieldFromRays.apply(oh, dh, vh, z.to(DEV), coarse.packed(), L.FIELD_STATIC)
+        raw_t.backward(g_raw.permute(0, 2, 1).contiguous().to(DEV))
+    finally:
+        ops.TIMERS = None
+    tag = f"field_static[{Wd},{C},{S}]" + ("" if net == "coarse" else "[fine net, NeRFW off]")
+    assert ops.static_h3(coarse.packed()) and {"field_fwd[static,h3]", "field_bwd[static,h3]"} <= set(timers), sorted(timers)   # the fp16 instances ran
     B.three_way(tag, "raw", raw_t.permute(0, 2, 1), res[torch.float32][0], res[torch.float64][0])
 
     def oracle_run(dt, act, _):
         oo, dd, vv = (t.to(dt).clone().requires_grad_() for t in (o, d, v))
         pts = oo[:, None, :] + dd[:, None, :] * z.to(dt)[..., None]
-        O.query_field({k: w.to(dt) for k, w in pc.items()}, pts, vv, "coarse", False, False, act=act).backward(g_raw.to(dt))
+        O.query_field({k: w.to(dt) for k, w in pc.items()}, pts, vv, net, False, False, act=act).backward(g_raw.to(dt))
         return {"d rays_o": oo.grad, "d rays_d": dd.grad, "d viewdirs": vv.grad}
 
     B.pinned_gradients(tag, {"d rays_o": oh.grad, "d rays_d": dh.grad, "d viewdirs": vh.grad}, tap, Wd, oracle_run)

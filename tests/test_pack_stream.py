@@ -642,7 +642,7 @@ def test_no_accumulator_tile_is_relocated_inside_the_asm_scheduled_kernels(tmp_p
                 continue
             # forward: field_fwd_h3_kernel<MODE, ENC, 256, ...> (inference); backward: field_bwd_h3_kernel<256, C3, ENC, HAS_T, false>
             wide = (re.match(r"void field_fwd_h3_kernel<\d+, \d+, 256, \d+, false>", name) or
-                    re.match(r"void field_bwd_h3_kernel<256, \d+, \d+, true, false>", name))
+                    re.match(r"void field_bwd_h3_kernel<256, \d+, \d+, (true|false), false>", name))      # (HAS_T false: the static-head instances of round 5)
             if not wide:
                 continue
             c = checked.setdefault(name, {"mfma": 0, "mov": 0, "runs": 0, "inside": False})
@@ -659,7 +659,7 @@ def test_no_accumulator_tile_is_relocated_inside_the_asm_scheduled_kernels(tmp_p
                     c["mov"] += 1
     assert len(checked) >= 5, list(checked)                        # sigma / full x two encodings forward, two encodings backward
     for name, c in checked.items():
-        assert c["runs"] >= 1 and not c["inside"] and c["mfma"] > 1000 and c["mov"] == 0, (name, c)
+        assert c["runs"] >= 1 and not c["inside"] and c["mfma"] > 900 and c["mov"] == 0, (name, c)
 
 
 # ---- fp16 two-part streams (layout.h NEFES_STREAM_*_H3, pack.cpp h3 segments, field_h3.h) -------------------------------------
