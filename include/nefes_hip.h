@@ -239,6 +239,20 @@ int nefes_field_fwd_h3_zrow(const NefesNetDesc* desc, const void* packed, int mo
 int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
                        const float* z, const float* pts, const float* viewdirs, const float* raw_t, const float* g_raw_t,
                        const uint32_t* masks, float* g_pts, float* g_xyz_enc, float* g_viewdirs_s, void* stream);
+/* BASELINE configs[3] with the hash grid INSIDE the field kernels (round 5): for a NEFES_XYZ_EXTERNAL32 network whose 32 features
+ * are the multiresolution hash grid of pts = o + d z (script/models/nerfh_tcnn.py:60-75,151-182; `grid` / `table` as for
+ * nefes_hashgrid_fwd, sixteen levels), the forward gathers the table in its prologue and the backward returns g_pts [N*S, 3] =
+ * d loss / d pts through the MLP and the grid (frozen table) -- nefes_hashgrid_fwd + nefes_field_fwd_h3(xyz_enc) and
+ * nefes_field_bwd_h3(g_xyz_enc) + nefes_hashgrid_bwd_x without the two [M, 32] tensors (10 GB each per fine pass at 854x480).
+ * Forward outputs are bit-identical to that sequence.  z: [N, S], or (forward, z_is_row != 0) one row [S] shared by every ray.
+ * Width 256, C <= 29.  PARITY UNPINNED like nefes_hashgrid_fwd. */
+int nefes_field_fwd_h3_hashgrid(const NefesNetDesc* desc, const void* packed, const NefesHashGridDesc* grid, const float* table,
+                                int mode, int N, int S, const float* rays_o, const float* rays_d, const float* z, int z_is_row,
+                                const float* viewdirs, float* raw_t, uint32_t* masks, void* stream);
+int nefes_field_bwd_h3_hashgrid(const NefesNetDesc* desc, const void* packed, const NefesHashGridDesc* grid, const float* table,
+                                int N, int S, const float* rays_o, const float* rays_d, const float* z, const float* viewdirs,
+                                const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts, float* g_viewdirs_s,
+                                void* stream);
 /* nefes_field_bwd_static on the fp16 two-part pipe (round 5): backward-to-inputs of a NEFES_FIELD_STATIC forward
  * (nefes_field_fwd_h3 accepts that mode for the frequency embedding) for every compiled (width, head class) pair -- a frozen coarse
  * network with test_time False (script/models/rendering.py:116-125) or a fine network with NeRFW off

@@ -27,7 +27,9 @@
 #include "field_common.h"
 #include "field_x6.h"
 #include "field_h3.h"
+#include "hashgrid.h"
 #include "../../include/nefes_hip.h"
+#define NEFES_XYZ_HASHGRID_FUSED 2   /* kernel-internal ENC value (field_fwd_h3.hip): the 32-feature hash-grid encoding evaluated by the kernel */
 #ifndef H3B_WIDE_LAYERS
 #define H3B_WIDE_LAYERS 0x1ff   /* bit L: layer L's transposed product on the gap-by-gap schedule; bit 0: xyz_encoding_final's (debugging) */
 #endif
@@ -62,6 +64,8 @@ struct FieldBwdH3Args {
     int n_tiles;
     float* dacts;           // TRAIN instances: [n_tiles][rows][128] gradient buffer (layout.h row map)
     int rows;
+    const float2* hg_table; // NEFES_XYZ_HASHGRID_FUSED: the hash-grid table and its level geometry (hashgrid.h)
+    HgGeom hg;
 };
 
 // TRAIN instances: the (masked) gradient vector a product consumes is d loss / d pre-activation of a hidden layer, which the
@@ -118,9 +122,16 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    int* tab_i = (int*)(smem + NEFES_H3B_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (MW + 8) * 256);
+    // per-lane LDS column behind the mask words: 8 stash words (x, v, d sigma); the fused hash-grid instance parks sixteen more there
+    // (the skip's share of d encoding waits for layer 1's: in registers it pushed the allocator into moving accumulator tiles)
+    constexpr int SX = ENC == NEFES_XYZ_HASHGRID_FUSED ? 24 : 8;
+    int* tab_i = (int*)(smem + NEFES_H3B_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (MW + SX) * 256);
     const float* tab_f = (const float*)tab_i;
     if (threadIdx.x < 2 * (HAS_T ? NEFES_H3B_N : NEFES_H3B_N_STATIC)) tab_i[threadIdx.x] = a.tab[threadIdx.x];
+    HgGeom* hg_lds = (HgGeom*)(tab_i + 64);                     // NEFES_XYZ_HASHGRID_FUSED: level geometry behind the scale table (see field_fwd_h3.hip)
+    if constexpr (ENC == NEFES_XYZ_HASHGRID_FUSED) {
+        if (threadIdx.x == 0) *hg_lds = a.hg;
+    }
     auto wexp = [&](int seg) { return tab_i[nefes_h3_tab_exp(nefes_h3b_seg(HAS_T, seg))]; };     // (segment ordinals of the full stream)
     auto rowb = [&](int seg) { return tab_f[nefes_h3_tab_bound(nefes_h3b_seg(HAS_T, seg))]; };
     StagedRing ring;
@@ -128,7 +139,7 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
     const char* ring_lane = smem + lane * 16;
     ring.prime(ring_lane);                                       // (its barrier also publishes the scale table)
     // this wave's mask words in LDS: [MW/4][64 lanes][4 words]
-    uint32_t* mlds = (uint32_t*)(smem + NEFES_H3B_SLOTS * NEFES_SLAB_BYTES) + wave * ((MW + 8) * 64) + lane * 4;
+    uint32_t* mlds = (uint32_t*)(smem + NEFES_H3B_SLOTS * NEFES_SLAB_BYTES) + wave * ((MW + SX) * 64) + lane * 4;
     auto MASKW = [&](int w) { return mlds[(w >> 2) * 256 + (w & 3)]; };
     float* stash = (float*)mlds;                 // words [MW, MW+8) of the same per-lane LDS column: x, v, d sigma
     auto STASH = [&](int k) -> float& { return stash[((MW + k) >> 2) * 256 + ((MW + k) & 3)]; };
@@ -348,6 +359,13 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
 #pragma unroll
             for (int c = 0; c < 3; ++c) v3[c] = STASH(3 + c);
             embed_slots_bwd<NEFES_N_FREQ_DIR>(gv, dDv, v3, h);
+            if constexpr (ENC == NEFES_XYZ_HASHGRID_FUSED) {
+                // parked in LDS (over the view direction, which is not needed again): left in registers, hipcc sank this whole
+                // computation to the end of the tile in this instance -- the tile alive until then, spilled, and accumulator tiles
+                // moved inside the asm-scheduled runs (tests/test_pack_stream.py); a store cannot sink past the ring's acquires
+#pragma unroll
+                for (int c = 0; c < 3; ++c) STASH(3 + c) = gv[c];
+            }
         }
         // ---- xyz_encoding_final^T (no ReLU on its output) + static_sigma^T (one extra fp32 k-step) -> d h8 ----
         int es_b;
@@ -384,7 +402,11 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
         float ge[ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : 1];
         {
             const float inv = pow2i(-es_e);
-            if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+            if constexpr (ENC == NEFES_XYZ_HASHGRID_FUSED) {
+#pragma unroll
+                for (int s_ = 0; s_ < NEFES_X_STEPS; ++s_) STASH(8 + s_) = XB[0][s_] * inv;       // parked in LDS until layer 1's share exists
+                ge[0] = 0.f;
+            } else if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
 #pragma unroll
                 for (int s_ = 0; s_ < NEFES_X_STEPS; ++s_) ge[s_] = XB[0][s_] * inv;
             } else {
@@ -414,7 +436,22 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
         }
         // ---- embedding backward (Embedder.embed :257-267): layer 1's share; the other two were taken where they were produced ----
         const float inv1 = pow2i(-es_1);
-        if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+        if constexpr (ENC == NEFES_XYZ_HASHGRID_FUSED) {
+            // d loss / d pts through the hash grid HERE (frozen table): the [M, 32] encoding gradient (10 GB per frame at 854x480) is
+            // neither written nor re-read by a separate gather launch; both lane halves return their eight levels' share
+            float x3[3];
+#pragma unroll
+            for (int s_ = 0; s_ < NEFES_X_STEPS; ++s_) STASH(8 + s_) = STASH(8 + s_) + XB[0][s_] * inv1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x3[c] = STASH(c);
+            // the position passes through an opaque statement HERE: the cells, indices and table gathers depend on nothing but it, and
+            // hipcc otherwise starts them in front of the layer chain (128 registers of gathered entries alive through every run:
+            // spills, and accumulator tiles moved inside the asm-scheduled stretches -- tests/test_pack_stream.py caught it)
+            asm volatile("" : "+v"(x3[0]), "+v"(x3[1]), "+v"(x3[2]));
+            hg_encode_slots_bwd(gx, [&](int s_) { return STASH(8 + s_); }, x3, h, *hg_lds, a.hg_table);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gv[c] = STASH(3 + c);
+        } else if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
 #pragma unroll
             for (int s_ = 0; s_ < NEFES_X_STEPS; ++s_) ge[s_] += XB[0][s_] * inv1;
             if (valid) {
@@ -452,7 +489,10 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
 
 template <int W, int KR16, int ENC, bool HAS_T = true, bool TRAIN = false>
 static int launch_bwd_h3(const FieldBwdH3Args& a, hipStream_t st) {
-    const size_t lds = (size_t)NEFES_H3B_SLOTS * NEFES_SLAB_BYTES + (size_t)4 * (8 * (W / 64) + 4 * (W / 128) + 8) * 256 + 256;
+    const size_t lds = (size_t)NEFES_H3B_SLOTS * NEFES_SLAB_BYTES
+                       + (size_t)4 * (8 * (W / 64) + 4 * (W / 128) + (ENC == NEFES_XYZ_HASHGRID_FUSED ? 24 : 8)) * 256 + 256
+                       + (ENC == NEFES_XYZ_HASHGRID_FUSED ? 512 : 0);
+    static_assert(sizeof(HgGeom) <= 512 && 2 * NEFES_H3B_N <= 64, "scale table (256 bytes) + the level geometry's LDS slot");
     auto k = field_bwd_h3_kernel<W, KR16, ENC, HAS_T, TRAIN>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -472,7 +512,7 @@ static int launch_bwd_h3(const FieldBwdH3Args& a, hipStream_t st) {
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { BWD_H3_EXT = 0, BWD_H3_FULL, BWD_H3_TRAIN_STATIC, BWD_H3_TRAIN_FULL, BWD_H3_STATIC };
+enum { BWD_H3_EXT = 0, BWD_H3_FULL, BWD_H3_TRAIN_STATIC, BWD_H3_TRAIN_FULL, BWD_H3_STATIC, BWD_H3_HG };
 int nefes_bwd_h3_launch_part1(int which, const FieldBwdH3Args& a, hipStream_t st);
 int nefes_bwd_h3_launch_part2(int which, const FieldBwdH3Args& a, hipStream_t st);
 int nefes_bwd_h3_launch_part3(int which, const FieldBwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256, class 0
@@ -498,6 +538,11 @@ int nefes_bwd_h3_launch_part2(int which, const FieldBwdH3Args& a, hipStream_t st
 int nefes_bwd_h3_launch_part3(int which, const FieldBwdH3Args& a, hipStream_t st) {
     if (which == BWD_H3_TRAIN_STATIC) return launch_bwd_h3<256, 2, NEFES_XYZ_FREQ10, false, true>(a, st);
     if (which == BWD_H3_TRAIN_FULL) return launch_bwd_h3<256, 2, NEFES_XYZ_FREQ10, true, true>(a, st);
+    // The hash grid's backward in the epilogue (round 5).  In THIS object (block-per-pair runs, compiler-placed MFMAs) on purpose: on
+    // the gap-by-gap schedule of parts 0 / 1 hipcc split an accumulator tile's live range inside an asm-scheduled run for this
+    // instance (a v_accvgpr_mov behind an MFMA that has not written the tile yet: tests/test_pack_stream.py); that schedule is worth
+    // 1.5 % of the backward, the fusion 10 %.
+    if (which == BWD_H3_HG) return launch_bwd_h3<256, 2, NEFES_XYZ_HASHGRID_FUSED>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 4      // (built like part 2)
@@ -598,14 +643,15 @@ extern "C" int nefes_field_bwd_static_h3(const NefesNetDesc* desc, const void* p
     return cls == 1 ? nefes_bwd_h3_launch_part2(BWD_H3_STATIC, a, st) : nefes_bwd_h3_launch_part6(BWD_H3_STATIC, a, st);
 }
 
-extern "C" int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+static int field_bwd_h3_impl(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
                                   const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                   const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
-                                  float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
+                                  float* g_xyz_enc, float* g_viewdirs_s, void* stream, const NefesHashGridDesc* grid, const float* table) {
     if (!desc || !packed || !viewdirs || !raw_t || !g_raw_t || !masks || !g_viewdirs_s || N <= 0 || S <= 0)
         return NEFES_E_BADARG;
     const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
-    if (ext ? !g_xyz_enc : (!g_pts || (!pts && !(rays_o && rays_d && z)))) return NEFES_E_BADARG;
+    const bool fused_grid = ext && table != nullptr;            // d pts through the hash grid inside the kernel (hashgrid.h)
+    if (fused_grid ? !(g_pts && grid && rays_o && rays_d && z) : (ext ? !g_xyz_enc : (!g_pts || (!pts && !(rays_o && rays_d && z))))) return NEFES_E_BADARG;
     if (!desc->has_transient) return NEFES_E_UNSUPPORTED;
     NefesBlobInfo info;
     int rc = nefes_blob_info(desc, &info);
@@ -622,12 +668,38 @@ extern "C" int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, 
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
     a.dacts = nullptr; a.rows = 0;
+    a.hg_table = (const float2*)table;
+    if (fused_grid) {
+        rc = hg_geometry(grid, &a.hg, nullptr);
+        if (rc) return rc;
+        if (a.hg.n_levels != 16) return NEFES_E_UNSUPPORTED;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int cls = nefes_head_class(desc->feat_dim);          // compiled set: as nefes_field_fwd_h3
     if (cls < 0) return NEFES_E_UNSUPPORTED;
+    if (desc->width == 256 && fused_grid) return cls == 0 ? nefes_bwd_h3_launch_part3(BWD_H3_HG, a, st) : NEFES_E_UNSUPPORTED;
     if (desc->width == 256 && ext) return cls == 0 ? nefes_bwd_h3_launch_part1(BWD_H3_EXT, a, st) : NEFES_E_UNSUPPORTED;
     if (desc->width == 256) return cls == 0 ? launch_bwd_h3<256, 2, NEFES_XYZ_FREQ10>(a, st) : nefes_bwd_h3_launch_part5(BWD_H3_FULL, a, st);
     if (desc->width == 128 && !ext) return cls == 1 ? nefes_bwd_h3_launch_part2(BWD_H3_FULL, a, st) : nefes_bwd_h3_launch_part6(BWD_H3_FULL, a, st);
     return NEFES_E_UNSUPPORTED;
+}
+
+extern "C" int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
+                                  const float* rays_d, const float* z, const float* pts, const float* viewdirs,
+                                  const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
+                                  float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
+    return field_bwd_h3_impl(desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc, g_viewdirs_s, stream,
+                             nullptr, nullptr);
+}
+
+// nefes_field_bwd_h3 for a nefes_field_fwd_h3_hashgrid forward: g_pts [N*S, 3] = d loss / d (o + d z) through the MLP AND the hash
+// grid (frozen table) -- what nefes_field_bwd_h3 (g_xyz_enc) followed by nefes_hashgrid_bwd_x compute, without the [M, 32] gradient.
+extern "C" int nefes_field_bwd_h3_hashgrid(const NefesNetDesc* desc, const void* packed, const NefesHashGridDesc* grid,
+                                           const float* table, int N, int S, const float* rays_o, const float* rays_d, const float* z,
+                                           const float* viewdirs, const float* raw_t, const float* g_raw_t, const uint32_t* masks,
+                                           float* g_pts, float* g_viewdirs_s, void* stream) {
+    if (!desc || desc->xyz_encoding != NEFES_XYZ_EXTERNAL32 || !grid || !table) return NEFES_E_BADARG;
+    return field_bwd_h3_impl(desc, packed, N, S, rays_o, rays_d, z, nullptr, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr, g_viewdirs_s, stream,
+                             grid, table);
 }
 #endif   // NEFES_TU_PART

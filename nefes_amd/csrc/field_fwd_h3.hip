@@ -23,6 +23,8 @@
 #include "../../include/nefes_hip.h"
 
 #include "field_x6.h"
+#include "hashgrid.h"
+#define NEFES_XYZ_HASHGRID_FUSED 2   /* kernel-internal ENC value: a NEFES_XYZ_EXTERNAL32 network whose 32 features the kernel gathers itself */
 #if !defined(NEFES_TU_W128) && !defined(H3_NO_ACC_READ_ASM)
 #define H3_ACC_READ_ASM        // Wd = 256 objects: source tiles are read out of their AGPRs inside the MFMA gaps (field_h3.h acc_read)
 #endif
@@ -48,6 +50,8 @@ struct FieldFwdH3Args {
     float* acts;             // TRAIN instances: [n_tiles][rows][128] pre-activations + embeddings (layout.h row map)
     int rows;
     int z_row;               // 1: `z` is ONE row of S depths shared by every ray (scalar near / far, no jitter: rendering.py:96-100)
+    const float2* hg_table;  // NEFES_XYZ_HASHGRID_FUSED: the hash-grid table and its level geometry (hashgrid.h)
+    HgGeom hg;
 };
 
 // TRAIN: tiles X[T0 .. T0+NT) hold a layer's pre-activations times 2^es; rows [row0, row0 + 32 NT) of this tile of `acts` get
@@ -71,7 +75,7 @@ template <int MODE, int ENC, int W = 256, int NTR = 1, bool TRAIN = false>
 __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(FieldFwdH3Args a) {
     static_assert(NEFES_SLAB_KIB == (W == 128 ? NEFES_H3_FWD_SLAB_KIB_128 : NEFES_H3_FWD_SLAB_KIB), "ring slab size != the packer's for this width");
     constexpr int NTW = W / 32, NTH = W / 64;
-    constexpr int ES = ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : NEFES_E_STEPS;
+    constexpr int ES = ENC != NEFES_XYZ_FREQ10 ? NEFES_X_STEPS : NEFES_E_STEPS;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128), WT = (NTW + 1) / 2, WH = (NTH + 1) / 2;
     constexpr int NSEG = MODE == NEFES_FIELD_SIGMA ? NEFES_H3F_SIG + 1 : (MODE == NEFES_FIELD_STATIC ? NEFES_H3F_N_STATIC : NEFES_H3F_N);   // segments of the stream
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,6 +87,12 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     for (uint32_t i = threadIdx.x; i < a.bias_floats; i += 256) bias_lds[i] = a.bias[i];
+    // NEFES_XYZ_HASHGRID_FUSED: the level geometry waits in LDS behind the embedding stash (read out of the kernel arguments at its
+    // uses, hipcc hoists the eighty scalar loads out of the tile loop and spills them); published by ring.prime()'s barrier
+    HgGeom* hg_lds = (HgGeom*)(bias_lds + ((a.bias_floats + 63) / 64) * 64 + 4 * ES * 64);
+    if constexpr (ENC == NEFES_XYZ_HASHGRID_FUSED) {
+        if (threadIdx.x == 0) *hg_lds = a.hg;
+    }
     StagedRing ring;
     ring.init(a.stream, a.n_slabs, ring_base, wave, lane);
     const char* ring_lane = ring_base + lane * 16;
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
         if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
 #pragma unroll
             for (int s = 0; s < ES; ++s) E[s] = a.xyz_enc[(size_t)m * 32 + 2 * s + h];    // compact slots: feature 2s+h
-        } else if (a.pts) {
+        } else if (ENC != NEFES_XYZ_HASHGRID_FUSED && a.pts) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) in_o[c] = a.pts[(size_t)m * 3 + c];
         } else {
@@ -126,6 +136,14 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
         }
         float mE;                                                   // largest embedding magnitude of the sample (true units)
         if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+            mE = pair_max(array_max(E));
+        } else if constexpr (ENC == NEFES_XYZ_HASHGRID_FUSED) {
+            // the hash-grid encoding of pts = o + d z (rendering.py:114,142; nerfh_tcnn.py:151-156) gathered HERE: the [M, 32]
+            // encoding (10 GB per fine pass of the 854x480 frame), the stand-alone gather launch and the torch expression for pts go
+            float x[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[c] = add_rn(in_o[c], mul_rn(in_d[c], in_z));
+            hg_encode_slots(E, x, h, *hg_lds, a.hg_table);
             mE = pair_max(array_max(E));
         } else {
             float x[3];
@@ -429,8 +447,10 @@ static void magic_div(uint32_t d, uint32_t& magic, uint32_t& shift) {
 
 template <int MODE, int ENC, int W = 256, int NTR = 1, bool TRAIN = false>
 static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
-    constexpr int ES_ = ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : NEFES_E_STEPS;
-    const size_t lds = (size_t)NEFES_H3_SLOTS * NEFES_SLAB_BYTES + ((a.bias_floats + 63) / 64) * 256 + (size_t)4 * ES_ * 64 * 4;
+    constexpr int ES_ = ENC != NEFES_XYZ_FREQ10 ? NEFES_X_STEPS : NEFES_E_STEPS;
+    const size_t lds = (size_t)NEFES_H3_SLOTS * NEFES_SLAB_BYTES + ((a.bias_floats + 63) / 64) * 256 + (size_t)4 * ES_ * 64 * 4
+                       + (ENC == NEFES_XYZ_HASHGRID_FUSED ? 512 : 0);
+    static_assert(sizeof(HgGeom) <= 512, "the level geometry's LDS slot");
     auto k = field_fwd_h3_kernel<MODE, ENC, W, NTR, TRAIN>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -455,7 +475,7 @@ static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_SIGMA, H3_FULL, H3_TRAIN_STATIC, H3_TRAIN_FULL, H3_STATIC };
+enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_SIGMA, H3_FULL, H3_TRAIN_STATIC, H3_TRAIN_FULL, H3_STATIC, H3_HG_SIGMA, H3_HG_FULL };
 int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st);
 int nefes_fwd_h3_launch_part2(int which, const FieldFwdH3Args& a, hipStream_t st);
 int nefes_fwd_h3_launch_part3(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256, class 0
@@ -472,6 +492,8 @@ int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st
         case H3_EXT_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_EXTERNAL32>(a, st);
         case H3_EXT_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_EXTERNAL32>(a, st);
         case H3_STATIC: return launch_h3<NEFES_FIELD_STATIC, NEFES_XYZ_FREQ10, 256, 1>(a, st);    // static head alone, inference (round 5)
+        case H3_HG_SIGMA: return launch_h3<NEFES_FIELD_SIGMA, NEFES_XYZ_HASHGRID_FUSED>(a, st);     // hash grid gathered in the prologue (round 5)
+        case H3_HG_FULL: return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_HASHGRID_FUSED>(a, st);
     }
     return NEFES_E_UNSUPPORTED;
 }
@@ -571,10 +593,12 @@ extern "C" int nefes_field_fwd_train_h3(const NefesNetDesc* desc, const void* pa
 
 static int field_fwd_h3_impl(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                              const float* rays_d, const float* z, int z_row, const float* pts, const float* xyz_enc,
-                             const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
+                             const float* viewdirs, float* raw_t, uint32_t* masks, void* stream,
+                             const NefesHashGridDesc* grid = nullptr, const float* table = nullptr) {
     if (!desc || !packed || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
     const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
-    if (ext ? !xyz_enc : (!pts && !(rays_o && rays_d && z))) return NEFES_E_BADARG;
+    const bool fused_grid = ext && table != nullptr;            // the kernel gathers the 32 features itself (hashgrid.h)
+    if (fused_grid ? !(rays_o && rays_d && z && grid) : (ext ? !xyz_enc : (!pts && !(rays_o && rays_d && z)))) return NEFES_E_BADARG;
     if (mode != NEFES_FIELD_SIGMA && mode != NEFES_FIELD_FULL && mode != NEFES_FIELD_STATIC) return NEFES_E_UNSUPPORTED;
     if (mode == NEFES_FIELD_FULL && (!viewdirs || !desc->has_transient)) return NEFES_E_BADARG;
     if (mode == NEFES_FIELD_STATIC && (!viewdirs || ext)) return ext ? NEFES_E_UNSUPPORTED : NEFES_E_BADARG;   // (frequency embedding only)
@@ -595,6 +619,12 @@ static int field_fwd_h3_impl(const NefesNetDesc* desc, const void* packed, int m
     a.n_slabs = si.n_slabs; a.bias_floats = si.bias_floats; a.scale_off = si.scale_off;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.xyz_enc = xyz_enc; a.viewdirs = viewdirs; a.raw_t = raw_t; a.masks = masks;
     a.acts = nullptr; a.rows = 0; a.z_row = z_row;
+    a.hg_table = (const float2*)table;
+    if (fused_grid) {
+        rc = hg_geometry(grid, &a.hg, nullptr);
+        if (rc) return rc;
+        if (a.hg.n_levels != 16) return NEFES_E_UNSUPPORTED;       // sixteen levels x two features = the network's 32 inputs
+    }
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = mode == NEFES_FIELD_SIGMA ? 1 : 3 + a.C + (mode == NEFES_FIELD_STATIC ? 1 : 6);
     a.M = (long long)N * S;
     if (a.M >= (1ll << 31) - 256) return NEFES_E_UNSUPPORTED;      // the kernel indexes samples with 32 bits
@@ -608,6 +638,7 @@ static int field_fwd_h3_impl(const NefesNetDesc* desc, const void* packed, int m
         if (big) return cls == 0 ? nefes_fwd_h3_launch_part1(H3_STATIC, a, st) : nefes_fwd_h3_launch_part5(H3_STATIC, a, st);
         return cls == 1 ? nefes_fwd_h3_launch_part2(H3_STATIC, a, st) : nefes_fwd_h3_launch_part6(H3_STATIC, a, st);
     }
+    if (fused_grid) return nefes_fwd_h3_launch_part1(mode == NEFES_FIELD_SIGMA ? H3_HG_SIGMA : H3_HG_FULL, a, st);
     if (ext) return nefes_fwd_h3_launch_part1(mode == NEFES_FIELD_SIGMA ? H3_EXT_SIGMA : H3_EXT_FULL, a, st);
     if (small) {
         if (mode == NEFES_FIELD_SIGMA) return nefes_fwd_h3_launch_part2(H3_SIGMA, a, st);
@@ -621,6 +652,18 @@ extern "C" int nefes_field_fwd_h3(const NefesNetDesc* desc, const void* packed, 
                                   const float* rays_d, const float* z, const float* pts, const float* xyz_enc,
                                   const float* viewdirs, float* raw_t, uint32_t* masks, void* stream) {
     return field_fwd_h3_impl(desc, packed, mode, N, S, rays_o, rays_d, z, 0, pts, xyz_enc, viewdirs, raw_t, masks, stream);
+}
+
+// A NEFES_XYZ_EXTERNAL32 network whose 32 features are a multiresolution hash grid of pts = o + d z (BASELINE configs[3]:
+// script/models/nerfh_tcnn.py:60-75,151-182): the kernel gathers the table itself instead of reading an [M, 32] encoding that
+// nefes_hashgrid_fwd wrote (10 GB per fine pass at 854x480).  z: [N, S], or one row [S] shared by every ray (z_is_row).
+extern "C" int nefes_field_fwd_h3_hashgrid(const NefesNetDesc* desc, const void* packed, const NefesHashGridDesc* grid,
+                                           const float* table, int mode, int N, int S, const float* rays_o, const float* rays_d,
+                                           const float* z, int z_is_row, const float* viewdirs, float* raw_t, uint32_t* masks,
+                                           void* stream) {
+    if (!desc || desc->xyz_encoding != NEFES_XYZ_EXTERNAL32 || !grid || !table) return NEFES_E_BADARG;
+    return field_fwd_h3_impl(desc, packed, mode, N, S, rays_o, rays_d, z, z_is_row ? 1 : 0, nullptr, nullptr, viewdirs, raw_t, masks, stream,
+                             grid, table);
 }
 
 // The same pass with ONE row of S depths shared by every ray (`z_row` [S]): the coarse pass at test time with scalar near / far

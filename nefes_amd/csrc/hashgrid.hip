@@ -6,58 +6,7 @@
 // Roofline: gather-bound.  Per sample: 16 levels x 8 corners x 8 B (fp32 x2) = 1 KiB of table reads, 12 B in, 128 B out.
 // The 48.8 MB table stays in the 256 MiB Infinity Cache.  One thread per (sample, level): a wave covers 4 samples,
 // writes 512 contiguous bytes, and the backward reduces the 16 levels of a sample with 4 xor-shuffles.
-#include <hip/hip_runtime.h>
-#include <math.h>
-
-#include "../../include/nefes_hip.h"
-
-#define HG_MAX_LEVELS 16
-struct HgLevel {
-    float scale;
-    uint32_t res, entries, offset, hashed;
-};
-struct HgGeom {
-    HgLevel lv[HG_MAX_LEVELS];
-    int n_levels;
-    float inv_range;   // 1 / (2 bound)
-    float bound;
-};
-
-static int hg_geometry(const NefesHashGridDesc* d, HgGeom* g, uint64_t* total) {
-    if (!d || d->n_levels <= 0 || d->n_levels > HG_MAX_LEVELS || d->n_features != 2 || d->log2_hashmap_size <= 0 ||
-        d->log2_hashmap_size > 24 || !(d->bound > 0.f))
-        return NEFES_E_UNSUPPORTED;
-    uint64_t off = 0;
-    g->n_levels = d->n_levels;
-    g->bound = d->bound;
-    g->inv_range = 1.f / (2.f * d->bound);
-    for (int l = 0; l < d->n_levels; ++l) {
-        // level scale evaluated in f64 from the fp32 growth factor and rounded once (oracle/hashgrid_ref.py does the same)
-        const float scale = (float)((double)d->base_resolution * pow((double)d->per_level_scale, (double)l) - 1.0);
-        const uint32_t res = (uint32_t)ceilf(scale) + 1u;
-        const uint64_t dense = (uint64_t)res * res * res;
-        uint64_t entries = (dense + 7) / 8 * 8;
-        const uint64_t cap = 1ull << d->log2_hashmap_size;
-        if (entries > cap) entries = cap;
-        g->lv[l] = {scale, res, (uint32_t)entries, (uint32_t)off, dense > entries ? 1u : 0u};
-        off += entries;
-    }
-    if (total) *total = off;
-    return 0;
-}
-
-// index % entries without the division on the common path: a hashed level has entries = 2^log2_hashmap_size (mask); a dense
-// level has entries >= res^3 and, for positions inside the bound, corner coordinates <= res, so its linear index is
-// < 2 * entries (one conditional subtraction).  Positions outside the bound take the division (same result as before).
-__device__ __forceinline__ uint32_t hg_index(const HgLevel& L, uint32_t x, uint32_t y, uint32_t z) {
-    if (L.hashed) return L.offset + ((x ^ (y * 2654435761u) ^ (z * 805459861u)) & (L.entries - 1u));
-    uint32_t i = x + y * L.res + z * L.res * L.res;
-    if (i >= L.entries) {
-        i -= L.entries;
-        if (i >= L.entries) i %= L.entries;
-    }
-    return L.offset + i;
-}
+#include "hashgrid.h"
 
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(HgGeom g, const float2* __restrict__ table, long long M,
                                                            const float* __restrict__ x, float2* __restrict__ enc) {
@@ -66,25 +15,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(HgGeom g, const float
     const int l = (int)(tid - m * g.n_levels);
     if (m >= M) return;
     const HgLevel L = g.lv[l];
-    float w[3];
-    uint32_t c[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float x01 = (x[m * 3 + k] + g.bound) / (2.f * g.bound);   // nerfh_tcnn.py:156
-        const float pos = x01 * L.scale + 0.5f;
-        const float fl = floorf(pos);
-        c[k] = (uint32_t)(int)fl;
-        w[k] = pos - fl;
-    }
-    float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-        const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
-        const float wc = (dx ? w[0] : 1.f - w[0]) * (dy ? w[1] : 1.f - w[1]) * (dz ? w[2] : 1.f - w[2]);
-        const float2 f = table[hg_index(L, c[0] + dx, c[1] + dy, c[2] + dz)];
-        acc.x = fmaf(wc, f.x, acc.x);
-        acc.y = fmaf(wc, f.y, acc.y);
-    }
+    const float xs[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
+    const float2 acc = hg_level_fwd(L, g.bound, table, xs);
     // the embedding is written once and read once by the field kernel: a non-temporal store, so that 10 GB of output per fine pass
     // do not push the table (the data with reuse: 67 MB, four times the L2s) out of the caches on its way
     __builtin_nontemporal_store(acc.x, &enc[tid].x);     // enc[m][2l .. 2l+1]
@@ -102,31 +34,10 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_x_kernel(HgGeom g, const flo
     float gx[3] = {0.f, 0.f, 0.f};
     if (live) {
         const HgLevel L = g.lv[l];
-        float w[3];
-        uint32_t c[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float x01 = (x[m * 3 + k] + g.bound) / (2.f * g.bound);
-            const float pos = x01 * L.scale + 0.5f;
-            const float fl = floorf(pos);
-            c[k] = (uint32_t)(int)fl;
-            w[k] = pos - fl;
-        }
+        const float xs[3] = {x[m * 3 + 0], x[m * 3 + 1], x[m * 3 + 2]};
         const float* gep = (const float*)&g_enc[m * g.n_levels + l];                       // (read once: non-temporal)
         const float2 ge = make_float2(__builtin_nontemporal_load(gep), __builtin_nontemporal_load(gep + 1));
-#pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
-            const float2 f = table[hg_index(L, c[0] + dx, c[1] + dy, c[2] + dz)];
-            const float v = f.x * ge.x + f.y * ge.y;
-            const float wx = dx ? w[0] : 1.f - w[0], wy = dy ? w[1] : 1.f - w[1], wz = dz ? w[2] : 1.f - w[2];
-            gx[0] += (dx ? v : -v) * wy * wz;
-            gx[1] += (dy ? v : -v) * wx * wz;
-            gx[2] += (dz ? v : -v) * wx * wy;
-        }
-        const float s = L.scale * g.inv_range;   // d pos / d x
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gx[k] *= s;
+        hg_level_bwd_x(L, g.bound, g.inv_range, table, xs, ge, gx);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k)

@@ -197,20 +197,29 @@ def coarse_depth_row(Nc, near, far, lindisp=False, device="cuda"):
     return z
 
 
-def fused_coarse_pass_ok(pk, Nc, Ni, N=0):
+def fused_coarse_pass_ok(pk, Nc, Ni, N=0, grid=None):
     """The coarse pass as two launches (sigma-only field kernel on a shared depth row + coarse_sample) instead of four: fp16 two-part
-    instances, frequency embedding, Nc = 64 / 128 / 256, Nc + Ni <= 512 (csrc/sample_pdf.hip coarse_sample_kernel)."""
-    return (FUSED_COARSE and _h3(pk) and h3_shape(pk) and pk.xyz_encoding == L.XYZ_FREQ10 and Nc in (64, 128, 256)
+    instances, frequency embedding (or a hash grid the field kernel gathers itself: hashgrid_fused_ok), Nc = 64 / 128 / 256,
+    Nc + Ni <= 512 (csrc/sample_pdf.hip coarse_sample_kernel)."""
+    enc_ok = pk.xyz_encoding == L.XYZ_FREQ10 if grid is None else hashgrid_fused_ok(pk, grid)
+    return (FUSED_COARSE and _h3(pk) and h3_shape(pk) and enc_ok and Nc in (64, 128, 256)
             and Ni > 0 and Nc + Ni <= 512 and N * Nc < (1 << 31) - 256)      # (beyond the 32-bit sample index: the four-launch path)
 
 
-def field_sigma_row(pk, rays_o, rays_d, z_row):
-    """sigma [N,1,Nc] of the coarse network along rays whose depths are ONE shared row (no gradient: nerfh_nff.py:192-202)."""
+def field_sigma_row(pk, rays_o, rays_d, z_row, grid=None):
+    """sigma [N,1,Nc] of the coarse network along rays whose depths are ONE shared row (no gradient: nerfh_nff.py:192-202).
+    grid: an ops.HashGrid whose encoding the kernel evaluates itself (hashgrid_fused_ok)."""
     rays_o, rays_d = _f32(rays_o), _f32(rays_d)
     N, S = rays_o.shape[0], z_row.numel()
     if N * S >= (1 << 31) - 256:
         raise RuntimeError("nefes_amd: too many samples for one launch of the fp16 two-part kernels (32-bit sample index)")
     raw_t = torch.empty(N, 1, S, device=rays_o.device)
+    if grid is not None:
+        with _timed("field_fwd[sigma,h3,hashgrid]"):
+            L.check(L.load().nefes_field_fwd_h3_hashgrid(pk.desc, _chk(pk.blob, "blob", torch.uint8), grid.desc, _chk(grid.table, "table"), L.FIELD_SIGMA,
+                                                         N, S, _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d"), _chk(z_row, "z_row"), 1, None,
+                                                         _chk(raw_t, "raw_t"), None, _stream()), "nefes_field_fwd_h3_hashgrid")
+        return raw_t
     with _timed("field_fwd[sigma,h3]"):
         L.check(L.load().nefes_field_fwd_h3_zrow(pk.desc, _chk(pk.blob, "blob", torch.uint8), L.FIELD_SIGMA, N, S, _chk(rays_o, "rays_o"),
                                                  _chk(rays_d, "rays_d"), _chk(z_row, "z_row"), None, _chk(raw_t, "raw_t"), None, _stream()),
@@ -707,6 +716,63 @@ class HashGrid:
 
     def __call__(self, x):
         return HashGridEncode.apply(x, self)
+
+
+# BASELINE configs[3] with the hash grid evaluated INSIDE the field kernels (csrc/hashgrid.h, nefes_field_fwd_h3_hashgrid /
+# nefes_field_bwd_h3_hashgrid); "0": the separate launches HashGridEncode + FieldFromEncoding (the tests compare the two)
+FUSED_HASHGRID = os.environ.get("NEFES_FUSED_HASHGRID", "1") != "0"
+
+
+def hashgrid_fused_ok(pk, grid):
+    """The fp16 two-part field kernels can gather this hash grid themselves: width 256, head class 0, sixteen levels x two features."""
+    return (FUSED_HASHGRID and isinstance(grid, HashGrid) and _h3(pk) and pk.xyz_encoding == L.XYZ_EXTERNAL32 and pk.width == 256
+            and head_class(pk.feat_dim) == 0 and grid.desc.n_levels == 16 and grid.desc.n_features == 2)
+
+
+class FieldFromRaysHashGrid(torch.autograd.Function):
+    """pts = o + d z -> hash-grid encoding -> MLP in ONE launch each way (rendering.py:114,142 + nerfh_tcnn.py:151-182): raw_t [N, R, S];
+    differentiable w.r.t. rays_o, rays_d, viewdirs in FULL mode (frozen weights, frozen table).  Forward bit-identical to
+    HashGridEncode + FieldFromEncoding."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, viewdirs, z, pk, mode, grid):
+        rays_o, rays_d, viewdirs, z = _f32(rays_o), _f32(rays_d), _f32(viewdirs), _f32(z)
+        N, S = z.shape
+        if N * S >= (1 << 31) - 256:
+            raise RuntimeError("nefes_amd: too many samples for one launch of the fp16 two-part kernels (32-bit sample index)")
+        if mode not in (L.FIELD_SIGMA, L.FIELD_FULL):
+            raise NotImplementedError("nefes_amd: the hash-grid field kernels evaluate the sigma-only or the full head")
+        need = mode == L.FIELD_FULL and any(ctx.needs_input_grad[:3])
+        raw_t = torch.empty(N, pk.n_raw(mode), S, device=z.device)
+        masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=z.device) if need else None
+        with _timed(f"field_fwd[{('sigma', 'static', 'full')[mode]},h3,hashgrid]"):
+            L.check(L.load().nefes_field_fwd_h3_hashgrid(pk.desc, _chk(pk.blob, "blob", torch.uint8), grid.desc, _chk(grid.table, "table"), mode, N, S,
+                                                         _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d"), _chk(z, "z"), 0, _chk(viewdirs, "viewdirs"),
+                                                         _chk(raw_t, "raw_t"), _chk(masks, "masks", torch.int32), _stream()),
+                    "nefes_field_fwd_h3_hashgrid")
+        if masks is not None:
+            _tap("masks", (masks, N, S, pk.width, mode))
+        ctx.pk, ctx.grid, ctx.have, ctx.pk_gen = pk, grid, need, pk.generation
+        if need:
+            ctx.save_for_backward(rays_o, rays_d, viewdirs, z, raw_t, masks)
+        return raw_t
+
+    @staticmethod
+    def backward(ctx, g_raw_t):
+        if not ctx.have:
+            raise NotImplementedError("nefes_amd: the sigma-only field pass has no backward (nerfh_nff.py:192-202 runs it without gradients)")
+        rays_o, rays_d, viewdirs, z, raw_t, masks = ctx.saved_tensors
+        N, S = z.shape
+        pk, grid = ctx.pk, ctx.grid
+        pk.check_generation(ctx.pk_gen)
+        g_pts, g_vs = torch.empty(N * S, 3, device=z.device), torch.empty(N * S, 3, device=z.device)
+        with _timed("field_bwd[h3,hashgrid]"):
+            L.check(L.load().nefes_field_bwd_h3_hashgrid(pk.desc, _chk(pk.blob, "blob", torch.uint8), grid.desc, _chk(grid.table, "table"), N, S,
+                                                         _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(viewdirs, "viewdirs"),
+                                                         _chk(raw_t, "raw_t"), _chk(_f32(g_raw_t), "g_raw_t"), _chk(masks, "masks", torch.int32),
+                                                         _chk(g_pts, "g_pts"), _chk(g_vs, "g_vs"), _stream()), "nefes_field_bwd_h3_hashgrid")
+        g_o, g_d, g_v = ray_grad_reduce(N, S, z, g_pts, g_vs)
+        return g_o, g_d, g_v, None, None, None, None
 
 
 class HashGridEncode(torch.autograd.Function):

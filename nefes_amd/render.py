@@ -104,6 +104,9 @@ def _field(pk, mode, rays_o, rays_d, viewdirs, z, xyz_encoder):
     """raw_t [N,R,S] for samples z along the rays; differentiable w.r.t. rays_o, rays_d, viewdirs in FULL mode."""
     if xyz_encoder is None:
         return ops.FieldFromRays.apply(rays_o, rays_d, viewdirs, z, pk, mode)
+    if mode != L.FIELD_STATIC and ops.hashgrid_fused_ok(pk, xyz_encoder) and z.shape[0] * z.shape[1] < (1 << 31) - 256:
+        # BASELINE configs[3]: the field kernels gather the hash grid themselves (no [M, 32] encoding, no pts tensor)
+        return ops.FieldFromRaysHashGrid.apply(rays_o, rays_d, viewdirs, z, pk, mode, xyz_encoder)
     pts = rays_o[:, None, :] + rays_d[:, None, :] * z[..., None]                    # rendering.py:114,142 (torch glue)
     return ops.FieldFromEncoding.apply(xyz_encoder(pts), viewdirs, pk, mode)
 
@@ -130,14 +133,14 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
     pk_c = network_fn.packed()
     C = pk_c.feat_dim
     store_rgb = (Ni == 0)
-    if (cfg.test_time and cfg.perturb == 0. and cfg.raw_noise_std == 0. and bounds is None and cfg.xyz_encoder is None
-            and not cfg.use_fine_only and ops.fused_coarse_pass_ok(pk_c, Nc, Ni, N)):
+    if (cfg.test_time and cfg.perturb == 0. and cfg.raw_noise_std == 0. and bounds is None
+            and not cfg.use_fine_only and ops.fused_coarse_pass_ok(pk_c, Nc, Ni, N, cfg.xyz_encoder)):
         # The coarse pass at test time (:96-141, nerfh_nff.py:192-202) as TWO launches: every ray shares one row of depths, which is
         # computed once per (near, far, Nc) and never expanded; the sigma-only field kernel reads it; compositing variant D,
         # sample_pdf and the sort run per ray in one kernel, the coarse weights stay in registers.
         with torch.no_grad():
             z_row = ops.coarse_depth_row(Nc, near, far, cfg.lindisp, dev)
-            raw_c = ops.field_sigma_row(pk_c, rays_o.detach(), rays_d.detach(), z_row)
+            raw_c = ops.field_sigma_row(pk_c, rays_o.detach(), rays_d.detach(), z_row, cfg.xyz_encoder)
             z_fine, z_samples = ops.coarse_sample(raw_c, z_row, Ni, want_samples=False)
         return _fine_pass(rays_o, rays_d, viewdirs, z_fine, z_samples, network_fine, cfg, C, field, None)
     t_rand = torch.rand(N, Nc, device=dev) if cfg.perturb > 0. else None            # :110 (RNG stays in torch)

@@ -150,3 +150,73 @@ def test_cambridge_frame_854x480_properties():
         del r, e, part
     P.record("cam_frame_854x480", "pose gradient: sum over two row shards vs the whole frame", direct=rel(acc_g, g1), bound=1e-5)
     assert rel(acc_g, g1) < 1e-5
+
+
+def test_fused_hashgrid_kernels_equal_the_separate_launches():
+    """Round 5: the field kernels gather the hash grid themselves (nefes_field_fwd_h3_hashgrid / nefes_field_bwd_h3_hashgrid:
+    csrc/hashgrid.h).  Against the launches they replace -- nefes_hashgrid_fwd -> [M, 32] -> nefes_field_fwd_h3(xyz_enc), and
+    nefes_field_bwd_h3(g_xyz_enc) -> nefes_hashgrid_bwd_x -- at this configuration's geometry: the forward's raw outputs and ReLU-mask
+    words bit for bit (sigma-only and full), the ray gradients to 1e-5 (the levels' contributions are summed in another order), and a
+    whole render() bit for bit with the fusion switched off."""
+    from nefes_amd import lib as L
+    from nefes_amd import ops
+    from nefes_amd.render import render
+    coarse, fine = nets()
+    table = HG.make_table(0) * TABLE_GAIN
+    grid = ops.HashGrid(BOUND, table=table)
+    g = torch.Generator().manual_seed(5)
+    N, S = 37, 75                                                   # ragged: 2 775 samples, a partial last tile
+    o = ((torch.rand(N, 3, generator=g) - .5) * 8).to(DEV).requires_grad_()
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    v = d.clone().to(DEV).requires_grad_()
+    d = (d * (0.5 + torch.rand(N, 1, generator=g))).to(DEV).requires_grad_()
+    z = torch.sort(torch.rand(N, S, generator=g) * FAR, -1)[0].to(DEV)
+    G = torch.randn(N, 3 + C + 6, S, generator=g).to(DEV)
+    pk_c, pk_f = coarse.packed(), fine.packed()
+    assert ops.hashgrid_fused_ok(pk_f, grid) and ops.hashgrid_fused_ok(pk_c, grid)
+
+    def separate(pk, mode):
+        pts = o[:, None, :] + d[:, None, :] * z[..., None]
+        return ops.FieldFromEncoding.apply(grid(pts), v, pk, mode)
+
+    ops.TIMERS = timers = {}
+    try:
+        with tapped() as tap:
+            sig_f = ops.FieldFromRaysHashGrid.apply(o, d, v, z, pk_c, L.FIELD_SIGMA, grid)
+            raw_f = ops.FieldFromRaysHashGrid.apply(o, d, v, z, pk_f, L.FIELD_FULL, grid)
+            gf = torch.autograd.grad((raw_f * G).sum(), (o, d, v))
+            sig_s = separate(pk_c, L.FIELD_SIGMA)
+            raw_s = separate(pk_f, L.FIELD_FULL)
+            gs = torch.autograd.grad((raw_s * G).sum(), (o, d, v))
+    finally:
+        ops.TIMERS = None
+    assert {"field_fwd[sigma,h3,hashgrid]", "field_fwd[full,h3,hashgrid]", "field_bwd[h3,hashgrid]", "hashgrid_fwd", "hashgrid_bwd_x"} <= set(timers), sorted(timers)
+    assert torch.equal(sig_f, sig_s) and torch.equal(raw_f, raw_s)
+    m_f, m_s = tap["masks"][0][0], tap["masks"][1][0]
+    assert torch.equal(m_f, m_s)                                    # same ReLU-mask words
+    for name, a, b in zip(("d rays_o", "d rays_d", "d viewdirs"), gf, gs):
+        e = rel(a, b)
+        P.record("cam_fused_hashgrid", f"{name}: fused kernels vs separate launches", direct=e, bound=1e-5)
+        assert e < 1e-5, (name, e)
+    # one shared row of depths (the coarse pass at test time): the same sigma as the expanded [N, S] tensor
+    z_row = ops.coarse_depth_row(NC, NEAR, FAR, False, torch.device(DEV))
+    sig_row = ops.field_sigma_row(pk_c, o.detach(), d.detach(), z_row, grid)
+    sig_exp = ops.FieldFromRaysHashGrid.apply(o.detach(), d.detach(), v.detach(), z_row[None].expand(N, NC).contiguous(), pk_c, L.FIELD_SIGMA, grid)
+    assert torch.equal(sig_row, sig_exp)
+    # end to end: render() with and without the fusion
+    kw = kwargs(coarse, fine, grid)
+    H, W = 5, 8
+    focal = FOCAL_AT_854 * W / 854.
+    pose = O.se3_exp_pose((0.4, -0.9, 0.15), (3.0, -2.0, 4.5)).to(DEV)
+    outs = []
+    for fused in (True, False):
+        ops.FUSED_HASHGRID = fused
+        try:
+            c2w = pose.clone().requires_grad_()
+            rgb, disp, acc, ex = render(H, W, focal, c2w=c2w, near=NEAR, far=FAR, **kw)
+            (gc,) = torch.autograd.grad(O.bench_loss(rgb, ex["feat_map"]), c2w)
+            outs.append((rgb.detach(), ex["feat_map"].detach(), disp.detach(), gc))
+        finally:
+            ops.FUSED_HASHGRID = True
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert rel(outs[0][3], outs[1][3]) < 1e-5
