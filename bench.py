@@ -469,10 +469,11 @@ def main():
         fwd_key = next(k for k in kern if k.startswith("field_fwd[full"))
         bwd_key = next(k for k in kern if k.startswith("field_bwd"))
         dom_key = max((fwd_key, bwd_key), key=lambda k: kern[k])
-        h3 = dom_key.endswith("h3]")                      # fp16 two-part split products: three MFMAs per algorithmic product
+        h3 = ",h3" in dom_key or "[h3" in dom_key         # fp16 two-part split products: three MFMAs per algorithmic product
+        grid_in_kernel = "hashgrid" in dom_key            # configs[3], round 5: the field kernels gather the hash grid themselves
         x6 = dom_key.endswith("x6]")
         ach = flop_fwd / (kern[dom_key] * 1e-3) / 1e12
-        enc = int(wl['hashgrid'])
+        enc = 2 if grid_in_kernel else int(wl['hashgrid'])
         if dom_key == bwd_key:
             dom_name = (f"field_bwd_h3_kernel<{Wd},{2 if 3 + C <= 32 else 9},{enc}>" if h3 else
                         f"field_bwd_kernel<{Wd},{3 + C},{enc}{',X6' if x6 else ''}>")
