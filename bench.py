@@ -481,6 +481,8 @@ def main():
             dom_name = (f"field_fwd_h3_kernel<FULL,{enc},{Wd},{1 if 3 + C <= 32 else 5}>" if h3 else
                         "field_fwd_x6_kernel<FULL>" if x6
                         else f"field_fwd_kernel<{Wd},{(3 + C + 31) // 32},FULL,{enc}>")
+        if "fh]" in dom_key:                              # factored feature head (round 5): the 3-row colour head's instance, FH = true
+            dom_name = (f"field_bwd_h3_kernel<{Wd},2,0,FH>" if dom_key == bwd_key else f"field_fwd_h3_kernel<FULL,0,{Wd},1,FH>")
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if h3 else (PEAK_BF16_MFMA_TFLOPS / 6.0 if x6 else PEAK_F32_MFMA_TFLOPS)
         flop_frame = 2.0 * (Nc * macs_sigma(Wd, in_xyz) + 2 * (Nc + Ni) * macs_full(Wd, C, in_xyz)) * n_total
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure

@@ -253,6 +253,18 @@ int nefes_field_bwd_h3_hashgrid(const NefesNetDesc* desc, const void* packed, co
                                 int N, int S, const float* rays_o, const float* rays_d, const float* z, const float* viewdirs,
                                 const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts, float* g_viewdirs_s,
                                 void* stream);
+/* FACTORED HEAD (round 5).  The static rgb+feature head is linear in g = relu(dir_encoding output) (no activation when C > 0:
+ * script/models/nerfh_nff.py:487-490) and so is compositing (feat = sum_s w_s (W_f g_s + b_f), :119-125), so for a network whose head
+ * has more channels than g -- the reference's default: 3 + 128 channels against W/2 = 64 -- the field kernels can emit g instead of the
+ * feature channels and the caller applies W_f once per RAY to the composited g.  `desc` / `packed`: the network packed WITHOUT its
+ * feature rows (feat_dim = 0, static_rgb = its first three rows); raw_t / g_raw_t [N][3 + (W/2 + 1) + 6][S] = rgb (3) | g (W/2) | a
+ * channel of ones (its composite is sum_s w_s, the bias's factor) | sigma | transient rgb (3), sigma, beta: what nefes_composite_fwd /
+ * _bwd take with C = W/2 + 1.  Width 128, frequency embedding, full head, frozen weights. */
+int nefes_field_fwd_h3_fh(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                          const float* rays_d, const float* z, const float* viewdirs, float* raw_t, uint32_t* masks, void* stream);
+int nefes_field_bwd_h3_fh(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
+                          const float* z, const float* viewdirs, const float* raw_t, const float* g_raw_t, const uint32_t* masks,
+                          float* g_pts, float* g_viewdirs_s, void* stream);
 /* nefes_field_bwd_static on the fp16 two-part pipe (round 5): backward-to-inputs of a NEFES_FIELD_STATIC forward
  * (nefes_field_fwd_h3 accepts that mode for the frequency embedding) for every compiled (width, head class) pair -- a frozen coarse
  * network with test_time False (script/models/rendering.py:116-125) or a fine network with NeRFW off

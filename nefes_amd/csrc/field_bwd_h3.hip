@@ -66,6 +66,7 @@ struct FieldBwdH3Args {
     int rows;
     const float2* hg_table; // NEFES_XYZ_HASHGRID_FUSED: the hash-grid table and its level geometry (hashgrid.h)
     HgGeom hg;
+    int gout;               // FH instances (field_fwd_h3.hip): W / 2 channels of d loss / d relu(dir_encoding) in the feature channels' place
 };
 
 // TRAIN instances: the (masked) gradient vector a product consumes is d loss / d pre-activation of a hidden layer, which the
@@ -108,7 +109,9 @@ __device__ __forceinline__ T ld_stream(const T* p) {
 // NEFES_STREAM_BWD_STATIC_H3 and the transient segments are absent.  TRAIN: see StoringSplitH.
 // KR16 = k-steps of 16 upstream channels of static_rgb^T = the head class of layout.h (2: 3 + C <= 32; 9: 3 + C <= 144); C itself is
 // a run-time argument (a.C).  ENC = NEFES_XYZ_*
-template <int W, int KR16, int ENC, bool HAS_T = true, bool TRAIN = false>
+// FH: the factored head of field_fwd_h3.hip -- the upstream gradient carries d loss / d g (g = relu(dir_encoding)) in raw channels
+// 3 .. 3 + W/2, which joins the 3-row colour head's transposed product in front of dir_encoding^T.
+template <int W, int KR16, int ENC, bool HAS_T = true, bool TRAIN = false, bool FH = false>
 __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kernel(FieldBwdH3Args a) {
     constexpr int NTW = W / 32, NTH = W / 64, HS = W / 2, GS = W / 4;
     constexpr int MW = 8 * (W / 64) + 4 * (W / 128);
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
         // row offsets out of the tile loop (144 registers at KR16 = 9, spilled to scratch -- seen in the disassembly).
         // (the same for 3 + C, whose 2 x 8 KR16 wave-uniform comparisons would be hoisted into spilled scalar registers)
         {
-            int S_t = a.S, c3 = C3;
+            int S_t = a.S, c3 = FH ? 3 : C3;                  // (FH: only the three colour channels feed the head's transposed product)
             asm volatile("" : "+s"(S_t), "+s"(c3));
             const float* g0 = a.g_raw_t + chan0;
             const float* g4 = g0 + (size_t)(4 * h) * S_t;
@@ -295,13 +298,35 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
         //      (KR16 k-steps of v_mfma_f32_32x32x16_f16 x 3; it was (3+C)/2 k-steps of the 64-cycle fp32 MFMA: a fifth of the matrix
         //      time at C = 128).  The operand's exact maximum is known here, so its exponent is picked from it. ----
         const float M_dr = pair_max(array_max(dr));
+        // FH: d loss / d g of this lane's sample sits in raw channels 3 + feature (element 16 t + r <-> feature 32 t + rho_h(r)).  It joins
+        // G2 where dir_encoding^T reads it (MaskedAddSplitH), but its largest magnitude is needed before that, for the exponent the
+        // transient_encoding.0^T / dir_encoding^T pair shares: the values are read TWICE -- here for the maximum only, and again in front of
+        // that pair (the second read hits L2) -- rather than kept in 32 registers through the four runs in between (spills; and as the C
+        // operand / a VALU update of G2 they broke the fp32 run behind the head's: tools/dbg_fh.py).
+        auto load_dg = [&](float (&dst)[FH ? 16 * NTH : 1]) {
+            if constexpr (FH) {
+                int S_g = a.S;
+                asm volatile("" : "+s"(S_g)::"memory");
+                const float* gg = a.g_raw_t + chan0 + (size_t)(3 + 4 * h) * S_g;
+#pragma unroll
+                for (int e = 0; e < 16 * NTH; ++e) dst[e] = valid ? ld_stream(gg + (size_t)(32 * (e >> 4) + nefes_rho(0, e & 15)) * S_g) : 0.f;
+            } else {
+                dst[0] = 0.f;
+            }
+        };
+        float M_dg = 0.f;
+        if constexpr (FH) {
+            float tmp[16 * NTH];
+            load_dg(tmp);
+            M_dg = pair_max(array_max(tmp));
+        }
         int es_g2;
         {
             const int ew = wexp(NEFES_H3B_RGB), tau = tau_of(M_dr, ew);
             es_g2 = tau + ew;
             mma_run_h3<NTH, KR16, 0, true>(ring, ring_lane, ArraySplitH<8 * KR16>{dr, pow2i(tau)}, ZeroInit{}, G2);
         }
-        const float M_g2 = rowb(NEFES_H3B_RGB) * M_dr;
+        const float M_g2 = rowb(NEFES_H3B_RGB) * M_dr + M_dg;
         float M = 0.f;
         int es3 = 0;
         if constexpr (HAS_T) {
@@ -339,11 +364,16 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
             const int tau = tau_of(HAS_T ? fmaxf(M, M_g2) : M_g2, ew);
             float mt = 0.f, mg = 0.f;
             es_dt = tau + ew;
+            float dgv[FH ? 16 * NTH : 1];
+            load_dg(dgv);                                          // (in flight behind the transient_encoding.0^T run)
             if constexpr (HAS_T) {
                 load_bits(bh, MW_TRUNK + WH, WH);
                 mma_run_h3<NTW + 1, GS / 8, 1, true>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{T3, bh, pow2i(tau - es3), mt}, gptr(NEFES_TB_T0), pow2i(-es3)), ZeroInit{}, XA);
             }
             load_bits(bh, MW_TRUNK, WH);
+            if constexpr (FH)
+                mma_run_h3<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, MaskedAddSplitH<NTH, WH, 0, 16 * NTH>{G2, bh, pow2i(tau - es_g2), mg, dgv, pow2i(es_g2)}, ZeroInit{}, XA);
+            else
             mma_run_h3<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{G2, bh, pow2i(tau - es_g2), mg}, gptr(NEFES_TB_DIR), pow2i(-es_g2)), ZeroInit{}, XA);
             M = (HAS_T ? rowb(NEFES_H3B_T0) * (pair_max(mt) * pow2i(-es3)) : 0.f) + rowb(NEFES_H3B_DIR) * (pair_max(mg) * pow2i(-es_g2));
         }
@@ -487,13 +517,13 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
     ring.drain();
 }
 
-template <int W, int KR16, int ENC, bool HAS_T = true, bool TRAIN = false>
+template <int W, int KR16, int ENC, bool HAS_T = true, bool TRAIN = false, bool FH = false>
 static int launch_bwd_h3(const FieldBwdH3Args& a, hipStream_t st) {
     const size_t lds = (size_t)NEFES_H3B_SLOTS * NEFES_SLAB_BYTES
                        + (size_t)4 * (8 * (W / 64) + 4 * (W / 128) + (ENC == NEFES_XYZ_HASHGRID_FUSED ? 24 : 8)) * 256 + 256
                        + (ENC == NEFES_XYZ_HASHGRID_FUSED ? 512 : 0);
     static_assert(sizeof(HgGeom) <= 512 && 2 * NEFES_H3B_N <= 64, "scale table (256 bytes) + the level geometry's LDS slot");
-    auto k = field_bwd_h3_kernel<W, KR16, ENC, HAS_T, TRAIN>;
+    auto k = field_bwd_h3_kernel<W, KR16, ENC, HAS_T, TRAIN, FH>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -512,7 +542,7 @@ static int launch_bwd_h3(const FieldBwdH3Args& a, hipStream_t st) {
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { BWD_H3_EXT = 0, BWD_H3_FULL, BWD_H3_TRAIN_STATIC, BWD_H3_TRAIN_FULL, BWD_H3_STATIC, BWD_H3_HG };
+enum { BWD_H3_EXT = 0, BWD_H3_FULL, BWD_H3_TRAIN_STATIC, BWD_H3_TRAIN_FULL, BWD_H3_STATIC, BWD_H3_HG, BWD_H3_FH };
 int nefes_bwd_h3_launch_part1(int which, const FieldBwdH3Args& a, hipStream_t st);
 int nefes_bwd_h3_launch_part2(int which, const FieldBwdH3Args& a, hipStream_t st);
 int nefes_bwd_h3_launch_part3(int which, const FieldBwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256, class 0
@@ -561,6 +591,7 @@ int nefes_bwd_h3_launch_part5(int which, const FieldBwdH3Args& a, hipStream_t st
 int nefes_bwd_h3_launch_part6(int which, const FieldBwdH3Args& a, hipStream_t st) {
     if (which == BWD_H3_FULL) return launch_bwd_h3<128, 2, NEFES_XYZ_FREQ10>(a, st);
     if (which == BWD_H3_STATIC) return launch_bwd_h3<128, 2, NEFES_XYZ_FREQ10, false>(a, st);
+    if (which == BWD_H3_FH) return launch_bwd_h3<128, 2, NEFES_XYZ_FREQ10, true, false, true>(a, st);      // factored head (round 5)
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 7
@@ -604,7 +635,7 @@ extern "C" int nefes_field_bwd_train_h3(const NefesNetDesc* desc, const void* pa
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + (full ? 6 : 1);
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
-    a.dacts = dacts;
+    a.dacts = dacts; a.gout = 0; a.hg_table = nullptr;
     a.rows = nefes_train_row(desc->width, desc->feat_dim, NEFES_TB_END);
     const int which = full ? BWD_H3_TRAIN_FULL : BWD_H3_TRAIN_STATIC;
     hipStream_t st = (hipStream_t)stream;
@@ -637,7 +668,7 @@ extern "C" int nefes_field_bwd_static_h3(const NefesNetDesc* desc, const void* p
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + 1;
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
-    a.dacts = nullptr; a.rows = 0;
+    a.dacts = nullptr; a.rows = 0; a.gout = 0; a.hg_table = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (desc->width == 256) return cls == 0 ? nefes_bwd_h3_launch_part1(BWD_H3_STATIC, a, st) : nefes_bwd_h3_launch_part5(BWD_H3_STATIC, a, st);
     return cls == 1 ? nefes_bwd_h3_launch_part2(BWD_H3_STATIC, a, st) : nefes_bwd_h3_launch_part6(BWD_H3_STATIC, a, st);
@@ -646,7 +677,8 @@ extern "C" int nefes_field_bwd_static_h3(const NefesNetDesc* desc, const void* p
 static int field_bwd_h3_impl(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o,
                                   const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                   const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
-                                  float* g_xyz_enc, float* g_viewdirs_s, void* stream, const NefesHashGridDesc* grid, const float* table) {
+                                  float* g_xyz_enc, float* g_viewdirs_s, void* stream, const NefesHashGridDesc* grid, const float* table,
+                                  bool fh = false) {
     if (!desc || !packed || !viewdirs || !raw_t || !g_raw_t || !masks || !g_viewdirs_s || N <= 0 || S <= 0)
         return NEFES_E_BADARG;
     const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
@@ -665,6 +697,13 @@ static int field_bwd_h3_impl(const NefesNetDesc* desc, const void* packed, int N
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.viewdirs = viewdirs;
     a.raw_t = raw_t; a.g_raw_t = g_raw_t; a.masks = masks; a.g_pts = g_pts; a.g_enc = g_xyz_enc; a.g_vs = g_viewdirs_s;
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + 6;
+    a.gout = 0;
+    if (fh) {                                                     // factored head: see nefes_field_fwd_h3_fh
+        if (desc->feat_dim != 0 || desc->width != 128 || ext) return NEFES_E_UNSUPPORTED;
+        a.gout = desc->width / 2;
+        a.C = a.gout + 1;
+        a.R = 3 + a.C + 6;
+    }
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
     a.dacts = nullptr; a.rows = 0;
@@ -677,6 +716,7 @@ static int field_bwd_h3_impl(const NefesNetDesc* desc, const void* packed, int N
     hipStream_t st = (hipStream_t)stream;
     const int cls = nefes_head_class(desc->feat_dim);          // compiled set: as nefes_field_fwd_h3
     if (cls < 0) return NEFES_E_UNSUPPORTED;
+    if (fh) return nefes_bwd_h3_launch_part6(BWD_H3_FH, a, st);
     if (desc->width == 256 && fused_grid) return cls == 0 ? nefes_bwd_h3_launch_part3(BWD_H3_HG, a, st) : NEFES_E_UNSUPPORTED;
     if (desc->width == 256 && ext) return cls == 0 ? nefes_bwd_h3_launch_part1(BWD_H3_EXT, a, st) : NEFES_E_UNSUPPORTED;
     if (desc->width == 256) return cls == 0 ? launch_bwd_h3<256, 2, NEFES_XYZ_FREQ10>(a, st) : nefes_bwd_h3_launch_part5(BWD_H3_FULL, a, st);
@@ -690,6 +730,16 @@ extern "C" int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, 
                                   float* g_xyz_enc, float* g_viewdirs_s, void* stream) {
     return field_bwd_h3_impl(desc, packed, N, S, rays_o, rays_d, z, pts, viewdirs, raw_t, g_raw_t, masks, g_pts, g_xyz_enc, g_viewdirs_s, stream,
                              nullptr, nullptr);
+}
+
+// nefes_field_bwd_h3 for a nefes_field_fwd_h3_fh forward: g_raw_t [N][3 + (W/2 + 1) + 6][S] carries d loss / d g in channels 3 .. 3 + W/2
+// (the gradient of the ones channel is ignored).
+extern "C" int nefes_field_bwd_h3_fh(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
+                                     const float* z, const float* viewdirs, const float* raw_t, const float* g_raw_t,
+                                     const uint32_t* masks, float* g_pts, float* g_viewdirs_s, void* stream) {
+    if (!rays_o || !rays_d || !z) return NEFES_E_BADARG;
+    return field_bwd_h3_impl(desc, packed, N, S, rays_o, rays_d, z, nullptr, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr, g_viewdirs_s, stream,
+                             nullptr, nullptr, true);
 }
 
 // nefes_field_bwd_h3 for a nefes_field_fwd_h3_hashgrid forward: g_pts [N*S, 3] = d loss / d (o + d z) through the MLP AND the hash

@@ -52,6 +52,7 @@ struct FieldFwdH3Args {
     int z_row;               // 1: `z` is ONE row of S depths shared by every ray (scalar near / far, no jitter: rendering.py:96-100)
     const float2* hg_table;  // NEFES_XYZ_HASHGRID_FUSED: the hash-grid table and its level geometry (hashgrid.h)
     HgGeom hg;
+    int gout;                // FH instances: W / 2 = the channels of relu(dir_encoding) written in place of the feature head's outputs
 };
 
 // TRAIN: tiles X[T0 .. T0+NT) hold a layer's pre-activations times 2^es; rows [row0, row0 + 32 NT) of this tile of `acts` get
@@ -71,7 +72,12 @@ __device__ __forceinline__ void train_save_h3(float* tile_base, uint32_t voff, i
 // ENC: NEFES_XYZ_FREQ10 or NEFES_XYZ_EXTERNAL32 (hash grid); W = 128 or 256; NTR = tiles of the rgb+feature head = the head class
 // of layout.h (1: 3 + C <= 32, e.g. BASELINE's C = 16; 5: 3 + C <= 144, e.g. the reference's FEATURE_DIM = 128) -- C itself is a
 // run-time argument.  TRAIN: every hidden layer's pre-activation and both embeddings also go to a.acts (weight gradients).
-template <int MODE, int ENC, int W = 256, int NTR = 1, bool TRAIN = false>
+// FH ("factored head", round 5): the network's static rgb+feature head is LINEAR in g = relu(dir_encoding) and so is compositing
+// (raw2outputs: feat = sum_s w_s (W_f g_s + b_f), nerfh_nff.py:119-125 -- no activation on the head when C > 0, :487-490), so a network
+// whose head has more channels than g (the reference's default: 3 + 128 against 64) emits g itself -- W/2 channels + a channel of ones
+// (for b_f sum_s w_s) in the feature channels' place, the 3 colour channels from a 3-row head (head class 0) -- and the caller applies
+// W_f once per RAY to the composited g (nefes_amd/render.py).  44 of the head's 60 MFMAs per 32 samples and 63 of 137 raw channels go.
+template <int MODE, int ENC, int W = 256, int NTR = 1, bool TRAIN = false, bool FH = false>
 __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(FieldFwdH3Args a) {
     static_assert(NEFES_SLAB_KIB == (W == 128 ? NEFES_H3_FWD_SLAB_KIB_128 : NEFES_H3_FWD_SLAB_KIB), "ring slab size != the packer's for this width");
     constexpr int NTW = W / 32, NTH = W / 64;
@@ -348,6 +354,22 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                     if constexpr (FULL) train_save_h3<NTH, NTH>(act_tile, act_voff, nefes_train_row(W, 0, NEFES_TB_T0), dt, pow2i(-es_dt));
                 }
             }
+            if constexpr (FH) {
+                // g = relu(dir_encoding output) in true units -> raw channels 3 + feature (feature 32 t + rho_h(r)); ones -> channel 3 + W/2
+                float* col = raw_col();
+                if (col) {
+                    int S_g = a.S;
+                    asm volatile("" : "+s"(S_g));
+                    const float inv = pow2i(-es_dt);
+                    float* pg = col + (size_t)(3 + 4 * h) * S_g;
+#pragma unroll
+                    for (int t = 0; t < NTH; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            __builtin_nontemporal_store(fmaxf(dt[t][r] * inv, 0.f), &pg[(size_t)(32 * t + nefes_rho(0, r)) * S_g]);
+                    if (h == 0) __builtin_nontemporal_store(1.f, &col[(size_t)(3 + W / 2) * S_g]);
+                }
+            }
             {
                 f32x16 ar[NTR];
                 clear2();
@@ -363,7 +385,7 @@ __global__ __launch_bounds__(256, W == 128 ? 2 : 1) void field_fwd_h3_kernel(Fie
                     // C is a run-time value inside the head class: tiles whose 32 rows are all channels store unpredicated (a
                     // wave-uniform test per tile), the tile that holds row 3 + C carries a per-lane predicate, the padding tiles
                     // behind it store nothing (80 predicated stores per tile at C = 128 otherwise)
-                    int S_t = a.S, c3 = 3 + a.C;                  // opaque per tile: the 16 NTR row offsets cu * S and the channel tests
+                    int S_t = a.S, c3 = FH ? 3 : 3 + a.C;         // opaque per tile: the 16 NTR row offsets cu * S and the channel tests
                     asm volatile("" : "+s"(S_t), "+s"(c3));      // are recomputed by the scalar ALU here instead of being hoisted out
                     const int full = c3 >> 5;                     // of the tile loop into (spilled) registers
 #pragma unroll
@@ -445,13 +467,13 @@ static void magic_div(uint32_t d, uint32_t& magic, uint32_t& shift) {
     shift = (uint32_t)(p - 32);
 }
 
-template <int MODE, int ENC, int W = 256, int NTR = 1, bool TRAIN = false>
+template <int MODE, int ENC, int W = 256, int NTR = 1, bool TRAIN = false, bool FH = false>
 static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
     constexpr int ES_ = ENC != NEFES_XYZ_FREQ10 ? NEFES_X_STEPS : NEFES_E_STEPS;
     const size_t lds = (size_t)NEFES_H3_SLOTS * NEFES_SLAB_BYTES + ((a.bias_floats + 63) / 64) * 256 + (size_t)4 * ES_ * 64 * 4
                        + (ENC == NEFES_XYZ_HASHGRID_FUSED ? 512 : 0);
     static_assert(sizeof(HgGeom) <= 512, "the level geometry's LDS slot");
-    auto k = field_fwd_h3_kernel<MODE, ENC, W, NTR, TRAIN>;
+    auto k = field_fwd_h3_kernel<MODE, ENC, W, NTR, TRAIN, FH>;
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
@@ -475,7 +497,7 @@ static int launch_h3(const FieldFwdH3Args& a, hipStream_t st) {
 #ifndef NEFES_TU_PART
 #define NEFES_TU_PART 0
 #endif
-enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_SIGMA, H3_FULL, H3_TRAIN_STATIC, H3_TRAIN_FULL, H3_STATIC, H3_HG_SIGMA, H3_HG_FULL };
+enum { H3_EXT_SIGMA = 0, H3_EXT_FULL, H3_SIGMA, H3_FULL, H3_TRAIN_STATIC, H3_TRAIN_FULL, H3_STATIC, H3_HG_SIGMA, H3_HG_FULL, H3_FH_FULL };
 int nefes_fwd_h3_launch_part1(int which, const FieldFwdH3Args& a, hipStream_t st);
 int nefes_fwd_h3_launch_part2(int which, const FieldFwdH3Args& a, hipStream_t st);
 int nefes_fwd_h3_launch_part3(int which, const FieldFwdH3Args& a, hipStream_t st);   // TRAIN instances, Wd = 256, class 0
@@ -537,6 +559,7 @@ int nefes_fwd_h3_launch_part5(int which, const FieldFwdH3Args& a, hipStream_t st
 int nefes_fwd_h3_launch_part6(int which, const FieldFwdH3Args& a, hipStream_t st) {
     if (which == H3_FULL) return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 1>(a, st);
     if (which == H3_STATIC) return launch_h3<NEFES_FIELD_STATIC, NEFES_XYZ_FREQ10, 128, 1>(a, st);
+    if (which == H3_FH_FULL) return launch_h3<NEFES_FIELD_FULL, NEFES_XYZ_FREQ10, 128, 1, false, true>(a, st);      // factored head (round 5)
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 7
@@ -583,7 +606,7 @@ extern "C" int nefes_field_fwd_train_h3(const NefesNetDesc* desc, const void* pa
     a.n_tiles = (int)((a.M + 127) / 128);
     a.acts = acts;
     a.rows = nefes_train_row(desc->width, desc->feat_dim, NEFES_TB_END);
-    a.z_row = 0;
+    a.z_row = 0; a.gout = 0; a.hg_table = nullptr;
     magic_div((uint32_t)S, a.s_magic, a.s_shift);
     const int which = mode == NEFES_FIELD_STATIC ? H3_TRAIN_STATIC : H3_TRAIN_FULL;
     hipStream_t st = (hipStream_t)stream;
@@ -594,7 +617,7 @@ extern "C" int nefes_field_fwd_train_h3(const NefesNetDesc* desc, const void* pa
 static int field_fwd_h3_impl(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                              const float* rays_d, const float* z, int z_row, const float* pts, const float* xyz_enc,
                              const float* viewdirs, float* raw_t, uint32_t* masks, void* stream,
-                             const NefesHashGridDesc* grid = nullptr, const float* table = nullptr) {
+                             const NefesHashGridDesc* grid = nullptr, const float* table = nullptr, bool fh = false) {
     if (!desc || !packed || !raw_t || N <= 0 || S <= 0) return NEFES_E_BADARG;
     const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
     const bool fused_grid = ext && table != nullptr;            // the kernel gathers the 32 features itself (hashgrid.h)
@@ -626,11 +649,21 @@ static int field_fwd_h3_impl(const NefesNetDesc* desc, const void* packed, int m
         if (a.hg.n_levels != 16) return NEFES_E_UNSUPPORTED;       // sixteen levels x two features = the network's 32 inputs
     }
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = mode == NEFES_FIELD_SIGMA ? 1 : 3 + a.C + (mode == NEFES_FIELD_STATIC ? 1 : 6);
+    a.gout = 0;
+    if (fh) {
+        // factored head: a network packed WITHOUT its feature rows (feat_dim 0: the 3-row colour head) whose raw output carries
+        // g = relu(dir_encoding) and a channel of ones where the feature channels would be: C' = W/2 + 1 "feature" channels
+        if (desc->feat_dim != 0 || desc->width != 128 || ext || mode != NEFES_FIELD_FULL) return NEFES_E_UNSUPPORTED;
+        a.gout = desc->width / 2;
+        a.C = a.gout + 1;
+        a.R = 3 + a.C + 6;
+    }
     a.M = (long long)N * S;
     if (a.M >= (1ll << 31) - 256) return NEFES_E_UNSUPPORTED;      // the kernel indexes samples with 32 bits
     a.n_tiles = (int)((a.M + 127) / 128);
     magic_div((uint32_t)S, a.s_magic, a.s_shift);
     hipStream_t st = (hipStream_t)stream;
+    if (fh) return nefes_fwd_h3_launch_part6(H3_FH_FULL, a, st);
     if (mode == NEFES_FIELD_STATIC) {
         // The static head alone at inference (round 5): what a frozen coarse network runs when test_time is False (rendering.py:116-125)
         // and a fine network with NeRFW off (nerfh_nff.py:217-231 with output_transient False) -- the TRAIN instances' kernel without
@@ -664,6 +697,15 @@ extern "C" int nefes_field_fwd_h3_hashgrid(const NefesNetDesc* desc, const void*
     if (!desc || desc->xyz_encoding != NEFES_XYZ_EXTERNAL32 || !grid || !table) return NEFES_E_BADARG;
     return field_fwd_h3_impl(desc, packed, mode, N, S, rays_o, rays_d, z, z_is_row ? 1 : 0, nullptr, nullptr, viewdirs, raw_t, masks, stream,
                              grid, table);
+}
+
+// Factored head (see the kernel's FH parameter): `desc` / `packed` describe the network WITHOUT its feature rows (feat_dim 0);
+// raw_t [N][3 + (W/2 + 1) + 6][S] = rgb (3) | relu(dir_encoding) (W/2) | ones | sigma | transient rgb (3), sigma, beta.
+extern "C" int nefes_field_fwd_h3_fh(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
+                                     const float* rays_d, const float* z, const float* viewdirs, float* raw_t, uint32_t* masks,
+                                     void* stream) {
+    if (!rays_o || !rays_d || !z) return NEFES_E_BADARG;
+    return field_fwd_h3_impl(desc, packed, mode, N, S, rays_o, rays_d, z, 0, nullptr, nullptr, viewdirs, raw_t, masks, stream, nullptr, nullptr, true);
 }
 
 // The same pass with ONE row of S depths shared by every ray (`z_row` [S]): the coarse pass at test time with scalar near / far

@@ -277,6 +277,30 @@ struct MaskedSplitH {
     template <bool NOP>
     __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
 };
+// MaskedSplitH whose values get a per-lane addend first: x = acc + add[e] * sa (element e = 8 q + 2 p of the k-step; sa brings the
+// addend to the accumulators' scale) -- the factored head's d loss / d g joining the colour head's transposed product in front of
+// dir_encoding^T (field_bwd_h3.hip FH).
+template <int NX, int NWORDS, int T0, int NADD>
+struct MaskedAddSplitH {
+    const f32x16 (&X)[NX];
+    uint32_t (&bits)[NWORDS];
+    float r;
+    float& m;
+    const float (&add)[NADD];
+    float sa;
+    __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
+        const float x0 = __builtin_fmaf(add[8 * q + 2 * p], sa, acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]));
+        const float x1 = __builtin_fmaf(add[8 * q + 2 * p + 1], sa, acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]));
+        s.x0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], x0);
+        s.x1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], x1);
+    }
+    __device__ __forceinline__ void stage_b(PairRegs& s) const { absmax3_acc(m, s.x0, s.x1); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c(Split2& o, int p, const PairRegs& s) const { split_pair_h<NOP>(o, p, s.x0, s.x1, r); }
+    __device__ __forceinline__ void stage_c1(Split2& o, int p, const PairRegs& s) const { split_pair_hi(o, p, s.x0, s.x1, r); }
+    template <bool NOP>
+    __device__ __forceinline__ void stage_c2(Split2& o, int p, const PairRegs& s) const { split_pair_lo<NOP>(o, p, s.x0, s.x1, r); }
+};
 template <int NX, int T0>
 struct IdentSplitH {
     const f32x16 (&X)[NX];

@@ -239,6 +239,31 @@ class NeRFH_NFF(nn.Module):
             self._pk_key = key
         return self._pk
 
+    def factored_head_ok(self):
+        """The factored-head kernels apply (csrc/field_fwd_h3.hip FH): a FROZEN fine network of width 128 on the frequency embedding whose
+        rgb+feature head has more channels than g = relu(dir_encoding) has features (+ the ones channel), on the fp16 two-part pipe."""
+        return (ops.FACTORED_HEAD and self.encode_transient and self.W == 128 and self.in_channels_xyz != 32 and self._supported()
+                and 3 + self.W_features > 3 + self.W // 2 + 1 and ops.SPLIT == "h3"
+                and not any(p.requires_grad for n, p in self.named_parameters()
+                            if not n.startswith(("fusion_net", "exposure_embedding"))))
+
+    def packed_fh(self):
+        """(PackedField of the network WITHOUT its feature rows -- static_rgb = its three colour rows, f_dim 0 --, W_f [C, W/2], b_f [C]):
+        what the factored-head kernels and the per-ray feature head of nefes_amd/render.py take.  Cached like packed()."""
+        names = ops.PackedField.LAYERS_FINE
+        sd = dict(self.named_parameters())
+        prm = [sd[n + s] for n in names for s in (".weight", ".bias")]
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in prm)
+        if getattr(self, "_pk_fh", None) is None or key != self._pk_fh_key:
+            dev = prm[0].device if prm[0].is_cuda else torch.device("cuda")
+            ksd = dict(self._kernel_params({n: p.detach() for n, p in sd.items()}))
+            w, b = ksd["static_rgb.0.weight"], ksd["static_rgb.0.bias"]
+            ksd["static_rgb.0.weight"], ksd["static_rgb.0.bias"] = w[:3].contiguous(), b[:3].contiguous()
+            pk = ops.PackedField(ksd, self.W, 0, True, dev, L.XYZ_FREQ10)
+            self._pk_fh = (pk, w[3:].to(dev, torch.float32).contiguous(), b[3:].to(dev, torch.float32).contiguous())
+            self._pk_fh_key = key
+        return self._pk_fh
+
     # -- nn.Module API on pre-embedded inputs (not on the render path) ---------------------------
     def forward(self, x, sigma_only=False, output_transient=True):
         if sigma_only:

@@ -538,6 +538,54 @@ class FieldFromRays(torch.autograd.Function):
         return g_o, g_d, g_v, None, None, None
 
 
+# The factored feature head (csrc/field_fwd_h3.hip FH, nefes_amd/render.py): a frozen width-128 fine network emits g = relu(dir_encoding)
+# instead of its 128 feature channels and the head's matrix is applied once per ray to the composited g; "0": the plain kernels.
+FACTORED_HEAD = os.environ.get("NEFES_FACTORED_HEAD", "1") != "0"
+
+
+class FieldFromRaysFH(torch.autograd.Function):
+    """FieldFromRays for the factored head: raw_t [N, 3 + (W/2 + 1) + 6, S] = rgb | g | ones | sigma | transient (5); pk = the network packed
+    without its feature rows (NeRFH_NFF.packed_fh).  Differentiable w.r.t. rays_o, rays_d, viewdirs (frozen weights)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, viewdirs, z, pk):
+        rays_o, rays_d, viewdirs, z = _f32(rays_o), _f32(rays_d), _f32(viewdirs), _f32(z)
+        N, S = z.shape
+        if N * S >= (1 << 31) - 256:
+            raise RuntimeError("nefes_amd: too many samples for one launch of the fp16 two-part kernels (32-bit sample index)")
+        need = any(ctx.needs_input_grad[:3])
+        R = 3 + pk.width // 2 + 1 + 6
+        raw_t = torch.empty(N, R, S, device=z.device)
+        masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=z.device) if need else None
+        with _timed("field_fwd[full,h3,fh]"):
+            L.check(L.load().nefes_field_fwd_h3_fh(pk.desc, _chk(pk.blob, "blob", torch.uint8), L.FIELD_FULL, N, S, _chk(rays_o, "rays_o"),
+                                                   _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(viewdirs, "viewdirs"), _chk(raw_t, "raw_t"),
+                                                   _chk(masks, "masks", torch.int32), _stream()), "nefes_field_fwd_h3_fh")
+        if masks is not None:
+            _tap("masks", (masks, N, S, pk.width, L.FIELD_FULL))
+        ctx.pk, ctx.have, ctx.pk_gen = pk, need, pk.generation
+        if need:
+            ctx.save_for_backward(rays_o, rays_d, viewdirs, z, raw_t, masks)
+        return raw_t
+
+    @staticmethod
+    def backward(ctx, g_raw_t):
+        if not ctx.have:
+            return None, None, None, None, None
+        rays_o, rays_d, viewdirs, z, raw_t, masks = ctx.saved_tensors
+        N, S = z.shape
+        pk = ctx.pk
+        pk.check_generation(ctx.pk_gen)
+        g_pts, g_vs = torch.empty(N * S, 3, device=z.device), torch.empty(N * S, 3, device=z.device)
+        with _timed("field_bwd[h3,fh]"):
+            L.check(L.load().nefes_field_bwd_h3_fh(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
+                                                   _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(viewdirs, "viewdirs"), _chk(raw_t, "raw_t"),
+                                                   _chk(_f32(g_raw_t), "g_raw_t"), _chk(masks, "masks", torch.int32), _chk(g_pts, "g_pts"),
+                                                   _chk(g_vs, "g_vs"), _stream()), "nefes_field_bwd_h3_fh")
+        g_o, g_d, g_v = ray_grad_reduce(N, S, z, g_pts, g_vs)
+        return g_o, g_d, g_v, None, None
+
+
 class FieldFromPoints(torch.autograd.Function):
     """run_network_NeRFH_NFF call surface: explicit pts [N,S,3] (+ viewdirs [N,3]) -> raw_t [N,R,S]."""
 

@@ -179,10 +179,28 @@ def _fine_pass(rays_o, rays_d, viewdirs, z_fine, z_samples, network_fine, cfg, C
     (rgb0, feat0, disp0, acc0) of a differentiable coarse pass, or None (test time)."""
     rgb0, feat0, disp0, acc0 = coarse_maps if coarse_maps is not None else (None, None, None, None)
     z_f = z_samples if cfg.use_fine_only else z_fine
+    flags = 0
+    if (cfg.test_time and cfg.NeRFW and cfg.nerfh_nff and cfg.xyz_encoder is None and cfg.raw_noise_std == 0.
+            and z_f.shape[0] * z_f.shape[1] < (1 << 31) - 256 and network_fine.factored_head_ok()):
+        # FACTORED HEAD (frozen width-128 network, test time).  The rgb+feature head is linear in g = relu(dir_encoding) and compositing is
+        # linear in the head's outputs with weights that do not depend on them (nerfh_nff.py:119-125, :487-490):
+        #     feat = sum_s w_s (W_f g_s + b_f) = W_f (sum_s w_s g_s) + b_f sum_s w_s.
+        # The field kernels emit g (64 channels) + a channel of ones instead of the 128 feature channels, the compositor runs on 65
+        # "features", and W_f is applied once per ray: 63 of 137 raw channels and 44 of the head's 60 MFMAs per 32 samples go.
+        pk_fh, w_f, b_f = network_fine.packed_fh()
+        raw_f = ops.FieldFromRaysFH.apply(rays_o, rays_d, viewdirs, z_f, pk_fh)
+        flags |= L.COMP_TRANSIENT
+        if not cfg.transient_at_test:
+            flags |= L.COMP_STATIC_ONLY
+        if cfg.white_bkgd:
+            flags |= L.COMP_WHITE_BKGD
+        Cg = network_fine.W // 2
+        rgb, gmap, disp, acc, depth, weights, beta = ops.Composite.apply(raw_f, z_f, Cg + 1, flags, float(network_fine.beta_min))
+        feat = torch.addmm(gmap[:, Cg:] * b_f[None, :], gmap[:, :Cg], w_f.t())        # [N, C]: once per ray
+        return {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "feat_map": feat}
     pk_f = network_fine.packed()
     mode = L.FIELD_FULL if cfg.NeRFW else L.FIELD_STATIC
     raw_f = field(network_fine, pk_f, mode, z_f)
-    flags = 0
     if cfg.NeRFW:
         flags |= L.COMP_TRANSIENT
         if cfg.test_time and not cfg.transient_at_test:

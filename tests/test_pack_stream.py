@@ -640,9 +640,9 @@ def test_no_accumulator_tile_is_relocated_inside_the_asm_scheduled_kernels(tmp_p
                 continue
             if name is None:
                 continue
-            # forward: field_fwd_h3_kernel<MODE, ENC, 256, ...> (inference); backward: field_bwd_h3_kernel<256, C3, ENC, HAS_T, false>
-            wide = (re.match(r"void field_fwd_h3_kernel<\d+, \d+, 256, \d+, false>", name) or
-                    re.match(r"void field_bwd_h3_kernel<256, \d+, [01], (true|false), false>", name))      # (HAS_T false: the static-head instances of round 5;
+            # forward: field_fwd_h3_kernel<MODE, ENC, 256, NTR, false, FH> (inference); backward: field_bwd_h3_kernel<256, KR16, ENC, HAS_T, false, FH>
+            wide = (re.match(r"void field_fwd_h3_kernel<\d+, \d+, 256, \d+, false, (true|false)>", name) or
+                    re.match(r"void field_bwd_h3_kernel<256, \d+, [01], (true|false), false, (true|false)>", name))      # (HAS_T false: the static-head instances of round 5;
             # ENC 2 -- the backward with the hash grid in its epilogue -- is built in a block-per-pair object on purpose: on the gap
             # schedule hipcc moved one of its tiles inside a run, which is exactly what this test exists to catch)
             if not wide:
