@@ -265,6 +265,11 @@ int nefes_field_fwd_h3_fh(const NefesNetDesc* desc, const void* packed, int mode
 int nefes_field_bwd_h3_fh(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
                           const float* z, const float* viewdirs, const float* raw_t, const float* g_raw_t, const uint32_t* masks,
                           float* g_pts, float* g_viewdirs_s, void* stream);
+/* the factored head's per-ray part: feat [N, C] = gmap[:, :F] W^T + gmap[:, F] b with gmap [N, F + 1] = the composited g and ones
+ * channels (nefes_composite_fwd with C = F + 1), w_t = W transposed [F, C]; and its backward to gmap (w = W [C, F]; W, b frozen).
+ * Every output is a sequential sum, independent of the batch: shards and batches stay bit-identical.  C <= 256, F < 256. */
+int nefes_feat_head_fwd(int N, int C, int F, const float* gmap, const float* w_t, const float* b, float* feat, void* stream);
+int nefes_feat_head_bwd(int N, int C, int F, const float* g_feat, const float* w, const float* b, float* g_gmap, void* stream);
 /* nefes_field_bwd_static on the fp16 two-part pipe (round 5): backward-to-inputs of a NEFES_FIELD_STATIC forward
  * (nefes_field_fwd_h3 accepts that mode for the frequency embedding) for every compiled (width, head class) pair -- a frozen coarse
  * network with test_time False (script/models/rendering.py:116-125) or a fine network with NeRFW off

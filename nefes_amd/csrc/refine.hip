@@ -524,7 +524,51 @@ __global__ void adam_kernel(int n, float* p, const float* g, float* m, float* v,
     if (i == 0) step[0] = t;
 }
 
+// The factored feature head's per-ray part (field_fwd_h3.hip FH; script/models/nerfh_nff.py:119-125 with the head of :487-490 pulled out of
+// the sum): feat[n][c] = sum_f gmap[n][f] W[c][f] + gmap[n][F] b[c], gmap = the composited g (F values) and the composited ones channel.
+// One workgroup per ray, the F + 1 inputs in LDS, every output a sequential sum over f: a ray's result does not depend on which other rays
+// are in the batch (row shards, batched poses and single renders stay bit-identical -- a library GEMM picks its tiling by the batch size).
+__global__ __launch_bounds__(256) void feat_head_fwd_kernel(int N, int C, int F, const float* __restrict__ gmap, const float* __restrict__ w_t,
+                                                            const float* __restrict__ b, float* __restrict__ feat) {
+    __shared__ float g[256];
+    const int n = blockIdx.x;
+    if (threadIdx.x <= F) g[threadIdx.x] = gmap[(size_t)n * (F + 1) + threadIdx.x];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int f = 0; f < F; ++f) acc = fmaf(g[f], w_t[(size_t)f * C + c], acc);
+        feat[(size_t)n * C + c] = fmaf(g[F], b[c], acc);
+    }
+}
+// its backward to gmap (W and b frozen): g_gmap[n][f] = sum_c g_feat[n][c] W[c][f]; g_gmap[n][F] = sum_c g_feat[n][c] b[c]
+__global__ __launch_bounds__(256) void feat_head_bwd_kernel(int N, int C, int F, const float* __restrict__ g_feat, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ g_gmap) {
+    __shared__ float g[256];
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) g[c] = g_feat[(size_t)n * C + c];
+    __syncthreads();
+    const int f = threadIdx.x;
+    if (f <= F) {
+        float acc = 0.f;
+        if (f < F) { for (int c = 0; c < C; ++c) acc = fmaf(g[c], w[(size_t)c * F + f], acc); }
+        else { for (int c = 0; c < C; ++c) acc = fmaf(g[c], b[c], acc); }
+        g_gmap[(size_t)n * (F + 1) + f] = acc;
+    }
+}
+
 }  // namespace
+
+extern "C" int nefes_feat_head_fwd(int N, int C, int F, const float* gmap, const float* w_t, const float* b, float* feat, void* stream) {
+    if (N <= 0 || C <= 0 || C > 256 || F <= 0 || F >= 256 || !gmap || !w_t || !b || !feat) return NEFES_E_BADARG;
+    hipLaunchKernelGGL(feat_head_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, N, C, F, gmap, w_t, b, feat);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_feat_head_bwd(int N, int C, int F, const float* g_feat, const float* w, const float* b, float* g_gmap, void* stream) {
+    if (N <= 0 || C <= 0 || C > 256 || F <= 0 || F >= 256 || !g_feat || !w || !b || !g_gmap) return NEFES_E_BADARG;
+    hipLaunchKernelGGL(feat_head_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, N, C, F, g_feat, w, b, g_gmap);
+    return (int)hipGetLastError();
+}
 
 extern "C" int nefes_fusion_input_fwd(int B, int HW, int C, const float* rgb, const float* feat, const float* affine, const float* mean3,
                                       const float* std3, float* x, float* y, void* stream) {

@@ -248,7 +248,7 @@ class NeRFH_NFF(nn.Module):
                             if not n.startswith(("fusion_net", "exposure_embedding"))))
 
     def packed_fh(self):
-        """(PackedField of the network WITHOUT its feature rows -- static_rgb = its three colour rows, f_dim 0 --, W_f [C, W/2], b_f [C]):
+        """(PackedField of the network WITHOUT its feature rows -- static_rgb = its three colour rows, f_dim 0 --, W_f [C, W/2], W_f^T, b_f [C]):
         what the factored-head kernels and the per-ray feature head of nefes_amd/render.py take.  Cached like packed()."""
         names = ops.PackedField.LAYERS_FINE
         sd = dict(self.named_parameters())
@@ -260,7 +260,8 @@ class NeRFH_NFF(nn.Module):
             w, b = ksd["static_rgb.0.weight"], ksd["static_rgb.0.bias"]
             ksd["static_rgb.0.weight"], ksd["static_rgb.0.bias"] = w[:3].contiguous(), b[:3].contiguous()
             pk = ops.PackedField(ksd, self.W, 0, True, dev, L.XYZ_FREQ10)
-            self._pk_fh = (pk, w[3:].to(dev, torch.float32).contiguous(), b[3:].to(dev, torch.float32).contiguous())
+            w_f = w[3:].to(dev, torch.float32).contiguous()
+            self._pk_fh = (pk, w_f, w_f.t().contiguous(), b[3:].to(dev, torch.float32).contiguous())
             self._pk_fh_key = key
         return self._pk_fh
 

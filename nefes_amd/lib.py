@@ -80,6 +80,8 @@ SIGNATURES = {
     "nefes_field_fwd_x6": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_bwd_h3": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_bwd_static_h3": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_feat_head_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
+    "nefes_feat_head_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
     "nefes_field_fwd_h3_fh": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_bwd_h3_fh": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_fwd_h3_hashgrid": (_i, [_desc, _p, C.POINTER(NefesHashGridDesc), _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),

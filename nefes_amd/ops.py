@@ -543,6 +543,34 @@ class FieldFromRays(torch.autograd.Function):
 FACTORED_HEAD = os.environ.get("NEFES_FACTORED_HEAD", "1") != "0"
 
 
+class FeatHead(torch.autograd.Function):
+    """The factored head's per-ray part: feat [N, C] = gmap[:, :F] W^T + gmap[:, F:] b (csrc/refine.hip feat_head_*_kernel; W, b frozen)."""
+
+    @staticmethod
+    def forward(ctx, gmap, w, w_t, b):
+        gmap = _f32(gmap)
+        N, F1 = gmap.shape
+        C = w.shape[0]
+        feat = torch.empty(N, C, device=gmap.device)
+        with _timed("feat_head_fwd"):
+            L.check(L.load().nefes_feat_head_fwd(N, C, F1 - 1, _chk(gmap, "gmap"), _chk(w_t, "w_t"), _chk(b, "b"), _chk(feat, "feat"), _stream()),
+                    "nefes_feat_head_fwd")
+        ctx.save_for_backward(w, b)
+        ctx.F1 = F1
+        return feat
+
+    @staticmethod
+    def backward(ctx, g_feat):
+        w, b = ctx.saved_tensors
+        g_feat = _f32(g_feat)
+        N, C = g_feat.shape
+        g_gmap = torch.empty(N, ctx.F1, device=g_feat.device)
+        with _timed("feat_head_bwd"):
+            L.check(L.load().nefes_feat_head_bwd(N, C, ctx.F1 - 1, _chk(g_feat, "g_feat"), _chk(w, "w"), _chk(b, "b"), _chk(g_gmap, "g_gmap"),
+                                                 _stream()), "nefes_feat_head_bwd")
+        return g_gmap, None, None, None
+
+
 class FieldFromRaysFH(torch.autograd.Function):
     """FieldFromRays for the factored head: raw_t [N, 3 + (W/2 + 1) + 6, S] = rgb | g | ones | sigma | transient (5); pk = the network packed
     without its feature rows (NeRFH_NFF.packed_fh).  Differentiable w.r.t. rays_o, rays_d, viewdirs (frozen weights)."""

@@ -187,7 +187,7 @@ def _fine_pass(rays_o, rays_d, viewdirs, z_fine, z_samples, network_fine, cfg, C
         #     feat = sum_s w_s (W_f g_s + b_f) = W_f (sum_s w_s g_s) + b_f sum_s w_s.
         # The field kernels emit g (64 channels) + a channel of ones instead of the 128 feature channels, the compositor runs on 65
         # "features", and W_f is applied once per ray: 63 of 137 raw channels and 44 of the head's 60 MFMAs per 32 samples go.
-        pk_fh, w_f, b_f = network_fine.packed_fh()
+        pk_fh, w_f, w_f_t, b_f = network_fine.packed_fh()
         raw_f = ops.FieldFromRaysFH.apply(rays_o, rays_d, viewdirs, z_f, pk_fh)
         flags |= L.COMP_TRANSIENT
         if not cfg.transient_at_test:
@@ -196,7 +196,7 @@ def _fine_pass(rays_o, rays_d, viewdirs, z_fine, z_samples, network_fine, cfg, C
             flags |= L.COMP_WHITE_BKGD
         Cg = network_fine.W // 2
         rgb, gmap, disp, acc, depth, weights, beta = ops.Composite.apply(raw_f, z_f, Cg + 1, flags, float(network_fine.beta_min))
-        feat = torch.addmm(gmap[:, Cg:] * b_f[None, :], gmap[:, :Cg], w_f.t())        # [N, C]: once per ray
+        feat = ops.FeatHead.apply(gmap, w_f, w_f_t, b_f)                                # [N, C]: once per ray, batch-independent sums
         return {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "feat_map": feat}
     pk_f = network_fine.packed()
     mode = L.FIELD_FULL if cfg.NeRFW else L.FIELD_STATIC

@@ -9,7 +9,7 @@ from nefes_amd.field import NeRFH_NFF
 dev="cuda"
 torch.manual_seed(0)
 fine = NeRFH_NFF('fine', W=128, f_dim=128, encode_appearance=True, encode_transient=True).requires_grad_(False).to(dev)
-pk = fine.packed(); pk_fh, w_f, b_f = fine.packed_fh()
+pk = fine.packed(); pk_fh, w_f, w_f_t, b_f = fine.packed_fh()
 N,S=37,64
 g=torch.Generator().manual_seed(1)
 o=(torch.randn(N,3,generator=g)*0.3).to(dev); d=torch.nn.functional.normalize(torch.randn(N,3,generator=g),dim=-1).to(dev)
