@@ -65,6 +65,9 @@ typedef struct NefesBlobInfo {
 #define NEFES_COMP_STATIC_ONLY 2u /* variant B: test_time and not transient_at_test (:92-117) */
 #define NEFES_COMP_SIGMA_ONLY 4u  /* variant D: coarse net at test time, raw = sigma only (:33-35,83-89) */
 #define NEFES_COMP_WHITE_BKGD 8u  /* :126-127 */
+#define NEFES_COMP_FEAT_WEIGHTS_ONLY 16u /* nefes_composite_bwd only: instead of the C rows w_s[s] g_feat[c] of the feature channels' gradient, write the
+                                          * static weight w_s[s] into the FIRST feature channel's row (the factored head's backward forms the
+                                          * products itself: nefes_field_bwd_h3_fh with g_gmap) */
 
 /* field forward modes (run_network_NeRFH_NFF branches, script/models/nerfh_nff.py:192-231) */
 #define NEFES_FIELD_SIGMA 0  /* coarse + test_time: sigma only, R = 1 */
@@ -262,9 +265,12 @@ int nefes_field_bwd_h3_hashgrid(const NefesNetDesc* desc, const void* packed, co
  * _bwd take with C = W/2 + 1.  Width 128, frequency embedding, full head, frozen weights. */
 int nefes_field_fwd_h3_fh(const NefesNetDesc* desc, const void* packed, int mode, int N, int S, const float* rays_o,
                           const float* rays_d, const float* z, const float* viewdirs, float* raw_t, uint32_t* masks, void* stream);
+/* g_gmap (nullable) [N][W/2 + 1] = d loss / d (composited g) per RAY: the gradient of a sample's g channels is then w_s g_gmap[ray][f], formed
+ * in the kernel from the static weight w_s that nefes_composite_bwd(NEFES_COMP_FEAT_WEIGHTS_ONLY) leaves in the first feature channel's row of
+ * g_raw_t -- the W/2 rows of products are neither written nor read.  Null: g_raw_t carries d loss / d g itself. */
 int nefes_field_bwd_h3_fh(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
-                          const float* z, const float* viewdirs, const float* raw_t, const float* g_raw_t, const uint32_t* masks,
-                          float* g_pts, float* g_viewdirs_s, void* stream);
+                          const float* z, const float* viewdirs, const float* raw_t, const float* g_raw_t, const float* g_gmap,
+                          const uint32_t* masks, float* g_pts, float* g_viewdirs_s, void* stream);
 /* the factored head's per-ray part: feat [N, C] = gmap[:, :F] W^T + gmap[:, F] b with gmap [N, F + 1] = the composited g and ones
  * channels (nefes_composite_fwd with C = F + 1), w_t = W transposed [F, C]; and its backward to gmap (w = W [C, F]; W, b frozen).
  * Every output is a sequential sum, independent of the batch: shards and batches stay bit-identical.  C <= 256, F < 256. */

@@ -292,8 +292,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs p) {
         graw[(size_t)C3 * S + s] = g_ss;
 #pragma unroll
         for (int c = 0; c < 3; ++c) graw[(size_t)c * S + s] = ws[q] * g_rgb[c];
+        if (p.flags & NEFES_COMP_FEAT_WEIGHTS_ONLY) {
+            graw[(size_t)3 * S + s] = ws[q];                          // the static weight itself rides in the first feature channel
+        } else {
         for (int c = 0; c < C; ++c)
             graw[(size_t)(3 + c) * S + s] = p.g_feat ? ws[q] * p.g_feat[(size_t)ray * C + c] : 0.f;
+        }
         if (transient) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) graw[(size_t)(C3 + 1 + c) * S + s] = wt[q] * g_rgb[c];
@@ -613,11 +617,19 @@ __global__ __launch_bounds__(256) void composite_bwd4_kernel(CompArgs p) {
         const float v[4] = {ws[0] * g_rgb[c], ws[1] * g_rgb[c], ws[2] * g_rgb[c], ws[3] * g_rgb[c]};
         store_row(c, v);
     }
+    if (p.flags & NEFES_COMP_FEAT_WEIGHTS_ONLY) {
+        // the factored head (field_bwd_h3.hip FH): d loss / d feature channel c at sample s is w_s[s] g_feat[c], which the field backward
+        // forms itself from g_feat (one row per RAY) and the static weight -- written HERE, into the first feature channel's row, in
+        // place of C rows of products
+        const float v[4] = {ws[0], ws[1], ws[2], ws[3]};
+        store_row(3, v);
+    } else {
     const float* gf = p.g_feat ? p.g_feat + (size_t)ray * C : nullptr;
     for (int c = 0; c < C; ++c) {
         const float gfc = gf ? gf[c] : 0.f;
         const float v[4] = {gf ? ws[0] * gfc : 0.f, gf ? ws[1] * gfc : 0.f, gf ? ws[2] * gfc : 0.f, gf ? ws[3] * gfc : 0.f};
         store_row(3 + c, v);
+    }
     }
     if (transient) {
 #pragma unroll

@@ -67,6 +67,9 @@ struct FieldBwdH3Args {
     const float2* hg_table; // NEFES_XYZ_HASHGRID_FUSED: the hash-grid table and its level geometry (hashgrid.h)
     HgGeom hg;
     int gout;               // FH instances (field_fwd_h3.hip): W / 2 channels of d loss / d relu(dir_encoding) in the feature channels' place
+    const float* g_gmap;    // FH, optional: [N][gout + 1] = d loss / d (composited g) per RAY; d loss / d g of a sample is then formed here as
+                            // w_s g_gmap[ray][f], with the static weight w_s read from the first feature channel's row of g_raw_t
+                            // (nefes_composite_bwd with NEFES_COMP_FEAT_WEIGHTS_ONLY) instead of gout rows of products
 };
 
 // TRAIN instances: the (masked) gradient vector a product consumes is d loss / d pre-activation of a hidden layer, which the
@@ -307,9 +310,16 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
             if constexpr (FH) {
                 int S_g = a.S;
                 asm volatile("" : "+s"(S_g)::"memory");
+                if (a.g_gmap) {
+                    const float ws = valid ? ld_stream(a.g_raw_t + chan0 + (size_t)3 * S_g) : 0.f;
+                    const float* gv = a.g_gmap + (size_t)ray * (a.gout + 1) + 4 * h;          // (one row per ray: the same 260 bytes for a ray's samples)
+#pragma unroll
+                    for (int e = 0; e < 16 * NTH; ++e) dst[e] = ws * gv[32 * (e >> 4) + nefes_rho(0, e & 15)];
+                } else {
                 const float* gg = a.g_raw_t + chan0 + (size_t)(3 + 4 * h) * S_g;
 #pragma unroll
                 for (int e = 0; e < 16 * NTH; ++e) dst[e] = valid ? ld_stream(gg + (size_t)(32 * (e >> 4) + nefes_rho(0, e & 15)) * S_g) : 0.f;
+                }
             } else {
                 dst[0] = 0.f;
             }
@@ -635,7 +645,7 @@ extern "C" int nefes_field_bwd_train_h3(const NefesNetDesc* desc, const void* pa
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + (full ? 6 : 1);
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
-    a.dacts = dacts; a.gout = 0; a.hg_table = nullptr;
+    a.dacts = dacts; a.gout = 0; a.hg_table = nullptr; a.g_gmap = nullptr;
     a.rows = nefes_train_row(desc->width, desc->feat_dim, NEFES_TB_END);
     const int which = full ? BWD_H3_TRAIN_FULL : BWD_H3_TRAIN_STATIC;
     hipStream_t st = (hipStream_t)stream;
@@ -668,7 +678,7 @@ extern "C" int nefes_field_bwd_static_h3(const NefesNetDesc* desc, const void* p
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + 1;
     a.M = (long long)N * S;
     a.n_tiles = (int)((a.M + 127) / 128);
-    a.dacts = nullptr; a.rows = 0; a.gout = 0; a.hg_table = nullptr;
+    a.dacts = nullptr; a.rows = 0; a.gout = 0; a.hg_table = nullptr; a.g_gmap = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (desc->width == 256) return cls == 0 ? nefes_bwd_h3_launch_part1(BWD_H3_STATIC, a, st) : nefes_bwd_h3_launch_part5(BWD_H3_STATIC, a, st);
     return cls == 1 ? nefes_bwd_h3_launch_part2(BWD_H3_STATIC, a, st) : nefes_bwd_h3_launch_part6(BWD_H3_STATIC, a, st);
@@ -678,7 +688,7 @@ static int field_bwd_h3_impl(const NefesNetDesc* desc, const void* packed, int N
                                   const float* rays_d, const float* z, const float* pts, const float* viewdirs,
                                   const float* raw_t, const float* g_raw_t, const uint32_t* masks, float* g_pts,
                                   float* g_xyz_enc, float* g_viewdirs_s, void* stream, const NefesHashGridDesc* grid, const float* table,
-                                  bool fh = false) {
+                                  bool fh = false, const float* g_gmap = nullptr) {
     if (!desc || !packed || !viewdirs || !raw_t || !g_raw_t || !masks || !g_viewdirs_s || N <= 0 || S <= 0)
         return NEFES_E_BADARG;
     const bool ext = desc->xyz_encoding == NEFES_XYZ_EXTERNAL32;
@@ -697,7 +707,7 @@ static int field_bwd_h3_impl(const NefesNetDesc* desc, const void* packed, int N
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.pts = pts; a.viewdirs = viewdirs;
     a.raw_t = raw_t; a.g_raw_t = g_raw_t; a.masks = masks; a.g_pts = g_pts; a.g_enc = g_xyz_enc; a.g_vs = g_viewdirs_s;
     a.N = N; a.S = S; a.C = desc->feat_dim; a.R = 3 + a.C + 6;
-    a.gout = 0;
+    a.gout = 0; a.g_gmap = g_gmap;
     if (fh) {                                                     // factored head: see nefes_field_fwd_h3_fh
         if (desc->feat_dim != 0 || desc->width != 128 || ext) return NEFES_E_UNSUPPORTED;
         a.gout = desc->width / 2;
@@ -735,11 +745,11 @@ extern "C" int nefes_field_bwd_h3(const NefesNetDesc* desc, const void* packed, 
 // nefes_field_bwd_h3 for a nefes_field_fwd_h3_fh forward: g_raw_t [N][3 + (W/2 + 1) + 6][S] carries d loss / d g in channels 3 .. 3 + W/2
 // (the gradient of the ones channel is ignored).
 extern "C" int nefes_field_bwd_h3_fh(const NefesNetDesc* desc, const void* packed, int N, int S, const float* rays_o, const float* rays_d,
-                                     const float* z, const float* viewdirs, const float* raw_t, const float* g_raw_t,
+                                     const float* z, const float* viewdirs, const float* raw_t, const float* g_raw_t, const float* g_gmap,
                                      const uint32_t* masks, float* g_pts, float* g_viewdirs_s, void* stream) {
     if (!rays_o || !rays_d || !z) return NEFES_E_BADARG;
     return field_bwd_h3_impl(desc, packed, N, S, rays_o, rays_d, z, nullptr, viewdirs, raw_t, g_raw_t, masks, g_pts, nullptr, g_viewdirs_s, stream,
-                             nullptr, nullptr, true);
+                             nullptr, nullptr, true, g_gmap);
 }
 
 // nefes_field_bwd_h3 for a nefes_field_fwd_h3_hashgrid forward: g_pts [N*S, 3] = d loss / d (o + d z) through the MLP AND the hash

@@ -526,33 +526,48 @@ __global__ void adam_kernel(int n, float* p, const float* g, float* m, float* v,
 
 // The factored feature head's per-ray part (field_fwd_h3.hip FH; script/models/nerfh_nff.py:119-125 with the head of :487-490 pulled out of
 // the sum): feat[n][c] = sum_f gmap[n][f] W[c][f] + gmap[n][F] b[c], gmap = the composited g (F values) and the composited ones channel.
-// One workgroup per ray, the F + 1 inputs in LDS, every output a sequential sum over f: a ray's result does not depend on which other rays
+// One workgroup per ray, the F + 1 inputs in LDS, every output a fixed-order sum over f: a ray's result does not depend on which other rays
 // are in the batch (row shards, batched poses and single renders stay bit-identical -- a library GEMM picks its tiling by the batch size).
-__global__ __launch_bounds__(256) void feat_head_fwd_kernel(int N, int C, int F, const float* __restrict__ gmap, const float* __restrict__ w_t,
+__global__ __launch_bounds__(128) void feat_head_fwd_kernel(int N, int C, int F, const float* __restrict__ gmap, const float* __restrict__ w_t,
                                                             const float* __restrict__ b, float* __restrict__ feat) {
     __shared__ float g[256];
     const int n = blockIdx.x;
-    if (threadIdx.x <= F) g[threadIdx.x] = gmap[(size_t)n * (F + 1) + threadIdx.x];
+    for (int f = threadIdx.x; f <= F; f += 128) g[f] = gmap[(size_t)n * (F + 1) + f];
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc = 0.f;
-        for (int f = 0; f < F; ++f) acc = fmaf(g[f], w_t[(size_t)f * C + c], acc);
-        feat[(size_t)n * C + c] = fmaf(g[F], b[c], acc);
+    for (int c = threadIdx.x; c < C; c += 128) {
+        // four interleaved partial sums (f mod 4), combined in a fixed order: four independent fma chains instead of one of length F
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int f = 0;
+        for (; f + 3 < F; f += 4) {
+            a0 = fmaf(g[f], w_t[(size_t)f * C + c], a0);
+            a1 = fmaf(g[f + 1], w_t[(size_t)(f + 1) * C + c], a1);
+            a2 = fmaf(g[f + 2], w_t[(size_t)(f + 2) * C + c], a2);
+            a3 = fmaf(g[f + 3], w_t[(size_t)(f + 3) * C + c], a3);
+        }
+        for (; f < F; ++f) a0 = fmaf(g[f], w_t[(size_t)f * C + c], a0);
+        feat[(size_t)n * C + c] = fmaf(g[F], b[c], (a0 + a1) + (a2 + a3));
     }
 }
 // its backward to gmap (W and b frozen): g_gmap[n][f] = sum_c g_feat[n][c] W[c][f]; g_gmap[n][F] = sum_c g_feat[n][c] b[c]
-__global__ __launch_bounds__(256) void feat_head_bwd_kernel(int N, int C, int F, const float* __restrict__ g_feat, const float* __restrict__ w,
+__global__ __launch_bounds__(128) void feat_head_bwd_kernel(int N, int C, int F, const float* __restrict__ g_feat, const float* __restrict__ w,
                                                             const float* __restrict__ b, float* __restrict__ g_gmap) {
     __shared__ float g[256];
     const int n = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += 256) g[c] = g_feat[(size_t)n * C + c];
+    for (int c = threadIdx.x; c < C; c += 128) g[c] = g_feat[(size_t)n * C + c];
     __syncthreads();
-    const int f = threadIdx.x;
-    if (f <= F) {
-        float acc = 0.f;
-        if (f < F) { for (int c = 0; c < C; ++c) acc = fmaf(g[c], w[(size_t)c * F + f], acc); }
-        else { for (int c = 0; c < C; ++c) acc = fmaf(g[c], b[c], acc); }
-        g_gmap[(size_t)n * (F + 1) + f] = acc;
+    for (int f = threadIdx.x; f <= F; f += 128) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float* col = f < F ? w + f : b;                       // column f of W (stride F), or the bias vector (stride 1)
+        const size_t st = f < F ? (size_t)F : 1;
+        int c = 0;
+        for (; c + 3 < C; c += 4) {
+            a0 = fmaf(g[c], col[(size_t)c * st], a0);
+            a1 = fmaf(g[c + 1], col[(size_t)(c + 1) * st], a1);
+            a2 = fmaf(g[c + 2], col[(size_t)(c + 2) * st], a2);
+            a3 = fmaf(g[c + 3], col[(size_t)(c + 3) * st], a3);
+        }
+        for (; c < C; ++c) a0 = fmaf(g[c], col[(size_t)c * st], a0);
+        g_gmap[(size_t)n * (F + 1) + f] = (a0 + a1) + (a2 + a3);
     }
 }
 
@@ -560,13 +575,13 @@ __global__ __launch_bounds__(256) void feat_head_bwd_kernel(int N, int C, int F,
 
 extern "C" int nefes_feat_head_fwd(int N, int C, int F, const float* gmap, const float* w_t, const float* b, float* feat, void* stream) {
     if (N <= 0 || C <= 0 || C > 256 || F <= 0 || F >= 256 || !gmap || !w_t || !b || !feat) return NEFES_E_BADARG;
-    hipLaunchKernelGGL(feat_head_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, N, C, F, gmap, w_t, b, feat);
+    hipLaunchKernelGGL(feat_head_fwd_kernel, dim3(N), dim3(128), 0, (hipStream_t)stream, N, C, F, gmap, w_t, b, feat);
     return (int)hipGetLastError();
 }
 
 extern "C" int nefes_feat_head_bwd(int N, int C, int F, const float* g_feat, const float* w, const float* b, float* g_gmap, void* stream) {
     if (N <= 0 || C <= 0 || C > 256 || F <= 0 || F >= 256 || !g_feat || !w || !b || !g_gmap) return NEFES_E_BADARG;
-    hipLaunchKernelGGL(feat_head_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, N, C, F, g_feat, w, b, g_gmap);
+    hipLaunchKernelGGL(feat_head_bwd_kernel, dim3(N), dim3(128), 0, (hipStream_t)stream, N, C, F, g_feat, w, b, g_gmap);
     return (int)hipGetLastError();
 }
 

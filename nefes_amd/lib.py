@@ -39,7 +39,7 @@ FIELD_SIGMA, FIELD_STATIC, FIELD_FULL = 0, 1, 2
 XYZ_FREQ10, XYZ_EXTERNAL32 = 0, 1
 (TB_E, TB_DV, TB_L1, TB_FINAL, TB_DIR, TB_T0, TB_T1, TB_T2, TB_RGB, TB_SIG, TB_TH, TB_END) = (0, 1, 2, 10, 11, 12, 13, 14, 15, 16,
                                                                                               17, 18)
-COMP_TRANSIENT, COMP_STATIC_ONLY, COMP_SIGMA_ONLY, COMP_WHITE_BKGD = 1, 2, 4, 8
+COMP_TRANSIENT, COMP_STATIC_ONLY, COMP_SIGMA_ONLY, COMP_WHITE_BKGD, COMP_FEAT_WEIGHTS_ONLY = 1, 2, 4, 8, 16
 
 _p, _i, _f, _u32, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t
 _desc = C.POINTER(NefesNetDesc)
@@ -83,7 +83,7 @@ SIGNATURES = {
     "nefes_feat_head_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
     "nefes_feat_head_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
     "nefes_field_fwd_h3_fh": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
-    "nefes_field_bwd_h3_fh": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "nefes_field_bwd_h3_fh": (_i, [_desc, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_fwd_h3_hashgrid": (_i, [_desc, _p, C.POINTER(NefesHashGridDesc), _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
     "nefes_field_bwd_h3_hashgrid": (_i, [_desc, _p, C.POINTER(NefesHashGridDesc), _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "nefes_field_fwd_h3": (_i, [_desc, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -608,10 +608,77 @@ class FieldFromRaysFH(torch.autograd.Function):
         with _timed("field_bwd[h3,fh]"):
             L.check(L.load().nefes_field_bwd_h3_fh(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
                                                    _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(viewdirs, "viewdirs"), _chk(raw_t, "raw_t"),
-                                                   _chk(_f32(g_raw_t), "g_raw_t"), _chk(masks, "masks", torch.int32), _chk(g_pts, "g_pts"),
+                                                   _chk(_f32(g_raw_t), "g_raw_t"), None, _chk(masks, "masks", torch.int32), _chk(g_pts, "g_pts"),
                                                    _chk(g_vs, "g_vs"), _stream()), "nefes_field_bwd_h3_fh")
         g_o, g_d, g_v = ray_grad_reduce(N, S, z, g_pts, g_vs)
         return g_o, g_d, g_v, None, None
+
+
+class RenderFineFH(torch.autograd.Function):
+    """The fine pass of a frozen width-128 network at test time with the factored head, as ONE autograd node: field forward (g channels) ->
+    compositing -> per-ray feature head; and back: feature head -> compositing backward, which leaves the static weight where the g
+    channels' gradient would go (COMP_FEAT_WEIGHTS_ONLY) -> field backward, which forms d loss / d g = w_s g_gmap[ray] itself.  One node
+    because that backward hands TWO tensors from the compositor's stage to the field's (g_raw_t and the per-ray g_gmap).
+    -> (rgb [N,3], feat [N,C], disp [N], acc [N]); differentiable w.r.t. rays_o, rays_d, viewdirs."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, viewdirs, z, pk, w_f, w_f_t, b_f, flags, beta_min):
+        rays_o, rays_d, viewdirs, z = _f32(rays_o), _f32(rays_d), _f32(viewdirs), _f32(z)
+        N, S = z.shape
+        need = any(ctx.needs_input_grad[:3])
+        Cg = pk.width // 2
+        raw_t = torch.empty(N, 3 + Cg + 1 + 6, S, device=z.device)
+        masks = torch.empty(pk.mask_bytes(N * S) // 4, dtype=torch.int32, device=z.device) if need else None
+        with _timed("field_fwd[full,h3,fh]"):
+            L.check(L.load().nefes_field_fwd_h3_fh(pk.desc, _chk(pk.blob, "blob", torch.uint8), L.FIELD_FULL, N, S, _chk(rays_o, "rays_o"),
+                                                   _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(viewdirs, "viewdirs"), _chk(raw_t, "raw_t"),
+                                                   _chk(masks, "masks", torch.int32), _stream()), "nefes_field_fwd_h3_fh")
+        if masks is not None:
+            _tap("masks", (masks, N, S, pk.width, L.FIELD_FULL))
+        rgb, gmap, disp, acc, _, _, _ = composite_fwd(raw_t, z, Cg + 1, flags, beta_min)
+        C = w_f.shape[0]
+        feat = torch.empty(N, C, device=z.device)
+        with _timed("feat_head_fwd"):
+            L.check(L.load().nefes_feat_head_fwd(N, C, Cg, _chk(gmap, "gmap"), _chk(w_f_t, "w_t"), _chk(b_f, "b"), _chk(feat, "feat"), _stream()),
+                    "nefes_feat_head_fwd")
+        ctx.set_materialize_grads(False)
+        ctx.pk, ctx.have, ctx.pk_gen, ctx.cfg = pk, need, pk.generation, (Cg, int(flags))
+        if need:
+            ctx.save_for_backward(rays_o, rays_d, viewdirs, z, raw_t, masks, w_f, b_f)
+        return rgb, feat, disp, acc
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_feat, g_disp, g_acc):
+        if not ctx.have:
+            return (None,) * 10
+        rays_o, rays_d, viewdirs, z, raw_t, masks, w_f, b_f = ctx.saved_tensors
+        N, S = z.shape
+        pk = ctx.pk
+        pk.check_generation(ctx.pk_gen)
+        Cg, flags = ctx.cfg
+        fix = lambda g: None if (g is None or g.numel() == 0) else _f32(g)
+        g_rgb, g_feat, g_disp, g_acc = fix(g_rgb), fix(g_feat), fix(g_disp), fix(g_acc)
+        g_gmap = None
+        if g_feat is not None:
+            g_gmap = torch.empty(N, Cg + 1, device=z.device)
+            with _timed("feat_head_bwd"):
+                L.check(L.load().nefes_feat_head_bwd(N, w_f.shape[0], Cg, _chk(g_feat, "g_feat"), _chk(w_f, "w"), _chk(b_f, "b"),
+                                                     _chk(g_gmap, "g_gmap"), _stream()), "nefes_feat_head_bwd")
+        else:
+            g_gmap = torch.zeros(N, Cg + 1, device=z.device)
+        g_raw_t = torch.empty_like(raw_t)          # (the g channels' rows beyond the first are neither written nor read)
+        with _timed("composite_bwd"):
+            L.check(L.load().nefes_composite_bwd(N, S, Cg + 1, flags | L.COMP_FEAT_WEIGHTS_ONLY, _chk(raw_t, "raw_t"), _chk(z, "z"),
+                                                 _chk(g_rgb, "g_rgb"), None, _chk(g_disp, "g_disp"), _chk(g_acc, "g_acc"), None, None, None,
+                                                 _chk(g_raw_t, "g_raw_t"), _stream()), "nefes_composite_bwd")
+        g_pts, g_vs = torch.empty(N * S, 3, device=z.device), torch.empty(N * S, 3, device=z.device)
+        with _timed("field_bwd[h3,fh]"):
+            L.check(L.load().nefes_field_bwd_h3_fh(pk.desc, _chk(pk.blob, "blob", torch.uint8), N, S, _chk(rays_o, "rays_o"),
+                                                   _chk(rays_d, "rays_d"), _chk(z, "z"), _chk(viewdirs, "viewdirs"), _chk(raw_t, "raw_t"),
+                                                   _chk(g_raw_t, "g_raw_t"), _chk(g_gmap, "g_gmap"), _chk(masks, "masks", torch.int32),
+                                                   _chk(g_pts, "g_pts"), _chk(g_vs, "g_vs"), _stream()), "nefes_field_bwd_h3_fh")
+        g_o, g_d, g_v = ray_grad_reduce(N, S, z, g_pts, g_vs)
+        return g_o, g_d, g_v, None, None, None, None, None, None, None
 
 
 class FieldFromPoints(torch.autograd.Function):

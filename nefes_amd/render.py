@@ -188,15 +188,12 @@ def _fine_pass(rays_o, rays_d, viewdirs, z_fine, z_samples, network_fine, cfg, C
         # The field kernels emit g (64 channels) + a channel of ones instead of the 128 feature channels, the compositor runs on 65
         # "features", and W_f is applied once per ray: 63 of 137 raw channels and 44 of the head's 60 MFMAs per 32 samples go.
         pk_fh, w_f, w_f_t, b_f = network_fine.packed_fh()
-        raw_f = ops.FieldFromRaysFH.apply(rays_o, rays_d, viewdirs, z_f, pk_fh)
         flags |= L.COMP_TRANSIENT
         if not cfg.transient_at_test:
             flags |= L.COMP_STATIC_ONLY
         if cfg.white_bkgd:
             flags |= L.COMP_WHITE_BKGD
-        Cg = network_fine.W // 2
-        rgb, gmap, disp, acc, depth, weights, beta = ops.Composite.apply(raw_f, z_f, Cg + 1, flags, float(network_fine.beta_min))
-        feat = ops.FeatHead.apply(gmap, w_f, w_f_t, b_f)                                # [N, C]: once per ray, batch-independent sums
+        rgb, feat, disp, acc = ops.RenderFineFH.apply(rays_o, rays_d, viewdirs, z_f, pk_fh, w_f, w_f_t, b_f, flags, float(network_fine.beta_min))
         return {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "feat_map": feat}
     pk_f = network_fine.packed()
     mode = L.FIELD_FULL if cfg.NeRFW else L.FIELD_STATIC

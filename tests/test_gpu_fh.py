@@ -62,3 +62,37 @@ def test_factored_head_is_not_used_where_it_does_not_apply():
     assert not mk(256, 128).requires_grad_(False).factored_head_ok()
     assert not mk(128, 16).requires_grad_(False).factored_head_ok()
     assert mk(128, 96).requires_grad_(False).factored_head_ok()
+
+
+def test_single_node_fine_pass_equals_the_three_node_chain():
+    """ops.RenderFineFH (the compositor leaves the static weight where the g channels' gradient would go, the field backward forms
+    w_s g_gmap[ray] itself) against the chain FieldFromRaysFH -> Composite -> FeatHead (64 rows of products written and read): same
+    maps bit for bit, same ray gradients to rounding."""
+    from nefes_amd import lib as L
+    from nefes_amd import ops
+    _, fine = nets(128, 128)
+    pk, w_f, w_f_t, b_f = fine.packed_fh()
+    g = torch.Generator().manual_seed(9)
+    N, S = 53, 128
+    o = (torch.randn(N, 3, generator=g) * 0.3).to(DEV)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).to(DEV)
+    z = torch.sort(torch.rand(N, S, generator=g) * 4, -1)[0].to(DEV)
+    G_rgb, G_feat = torch.randn(N, 3, generator=g).to(DEV), torch.randn(N, 128, generator=g).to(DEV)
+    flags = L.COMP_TRANSIENT
+    res = []
+    for single in (True, False):
+        oo, dd, vv = (t.clone().requires_grad_() for t in (o, d, d))
+        if single:
+            rgb, feat, disp, acc = ops.RenderFineFH.apply(oo, dd, vv, z, pk, w_f, w_f_t, b_f, flags, 0.1)
+        else:
+            raw = ops.FieldFromRaysFH.apply(oo, dd, vv, z, pk)
+            rgb, gmap, disp, acc, _, _, _ = ops.Composite.apply(raw, z, 65, flags, 0.1)
+            feat = ops.FeatHead.apply(gmap, w_f, w_f_t, b_f)
+        ((rgb * G_rgb).sum() + (feat * G_feat).sum()).backward()
+        res.append((rgb.detach(), feat.detach(), disp.detach(), acc.detach(), oo.grad, dd.grad, vv.grad))
+    for i in range(4):
+        assert torch.equal(res[0][i], res[1][i])
+    for i, name in ((4, "d rays_o"), (5, "d rays_d"), (6, "d viewdirs")):
+        e = rel(res[0][i], res[1][i])
+        P.record("factored_head_single_node", f"{name}: one node vs the three-node chain", direct=e, bound=2e-6)
+        assert e < 2e-6, (name, e)
