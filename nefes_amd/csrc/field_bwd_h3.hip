@@ -439,14 +439,10 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
         es_e = es_b;                                                         // exponent of the d xyz-embedding tiles XB[0], XB[1]
         // the skip connection's share of d xyz-embedding (XB tiles 0, 1), consumed at once (see the d dir-embedding tile above)
         float gx[3] = {0.f, 0.f, 0.f};
-        float ge[ENC == NEFES_XYZ_EXTERNAL32 ? NEFES_X_STEPS : 1];
+        float ge[ENC != NEFES_XYZ_FREQ10 ? NEFES_X_STEPS : 1];
         {
             const float inv = pow2i(-es_e);
-            if constexpr (ENC == NEFES_XYZ_HASHGRID_FUSED) {
-#pragma unroll
-                for (int s_ = 0; s_ < NEFES_X_STEPS; ++s_) STASH(8 + s_) = XB[0][s_] * inv;       // parked in LDS until layer 1's share exists
-                ge[0] = 0.f;
-            } else if constexpr (ENC == NEFES_XYZ_EXTERNAL32) {
+            if constexpr (ENC != NEFES_XYZ_FREQ10) {        // kept in registers until layer 1's share exists (see part 1's note below)
 #pragma unroll
                 for (int s_ = 0; s_ < NEFES_X_STEPS; ++s_) ge[s_] = XB[0][s_] * inv;
             } else {
@@ -481,7 +477,7 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
             // neither written nor re-read by a separate gather launch; both lane halves return their eight levels' share
             float x3[3];
 #pragma unroll
-            for (int s_ = 0; s_ < NEFES_X_STEPS; ++s_) STASH(8 + s_) = STASH(8 + s_) + XB[0][s_] * inv1;
+            for (int s_ = 0; s_ < NEFES_X_STEPS; ++s_) STASH(8 + s_) = ge[s_] + XB[0][s_] * inv1;
 #pragma unroll
             for (int c = 0; c < 3; ++c) x3[c] = STASH(c);
             // the position passes through an opaque statement HERE: the cells, indices and table gathers depend on nothing but it, and
@@ -566,6 +562,11 @@ int nefes_bwd_h3_launch_part8(int which, const FieldBwdH3Args& a, hipStream_t st
 int nefes_bwd_h3_launch_part1(int which, const FieldBwdH3Args& a, hipStream_t st) {
     if (which == BWD_H3_EXT) return launch_bwd_h3<256, 2, NEFES_XYZ_EXTERNAL32>(a, st);
     if (which == BWD_H3_STATIC) return launch_bwd_h3<256, 2, NEFES_XYZ_FREQ10, false>(a, st);     // static head alone, inference (round 5)
+    // The hash grid's backward in the epilogue (round 5), on the gap-by-gap schedule like its neighbours.  Its first form parked the
+    // skip connection's share of d encoding in LDS across layers 4..1 and hipcc then split an accumulator tile's live range inside
+    // an asm-scheduled run (a v_accvgpr_mov behind an MFMA that has not written the tile yet: tests/test_pack_stream.py caught it,
+    // no numerical test did); with the share in sixteen registers, as the external-encoding instance keeps it, the tiles stay put.
+    if (which == BWD_H3_HG) return launch_bwd_h3<256, 2, NEFES_XYZ_HASHGRID_FUSED>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 2      // built with -mllvm -amdgpu-mfma-vgpr-form: see field_fwd_h3.hip
@@ -578,11 +579,6 @@ int nefes_bwd_h3_launch_part2(int which, const FieldBwdH3Args& a, hipStream_t st
 int nefes_bwd_h3_launch_part3(int which, const FieldBwdH3Args& a, hipStream_t st) {
     if (which == BWD_H3_TRAIN_STATIC) return launch_bwd_h3<256, 2, NEFES_XYZ_FREQ10, false, true>(a, st);
     if (which == BWD_H3_TRAIN_FULL) return launch_bwd_h3<256, 2, NEFES_XYZ_FREQ10, true, true>(a, st);
-    // The hash grid's backward in the epilogue (round 5).  In THIS object (block-per-pair runs, compiler-placed MFMAs) on purpose: on
-    // the gap-by-gap schedule of parts 0 / 1 hipcc split an accumulator tile's live range inside an asm-scheduled run for this
-    // instance (a v_accvgpr_mov behind an MFMA that has not written the tile yet: tests/test_pack_stream.py); that schedule is worth
-    // 1.5 % of the backward, the fusion 10 %.
-    if (which == BWD_H3_HG) return launch_bwd_h3<256, 2, NEFES_XYZ_HASHGRID_FUSED>(a, st);
     return NEFES_E_UNSUPPORTED;
 }
 #elif NEFES_TU_PART == 4      // (built like part 2)
@@ -727,7 +723,7 @@ static int field_bwd_h3_impl(const NefesNetDesc* desc, const void* packed, int N
     const int cls = nefes_head_class(desc->feat_dim);          // compiled set: as nefes_field_fwd_h3
     if (cls < 0) return NEFES_E_UNSUPPORTED;
     if (fh) return nefes_bwd_h3_launch_part6(BWD_H3_FH, a, st);
-    if (desc->width == 256 && fused_grid) return cls == 0 ? nefes_bwd_h3_launch_part3(BWD_H3_HG, a, st) : NEFES_E_UNSUPPORTED;
+    if (desc->width == 256 && fused_grid) return cls == 0 ? nefes_bwd_h3_launch_part1(BWD_H3_HG, a, st) : NEFES_E_UNSUPPORTED;
     if (desc->width == 256 && ext) return cls == 0 ? nefes_bwd_h3_launch_part1(BWD_H3_EXT, a, st) : NEFES_E_UNSUPPORTED;
     if (desc->width == 256) return cls == 0 ? launch_bwd_h3<256, 2, NEFES_XYZ_FREQ10>(a, st) : nefes_bwd_h3_launch_part5(BWD_H3_FULL, a, st);
     if (desc->width == 128 && !ext) return cls == 1 ? nefes_bwd_h3_launch_part2(BWD_H3_FULL, a, st) : nefes_bwd_h3_launch_part6(BWD_H3_FULL, a, st);
