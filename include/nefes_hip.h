@@ -377,10 +377,30 @@ int nefes_cosine_loss_bwd(int C, int64_t P, const float* a, const float* b, cons
  * scratch: nefes_cosine_loss_scratch_doubles(C) doubles, kept for the backward; tmp: [C, OH-2crop, w] floats. */
 int nefes_upcos_loss_fwd(int C, int h, int w, int OH, int OW, int crop, const float* x, const float* target, double* scratch, float* loss,
                          void* stream);
-/* tx_* / ty_*: gather tables of the x and y axes (nefes_bicubic_gather_table with (w, OW, crop, OW-2crop) and (h, OH, crop, OH-2crop)). */
+/* tx_* / ty_*: gather tables of the x and y axes (nefes_bicubic_gather_table with (w, OW, crop, OW-2crop) and (h, OH, crop, OH-2crop)),
+ * BOTH built with the row length T passed here (the larger of the two axes' needs when OH / h != OW / w). */
 int nefes_upcos_loss_bwd(int C, int h, int w, int OH, int OW, int crop, const float* x, const float* target, const double* scratch,
                          const float* g_loss, const int* tx_first, const int* tx_count, const float* tx_wt, const int* ty_first,
                          const int* ty_count, const float* ty_wt, int T, float* tmp, float* g_x, void* stream);
+/* The same loss for a FIXED target (the refinement loop holds the query image's features for all opt_iter iterations of an image:
+ * DFM_APR_refine.py:100-131), through the Gram matrices of the up-sampling.  Per channel up = Uy X Ux^T, so
+ *     <up, target> = <X, Tt>, Tt = Uy^T target Ux;   |up|^2 = <X, Gy X Gx>, Gy = Uy^T Uy, Gx = Ux^T Ux;   |target|^2 a constant,
+ * and an iteration reads X, Tt and writes P = Gy X Gx (each [C,h,w]) instead of the [C, OH-2crop, OW-2crop] target twice.  float64 sums
+ * over the float32 tap weights of nefes_bicubic_up_fwd.
+ *   nefes_bicubic_gram:   G dev [n_in, n_in] doubles of one axis' window (once per geometry; zero outside |a - b| <= 3).
+ *   nefes_upcos_prepare:  once per target: tt dev [C,h,w] doubles, dbb dev [C] doubles; tmp dev [C, OH-2crop, w] doubles (work space);
+ *                         tx_* / ty_* the gather tables of nefes_upcos_loss_bwd.
+ *   nefes_upcos_gram_fwd: loss and scratch as nefes_upcos_loss_fwd writes them (same layout, same cosine_final launch);
+ *                         pmat dev [C,h,w] doubles kept for the backward; band >= the Gram matrices' half band width (3).
+ *   nefes_upcos_gram_bwd: g_x [C,h,w] = g_loss[0] * d loss / d x. */
+int nefes_bicubic_gram(int n_in, int n_out, int o0, int n_win, double* G, void* stream);
+int nefes_upcos_prepare(int C, int h, int w, int OH, int OW, int crop, const float* target, const int* tx_first, const int* tx_count,
+                        const float* tx_wt, const int* ty_first, const int* ty_count, const float* ty_wt, int T, double* tmp, double* tt,
+                        double* dbb, void* stream);
+int nefes_upcos_gram_fwd(int C, int h, int w, const float* x, const double* tt, const double* dbb, const double* gram_x, const double* gram_y,
+                         int band, double* scratch, double* pmat, float* loss, void* stream);
+int nefes_upcos_gram_bwd(int C, int h, int w, const double* tt, const double* pmat, const double* scratch, const float* g_loss, float* g_x,
+                         void* stream);
 /* Which up-sampled positions of the window [o0, o0 + n_win) of an axis (n_in -> n_out, bicubic) reach source index y, and with what
  * weight: first[y] (relative to o0), count[y], wt[y * T .. + count[y]) -- the transpose of the interpolation, a function of the sizes
  * only; T >= 4 n_out / n_in + 8. */

@@ -307,6 +307,164 @@ __global__ __launch_bounds__(256) void upcos_gather_rows_kernel(long outer, int 
     dst[idx] = gather_axis_table(gy, y, src + p * n_win * inner + q, inner);
 }
 
+
+// ---- the same loss for a FIXED target, through the Gram matrices of the up-sampling (round 5) ---------------------------------
+// Per channel the up-sampled, cropped image is  up = Uy X Ux^T  (Uy [CH, h], Ux [CW, w]: the bicubic taps of the window's rows and
+// columns, clamped at the borders).  The refinement loop holds the target for all iterations of an image (DFM_APR_refine.py:
+// 100-131: the query image's features are extracted once, the pose is optimised opt_iter times against them), so
+//     <up, target> = <X, Uy^T target Ux> = <X, Tt>            Tt [C, h, w]: once per image (upcos_prep_* below)
+//     |up|^2       = <X, Gy X Gx>                             Gy = Uy^T Uy [h, h], Gx = Ux^T Ux [w, w]: once per geometry, banded
+//     |target|^2                                              once per image
+//     d loss / d X = -g / C (k1 Tt - k2 Gy X Gx)              (k1, k2 of upcos_bwd_rows_kernel)
+// and an iteration touches the 2.4 MB of X, Tt and P = Gy X Gx instead of the 34 MB target twice: 30 + 47 + 14 us -> three small
+// launches.  Everything in float64 from the float32 tap weights (those of taps_of: what ATen's kernel uses), so the result is the
+// float64 value of the loss on the float32 taps -- the one-pass kernels above round every up-sampled value to float32 first.
+__global__ void bicubic_gram_kernel(int n_in, int o0, int n_win, float scale, double* __restrict__ G) {
+    using namespace nefes_bicubic;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_in * n_in) return;
+    const int ya = idx / n_in, yb = idx % n_in;
+    double acc = 0;
+    for (int o = o0; o < o0 + n_win; ++o) {
+        const Taps t = taps_of(scale, o);
+        double wa = 0, wb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = clampi(t.base - 1 + k, n_in);
+            if (y == ya) wa += (double)t.w[k];
+            if (y == yb) wb += (double)t.w[k];
+        }
+        acc += wa * wb;
+    }
+    G[idx] = acc;
+}
+
+// tmp[c][r][x] = sum_ox Wx(ox -> x) target[c][r][ox]
+__global__ __launch_bounds__(256) void upcos_prep_rows_kernel(long n, int CW, int w, nefes_bicubic::GatherTable gx,
+                                                              const float* __restrict__ target, double* __restrict__ tmp) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int x = (int)(idx % w);
+    const long row = idx / w;                                    // c * CH + r
+    const int f = gx.first[x], cnt = gx.count[x];
+    const float* wt = gx.wt + (long)x * gx.T;
+    const float* s = target + row * CW + f;
+    double acc = 0;
+    for (int i = 0; i < cnt; ++i) acc += (double)wt[i] * (double)s[i];
+    tmp[idx] = acc;
+}
+
+// tt[c][y][x] = sum_r Wy(r -> y) tmp[c][r][x]
+__global__ __launch_bounds__(256) void upcos_prep_cols_kernel(long n, int h, int CH, int w, nefes_bicubic::GatherTable gy,
+                                                              const double* __restrict__ tmp, double* __restrict__ tt) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int x = (int)(idx % w), y = (int)((idx / w) % h);
+    const long c = idx / ((long)w * h);
+    const int f = gy.first[y], cnt = gy.count[y];
+    const float* wt = gy.wt + (long)y * gy.T;
+    const double* s = tmp + (c * CH + f) * w + x;
+    double acc = 0;
+    for (int i = 0; i < cnt; ++i) acc += (double)wt[i] * s[(long)i * w];
+    tt[idx] = acc;
+}
+
+// dbb[c] = |target[c]|^2
+__global__ __launch_bounds__(256) void upcos_prep_norm_kernel(long P, const float* __restrict__ target, double* __restrict__ dbb) {
+    const float* pb = target + (long)blockIdx.x * P;
+    double acc = 0;
+    for (long i = threadIdx.x; i < P; i += 256) {
+        const double v = pb[i];
+        acc += v * v;
+    }
+    __shared__ double sh[256];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dbb[blockIdx.x] = sh[0];
+}
+
+// One workgroup per (channel, band of source rows): Q = X Gx on the band's rows and R more on either side (LDS), P = Gy Q on the
+// band, partial <X, Tt> and <X, P> in the layout cosine_final_kernel sums (|target|^2 rides in part 0).  Fixed order: deterministic.
+__global__ __launch_bounds__(256) void upcos_gram_fwd_kernel(int h, int w, int R, const float* __restrict__ x, const double* __restrict__ tt,
+                                                             const double* __restrict__ dbb, const double* __restrict__ Gx,
+                                                             const double* __restrict__ Gy, double* __restrict__ part,
+                                                             double* __restrict__ pmat) {
+    extern __shared__ double lds_d[];
+    const int c = blockIdx.x / kParts, q = blockIdx.x % kParts;
+    const int per = (h + kParts - 1) / kParts, r_lo = q * per < h ? q * per : h, r_hi = r_lo + per < h ? r_lo + per : h;
+    const int y_lo = r_lo - R > 0 ? r_lo - R : 0, y_hi = r_hi + R < h ? r_hi + R : h, nrow = r_hi > r_lo ? y_hi - y_lo : 0;
+    const int B = 2 * R + 1;
+    double* Q = lds_d;                                  // [nrow][w]
+    double* gxb = Q + (per + 2 * R) * w;                // [w][B]: column xx of Gx, rows xx - R .. xx + R (zero outside the matrix)
+    double* gyb = gxb + w * B;                          // [per][B]: row y of Gy, columns y - R .. y + R
+    float* X = (float*)(gyb + per * B);                 // [nrow][w]
+    const float* src = x + ((long)c * h + y_lo) * w;
+    // everything that comes from memory in ONE round: the rows of X, the band of Gx, this part's rows of Gy's band
+    for (int i = threadIdx.x; i < nrow * w; i += 256) X[i] = src[i];
+    for (int i = threadIdx.x; i < w * B; i += 256) {
+        const int xx = i / B, a = xx - R + i % B;
+        gxb[i] = a >= 0 && a < w ? Gx[(long)a * w + xx] : 0.0;
+    }
+    for (int i = threadIdx.x; i < (r_hi - r_lo) * B; i += 256) {
+        const int y = r_lo + i / B, b = y - R + i % B;
+        gyb[i] = b >= 0 && b < h ? Gy[(long)y * h + b] : 0.0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nrow * w; i += 256) {
+        const int xx = i % w, yy = i / w;
+        const int a0 = xx - R > 0 ? xx - R : 0, a1 = xx + R < w - 1 ? xx + R : w - 1;
+        double acc = 0;
+        for (int a = a0; a <= a1; ++a) acc += (double)X[yy * w + a] * gxb[xx * B + a - xx + R];
+        Q[i] = acc;
+    }
+    __syncthreads();
+    double dab = 0, daa = 0;
+    for (int i = threadIdx.x; i < (r_hi - r_lo) * w; i += 256) {
+        const int xx = i % w, y = r_lo + i / w;
+        const int b0 = y - R > 0 ? y - R : 0, b1 = y + R < h - 1 ? y + R : h - 1;
+        const long o = ((long)c * h + y) * w + xx;
+        const double tv = tt[o];
+        double p = 0;
+        for (int b = b0; b <= b1; ++b) p += gyb[(y - r_lo) * B + b - y + R] * Q[(b - y_lo) * w + xx];
+        const double xv = X[(y - y_lo) * w + xx];
+        dab += xv * tv;
+        daa += xv * p;
+        pmat[o] = p;
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = dab; sh[1][threadIdx.x] = daa;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double* o = part + ((long)c * kParts + q) * 3;
+        o[0] = sh[0][0]; o[1] = sh[1][0]; o[2] = q == 0 ? dbb[c] : 0.0;
+    }
+}
+
+// g_x = -g / C (k1 Tt - k2 P): the factors of upcos_bwd_rows_kernel
+__global__ __launch_bounds__(256) void upcos_gram_bwd_kernel(int C, long P, double eps, const double* __restrict__ tt, const double* __restrict__ pmat,
+                                                             const double* __restrict__ stats, const float* __restrict__ g_loss,
+                                                             float* __restrict__ g_x) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)C * P) return;
+    const int c = (int)(idx / P);
+    const double dab = stats[c * 4 + 0], na = stats[c * 4 + 1], nb = stats[c * 4 + 2];
+    const double nbc = nb > eps ? nb : eps;
+    const double k = -(double)g_loss[0] / C;
+    const double k1 = na > eps ? k / (na * nbc) : k / (eps * nbc), k2 = na > eps ? k * dab / (na * na * na * nbc) : 0.0;
+    g_x[idx] = (float)(k1 * tt[idx] - k2 * pmat[idx]);
+}
+
 }  // namespace
 
 extern "C" int nefes_upcos_loss_fwd(int C, int h, int w, int OH, int OW, int crop, const float* x, const float* target, double* scratch,
@@ -340,6 +498,54 @@ extern "C" int nefes_upcos_loss_bwd(int C, int h, int w, int OH, int OW, int cro
     const long n = (long)C * h * w;                    // g_x[c][y][x] = sum over the window's rows oy of Wy(oy -> y) tmp[c][oy - o0][x]
     hipLaunchKernelGGL(upcos_gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)C, h, CH, (long)w, gy,
                        (const float*)tmp, g_x);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_bicubic_gram(int n_in, int n_out, int o0, int n_win, double* G, void* stream) {
+    if (n_in <= 0 || n_out <= 0 || o0 < 0 || n_win <= 0 || o0 + n_win > n_out || !G) return NEFES_E_BADARG;
+    if ((long)n_in * n_in > (1 << 24)) return NEFES_E_UNSUPPORTED;
+    hipLaunchKernelGGL(bicubic_gram_kernel, dim3((unsigned)((n_in * n_in + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_in, o0, n_win,
+                       (float)n_in / n_out, G);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_upcos_prepare(int C, int h, int w, int OH, int OW, int crop, const float* target, const int* tx_first, const int* tx_count,
+                                   const float* tx_wt, const int* ty_first, const int* ty_count, const float* ty_wt, int T, double* tmp,
+                                   double* tt, double* dbb, void* stream) {
+    const int CH = OH - 2 * crop, CW = OW - 2 * crop;
+    if (C <= 0 || h <= 0 || w <= 0 || crop < 0 || CH <= 0 || CW <= 0 || !target || !tmp || !tt || !dbb) return NEFES_E_BADARG;
+    if (!tx_first || !tx_count || !tx_wt || !ty_first || !ty_count || !ty_wt || T <= 0) return NEFES_E_BADARG;
+    const nefes_bicubic::GatherTable gx{tx_first, tx_count, tx_wt, T}, gy{ty_first, ty_count, ty_wt, T};
+    const long n1 = (long)C * CH * w, n2 = (long)C * h * w;
+    if ((n1 + 255) / 256 > 0x7fffffffl) return NEFES_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(upcos_prep_rows_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, n1, CW, w, gx, target, tmp);
+    hipLaunchKernelGGL(upcos_prep_cols_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, n2, h, CH, w, gy, (const double*)tmp, tt);
+    hipLaunchKernelGGL(upcos_prep_norm_kernel, dim3((unsigned)C), dim3(256), 0, st, (long)CH * CW, target, dbb);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_upcos_gram_fwd(int C, int h, int w, const float* x, const double* tt, const double* dbb, const double* gram_x,
+                                    const double* gram_y, int band, double* scratch, double* pmat, float* loss, void* stream) {
+    if (C <= 0 || h <= 0 || w <= 0 || band < 0 || !x || !tt || !dbb || !gram_x || !gram_y || !scratch || !pmat || !loss) return NEFES_E_BADARG;
+    const int per = (h + kParts - 1) / kParts;
+    const size_t lds = (size_t)(per + 2 * band) * w * 12 + (size_t)(w + per) * (2 * band + 1) * 8;
+    if (lds > 96 * 1024) return NEFES_E_UNSUPPORTED;
+    hipError_t e = hipFuncSetAttribute((const void*)upcos_gram_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    double* part = scratch + (size_t)C * 4;
+    hipLaunchKernelGGL(upcos_gram_fwd_kernel, dim3((unsigned)(C * kParts)), dim3(256), lds, (hipStream_t)stream, h, w, band, x, tt, dbb, gram_x,
+                       gram_y, part, pmat);
+    hipLaunchKernelGGL(cosine_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, C, 1e-6, (const double*)part, scratch, loss);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_upcos_gram_bwd(int C, int h, int w, const double* tt, const double* pmat, const double* scratch, const float* g_loss,
+                                    float* g_x, void* stream) {
+    if (C <= 0 || h <= 0 || w <= 0 || !tt || !pmat || !scratch || !g_loss || !g_x) return NEFES_E_BADARG;
+    const long n = (long)C * h * w;
+    hipLaunchKernelGGL(upcos_gram_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C, (long)h * w, 1e-6, tt, pmat,
+                       scratch, g_loss, g_x);
     return (int)hipGetLastError();
 }
 

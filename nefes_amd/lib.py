@@ -54,6 +54,10 @@ SIGNATURES = {
     "nefes_upcos_loss_fwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "nefes_upcos_loss_bwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "nefes_bicubic_gather_table": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "nefes_bicubic_gram": (_i, [_i, _i, _i, _i, _p, _p]),
+    "nefes_upcos_prepare": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "nefes_upcos_gram_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "nefes_upcos_gram_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "nefes_adam_step": (_i, [_i, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]),
     "nefes_pack_weights": (_i, [_desc, C.POINTER(_p), _i, _p, _sz]),
     "nefes_pack_map": (_i, [_desc, _p, _sz, _p]),

@@ -111,6 +111,8 @@ class RayGen(torch.autograd.Function):
         (c2w,) = ctx.saved_tensors
         H, W, focal, row0, nrows = ctx.geom
         g = raygen_bwd(H, W, focal, c2w, row0, nrows, g_o, g_d, g_v)
+        if tuple(c2w.shape) == (3, 4) and c2w.dtype == torch.float32:
+            return g, None, None, None, None, None         # (the refinement loop's case: no zero fill + copy for a row that is not there)
         out = torch.zeros_like(c2w)
         out[:3, :4] = g
         return out, None, None, None, None, None
@@ -1098,11 +1100,14 @@ class CosineFeatureLoss(torch.autograd.Function):
         ctx.save_for_backward(af, bf, scratch)
         ctx.shape = a.shape
         cos = scratch[:4 * Cc].view(Cc, 4)[:, 3]          # float64 cosine similarity per channel (a view of the scratch)
+        ctx.set_materialize_grads(False)                  # no zero-filled gradient for `cos` in the backward
         ctx.mark_non_differentiable(cos)
         return loss, cos
 
     @staticmethod
     def backward(ctx, g, _g_cos):
+        if g is None:
+            return (None,) * 2
         af, bf, scratch = ctx.saved_tensors
         gf = _f32(g).reshape(1)
         g_a = torch.empty_like(af)
@@ -1122,12 +1127,17 @@ def cosine_feature_loss(a, b, return_cos=False):
 _GATHER_TABLES = {}
 
 
-def bicubic_gather_table(n_in, n_out, o0, n_win, device):
-    """(first, count, wt, T) of one axis (include/nefes_hip.h nefes_bicubic_gather_table), built once per geometry and device."""
-    key = (int(n_in), int(n_out), int(o0), int(n_win), str(device))
+def _gather_T(n_in, n_out):
+    return 4 * ((n_out + n_in - 1) // n_in) + 8
+
+
+def bicubic_gather_table(n_in, n_out, o0, n_win, device, T=None):
+    """(first, count, wt, T) of one axis (include/nefes_hip.h nefes_bicubic_gather_table), built once per geometry and device.  T: row
+    length of `wt` (default: what this axis needs; the kernels that take the tables of BOTH axes take one T: `bicubic_gather_tables`)."""
+    T = _gather_T(n_in, n_out) if T is None else int(T)
+    key = (int(n_in), int(n_out), int(o0), int(n_win), T, str(device))
     t = _GATHER_TABLES.get(key)
     if t is None:
-        T = 4 * ((n_out + n_in - 1) // n_in) + 8
         first = torch.zeros(n_in, dtype=torch.int32, device=device)
         count = torch.zeros(n_in, dtype=torch.int32, device=device)
         wt = torch.zeros(n_in, T, device=device)
@@ -1135,6 +1145,13 @@ def bicubic_gather_table(n_in, n_out, o0, n_win, device):
                 "nefes_bicubic_gather_table")
         t = _GATHER_TABLES[key] = (first, count, wt, T)
     return t
+
+
+def bicubic_gather_tables(h, w, OH, OW, crop, device):
+    """The x and y tables with ONE row length (nefes_upcos_loss_bwd / nefes_upcos_prepare take a single T): until round 5 the y table was
+    built with its own T and read with the x table's -- the same number for the loop's integer scale, not for OH / h != OW / w."""
+    T = max(_gather_T(w, OW), _gather_T(h, OH))
+    return (bicubic_gather_table(w, OW, crop, OW - 2 * crop, device, T), bicubic_gather_table(h, OH, crop, OH - 2 * crop, device, T))
 
 
 class UpsampledCosineLoss(torch.autograd.Function):
@@ -1156,19 +1173,21 @@ class UpsampledCosineLoss(torch.autograd.Function):
         ctx.save_for_backward(xf, tf, scratch)
         ctx.cfg = (x.shape, OH, OW, crop)
         cos = scratch[:4 * Cc].view(Cc, 4)[:, 3]
+        ctx.set_materialize_grads(False)                  # no zero-filled gradient for `cos` in the backward
         ctx.mark_non_differentiable(cos)
         return loss, cos
 
     @staticmethod
     def backward(ctx, g, _g_cos):
+        if g is None:
+            return (None,) * 5
         xf, tf, scratch = ctx.saved_tensors
         shape, OH, OW, crop = ctx.cfg
         Cc, h, w = xf.shape
         gf = _f32(g).reshape(1)
         tmp = torch.empty(Cc, OH - 2 * crop, w, device=xf.device)
         g_x = torch.empty_like(xf)
-        fx, cx, wx, T = bicubic_gather_table(w, OW, crop, OW - 2 * crop, xf.device)
-        fy, cy, wy, _ = bicubic_gather_table(h, OH, crop, OH - 2 * crop, xf.device)
+        (fx, cx, wx, T), (fy, cy, wy, _) = bicubic_gather_tables(h, w, OH, OW, crop, xf.device)
         with _timed("upcos_loss_bwd"):
             L.check(L.load().nefes_upcos_loss_bwd(Cc, h, w, OH, OW, crop, _chk(xf, "x"), _chk(tf, "target"), _chk(scratch, "scratch", torch.float64),
                                                   _chk(gf, "g_loss"), fx.data_ptr(), cx.data_ptr(), wx.data_ptr(), fy.data_ptr(), cy.data_ptr(),
@@ -1179,6 +1198,96 @@ class UpsampledCosineLoss(torch.autograd.Function):
 def upsampled_cosine_loss(x, target, size, crop=0, return_cos=False):
     """1 - mean over channels of the cosine similarity (over pixels) between the bicubically up-sampled, cropped x and target."""
     loss, cos = UpsampledCosineLoss.apply(x, target, int(size[0]), int(size[1]), int(crop))
+    return (loss, cos) if return_cos else loss
+
+
+_GRAMS = {}
+
+
+def bicubic_gram(n_in, n_out, o0, n_win, device):
+    """(G [n_in, n_in] float64, half band width) of one axis' window (include/nefes_hip.h nefes_bicubic_gram), once per geometry."""
+    key = (int(n_in), int(n_out), int(o0), int(n_win), str(device))
+    t = _GRAMS.get(key)
+    if t is None:
+        G = torch.zeros(n_in, n_in, dtype=torch.float64, device=device)
+        L.check(L.load().nefes_bicubic_gram(n_in, n_out, o0, n_win, G.data_ptr(), _stream()), "nefes_bicubic_gram")
+        nz = G.nonzero()
+        band = int((nz[:, 0] - nz[:, 1]).abs().max()) if nz.numel() else 0
+        t = _GRAMS[key] = (G, band)
+    return t
+
+
+class UpcosTarget:
+    """What upsampled_cosine_loss needs of a FIXED target [C, OH-2crop, OW-2crop] (the refinement loop's: one target for all
+    iterations of an image): Tt = Uy^T target Ux [C,h,w], |target|^2 per channel, and the Gram matrices of the two axes.  `update(target)`
+    refills the same buffers (a captured graph keeps reading them).  csrc/refine.hip upcos_prep_* / upcos_gram_*."""
+
+    def __init__(self, C, h, w, OH, OW, crop, device):
+        self.C, self.h, self.w, self.OH, self.OW, self.crop = int(C), int(h), int(w), int(OH), int(OW), int(crop)
+        CH, CW = self.OH - 2 * self.crop, self.OW - 2 * self.crop
+        self.tt = torch.zeros(self.C, self.h, self.w, dtype=torch.float64, device=device)
+        self.dbb = torch.zeros(self.C, dtype=torch.float64, device=device)
+        self.gx, bx = bicubic_gram(self.w, self.OW, self.crop, CW, device)
+        self.gy, by = bicubic_gram(self.h, self.OH, self.crop, CH, device)
+        self.band = max(bx, by)
+        self.tx, self.ty = bicubic_gather_tables(self.h, self.w, self.OH, self.OW, self.crop, device)
+        self.device = device
+
+    def update(self, target):
+        CH, CW = self.OH - 2 * self.crop, self.OW - 2 * self.crop
+        tf = _f32(target).reshape(self.C, CH, CW)
+        tmp = torch.empty(self.C, CH, self.w, dtype=torch.float64, device=tf.device)
+        (fx, cx, wx, T), (fy, cy, wy, _) = self.tx, self.ty
+        L.check(L.load().nefes_upcos_prepare(self.C, self.h, self.w, self.OH, self.OW, self.crop, _chk(tf, "target"), fx.data_ptr(), cx.data_ptr(),
+                                             wx.data_ptr(), fy.data_ptr(), cy.data_ptr(), wy.data_ptr(), T, _chk(tmp, "tmp", torch.float64),
+                                             _chk(self.tt, "tt", torch.float64), _chk(self.dbb, "dbb", torch.float64), _stream()),
+                "nefes_upcos_prepare")
+        return self
+
+
+class UpsampledCosineLossPrepared(torch.autograd.Function):
+    """UpsampledCosineLoss against a prepared target (UpcosTarget): two small launches forward, one backward, on [C,h,w] data only."""
+
+    @staticmethod
+    def forward(ctx, x, prep):
+        xf = _f32(x)
+        if tuple(xf.shape[-3:]) != (prep.C, prep.h, prep.w) or xf.numel() != prep.C * prep.h * prep.w:
+            raise ValueError(f"nefes_amd: features {tuple(x.shape)} do not match the prepared target ({prep.C}, {prep.h}, {prep.w})")
+        xf = xf.reshape(prep.C, prep.h, prep.w)
+        lib = L.load()
+        scratch = torch.empty(lib.nefes_cosine_loss_scratch_doubles(prep.C), dtype=torch.float64, device=xf.device)
+        pmat = torch.empty(prep.C, prep.h, prep.w, dtype=torch.float64, device=xf.device)
+        loss = torch.empty((), device=xf.device)
+        with _timed("upcos_gram_fwd"):
+            L.check(lib.nefes_upcos_gram_fwd(prep.C, prep.h, prep.w, _chk(xf, "x"), _chk(prep.tt, "tt", torch.float64),
+                                             _chk(prep.dbb, "dbb", torch.float64), _chk(prep.gx, "gram_x", torch.float64),
+                                             _chk(prep.gy, "gram_y", torch.float64), prep.band, _chk(scratch, "scratch", torch.float64),
+                                             _chk(pmat, "pmat", torch.float64), _chk(loss, "loss"), _stream()), "nefes_upcos_gram_fwd")
+        ctx.save_for_backward(scratch, pmat)
+        ctx.prep, ctx.shape = prep, x.shape
+        cos = scratch[:4 * prep.C].view(prep.C, 4)[:, 3]
+        ctx.set_materialize_grads(False)                  # no zero-filled gradient for `cos` in the backward
+        ctx.mark_non_differentiable(cos)
+        return loss, cos
+
+    @staticmethod
+    def backward(ctx, g, _g_cos):
+        if g is None:
+            return (None,) * 2
+        scratch, pmat = ctx.saved_tensors
+        prep = ctx.prep
+        gf = _f32(g).reshape(1)
+        g_x = torch.empty(prep.C, prep.h, prep.w, device=pmat.device)
+        with _timed("upcos_gram_bwd"):
+            L.check(L.load().nefes_upcos_gram_bwd(prep.C, prep.h, prep.w, _chk(prep.tt, "tt", torch.float64), _chk(pmat, "pmat", torch.float64),
+                                                  _chk(scratch, "scratch", torch.float64), _chk(gf, "g_loss"), _chk(g_x, "g_x"), _stream()),
+                    "nefes_upcos_gram_bwd")
+        return g_x.reshape(ctx.shape), None
+
+
+def upsampled_cosine_loss_prepared(x, prep, return_cos=False):
+    """upsampled_cosine_loss(x, target, (OH, OW), crop) for the target `prep` (an UpcosTarget) was last updated with."""
+    loss, cos = UpsampledCosineLossPrepared.apply(x, prep)
     return (loss, cos) if return_cos else loss
 
 

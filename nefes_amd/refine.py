@@ -12,6 +12,8 @@ loop's cost is the kernels' and not the host's; per-image state (pose delta, Ada
 lives in static device buffers that are reset in place.  The bicubic up-sampling runs on ops.BicubicUpsample (gather
 backward; the library's atomic scatter backward was 40 % of an iteration).  No CPU fallback anywhere on the path.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -95,6 +97,10 @@ class PoseRefiner:
     caller's (a CNN outside this path); implies `upsample=True`."""
 
     FUSED_UPSAMPLED_LOSS = True      # False: bicubic up-sampling and cosine loss as separate kernels (the tests compare the two)
+    # The loop's target is fixed for all iterations of an image: its share of the up-sampled loss (Uy^T target Ux, |target|^2) is
+    # computed when the target is set and an iteration runs on [C,h,w] data only (ops.UpcosTarget; csrc/refine.hip upcos_gram_*).
+    # False: the one-pass kernels that read the whole target every iteration (the tests compare the two).
+    PREPARED_TARGET = os.environ.get("NEFES_PREPARED_TARGET", "1") != "0"
 
     def __init__(self, render_kwargs, args, hwf, near, far, tinyscale=4, lr_r=0.01, lr_t=0.1, lietorch=False,
                  upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda", adam_capturable=None,
@@ -193,8 +199,12 @@ class PoseRefiner:
             _, _, fused = self.coarse.run_fusion_net(rgb, feat, self.h, self.w, B, per_image_norm=B > 1)
         if self.upsample and self.fused_glue and not self.per_pixel and self.FUSED_UPSAMPLED_LOSS:
             # up-sampling, crop and feature loss in one pass each way: the 34 MB up-sampled image is never written (ops.upsampled_cosine_loss)
-            mean_loss, cos = ops.upsampled_cosine_loss(fused.reshape(B * self.C, self.h, self.w), self.target.reshape(B * self.C, self.H - 20, self.W - 20),
-                                                       (self.H, self.W), crop=10, return_cos=True)
+            if self.PREPARED_TARGET:
+                mean_loss, cos = ops.upsampled_cosine_loss_prepared(fused.reshape(B * self.C, self.h, self.w), self._sync_upcos(), return_cos=True)
+            else:
+                mean_loss, cos = ops.upsampled_cosine_loss(fused.reshape(B * self.C, self.h, self.w),
+                                                           self.target.reshape(B * self.C, self.H - 20, self.W - 20), (self.H, self.W), crop=10,
+                                                           return_cos=True)
             if B > 1:
                 return mean_loss * float(B), (1.0 - cos.view(B, self.C).mean(1)).float()
             return mean_loss, mean_loss.detach()
@@ -215,11 +225,32 @@ class PoseRefiner:
             loss = feature_loss(fused, self.target, per_pixel=self.per_pixel)
         return loss, loss.detach()
 
+    def _sync_upcos(self):
+        """The prepared form of self.target (ops.UpcosTarget), recomputed whenever the target buffer was written since (tensor version
+        counter).  _reset / refine_apr call this after copying an image's target in, i.e. before a captured graph is replayed; under
+        capture the buffers must already be current (a re-computation would be replayed with every iteration)."""
+        key = (self.target.data_ptr(), self.target._version)
+        if getattr(self, "_upcos", None) is None or self._upcos_shape != tuple(self.target.shape):
+            self._upcos = ops.UpcosTarget(self.B * self.C, self.h, self.w, self.H, self.W, 10, self.dev)
+            self._upcos_shape, self._upcos_key = tuple(self.target.shape), None
+        if self._upcos_key != key:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("nefes_amd: the refinement target changed without PoseRefiner._sync_upcos() before graph capture")
+            with torch.no_grad():
+                self._upcos.update(self.target.reshape(self.B * self.C, self.H - 20, self.W - 20))
+            self._upcos_key = key
+        return self._upcos
+
+    def _uses_prepared_target(self):
+        return bool(self.upsample and self.fused_glue and not self.per_pixel and self.FUSED_UPSAMPLED_LOSS and self.PREPARED_TARGET)
+
     def loss_and_grad(self):
         """Loss at the current (r, t) and its gradient, written into the parameters' static .grad buffers (no optimizer step).
         The gradients are copied over the previous ones: nothing has to be zeroed between iterations."""
         loss, per_image = self._loss()
-        gr, gt = torch.autograd.grad(loss, [self.model.r, self.model.t])
+        if getattr(self, "_one", None) is None or self._one.shape != loss.shape:
+            self._one = torch.ones_like(loss)              # the root gradient, once: autograd otherwise fills a new one per iteration
+        gr, gt = torch.autograd.grad(loss, [self.model.r, self.model.t], grad_outputs=self._one)
         for p, g in ((self.model.r, gr), (self.model.t, gt)):
             if p.grad is None:
                 p.grad = torch.empty_like(p)
@@ -238,6 +269,8 @@ class PoseRefiner:
             self.model.t.zero_()
             self.model.init_c2w.copy_(init_c2w.reshape(self.B, 4, 4))
             self.target.copy_(feature_target.reshape(self.target.shape))
+            if self._uses_prepared_target():
+                self._sync_upcos()
             self.hist.copy_(hist.reshape(self.B, 10))
             expo = getattr(self.coarse, "exposure_embedding", None)
             if (self.fused_glue and getattr(self.args, "encode_hist", False) and expo is not None
@@ -334,6 +367,8 @@ class PoseRefiner:
         with torch.no_grad():
             self.photo.copy_(photo.to(dev).reshape(self.photo.shape))
             self.target.copy_(feature_target.to(dev).reshape(self.C, self.H, self.W)[:, 10:-10, 10:-10])
+            if self._uses_prepared_target():
+                self._sync_upcos()
             for pw, pb in zip(self.apr.parameters(), self.apr_base.parameters()):
                 pw.copy_(pb.to(dev))                                       # a fresh copy of the network per image (:209)
             for bw, bb in zip(self.apr.buffers(), self.apr_base.buffers()):

@@ -192,6 +192,41 @@ def test_upsampled_cosine_loss_equals_separate_kernels(C, h, w, ts):
     assert abs(float(la) - float(ld)) < 3e-7 and rel(xa.grad.cpu().numpy(), xd.grad.numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("C,h,w,OH,OW,crop", [(128, 60, 80, 240, 320, 10), (5, 15, 20, 60, 80, 10), (3, 9, 11, 31, 45, 3), (2, 8, 8, 32, 32, 0),
+                                              (4, 6, 70, 24, 280, 1)])
+def test_prepared_target_loss_equals_one_pass_kernels_and_torch(C, h, w, OH, OW, crop):
+    """ops.upsampled_cosine_loss_prepared (the fixed target folded through the up-sampling once: <up, t> = <x, Uy^T t Ux>,
+    |up|^2 = <x, Gy x Gx>; csrc/refine.hip upcos_gram_*) == ops.upsampled_cosine_loss == torch's Upsample + CosineSimilarity in
+    float64 (DFM_APR_refine.py:114-131), value, per-channel similarities and gradient; integer and non-integer scales, with and
+    without a crop, one all-zero channel (the eps clamp), and a second target through the same buffers (what a captured graph reads)."""
+    from nefes_amd import ops
+    from nefes_amd.refine import feature_loss
+    g = torch.Generator().manual_seed(C * h + OW)
+    x = torch.randn(1, C, h, w, generator=g)
+    x[0, C - 1] = 0.
+    up = torch.nn.functional.interpolate(x, size=(OH, OW), mode="bicubic")[0, :, crop:OH - crop, crop:OW - crop]
+    prep = ops.UpcosTarget(C, h, w, OH, OW, crop, DEV)
+    assert prep.band <= 3 and float((prep.gx - prep.gx.T).abs().max()) == 0.0
+    for k in range(2):
+        tgt = torch.randn(C, OH - 2 * crop, OW - 2 * crop, generator=g) + 0.5 * up
+        prep.update(tgt.to(DEV))
+        xa, xb = x.to(DEV).requires_grad_(), x.to(DEV).requires_grad_()
+        la, cos_a = ops.upsampled_cosine_loss_prepared(xa, prep, return_cos=True)
+        lb, cos_b = ops.upsampled_cosine_loss(xb, tgt.to(DEV), (OH, OW), crop=crop, return_cos=True)
+        (2.0 * la).backward()
+        (2.0 * lb).backward()
+        xd = x.double().requires_grad_()
+        ld = feature_loss(torch.nn.functional.interpolate(xd, size=(OH, OW), mode="bicubic")[0, :, crop:OH - crop, crop:OW - crop], tgt.double())
+        (2.0 * ld).backward()
+        e_prep, e_pass = rel(xa.grad.cpu().numpy(), xd.grad.numpy()), rel(xb.grad.cpu().numpy(), xd.grad.numpy())
+        P.record(f"upcos_prepared[{C},{h},{w},{OH},{OW},{crop}][{k}]", "d loss / d fused features (vs float64 torch)", e_hip=e_prep, e_ref=None,
+                 direct=e_prep, bound=2e-6, one_pass_kernels=e_pass, loss_err=abs(float(la) - float(ld)), loss_err_one_pass=abs(float(lb) - float(ld)))
+        assert abs(float(la) - float(lb)) < 1e-7 and abs(float(la) - float(ld)) < 3e-7
+        assert float((cos_a - cos_b).abs().max()) < 1e-6 and cos_a.shape == (C,)
+        assert rel(xa.grad.cpu().numpy(), xb.grad.cpu().numpy()) < 1e-6 and e_prep < 2e-6
+        assert float(xa.grad[0, C - 1].abs().max()) > 0          # the clamped-norm channel still has its b / (eps |b|) gradient
+
+
 def test_fused_glue_iteration_equals_torch_glue(golden):
     """One PoseRefiner iteration with the glue kernels == the same iteration with the torch expressions (APR variant: bicubic
     up-sampling + 10 px crop; DFM variant without): loss and (r, t) gradient."""
