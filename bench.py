@@ -167,7 +167,12 @@ class _TinyAPR(torch.nn.Module):
             self.fc.bias.copy_(torch.from_numpy(bias))
 
     def forward(self, x):
-        return self.fc(torch.nn.functional.adaptive_avg_pool2d(x, 2).reshape(x.shape[0], -1))
+        B, Cc, H, W = x.shape
+        if H % 2 == 0 and W % 2 == 0:       # = adaptive_avg_pool2d(x, 2), whose ROCm kernel takes 1.5 ms for this image (a stand-in
+            pooled = x.reshape(B, Cc, 2, H // 2, 2, W // 2).mean((3, 5))          # should not be the largest item of the iteration it times)
+        else:
+            pooled = torch.nn.functional.adaptive_avg_pool2d(x, 2)
+        return self.fc(pooled.reshape(B, -1))
 
 
 def refinement_loop(dev, iters=50, graph=True, images=1, mode="upsampled"):
@@ -209,7 +214,7 @@ def refinement_loop(dev, iters=50, graph=True, images=1, mode="upsampled"):
     n_img = 3
     if mode == "2":
         photo = T(g["photo_u8"]).float()[None] / 255.
-        ref = PoseRefiner(kw, args, (H, W, focal), float(g["near"]), float(g["far"]), graph=False, pose_model=_TinyAPR(g["m2_weight"][0], g["m2_bias"][0]),
+        ref = PoseRefiner(kw, args, (H, W, focal), float(g["near"]), float(g["far"]), graph=graph, pose_model=_TinyAPR(g["m2_weight"][0], g["m2_bias"][0]),
                           svd_reg=True, learning_rate=float(g["m2_lr"]), **common)
         pose, _, _ = ref.refine_apr(photo, full, hist, iters)
         torch.cuda.synchronize()
@@ -380,14 +385,16 @@ def main():
         sec, rays, err_up = refinement_loop(dev, graph=True)
         sec_b, _, _ = refinement_loop(dev, graph=True, images=8)
         sec3, _, err3 = refinement_loop(dev, graph=True, mode="3")
-        sec2, _, err2 = refinement_loop(dev, mode="2")
+        sec2e, _, _ = refinement_loop(dev, graph=False, mode="2")
+        sec2, _, err2 = refinement_loop(dev, graph=True, mode="2")
         print(json.dumps({"metric": "rays/s (fwd+bwd), secondary workload 'loop50'", "value": rays / sec, "unit": "rays/s",
                           "n_gpus": 1, "higher_is_better": True,
                           "dtype": "f32",
                           "data": "synthetic", "vs_baseline": None,
                           "ms_per_image_50_iterations": sec * 1e3, "ms_per_image_50_iterations_eager": sec_e * 1e3,
                           "ms_per_image_50_iterations_8_images_side_by_side": sec_b * 1e3,
-                          "ms_per_image_50_iterations_mode3": sec3 * 1e3, "ms_per_image_50_iterations_mode2_eager": sec2 * 1e3,
+                          "ms_per_image_50_iterations_mode3": sec3 * 1e3, "ms_per_image_50_iterations_mode2": sec2 * 1e3,
+                          "ms_per_image_50_iterations_mode2_eager": sec2e * 1e3,
                           "pose_error_m_deg_after_50_iterations": {"mode3": err3, "mode2": err2, "upsampled_loss_learnpose": err_up,
                                                                    "reference_from": "tests/golden/refine50_60x80.npz: the reference's own DFM_optimization_NFF / "
                                                                                      "train_on_batch on the CPU from the same start"},

@@ -362,6 +362,12 @@ int nefes_pose_compose_fwd(int n_poses, const float* r, const float* t, const fl
 /* g_c2w dev [n,3,4] -> g_r, g_t dev [n,3] (analytic derivative of the Rodrigues formula, float64 inside). */
 int nefes_pose_compose_bwd(int n_poses, const float* r, const float* t, const float* init_c2w, float pose_scale, const float* move,
                            float pose_scale2, const float* g_c2w, float* g_r, float* g_t, void* stream);
+/* svd_reg (dm/DFM_pose_refine.py:119-129): pose dev [n,3,4] -> out dev [n,3,4] with the 3x3 block replaced by U V^T of its SVD (its
+ * orthogonal polar factor), translation column copied.  float64 inside (one-sided Jacobi).  save: dev [n,21] doubles (U, V, sigma) for the
+ * backward, or NULL.  The backward is the polar factor's derivative d A = U [(H - H^T) o K] V^T, H = U^T G V, K_ij = 1 / (s_i + s_j):
+ * well conditioned at the near-rotations a pose network regresses, where autograd through torch.svd divides by s_i^2 - s_j^2 ~ 0. */
+int nefes_svd_reg_fwd(int n_poses, const float* pose, float* out, double* save, void* stream);
+int nefes_svd_reg_bwd(int n_poses, const double* save, const float* g_out, float* g_pose, void* stream);
 /* feature_loss (DFM_pose_refine.py:211-233, per_pixel=False): loss = 1 - mean_c cos(a[c,:], b[c,:]), a, b dev [C,P] contiguous,
  * torch.nn.CosineSimilarity(dim=1, eps=1e-6) semantics, float64 accumulation.  scratch: dev doubles,
  * nefes_cosine_loss_scratch_doubles(C) of them, kept by the caller for the backward. */

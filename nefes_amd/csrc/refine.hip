@@ -107,6 +107,120 @@ __global__ void pose_compose_bwd_kernel(PoseArgs p, const float* __restrict__ g,
     }
 }
 
+// ---- svd_reg (dm/DFM_pose_refine.py:119-129): the 3x3 block A of a regressed pose replaced by U V^T of its SVD ------------------------
+// = the orthogonal polar factor of A.  One thread per pose, float64 inside: one-sided Jacobi on the columns of A (B = A V, V a
+// product of plane rotations, until the columns are orthogonal; sigma_j = |B_j|, U_j = B_j / sigma_j).  U V^T does not depend on the
+// order or signs of the singular triplets, which is all the reference uses.  The backward is the derivative of the polar factor,
+//     d A = U [ (H - H^T) o K ] V^T,   H = U^T G V,   K_ij = 1 / (sigma_i + sigma_j)
+// -- well conditioned for the near-rotations a pose network regresses (sigma ~ 1: K ~ 1/2), where autograd through torch.svd divides
+// by sigma_i^2 - sigma_j^2 ~ 0 and the two halves of U V^T cancel (the loop-gradient excess of mode 2 lived there).
+struct Svd3 {
+    double U[3][3], V[3][3], s[3];
+};
+
+__device__ void svd3(const double A[3][3], Svd3& o) {
+    double B[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { B[i][j] = A[i][j]; V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int i = 0; i < 3; ++i) { al += B[i][p] * B[i][p]; be += B[i][q] * B[i][q]; ga += B[i][p] * B[i][q]; }
+                const double lim = 1e-17 * sqrt(al * be);
+                if (fabs(ga) <= lim || ga == 0.0) continue;
+                off = fmax(off, fabs(ga) / sqrt(al * be));
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < 3; ++i) {
+                    const double bp = B[i][p], bq = B[i][q];
+                    B[i][p] = c * bp - sn * bq;
+                    B[i][q] = sn * bp + c * bq;
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = c * vp - sn * vq;
+                    V[i][q] = sn * vp + c * vq;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    double smax = 0;
+    for (int j = 0; j < 3; ++j) {
+        o.s[j] = sqrt(B[0][j] * B[0][j] + B[1][j] * B[1][j] + B[2][j] * B[2][j]);
+        smax = fmax(smax, o.s[j]);
+    }
+    // U: normalised columns; a column of (numerically) zero length is completed to a right-handed frame with the others
+    bool ok[3];
+    for (int j = 0; j < 3; ++j) {
+        ok[j] = o.s[j] > 1e-300 && o.s[j] > 1e-14 * smax;
+        for (int i = 0; i < 3; ++i) o.U[i][j] = ok[j] ? B[i][j] / o.s[j] : 0.0;
+    }
+    for (int j = 0; j < 3; ++j)
+        if (!ok[j]) {
+            const int a = (j + 1) % 3, b = (j + 2) % 3;
+            if (!ok[a] || !ok[b]) {                     // rank <= 1: any completion; take coordinate axes not parallel to what exists
+                for (int i = 0; i < 3; ++i) o.U[i][j] = i == j ? 1.0 : 0.0;
+                continue;
+            }
+            o.U[0][j] = o.U[1][a] * o.U[2][b] - o.U[2][a] * o.U[1][b];
+            o.U[1][j] = o.U[2][a] * o.U[0][b] - o.U[0][a] * o.U[2][b];
+            o.U[2][j] = o.U[0][a] * o.U[1][b] - o.U[1][a] * o.U[0][b];
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) o.V[i][j] = V[i][j];
+}
+
+// pose [n,3,4] -> out [n,3,4] (rotation block U V^T, translation column copied); save [n,21] doubles = U, V (row-major), sigma
+__global__ void svd_reg_fwd_kernel(int n, const float* __restrict__ pose, float* __restrict__ out, double* __restrict__ save) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* p = pose + (long)k * 12;
+    double A[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = p[i * 4 + j];
+    Svd3 d;
+    svd3(A, d);
+    float* o = out + (long)k * 12;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) o[i * 4 + j] = (float)(d.U[i][0] * d.V[j][0] + d.U[i][1] * d.V[j][1] + d.U[i][2] * d.V[j][2]);
+        o[i * 4 + 3] = p[i * 4 + 3];
+    }
+    if (save) {
+        double* sv = save + (long)k * 21;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) { sv[i * 3 + j] = d.U[i][j]; sv[9 + i * 3 + j] = d.V[i][j]; }
+        for (int j = 0; j < 3; ++j) sv[18 + j] = d.s[j];
+    }
+}
+
+__global__ void svd_reg_bwd_kernel(int n, const double* __restrict__ save, const float* __restrict__ g_out, float* __restrict__ g_pose) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double* sv = save + (long)k * 21;
+    const float* g = g_out + (long)k * 12;
+    double U[3][3], V[3][3], s[3], GV[3][3], H[3][3], M[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { U[i][j] = sv[i * 3 + j]; V[i][j] = sv[9 + i * 3 + j]; }
+    for (int j = 0; j < 3; ++j) s[j] = sv[18 + j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) GV[i][j] = (double)g[i * 4 + 0] * V[0][j] + (double)g[i * 4 + 1] * V[1][j] + (double)g[i * 4 + 2] * V[2][j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) H[i][j] = U[0][i] * GV[0][j] + U[1][i] * GV[1][j] + U[2][i] * GV[2][j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const double den = s[i] + s[j];
+            M[i][j] = den > 0 ? (H[i][j] - H[j][i]) / den : 0.0;          // (rank <= 1: the polar factor is not differentiable there)
+        }
+    float* o = g_pose + (long)k * 12;
+    for (int i = 0; i < 3; ++i) {
+        double UM[3];
+        for (int j = 0; j < 3; ++j) UM[j] = U[i][0] * M[0][j] + U[i][1] * M[1][j] + U[i][2] * M[2][j];
+        for (int j = 0; j < 3; ++j) o[i * 4 + j] = (float)(UM[0] * V[j][0] + UM[1] * V[j][1] + UM[2] * V[j][2]);
+        o[i * 4 + 3] = g[i * 4 + 3];
+    }
+}
+
 // ---- cosine feature loss -------------------------------------------------------------------------------------------------
 constexpr int kParts = 8;      // blocks per channel
 
@@ -546,6 +660,18 @@ extern "C" int nefes_upcos_gram_bwd(int C, int h, int w, const double* tt, const
     const long n = (long)C * h * w;
     hipLaunchKernelGGL(upcos_gram_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C, (long)h * w, 1e-6, tt, pmat,
                        scratch, g_loss, g_x);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_svd_reg_fwd(int n_poses, const float* pose, float* out, double* save, void* stream) {
+    if (n_poses <= 0 || !pose || !out) return NEFES_E_BADARG;
+    hipLaunchKernelGGL(svd_reg_fwd_kernel, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_poses, pose, out, save);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_svd_reg_bwd(int n_poses, const double* save, const float* g_out, float* g_pose, void* stream) {
+    if (n_poses <= 0 || !save || !g_out || !g_pose) return NEFES_E_BADARG;
+    hipLaunchKernelGGL(svd_reg_bwd_kernel, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_poses, save, g_out, g_pose);
     return (int)hipGetLastError();
 }
 

@@ -1082,6 +1082,36 @@ def pose_compose(r, t, init_c2w, pose_scale=1.0, move=(0., 0., 0.), pose_scale2=
     return out[0] if r.dim() == 1 else out
 
 
+class SvdReg(torch.autograd.Function):
+    """svd_reg (dm/DFM_pose_refine.py:119-129) on [..., 3, 4] poses: rotation block -> U V^T, one launch each way (csrc/refine.hip
+    svd_reg_*; float64 inside; the backward is the polar factor's derivative, not autograd through an SVD)."""
+
+    @staticmethod
+    def forward(ctx, pose):
+        pf = _f32(pose).reshape(-1, 3, 4)
+        n = pf.shape[0]
+        out = torch.empty_like(pf)
+        save = torch.empty(n, 21, dtype=torch.float64, device=pf.device)
+        L.check(L.load().nefes_svd_reg_fwd(n, _chk(pf, "pose"), _chk(out, "out"), _chk(save, "save", torch.float64), _stream()), "nefes_svd_reg_fwd")
+        ctx.save_for_backward(save)
+        ctx.shape = pose.shape
+        return out.reshape(pose.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (save,) = ctx.saved_tensors
+        gf = _f32(g).reshape(-1, 3, 4)
+        g_pose = torch.empty_like(gf)
+        L.check(L.load().nefes_svd_reg_bwd(gf.shape[0], _chk(save, "save", torch.float64), _chk(gf, "g_out"), _chk(g_pose, "g_pose"), _stream()),
+                "nefes_svd_reg_bwd")
+        return g_pose.reshape(ctx.shape)
+
+
+def svd_reg(pose):
+    """[..., 3, 4] poses with the 3x3 block replaced by its nearest orthogonal matrix U V^T (include/nefes_hip.h nefes_svd_reg_fwd)."""
+    return SvdReg.apply(pose)
+
+
 class CosineFeatureLoss(torch.autograd.Function):
     """feature_loss (dm/DFM_pose_refine.py:211-233, per_pixel=False) on [C, ...] maps: 1 - mean over channels of the cosine
     similarity over pixels; two launches forward, one backward (to `a` only: the target carries no gradient)."""

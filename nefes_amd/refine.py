@@ -41,9 +41,16 @@ def feature_loss(feature_rgb, feature_target, img_in=True, per_pixel=False):
     return 1 - cos(feature_rgb, feature_target).mean()
 
 
+HIP_SVD_REG = os.environ.get("NEFES_HIP_SVD_REG", "1") != "0"
+
+
 def svd_reg(pose):
     """dm/DFM_pose_refine.py:119-129: the 3x3 block of a regressed [B,3,4] pose replaced by its nearest rotation U V^T.
-    Out of place (the reference writes into its argument)."""
+    Out of place (the reference writes into its argument).  fp32 poses on the GPU take ops.svd_reg (one launch each way, float64 inside,
+    the polar factor's own derivative -- torch.svd there is a solver call plus a backward that divides by sigma_i^2 - sigma_j^2, ~0 for
+    a near-rotation, and nothing of it can be captured into the iteration's graph); HIP_SVD_REG = False keeps the torch expression."""
+    if HIP_SVD_REG and pose.is_cuda and pose.dtype == torch.float32:
+        return ops.svd_reg(pose)
     u, _, v = torch.svd(pose[..., :3, :3])
     return torch.cat([u @ v.transpose(-2, -1), pose[..., :3, 3:]], -1)
 
@@ -151,7 +158,7 @@ class PoseRefiner:
         self.hist = torch.zeros(self.B, 10, device=self.dev)
         self.loss = torch.zeros((), device=self.dev) if self.B == 1 else torch.zeros(self.B, device=self.dev)
         self._affine = None            # static [1,12] buffer with the image's colour transform when the exposure network is frozen
-        self.use_graph, self.graph = bool(graph), None
+        self.use_graph, self.graph, self.apr_graph = bool(graph), None, None
 
     # one iteration on the static buffers -------------------------------------------------------------------------
     def _loss(self):
@@ -357,12 +364,9 @@ class PoseRefiner:
             pose = (self.apr if net is None else net)(self.photo).reshape(1, 3, 4)
             return (svd_reg(pose) if self.svd_reg else pose)[0]
 
-    def refine_apr(self, photo, feature_target, hist, iters=50, verification=True):
-        """One query image, `pose_only=2`: `photo` [1,3,H,W], `feature_target` [C,H,W] (the query image's features at full
-        resolution; cropped here as :125 does).  Returns (pose [3,4] in the regression network's coordinates, losses [iters],
-        info = dict(psnr=(first, last), ssim=(first, last), retreat=bool))."""
-        if self.apr is None:
-            raise RuntimeError("nefes_amd: PoseRefiner was built without pose_model=")
+    def _apr_image_state(self, photo, feature_target, hist):
+        """Per-image state of train_on_batch, written IN PLACE (a captured iteration keeps reading the same buffers): the query image, its
+        cropped features (:125), a fresh copy of the regression network (:209), the histogram and the colour transform's twelve numbers."""
         dev = self.dev
         with torch.no_grad():
             self.photo.copy_(photo.to(dev).reshape(self.photo.shape))
@@ -377,14 +381,69 @@ class PoseRefiner:
             expo = getattr(self.coarse, "exposure_embedding", None)
             if (self.fused_glue and getattr(self.args, "encode_hist", False) and expo is not None
                     and not any(p.requires_grad for p in expo.parameters())):
-                self._affine = self.coarse.exposure_coefficients(self.hist).clone()
-        self.apr_opt = torch.optim.Adam(self.apr.parameters(), lr=self.apr_opt.param_groups[0]["lr"])      # :212
+                a = self.coarse.exposure_coefficients(self.hist)
+                if self._affine is None:
+                    self._affine = a.clone()
+                else:
+                    self._affine.copy_(a)
+
+    def _apr_iteration(self):
+        self.apr_loss_and_grad()
+        self.apr_opt.step()
+
+    def _apr_fresh_adam(self):
+        """torch.optim.Adam(pp_model.parameters(), lr) per image (:212).  Under a graph the optimizer object is the captured one and its
+        state is zeroed in place instead -- the same thing to Adam (step 0, zero moments)."""
+        if self.apr_graph is None:
+            self.apr_opt = torch.optim.Adam(self.apr.parameters(), lr=self.apr_opt.param_groups[0]["lr"], capturable=self.use_graph)
+            return
+        with torch.no_grad():
+            for st in self.apr_opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+
+    def _capture_apr(self):
+        """One iteration of train_on_batch -- regression network, svd_reg, render, FusionNet, loss, backward to the network's weights,
+        Adam -- as ONE HIP graph.  Possible since round 5: svd_reg is a kernel (torch.svd calls a solver and checks its status on the
+        host), the target's share of the loss is prepared outside.  Warm-up on a side stream as _capture does; the caller re-writes the
+        image's state afterwards (the warm-up steps moved the network)."""
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._apr_iteration()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        for p in self.apr.parameters():
+            p.grad = None                                   # the captured backward allocates them in the graph's pool and keeps them there
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._apr_iteration()
+        self.apr_graph = g
+
+    def refine_apr(self, photo, feature_target, hist, iters=50, verification=True):
+        """One query image, `pose_only=2`: `photo` [1,3,H,W], `feature_target` [C,H,W] (the query image's features at full
+        resolution; cropped here as :125 does).  Returns (pose [3,4] in the regression network's coordinates, losses [iters],
+        info = dict(psnr=(first, last), ssim=(first, last), retreat=bool)).  PoseRefiner(graph=True): the iteration is captured on
+        first use and replayed (the regression network must be capturable: no host reads, static shapes)."""
+        if self.apr is None:
+            raise RuntimeError("nefes_amd: PoseRefiner was built without pose_model=")
+        dev = self.dev
+        self._apr_image_state(photo, feature_target, hist)
+        self._apr_fresh_adam()
+        if self.use_graph and self.apr_graph is None:
+            self._capture_apr()
+            self._apr_image_state(photo, feature_target, hist)
+            self._apr_fresh_adam()
         first = self.predicted_pose()
         losses = torch.empty(iters, device=dev)
         checks = []
         for i in range(iters):
-            self.apr_loss_and_grad()
-            self.apr_opt.step()
+            if self.apr_graph is not None:
+                self.apr_graph.replay()
+            else:
+                self._apr_iteration()
             losses[i] = self.loss
             if verification and (i == 0 or i == iters - 1):
                 checks.append(self._verification())

@@ -132,6 +132,44 @@ def test_pose_compose_matches_learnpose_and_fix_coord(r0):
     assert rel(r.grad.cpu().numpy(), m.r.grad[0].numpy()) < 1e-6 and rel(t.grad.cpu().numpy(), m.t.grad[0].numpy()) < 1e-6
 
 
+def test_svd_reg_kernels_match_float64_svd():
+    """ops.svd_reg (nefes_svd_reg_fwd/bwd: one-sided Jacobi in float64, the polar factor's own derivative) == svd_reg
+    (dm/DFM_pose_refine.py:119-129) through torch.svd + autograd in float64: near-rotations (what a pose network regresses; where
+    autograd through the fp32 SVD loses four digits), general matrices, det < 0, a scaled rotation, a batch; the translation column
+    and its gradient pass through.  The fp32 torch path's own error is recorded beside it."""
+    from nefes_amd import ops
+    g = torch.Generator().manual_seed(12)
+    q, _ = torch.linalg.qr(torch.randn(6, 3, 3, generator=g, dtype=torch.float64))
+    A = torch.cat([q + 1e-3 * torch.randn(6, 3, 3, generator=g, dtype=torch.float64),          # near-rotations
+                   torch.randn(4, 3, 3, generator=g, dtype=torch.float64),                      # general
+                   2.5 * q[:2], torch.diag(torch.tensor([1., 1., -1.], dtype=torch.float64))[None] @ q[:1]])
+    pose = torch.cat([A, torch.randn(A.shape[0], 3, 1, generator=g, dtype=torch.float64)], -1).float()
+    G = torch.randn(pose.shape, generator=g, dtype=torch.float64)
+
+    def torch_svd_reg(p):
+        u, _, v = torch.svd(p[..., :3, :3])
+        return torch.cat([u @ v.transpose(-2, -1), p[..., :3, 3:]], -1)
+    pd = pose.double().requires_grad_()
+    rd = torch_svd_reg(pd)
+    (rd * G).sum().backward()
+    ph = pose.to(DEV).requires_grad_()
+    rh = ops.svd_reg(ph)
+    (rh * G.float().to(DEV)).sum().backward()
+    pt = pose.to(DEV).requires_grad_()
+    rt = torch_svd_reg(pt)
+    (rt * G.float().to(DEV)).sum().backward()
+    e_val, e_grad = rel(rh.detach().cpu().numpy(), rd.detach().numpy()), rel(ph.grad.cpu().numpy(), pd.grad.numpy())
+    e_val_t, e_grad_t = rel(rt.detach().cpu().numpy(), rd.detach().numpy()), rel(pt.grad.cpu().numpy(), pd.grad.numpy())
+    P.record("svd_reg_gpu", "pose after svd_reg", e_hip=e_val, e_ref=e_val_t, direct=e_val, bound=3e-7)
+    P.record("svd_reg_gpu", "d / d regressed pose", e_hip=e_grad, e_ref=e_grad_t, direct=e_grad, bound=1e-6)
+    assert e_val < 3e-7 and e_grad < 1e-6, (e_val, e_grad, e_val_t, e_grad_t)
+    r3 = rh.detach()[:, :3, :3].double()
+    assert float((r3 @ r3.transpose(1, 2) - torch.eye(3, device=DEV, dtype=torch.float64)).abs().max()) < 5e-7
+    assert torch.equal(rh.detach()[:, :, 3], ph.detach()[:, :, 3]) and torch.equal(ph.grad[:, :, 3], G.float().to(DEV)[:, :, 3])
+    one = ops.svd_reg(pose[0].to(DEV))                                  # a single [3,4] pose keeps its shape
+    assert one.shape == (3, 4) and torch.equal(one, rh.detach()[0])
+
+
 @pytest.mark.parametrize("C,P", [(128, 220 * 300), (16, 12 * 16), (3, 1000)])
 def test_cosine_feature_loss_matches_torch(C, P):
     """nefes_cosine_loss_fwd/bwd == feature_loss (DFM_pose_refine.py:211-233) in float64 torch, value and gradient; one channel is

@@ -213,7 +213,7 @@ def test_mode2_iterations_match_reference_along_its_trajectory(golden, k):
     assert worst_abs < 1e-3 and worst_l < 1e-3, (worst_abs, worst_g, worst_l)
 
 
-STAGES = ["default", "field_fp32_mfma", "torch_convs", "separate_upsample_and_loss", "torch_glue", "svd_on_host", "svd_float64", "torch_upsample_and_loss",
+STAGES = ["default", "field_fp32_mfma", "torch_convs", "separate_upsample_and_loss", "one_pass_upsampled_loss", "svd_torch", "torch_glue", "svd_on_host", "svd_float64", "torch_upsample_and_loss",
           "torch_upsample_and_loss_float64", "fusion_net_float64", "render_maps_to_float64_tail",
           # pairs (VERDICT r4 "weak" 1: single-stage swaps cannot see an error two stages share)
           "svd_float64+field_fp32_mfma", "svd_float64+render_maps_to_float64_tail"]
@@ -247,6 +247,11 @@ def test_loop_gradient_error_by_stage(golden, variant, monkeypatch):
         monkeypatch.setattr(FusionNet, "HIP_CONVS", False)
     if variant == "separate_upsample_and_loss":
         monkeypatch.setattr(PoseRefiner, "FUSED_UPSAMPLED_LOSS", False)
+    if variant == "one_pass_upsampled_loss":          # the round-2 kernels that read the whole target every iteration (round 5: Gram form)
+        monkeypatch.setattr(PoseRefiner, "PREPARED_TARGET", False)
+    if variant == "svd_torch":                        # torch.svd and autograd through it, as the reference runs it (round 5: svd_reg kernels)
+        import nefes_amd.refine as NRF1
+        monkeypatch.setattr(NRF1, "HIP_SVD_REG", False)
     if variant in ("svd_on_host", "svd_float64"):
         # svd_reg (dm/DFM_pose_refine.py:119-129) is torch.svd on the device in the product as in the reference: LAPACK on the host /
         # float64 on the device instead tell whether the device's fp32 SVD and its backward own the loop's distance from float64
@@ -480,9 +485,11 @@ def test_mode3_population_of_50_iteration_runs(golden, graph):
     population_check(tag, g, poses, g["m3_pose"], g["m3_pose_f64"])
 
 
-def test_mode2_population_of_50_iteration_runs(golden):
+@pytest.mark.parametrize("graph", [False, True])
+def test_mode2_population_of_50_iteration_runs(golden, graph):
     """Free-running `train_on_batch` x 50 + the verification step's roll-back rule (DFM_APR_refine.py:233-250) from the eight
-    perturbed starts, through `PoseRefiner(pose_model=...)`."""
+    perturbed starts, through `PoseRefiner(pose_model=...)`; eager, and with the whole iteration (regression network, svd_reg, render,
+    FusionNet, loss, backward, Adam) as one replayed HIP graph -- captured once, the eight networks swapped in through `apr_base`."""
     g = golden("refine50")
     photo, tgt, n = photo_of(g), target_full(g), g["m2_loss"].shape[1]
     poses = []
@@ -490,15 +497,16 @@ def test_mode2_population_of_50_iteration_runs(golden):
     for k in range(len(g["init_c2w"])):
         apr = TinyAPR(g["m2_weight"][k], g["m2_bias"][k])
         if ref is None:
-            ref = refiner(g, apr=apr)
+            ref = refiner(g, apr=apr, graph=graph)
         else:
             ref.apr_base = apr
         pose, losses, info = ref.refine_apr(photo, tgt, T(g["hist"]), n)
+        assert (ref.apr_graph is not None) == graph
         poses.append(pose.cpu().numpy())
         assert info["retreat"] == bool(g["m2_retreat"][k])
         assert abs(info["psnr"][0] - g["m2_psnr"][k, 0]) < 2e-3 and abs(info["psnr"][1] - g["m2_psnr"][k, -1]) < 5e-2, (info, g["m2_psnr"][k, [0, -1]])
         assert rel(losses.cpu().numpy(), g["m2_loss"][k]) < 2e-3
-    population_check("refine50_mode2", g, poses, g["m2_final"], g["m2_final_f64"])
+    population_check(f"refine50_mode2[{'graph' if graph else 'eager'}]", g, poses, g["m2_final"], g["m2_final_f64"])
 
 
 class AprWithUnusedHead(TinyAPR):
