@@ -65,6 +65,40 @@ class FusionNet(nn.Module):
         x = ops.frozen_conv2d(x, c2.weight, c2.bias, relu=True)
         return ops.frozen_conv2d(x, c3.weight, c3.bias, relu=False)
 
+    def _conv0_on_gmap(self, w_f, b_f):
+        """Conv2d(3 + C, 64, 3) o the factored feature head: the first layer's weights acting on (rgb, sum_s w_s g_s, sum_s w_s)
+        [3 + Cg + 1 channels] instead of on (rgb, feat) -- feat = W_f gmap + b_f (sum_s w_s) per pixel (ops.RenderFineFH) and the layer is
+        linear in feat; zero padding commutes (gmap = 0 outside the image gives feat = 0 there).  Composed once in float64 for frozen
+        weights: [64, 3 + Cg + 1, 3, 3] fp32."""
+        c0 = self.net[0]
+        key = (c0.weight.data_ptr(), c0.weight._version, w_f.data_ptr(), w_f._version, b_f.data_ptr(), b_f._version)
+        if getattr(self, "_gmap_conv0", None) is None or self._gmap_conv0[0] != key:
+            with torch.no_grad():
+                w1, wf, bf = c0.weight.detach().double(), w_f.detach().double(), b_f.detach().double()
+                wg = torch.einsum("ocyx,cj->ojyx", w1[:, 3:], wf)
+                wb = torch.einsum("ocyx,c->oyx", w1[:, 3:], bf)[:, None]
+                self._gmap_conv0 = (key, torch.cat([w1[:, :3], wg, wb], 1).float().contiguous())
+        return self._gmap_conv0[1]
+
+    def forward_prepared_gmap(self, x, w_f, b_f, per_image_norm=False):
+        """forward_prepared for x = [B, 3 + Cg + 1, H, W] holding the factored head's per-pixel INPUT in the features' place
+        (render(..., feat_as_gmap=True)): the head is folded into the first convolution (_conv0_on_gmap), so neither the per-ray head
+        kernels nor 128 feature channels exist.  Frozen weights on the GPU, no residual connection (it needs the features)."""
+        from . import ops
+        if self.fusion_residule or not self._use_hip(x):
+            raise RuntimeError("nefes_amd: forward_prepared_gmap needs frozen FusionNet weights on the GPU and no residual connection")
+        c0, c1, c2, c3 = self.net[0], self.net[2], self.net[4], self.net[6]
+        y = ops.frozen_conv2d(x, self._conv0_on_gmap(w_f, b_f), c0.bias, relu=True)
+        y = ops.frozen_conv2d(y, c1.weight, c1.bias, relu=True)
+        y = ops.frozen_conv2d(y, c2.weight, c2.bias, relu=True)
+        y = ops.frozen_conv2d(y, c3.weight, c3.bias, relu=False)
+        if self.no_BN:
+            return y
+        if per_image_norm and x.shape[0] > 1 and self.net[-1].training:
+            bn = self.net[-1]
+            return nn.functional.instance_norm(y, weight=bn.weight, bias=bn.bias, eps=bn.eps)
+        return self.net[-1](y)
+
     def forward_parts(self, rgb_nchw, feat_nchw, per_image_norm=False):
         """forward(cat([rgb, feat], 1)) without the in-place slice assignment (whose autograd costs a fill and two copies):
         the colour channels are normalised before the concatenation -- same values, same order of operations.

@@ -624,7 +624,7 @@ class RenderFineFH(torch.autograd.Function):
     -> (rgb [N,3], feat [N,C], disp [N], acc [N]); differentiable w.r.t. rays_o, rays_d, viewdirs."""
 
     @staticmethod
-    def forward(ctx, rays_o, rays_d, viewdirs, z, pk, w_f, w_f_t, b_f, flags, beta_min):
+    def forward(ctx, rays_o, rays_d, viewdirs, z, pk, w_f, w_f_t, b_f, flags, beta_min, emit_gmap=False):
         rays_o, rays_d, viewdirs, z = _f32(rays_o), _f32(rays_d), _f32(viewdirs), _f32(z)
         N, S = z.shape
         need = any(ctx.needs_input_grad[:3])
@@ -638,13 +638,18 @@ class RenderFineFH(torch.autograd.Function):
         if masks is not None:
             _tap("masks", (masks, N, S, pk.width, L.FIELD_FULL))
         rgb, gmap, disp, acc, _, _, _ = composite_fwd(raw_t, z, Cg + 1, flags, beta_min)
-        C = w_f.shape[0]
-        feat = torch.empty(N, C, device=z.device)
-        with _timed("feat_head_fwd"):
-            L.check(L.load().nefes_feat_head_fwd(N, C, Cg, _chk(gmap, "gmap"), _chk(w_f_t, "w_t"), _chk(b_f, "b"), _chk(feat, "feat"), _stream()),
-                    "nefes_feat_head_fwd")
+        if emit_gmap:
+            # the caller applies the feature head itself, folded into whatever linear layer consumes the features (the refinement loop:
+            # FusionNet's first convolution, FusionNet.forward_prepared_gmap): feat = [N, Cg + 1] = (sum_s w_s g_s, sum_s w_s)
+            feat = gmap
+        else:
+            C = w_f.shape[0]
+            feat = torch.empty(N, C, device=z.device)
+            with _timed("feat_head_fwd"):
+                L.check(L.load().nefes_feat_head_fwd(N, C, Cg, _chk(gmap, "gmap"), _chk(w_f_t, "w_t"), _chk(b_f, "b"), _chk(feat, "feat"), _stream()),
+                        "nefes_feat_head_fwd")
         ctx.set_materialize_grads(False)
-        ctx.pk, ctx.have, ctx.pk_gen, ctx.cfg = pk, need, pk.generation, (Cg, int(flags))
+        ctx.pk, ctx.have, ctx.pk_gen, ctx.cfg, ctx.emit_gmap = pk, need, pk.generation, (Cg, int(flags)), bool(emit_gmap)
         if need:
             ctx.save_for_backward(rays_o, rays_d, viewdirs, z, raw_t, masks, w_f, b_f)
         return rgb, feat, disp, acc
@@ -652,7 +657,7 @@ class RenderFineFH(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_feat, g_disp, g_acc):
         if not ctx.have:
-            return (None,) * 10
+            return (None,) * 11
         rays_o, rays_d, viewdirs, z, raw_t, masks, w_f, b_f = ctx.saved_tensors
         N, S = z.shape
         pk = ctx.pk
@@ -661,7 +666,9 @@ class RenderFineFH(torch.autograd.Function):
         fix = lambda g: None if (g is None or g.numel() == 0) else _f32(g)
         g_rgb, g_feat, g_disp, g_acc = fix(g_rgb), fix(g_feat), fix(g_disp), fix(g_acc)
         g_gmap = None
-        if g_feat is not None:
+        if g_feat is not None and ctx.emit_gmap:
+            g_gmap = g_feat                                  # already d loss / d (sum_s w_s g_s, sum_s w_s)
+        elif g_feat is not None:
             g_gmap = torch.empty(N, Cg + 1, device=z.device)
             with _timed("feat_head_bwd"):
                 L.check(L.load().nefes_feat_head_bwd(N, w_f.shape[0], Cg, _chk(g_feat, "g_feat"), _chk(w_f, "w"), _chk(b_f, "b"),
@@ -680,7 +687,7 @@ class RenderFineFH(torch.autograd.Function):
                                                    _chk(g_raw_t, "g_raw_t"), _chk(g_gmap, "g_gmap"), _chk(masks, "masks", torch.int32),
                                                    _chk(g_pts, "g_pts"), _chk(g_vs, "g_vs"), _stream()), "nefes_field_bwd_h3_fh")
         g_o, g_d, g_v = ray_grad_reduce(N, S, z, g_pts, g_vs)
-        return g_o, g_d, g_v, None, None, None, None, None, None, None
+        return g_o, g_d, g_v, None, None, None, None, None, None, None, None
 
 
 class FieldFromPoints(torch.autograd.Function):

@@ -108,6 +108,10 @@ class PoseRefiner:
     # computed when the target is set and an iteration runs on [C,h,w] data only (ops.UpcosTarget; csrc/refine.hip upcos_gram_*).
     # False: the one-pass kernels that read the whole target every iteration (the tests compare the two).
     PREPARED_TARGET = os.environ.get("NEFES_PREPARED_TARGET", "1") != "0"
+    # Where the factored feature head renders the fine pass (ops.RenderFineFH: frozen width-128 network at test time), the head is not
+    # applied per ray at all: render() hands over its input (65 channels) and FusionNet's first convolution runs on weights composed with
+    # the head's (FusionNet.forward_prepared_gmap) -- the only consumer of the rendered features in this loop is that linear layer.
+    GMAP_CONV0 = os.environ.get("NEFES_GMAP_CONV0", "1") != "0"
 
     def __init__(self, render_kwargs, args, hwf, near, far, tinyscale=4, lr_r=0.01, lr_t=0.1, lietorch=False,
                  upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda", adam_capturable=None,
@@ -180,21 +184,30 @@ class PoseRefiner:
             c2w = self.model(0)[None, :3, :4]
             if self.world_setup is not None:
                 c2w = fix_coord_supp(c2w, self.world_setup)
-        if B == 1:
-            # (a view, not c2w[0]: indexing costs a zero fill and a copy in the backward)
-            rgb, _, _, ex = render(self.h, self.w, self.focal, c2w=c2w.reshape(3, 4), near=self.near, far=self.far, img_idx=self.hist, **self.kw)
-            feat = ex["feat_map"]
-        else:
-            rgb, _, _, ex = render_poses(self.h, self.w, self.focal, c2w, near=self.near, far=self.far, **self.kw)
-            rgb, feat = rgb.reshape(-1, 3), ex["feat_map"].reshape(-1, self.C)
         enc = bool(getattr(self.args, "encode_hist", False))
         fnet = self.coarse.fusion_net
-        if self.fused_glue and (not enc or self._affine is not None) and fnet._use_hip(rgb):
+        fused_input = self.fused_glue and (not enc or self._affine is not None) and fnet._use_hip(self.hist)
+        kw = self.kw
+        if fused_input and self.GMAP_CONV0 and not fnet.fusion_residule and kw.get("network_fine", None) is not None:
+            kw = dict(kw, feat_as_gmap=True)               # honoured only where render() takes the factored head (extras["feat_is_gmap"])
+        if B == 1:
+            # (a view, not c2w[0]: indexing costs a zero fill and a copy in the backward)
+            rgb, _, _, ex = render(self.h, self.w, self.focal, c2w=c2w.reshape(3, 4), near=self.near, far=self.far, img_idx=self.hist, **kw)
+            feat = ex["feat_map"]
+        else:
+            rgb, _, _, ex = render_poses(self.h, self.w, self.focal, c2w, near=self.near, far=self.far, **kw)
+            rgb, feat = rgb.reshape(-1, 3), ex["feat_map"].reshape(-1, ex["feat_map"].shape[-1])
+        gmap = bool(ex.get("feat_is_gmap", False))
+        if fused_input:
             # colour transform + normalisation + the NCHW concatenation as one launch each way (ops.fusion_input)
             x = ops.fusion_input(rgb, feat, self._affine if enc else None, B, self.h, self.w, fnet.mean, fnet.std)
             if self.apr is not None:
                 self._x_rgb = x.detach()[:, :3]            # the verification step's image, still normalised (:117-118)
-            fused = fnet.forward_prepared(x, per_image_norm=B > 1)
+            if gmap:
+                _, w_f, _, b_f = kw["network_fine"].packed_fh()
+                fused = fnet.forward_prepared_gmap(x, w_f, b_f, per_image_norm=B > 1)
+            else:
+                fused = fnet.forward_prepared(x, per_image_norm=B > 1)
         else:
             if enc:
                 if self._affine is not None:               # frozen exposure network: its 12 numbers were computed once per image

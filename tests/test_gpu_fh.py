@@ -96,3 +96,47 @@ def test_single_node_fine_pass_equals_the_three_node_chain():
         e = rel(res[0][i], res[1][i])
         P.record("factored_head_single_node", f"{name}: one node vs the three-node chain", direct=e, bound=2e-6)
         assert e < 2e-6, (name, e)
+
+
+def test_feature_head_folded_into_fusion_nets_first_convolution():
+    """render(..., feat_as_gmap=True) hands over the factored head's per-ray input (sum_s w_s g_s, sum_s w_s) in the features' place, and
+    FusionNet.forward_prepared_gmap runs its first convolution on weights composed with the head's (the refinement loop's path since
+    round 5): the head applied to that input is the feature map of the ordinary render, and the fused features and the pose gradient
+    through FusionNet are those of the ordinary chain (render -> per-ray head -> fusion_input -> four convolutions -> BatchNorm)."""
+    from nefes_amd import ops
+    R, M, _ = dropin()
+    Wd, C = 128, 128
+    coarse, fine = nets(Wd, C)
+    coarse, fine = coarse.requires_grad_(False), fine.requires_grad_(False)
+    kw = dict(kwargs(M, coarse, fine, 64, tat=True), use_viewdirs=True, ndc=False)
+    H, W, focal = 6, 8, 7.0
+    fnet = coarse.fusion_net
+    assert not fnet.fusion_residule and fnet._use_hip(torch.zeros(1, device=DEV))
+    _, w_f, _, b_f = fine.packed_fh()
+    gen = torch.Generator().manual_seed(4)
+    G = torch.randn(1, C, H, W, generator=gen).to(DEV)
+    outs = {}
+    for gm in (False, True):
+        c2w = O.bench_pose().to(DEV).requires_grad_()
+        rgb, _, _, ex = R.render(H, W, focal, c2w=c2w, near=0., far=4., **dict(kw, feat_as_gmap=gm))
+        assert bool(ex.get("feat_is_gmap", False)) == gm
+        feat = ex["feat_map"]
+        x = ops.fusion_input(rgb, feat, None, 1, H, W, fnet.mean, fnet.std)
+        fused = fnet.forward_prepared_gmap(x, w_f, b_f) if gm else fnet.forward_prepared(x)
+        (g,) = torch.autograd.grad((fused * G).sum(), c2w)
+        outs[gm] = (feat.detach(), fused.detach(), g)
+    gmap = outs[True][0]
+    assert gmap.shape == (H * W, Wd // 2 + 1) and outs[False][0].shape == (H * W, C)
+    head = gmap[:, :-1].double() @ w_f.double().t() + gmap[:, -1:].double() * b_f.double()
+    e_feat, e_fused, e_g = rel(head, outs[False][0]), rel(outs[True][1], outs[False][1]), rel(outs[True][2], outs[False][2])
+    P.record("gmap_conv0", "feature head applied to the handed-over input vs feat_map", direct=e_feat, bound=2e-6)
+    P.record("gmap_conv0", "fused features: head folded into conv0 vs per-ray head", direct=e_fused, bound=1e-5)
+    P.record("gmap_conv0", "d c2w through FusionNet: head folded into conv0 vs per-ray head", direct=e_g, bound=5e-5)
+    assert e_feat < 2e-6 and e_fused < 1e-5 and e_g < 5e-5, (e_feat, e_fused, e_g)
+    # where the factored head does not apply (here: switched off) the flag is ignored and says so
+    ops.FACTORED_HEAD = False
+    try:
+        _, _, _, ex = R.render(H, W, focal, c2w=O.bench_pose().to(DEV), near=0., far=4., **dict(kw, feat_as_gmap=True))
+        assert "feat_is_gmap" not in ex and ex["feat_map"].shape == (H * W, C)
+    finally:
+        ops.FACTORED_HEAD = True
