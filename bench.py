@@ -175,7 +175,7 @@ class _TinyAPR(torch.nn.Module):
         return self.fc(pooled.reshape(B, -1))
 
 
-def refinement_loop(dev, iters=50, graph=True, images=1, mode="upsampled"):
+def refinement_loop(dev, iters=50, graph=True, images=1, mode="upsampled", streams=1):
     """BASELINE configs[4] without the DFNet CNN (out of scope) on the scene of tests/golden/refine50_60x80.npz --
     the 60 x 80 rays the reference's own loop renders (DFM_APR_refine.py:107), one perturbed start, the reference's 50-iteration
     results beside it.  Per query image `iters` iterations of pose -> render(80x60) -> affine colour transform -> FusionNet ->
@@ -231,12 +231,21 @@ def refinement_loop(dev, iters=50, graph=True, images=1, mode="upsampled"):
             init, hist, target = init[None].repeat(images, 1, 1), hist.repeat(images, 1), target[None].repeat(images, 1, 1, 1)
         ref = PoseRefiner(kw, args, (H, W, focal), float(g["near"]), float(g["far"]), upsample=up, graph=graph, images=images, **common)
         pose, _ = ref.refine(init, target, hist, iters)               # packs weights, warms MIOpen, captures the graph
+        if streams > 1:     # `streams` query images at the same time, one PoseRefiner + one HIP stream each (refine_concurrently)
+            from nefes_amd.refine import refine_concurrently
+            refs = [ref] + [PoseRefiner(kw, args, (H, W, focal), float(g["near"]), float(g["far"]), upsample=up, graph=graph, **common)
+                            for _ in range(streams - 1)]
+            jobs = [(init, target, hist)] * streams
+            refine_concurrently(refs, jobs, iters)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_img):
-            pose, _ = ref.refine(init, target, hist, iters)
+            if streams > 1:
+                pose = refine_concurrently(refs, jobs, iters)[-1][0]
+            else:
+                pose, _ = ref.refine(init, target, hist, iters)
         torch.cuda.synchronize()
-        sec = (time.perf_counter() - t0) / n_img / images
+        sec = (time.perf_counter() - t0) / n_img / images / streams
         p0 = (pose if images == 1 else pose[0])[:3, :4].cpu().numpy()
         err = {"hip": _pose_error(g["true_c2w"], p0)}
         if mode == "3":
@@ -384,6 +393,8 @@ def main():
         sec_e, rays, _ = refinement_loop(dev, graph=False)
         sec, rays, err_up = refinement_loop(dev, graph=True)
         sec_b, _, _ = refinement_loop(dev, graph=True, images=8)
+        sec_s2, _, err_s2 = refinement_loop(dev, graph=True, streams=2)
+        sec_s3, _, _ = refinement_loop(dev, graph=True, streams=3)
         sec3, _, err3 = refinement_loop(dev, graph=True, mode="3")
         sec2e, _, _ = refinement_loop(dev, graph=False, mode="2")
         sec2, _, err2 = refinement_loop(dev, graph=True, mode="2")
@@ -393,6 +404,8 @@ def main():
                           "data": "synthetic", "vs_baseline": None,
                           "ms_per_image_50_iterations": sec * 1e3, "ms_per_image_50_iterations_eager": sec_e * 1e3,
                           "ms_per_image_50_iterations_8_images_side_by_side": sec_b * 1e3,
+                          "ms_per_image_50_iterations_2_images_on_2_streams": sec_s2 * 1e3,
+                          "ms_per_image_50_iterations_3_images_on_3_streams": sec_s3 * 1e3,
                           "ms_per_image_50_iterations_mode3": sec3 * 1e3, "ms_per_image_50_iterations_mode2": sec2 * 1e3,
                           "ms_per_image_50_iterations_mode2_eager": sec2e * 1e3,
                           "pose_error_m_deg_after_50_iterations": {"mode3": err3, "mode2": err2, "upsampled_loss_learnpose": err_up,

@@ -609,7 +609,17 @@ __global__ __launch_bounds__(256) void composite_bwd4_kernel(CompArgs p) {
         gss[k] = (float)(transient ? d_as * dl * r.e_s[k] + d_ac * dl * r.e_c[k] : d_ac * dl * r.e_c[k]);
         gst[k] = (float)(d_at * dl * r.e_t[k] + d_ac * dl * r.e_c[k]);
     }
-    auto store_row = [&](int ch, const float (&v)[4]) { *(float4*)(graw + (size_t)ch * S + s0) = make_float4(v[0], v[1], v[2], v[3]); };
+    // A 16-byte store per lane, then NOTHING that may overwrite its data registers for 16 wait states.  hipcc (ROCm 7.2) places one wait
+    // state between a global_store_dwordx4 and a vector write of its data registers; with a field kernel of another stream resident on the
+    // same CUs (tools/concurrency_bisect2.py: two refinement loops on two streams) the last 16 lanes of such a store went out holding the
+    // register's NEXT value -- `v_mov_b32 v6, v56` four instructions behind `global_store_dwordx4 v[14:15], v[6:9]` here: the green
+    // transient row's first element of four came out as g_beta (0) on ~20 rays of 4 800 in every second launch.  Alone on the device the
+    // kernel is bit-stable (every test and the graph-replayed loop run it that way); the fence keeps it so under co-residency.
+    auto store_row = [&](int ch, const float (&v)[4]) {
+        float* q = graw + (size_t)ch * S + s0;
+        const float2 lo = make_float2(v[0], v[1]), hi = make_float2(v[2], v[3]);
+        asm volatile("global_store_dwordx2 %0, %1, off\n\tglobal_store_dwordx2 %0, %2, off offset:8" :: "v"(q), "v"(lo), "v"(hi) : "memory");
+    };
     if (sigma_only) { store_row(0, gss); return; }
     store_row(C3, gss);
 #pragma unroll

@@ -468,3 +468,47 @@ class PoseRefiner:
             if info["retreat"]:
                 pose = first
         return pose.detach().clone(), losses, info
+
+
+def refine_concurrently(refiners, jobs, iters=50):
+    """K query images refined AT THE SAME TIME: one PoseRefiner (its own static buffers and captured graph; the frozen networks can be
+    shared) and one HIP stream per image, replays issued round-robin.  An iteration is ~1.45 ms of field kernels, which hold the whole
+    chip at its power limit, and ~0.3 ms of FusionNet convolutions, loss and pose kernels that are bound by launch and L2 latency on a
+    fraction of the CUs: alone on the device those 0.3 ms are idle silicon, next to another image's field kernels they are nearly
+    free (two images: -8 % per image; tools/two_streams.py).  Every image walks exactly the trajectory it walks alone -- bit for bit
+    (tests/test_gpu_streams.py; that test is also what found the 16-byte-store hazard noted in csrc/composite.hip).
+    jobs = [(init_c2w, feature_target, hist), ...] as PoseRefiner.refine takes them -> [(refined c2w, losses [iters]), ...]."""
+    if len(refiners) != len(jobs) or not refiners:
+        raise ValueError("nefes_amd: refine_concurrently needs one PoseRefiner per job")
+    if len({id(r) for r in refiners}) != len(refiners):
+        raise ValueError("nefes_amd: refine_concurrently needs DISTINCT PoseRefiner objects (each owns the static buffers of its image)")
+    dev = refiners[0].dev
+    jobs = [tuple(t.to(dev) for t in job) for job in jobs]
+    for r, job in zip(refiners, jobs):
+        if r.use_graph and r.graph is None:
+            r.refine(*job, iters=0)                        # reset, warm-up, capture (on the caller's stream, one refiner at a time)
+    cur = torch.cuda.current_stream(dev)
+    for r in refiners:
+        if getattr(r, "_own_stream", None) is None:
+            r._own_stream = torch.cuda.Stream(device=dev)
+        r._own_stream.wait_stream(cur)
+    losses = [torch.empty((iters,) + tuple(r.loss.shape), device=dev) for r in refiners]
+    for r, job in zip(refiners, jobs):
+        with torch.cuda.stream(r._own_stream):
+            r._reset(*job)
+    for i in range(iters):
+        for r, l in zip(refiners, losses):
+            with torch.cuda.stream(r._own_stream):
+                if r.use_graph:
+                    r.graph.replay()
+                else:
+                    r._iteration()
+                l[i] = r.loss
+    outs = []
+    for r, l in zip(refiners, losses):
+        with torch.cuda.stream(r._own_stream), torch.no_grad():
+            pose = r.model(0) if r.B == 1 else r.model(torch.arange(r.B, device=dev))
+            outs.append((pose.detach().clone(), l))
+    for r in refiners:
+        cur.wait_stream(r._own_stream)
+    return outs

@@ -1,0 +1,78 @@
+"""Kernels of different HIP streams resident on the device at the same time (round 5: nefes_amd.refine.refine_concurrently).  Every
+result must be the one the same launch sequence gives alone on the device, bit for bit: the kernels have no atomics and no shared
+state, so anything else is a hazard.  The first version of this test found one: composite_bwd4_kernel's 16-byte stores went out with
+the NEXT value of one of their data registers on the wave's last 16 lanes whenever a field kernel of another stream shared the CUs
+(csrc/composite.hip, tools/concurrency_bisect2.py)."""
+import pytest
+import torch
+
+from tests.test_gpu_refine50 import T, refiner
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_render_chain_is_bit_stable_next_to_another_streams_field_kernels():
+    """field forward -> compositing -> loss -> compositing backward -> field backward -> ray reduction at the refinement frame's size
+    (4 800 rays x 128 samples, 8 x 128 network, C = 128), alone and with the same chain / a bare field forward running on a second
+    stream: every tensor of the chain equals its solo value."""
+    from nefes_amd import lib as L
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    Wd, C, N, S = 128, 128, 4800, 128
+    torch.manual_seed(0)
+    fine = NeRFH_NFF('fine', W=Wd, f_dim=C, encode_appearance=True, encode_transient=True).requires_grad_(False).to(DEV)
+    pk = fine.packed()
+    g = torch.Generator().manual_seed(1)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    ro, rd = mk(N, 3) * 0.1, torch.nn.functional.normalize(mk(N, 3), dim=-1)
+    z = (torch.rand(N, S, generator=g).sort(-1).values * 3 + 0.2).to(DEV)
+
+    def chain():
+        o, d, v = ro.clone().requires_grad_(), rd.clone().requires_grad_(), rd.clone().requires_grad_()
+        raw = ops.FieldFromRays.apply(o, d, v, z, pk, L.FIELD_FULL)
+        early = []
+        raw.register_hook(lambda g_: early.append(g_.clone()))
+        rgb, feat, disp, acc, depth, weights, beta = ops.Composite.apply(raw, z, C, L.COMP_TRANSIENT, 0.03)
+        ((rgb ** 2).sum() + (feat ** 2).sum() + (disp ** 2).sum()).backward()
+        return dict(raw=raw.detach(), rgb=rgb.detach(), feat=feat.detach(), g_raw=early[0], g_rays=torch.cat([o.grad, d.grad, v.grad], 1))
+
+    def field_forward():
+        with torch.no_grad():
+            return ops.FieldFromRays.apply(ro, rd, rd, z, pk, L.FIELD_FULL)
+
+    solo = chain()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for other in (field_forward, chain):
+        for rep in range(12):
+            with torch.cuda.stream(streams[0]):
+                a = chain()
+            with torch.cuda.stream(streams[1]):
+                b = other()
+            torch.cuda.synchronize()
+            for k, v in solo.items():
+                assert torch.equal(a[k], v), (other.__name__, rep, k, int((a[k] != v).sum()))
+            if isinstance(b, dict):
+                for k, v in solo.items():
+                    assert torch.equal(b[k], v), (other.__name__, rep, k, "second stream")
+
+
+def test_two_images_on_two_streams_walk_their_solo_trajectories(golden):
+    """refine_concurrently: two PoseRefiners (own buffers, own captured graph), two streams, 20 iterations -- poses and loss curves
+    bit-identical to PoseRefiner.refine of each image alone (different starts, so the two graphs do different work)."""
+    from nefes_amd.refine import refine_concurrently
+    g = golden("refine50")
+    refs = [refiner(g, graph=True), refiner(g, graph=True)]
+    jobs = [(T(g["init_c2w"][k]), T(g["target_low"]), T(g["hist"])) for k in (0, 3)]
+    n = 20
+    solo = [r.refine(*job, iters=n) for r, job in zip(refs, jobs)]
+    solo = [(p.clone(), l.clone()) for p, l in solo]
+    for rep in range(3):
+        outs = refine_concurrently(refs, jobs, iters=n)
+        torch.cuda.synchronize()
+        for (p, l), (ps, ls) in zip(outs, solo):
+            assert torch.equal(p, ps) and torch.equal(l, ls), rep
+    assert not torch.equal(solo[0][0], solo[1][0])
+    with pytest.raises(ValueError):
+        refine_concurrently([refs[0], refs[0]], jobs, iters=1)
