@@ -431,6 +431,10 @@ int nefes_adam_step(int n, float* p, const float* g, float* m, float* v, float* 
  *      v_mfma_f32_32x32x16_f16 back to back on every SIMD for ~ms_target milliseconds (operands all zero, or random bits) and
  *      returns the settled shader clock and the dense fp16 rate.  Synchronises the stream.  Not part of the render path. ---- */
 int nefes_probe_mfma_clock(int random_operands, int ms_target, double* clock_ghz, double* fp16_dense_tflops, void* stream);
+/* Diagnostic (tools/store_hazard.py): out dev [8][n_float4][4] floats; lane i stores (v, v, v + j, v), v = (i mod 2^20) + 1, to plane
+ * j = 0..7 with global_store_dwordx4 from the SAME four registers, adding 1 to the third `nops` + 1 wait states behind each store
+ * (nops in {0, 1, 3, 7, 15}).  out[j][i][2] != v + j = that store went out with a later value of its register. */
+int nefes_probe_store_hazard(float* out, int64_t n_float4, int nops, void* stream);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,51 @@ __global__ __launch_bounds__(256) void mfma_clock_kernel(int random, int iters, 
 }
 }  // namespace
 
+// Sixteen-byte stores that re-use their data registers, as compiled code does: a lane stores (v, v, v + j, v) to plane j = 0..7 from the
+// SAME four registers, adding 1 to the third one `NOPS` + 1 wait states behind each store (two are what the hardware documents and what
+// hipcc leaves; more is always legal).  out[j][i][2] != v + j = that store went out with a LATER value of its register.
+// tools/store_hazard.py runs it alone on the device and next to the field kernels of another stream.
+template <int NOPS>
+__global__ __launch_bounds__(256) void store_hazard_kernel(float* __restrict__ out, long n, int reps) {
+    const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
+    for (int r = 0; r < reps; ++r) {
+        const long i = i0 + (long)r * gridDim.x * 256;
+        if (i >= n) return;
+        float* q = out + 4 * i;
+        const float v = (float)(i & 0xfffff) + 1.f;
+        const long plane = 4 * n * 4;                        // bytes between the eight planes a lane stores to
+        asm volatile(
+            "v_mov_b32 v10, %1\n\tv_mov_b32 v11, %1\n\tv_mov_b32 v12, %1\n\tv_mov_b32 v13, %1\n\t"
+            "v_mov_b32 v14, %0\n\tv_mov_b32 v15, %4\n\t"
+            "s_nop 4\n\t"
+            ".rept 8\n\t"
+            "global_store_dwordx4 v[14:15], v[10:13], off\n\t"
+            "s_nop %2\n\t"
+            "v_add_f32 v12, 1.0, v12\n\t"
+            "v_lshl_add_u64 v[14:15], %3, 0, v[14:15]\n\t"
+            ".endr\n\t"
+            "s_nop 4"
+            :: "v"((uint32_t)(uintptr_t)q), "v"(v), "n"(NOPS), "s"(plane), "v"((uint32_t)((uintptr_t)q >> 32))
+            : "v10", "v11", "v12", "v13", "v14", "v15", "memory");
+    }
+}
+
+extern "C" int nefes_probe_store_hazard(float* out, int64_t n_float4, int nops, void* stream) {
+    if (!out || n_float4 <= 0) return NEFES_E_BADARG;
+    const int reps = 8;
+    const unsigned blocks = (unsigned)((n_float4 + 256 * reps - 1) / (256 * reps));
+    hipStream_t st = (hipStream_t)stream;
+    switch (nops) {
+        case 0: hipLaunchKernelGGL(store_hazard_kernel<0>, dim3(blocks), dim3(256), 0, st, out, (long)n_float4, reps); break;
+        case 1: hipLaunchKernelGGL(store_hazard_kernel<1>, dim3(blocks), dim3(256), 0, st, out, (long)n_float4, reps); break;
+        case 3: hipLaunchKernelGGL(store_hazard_kernel<3>, dim3(blocks), dim3(256), 0, st, out, (long)n_float4, reps); break;
+        case 7: hipLaunchKernelGGL(store_hazard_kernel<7>, dim3(blocks), dim3(256), 0, st, out, (long)n_float4, reps); break;
+        case 15: hipLaunchKernelGGL(store_hazard_kernel<15>, dim3(blocks), dim3(256), 0, st, out, (long)n_float4, reps); break;
+        default: return NEFES_E_UNSUPPORTED;
+    }
+    return (int)hipGetLastError();
+}
+
 extern "C" int nefes_probe_mfma_clock(int random_operands, int ms_target, double* clock_ghz, double* fp16_dense_tflops,
                                       void* stream) {
     if (!clock_ghz || !fp16_dense_tflops || ms_target <= 0 || ms_target > 2000) return NEFES_E_BADARG;
