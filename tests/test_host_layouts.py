@@ -81,3 +81,25 @@ def test_factored_head_applies_only_where_its_algebra_pays_and_holds():
     for n, p in net.named_parameters():
         p.requires_grad_(n.startswith(("fusion_net", "exposure_embedding")))
     assert net.factored_head_ok()
+
+
+def test_feature_head_composed_into_fusion_nets_first_convolution_is_exact_algebra():
+    """FusionNet._conv0_on_gmap (nefes_amd/field.py; the refinement loop's path): Conv2d(3 + C, 64, 3) applied to
+    (rgb, W_f g + b_f a) equals the composed weights applied to (rgb, g, a) -- zero padding included -- in float64 on the CPU."""
+    import torch
+    from nefes_amd.field import FusionNet
+    torch.manual_seed(3)
+    C, Cg, H, W = 12, 5, 7, 9
+    fnet = FusionNet(C).double()
+    w_f, b_f = torch.randn(C, Cg, dtype=torch.float64), torch.randn(C, dtype=torch.float64)
+    rgb, g, a = (torch.randn(2, n, H, W, dtype=torch.float64) for n in (3, Cg, 1))
+    feat = torch.einsum("cj,bjyx->bcyx", w_f, g) + b_f[None, :, None, None] * a
+    c0 = fnet.net[0]
+    ref = torch.nn.functional.conv2d(torch.cat([rgb, feat], 1), c0.weight, c0.bias, padding=1)
+    w = fnet._conv0_on_gmap(w_f, b_f).double()
+    assert w.shape == (64, 3 + Cg + 1, 3, 3)
+    out = torch.nn.functional.conv2d(torch.cat([rgb, g, a], 1), w, c0.bias, padding=1)
+    assert float((out - ref).abs().max()) < 1e-5 * float(ref.abs().max())          # (the composed weights are stored in fp32)
+    assert fnet._conv0_on_gmap(w_f, b_f) is fnet._conv0_on_gmap(w_f, b_f)            # cached while nothing changes
+    w_f.mul_(2.0)
+    assert not torch.equal(fnet._conv0_on_gmap(w_f, b_f).double(), w)                # ... and recomposed when a weight is written
