@@ -76,3 +76,71 @@ def test_two_images_on_two_streams_walk_their_solo_trajectories(golden):
     assert not torch.equal(solo[0][0], solo[1][0])
     with pytest.raises(ValueError):
         refine_concurrently([refs[0], refs[0]], jobs, iters=1)
+
+
+@pytest.mark.parametrize("case", ["headline", "hashgrid", "train"])
+def test_other_paths_are_bit_stable_next_to_another_streams_field_kernels(case):
+    """The same question for the paths the refinement loop does not run: the headline network's chain (8 x 256, C = 16, 64 + 128 samples),
+    the instances with the hash grid inside (configs[3]), and a train-mode step (activations saved by the forward, dX chain, dW kernels;
+    outputs: the rendered colours and every parameter gradient)."""
+    import types
+    from nefes_amd import lib as L
+    from nefes_amd import ops
+    from nefes_amd.field import NeRFH_NFF
+    from nefes_amd.render import render
+    from oracle import ref_cpu as O
+    g = torch.Generator().manual_seed(2)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+
+    def rays(N, S):
+        return mk(N, 3) * 0.1, torch.nn.functional.normalize(mk(N, 3), dim=-1), (torch.rand(N, S, generator=g).sort(-1).values * 3 + 0.2).to(DEV)
+    if case == "train":
+        H = W = 96
+        torch.manual_seed(0)
+        coarse = NeRFH_NFF('coarse', W=128, f_dim=128).to(DEV)
+        prm = [p for n, p in coarse.named_parameters() if not n.startswith(("fusion_net", "exposure_embedding"))]
+        args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True, netchunk=1024)
+        kw = dict(network_query_fn=None, perturb=0., N_importance=0, N_samples=64, network_fn=coarse, network_fine=None, use_viewdirs=True,
+                  white_bkgd=False, raw_noise_std=0., test_time=False, args=args, ndc=False, lindisp=False)
+        ro, rd, _ = ops.raygen_fwd(H, W, 200.0, O.bench_pose().to(DEV))
+        target = torch.rand(H * W, 3, generator=g).to(DEV)
+
+        def fn():
+            rgb, _, _, _ = render(H, W, 200.0, rays=(ro, rd), near=0., far=4., **kw)
+            grads = torch.autograd.grad(((rgb - target) ** 2).mean(), prm)
+            return torch.cat([rgb.detach().reshape(-1)] + [g_.reshape(-1) for g_ in grads])
+    else:
+        grid = None
+        if case == "hashgrid":
+            grid = ops.HashGrid(25.0, device=DEV)
+            grid.table.mul_(3e3)
+        fine = NeRFH_NFF('fine', W=256, f_dim=16, in_channels_xyz=32 if grid is not None else 63, encode_appearance=True,
+                         encode_transient=True).requires_grad_(False).to(DEV)
+        pk = fine.packed()
+        ro, rd, z = rays(3200, 192)
+
+        def fn():
+            o, d, v = ro.clone().requires_grad_(), rd.clone().requires_grad_(), rd.clone().requires_grad_()
+            raw = (ops.FieldFromRaysHashGrid.apply(o, d, v, z, pk, L.FIELD_FULL, grid) if grid is not None
+                   else ops.FieldFromRays.apply(o, d, v, z, pk, L.FIELD_FULL))
+            rgb, feat, disp, acc, depth, weights, beta = ops.Composite.apply(raw, z, 16, L.COMP_TRANSIENT, 0.03)
+            ((rgb ** 2).sum() + (feat ** 2).sum() + (disp ** 2).sum()).backward()
+            return torch.cat([rgb.detach().reshape(-1), feat.detach().reshape(-1), o.grad.reshape(-1), d.grad.reshape(-1), v.grad.reshape(-1)])
+    nfine = NeRFH_NFF('fine', W=128, f_dim=128, encode_appearance=True, encode_transient=True).requires_grad_(False).to(DEV)
+    npk = nfine.packed()
+    nro, nrd, nz = rays(4800, 128)
+
+    def neighbour():
+        with torch.no_grad():
+            return ops.FieldFromRays.apply(nro, nrd, nrd, nz, npk, L.FIELD_FULL)
+    solo = fn().clone()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for other in (neighbour, fn):
+        for rep in range(6):
+            with torch.cuda.stream(streams[0]):
+                a = fn()
+            with torch.cuda.stream(streams[1]):
+                b = other()
+            torch.cuda.synchronize()
+            assert torch.equal(a, solo), (case, other.__name__, rep, int((a != solo).sum()))
