@@ -609,12 +609,15 @@ __global__ __launch_bounds__(256) void composite_bwd4_kernel(CompArgs p) {
         gss[k] = (float)(transient ? d_as * dl * r.e_s[k] + d_ac * dl * r.e_c[k] : d_ac * dl * r.e_c[k]);
         gst[k] = (float)(d_at * dl * r.e_t[k] + d_ac * dl * r.e_c[k]);
     }
-    // A 16-byte store per lane, then NOTHING that may overwrite its data registers for 16 wait states.  hipcc (ROCm 7.2) places one wait
-    // state between a global_store_dwordx4 and a vector write of its data registers; with a field kernel of another stream resident on the
-    // same CUs (tools/concurrency_bisect2.py: two refinement loops on two streams) the last 16 lanes of such a store went out holding the
-    // register's NEXT value -- `v_mov_b32 v6, v56` four instructions behind `global_store_dwordx4 v[14:15], v[6:9]` here: the green
-    // transient row's first element of four came out as g_beta (0) on ~20 rays of 4 800 in every second launch.  Alone on the device the
-    // kernel is bit-stable (every test and the graph-replayed loop run it that way); the fence keeps it so under co-residency.
+    // Rows go out as TWO 8-byte stores per lane, not one 16-byte store.  With `*(float4*)... = ...` (global_store_dwordx4) and a field
+    // kernel of ANOTHER stream resident on the same CUs (two refinement loops on two streams: tools/concurrency_bisect2.py), the last 16
+    // lanes of one such store went out holding the NEXT value of one of its data registers -- `v_mov_b32 v6, v56` four instructions behind
+    // `global_store_dwordx4 v[14:15], v[6:9]`: the green transient row's first element of four came out as g_beta (0) on ~20 rays of
+    // 4 800 in every second launch; sixteen `s_nop`s fenced in behind every store moved the wrong element to the register re-used first
+    // after them, and did not remove it.  Alone on the device the kernel was bit-stable (every test, the bench and the graph-replayed loop
+    // run it that way).  The instruction's documented hazard (two wait states before a vector write of the data registers) is what
+    // tools/store_hazard.py measures, alone and next to the same neighbours: that is not it.  Not understood; with 8-byte stores the kernel
+    // is bit-stable next to everything tried (tests/test_gpu_streams.py), for +5 % of its HBM-bound launch.
     auto store_row = [&](int ch, const float (&v)[4]) {
         float* q = graw + (size_t)ch * S + s0;
         const float2 lo = make_float2(v[0], v[1]), hi = make_float2(v[2], v[3]);
