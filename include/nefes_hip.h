@@ -435,6 +435,12 @@ int nefes_probe_mfma_clock(int random_operands, int ms_target, double* clock_ghz
  * j = 0..7 with global_store_dwordx4 from the SAME four registers, adding 1 to the third `nops` + 1 wait states behind each store
  * (nops in {0, 1, 3, 7, 15}).  out[j][i][2] != v + j = that store went out with a later value of its register. */
 int nefes_probe_store_hazard(float* out, int64_t n_float4, int nops, void* stream);
+/* Diagnostic: every lane runs `iters` v_pk_mul_f32 with op_sel:[0,1] / op_sel_hi:[1,0] on fresh operands; out dev [n] = how many of its
+ * results were not the two products. */
+int nefes_probe_pk_mul(unsigned* out, int64_t n, int iters, void* stream);
+/* Diagnostic neighbour for nefes_probe_pk_mul: `blocks` workgroups of 256 run `iters` rounds of one instruction kind (0: v_fma_mixlo/hi_f16,
+ * 1: v_mfma_f32_32x32x16_f16, 2: both, 3: v_pk_fma_f32 with op_sel_hi, 4: v_fma_f32); sink dev [blocks * 256] floats. */
+int nefes_probe_aggressor(int kind, int iters, int blocks, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

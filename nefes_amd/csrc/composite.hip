@@ -11,6 +11,10 @@
 #include "../../include/nefes_hip.h"
 #include "wave.h"
 
+#ifndef NEFES_COMP_STORE
+#define NEFES_COMP_STORE 1     /* how composite_bwd4_kernel stores a row: 1 = one 16-byte store; 0 / 2: A/B builds (see there) */
+#endif
+
 struct CompArgs {
     int N, S, C, R;
     uint32_t flags;
@@ -609,19 +613,24 @@ __global__ __launch_bounds__(256) void composite_bwd4_kernel(CompArgs p) {
         gss[k] = (float)(transient ? d_as * dl * r.e_s[k] + d_ac * dl * r.e_c[k] : d_ac * dl * r.e_c[k]);
         gst[k] = (float)(d_at * dl * r.e_t[k] + d_ac * dl * r.e_c[k]);
     }
-    // Rows go out as TWO 8-byte stores per lane, not one 16-byte store.  With `*(float4*)... = ...` (global_store_dwordx4) and a field
-    // kernel of ANOTHER stream resident on the same CUs (two refinement loops on two streams: tools/concurrency_bisect2.py), the last 16
-    // lanes of one such store went out holding the NEXT value of one of its data registers -- `v_mov_b32 v6, v56` four instructions behind
-    // `global_store_dwordx4 v[14:15], v[6:9]`: the green transient row's first element of four came out as g_beta (0) on ~20 rays of
-    // 4 800 in every second launch; sixteen `s_nop`s fenced in behind every store moved the wrong element to the register re-used first
-    // after them, and did not remove it.  Alone on the device the kernel was bit-stable (every test, the bench and the graph-replayed loop
-    // run it that way).  The instruction's documented hazard (two wait states before a vector write of the data registers) is what
-    // tools/store_hazard.py measures, alone and next to the same neighbours: that is not it.  Not understood; with 8-byte stores the kernel
-    // is bit-stable next to everything tried (tests/test_gpu_streams.py), for +5 % of its HBM-bound launch.
+    // (Round 5: with a field kernel of ANOTHER stream resident on the same CUs this kernel once wrote wrong values -- the last 16 lanes of
+    // the green transient row.  Not the store: the `v_pk_mul_f32 ..., op_sel:[0,1]` hipcc's SLP vectoriser had made of `wt[k] * g_rgb[1]`.
+    // That instruction form returns a wrong low result on lanes 48..63 next to another queue's v_mfma_f32_32x32x16_f16 kernel
+    // (tools/store_hazard.py).  The library is built without the vectoriser now; NEFES_COMP_STORE = 0 / 2 are the store
+    // variants tried on the way -- two 8-byte stores happened to make the compiler drop the packed multiply, waiting for every store did not.)
     auto store_row = [&](int ch, const float (&v)[4]) {
         float* q = graw + (size_t)ch * S + s0;
+#if NEFES_COMP_STORE == 0
         const float2 lo = make_float2(v[0], v[1]), hi = make_float2(v[2], v[3]);
         asm volatile("global_store_dwordx2 %0, %1, off\n\tglobal_store_dwordx2 %0, %2, off offset:8" :: "v"(q), "v"(lo), "v"(hi) : "memory");
+#else       // A/B builds (make EXTRA=-DNEFES_COMP_STORE=1|2): the original 16-byte store; the same + a wait for every store's completion
+        *(float4*)q = make_float4(v[0], v[1], v[2], v[3]);
+#if NEFES_COMP_STORE == 2
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
     };
     if (sigma_only) { store_row(0, gss); return; }
     store_row(C3, gss);

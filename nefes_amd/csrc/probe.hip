@@ -86,6 +86,93 @@ extern "C" int nefes_probe_store_hazard(float* out, int64_t n_float4, int nops, 
     return (int)hipGetLastError();
 }
 
+// v_pk_mul_f32 / v_pk_add_f32 with op_sel:[0,1] and [1,0] (the low result takes the HIGH half of one operand): the form that produced
+// composite_bwd4_kernel's wrong elements (section 4.7 of DESIGN.md).  Every lane runs `iters` of them on fresh operands and counts the
+// results that are not the two products (bit-exact); out[i] = four byte-wide counts (iters <= 255).  tools/store_hazard.py runs it next to another stream's
+// field kernels.
+__global__ __launch_bounds__(256) void pk_mul_probe_kernel(unsigned* __restrict__ out, long n, int iters) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned bad = 0;
+    float a = (float)(i & 1023) * 0.37f + 1.f, b = (float)(i & 511) * 0.11f + 2.f;
+    for (int k = 0; k < iters; ++k) {
+        const float2 x = make_float2(a, b), y = make_float2(3.f + (float)(k & 7), 5.f + (float)(k & 3));
+        float2 r01, r10, s01, s10;
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r01) : "v"(x), "v"(y));
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r10) : "v"(x), "v"(y));
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(s01) : "v"(x), "v"(y));
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(s10) : "v"(x), "v"(y));
+        // op_sel = which half feeds the LOW result (op_sel_hi, default [1,1], feeds the high one).  One byte per instruction: wrong results
+        // in either half -- mul [0,1], mul [1,0], add [0,1], add [1,0] (saturating at 255)
+        const unsigned e0 = (r01.x != a * y.y) | (r01.y != b * y.y), e1 = (r10.x != b * y.x) | (r10.y != b * y.y);
+        const unsigned e2 = (s01.x != a + y.y) | (s01.y != b + y.y), e3 = (s10.x != b + y.x) | (s10.y != b + y.y);
+        bad += e0 + (e1 << 8) + (e2 << 16) + (e3 << 24);
+        a += 0.25f; b += 0.5f;
+    }
+    out[i] = bad;
+}
+
+// A neighbour for pk_mul_probe_kernel: `iters` rounds of ONE instruction kind on every SIMD of the device, to find which instruction
+// of the field kernels it is that another wave's v_pk_mul_f32 op_sel:[0,1] does not survive.
+//   0: v_fma_mixlo_f16 / v_fma_mixhi_f16 (the fp16 two-part split's conversions: VOP3P with op_sel, like the victim)
+//   1: v_mfma_f32_32x32x16_f16 back to back      2: both, alternating      3: v_pk_fma_f32 with op_sel_hi:[1,0,1]
+//   4: plain v_fma_f32 (control)
+template <int KIND>
+__global__ __launch_bounds__(256) void aggressor_kernel(float* __restrict__ sink, int iters) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    float x = (float)threadIdx.x * 0.001f + 1.f, y = 0.5f, z = 0.25f;
+    unsigned h = 0;
+    f16v acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    h8 a, b;
+    for (int r = 0; r < 8; ++r) { a[r] = (_Float16)(0.01f * (float)(threadIdx.x + r)); b[r] = (_Float16)(0.02f * (float)r); }
+    float2 p = make_float2(x, y), q = make_float2(z, x);
+    for (int k = 0; k < iters; ++k) {
+        if (KIND == 0 || KIND == 2) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0\n\tv_fma_mixhi_f16 %0, %2, %1, 0" : "+v"(h) : "v"(x), "v"(y));
+        }
+        if (KIND == 1 || KIND == 2) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+        }
+        if (KIND == 3) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p) : "v"(q), "v"(q));
+        }
+        if (KIND == 4) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(z) : "v"(x), "v"(y));
+        }
+    }
+    if (sink) sink[(long)blockIdx.x * 256 + threadIdx.x] = (float)h + acc[0] + acc[7] + p.x + p.y + z;
+}
+
+extern "C" int nefes_probe_aggressor(int kind, int iters, int blocks, float* sink, void* stream) {
+    if (iters <= 0 || blocks <= 0 || !sink) return NEFES_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (kind) {
+        case 0: hipLaunchKernelGGL(aggressor_kernel<0>, dim3(blocks), dim3(256), 0, st, sink, iters); break;
+        case 1: hipLaunchKernelGGL(aggressor_kernel<1>, dim3(blocks), dim3(256), 0, st, sink, iters); break;
+        case 2: hipLaunchKernelGGL(aggressor_kernel<2>, dim3(blocks), dim3(256), 0, st, sink, iters); break;
+        case 3: hipLaunchKernelGGL(aggressor_kernel<3>, dim3(blocks), dim3(256), 0, st, sink, iters); break;
+        case 4: hipLaunchKernelGGL(aggressor_kernel<4>, dim3(blocks), dim3(256), 0, st, sink, iters); break;
+        default: return NEFES_E_UNSUPPORTED;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_probe_pk_mul(unsigned* out, int64_t n, int iters, void* stream) {
+    if (!out || n <= 0 || iters <= 0) return NEFES_E_BADARG;
+    hipLaunchKernelGGL(pk_mul_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long)n, iters);
+    return (int)hipGetLastError();
+}
+
 extern "C" int nefes_probe_mfma_clock(int random_operands, int ms_target, double* clock_ghz, double* fp16_dense_tflops,
                                       void* stream) {
     if (!clock_ghz || !fp16_dense_tflops || ms_target <= 0 || ms_target > 2000) return NEFES_E_BADARG;

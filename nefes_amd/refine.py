@@ -476,7 +476,7 @@ def refine_concurrently(refiners, jobs, iters=50):
     chip at its power limit, and ~0.3 ms of FusionNet convolutions, loss and pose kernels that are bound by launch and L2 latency on a
     fraction of the CUs: alone on the device those 0.3 ms are idle silicon, next to another image's field kernels they are nearly
     free (two images: -8 % per image; tools/two_streams.py).  Every image walks exactly the trajectory it walks alone -- bit for bit
-    (tests/test_gpu_streams.py; that test is also what found the 16-byte-store hazard noted in csrc/composite.hip).
+    (tests/test_gpu_streams.py; that test is also what found the packed-fp32 op_sel instruction of DESIGN.md 4.7).
     jobs = [(init_c2w, feature_target, hist), ...] as PoseRefiner.refine takes them -> [(refined c2w, losses [iters]), ...]."""
     if len(refiners) != len(jobs) or not refiners:
         raise ValueError("nefes_amd: refine_concurrently needs one PoseRefiner per job")
