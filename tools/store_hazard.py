@@ -104,6 +104,7 @@ sink = torch.zeros(2048 * 256, device=dev)
 cx, cw = torch.randn(8, 64, 60, 80, device=dev), torch.randn(128, 64, 5, 5, device=dev)
 with torch.no_grad():
     craw = ops.FieldFromRays.apply(ro, rd, rd, z, pk, L.FIELD_FULL)
+torch.cuda.synchronize()                   # (the first measurement below is "next to nothing": nothing of the set-up may still be running)
 KINDS = ("nothing", "copy kernel", "fp16 GEMM (torch.mm)", "fp32 GEMM (torch.mm)", "instruction loop #0 v_fma_mixlo/hi_f16", "instruction loop #1 MFMA 32x32x16 f16",
          "instruction loop #2 both", "instruction loop #3 v_pk_fma_f32 op_sel_hi", "instruction loop #4 v_fma_f32", "FusionNet convolution 5x5 (fp32 MFMA)",
          "compositing forward", "field forward, split f32", "field forward, split x6", "sigma-only field forward",
