@@ -362,6 +362,15 @@ int nefes_pose_compose_fwd(int n_poses, const float* r, const float* t, const fl
 /* g_c2w dev [n,3,4] -> g_r, g_t dev [n,3] (analytic derivative of the Rodrigues formula, float64 inside). */
 int nefes_pose_compose_bwd(int n_poses, const float* r, const float* t, const float* init_c2w, float pose_scale, const float* move,
                            float pose_scale2, const float* g_c2w, float* g_r, float* g_t, void* stream);
+/* FusionNet's BatchNorm2d in TRAIN mode with frozen affine parameters (nerfh_nff.py:356-418; torch.nn.BatchNorm2d semantics): x dev
+ * [B,C,P] -> y, normalised by the batch's statistics (per_image = 0; running_mean / running_var dev [C] updated with `momentum`, the int64 batch counter incremented; any of them NULL: left alone)
+ * or by every image's own (per_image = 1: what the reference's one-image-at-a-time loop computes for a batch; running statistics
+ * untouched).  float64 sums.  save: dev [groups * C * 2] doubles (mean, 1 / sqrt(var + eps)) for the backward, which returns d x only. */
+int nefes_bn_train_fwd(int B, int C, int64_t P, int per_image, const float* x, const float* weight, const float* bias, double eps,
+                       double momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y, double* save,
+                       void* stream);
+int nefes_bn_train_bwd(int B, int C, int64_t P, int per_image, const float* x, const float* weight, const double* save, const float* g_y,
+                       float* g_x, void* stream);
 /* svd_reg (dm/DFM_pose_refine.py:119-129): pose dev [n,3,4] -> out dev [n,3,4] with the 3x3 block replaced by U V^T of its SVD (its
  * orthogonal polar factor), translation column copied.  float64 inside (one-sided Jacobi).  save: dev [n,21] doubles (U, V, sigma) for the
  * backward, or NULL.  The backward is the polar factor's derivative d A = U [(H - H^T) o K] V^T, H = U^T G V, K_ij = 1 / (s_i + s_j):

@@ -14,6 +14,7 @@
 
 #include "../../include/nefes_hip.h"
 #include "bicubic.h"
+#include "wave.h"
 
 namespace {
 
@@ -104,6 +105,138 @@ __global__ void pose_compose_bwd_kernel(PoseArgs p, const float* __restrict__ g,
             for (int j = 0; j < 3; ++j) v += GR[i][j] * dR[k][i][j];
         g_r[k] = (float)v;
         g_t[k] = (float)((double)g[k * 4 + 3] * (double)p.sc * (double)p.sc2);
+    }
+}
+
+// ---- FusionNet's BatchNorm2d in TRAIN mode with frozen affine parameters (nerfh_nff.py:356-418; the reference runs the net with the
+// module in train mode, one image at a time: the output is normalised by THAT image's statistics) -------------------------------------
+// x [B, C, P] -> y; one workgroup per (group, channel), groups = 1 (statistics over the whole batch: torch's BatchNorm) or B (per image:
+// what the reference's one-image-at-a-time loop computes; PoseRefiner(images=B)).  float64 sums in a fixed order; biased variance for the
+// output, unbiased for the running estimate (torch.nn.BatchNorm2d semantics; momentum m: r <- (1 - m) r + m s).  save [groups*C][2] doubles
+// = (mean, 1 / sqrt(var + eps)).  In-house because the loop's other kernels are: no library launch is left in an iteration, and no
+// foreign code shares the CUs with the field kernels of another stream.
+__global__ __launch_bounds__(256) void bn_train_fwd_kernel(int B, int C, long P, int groups, const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, double eps, double momentum, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, long long* __restrict__ batches, float* __restrict__ y, double* __restrict__ save) {
+    __shared__ double sh[256];
+    const int c = blockIdx.x % C, g = blockIdx.x / C;
+    const int per = B / groups;                              // images per group
+    const long n = (long)per * P;
+    // element i of this (group, channel): one image per group (the loop's case) needs no division
+    auto at = [&](long i) -> long { return per == 1 ? ((long)g * C + c) * P + i : ((long)(g * per + i / P) * C + c) * P + i % P; };
+    auto reduce = [&](double v) -> double {                 // wave sums on DPP (wave.h), the four of them added in wave order
+        const double ws_ = wave_sum(v);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ws_;
+        __syncthreads();
+        const double r = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        __syncthreads();
+        return r;
+    };
+    const double ww = w ? (double)w[c] : 1.0, bb = b ? (double)b[c] : 0.0;
+    double mean, ss, var, inv;
+    constexpr int KE = 20;                                   // elements a thread keeps in registers (the loop's 60 x 80 image: 18.75)
+    if (per == 1 && n <= 256 * KE) {                         // one read of x: the three passes run on registers
+        const float* xp = x + ((long)g * C + c) * P;
+        float v[KE];
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < KE; ++k) {
+            const long i = threadIdx.x + 256 * k;
+            v[k] = i < n ? xp[i] : 0.f;
+            acc += (double)v[k];
+        }
+        mean = reduce(acc) / (double)n;
+        acc = 0;
+#pragma unroll
+        for (int k = 0; k < KE; ++k) {
+            const double d = (double)v[k] - mean;
+            acc += threadIdx.x + 256 * k < n ? d * d : 0.0;
+        }
+        ss = reduce(acc); var = ss / (double)n; inv = 1.0 / sqrt(var + eps);
+        float* yp = y + ((long)g * C + c) * P;
+#pragma unroll
+        for (int k = 0; k < KE; ++k) {
+            const long i = threadIdx.x + 256 * k;
+            if (i < n) yp[i] = (float)(((double)v[k] - mean) * inv * ww + bb);
+        }
+    } else {
+        double acc = 0;
+        for (long i = threadIdx.x; i < n; i += 256) acc += (double)x[at(i)];
+        mean = reduce(acc) / (double)n;
+        acc = 0;
+        for (long i = threadIdx.x; i < n; i += 256) {
+            const double d = (double)x[at(i)] - mean;
+            acc += d * d;
+        }
+        ss = reduce(acc); var = ss / (double)n; inv = 1.0 / sqrt(var + eps);
+        for (long i = threadIdx.x; i < n; i += 256) {
+            const long o = at(i);
+            y[o] = (float)(((double)x[o] - mean) * inv * ww + bb);
+        }
+    }
+    if (threadIdx.x == 0) {
+        save[((long)g * C + c) * 2 + 0] = mean;
+        save[((long)g * C + c) * 2 + 1] = inv;
+        if (blockIdx.x == 0 && batches) *batches += 1;       // num_batches_tracked
+        if (groups == 1 && running_mean && running_var) {
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * (n > 1 ? ss / (double)(n - 1) : var));
+        }
+    }
+}
+
+// d x = (w / sigma) (d y - mean(d y) - xhat mean(d y xhat)) over the group's elements
+__global__ __launch_bounds__(256) void bn_train_bwd_kernel(int B, int C, long P, int groups, const float* __restrict__ x, const float* __restrict__ w,
+                                                           const double* __restrict__ save, const float* __restrict__ gy, float* __restrict__ gx) {
+    __shared__ double sh[2][256];
+    const int c = blockIdx.x % C, g = blockIdx.x / C;
+    const int per = B / groups;
+    const long n = (long)per * P;
+    const double mean = save[((long)g * C + c) * 2 + 0], inv = save[((long)g * C + c) * 2 + 1];
+    auto at = [&](long i) -> long { return per == 1 ? ((long)g * C + c) * P + i : ((long)(g * per + i / P) * C + c) * P + i % P; };
+    constexpr int KE = 20;
+    const bool fast = per == 1 && n <= 256 * KE;
+    const float* xp = x + ((long)g * C + c) * P;
+    const float* gp = gy + ((long)g * C + c) * P;
+    float xv[KE], gv[KE];
+    double s1 = 0, s2 = 0;
+    if (fast) {
+#pragma unroll
+        for (int k = 0; k < KE; ++k) {
+            const long i = threadIdx.x + 256 * k;
+            xv[k] = i < n ? xp[i] : 0.f;
+            gv[k] = i < n ? gp[i] : 0.f;
+            const double d = gv[k];
+            s1 += d;
+            s2 += d * ((double)xv[k] - mean) * inv;          // (out-of-range slots hold d = 0)
+        }
+    } else {
+        for (long i = threadIdx.x; i < n; i += 256) {
+            const long o = at(i);
+            const double d = gy[o];
+            s1 += d;
+            s2 += d * ((double)x[o] - mean) * inv;
+        }
+    }
+    {
+        const double w1 = wave_sum(s1), w2 = wave_sum(s2);
+        if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = w1; sh[1][threadIdx.x >> 6] = w2; }
+        __syncthreads();
+    }
+    const double m1 = (((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3]) / (double)n, m2 = (((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3]) / (double)n;
+    const double k_ = (w ? (double)w[c] : 1.0) * inv;
+    if (fast) {
+        float* op = gx + ((long)g * C + c) * P;
+#pragma unroll
+        for (int k = 0; k < KE; ++k) {
+            const long i = threadIdx.x + 256 * k;
+            if (i < n) op[i] = (float)(k_ * ((double)gv[k] - m1 - ((double)xv[k] - mean) * inv * m2));
+        }
+    } else {
+        for (long i = threadIdx.x; i < n; i += 256) {
+            const long o = at(i);
+            gx[o] = (float)(k_ * ((double)gy[o] - m1 - ((double)x[o] - mean) * inv * m2));
+        }
     }
 }
 
@@ -660,6 +793,24 @@ extern "C" int nefes_upcos_gram_bwd(int C, int h, int w, const double* tt, const
     const long n = (long)C * h * w;
     hipLaunchKernelGGL(upcos_gram_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C, (long)h * w, 1e-6, tt, pmat,
                        scratch, g_loss, g_x);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_bn_train_fwd(int B, int C, int64_t P, int per_image, const float* x, const float* weight, const float* bias, double eps,
+                                  double momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y, double* save,
+                                  void* stream) {
+    if (B <= 0 || C <= 0 || P <= 0 || !x || !y || !save) return NEFES_E_BADARG;
+    const int groups = per_image ? B : 1;
+    hipLaunchKernelGGL(bn_train_fwd_kernel, dim3((unsigned)(groups * C)), dim3(256), 0, (hipStream_t)stream, B, C, (long)P, groups, x, weight, bias, eps,
+                       momentum, running_mean, running_var, (long long*)num_batches_tracked, y, save);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_bn_train_bwd(int B, int C, int64_t P, int per_image, const float* x, const float* weight, const double* save, const float* g_y,
+                                  float* g_x, void* stream) {
+    if (B <= 0 || C <= 0 || P <= 0 || !x || !save || !g_y || !g_x) return NEFES_E_BADARG;
+    const int groups = per_image ? B : 1;
+    hipLaunchKernelGGL(bn_train_bwd_kernel, dim3((unsigned)(groups * C)), dim3(256), 0, (hipStream_t)stream, B, C, (long)P, groups, x, weight, save, g_y, g_x);
     return (int)hipGetLastError();
 }
 

@@ -65,6 +65,20 @@ class FusionNet(nn.Module):
         x = ops.frozen_conv2d(x, c2.weight, c2.bias, relu=True)
         return ops.frozen_conv2d(x, c3.weight, c3.bias, relu=False)
 
+    HIP_BATCHNORM = os.environ.get("NEFES_HIP_BATCHNORM", "1") != "0"   # the refinement loop's case (train mode, frozen affine parameters, GPU): csrc/refine.hip bn_train_* instead of MIOpen
+
+    def _bn(self, y, per_image_norm):
+        """The last layer on the convolutions' output y [B,C,H,W]."""
+        from . import ops
+        bn = self.net[-1]
+        per_image = bool(per_image_norm and y.shape[0] > 1 and bn.training)
+        if (self.HIP_BATCHNORM and self.HIP_CONVS and y.is_cuda and y.dtype == torch.float32 and bn.training and bn.momentum is not None
+                and not any(p is not None and p.requires_grad for p in (bn.weight, bn.bias))):
+            return ops.batch_norm_train_frozen(y, bn, per_image)
+        if per_image:
+            return nn.functional.instance_norm(y, weight=bn.weight, bias=bn.bias, eps=bn.eps)
+        return bn(y)
+
     def _conv0_on_gmap(self, w_f, b_f):
         """Conv2d(3 + C, 64, 3) o the factored feature head: the first layer's weights acting on (rgb, sum_s w_s g_s, sum_s w_s)
         [3 + Cg + 1 channels] instead of on (rgb, feat) -- feat = W_f gmap + b_f (sum_s w_s) per pixel (ops.RenderFineFH) and the layer is
@@ -92,12 +106,7 @@ class FusionNet(nn.Module):
         y = ops.frozen_conv2d(y, c1.weight, c1.bias, relu=True)
         y = ops.frozen_conv2d(y, c2.weight, c2.bias, relu=True)
         y = ops.frozen_conv2d(y, c3.weight, c3.bias, relu=False)
-        if self.no_BN:
-            return y
-        if per_image_norm and x.shape[0] > 1 and self.net[-1].training:
-            bn = self.net[-1]
-            return nn.functional.instance_norm(y, weight=bn.weight, bias=bn.bias, eps=bn.eps)
-        return self.net[-1](y)
+        return y if self.no_BN else self._bn(y, per_image_norm)
 
     def forward_parts(self, rgb_nchw, feat_nchw, per_image_norm=False):
         """forward(cat([rgb, feat], 1)) without the in-place slice assignment (whose autograd costs a fill and two copies):
@@ -115,11 +124,7 @@ class FusionNet(nn.Module):
         """forward_parts from the concatenated, colour-normalised input [B,3+C,H,W] on (ops.fusion_input builds it in one launch)."""
         feat_nchw = x[:, 3:]
         convs = self._convs_hip if self._use_hip(x) else self.net[:7]
-        if per_image_norm and not self.no_BN and x.shape[0] > 1 and self.net[-1].training:
-            bn = self.net[-1]
-            out = nn.functional.instance_norm(convs(x), weight=bn.weight, bias=bn.bias, eps=bn.eps)
-        else:
-            out = convs(x) if self.no_BN else self.net[-1](convs(x))
+        out = convs(x) if self.no_BN else self._bn(convs(x), per_image_norm)
         return feat_nchw + out if self.fusion_residule else out
 
 

@@ -55,6 +55,8 @@ SIGNATURES = {
     "nefes_upcos_loss_bwd": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "nefes_bicubic_gather_table": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "nefes_bicubic_gram": (_i, [_i, _i, _i, _i, _p, _p]),
+    "nefes_bn_train_fwd": (_i, [_i, _i, C.c_int64, _i, _p, _p, _p, C.c_double, C.c_double, _p, _p, _p, _p, _p, _p]),
+    "nefes_bn_train_bwd": (_i, [_i, _i, C.c_int64, _i, _p, _p, _p, _p, _p, _p]),
     "nefes_svd_reg_fwd": (_i, [_i, _p, _p, _p, _p]),
     "nefes_svd_reg_bwd": (_i, [_i, _p, _p, _p, _p]),
     "nefes_upcos_prepare": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),

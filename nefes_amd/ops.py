@@ -1089,6 +1089,54 @@ def pose_compose(r, t, init_c2w, pose_scale=1.0, move=(0., 0., 0.), pose_scale2=
     return out[0] if r.dim() == 1 else out
 
 
+class BatchNormTrainFrozen(torch.autograd.Function):
+    """torch.nn.BatchNorm2d in TRAIN mode with frozen affine parameters on [B,C,H,W] (FusionNet's last layer in the refinement loop,
+    nerfh_nff.py:356-418): output normalised by the batch's statistics (running statistics and the batch counter updated as the module
+    does), or by every image's own (`per_image`: torch's instance_norm with the BatchNorm's affine parameters, what the reference's
+    one-image-at-a-time loop computes; running statistics untouched).  csrc/refine.hip bn_train_*: float64 sums, gradient to x only."""
+
+    @staticmethod
+    def forward(ctx, x, bn, per_image):
+        xf = _f32(x)
+        B, Cc = xf.shape[0], xf.shape[1]
+        P = xf.numel() // (B * Cc)
+        y = torch.empty_like(xf)
+        groups = B if per_image else 1
+        save = torch.empty(groups * Cc * 2, dtype=torch.float64, device=xf.device)
+        w = None if bn.weight is None else _f32(bn.weight)
+        b = None if bn.bias is None else _f32(bn.bias)
+        track = (not per_image) and bn.track_running_stats and bn.running_mean is not None
+        momentum = 0.1
+        if track:
+            if bn.momentum is None:
+                raise NotImplementedError("nefes_amd: BatchNorm with momentum=None (cumulative average) takes the torch module")
+            momentum = float(bn.momentum)
+        L.check(L.load().nefes_bn_train_fwd(B, Cc, P, 1 if per_image else 0, _chk(xf, "x"), _chk(w, "weight"), _chk(b, "bias"), float(bn.eps), momentum,
+                                            _chk(bn.running_mean, "running_mean") if track else None, _chk(bn.running_var, "running_var") if track else None,
+                                            _chk(bn.num_batches_tracked, "num_batches_tracked", torch.int64) if track and bn.num_batches_tracked is not None else None,
+                                            _chk(y, "y"), _chk(save, "save", torch.float64), _stream()), "nefes_bn_train_fwd")
+        ctx.save_for_backward(xf, save)
+        ctx.w, ctx.per_image = w, bool(per_image)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xf, save = ctx.saved_tensors
+        gf = _f32(g)
+        B, Cc = xf.shape[0], xf.shape[1]
+        g_x = torch.empty_like(xf)
+        L.check(L.load().nefes_bn_train_bwd(B, Cc, xf.numel() // (B * Cc), 1 if ctx.per_image else 0, _chk(xf, "x"), _chk(ctx.w, "weight"),
+                                            _chk(save, "save", torch.float64), _chk(gf, "g_y"), _chk(g_x, "g_x"), _stream()), "nefes_bn_train_bwd")
+        return g_x, None, None
+
+
+def batch_norm_train_frozen(x, bn, per_image=False):
+    """bn(x) for a torch.nn.BatchNorm2d in train mode whose weight and bias carry no gradient (see BatchNormTrainFrozen)."""
+    if not bn.training or any(p is not None and p.requires_grad for p in (bn.weight, bn.bias)):
+        raise ValueError("nefes_amd: batch_norm_train_frozen is for a BatchNorm in train mode with frozen affine parameters")
+    return BatchNormTrainFrozen.apply(x, bn, bool(per_image))
+
+
 class SvdReg(torch.autograd.Function):
     """svd_reg (dm/DFM_pose_refine.py:119-129) on [..., 3, 4] poses: rotation block -> U V^T, one launch each way (csrc/refine.hip
     svd_reg_*; float64 inside; the backward is the polar factor's derivative, not autograd through an SVD)."""

@@ -418,3 +418,38 @@ def test_fusion_net_hip_convs_against_float64():
         for name, e_hip, e_ref in zip(("fused", "d rgb", "d feature"), err[True], err[False]):
             P.record(f"fusion_net[{B}]", name + " vs float64 (e_ref = torch fp32 on the GPU)", e_hip=e_hip, e_ref=e_ref, bound=1e-4)
             assert e_hip < 1e-4, (B, name, e_hip, e_ref)
+
+
+@pytest.mark.parametrize("B,C,H,W,per_image", [(1, 128, 60, 80, False), (3, 7, 5, 9, False), (3, 7, 5, 9, True), (8, 128, 15, 20, True)])
+def test_batch_norm_train_kernels_match_torch_in_float64(B, C, H, W, per_image):
+    """ops.batch_norm_train_frozen (nefes_bn_train_fwd/bwd) == torch.nn.BatchNorm2d in train mode (== instance_norm with the module's
+    affine parameters for `per_image`, FusionNet.forward_parts' rule for a batch of images) in float64: output, gradient to the input,
+    running mean / variance (unbiased) and the batch counter after two calls."""
+    from nefes_amd import ops
+    g = torch.Generator().manual_seed(B * C + H)
+    x = torch.randn(B, C, H, W, generator=g) * 2.0 + 0.3
+    G = torch.randn(B, C, H, W, generator=g)
+    bn64 = torch.nn.BatchNorm2d(C).double().train()
+    with torch.no_grad():
+        bn64.weight.copy_(torch.randn(C, generator=g).double())
+        bn64.bias.copy_(torch.randn(C, generator=g).double())
+    import copy
+    bn = copy.deepcopy(bn64).float().to(DEV).requires_grad_(False).train()
+    for rep in range(2):
+        xd = x.double().requires_grad_()
+        if per_image:
+            yd = torch.nn.functional.instance_norm(xd, weight=bn64.weight, bias=bn64.bias, eps=bn64.eps)
+        else:
+            yd = bn64(xd)
+        (yd * G.double()).sum().backward()
+        xh = x.to(DEV).requires_grad_()
+        yh = ops.batch_norm_train_frozen(xh, bn, per_image)
+        (yh * G.to(DEV)).sum().backward()
+        e_y, e_g = rel(yh.detach().cpu().numpy(), yd.detach().numpy()), rel(xh.grad.cpu().numpy(), xd.grad.numpy())
+        assert e_y < 1e-6 and e_g < 2e-6, (rep, e_y, e_g)
+    P.record(f"batch_norm_train[{B},{C},{H},{W},{int(per_image)}]", "output / d input vs float64 torch", e_hip=max(e_y, e_g), e_ref=None, direct=max(e_y, e_g), bound=2e-6)
+    if per_image:
+        assert int(bn.num_batches_tracked) == 0 and float(bn.running_mean.abs().max()) == 0.0            # untouched
+    else:
+        assert int(bn.num_batches_tracked) == 2
+        assert rel(bn.running_mean.cpu().numpy(), bn64.running_mean.numpy()) < 1e-6 and rel(bn.running_var.cpu().numpy(), bn64.running_var.numpy()) < 1e-6
