@@ -477,11 +477,19 @@ def refine_concurrently(refiners, jobs, iters=50):
     fraction of the CUs: alone on the device those 0.3 ms are idle silicon, next to another image's field kernels they are nearly
     free (two images: -8 % per image; tools/two_streams.py).  Every image walks exactly the trajectory it walks alone -- bit for bit
     (tests/test_gpu_streams.py; that test is also what found the packed-fp32 op_sel instruction of DESIGN.md 4.7).
-    jobs = [(init_c2w, feature_target, hist), ...] as PoseRefiner.refine takes them -> [(refined c2w, losses [iters]), ...]."""
-    if len(refiners) != len(jobs) or not refiners:
-        raise ValueError("nefes_amd: refine_concurrently needs one PoseRefiner per job")
+    jobs = [(init_c2w, feature_target, hist), ...] as PoseRefiner.refine takes them -> [(refined c2w, losses [iters]), ...] in job order.
+    More jobs than refiners: rounds of len(refiners) images (the last one smaller)."""
+    if not refiners or not jobs:
+        raise ValueError("nefes_amd: refine_concurrently needs at least one PoseRefiner and one job")
     if len({id(r) for r in refiners}) != len(refiners):
         raise ValueError("nefes_amd: refine_concurrently needs DISTINCT PoseRefiner objects (each owns the static buffers of its image)")
+    if len(jobs) > len(refiners):
+        out = []
+        for k in range(0, len(jobs), len(refiners)):
+            part = jobs[k:k + len(refiners)]
+            out += refine_concurrently(refiners[:len(part)], part, iters)
+        return out
+    refiners = refiners[:len(jobs)]
     dev = refiners[0].dev
     jobs = [tuple(t.to(dev) for t in job) for job in jobs]
     for r, job in zip(refiners, jobs):

@@ -77,6 +77,10 @@ def test_two_images_on_two_streams_walk_their_solo_trajectories(golden):
     assert not torch.equal(solo[0][0], solo[1][0])
     with pytest.raises(ValueError):
         refine_concurrently([refs[0], refs[0]], jobs, iters=1)
+    # more images than refiners: rounds of two, results in job order
+    three = refine_concurrently(refs, [jobs[1], jobs[0], jobs[1]], iters=n)
+    for (p, l), k in zip(three, (1, 0, 1)):
+        assert torch.equal(p, solo[k][0]) and torch.equal(l, solo[k][1])
 
 
 @pytest.mark.parametrize("case", ["headline", "hashgrid", "train"])
