@@ -8,6 +8,10 @@
 // look-ahead batches of 2 k-steps for the narrow segments: with 4 the Wd = 128 bf16x6 instance spills (316 B scratch)
 #define NEFES_B_BATCH 2
 #define NEFES_B_BATCH_NT8 4
+// every run of compiler-placed MFMAs ends with field_common.h mfma_results_fence: hipcc pads an MFMA's result against its own vector
+// instructions, but takes the first path it finds to the MFMA where two join (seen: 7 of 18 wait states on the path that skips the
+// mask stores) and does not look into the asm statements of the operand functors at all (tools/hazard_lint.py rules B1 / B2)
+#define NEFES_ASM_READS_ACC
 #include "field_common.h"
 #include "field_x6.h"
 #include "../../include/nefes_hip.h"

@@ -6,6 +6,9 @@
 // 1 k-values) stay on the fp32 MFMA.  Every gradient vector carries a per-lane scale exponent (field_h3.h).
 #if defined(NEFES_TU_PART) && NEFES_TU_PART >= 2 && NEFES_TU_PART % 2 == 0
 #define NEFES_SLAB_KIB 16      // even parts from 2 on: the Wd = 128 instances (layout.h NEFES_H3_BWD_SLAB_KIB_128)
+#define NEFES_ASM_READS_ACC    // built with -amdgpu-mfma-vgpr-form: the functors' asm statements read the MFMAs' own VGPRs (field_common.h)
+#define NEFES_ACC_VGPR_FORM
+#define NEFES_FENCE_TILES
 #else
 #define NEFES_SLAB_KIB 32
 // The Wd = 256 inference objects (parts 0, 1) run their 8-/10-tile products on field_h3.h's gap-by-gap schedule (asm MFMAs on AGPR
@@ -17,6 +20,8 @@
 #if !defined(NEFES_TU_PART) || NEFES_TU_PART == 0 || NEFES_TU_PART == 1 || NEFES_TU_PART == 5
 #define H3B_WIDE
 #define H3_ACC_READ_ASM        // source tiles are read out of their AGPRs inside the MFMA gaps (field_h3.h acc_read)
+#define NEFES_ASM_READS_ACC    // ... by asm statements: compiler-placed runs end with field_common.h mfma_results_fence_tiles
+#define NEFES_FENCE_TILES
 #define H3_WIDE_ENTRY_FENCE    // wide runs follow compiler-scheduled segments here (field_h3.h mma_run_h3_wide)
 #else
 #define NEFES_H3_WIDE_MIN 99   // TRAIN instances: block-per-pair form for every segment
@@ -121,6 +126,13 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
     constexpr int WT = (NTW + 1) / 2, WH = (NTH + 1) / 2;   // mask words per trunk / half-width layer
     constexpr int MW_TRUNK = 8 * WT;
     constexpr int NTR = KR16 <= 2 ? 1 : 5;                          // tiles of the rgb+feature head block in `dacts` (TRAIN)
+    // Layers on the gap-by-gap schedule (asm MFMAs, field_h3.h mma_run_h3_wide).  Not in the instance with the hash grid in its
+    // epilogue: there hipcc splits the live range of one accumulator tile INSIDE an asm-scheduled run whenever anything about the
+    // kernel's register use changes (round 5: the skip's share parked in LDS; round 6: the ReLU-mask words read in place) -- a
+    // v_accvgpr_mov one wait state behind the asm MFMA that writes the tile, which the compiler cannot know needs twelve
+    // (tools/hazard_lint.py rule B1; tests/test_pack_stream.py finds the move itself).  With compiler-placed MFMAs a moved tile is
+    // the compiler's to pad.  Costs configs[3] ~4 ms of 590 per frame.
+    constexpr int WIDE_LAYERS = ENC == NEFES_XYZ_HASHGRID_FUSED ? 0 : H3B_WIDE_LAYERS;
     static_assert(KR16 == 2 || KR16 == 9, "head classes of layout.h (nefes_head_kr16 / nefes_head_ntr)");
     const int C3 = 3 + a.C;                                         // static rgb/feature head^T: 3+C upstream channels as fp16 k-steps
     static_assert(MW % 4 == 0, "mask words are staged as 16-byte groups");
@@ -413,11 +425,17 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
             const int ew = wexp(NEFES_H3B_FINAL), tau = tau_of(M, ew);
             float mx = 0.f;
             es_b = tau + ew;
-            mma_run_h3<NTW, W / 16, 2, true, 2, (H3B_WIDE_LAYERS & 1) != 0>(ring, ring_lane, wrap_store_h3<TRAIN>(IdentSplitH<NTW + 2, 2>{XA, pow2i(tau - es_dt), mx}, gptr(NEFES_TB_FINAL), pow2i(-es_dt)), ZeroInit{}, XB);
+            mma_run_h3<NTW, W / 16, 2, true, 2, (WIDE_LAYERS & 1) != 0>(ring, ring_lane, wrap_store_h3<TRAIN>(IdentSplitH<NTW + 2, 2>{XA, pow2i(tau - es_dt), mx}, gptr(NEFES_TB_FINAL), pow2i(-es_dt)), ZeroInit{}, XB);
             const float dsig = STASH(6);
             float dsg[1];
             dsg[0] = dsig * pow2i(es_b);
+            // (no trailing fence where layer 8's run is a wide one: its entry fence is the same 18 wait states, and a second
+            // scheduling barrier here made hipcc move an accumulator tile inside that run in the hash-grid instance)
+#if defined(H3B_WIDE) && defined(H3_WIDE_ENTRY_FENCE)
+            mma_run<NTW, 1, 2, false, ((WIDE_LAYERS >> 8) & 1) == 0 || (NTW < NEFES_H3_WIDE_MIN)>(ring, ring_lane, ArrayIn<1>{dsg}, ZeroInit{}, XB);
+#else
             mma_run<NTW, 1, 2, false>(ring, ring_lane, ArrayIn<1>{dsg}, ZeroInit{}, XB);
+#endif
             M = rowb(NEFES_H3B_FINAL) * (pair_max(mx) * pow2i(-es_dt)) + rowb(NEFES_H3B_SIG) * pair_max(fabsf(dsig));
         }
         // ---- xyz_encoding_8^T .. xyz_encoding_2^T, straight-line (XB -> XA -> XB ...).  Layer 5 also emits the skip's d
@@ -429,7 +447,7 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
             const int ew = wexp(NEFES_H3B_L8 + 8 - (L)), tau = tau_of(M, ew);                                       \
             float mx = 0.f;                                                                                         \
             ES_DST = tau + ew;                                                                                      \
-            mma_run_h3<NTILES, W / 16, T0, true, 2, ((H3B_WIDE_LAYERS >> (L)) & 1) != 0>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTW + 2, WT, 2>{SRC, bt, pow2i(tau - ES_SRC), mx}, gptr(NEFES_TB_L1 + (L) - 1), pow2i(-(ES_SRC))), ZeroInit{}, DST); \
+            mma_run_h3<NTILES, W / 16, T0, true, 2, ((WIDE_LAYERS >> (L)) & 1) != 0>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTW + 2, WT, 2>{SRC, bt, pow2i(tau - ES_SRC), mx}, gptr(NEFES_TB_L1 + (L) - 1), pow2i(-(ES_SRC))), ZeroInit{}, DST); \
             M = rowb(NEFES_H3B_L8 + 8 - (L)) * (pair_max(mx) * pow2i(-(ES_SRC)));                                   \
         }
         NEFES_BWD_LAYER(8, XB, XA, es_b, es_a, NTW, 2)

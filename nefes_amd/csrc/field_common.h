@@ -67,20 +67,23 @@ __device__ __forceinline__ float relu1(float v) {
     else asm volatile("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
     return r;
 }
-// ReLU-mask words are built by shifting, one VALU instruction per activation on either side of a word's life:
-// forward shifts the SIGN bit of the pre-activation in from the right (v_alignbit_b32: {word, v} >> 31 = word<<1 | sign),
-// backward shifts the bits out from the left (v_add_co -> carry) and zeroes the gradient where the sign was set
-// (v_cndmask).  Bit = 1 means "pre-activation negative" (relu' = 0).  Both sides walk a layer's activations in the same
-// order, 32 per word, so the first activation of a word travels to bit 31 and is the first to come back out.
+// ReLU-mask words: forward shifts the SIGN bit of the pre-activation in from the right (v_alignbit_b32: {word, v} >> 31 = word<<1 |
+// sign), one VALU instruction per activation; 32 activations per word, walked in the same order on both sides, so activation e of a
+// layer ends up in bit 31 - (e % 32) of word e / 32.  Bit = 1 means "pre-activation negative" (relu' = 0).  Backward picks that bit
+// (v_bfe_i32: 0 or -1) and clears the gradient where it is set (v_bfi_b32): two VALU instructions per value, none of them through
+// an SGPR.  (Rounds 1-5 shifted the bits out through the carry: v_add_co_u32 vcc + v_cndmask_b32 back to back inside one asm
+// statement -- two wait states short of what gfx940+ asks between a VALU write of VCC and a VALU read of it as a scalar operand,
+// which hipcc pads for its own instructions and cannot see inside asm: tools/hazard_lint.py rule C10)
 // (A pre-activation of exactly +0.0 passes the gradient where torch's relu' gives 0; -0.0 does not.)
 __device__ __forceinline__ void mask_shift_in(uint32_t& bits, float v) {
     asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(bits) : "v"(v));
 }
+// e = index of the activation in its layer's walking order (a compile-time constant after unrolling); bits = word e / 32
 template <bool NOP = true>
-__device__ __forceinline__ float mask_shift_out(uint32_t& bits, float v) {
-    float r;
-    if (NOP) asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, %2, 0, vcc\n\ts_nop 1" : "+v"(bits), "=v"(r) : "v"(v) : "vcc");
-    else asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, %2, 0, vcc" : "+v"(bits), "=v"(r) : "v"(v) : "vcc");
+__device__ __forceinline__ float mask_pick(const uint32_t& bits, int e, float v) {
+    float r;                    // (also the scratch for the picked bit: early-clobber, it is written before v is read)
+    if (NOP) asm volatile("v_bfe_i32 %0, %1, %2, 1\n\tv_bfi_b32 %0, %0, 0, %3\n\ts_nop 1" : "=&v"(r) : "v"(bits), "n"(31 - (e & 31)), "v"(v));
+    else asm volatile("v_bfe_i32 %0, %1, %2, 1\n\tv_bfi_b32 %0, %0, 0, %3" : "=&v"(r) : "v"(bits), "n"(31 - (e & 31)), "v"(v));
     return r;
 }
 
@@ -161,6 +164,67 @@ __device__ __forceinline__ void pin(T (&v)[N]) {
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
 }
 
+// ---- results of compiler-placed MFMAs that ASM statements read -----------------------------------------------------------
+// hipcc pads the wait states between an MFMA and a vector instruction that touches its result (12 after the 8-pass
+// v_mfma_f32_32x32x16_f16 / bf16, 18 after the 16-pass v_mfma_f32_32x32x2_f32 on gfx950) -- for vector instructions it can see.  An
+// `asm volatile` statement is not one of them (GCNHazardRecognizer: INLINEASM is neither VALU nor MFMA).  Where the functors of the
+// NEXT product read a run's tiles through asm -- directly out of the MFMA's own VGPRs in the objects built with
+// -amdgpu-mfma-vgpr-form (the Wd = 128 fp16 instances), or through field_h3.h acc_read's asm v_accvgpr_read_b32 (the Wd = 256
+// inference objects) -- nothing stood between the run's last MFMA and that read but whatever the scheduler had put there:
+// tools/hazard_lint.py found the transient heads' fp32 product read 2-6 wait states after its last k-step in every such backward
+// instance, the headline one included.  That k-step carries d loss / d beta and a padding row, zero in every test-time loss, which
+// is why nothing showed -- until round 5's factored head moved the schedule and the read fell one k-step earlier.
+// Translation units that read accumulators through asm define NEFES_ASM_READS_ACC; their runs end with this fence.
+template <int WS>
+__device__ __forceinline__ void mfma_results_fence() {
+#if defined(NEFES_ASM_READS_ACC) && !defined(NEFES_NO_RESULTS_FENCE)
+    static_assert(WS >= 1 && WS <= 32, "one or two s_nop");
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (WS > 16) asm volatile("s_nop 15\n\ts_nop %0" ::"n"(WS - 17) : "memory");
+    else asm volatile("s_nop %0" ::"n"(WS - 1) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// The same wait states TIED TO THE RUN'S TILES instead of fenced off with scheduling barriers (the fp16 objects: NEFES_FENCE_TILES):
+// every MFMA of the run precedes the statement (it reads and writes all NT tiles), every reader of a tile follows it, and everything
+// else -- the next run's LDS reads, mask words, exponent arithmetic -- moves across it freely.  (With sched_barrier(0) on both sides
+// the Wd = 128 kernels lost 7-11 %: profiles/r06/README.md; the wait states themselves are 0.6 % of a tile.)
+// NEFES_ACC_VGPR_FORM: the object is built with -amdgpu-mfma-vgpr-form, its accumulators are VGPRs.
+#if defined(NEFES_ACC_VGPR_FORM)
+#define NEFES_ACC_RW(x) "+v"(x)
+#else
+#define NEFES_ACC_RW(x) "+a"(x)
+#endif
+template <int WS, int NT, int T0, int NACC>
+__device__ __forceinline__ void mfma_results_fence_tiles(f32x16 (&acc)[NACC]) {
+#if defined(NEFES_ASM_READS_ACC) && !defined(NEFES_NO_RESULTS_FENCE)
+#if !defined(NEFES_FENCE_TILES)
+    mfma_results_fence<WS>();
+#else
+    static_assert(WS == 12 || WS == 18, "12: 8-pass XDL MFMAs, 18: the 16-pass fp32 MFMA");
+    static_assert(NT >= 1 && NT <= 10, "tiles of one run");
+#define NEFES_FENCE_ASM(...)                                                                  \
+    do {                                                                                      \
+        if constexpr (WS == 12) asm volatile("s_nop 11" : __VA_ARGS__);                       \
+        else asm volatile("s_nop 15\n\ts_nop 1" : __VA_ARGS__);                                \
+    } while (0)
+#define A_(i) NEFES_ACC_RW(acc[T0 + (i)])
+    if constexpr (NT == 1) NEFES_FENCE_ASM(A_(0));
+    else if constexpr (NT == 2) NEFES_FENCE_ASM(A_(0), A_(1));
+    else if constexpr (NT == 3) NEFES_FENCE_ASM(A_(0), A_(1), A_(2));
+    else if constexpr (NT == 4) NEFES_FENCE_ASM(A_(0), A_(1), A_(2), A_(3));
+    else if constexpr (NT == 5) NEFES_FENCE_ASM(A_(0), A_(1), A_(2), A_(3), A_(4));
+    else if constexpr (NT == 6) NEFES_FENCE_ASM(A_(0), A_(1), A_(2), A_(3), A_(4), A_(5));
+    else if constexpr (NT == 7) NEFES_FENCE_ASM(A_(0), A_(1), A_(2), A_(3), A_(4), A_(5), A_(6));
+    else if constexpr (NT == 8) NEFES_FENCE_ASM(A_(0), A_(1), A_(2), A_(3), A_(4), A_(5), A_(6), A_(7));
+    else if constexpr (NT == 9) NEFES_FENCE_ASM(A_(0), A_(1), A_(2), A_(3), A_(4), A_(5), A_(6), A_(7), A_(8));
+    else NEFES_FENCE_ASM(A_(0), A_(1), A_(2), A_(3), A_(4), A_(5), A_(6), A_(7), A_(8), A_(9));
+#undef A_
+#undef NEFES_FENCE_ASM
+#endif
+#endif
+}
+
 // ---- B-operand producers (one float per k-step and lane) and C-operand initialisers (one tile at a time) ----------
 // Consumer-side activation: a layer never materialises its activated output.  The NEXT layer's product reads the
 // producer's accumulators register by register (k-step s <-> accumulator tile s/16, register s%16), applies the
@@ -190,11 +254,11 @@ struct IdentIn {                // X as is (tiles T0..)
     __device__ __forceinline__ float get(int s) const { return X[T0 + (s >> 4)][s & 15]; }
 };
 template <int NX, int NW, int T0 = 0>
-struct MaskedIn {               // backward: mask bit of activation s ? X : 0   (consumes the word by shifting)
+struct MaskedIn {               // backward: mask bit of activation s ? 0 : X
     const f32x16 (&X)[NX];
     uint32_t (&bits)[NW];
     template <bool NOP>
-    __device__ __forceinline__ float get(int s) const { return mask_shift_out<NOP>(bits[s >> 5], X[T0 + (s >> 4)][s & 15]); }
+    __device__ __forceinline__ float get(int s) const { return mask_pick<NOP>(bits[s >> 5], s, X[T0 + (s >> 4)][s & 15]); }
 };
 // TRAIN instances of the backward kernel: the (masked) gradient vector a product consumes is also what the weight-gradient
 // kernels need, so it is stored on the way in -- element s (feature 32*(s/16) + rho_h(s%16)) of this lane's sample goes to
@@ -247,7 +311,8 @@ struct BiasInit {               // C operand of the first k-step = bias rows of 
 // acc[T0 .. T0+NT) (+)= W-block * in   over KS k-steps, fully unrolled: every register index below is a compile-time
 // constant after unrolling.  FIRST: the first k-step takes its C operand from init(t) (bias or zero) instead of acc,
 // so accumulators need no initialisation pass.  ring_lane = LDS pointer of the ring base + lane*16.
-template <int NT, int KS, int T0, bool FIRST, class InFn, class InitFn, int NACC, class Ring>
+// FENCE = false: the caller's next statement provides the wait states itself (field_h3.h H3_WIDE_ENTRY_FENCE)
+template <int NT, int KS, int T0, bool FIRST, bool FENCE = true, class InFn, class InitFn, int NACC, class Ring>
 __device__ __forceinline__ void mma_run(Ring& ring, const char* ring_lane, const InFn& in, const InitFn& init,
                                         f32x16 (&acc)[NACC]) {
     static_assert(T0 + NT <= NACC, "accumulator array too small");
@@ -346,6 +411,7 @@ __device__ __forceinline__ void mma_run(Ring& ring, const char* ring_lane, const
         }
         ring.pf = a;
     }
+    if constexpr (FENCE) mfma_results_fence_tiles<18, NT, T0>(acc);
 }
 // array-input, accumulate-into-acc form (callers initialise acc themselves)
 template <int NT, int KS, int T0 = 0, int NACC, class Ring>
@@ -393,11 +459,8 @@ __device__ __forceinline__ void act_store(float (&dst)[NOUT], const f32x16 (&acc
 // backward: dst[s] = (mask bit of activation s) ? acc[T0 + s/16][s%16] : 0, words consumed in shift order (see mask_shift_in)
 template <int NT, int T0, int NACC, int NOUT>
 __device__ __forceinline__ void mask_store(float (&dst)[NOUT], const f32x16 (&acc)[NACC], const uint32_t (&bits)[(NT + 1) / 2]) {
-    uint32_t w[(NT + 1) / 2];
 #pragma unroll
-    for (int k = 0; k < (NT + 1) / 2; ++k) w[k] = bits[k];
-#pragma unroll
-    for (int s = 0; s < NT * 16; ++s) dst[s] = mask_shift_out(w[s >> 5], acc[T0 + (s >> 4)][s & 15]);
+    for (int s = 0; s < NT * 16; ++s) dst[s] = mask_pick(bits[s >> 5], s, acc[T0 + (s >> 4)][s & 15]);
 }
 
 // sin/cos of x*2^k for the frequency embedding.  x*2^k is exact in fp32 (the reference computes sin(x * 2^k)), so the argument

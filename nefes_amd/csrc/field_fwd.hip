@@ -6,6 +6,10 @@
 // SURVEY.md §8d (491 264 sigma-only / 665 088 full at Wd=256,C=16).  Weights: LDS-DMA ring, read once
 // per 128-sample workgroup tile from L2 (2.7 MB stream, resident).  Activations never leave registers.
 #define NEFES_SLAB_KIB NEFES_FWD_SLAB_KIB
+// every run of compiler-placed MFMAs ends with field_common.h mfma_results_fence: hipcc pads an MFMA's result against its own vector
+// instructions, but takes the first path it finds to the MFMA where two join (seen: 7 of 18 wait states on the path that skips the
+// mask stores) and does not look into the asm statements of the operand functors at all (tools/hazard_lint.py rules B1 / B2)
+#define NEFES_ASM_READS_ACC
 #include "field_common.h"
 #include "../../include/nefes_hip.h"
 

@@ -15,6 +15,15 @@
 #define NEFES_SLAB_KIB 32
 #endif
 #include <stdlib.h>
+// Accumulators read by asm statements: the Wd = 128 objects (-amdgpu-mfma-vgpr-form: the functors' asm reads the MFMAs' own VGPRs) and
+// the Wd = 256 objects (H3_ACC_READ_ASM below): compiler-placed runs end with field_common.h mfma_results_fence
+#if defined(NEFES_TU_W128) || !defined(H3_NO_ACC_READ_ASM)
+#define NEFES_ASM_READS_ACC
+#define NEFES_FENCE_TILES
+#endif
+#if defined(NEFES_TU_W128)
+#define NEFES_ACC_VGPR_FORM
+#endif
 
 #ifndef NEFES_FWD_CONSUMER_BIAS
 #define NEFES_FWD_CONSUMER_BIAS 1   /* 0: bias tiles written by the producing run (A/B builds) */

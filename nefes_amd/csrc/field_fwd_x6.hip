@@ -10,6 +10,10 @@
 // The bf16 MFMA holds the vector issue port for a quarter of its time, so the split (5.5 VALU per element) hides in the
 // gaps (tools/probe/overlap_probe.hip).  Weight stream: 48 KiB slabs = 16 units of three 1 KiB groups (hi, mid, lo).
 #define NEFES_SLAB_KIB NEFES_X6_SLAB_KIB
+// every run of compiler-placed MFMAs ends with field_common.h mfma_results_fence: hipcc pads an MFMA's result against its own vector
+// instructions, but takes the first path it finds to the MFMA where two join (seen: 7 of 18 wait states on the path that skips the
+// mask stores) and does not look into the asm statements of the operand functors at all (tools/hazard_lint.py rules B1 / B2)
+#define NEFES_ASM_READS_ACC
 #include "field_common.h"
 #include "../../include/nefes_hip.h"
 

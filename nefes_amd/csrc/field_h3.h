@@ -265,8 +265,8 @@ struct MaskedSplitH {
     float r;
     float& m;
     __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
-        s.x0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]));
-        s.x1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]));
+        s.x0 = mask_pick<false>(bits[(8 * q + 2 * p) >> 5], 8 * q + 2 * p, acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]));
+        s.x1 = mask_pick<false>(bits[(8 * q + 2 * p + 1) >> 5], 8 * q + 2 * p + 1, acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]));
     }
     __device__ __forceinline__ void stage_b(PairRegs& s) const {
         absmax3_acc(m, s.x0, s.x1);
@@ -291,8 +291,8 @@ struct MaskedAddSplitH {
     __device__ __forceinline__ void stage_a(PairRegs& s, int q, int p) const {
         const float x0 = __builtin_fmaf(add[8 * q + 2 * p], sa, acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]));
         const float x1 = __builtin_fmaf(add[8 * q + 2 * p + 1], sa, acc_read(X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]));
-        s.x0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], x0);
-        s.x1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], x1);
+        s.x0 = mask_pick<false>(bits[(8 * q + 2 * p) >> 5], 8 * q + 2 * p, x0);
+        s.x1 = mask_pick<false>(bits[(8 * q + 2 * p + 1) >> 5], 8 * q + 2 * p + 1, x1);
     }
     __device__ __forceinline__ void stage_b(PairRegs& s) const { absmax3_acc(m, s.x0, s.x1); }
     template <bool NOP>
@@ -615,6 +615,12 @@ __device__ __forceinline__ void mma_run_h3_wide(Ring& ring, const char* ring_lan
     asm volatile("s_nop 12\n\ts_nop 4"
                  : "+a"(acc[T0 + NT - 1]), "+a"(acc[T0 + NT - 2])
                  : "v"(HA(NU - 1)), "v"(BQ(KS16 - 1).h), "v"(BQ(KS16 - 1).l));
+    // The run's VGPR tiles keep their registers through those wait states even when nobody reads them afterwards (the second d
+    // embedding tile of the instances with an external / hash-grid encoding is such a tile): a dead tile's registers were handed to
+    // the next ring loads ONE wait state behind the asm MFMA still writing them (tools/hazard_lint.py rule B2, write after write).
+#pragma unroll
+    for (int t = 0; t < VT; ++t)
+        if (t >= T0 && t < T0 + NT) asm volatile("" : "+v"(acc[t]));
 }
 
 // Narrow segments (fewer than eight tiles: the half-width layers and the heads, a few per cent of the MFMAs): the operand of the
@@ -708,6 +714,7 @@ __device__ __forceinline__ void mma_run_h3_small(Ring& ring, const char* ring_la
         }
     }
     ring.pf = ah;
+    mfma_results_fence_tiles<12, NT, T0>(acc);
 }
 
 template <int NT, int KS16, int T0, bool FIRST = true, int VT = 0, bool ALLOW_WIDE = true, class SrcFn, class InitFn, int NACC, class Ring>

@@ -90,8 +90,8 @@ struct MaskedSplit {            // backward: mask bit ? X : 0
     const f32x16 (&X)[NX];
     uint32_t (&bits)[NWORDS];
     __device__ __forceinline__ void vals(int q, int p, float& x0, float& x1) const {
-        x0 = mask_shift_out<false>(bits[(8 * q + 2 * p) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
-        x1 = mask_shift_out<false>(bits[(8 * q + 2 * p + 1) >> 5], X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
+        x0 = mask_pick<false>(bits[(8 * q + 2 * p) >> 5], 8 * q + 2 * p, X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p]);
+        x1 = mask_pick<false>(bits[(8 * q + 2 * p + 1) >> 5], 8 * q + 2 * p + 1, X[T0 + (q >> 1)][(q & 1) * 8 + 2 * p + 1]);
     }
     template <int NP = 6>
     __device__ __forceinline__ void pair(Split3& o, int q, int p) const { float x0, x1; vals(q, p, x0, x1); split_pair_n<NP>(o, p, x0, x1); }
@@ -228,5 +228,6 @@ __device__ __forceinline__ void mma_run_x6(WeightRing<SLOTS>& ring, const char* 
         }
     }
     ring.pf = ah;
+    mfma_results_fence<12>();
 }
 

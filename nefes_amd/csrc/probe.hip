@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void aggressor_kernel(float* __restrict__ sink
     h8 a, b;
     for (int r = 0; r < 8; ++r) { a[r] = (_Float16)(0.01f * (float)(threadIdx.x + r)); b[r] = (_Float16)(0.02f * (float)r); }
     float2 p = make_float2(x, y), q = make_float2(z, x);
+    asm volatile("s_nop 1" : "+v"(acc), "+v"(a), "+v"(b));       // (vector writes of the operands -> the first asm MFMA: two wait states)
     for (int k = 0; k < iters; ++k) {
         if (KIND == 0 || KIND == 2) {
 #pragma unroll
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256) void aggressor_kernel(float* __restrict__ sink
                 asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(z) : "v"(x), "v"(y));
         }
     }
+    asm volatile("s_nop 11" : "+v"(acc));                         // (the last asm MFMA -> vector reads of its result: twelve)
     if (sink) sink[(long)blockIdx.x * 256 + threadIdx.x] = (float)h + acc[0] + acc[7] + p.x + p.y + z;
 }
 

@@ -1,0 +1,148 @@
+"""Software wait states of the gfx950 code objects (tools/hazard_lint.py), on the CPU.
+
+The field kernels are built from `asm volatile` statements (csrc/field_h3.h, field_common.h), which hipcc's hazard recognizer does not
+look into: every producer -> consumer pair with one end inside such a statement is the program's to pad.  The linter re-checks LLVM's
+gfx940 / gfx950 rules on the disassembly of the built library, where asm and compiler code are the same thing.  First the linter
+itself on hand-written sequences (each rule red when violated, green when padded; a hazard that only exists along one of two joining
+paths); then the shipped library: no violation in any kernel but the probe that exists to violate one.
+
+What it found in round 5's library (profiles/r06/hazard_lint_r05_library.txt): the transient heads' fp32
+product read 2-6 wait states after its last k-step (18 required) in every backward instance whose functors read accumulators through asm
+-- the owner of DESIGN 4.9's "not understood" 10-25 % error --, 29 000 VCC round trips inside one asm statement, compiler-made reads on
+the short side of a branch, a dead VGPR tile overwritten one wait state behind the MFMA still writing it."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import hazard_lint as H  # noqa: E402
+
+TOOLS_OK = all(os.path.exists(os.path.join(H.BIN, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump"))
+
+
+def _text(lines, name="k"):
+    """objdump-style text of one function; a line 'L3:' labels the next instruction, 'branch L3' refers to it"""
+    addr, labels, body = 0x1000, {}, []
+    for ln in lines:                                   # first pass: addresses (4 bytes per instruction is enough for the CFG)
+        if ln.endswith(":"):
+            labels[ln[:-1]] = addr
+        else:
+            addr += 4
+    addr = 0x1000
+    out = [f"{0x1000:016x} <{name}>:"]
+    for ln in lines:
+        if ln.endswith(":"):
+            continue
+        parts = ln.split()
+        cmt = ""
+        if parts[0].startswith(("s_cbranch", "s_branch")):
+            tgt = labels[parts[1]]
+            ln = f"{parts[0]} {(tgt - addr - 4) // 4}"
+            cmt = f" <{name}+0x{tgt - 0x1000:x}>"
+        out.append(f"\t{ln:60s}// {addr:012X}: 00000000{cmt}")
+        addr += 4
+    return "\n".join(out) + "\n"
+
+
+def _lint(lines):
+    (name, base, insts), = H.functions(_text(lines))
+    return [(v[1], v[2], v[3]) for v in H.lint_function(name, base, insts)]       # (rule, need, have)
+
+
+XDL = "v_mfma_f32_32x32x16_f16 a[0:15], v[0:3], v[4:7], a[0:15]"
+F32 = "v_mfma_f32_32x32x2_f32 v[16:31], v0, v1, v[16:31]"
+NOP = "s_mov_b32 s0, s1"                                 # any instruction = one wait state
+
+
+@pytest.mark.parametrize("producer,consumer,rule,need", [
+    (XDL, "v_accvgpr_read_b32 v9, a3", "B1", 12),                       # 8-pass XDL result read by the vector ALU
+    (F32, "v_cndmask_b32_e64 v40, v16, 0, vcc", "B1", 18),              # 16-pass fp32 MFMA result: round 5's transient-head read
+    (F32, "ds_write_b32 v40, v17", "B1", 18),                           # ... by an LDS instruction
+    (F32, "global_store_dword v[40:41], v18, off", "B1", 18),           # ... by a store
+    (XDL, "v_accvgpr_write_b32 a5, v9", "B2", 12),                      # write after write
+    ("v_mfma_f32_32x32x16_f16 v[16:31], v[0:3], v[4:7], v[16:31]", "ds_read_b128 v[16:19], v40", "B2", 12),   # a load into a dead tile
+    (XDL, "v_mfma_f32_32x32x16_f16 a[16:31], a[0:3], v[4:7], a[16:31]", "A3", 12),     # result as the next MFMA's A operand
+    (F32, "v_mfma_f32_32x32x2_f32 v[32:47], v16, v1, v[32:47]", "A3", 18),
+    (XDL, "v_mfma_f32_32x32x16_f16 a[8:23], v[0:3], v[4:7], a[8:23]", "A2", 10),       # overlapping, not identical, C operand
+    ("v_mov_b32_e32 v4, v9", XDL, "A1", 2),                             # vector write of an MFMA operand
+    ("v_accvgpr_write_b32 a7, v9", XDL, "A1", 2),
+    ("v_add_co_u32_e32 v44, vcc, v44, v44", "v_cndmask_b32_e64 v8, v8, 0, vcc", "C10", 2),    # rounds 1-5's mask_shift_out
+    ("v_cmp_gt_f32_e64 s[4:5], v1, v2", "v_cndmask_b32_e64 v8, v8, 0, s[4:5]", "C10", 2),
+    ("v_readlane_b32 s7, v1, 3", "global_load_dword v2, v3, s[6:7]", "C1", 5),
+    ("v_readfirstlane_b32 s7, v1", "v_readlane_b32 s9, v2, s7", "C2", 4),
+    ("v_cmp_gt_f32_e32 vcc, v1, v2", "v_div_fmas_f32 v3, v4, v5, v6", "C3", 4),
+    ("v_mov_b32_e32 v2, v9", "v_mov_b32_dpp v3, v2 row_shr:1 row_mask:0xf bank_mask:0xf", "C4", 2),
+    ("s_mov_b32 m0, s7", "global_load_lds_dwordx4 v[2:3], off", "C5", 1),
+    ("global_store_dwordx4 v[14:15], v[10:13], off", "v_add_f32_e32 v12, 1.0, v12", "C6", 2),
+    ("v_exp_f32_e32 v3, v2", "v_add_f32_e32 v4, v3, v3", "C7", 1),
+    ("v_mov_b32_e32 v2, v9", "v_permlane32_swap_b32_e32 v2, v3", "C9", 2),
+    ("v_mov_b32_e32 v2, v9", "v_readfirstlane_b32 s3, v2", "C11", 1),
+])
+def test_each_rule_is_red_when_short_and_green_when_padded(producer, consumer, rule, need):
+    for pad in (0, need - 1):
+        got = _lint([producer] + [NOP] * pad + [consumer, "s_endpgm"])
+        assert (rule, need, pad) in got, (pad, got)
+    assert not [g for g in _lint([producer] + [NOP] * need + [consumer, "s_endpgm"]) if g[0] == rule]
+    # s_nop N counts N + 1
+    if need >= 2:
+        assert not [g for g in _lint([producer, f"s_nop {need - 1}", consumer, "s_endpgm"]) if g[0] == rule]
+        assert (rule, need, need - 1) in _lint([producer, f"s_nop {need - 2}", consumer, "s_endpgm"])
+
+
+def test_the_accumulate_chain_needs_no_wait_states():
+    assert _lint([XDL, XDL, XDL, "s_nop 11", "v_accvgpr_read_b32 v9, a3", "s_endpgm"]) == []
+    assert _lint([F32, F32, "s_nop 15", "s_nop 1", "v_max_f32_e32 v40, 0, v16", "s_endpgm"]) == []
+
+
+def test_write_after_read_of_an_xdl_c_operand():
+    got = _lint(["v_mfma_f32_32x32x16_f16 a[16:31], v[0:3], v[4:7], v[32:47]", NOP, "v_mov_b32_e32 v33, 0", "s_endpgm"])
+    assert ("B3", 7, 1) in got
+
+
+def test_the_shorter_of_two_joining_paths_decides():
+    """hipcc's own recognizer marks a predecessor block visited on the first path that reaches it and so misses the short side of a
+    diamond (field_fwd_kernel read a79 seven wait states behind its fp32 MFMA where a null mask pointer skips the mask stores): the
+    linter follows every path."""
+    long_side = [NOP] * 20
+    prog = [F32, "s_cbranch_vccnz L1"] + long_side + ["L1:", NOP, "v_max_f32_e32 v40, 0, v31", "s_endpgm"]
+    got = _lint(prog)
+    assert ("B1", 18, 2) in got                              # branch + NOP on the taken path
+    prog = [F32, "s_cbranch_vccnz L1"] + long_side + ["L1:", "s_nop 15", "s_nop 1", "v_max_f32_e32 v40, 0, v31", "s_endpgm"]
+    assert _lint(prog) == []
+
+
+def test_a_loop_back_edge_carries_the_producer():
+    prog = ["L0:", "v_accvgpr_read_b32 v9, a3", NOP, XDL, "s_cbranch_scc1 L0", "s_endpgm"]
+    assert ("B1", 12, 1) in _lint(prog)
+
+
+def test_operand_parsing():
+    ops, mods = H.split_operands("v[10:11], v[12:13], v[54:55] op_sel:[0,1]")
+    assert ops == ["v[10:11]", "v[12:13]", "v[54:55]"] and mods == "op_sel:[0,1]"
+    assert H.parse_reg("-|v3|") == ("v", 3, 1) and H.parse_reg("a[16:31]") == ("a", 16, 16) and H.parse_reg("vcc") == ("s", 106, 2)
+    assert H.parse_reg("0x1700") is None and H.parse_reg("off") is None and H.parse_reg("vmcnt(0)") is None
+    I = H.decode(0, "v_add_co_u32_e32", "v1, vcc, v2, v3", "")
+    assert ("v", 1) in I.defs and H.VCC in I.defs and ("v", 2) in I.uses
+    I = H.decode(0, "global_load_lds_dwordx4", "v197, s[10:11]", "")
+    assert I.reads_m0_dma and not I.defs
+    I = H.decode(0, "v_permlane32_swap_b32_e32", "v9, v11", "")
+    assert {("v", 9), ("v", 11)} <= set(I.defs) and {("v", 9), ("v", 11)} <= set(I.uses)
+
+
+# kernels allowed to carry a finding, and why
+ALLOWED = {
+    ("store_hazard_kernel<0>", "C6"): "csrc/probe.hip: the probe whose purpose is to overwrite a 16-byte store's data registers at once",
+}
+
+
+@pytest.mark.skipif(not TOOLS_OK, reason="ROCm LLVM tools not installed")
+def test_shipped_library_has_no_unpadded_hazard():
+    from nefes_amd import lib as L
+    viol, kernels, insts = H.lint(L.LIB_PATH)
+    assert kernels > 150 and insts > 1_000_000, (kernels, insts)                       # (the whole library was read)
+    bad = [v for v in viol if not any(k in v[0] and v[2] == r for (k, r) in ALLOWED)]
+    assert not bad, [(v[0][:80], hex(v[1]), v[2], f"need {v[3]} have {v[4]}", v[5], v[6]) for v in bad[:8]]
+    # the probe's intended violation is still seen: the rule is alive on real disassembly
+    assert any("store_hazard_kernel<0>" in v[0] and v[2] == "C6" for v in viol)

@@ -685,7 +685,8 @@ def test_no_accumulator_tile_is_relocated_inside_the_asm_scheduled_kernels(tmp_p
             # forward: field_fwd_h3_kernel<MODE, ENC, 256, NTR, false, FH> (inference); backward: field_bwd_h3_kernel<256, KR16, ENC, HAS_T, false, FH>
             wide = (re.match(r"void field_fwd_h3_kernel<\d+, \d+, 256, \d+, false, (true|false)>", name) or
                     re.match(r"void field_bwd_h3_kernel<256, \d+, [012], (true|false), false, (true|false)>", name))     # (HAS_T false: the static-head instances of round 5;
-            # ENC 2: the backward with the hash grid in its epilogue -- its first form had a tile moved inside a run, found HERE)
+            # ENC 2: the backward with the hash grid in its epilogue -- its first form had a tile moved inside a run, found HERE; round 6: it
+            # did it again when the ReLU-mask words changed from shifted to picked, and left the asm schedule: it must carry NO asm run now)
             if not wide:
                 continue
             c = checked.setdefault(name, {"mfma": 0, "mov": 0, "runs": 0, "inside": False})
@@ -702,6 +703,9 @@ def test_no_accumulator_tile_is_relocated_inside_the_asm_scheduled_kernels(tmp_p
                     c["mov"] += 1
     assert len(checked) >= 5 and any("field_bwd_h3_kernel<256, 2, 2," in n for n in checked), list(checked)                       # sigma / full x two encodings forward, two encodings backward
     for name, c in checked.items():
+        if "field_bwd_h3_kernel<256, 2, 2," in name:                # (compiler-placed MFMAs: a moved tile is the compiler's to pad; tests/test_hazard_lint.py)
+            assert c["runs"] == 0, (name, c)
+            continue
         assert c["runs"] >= 1 and not c["inside"] and c["mfma"] > 900 and c["mov"] == 0, (name, c)
 
 
