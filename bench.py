@@ -211,6 +211,8 @@ def refinement_loop(dev, iters=50, graph=True, images=1, mode="upsampled", strea
     low = T(g["target_low"])
     full = torch.nn.functional.interpolate(low[None], size=(H, W), mode="bicubic")[0]            # what mode 2 matches against
     common = dict(tinyscale=ts, lr_r=float(g["lr"][0]), lr_t=float(g["lr"][1]), world_setup=world, device=dev)
+    if streams > 1:            # refiners on several streams share the frozen networks: no BatchNorm bookkeeping (refine_concurrently)
+        common["bn_running_stats"] = False
     n_img = 3
     if mode == "2":
         photo = T(g["photo_u8"]).float()[None] / 255.
@@ -335,6 +337,72 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+# What each rank of an N-GPU run executes, measured on ONE GPU (tools/shard_times.sh, round 3: the headline step on the first 1/N of the
+# frame's rows): the step has no fixed cost worth naming, so this is the per-rank time a perfect N-GPU run would show on that box.
+SHARD_MS_ONE_GPU = {1: 433.3, 2: 216.6, 4: 108.1, 8: 54.2}
+
+
+def multi_gpu_diagnostics(dist, dev, world, rank, ar_times, a):
+    """What a one-shot N-GPU run needs to explain itself: time inside the pose-gradient all-reduce per rank, every
+    rank's sustained MFMA clock right after the timed region, the collective library's version and the node's link topology."""
+    import ctypes as _C
+    from nefes_amd import lib as L
+    dev_ms = [s.elapsed_time(e) for s, e, _ in (ar_times or [])]
+    host_ms = [h * 1e3 for _, _, h in (ar_times or [])]
+    mine = torch.tensor([sum(dev_ms) / max(len(dev_ms), 1), max(dev_ms, default=0.), sum(host_ms) / max(len(host_ms), 1), 0., 0.],
+                        device=dev, dtype=torch.float64)
+    try:
+        ghz, tf = _C.c_double(), _C.c_double()
+        L.check(L.load().nefes_probe_mfma_clock(1, 40, _C.byref(ghz), _C.byref(tf), None), "nefes_probe_mfma_clock")
+        mine[3], mine[4] = ghz.value, tf.value
+    except Exception:
+        pass
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    if rank != 0:
+        return None
+    rows = [[float(v) for v in t.tolist()] for t in every]
+    out = {"all_reduce_ms_device_mean_by_rank": [round(r[0], 4) for r in rows], "all_reduce_ms_device_max_by_rank": [round(r[1], 4) for r in rows],
+           "all_reduce_ms_host_call_mean_by_rank": [round(r[2], 4) for r in rows], "all_reduces_per_rank": len(dev_ms),
+           "sustained_clock_ghz_by_rank": [round(r[3], 3) for r in rows], "sustained_16bit_mfma_tflops_by_rank": [round(r[4], 1) for r in rows],
+           "note": "all_reduce device time = events on the compute stream around the call: it includes waiting for the slowest rank to arrive"}
+    try:
+        out["collective_library"] = {"backend": dist.get_backend(), "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                                     "env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))}}
+    except Exception as e:
+        out["collective_library"] = {"error": str(e)}
+    try:                                                            # link types / hops between the node's GPUs (a child process; never an exec)
+        import subprocess
+        r = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showtopotype", "--showtopohops", "--csv"], capture_output=True, text=True, timeout=30)
+        out["topology"] = [ln for ln in r.stdout.splitlines() if ln.strip()][:40]
+    except Exception as e:
+        out["topology"] = f"unavailable: {e}"
+    if (a.workload, a.height, a.width) == ("metric", 0, 0) and world in SHARD_MS_ONE_GPU:
+        out["one_gpu_shard_ms_reference"] = SHARD_MS_ONE_GPU[world]
+        out["one_gpu_shard_ms_reference_source"] = "tools/shard_times.sh, round 3, one box (boxes differ by +-3 %)"
+    return out
+
+
+def hbm_kernel_lines(kern, rays, Nc, Ni, Wd, C):
+    """the HBM-bound kernels of the step as GB/s of ALGORITHMIC bytes against the 8 TB/s spec (DESIGN.md 4.2 / 4.3 state the
+    byte counts: the forward reads a ray's raw block + depths and writes weights + maps; the backward reads nine rows + depths + the
+    upstream maps and writes the gradient block; the coarse pass reads sigma and writes the merged depths)."""
+    S = Nc + Ni
+    fh = any("fh]" in k for k in kern)
+    R = 3 + (Wd // 2 + 1 if fh else C) + 6
+    rows_written_bwd = (3 + 1 + 6) if fh else R                 # factored head: the static weight in place of the g rows' products
+    maps = (3 + (Wd // 2 + 1 if fh else C) + 3) * 4
+    per_ray = {"composite_fwd": S * R * 4 + S * 4 + S * 4 + maps,
+               "composite_bwd": 9 * S * 4 + S * 4 + rows_written_bwd * S * 4 + maps,
+               "coarse_sample": Nc * 4 + S * 4}
+    out = {}
+    for k, b in per_ray.items():
+        if k in kern and kern[k] > 0:
+            gbs = b * rays / (kern[k] * 1e-3) / 1e9
+            out[k] = {"ms": round(kern[k], 4), "algorithmic_bytes_per_ray": b, "GB/s": round(gbs, 1), "frac_of_8TB/s": round(gbs / 8000.0, 4)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -452,6 +520,7 @@ def main():
         step()
     barrier()
     ops.TIMERS = {}
+    D.ALLREDUCE_TIMES = [] if world > 1 else None
     t0 = time.perf_counter()
     trace = os.environ.get("NEFES_BENCH_TRACE", "0") == "1"           # debugging: host time of every step (adds a sync per step)
     for _ in range(a.steps):
@@ -467,7 +536,9 @@ def main():
     if trace:
         print(f"enqueue {t_enq:.4f} s, with the final sync {dt:.4f} s", file=sys.stderr, flush=True)
     timers, ops.TIMERS = ops.TIMERS, None
+    ar_times, D.ALLREDUCE_TIMES = D.ALLREDUCE_TIMES, None
     rank_ms = [dt / a.steps * 1e3]
+    multi = None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(tmax) for _ in range(world)]
@@ -475,6 +546,7 @@ def main():
         rank_ms = [float(t.item()) / a.steps * 1e3 for t in every]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        multi = multi_gpu_diagnostics(dist, dev, world, rank, ar_times, a)
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -537,7 +609,10 @@ def main():
                          "vs_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_unit": "bytes/launch (HBM side: 2 x FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC passes, profiles/)",
-                         "end_to_end_frac": value * (flop_frame / n_total) / (PEAK_F32_MFMA_TFLOPS * 1e12 * world)},
+                         # whole step against the same bound as the dominant kernel (weak: the step is 99.9 % these kernels)
+                         "end_to_end_frac": value * (flop_frame / n_total) / (peak * 1e12 * world),
+                         "end_to_end_vs_fp32_mfma_peak": value * (flop_frame / n_total) / (PEAK_F32_MFMA_TFLOPS * 1e12 * world),
+                         "hbm_kernels": hbm_kernel_lines(kern, rays_local, Nc, Ni, Wd, C)},
             "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items())},
             "pose_grad_abs_max": float(g.abs().max()),
             # the all-reduced 3x4 pose gradient itself (row-major), so that an N-rank run can be compared with the 1-rank run number
@@ -545,6 +620,10 @@ def main():
             "pose_grad": [float(v) for v in g.detach().reshape(-1).cpu().tolist()],
             "ms_per_step_by_rank": {"min": min(rank_ms), "max": max(rank_ms), "all": [round(t, 4) for t in rank_ms]},
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
+            if "one_gpu_shard_ms_reference" in multi:
+                out["multi_gpu"]["scaling_efficiency_vs_one_gpu_shard"] = multi["one_gpu_shard_ms_reference"] / ms_step
         if h3 or x6:
             # The 2 500 TFLOP/s data-sheet peak is a 2.4 GHz figure; under sustained MFMA issue with operands whose bits toggle
             # the chip's power management holds a lower clock.  Measured here, on this box, right after the timed region

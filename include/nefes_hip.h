@@ -377,6 +377,13 @@ int nefes_bn_train_bwd(int B, int C, int64_t P, int per_image, const float* x, c
  * well conditioned at the near-rotations a pose network regresses, where autograd through torch.svd divides by s_i^2 - s_j^2 ~ 0. */
 int nefes_svd_reg_fwd(int n_poses, const float* pose, float* out, double* save, void* stream);
 int nefes_svd_reg_bwd(int n_poses, const double* save, const float* g_out, float* g_pose, void* stream);
+/* The pose chain behind the regression network of train_on_batch (dm/DFM_APR_refine.py:91-97) as one launch each way: svd_reg as above
+ * (do_svd = 0: the rotation block is copied) and fix_coord_supp's translation (dm/direct_pose_model.py:210-232: t' = (t sc + move) sc2,
+ * passed as t_scale = sc sc2 and (mx, my, mz) = move sc2; fp32, one multiply and one add as the torch expression rounds).  The backward
+ * returns d pose [n,3,4]: the polar factor's derivative for the block, g_t t_scale for the translation. */
+int nefes_regressed_pose_fwd(int n_poses, const float* pose, int do_svd, float t_scale, float mx, float my, float mz, float* out, double* save,
+                             void* stream);
+int nefes_regressed_pose_bwd(int n_poses, const double* save, int do_svd, float t_scale, const float* g_out, float* g_pose, void* stream);
 /* feature_loss (DFM_pose_refine.py:211-233, per_pixel=False): loss = 1 - mean_c cos(a[c,:], b[c,:]), a, b dev [C,P] contiguous,
  * torch.nn.CosineSimilarity(dim=1, eps=1e-6) semantics, float64 accumulation.  scratch: dev doubles,
  * nefes_cosine_loss_scratch_doubles(C) of them, kept by the caller for the backward. */
@@ -414,6 +421,9 @@ int nefes_upcos_prepare(int C, int h, int w, int OH, int OW, int crop, const flo
                         double* dbb, void* stream);
 int nefes_upcos_gram_fwd(int C, int h, int w, const float* x, const double* tt, const double* dbb, const double* gram_x, const double* gram_y,
                          int band, double* scratch, double* pmat, float* loss, void* stream);
+/* LDS bytes one workgroup of nefes_upcos_gram_fwd needs at this geometry; above 96 KiB the launch returns NEFES_E_UNSUPPORTED and the
+ * caller stays on the one-pass kernels (nefes_upcos_loss_fwd / _bwd), which take any geometry (asked when the target is prepared). */
+size_t nefes_upcos_gram_lds_bytes(int h, int w, int band);
 int nefes_upcos_gram_bwd(int C, int h, int w, const double* tt, const double* pmat, const double* scratch, const float* g_loss, float* g_x,
                          void* stream);
 /* Which up-sampled positions of the window [o0, o0 + n_win) of an axis (n_in -> n_out, bicubic) reach source index y, and with what

@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
     // Layers on the gap-by-gap schedule (asm MFMAs, field_h3.h mma_run_h3_wide).  Not in the instance with the hash grid in its
     // epilogue: there hipcc splits the live range of one accumulator tile INSIDE an asm-scheduled run whenever anything about the
     // kernel's register use changes (round 5: the skip's share parked in LDS; round 6: the ReLU-mask words read in place) -- a
-    // v_accvgpr_mov one wait state behind the asm MFMA that writes the tile, which the compiler cannot know needs twelve
-    // (tools/hazard_lint.py rule B1; tests/test_pack_stream.py finds the move itself).  With compiler-placed MFMAs a moved tile is
+    // v_accvgpr_mov one wait state behind the asm MFMA that writes the tile, where hipcc would put twelve behind an MFMA of its own
+    // (tools/hazard_lint.py rule B1; tests/test_pack_stream.py finds the move itself; round 3 saw wrong gradients from such a move).  With compiler-placed MFMAs a moved tile is
     // the compiler's to pad.  Costs configs[3] ~4 ms of 590 per frame.
     constexpr int WIDE_LAYERS = ENC == NEFES_XYZ_HASHGRID_FUSED ? 0 : H3B_WIDE_LAYERS;
     static_assert(KR16 == 2 || KR16 == 9, "head classes of layout.h (nefes_head_kr16 / nefes_head_ntr)");
@@ -393,9 +393,21 @@ __global__ __launch_bounds__(256, NEFES_H3B_WG_PER_CU(W)) void field_bwd_h3_kern
                 mma_run_h3<NTW + 1, GS / 8, 1, true>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{T3, bh, pow2i(tau - es3), mt}, gptr(NEFES_TB_T0), pow2i(-es3)), ZeroInit{}, XA);
             }
             load_bits(bh, MW_TRUNK, WH);
+#ifdef NEFES_FH_VARIANT_VALU_UPDATE
+            // Round 5's failing bring-up form as far as it can be reconstructed, kept buildable for tools/fh_variant.sh (DESIGN.md
+            // 4.10): d loss / d g added to the head's tiles by the vector ALU, the pair's second product on the plain functor.  The
+            // linter is red on it without the result fences (the transient heads' fp32 tile read 2 wait states behind its MFMA) --
+            // and it is numerically RIGHT with and without them on round 6's boxes: round 5's 10-25 % error did not come back.
+            if constexpr (FH) {
+#pragma unroll
+                for (int e = 0; e < 16 * NTH; ++e) G2[e >> 4][e & 15] += dgv[e] * pow2i(es_g2);
+                mma_run_h3<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, MaskedSplitH<NTH, WH, 0>{G2, bh, pow2i(tau - es_g2), mg}, ZeroInit{}, XA);
+            } else
+#else
             if constexpr (FH)
                 mma_run_h3<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, MaskedAddSplitH<NTH, WH, 0, 16 * NTH>{G2, bh, pow2i(tau - es_g2), mg, dgv, pow2i(es_g2)}, ZeroInit{}, XA);
             else
+#endif
             mma_run_h3<NTW + 1, GS / 8, 1, !HAS_T>(ring, ring_lane, wrap_store_h3<TRAIN>(MaskedSplitH<NTH, WH, 0>{G2, bh, pow2i(tau - es_g2), mg}, gptr(NEFES_TB_DIR), pow2i(-es_g2)), ZeroInit{}, XA);
             M = (HAS_T ? rowb(NEFES_H3B_T0) * (pair_max(mt) * pow2i(-es3)) : 0.f) + rowb(NEFES_H3B_DIR) * (pair_max(mg) * pow2i(-es_g2));
         }

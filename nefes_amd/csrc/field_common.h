@@ -72,8 +72,9 @@ __device__ __forceinline__ float relu1(float v) {
 // layer ends up in bit 31 - (e % 32) of word e / 32.  Bit = 1 means "pre-activation negative" (relu' = 0).  Backward picks that bit
 // (v_bfe_i32: 0 or -1) and clears the gradient where it is set (v_bfi_b32): two VALU instructions per value, none of them through
 // an SGPR.  (Rounds 1-5 shifted the bits out through the carry: v_add_co_u32 vcc + v_cndmask_b32 back to back inside one asm
-// statement -- two wait states short of what gfx940+ asks between a VALU write of VCC and a VALU read of it as a scalar operand,
-// which hipcc pads for its own instructions and cannot see inside asm: tools/hazard_lint.py rule C10)
+// statement -- two wait states short of what hipcc itself puts between a VALU write of VCC and a VALU read of it as a scalar operand
+// on gfx940+, and which it cannot see inside asm: tools/hazard_lint.py rule C10, DESIGN.md section 4.10.  No wrong result was ever
+// traced to it; the pick costs the same two instructions and drops the serial chain through the mask word.)
 // (A pre-activation of exactly +0.0 passes the gradient where torch's relu' gives 0; -0.0 does not.)
 __device__ __forceinline__ void mask_shift_in(uint32_t& bits, float v) {
     asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(bits) : "v"(v));
@@ -172,8 +173,10 @@ __device__ __forceinline__ void pin(T (&v)[N]) {
 // -amdgpu-mfma-vgpr-form (the Wd = 128 fp16 instances), or through field_h3.h acc_read's asm v_accvgpr_read_b32 (the Wd = 256
 // inference objects) -- nothing stood between the run's last MFMA and that read but whatever the scheduler had put there:
 // tools/hazard_lint.py found the transient heads' fp32 product read 2-6 wait states after its last k-step in every such backward
-// instance, the headline one included.  That k-step carries d loss / d beta and a padding row, zero in every test-time loss, which
-// is why nothing showed -- until round 5's factored head moved the schedule and the read fell one k-step earlier.
+// instance of round 5's library, the headline one included.  Measured on MI355X (tools/fh_variant.sh): a read two wait
+// states behind the MFMA still returns the finished result -- every upstream channel alone, beta (= that last k-step) included --, so
+// the hardware evidently interlocks this dependency and no wrong number was ever traced to it.  The rule is the toolchain's own
+// (it is what hipcc inserts for its own code); the library now satisfies it everywhere, at no measurable cost, and the linter keeps it so.
 // Translation units that read accumulators through asm define NEFES_ASM_READS_ACC; their runs end with this fence.
 template <int WS>
 __device__ __forceinline__ void mfma_results_fence() {

@@ -11,6 +11,7 @@
 //                     float64 accumulation; backward d loss / d a in one pass.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/nefes_hip.h"
 #include "bicubic.h"
@@ -305,19 +306,33 @@ __device__ void svd3(const double A[3][3], Svd3& o) {
 }
 
 // pose [n,3,4] -> out [n,3,4] (rotation block U V^T, translation column copied); save [n,21] doubles = U, V (row-major), sigma
-__global__ void svd_reg_fwd_kernel(int n, const float* __restrict__ pose, float* __restrict__ out, double* __restrict__ save) {
+// WORLD (nefes_regressed_pose_*): the translation column leaves as t * t_scale + t_move (fix_coord_supp, dm/direct_pose_model.py:210-232,
+// in torch's fp32 operation order: one multiply, one add); do_svd = 0 copies the rotation block (svd_reg off).
+struct WorldT {
+    float scale, mx, my, mz;
+};
+template <bool WORLD>
+__global__ void svd_reg_fwd_kernel(int n, const float* __restrict__ pose, float* __restrict__ out, double* __restrict__ save, int do_svd, WorldT wt) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const float* p = pose + (long)k * 12;
+    float* o = out + (long)k * 12;
+    if (WORLD && !do_svd) {
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) o[i * 4 + j] = p[i * 4 + j];
+            o[i * 4 + 3] = __fadd_rn(__fmul_rn(p[i * 4 + 3], wt.scale), i == 0 ? wt.mx : (i == 1 ? wt.my : wt.mz));
+        }
+        return;
+    }
     double A[3][3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) A[i][j] = p[i * 4 + j];
     Svd3 d;
     svd3(A, d);
-    float* o = out + (long)k * 12;
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) o[i * 4 + j] = (float)(d.U[i][0] * d.V[j][0] + d.U[i][1] * d.V[j][1] + d.U[i][2] * d.V[j][2]);
-        o[i * 4 + 3] = p[i * 4 + 3];
+        if (WORLD) o[i * 4 + 3] = __fadd_rn(__fmul_rn(p[i * 4 + 3], wt.scale), i == 0 ? wt.mx : (i == 1 ? wt.my : wt.mz));
+        else o[i * 4 + 3] = p[i * 4 + 3];
     }
     if (save) {
         double* sv = save + (long)k * 21;
@@ -327,11 +342,21 @@ __global__ void svd_reg_fwd_kernel(int n, const float* __restrict__ pose, float*
     }
 }
 
-__global__ void svd_reg_bwd_kernel(int n, const double* __restrict__ save, const float* __restrict__ g_out, float* __restrict__ g_pose) {
+template <bool WORLD>
+__global__ void svd_reg_bwd_kernel(int n, const double* __restrict__ save, const float* __restrict__ g_out, float* __restrict__ g_pose, int do_svd,
+                                   float t_scale) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const double* sv = save + (long)k * 21;
     const float* g = g_out + (long)k * 12;
+    if (WORLD && !do_svd) {
+        float* o_ = g_pose + (long)k * 12;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) o_[i * 4 + j] = g[i * 4 + j];
+            o_[i * 4 + 3] = g[i * 4 + 3] * t_scale;
+        }
+        return;
+    }
     double U[3][3], V[3][3], s[3], GV[3][3], H[3][3], M[3][3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) { U[i][j] = sv[i * 3 + j]; V[i][j] = sv[9 + i * 3 + j]; }
@@ -350,7 +375,7 @@ __global__ void svd_reg_bwd_kernel(int n, const double* __restrict__ save, const
         double UM[3];
         for (int j = 0; j < 3; ++j) UM[j] = U[i][0] * M[0][j] + U[i][1] * M[1][j] + U[i][2] * M[2][j];
         for (int j = 0; j < 3; ++j) o[i * 4 + j] = (float)(UM[0] * V[j][0] + UM[1] * V[j][1] + UM[2] * V[j][2]);
-        o[i * 4 + 3] = g[i * 4 + 3];
+        o[i * 4 + 3] = WORLD ? g[i * 4 + 3] * t_scale : g[i * 4 + 3];
     }
 }
 
@@ -772,14 +797,31 @@ extern "C" int nefes_upcos_prepare(int C, int h, int w, int OH, int OW, int crop
     return (int)hipGetLastError();
 }
 
+// LDS bytes of one upcos_gram_fwd_kernel workgroup (a band of rows of one channel: Q = X Gx and the two Gram bands); the launch needs
+// it within NEFES_UPCOS_GRAM_LDS_MAX.  Callers ask BEFORE they commit to the prepared-target form (ops.UpcosTarget.fits): the one-pass
+// kernels (nefes_upcos_loss_fwd / _bwd) take any geometry.
+#define NEFES_UPCOS_GRAM_LDS_MAX (96 * 1024)
+extern "C" size_t nefes_upcos_gram_lds_bytes(int h, int w, int band) {
+    if (h <= 0 || w <= 0 || band < 0) return 0;
+    const int per = (h + kParts - 1) / kParts;
+    return (size_t)(per + 2 * band) * w * 12 + (size_t)(w + per) * (2 * band + 1) * 8;
+}
+
 extern "C" int nefes_upcos_gram_fwd(int C, int h, int w, const float* x, const double* tt, const double* dbb, const double* gram_x,
                                     const double* gram_y, int band, double* scratch, double* pmat, float* loss, void* stream) {
     if (C <= 0 || h <= 0 || w <= 0 || band < 0 || !x || !tt || !dbb || !gram_x || !gram_y || !scratch || !pmat || !loss) return NEFES_E_BADARG;
-    const int per = (h + kParts - 1) / kParts;
-    const size_t lds = (size_t)(per + 2 * band) * w * 12 + (size_t)(w + per) * (2 * band + 1) * 8;
-    if (lds > 96 * 1024) return NEFES_E_UNSUPPORTED;
-    hipError_t e = hipFuncSetAttribute((const void*)upcos_gram_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    const size_t lds = nefes_upcos_gram_lds_bytes(h, w, band);
+    if (lds > NEFES_UPCOS_GRAM_LDS_MAX) return NEFES_E_UNSUPPORTED;
+    // the kernel's dynamic-LDS ceiling, once per device of this process (a constant: not state a caller could observe)
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+        hipError_t e = hipFuncSetAttribute((const void*)upcos_gram_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NEFES_UPCOS_GRAM_LDS_MAX);
+        if (e != hipSuccess) return (int)e;
+        attr_set.fetch_or(bit, std::memory_order_relaxed);
+    }
     double* part = scratch + (size_t)C * 4;
     hipLaunchKernelGGL(upcos_gram_fwd_kernel, dim3((unsigned)(C * kParts)), dim3(256), lds, (hipStream_t)stream, h, w, band, x, tt, dbb, gram_x,
                        gram_y, part, pmat);
@@ -816,13 +858,31 @@ extern "C" int nefes_bn_train_bwd(int B, int C, int64_t P, int per_image, const 
 
 extern "C" int nefes_svd_reg_fwd(int n_poses, const float* pose, float* out, double* save, void* stream) {
     if (n_poses <= 0 || !pose || !out) return NEFES_E_BADARG;
-    hipLaunchKernelGGL(svd_reg_fwd_kernel, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_poses, pose, out, save);
+    hipLaunchKernelGGL(svd_reg_fwd_kernel<false>, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_poses, pose, out, save, 1, WorldT{1.f, 0.f, 0.f, 0.f});
     return (int)hipGetLastError();
 }
 
 extern "C" int nefes_svd_reg_bwd(int n_poses, const double* save, const float* g_out, float* g_pose, void* stream) {
     if (n_poses <= 0 || !save || !g_out || !g_pose) return NEFES_E_BADARG;
-    hipLaunchKernelGGL(svd_reg_bwd_kernel, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_poses, save, g_out, g_pose);
+    hipLaunchKernelGGL(svd_reg_bwd_kernel<false>, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_poses, save, g_out, g_pose, 1, 1.f);
+    return (int)hipGetLastError();
+}
+
+// train_on_batch's pose chain behind the regression network as ONE launch each way (DFM_APR_refine.py:91-97): svd_reg (optional) and
+// fix_coord_supp's translation t' = t * t_scale + t_move.  In torch that chain is ~8 element-wise / cat launches forward and ~12 in
+// autograd's backward: two thirds of what an iteration of the shipped default mode cost over the LearnPose mode.
+extern "C" int nefes_regressed_pose_fwd(int n_poses, const float* pose, int do_svd, float t_scale, float mx, float my, float mz, float* out,
+                                        double* save, void* stream) {
+    if (n_poses <= 0 || !pose || !out || (do_svd && !save)) return NEFES_E_BADARG;
+    hipLaunchKernelGGL(svd_reg_fwd_kernel<true>, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_poses, pose, out, save,
+                       do_svd, WorldT{t_scale, mx, my, mz});
+    return (int)hipGetLastError();
+}
+
+extern "C" int nefes_regressed_pose_bwd(int n_poses, const double* save, int do_svd, float t_scale, const float* g_out, float* g_pose, void* stream) {
+    if (n_poses <= 0 || !g_out || !g_pose || (do_svd && !save)) return NEFES_E_BADARG;
+    hipLaunchKernelGGL(svd_reg_bwd_kernel<true>, dim3((unsigned)((n_poses + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n_poses, save, g_out, g_pose,
+                       do_svd, t_scale);
     return (int)hipGetLastError();
 }
 

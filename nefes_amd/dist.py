@@ -18,6 +18,11 @@ def row_shard(H: int, rank: int, world: int):
     return row0, nrows
 
 
+# Diagnostics of the one collective (bench.py sets this to a list for its timed region): per all-reduce a pair of events recorded on
+# the current stream around the call (device time the stream spends in / waiting for the collective) and the host time of the call.
+ALLREDUCE_TIMES = None
+
+
 class _PoseGradAllReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, c2w, group):
@@ -28,7 +33,18 @@ class _PoseGradAllReduce(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous().clone()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(ctx.group) > 1:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)      # the single collective: 12 floats
+            rec = ALLREDUCE_TIMES
+            if rec is not None and g.is_cuda:
+                import time
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                t0 = time.perf_counter()
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+                host = time.perf_counter() - t0
+                e1.record()
+                rec.append((e0, e1, host))
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)      # the single collective: 12 floats
         return g, None
 
 

@@ -67,6 +67,11 @@ class FusionNet(nn.Module):
 
     HIP_BATCHNORM = os.environ.get("NEFES_HIP_BATCHNORM", "1") != "0"   # the refinement loop's case (train mode, frozen affine parameters, GPU): csrc/refine.hip bn_train_* instead of MIOpen
 
+    # False: train-mode BatchNorm calls leave the module's running statistics and batch counter alone (its outputs never depend on
+    # them; the reference's loop never reads them either: the net is never .eval()ed).  PoseRefiner(bn_running_stats=False) sets it
+    # around its own calls: refiners on different streams share this module, and the update is a read-modify-write of its buffers.
+    track_bn_stats = True
+
     def _bn(self, y, per_image_norm):
         """The last layer on the convolutions' output y [B,C,H,W]."""
         from . import ops
@@ -74,9 +79,11 @@ class FusionNet(nn.Module):
         per_image = bool(per_image_norm and y.shape[0] > 1 and bn.training)
         if (self.HIP_BATCHNORM and self.HIP_CONVS and y.is_cuda and y.dtype == torch.float32 and bn.training and bn.momentum is not None
                 and not any(p is not None and p.requires_grad for p in (bn.weight, bn.bias))):
-            return ops.batch_norm_train_frozen(y, bn, per_image)
+            return ops.batch_norm_train_frozen(y, bn, per_image, track_stats=self.track_bn_stats)
         if per_image:
             return nn.functional.instance_norm(y, weight=bn.weight, bias=bn.bias, eps=bn.eps)
+        if bn.training and not self.track_bn_stats:
+            return nn.functional.batch_norm(y, None, None, bn.weight, bn.bias, True, 0.0, bn.eps)
         return bn(y)
 
     def _conv0_on_gmap(self, w_f, b_f):

@@ -59,9 +59,12 @@ SIGNATURES = {
     "nefes_bn_train_bwd": (_i, [_i, _i, C.c_int64, _i, _p, _p, _p, _p, _p, _p]),
     "nefes_svd_reg_fwd": (_i, [_i, _p, _p, _p, _p]),
     "nefes_svd_reg_bwd": (_i, [_i, _p, _p, _p, _p]),
+    "nefes_regressed_pose_fwd": (_i, [_i, _p, _i, _f, _f, _f, _f, _p, _p, _p]),
+    "nefes_regressed_pose_bwd": (_i, [_i, _p, _i, _f, _p, _p, _p]),
     "nefes_upcos_prepare": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "nefes_upcos_gram_fwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "nefes_upcos_gram_bwd": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "nefes_upcos_gram_lds_bytes": (_sz, [_i, _i, _i]),
     "nefes_adam_step": (_i, [_i, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]),
     "nefes_pack_weights": (_i, [_desc, C.POINTER(_p), _i, _p, _sz]),
     "nefes_pack_map": (_i, [_desc, _p, _sz, _p]),

@@ -1096,7 +1096,7 @@ class BatchNormTrainFrozen(torch.autograd.Function):
     one-image-at-a-time loop computes; running statistics untouched).  csrc/refine.hip bn_train_*: float64 sums, gradient to x only."""
 
     @staticmethod
-    def forward(ctx, x, bn, per_image):
+    def forward(ctx, x, bn, per_image, track_stats=True):
         xf = _f32(x)
         B, Cc = xf.shape[0], xf.shape[1]
         P = xf.numel() // (B * Cc)
@@ -1105,7 +1105,7 @@ class BatchNormTrainFrozen(torch.autograd.Function):
         save = torch.empty(groups * Cc * 2, dtype=torch.float64, device=xf.device)
         w = None if bn.weight is None else _f32(bn.weight)
         b = None if bn.bias is None else _f32(bn.bias)
-        track = (not per_image) and bn.track_running_stats and bn.running_mean is not None
+        track = bool(track_stats) and (not per_image) and bn.track_running_stats and bn.running_mean is not None
         momentum = 0.1
         if track:
             if bn.momentum is None:
@@ -1127,14 +1127,17 @@ class BatchNormTrainFrozen(torch.autograd.Function):
         g_x = torch.empty_like(xf)
         L.check(L.load().nefes_bn_train_bwd(B, Cc, xf.numel() // (B * Cc), 1 if ctx.per_image else 0, _chk(xf, "x"), _chk(ctx.w, "weight"),
                                             _chk(save, "save", torch.float64), _chk(gf, "g_y"), _chk(g_x, "g_x"), _stream()), "nefes_bn_train_bwd")
-        return g_x, None, None
+        return g_x, None, None, None
 
 
-def batch_norm_train_frozen(x, bn, per_image=False):
-    """bn(x) for a torch.nn.BatchNorm2d in train mode whose weight and bias carry no gradient (see BatchNormTrainFrozen)."""
+def batch_norm_train_frozen(x, bn, per_image=False, track_stats=True):
+    """bn(x) for a torch.nn.BatchNorm2d in train mode whose weight and bias carry no gradient (see BatchNormTrainFrozen).
+    track_stats=False: the module's running statistics and batch counter are left alone (the outputs do not depend on them in train
+    mode): what a caller passes whose launches run on several streams at once over ONE shared module -- the update is a plain
+    read-modify-write of the module's buffers (nefes_amd.refine.refine_concurrently)."""
     if not bn.training or any(p is not None and p.requires_grad for p in (bn.weight, bn.bias)):
         raise ValueError("nefes_amd: batch_norm_train_frozen is for a BatchNorm in train mode with frozen affine parameters")
-    return BatchNormTrainFrozen.apply(x, bn, bool(per_image))
+    return BatchNormTrainFrozen.apply(x, bn, bool(per_image), bool(track_stats))
 
 
 class SvdReg(torch.autograd.Function):
@@ -1165,6 +1168,43 @@ class SvdReg(torch.autograd.Function):
 def svd_reg(pose):
     """[..., 3, 4] poses with the 3x3 block replaced by its nearest orthogonal matrix U V^T (include/nefes_hip.h nefes_svd_reg_fwd)."""
     return SvdReg.apply(pose)
+
+
+class RegressedPose(torch.autograd.Function):
+    """svd_reg (optional) + fix_coord_supp on [..., 3, 4] regressed poses, one launch each way (include/nefes_hip.h
+    nefes_regressed_pose_fwd): what train_on_batch does to the regression network's output before it renders (DFM_APR_refine.py:91-97)."""
+
+    @staticmethod
+    def forward(ctx, pose, do_svd, t_scale, move):
+        pf = _f32(pose).reshape(-1, 3, 4)
+        n = pf.shape[0]
+        out = torch.empty_like(pf)
+        save = torch.empty(n, 21, dtype=torch.float64, device=pf.device) if do_svd else None
+        L.check(L.load().nefes_regressed_pose_fwd(n, _chk(pf, "pose"), 1 if do_svd else 0, float(t_scale), float(move[0]), float(move[1]), float(move[2]),
+                                                  _chk(out, "out"), _chk(save, "save", torch.float64), _stream()), "nefes_regressed_pose_fwd")
+        if do_svd:
+            ctx.save_for_backward(save)
+        ctx.shape, ctx.do_svd, ctx.t_scale = pose.shape, bool(do_svd), float(t_scale)
+        return out.reshape(pose.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        save = ctx.saved_tensors[0] if ctx.do_svd else None
+        gf = _f32(g).reshape(-1, 3, 4)
+        g_pose = torch.empty_like(gf)
+        L.check(L.load().nefes_regressed_pose_bwd(gf.shape[0], _chk(save, "save", torch.float64), 1 if ctx.do_svd else 0, ctx.t_scale,
+                                                  _chk(gf, "g_out"), _chk(g_pose, "g_pose"), _stream()), "nefes_regressed_pose_bwd")
+        return g_pose.reshape(ctx.shape), None, None, None
+
+
+def regressed_pose(pose, do_svd, world_setup=None):
+    """[..., 3, 4] regressed poses -> svd_reg (if do_svd) -> fix_coord_supp(world_setup) (identity translation map when None)."""
+    if world_setup is None:
+        sc, mv = 1.0, (0., 0., 0.)
+    else:
+        s1, s2 = float(world_setup["pose_scale"]), float(world_setup["pose_scale2"])
+        sc, mv = s1 * s2, tuple(float(v) * s2 for v in world_setup["move_all_cam_vec"])
+    return RegressedPose.apply(pose, bool(do_svd), sc, mv)
 
 
 class CosineFeatureLoss(torch.autograd.Function):
@@ -1302,6 +1342,9 @@ def bicubic_gram(n_in, n_out, o0, n_win, device):
     return t
 
 
+UPCOS_GRAM_LDS_MAX = 96 * 1024          # csrc/refine.hip NEFES_UPCOS_GRAM_LDS_MAX
+
+
 class UpcosTarget:
     """What upsampled_cosine_loss needs of a FIXED target [C, OH-2crop, OW-2crop] (the refinement loop's: one target for all
     iterations of an image): Tt = Uy^T target Ux [C,h,w], |target|^2 per channel, and the Gram matrices of the two axes.  `update(target)`
@@ -1317,6 +1360,9 @@ class UpcosTarget:
         self.band = max(bx, by)
         self.tx, self.ty = bicubic_gather_tables(self.h, self.w, self.OH, self.OW, self.crop, device)
         self.device = device
+        # one workgroup of the Gram-form forward holds a band of rows in LDS: geometries beyond its ceiling (h ~ 240 with w ~ 427, or
+        # a wide band from a non-integer scale) stay on the one-pass kernels -- decided HERE, not by an error in the middle of a loop
+        self.fits = int(L.load().nefes_upcos_gram_lds_bytes(self.h, self.w, self.band)) <= UPCOS_GRAM_LDS_MAX
 
     def update(self, target):
         CH, CW = self.OH - 2 * self.crop, self.OW - 2 * self.crop

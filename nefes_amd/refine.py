@@ -115,8 +115,13 @@ class PoseRefiner:
 
     def __init__(self, render_kwargs, args, hwf, near, far, tinyscale=4, lr_r=0.01, lr_t=0.1, lietorch=False,
                  upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda", adam_capturable=None,
-                 fused_glue=True, images=1, pose_model=None, svd_reg=False, learning_rate=1e-5):
+                 fused_glue=True, images=1, pose_model=None, svd_reg=False, learning_rate=1e-5, bn_running_stats=True):
         self.kw, self.args = dict(render_kwargs), args
+        # False: FusionNet's train-mode BatchNorm leaves its running statistics and batch counter alone in this refiner's iterations
+        # (nothing in the loop reads them; the reference never puts the net in eval mode).  REQUIRED for refiners that share a
+        # FusionNet and run at the same time (refine_concurrently): the update is a read-modify-write of the shared module's buffers.
+        self.bn_running_stats = bool(bn_running_stats)
+        self.use_graph, self.fused_glue = bool(graph), bool(fused_glue)        # (read by _apr_adam below)
         H, W, focal = hwf
         self.H, self.W = int(H), int(W)
         self.h, self.w, self.focal = int(H // tinyscale), int(W // tinyscale), float(focal) / tinyscale
@@ -142,7 +147,7 @@ class PoseRefiner:
             self.apr_base, self.svd_reg = pose_model, bool(svd_reg)
             self.apr = copy.deepcopy(pose_model).to(self.dev).train()           # DFM_post_processing :209 (`pp_model`)
             self.photo = torch.zeros(1, 3, self.H, self.W, device=self.dev)
-            self.apr_opt = torch.optim.Adam(self.apr.parameters(), lr=learning_rate)
+            self.apr_opt = self._apr_adam(learning_rate)
             self._rgb = self._x_rgb = None
         self.model = LearnPose(self.B, True, True, init_c2w=torch.eye(4)[None].repeat(self.B, 1, 1), lietorch=lietorch).to(self.dev)
         # fused_glue: the pose chain, the crop and the feature loss as library kernels (ops.pose_compose, the windowed
@@ -171,10 +176,13 @@ class PoseRefiner:
         B = self.B
         if self.apr is not None:                           # train_on_batch :91-97
             c2w = self.apr(self.photo).reshape(1, 3, 4)
-            if self.svd_reg:
-                c2w = svd_reg(c2w)
-            if self.world_setup is not None:
-                c2w = fix_coord_supp(c2w, self.world_setup)
+            if self.fused_glue and HIP_SVD_REG and c2w.is_cuda and c2w.dtype == torch.float32:
+                c2w = ops.regressed_pose(c2w, self.svd_reg, self.world_setup)          # svd_reg + fix_coord_supp: one launch each way
+            else:
+                if self.svd_reg:
+                    c2w = svd_reg(c2w)
+                if self.world_setup is not None:
+                    c2w = fix_coord_supp(c2w, self.world_setup)
         elif self.fused_glue and not self.model.lietorch:
             ws = self.world_setup or {"pose_scale": 1.0, "pose_scale2": 1.0, "move_all_cam_vec": (0., 0., 0.)}
             into = (self.model.r.grad, self.model.t.grad) if isinstance(self.opt, ops.FusedAdam) else None
@@ -186,6 +194,7 @@ class PoseRefiner:
                 c2w = fix_coord_supp(c2w, self.world_setup)
         enc = bool(getattr(self.args, "encode_hist", False))
         fnet = self.coarse.fusion_net
+        fnet.track_bn_stats = self.bn_running_stats        # (read at call time by FusionNet._bn: eager calls and graph capture alike)
         fused_input = self.fused_glue and (not enc or self._affine is not None) and fnet._use_hip(self.hist)
         kw = self.kw
         if fused_input and self.GMAP_CONV0 and not fnet.fusion_residule and kw.get("network_fine", None) is not None:
@@ -219,7 +228,7 @@ class PoseRefiner:
             _, _, fused = self.coarse.run_fusion_net(rgb, feat, self.h, self.w, B, per_image_norm=B > 1)
         if self.upsample and self.fused_glue and not self.per_pixel and self.FUSED_UPSAMPLED_LOSS:
             # up-sampling, crop and feature loss in one pass each way: the 34 MB up-sampled image is never written (ops.upsampled_cosine_loss)
-            if self.PREPARED_TARGET:
+            if self._uses_prepared_target():
                 mean_loss, cos = ops.upsampled_cosine_loss_prepared(fused.reshape(B * self.C, self.h, self.w), self._sync_upcos(), return_cos=True)
             else:
                 mean_loss, cos = ops.upsampled_cosine_loss(fused.reshape(B * self.C, self.h, self.w),
@@ -262,7 +271,17 @@ class PoseRefiner:
         return self._upcos
 
     def _uses_prepared_target(self):
-        return bool(self.upsample and self.fused_glue and not self.per_pixel and self.FUSED_UPSAMPLED_LOSS and self.PREPARED_TARGET)
+        """The Gram-form loss against the prepared target -- where the loop takes the fused up-sampled loss at all AND the geometry fits
+        the Gram kernel's LDS (ops.UpcosTarget.fits, known once the buffers exist); otherwise the one-pass kernels, which read
+        self.target itself on every iteration."""
+        if not (self.upsample and self.fused_glue and not self.per_pixel and self.FUSED_UPSAMPLED_LOSS and self.PREPARED_TARGET):
+            return False
+        if getattr(self, "_upcos", None) is None or self._upcos_shape != tuple(self.target.shape):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("nefes_amd: the refinement target changed without PoseRefiner._sync_upcos() before graph capture")
+            self._upcos = ops.UpcosTarget(self.B * self.C, self.h, self.w, self.H, self.W, 10, self.dev)
+            self._upcos_shape, self._upcos_key = tuple(self.target.shape), None
+        return bool(self._upcos.fits)
 
     def loss_and_grad(self):
         """Loss at the current (r, t) and its gradient, written into the parameters' static .grad buffers (no optimizer step).
@@ -325,6 +344,15 @@ class PoseRefiner:
             self._iteration()
         self.graph = g
 
+    def replay(self, apr=False):
+        """One iteration as the captured graph -- after a HOST check that what the graph reads in place is current: the prepared form of
+        self.target (ops.UpcosTarget) is refreshed when the target buffer was written since (its tensor version moved).  Code that
+        writes refiner.target itself and replays refiner.graph directly optimises against the OLD target without any error (the
+        one-pass kernels read self.target on every iteration; the prepared form cannot); this is the call to use instead."""
+        if self._uses_prepared_target():
+            self._sync_upcos()
+        (self.apr_graph if apr else self.graph).replay()
+
     def refine(self, init_c2w, feature_target, hist, iters=50):
         """One image (images=1): (refined 4x4 c2w, losses [iters]).  A batch (images=B): init_c2w [B,4,4], feature_target
         [B,C,h,w], hist [B,10] -> (refined poses [B,4,4], losses [iters,B]), each image as if refined alone."""
@@ -336,7 +364,7 @@ class PoseRefiner:
         losses = torch.empty((iters,) + tuple(self.loss.shape), device=self.dev)
         for i in range(iters):
             if self.use_graph:
-                self.graph.replay()
+                self.replay()
             else:
                 self._iteration()
             losses[i] = self.loss
@@ -404,11 +432,20 @@ class PoseRefiner:
         self.apr_loss_and_grad()
         self.apr_opt.step()
 
+    def _apr_adam(self, lr):
+        """torch.optim.Adam over the regression network's parameters (DFM_APR_refine.py:212).  On the GPU its multi-tensor form
+        (`fused=True`: ONE launch for all parameters + one for the step counters; same update, same rounding order per element) instead
+        of the default for-each form's ten element-wise launches per step -- the network is the caller's, so is the number of its
+        parameter tensors (DFNet: ~100)."""
+        params = list(self.apr.parameters())
+        on_gpu = all(p.is_cuda for p in params)
+        return torch.optim.Adam(params, lr=lr, capturable=bool(self.use_graph) and on_gpu, fused=True if (on_gpu and self.fused_glue) else None)
+
     def _apr_fresh_adam(self):
         """torch.optim.Adam(pp_model.parameters(), lr) per image (:212).  Under a graph the optimizer object is the captured one and its
         state is zeroed in place instead -- the same thing to Adam (step 0, zero moments)."""
         if self.apr_graph is None:
-            self.apr_opt = torch.optim.Adam(self.apr.parameters(), lr=self.apr_opt.param_groups[0]["lr"], capturable=self.use_graph)
+            self.apr_opt = self._apr_adam(self.apr_opt.param_groups[0]["lr"])
             return
         with torch.no_grad():
             for st in self.apr_opt.state.values():
@@ -454,7 +491,7 @@ class PoseRefiner:
         checks = []
         for i in range(iters):
             if self.apr_graph is not None:
-                self.apr_graph.replay()
+                self.replay(apr=True)
             else:
                 self._apr_iteration()
             losses[i] = self.loss
@@ -470,6 +507,30 @@ class PoseRefiner:
         return pose.detach().clone(), losses, info
 
 
+def _check_concurrent(refiners):
+    """What refine_concurrently's guarantees rest on, checked instead of assumed.
+    (1) No shared mutable state between streams: refiners that share a FusionNet must not update its BatchNorm's running statistics
+        (a read-modify-write of the module's buffers from several streams: lost counter increments, non-deterministic statistics).
+    (2) Every kernel of an iteration is this library's: the bit-identity of concurrent and solo trajectories holds for kernels built
+        without the packed-fp32 op_sel:[0,1] forms; MIOpen / ATen kernels next to another stream's MFMA kernels are
+        exposed to it.  A refiner on the torch glue, torch convolutions / BatchNorm or torch.optim.Adam is refused here."""
+    shared = {}
+    for r in refiners:
+        fnet = r.coarse.fusion_net
+        bn_tracks = (not fnet.no_BN) and r.B == 1 and fnet.net[-1].training and fnet.net[-1].track_running_stats
+        other = shared.setdefault(id(fnet), r)
+        if other is not r and bn_tracks and (r.bn_running_stats or other.bn_running_stats):
+            raise ValueError("nefes_amd: refine_concurrently: these refiners share one FusionNet whose BatchNorm would update its running "
+                             "statistics from several streams at once; construct them with PoseRefiner(..., bn_running_stats=False)")
+        in_house = (r.fused_glue and isinstance(r.opt, ops.FusedAdam) and fnet.HIP_CONVS and (fnet.no_BN or fnet.HIP_BATCHNORM)
+                    and fnet._use_hip(r.hist))
+        if not in_house:
+            raise ValueError("nefes_amd: refine_concurrently needs every refiner on the library's own kernels (fused_glue=True, "
+                             "lietorch=False, FusionNet.HIP_CONVS / HIP_BATCHNORM, frozen FusionNet on the GPU): torch's kernels next to "
+                             "another stream's field kernels are exposed to the packed-fp32 finding of DESIGN.md 4.7; run such "
+                             "refiners one after the other (PoseRefiner.refine)")
+
+
 def refine_concurrently(refiners, jobs, iters=50):
     """K query images refined AT THE SAME TIME: one PoseRefiner (its own static buffers and captured graph; the frozen networks can be
     shared) and one HIP stream per image, replays issued round-robin.  An iteration is ~1.45 ms of field kernels, which hold the whole
@@ -478,7 +539,9 @@ def refine_concurrently(refiners, jobs, iters=50):
     free (two images: -8 % per image; tools/two_streams.py).  Every image walks exactly the trajectory it walks alone -- bit for bit
     (tests/test_gpu_streams.py; that test is also what found the packed-fp32 op_sel instruction of DESIGN.md 4.7).
     jobs = [(init_c2w, feature_target, hist), ...] as PoseRefiner.refine takes them -> [(refined c2w, losses [iters]), ...] in job order.
-    More jobs than refiners: rounds of len(refiners) images (the last one smaller)."""
+    More jobs than refiners: rounds of len(refiners) images (the last one smaller).
+    Refiners that share a FusionNet are constructed with bn_running_stats=False, and every refiner runs on the library's own kernels
+    (_check_concurrent refuses anything else: see there)."""
     if not refiners or not jobs:
         raise ValueError("nefes_amd: refine_concurrently needs at least one PoseRefiner and one job")
     if len({id(r) for r in refiners}) != len(refiners):
@@ -491,6 +554,7 @@ def refine_concurrently(refiners, jobs, iters=50):
         return out
     refiners = refiners[:len(jobs)]
     dev = refiners[0].dev
+    _check_concurrent(refiners)
     jobs = [tuple(t.to(dev) for t in job) for job in jobs]
     for r, job in zip(refiners, jobs):
         if r.use_graph and r.graph is None:
@@ -508,7 +572,7 @@ def refine_concurrently(refiners, jobs, iters=50):
         for r, l in zip(refiners, losses):
             with torch.cuda.stream(r._own_stream):
                 if r.use_graph:
-                    r.graph.replay()
+                    r.replay()
                 else:
                     r._iteration()
                 l[i] = r.loss

@@ -1,11 +1,11 @@
 """The numerical side of tools/hazard_lint.py (tests/test_hazard_lint.py is the mechanical one, on the CPU).
 
 1. Backward-to-inputs of every fp16 instance family, ONE upstream channel at a time: each of the six sigma / transient channels
-   (sigma_s, rgb_t x 3, sigma_t, beta) alone, the colour channels alone, the feature channels alone.  Round 5 found a build whose
-   transient channels' gradient was 10-25 % off with everything else exact (then "not understood"); the owner
-    is a read of the transient heads' fp32 product behind too few wait states, which the shipped schedule survived only
-   because its last k-step carries d loss / d beta and a padding row -- zero in every test-time loss.  A per-channel test with beta
-   among the channels is the one that sees such a read (tools/check_fh.py was the by-hand version of this).
+   (sigma_s, rgb_t x 3, sigma_t, beta) alone, the colour channels alone, the feature channels alone.  Round 5 had a build whose transient
+   channels' gradient was 10-25 % off with everything else exact; tools/check_fh.py was the by-hand version of this
+   test.  The linter's suspect -- the transient heads' fp32 product read a few wait states behind its last MFMA, whose last k-step is
+   beta's -- is what the beta-only case would expose; on MI355X it turned out to be interlocked, and the test stays as
+   the net under the next schedule change.
 2. The packed-fp32 finding of round 5 (`v_pk_mul_f32 / v_pk_add_f32 op_sel:[0,1]` wrong on lanes 48-63 next to another
    queue's 16-bit K = 16 MFMA kernel) RECORDED on whatever box runs this: the counts go to the parity log and into a warning, so
    that the driver's own run carries them.  Asserted: nothing wrong alone on the device, nothing wrong in the op_sel:[1,0] forms."""

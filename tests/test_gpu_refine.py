@@ -170,6 +170,35 @@ def test_svd_reg_kernels_match_float64_svd():
     assert one.shape == (3, 4) and torch.equal(one, rh.detach()[0])
 
 
+@pytest.mark.parametrize("do_svd", [True, False])
+def test_regressed_pose_kernels_equal_svd_reg_then_fix_coord_supp(do_svd):
+    """ops.regressed_pose (nefes_regressed_pose_fwd/bwd: what train_on_batch does to the regression network's output before it renders,
+    DFM_APR_refine.py:91-97, one launch each way) == ops.svd_reg followed by refine.fix_coord_supp's torch expression: the rotation block
+    bit for bit (same kernel body), the translation bit for bit (one fp32 multiply and one add, in that order), gradients to rounding."""
+    from nefes_amd import ops
+    from nefes_amd.refine import fix_coord_supp
+    g = torch.Generator().manual_seed(21)
+    q, _ = torch.linalg.qr(torch.randn(5, 3, 3, generator=g, dtype=torch.float64))
+    pose = torch.cat([q + 1e-3 * torch.randn(5, 3, 3, generator=g, dtype=torch.float64), torch.randn(5, 3, 1, generator=g, dtype=torch.float64)], -1).float()
+    G = torch.randn(pose.shape, generator=g).to(DEV)
+    ws = dict(pose_scale=0.3027, pose_scale2=0.83, move_all_cam_vec=[0.11, -0.23, 0.07])
+    a = pose.to(DEV).requires_grad_()
+    ra = ops.regressed_pose(a, do_svd, ws)
+    (ra * G).sum().backward()
+    b = pose.to(DEV).requires_grad_()
+    rb = fix_coord_supp(ops.svd_reg(b) if do_svd else b, ws)
+    (rb * G).sum().backward()
+    assert torch.equal(ra.detach(), rb.detach())
+    e = rel(a.grad.cpu().numpy(), b.grad.cpu().numpy())
+    assert e < 2e-7, e
+    # no world set-up: svd_reg alone
+    c = pose.to(DEV).requires_grad_()
+    rc = ops.regressed_pose(c, do_svd, None)
+    assert torch.equal(rc.detach(), (ops.svd_reg(pose.to(DEV)) if do_svd else pose.to(DEV)))
+    one = ops.regressed_pose(pose[0].to(DEV), do_svd, ws)
+    assert one.shape == (3, 4) and torch.equal(one, ra.detach()[0])
+
+
 @pytest.mark.parametrize("C,P", [(128, 220 * 300), (16, 12 * 16), (3, 1000)])
 def test_cosine_feature_loss_matches_torch(C, P):
     """nefes_cosine_loss_fwd/bwd == feature_loss (DFM_pose_refine.py:211-233) in float64 torch, value and gradient; one channel is

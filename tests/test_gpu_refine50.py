@@ -63,9 +63,9 @@ def nets(g):
     return coarse.requires_grad_(False).to(DEV), fine.requires_grad_(False).to(DEV)
 
 
-def refiner(g, graph=False, apr=None):
+def refiner(g, graph=False, apr=None, networks=None, **more):
     from nefes_amd.refine import PoseRefiner
-    coarse, fine = nets(g)
+    coarse, fine = networks if networks is not None else nets(g)
     args = types.SimpleNamespace(nerfh_nff=True, use_fine_only=False, NeRFW=True, transient_at_test=True, encode_hist=True)
     kw = dict(network_query_fn=None, perturb=0., N_importance=int(g["Ni"]), N_samples=int(g["Nc"]), network_fn=coarse,
               network_fine=fine, use_viewdirs=True, white_bkgd=False, raw_noise_std=0., test_time=True, args=args, ndc=False,
@@ -74,7 +74,7 @@ def refiner(g, graph=False, apr=None):
     H, W, focal = g["hwf"].tolist()
     extra = {} if apr is None else dict(pose_model=apr, svd_reg=True, learning_rate=float(g["m2_lr"]))
     return PoseRefiner(kw, args, (H, W, focal), float(g["near"]), float(g["far"]), tinyscale=int(g["tinyscale"]),
-                       lr_r=float(g["lr"][0]), lr_t=float(g["lr"][1]), world_setup=world, graph=graph, device=DEV, **extra)
+                       lr_r=float(g["lr"][0]), lr_t=float(g["lr"][1]), world_setup=world, graph=graph, device=DEV, **extra, **more)
 
 
 def target_full(g):

@@ -7,7 +7,7 @@ tools/store_hazard.py, tests/test_pack_stream.py)."""
 import pytest
 import torch
 
-from tests.test_gpu_refine50 import T, refiner
+from tests.test_gpu_refine50 import T, nets, refiner
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -81,6 +81,40 @@ def test_two_images_on_two_streams_walk_their_solo_trajectories(golden):
     three = refine_concurrently(refs, [jobs[1], jobs[0], jobs[1]], iters=n)
     for (p, l), k in zip(three, (1, 0, 1)):
         assert torch.equal(p, solo[k][0]) and torch.equal(l, solo[k][1])
+
+
+def test_refiners_that_share_a_fusion_net_do_not_touch_its_running_statistics(golden):
+    """FusionNet's train-mode BatchNorm updates running_mean / running_var / num_batches_tracked with plain
+    read-modify-writes; refiners that share the frozen networks would do that from several streams at once.  Such refiners are built
+    with bn_running_stats=False (the outputs never depend on those buffers) and refine_concurrently refuses the other kind.  A solo
+    refiner keeps the module's behaviour: the counter advances once per iteration it ran."""
+    from nefes_amd.refine import refine_concurrently
+    g = golden("refine50")
+    shared = nets(g)
+    bn = shared[0].fusion_net.net[-1]
+    jobs = [(T(g["init_c2w"][k]), T(g["target_low"]), T(g["hist"])) for k in (0, 3)]
+    n = 8
+    tracking = [refiner(g, graph=True, networks=shared), refiner(g, graph=True, networks=shared)]
+    with pytest.raises(ValueError, match="bn_running_stats=False"):
+        refine_concurrently(tracking, jobs, iters=1)
+    c0 = int(bn.num_batches_tracked)
+    solo_pose, solo_loss = tracking[0].refine(*jobs[0], iters=n)
+    torch.cuda.synchronize()
+    ran = int(bn.num_batches_tracked) - c0
+    assert ran >= n                                                   # (n iterations + whatever the first call's warm-up / capture ran)
+    c1 = int(bn.num_batches_tracked)
+    tracking[0].refine(*jobs[0], iters=n)
+    torch.cuda.synchronize()
+    assert int(bn.num_batches_tracked) - c1 == n                      # a captured graph replayed n times: exactly n updates
+    quiet = [refiner(g, graph=True, networks=shared, bn_running_stats=False) for _ in range(2)]
+    before = (int(bn.num_batches_tracked), bn.running_mean.clone(), bn.running_var.clone())
+    outs = refine_concurrently(quiet, jobs, iters=n)
+    torch.cuda.synchronize()
+    assert int(bn.num_batches_tracked) == before[0] and torch.equal(bn.running_mean, before[1]) and torch.equal(bn.running_var, before[2])
+    assert torch.equal(outs[0][0], solo_pose) and torch.equal(outs[0][1], solo_loss)      # same trajectory with or without the bookkeeping
+    # a refiner on torch's glue is refused too (its kernels next to another stream's field kernels: DESIGN.md 4.7)
+    with pytest.raises(ValueError, match="library's own kernels"):
+        refine_concurrently([quiet[0], refiner(g, graph=False, networks=shared, bn_running_stats=False, fused_glue=False)], jobs, iters=1)
 
 
 @pytest.mark.parametrize("case", ["headline", "hashgrid", "train"])

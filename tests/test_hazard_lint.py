@@ -7,9 +7,10 @@ itself on hand-written sequences (each rule red when violated, green when padded
 paths); then the shipped library: no violation in any kernel but the probe that exists to violate one.
 
 What it found in round 5's library (profiles/r06/hazard_lint_r05_library.txt): the transient heads' fp32
-product read 2-6 wait states after its last k-step (18 required) in every backward instance whose functors read accumulators through asm
--- the owner of DESIGN 4.9's "not understood" 10-25 % error --, 29 000 VCC round trips inside one asm statement, compiler-made reads on
-the short side of a branch, a dead VGPR tile overwritten one wait state behind the MFMA still writing it."""
+product read 2-6 wait states after its last k-step (18 by the table) in every backward instance whose functors read accumulators through
+asm, 29 000 VCC round trips inside one asm statement, compiler-made reads on the short side of a branch, a dead VGPR tile overwritten
+one wait state behind the MFMA still writing it.  The hardware turned out to interlock the first kind (tools/fh_variant.sh: right
+numbers with two wait states); the rules are the ones hipcc applies to its own code, and the library now meets them everywhere."""
 import os
 import sys
 
