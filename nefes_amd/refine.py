@@ -112,6 +112,9 @@ class PoseRefiner:
     # applied per ray at all: render() hands over its input (65 channels) and FusionNet's first convolution runs on weights composed with
     # the head's (FusionNet.forward_prepared_gmap) -- the only consumer of the rendered features in this loop is that linear layer.
     GMAP_CONV0 = os.environ.get("NEFES_GMAP_CONV0", "1") != "0"
+    # Mode 2: svd_reg + fix_coord_supp behind the regression network as one launch each way (ops.regressed_pose).  False: ops.svd_reg
+    # followed by fix_coord_supp's torch expression (the tests compare the two and tap the pose in between).
+    FUSED_REGRESSED_POSE = True
 
     def __init__(self, render_kwargs, args, hwf, near, far, tinyscale=4, lr_r=0.01, lr_t=0.1, lietorch=False,
                  upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda", adam_capturable=None,
@@ -176,7 +179,7 @@ class PoseRefiner:
         B = self.B
         if self.apr is not None:                           # train_on_batch :91-97
             c2w = self.apr(self.photo).reshape(1, 3, 4)
-            if self.fused_glue and HIP_SVD_REG and c2w.is_cuda and c2w.dtype == torch.float32:
+            if self.fused_glue and self.FUSED_REGRESSED_POSE and HIP_SVD_REG and c2w.is_cuda and c2w.dtype == torch.float32:
                 c2w = ops.regressed_pose(c2w, self.svd_reg, self.world_setup)          # svd_reg + fix_coord_supp: one launch each way
             else:
                 if self.svd_reg:

@@ -213,7 +213,7 @@ def test_mode2_iterations_match_reference_along_its_trajectory(golden, k):
     assert worst_abs < 1e-3 and worst_l < 1e-3, (worst_abs, worst_g, worst_l)
 
 
-STAGES = ["default", "field_fp32_mfma", "torch_convs", "separate_upsample_and_loss", "one_pass_upsampled_loss", "svd_torch", "feature_head_per_ray", "torch_batchnorm", "torch_glue", "svd_on_host", "svd_float64", "torch_upsample_and_loss",
+STAGES = ["default", "pose_chain_unfused", "field_fp32_mfma", "torch_convs", "separate_upsample_and_loss", "one_pass_upsampled_loss", "svd_torch", "feature_head_per_ray", "torch_batchnorm", "torch_glue", "svd_on_host", "svd_float64", "torch_upsample_and_loss",
           "torch_upsample_and_loss_float64", "fusion_net_float64", "render_maps_to_float64_tail",
           # pairs (VERDICT r4 "weak" 1: single-stage swaps cannot see an error two stages share)
           "svd_float64+field_fp32_mfma", "svd_float64+render_maps_to_float64_tail"]
@@ -241,6 +241,9 @@ def test_loop_gradient_error_by_stage(golden, variant, monkeypatch):
             u, _, v = torch.svd(pose[..., :3, :3].double())
             return torch.cat([(u @ v.transpose(-2, -1)).to(pose.dtype), pose[..., :3, 3:]], -1)
         monkeypatch.setattr(NRF0, "svd_reg", svd_reg_f64)
+        monkeypatch.setattr(PoseRefiner, "FUSED_REGRESSED_POSE", False)       # (the fused kernel pair would bypass the patched function)
+    if variant == "pose_chain_unfused":               # ops.svd_reg + fix_coord_supp's torch expression (round 6: one kernel pair, ops.regressed_pose)
+        monkeypatch.setattr(PoseRefiner, "FUSED_REGRESSED_POSE", False)
     if variant == "field_fp32_mfma":
         monkeypatch.setattr(ops, "SPLIT", "f32")
     if variant == "torch_convs":
@@ -267,6 +270,7 @@ def test_loop_gradient_error_by_stage(golden, variant, monkeypatch):
             u, _, v = torch.svd(m)
             return torch.cat([(u @ v.transpose(-2, -1)).to(pose.device, pose.dtype), pose[..., :3, 3:]], -1)
         monkeypatch.setattr(NRF, "svd_reg", svd_reg_alt)
+        monkeypatch.setattr(PoseRefiner, "FUSED_REGRESSED_POSE", False)
     if variant.startswith("torch_upsample_and_loss"):
         # bicubic up-sampling, crop and cosine loss through torch's own operators on the device (fp32, or float64 in between)
         import nefes_amd.refine as NRF
@@ -390,6 +394,7 @@ def test_mode2_gradient_excess_has_an_owner(golden, k, i, monkeypatch):
         seen["pose"] = out
         return out
     monkeypatch.setattr(NRF, "svd_reg", svd_tap)
+    monkeypatch.setattr(NRF.PoseRefiner, "FUSED_REGRESSED_POSE", False)    # (the pose between svd_reg and fix_coord_supp is what is tapped)
     with B.tapped() as tap:
         loss, _ = ref._loss()
     loss.backward()
