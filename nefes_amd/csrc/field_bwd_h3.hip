@@ -89,8 +89,10 @@ struct StoringSplitH {
     __device__ __forceinline__ void stage_a(PairRegs& s, int q, int pp) const {
         in.stage_a(s, q, pp);
         const int e = 8 * q + 2 * pp;
+#ifndef NEFES_TRAIN_NO_STORES      /* (ablation builds: what the stores cost, tools/ab_side.sh) */
         __builtin_nontemporal_store(s.x0 * inv, &p[(e >> 4) * 4096 + nefes_rho(0, e & 15) * 16]);      // layout.h nefes_train_off
         __builtin_nontemporal_store(s.x1 * inv, &p[((e + 1) >> 4) * 4096 + nefes_rho(0, (e + 1) & 15) * 16]);
+#endif
     }
     __device__ __forceinline__ void stage_b(PairRegs& s) const { in.stage_b(s); }
     template <bool NOP>

@@ -66,6 +66,10 @@ struct FieldFwdH3Args {
 
 // TRAIN: tiles X[T0 .. T0+NT) hold a layer's pre-activations times 2^es; rows [row0, row0 + 32 NT) of this tile of `acts` get
 // the true values (inv = 2^-es).  One register = two 128-byte row segments (lane halves hold rows rho and rho + 4).
+// (Round 6 tried the register PAIRS swapped across 16-lane rows so that every store instruction writes two full 128-byte lines --
+// in isolation full-line non-temporal writes run at 5.2-6.0 TB/s against 3.0-3.4 for these half lines, tools/probe/write_probe.hip --
+// and the kernel did not move: 3.465 vs 3.47 ms.  What the stores cost here, 0.95 of 3.47 ms by the -DNEFES_TRAIN_NO_STORES build, is
+// the wave's own ring loads waiting behind them in the in-order vmcnt, not the write pattern: DESIGN.md section 7 item 2.)
 template <int NT, int T0, int NX>
 __device__ __forceinline__ void train_save_h3(float* tile_base, uint32_t voff, int row0, const f32x16 (&X)[NX], float inv) {
     float* p = tile_base + (size_t)(row0 >> 5) * 4096 + voff;      // layout.h nefes_train_off: voff = nefes_train_lane_off
@@ -73,7 +77,9 @@ __device__ __forceinline__ void train_save_h3(float* tile_base, uint32_t voff, i
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+#ifndef NEFES_TRAIN_NO_STORES      /* (ablation builds: what the stores cost, tools/ab_side.sh) */
             __builtin_nontemporal_store(X[T0 + t][r] * inv, &p[t * 4096 + nefes_rho(0, r) * 16]);
+#endif
         }
 }
 
