@@ -1,0 +1,250 @@
+// What MI355X itself does with the dependencies tools/hazard_lint.py checks (round 6).  The linter's numbers are the
+// wait states LLVM's GCNHazardRecognizer inserts for gfx940 / gfx950; this probe issues each producer -> consumer pair with K = 0, 1, 2, ...
+// wait states between them, on every SIMD of the device, many times, and counts the lanes whose result differs from the one obtained
+// with the full distance.  0 at every K = the hardware resolves the dependency itself (the rule is the toolchain's caution);
+// > 0 below some K = a real software obligation, and the K at which the count reaches 0 is the measured requirement.
+//
+//   raw_f32_v   v_mfma_f32_32x32x2_f32 (16 passes) -> v_mov reads its VGPR result            LLVM: 18
+//   raw_f16_v   v_mfma_f32_32x32x16_f16 (8 passes) -> v_mov reads its VGPR result            LLVM: 12
+//   raw_f16_a   the same with the result in AGPRs, read by v_accvgpr_read_b32                LLVM: 12
+//   war_b       v_mfma_f32_32x32x16_f16 reads SrcB -> v_mov overwrites that register         LLVM: none (field_h3.h holds operands by hand)
+//   war_c       v_mfma_f32_32x32x16_f16 reads SrcC (other registers than vDst) -> v_mov      LLVM: 7
+//   valu_b      v_mov writes SrcB -> v_mfma_f32_32x32x16_f16 reads it                        LLVM: 2
+//   valu_c      v_mov writes SrcC -> v_mfma reads it                                         LLVM: 2
+//   vcc_valu    v_cmp writes VCC -> v_cndmask reads it                                       LLVM: 2
+//   mfma_ab     v_mfma result (VGPR) -> next v_mfma reads it as SrcB                          LLVM: 12
+//
+//     hipcc --offload-arch=gfx950 -O3 -o tools/probe/hazard_probe tools/probe/hazard_probe.hip && tools/probe/hazard_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define STR2(x) #x
+#define STR(x) STR2(x)
+// K wait states: nothing, or s_nop K-1 (K <= 16), or two of them
+#define NOPS(K) ((K) == 0 ? "" : "")
+
+template <int K>
+struct Nop {
+    static __device__ __forceinline__ void emit() {
+        if constexpr (K == 0) {
+        } else if constexpr (K <= 16) {
+            asm volatile("s_nop %0" ::"n"(K - 1));
+        } else {
+            asm volatile("s_nop 15\n\ts_nop %0" ::"n"(K - 17));
+        }
+    }
+};
+
+// Every test: out[2 * i] = value obtained with K wait states, out[2 * i + 1] = value with the full distance.  All registers are named
+// explicitly (clobbered), so that nothing the compiler does can sit between producer and consumer: one asm statement per measurement.
+#define SETTLE "s_nop 15\n\ts_nop 15\n\ts_nop 7\n\t"
+
+template <int K>
+__device__ __forceinline__ void raw_f32_v(float a, float b, float& early, float& late) {
+    asm volatile(
+        "v_mov_b32 v32, 0\n\tv_mov_b32 v47, 0\n\t"
+        ".irp r,33,34,35,36,37,38,39,40,41,42,43,44,45,46\n\tv_mov_b32 v\\r, 0\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x2_f32 v[32:47], %2, %3, v[32:47]\n\t"
+        ".if %4 > 16\n\ts_nop 15\n\ts_nop %4-17\n\t.elseif %4 > 0\n\ts_nop %4-1\n\t.endif\n\t"
+        "v_mov_b32 %0, v32\n\t" SETTLE
+        "v_mov_b32 %1, v32\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(a), "v"(b), "n"(K)
+        : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+}
+
+template <int K>
+__device__ __forceinline__ void raw_f16_v(unsigned a, unsigned b, float& early, float& late) {
+    asm volatile(
+        ".irp r,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47\n\tv_mov_b32 v\\r, 0\n\t.endr\n\t"
+        ".irp r,48,49,50,51\n\tv_mov_b32 v\\r, %2\n\t.endr\n\t.irp r,52,53,54,55\n\tv_mov_b32 v\\r, %3\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 v[32:47], v[48:51], v[52:55], v[32:47]\n\t"
+        ".if %4 > 16\n\ts_nop 15\n\ts_nop %4-17\n\t.elseif %4 > 0\n\ts_nop %4-1\n\t.endif\n\t"
+        "v_mov_b32 %0, v32\n\t" SETTLE
+        "v_mov_b32 %1, v32\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(a), "v"(b), "n"(K)
+        : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
+          "v51", "v52", "v53", "v54", "v55");
+}
+
+template <int K>
+__device__ __forceinline__ void raw_f16_a(unsigned a, unsigned b, float& early, float& late) {
+    asm volatile(
+        ".irp r,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n\tv_accvgpr_write_b32 a\\r, 0\n\t.endr\n\t"
+        ".irp r,48,49,50,51\n\tv_mov_b32 v\\r, %2\n\t.endr\n\t.irp r,52,53,54,55\n\tv_mov_b32 v\\r, %3\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 a[0:15], v[48:51], v[52:55], a[0:15]\n\t"
+        ".if %4 > 16\n\ts_nop 15\n\ts_nop %4-17\n\t.elseif %4 > 0\n\ts_nop %4-1\n\t.endif\n\t"
+        "v_accvgpr_read_b32 %0, a0\n\t" SETTLE
+        "v_accvgpr_read_b32 %1, a0\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(a), "v"(b), "n"(K)
+        : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "v48", "v49", "v50", "v51", "v52",
+          "v53", "v54", "v55");
+}
+
+// SrcB overwritten K wait states behind the MFMA that reads it; `late` = the same MFMA with the operand left alone
+template <int K>
+__device__ __forceinline__ void war_b(unsigned a, unsigned b, unsigned junk, float& early, float& late) {
+    asm volatile(
+        ".irp r,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47\n\tv_mov_b32 v\\r, 0\n\t.endr\n\t"
+        ".irp r,48,49,50,51\n\tv_mov_b32 v\\r, %2\n\t.endr\n\t.irp r,52,53,54,55\n\tv_mov_b32 v\\r, %3\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 v[32:47], v[48:51], v[52:55], v[32:47]\n\t"
+        ".if %5 > 16\n\ts_nop 15\n\ts_nop %5-17\n\t.elseif %5 > 0\n\ts_nop %5-1\n\t.endif\n\t"
+        ".irp r,52,53,54,55\n\tv_mov_b32 v\\r, %4\n\t.endr\n\t" SETTLE
+        "v_mov_b32 %0, v47\n\t"
+        ".irp r,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47\n\tv_mov_b32 v\\r, 0\n\t.endr\n\t"
+        ".irp r,52,53,54,55\n\tv_mov_b32 v\\r, %3\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 v[32:47], v[48:51], v[52:55], v[32:47]\n\t" SETTLE
+        "v_mov_b32 %1, v47\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(a), "v"(b), "v"(junk), "n"(K)
+        : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
+          "v51", "v52", "v53", "v54", "v55");
+}
+
+// SrcC (v[56:71], not the destination) overwritten K wait states behind the MFMA
+template <int K>
+__device__ __forceinline__ void war_c(unsigned a, unsigned b, float c, float junk, float& early, float& late) {
+    asm volatile(
+        ".irp r,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71\n\tv_mov_b32 v\\r, %4\n\t.endr\n\t"
+        ".irp r,48,49,50,51\n\tv_mov_b32 v\\r, %2\n\t.endr\n\t.irp r,52,53,54,55\n\tv_mov_b32 v\\r, %3\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 v[32:47], v[48:51], v[52:55], v[56:71]\n\t"
+        ".if %6 > 16\n\ts_nop 15\n\ts_nop %6-17\n\t.elseif %6 > 0\n\ts_nop %6-1\n\t.endif\n\t"
+        ".irp r,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71\n\tv_mov_b32 v\\r, %5\n\t.endr\n\t" SETTLE
+        "v_mov_b32 %0, v47\n\t"
+        ".irp r,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71\n\tv_mov_b32 v\\r, %4\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 v[32:47], v[48:51], v[52:55], v[56:71]\n\t" SETTLE
+        "v_mov_b32 %1, v47\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(a), "v"(b), "v"(c), "v"(junk), "n"(K)
+        : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
+          "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69",
+          "v70", "v71");
+}
+
+// SrcB written by the vector ALU K wait states in front of the MFMA (old value = junk, new = b)
+template <int K>
+__device__ __forceinline__ void valu_b(unsigned a, unsigned b, unsigned junk, float& early, float& late) {
+    asm volatile(
+        ".irp r,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47\n\tv_mov_b32 v\\r, 0\n\t.endr\n\t"
+        ".irp r,48,49,50,51\n\tv_mov_b32 v\\r, %2\n\t.endr\n\t.irp r,52,53,54,55\n\tv_mov_b32 v\\r, %4\n\t.endr\n\t" SETTLE
+        ".irp r,52,53,54,55\n\tv_mov_b32 v\\r, %3\n\t.endr\n\t"
+        ".if %5 > 16\n\ts_nop 15\n\ts_nop %5-17\n\t.elseif %5 > 0\n\ts_nop %5-1\n\t.endif\n\t"
+        "v_mfma_f32_32x32x16_f16 v[32:47], v[48:51], v[52:55], v[32:47]\n\t" SETTLE
+        "v_mov_b32 %0, v47\n\t"
+        ".irp r,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47\n\tv_mov_b32 v\\r, 0\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 v[32:47], v[48:51], v[52:55], v[32:47]\n\t" SETTLE
+        "v_mov_b32 %1, v47\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(a), "v"(b), "v"(junk), "n"(K)
+        : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
+          "v51", "v52", "v53", "v54", "v55");
+}
+
+// SrcC = vDst written by the vector ALU K wait states in front of the MFMA (old value = junk, new = c)
+template <int K>
+__device__ __forceinline__ void valu_c(unsigned a, unsigned b, float c, float junk, float& early, float& late) {
+    asm volatile(
+        ".irp r,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47\n\tv_mov_b32 v\\r, %5\n\t.endr\n\t"
+        ".irp r,48,49,50,51\n\tv_mov_b32 v\\r, %2\n\t.endr\n\t.irp r,52,53,54,55\n\tv_mov_b32 v\\r, %3\n\t.endr\n\t" SETTLE
+        ".irp r,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47\n\tv_mov_b32 v\\r, %4\n\t.endr\n\t"
+        ".if %6 > 16\n\ts_nop 15\n\ts_nop %6-17\n\t.elseif %6 > 0\n\ts_nop %6-1\n\t.endif\n\t"
+        "v_mfma_f32_32x32x16_f16 v[32:47], v[48:51], v[52:55], v[32:47]\n\t" SETTLE
+        "v_mov_b32 %0, v47\n\t"
+        ".irp r,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47\n\tv_mov_b32 v\\r, %4\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 v[32:47], v[48:51], v[52:55], v[32:47]\n\t" SETTLE
+        "v_mov_b32 %1, v47\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(a), "v"(b), "v"(c), "v"(junk), "n"(K)
+        : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
+          "v51", "v52", "v53", "v54", "v55");
+}
+
+// VCC written by v_cmp (this lane: x > 0) K wait states in front of a v_cndmask that selects by it; VCC held the opposite before
+template <int K>
+__device__ __forceinline__ void vcc_valu(float x, float& early, float& late) {
+    asm volatile(
+        "v_cmp_lt_f32 vcc, 0, %2\n\t" SETTLE                         // vcc = (0 < x)
+        "v_cmp_gt_f32 vcc, 0, %2\n\t"                                // vcc = (0 > x): flips in every lane with x != 0
+        ".if %3 > 0\n\ts_nop %3-1\n\t.endif\n\t"
+        "v_cndmask_b32 %0, 1.0, 2.0, vcc\n\t" SETTLE
+        "v_cndmask_b32 %1, 1.0, 2.0, vcc\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(x), "n"(K) : "vcc");
+}
+
+// An MFMA's VGPR result as the next MFMA's SrcB, K wait states later
+template <int K>
+__device__ __forceinline__ void mfma_ab(unsigned a, unsigned b, float& early, float& late) {
+    asm volatile(
+        ".irp r,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47\n\tv_mov_b32 v\\r, 0\n\t.endr\n\t"
+        ".irp r,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71\n\tv_mov_b32 v\\r, 0\n\t.endr\n\t"
+        ".irp r,48,49,50,51\n\tv_mov_b32 v\\r, %2\n\t.endr\n\t.irp r,52,53,54,55\n\tv_mov_b32 v\\r, %3\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 v[32:47], v[48:51], v[52:55], v[32:47]\n\t"
+        ".if %4 > 16\n\ts_nop 15\n\ts_nop %4-17\n\t.elseif %4 > 0\n\ts_nop %4-1\n\t.endif\n\t"
+        "v_mfma_f32_32x32x16_f16 v[56:71], v[48:51], v[32:35], v[56:71]\n\t" SETTLE
+        "v_mov_b32 %0, v71\n\t"
+        ".irp r,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71\n\tv_mov_b32 v\\r, 0\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 v[56:71], v[48:51], v[32:35], v[56:71]\n\t" SETTLE
+        "v_mov_b32 %1, v71\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(a), "v"(b), "n"(K)
+        : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
+          "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69",
+          "v70", "v71");
+}
+
+template <int TEST, int K>
+__global__ __launch_bounds__(256) void probe_kernel(unsigned* __restrict__ bad, int iters) {
+    const int lane = threadIdx.x & 63;
+    unsigned n = 0;
+    for (int it = 0; it < iters; ++it) {
+        const float fa = 1.f + 0.001f * (float)(lane + it), fb = 2.f + 0.01f * (float)(it & 31);
+        // two packed halves per dword, values that differ per lane and iteration (fp16 of small integers)
+        const unsigned ha = 0x3c003c00u + (((lane + it) & 7) << 10), hb = 0x40004000u + (((lane * 3 + it) & 7) << 10), junk = 0x7bff7bffu;
+        float e = 0.f, l = 0.f;
+        if constexpr (TEST == 0) raw_f32_v<K>(fa, fb, e, l);
+        if constexpr (TEST == 1) raw_f16_v<K>(ha, hb, e, l);
+        if constexpr (TEST == 2) raw_f16_a<K>(ha, hb, e, l);
+        if constexpr (TEST == 3) war_b<K>(ha, hb, junk, e, l);
+        if constexpr (TEST == 4) war_c<K>(ha, hb, fa, 12345.f, e, l);
+        if constexpr (TEST == 5) valu_b<K>(ha, hb, junk, e, l);
+        if constexpr (TEST == 6) valu_c<K>(ha, hb, fa, 12345.f, e, l);
+        if constexpr (TEST == 7) vcc_valu<K>((lane & 1) ? fa : -fa, e, l);
+        if constexpr (TEST == 8) mfma_ab<K>(ha, hb, e, l);
+        n += (__float_as_uint(e) != __float_as_uint(l)) ? 1u : 0u;
+    }
+    atomicAdd(&bad[0], n);
+}
+
+template <int TEST, int K>
+static unsigned run(unsigned* d_bad, int blocks, int iters) {
+    hipMemset(d_bad, 0, 4);
+    hipLaunchKernelGGL((probe_kernel<TEST, K>), dim3(blocks), dim3(256), 0, 0, d_bad, iters);
+    unsigned h = 0;
+    hipMemcpy(&h, d_bad, 4, hipMemcpyDeviceToHost);
+    return h;
+}
+
+template <int TEST>
+static void sweep(const char* name, const char* llvm, unsigned* d_bad, int blocks, int iters) {
+    printf("%-10s LLVM pads %-4s wrong lanes of %lld at K = 0 1 2 3 4 6 8 10 11 12 16 17 18: ", name, llvm, (long long)blocks * 256 * iters);
+    unsigned r[13] = {run<TEST, 0>(d_bad, blocks, iters), run<TEST, 1>(d_bad, blocks, iters), run<TEST, 2>(d_bad, blocks, iters),
+                      run<TEST, 3>(d_bad, blocks, iters), run<TEST, 4>(d_bad, blocks, iters), run<TEST, 6>(d_bad, blocks, iters),
+                      run<TEST, 8>(d_bad, blocks, iters), run<TEST, 10>(d_bad, blocks, iters), run<TEST, 11>(d_bad, blocks, iters),
+                      run<TEST, 12>(d_bad, blocks, iters), run<TEST, 16>(d_bad, blocks, iters), run<TEST, 17>(d_bad, blocks, iters),
+                      run<TEST, 18>(d_bad, blocks, iters)};
+    for (int i = 0; i < 13; ++i) printf("%u ", r[i]);
+    printf("\n");
+}
+
+int main() {
+    unsigned* d_bad = nullptr;
+    if (hipMalloc(&d_bad, 4) != hipSuccess) { printf("no device\n"); return 1; }
+    const int blocks = 1024, iters = 200;
+    sweep<0>("raw_f32_v", "18", d_bad, blocks, iters);
+    sweep<1>("raw_f16_v", "12", d_bad, blocks, iters);
+    sweep<2>("raw_f16_a", "12", d_bad, blocks, iters);
+    sweep<3>("war_b", "-", d_bad, blocks, iters);
+    sweep<4>("war_c", "7", d_bad, blocks, iters);
+    sweep<5>("valu_b", "2", d_bad, blocks, iters);
+    sweep<6>("valu_c", "2", d_bad, blocks, iters);
+    sweep<7>("vcc_valu", "2", d_bad, blocks, iters);
+    sweep<8>("mfma_ab", "12", d_bad, blocks, iters);
+    hipFree(d_bad);
+    return 0;
+}
