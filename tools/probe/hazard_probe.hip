@@ -13,6 +13,8 @@
 //   valu_c      v_mov writes SrcC -> v_mfma reads it                                         LLVM: 2
 //   vcc_valu    v_cmp writes VCC -> v_cndmask reads it                                       LLVM: 2
 //   mfma_ab     v_mfma result (VGPR) -> next v_mfma reads it as SrcB                          LLVM: 12
+//   waw_v       v_mfma_f32_32x32x16_f16 result register overwritten by v_mov                 LLVM: 12
+//   raw_f16_lds v_mfma_f32_32x32x16_f16 result read by ds_write_b32                          LLVM: 12
 //
 //     hipcc --offload-arch=gfx950 -O3 -o tools/probe/hazard_probe tools/probe/hazard_probe.hip && tools/probe/hazard_probe
 #include <hip/hip_runtime.h>
@@ -188,6 +190,38 @@ __device__ __forceinline__ void mfma_ab(unsigned a, unsigned b, float& early, fl
           "v70", "v71");
 }
 
+
+// XDL result register OVERWRITTEN by the vector ALU K wait states later (write after write): in program order the VALU's value stays
+template <int K>
+__device__ __forceinline__ void waw_v(unsigned a, unsigned b, float mark, float& early, float& late) {
+    asm volatile(
+        ".irp r,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47\n\tv_mov_b32 v\\r, 0\n\t.endr\n\t"
+        ".irp r,48,49,50,51\n\tv_mov_b32 v\\r, %2\n\t.endr\n\t.irp r,52,53,54,55\n\tv_mov_b32 v\\r, %3\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 v[32:47], v[48:51], v[52:55], v[32:47]\n\t"
+        ".if %5 > 16\n\ts_nop 15\n\ts_nop %5-17\n\t.elseif %5 > 0\n\ts_nop %5-1\n\t.endif\n\t"
+        "v_mov_b32 v32, %4\n\tv_mov_b32 v47, %4\n\t" SETTLE
+        "v_add_f32 %0, v32, v47\n\t"
+        "v_add_f32 %1, %4, %4\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(a), "v"(b), "v"(mark), "n"(K)
+        : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
+          "v51", "v52", "v53", "v54", "v55");
+}
+
+// XDL result read by an LDS store K wait states later (ds_write_b32 of v32, read back after the settle time)
+template <int K>
+__device__ __forceinline__ void raw_f16_lds(unsigned a, unsigned b, unsigned lds_addr, float& early, float& late) {
+    asm volatile(
+        ".irp r,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47\n\tv_mov_b32 v\\r, 0\n\t.endr\n\t"
+        ".irp r,48,49,50,51\n\tv_mov_b32 v\\r, %2\n\t.endr\n\t.irp r,52,53,54,55\n\tv_mov_b32 v\\r, %3\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 v[32:47], v[48:51], v[52:55], v[32:47]\n\t"
+        ".if %5 > 16\n\ts_nop 15\n\ts_nop %5-17\n\t.elseif %5 > 0\n\ts_nop %5-1\n\t.endif\n\t"
+        "ds_write_b32 %4, v32\n\t" SETTLE
+        "s_waitcnt lgkmcnt(0)\n\tds_read_b32 %0, %4\n\tv_mov_b32 %1, v32\n\ts_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(a), "v"(b), "v"(lds_addr), "n"(K)
+        : "memory", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49",
+          "v50", "v51", "v52", "v53", "v54", "v55");
+}
+
 template <int TEST, int K>
 __global__ __launch_bounds__(256) void probe_kernel(unsigned* __restrict__ bad, int iters) {
     const int lane = threadIdx.x & 63;
@@ -206,6 +240,11 @@ __global__ __launch_bounds__(256) void probe_kernel(unsigned* __restrict__ bad, 
         if constexpr (TEST == 6) valu_c<K>(ha, hb, fa, 12345.f, e, l);
         if constexpr (TEST == 7) vcc_valu<K>((lane & 1) ? fa : -fa, e, l);
         if constexpr (TEST == 8) mfma_ab<K>(ha, hb, e, l);
+        if constexpr (TEST == 9) waw_v<K>(ha, hb, 7.f + (float)lane, e, l);
+        if constexpr (TEST == 10) {
+            __shared__ float buf[256];
+            raw_f16_lds<K>(ha, hb, (unsigned)(size_t)(&buf[threadIdx.x]) , e, l);
+        }
         n += (__float_as_uint(e) != __float_as_uint(l)) ? 1u : 0u;
     }
     atomicAdd(&bad[0], n);
@@ -222,11 +261,11 @@ static unsigned run(unsigned* d_bad, int blocks, int iters) {
 
 template <int TEST>
 static void sweep(const char* name, const char* llvm, unsigned* d_bad, int blocks, int iters) {
-    printf("%-10s LLVM pads %-4s wrong lanes of %lld at K = 0 1 2 3 4 6 8 10 11 12 16 17 18: ", name, llvm, (long long)blocks * 256 * iters);
+    printf("%-10s LLVM pads %-4s wrong lanes of %lld at K = 0 1 2 3 4 5 6 7 8 10 12 16 18: ", name, llvm, (long long)blocks * 256 * iters);
     unsigned r[13] = {run<TEST, 0>(d_bad, blocks, iters), run<TEST, 1>(d_bad, blocks, iters), run<TEST, 2>(d_bad, blocks, iters),
-                      run<TEST, 3>(d_bad, blocks, iters), run<TEST, 4>(d_bad, blocks, iters), run<TEST, 6>(d_bad, blocks, iters),
-                      run<TEST, 8>(d_bad, blocks, iters), run<TEST, 10>(d_bad, blocks, iters), run<TEST, 11>(d_bad, blocks, iters),
-                      run<TEST, 12>(d_bad, blocks, iters), run<TEST, 16>(d_bad, blocks, iters), run<TEST, 17>(d_bad, blocks, iters),
+                      run<TEST, 3>(d_bad, blocks, iters), run<TEST, 4>(d_bad, blocks, iters), run<TEST, 5>(d_bad, blocks, iters),
+                      run<TEST, 6>(d_bad, blocks, iters), run<TEST, 7>(d_bad, blocks, iters), run<TEST, 8>(d_bad, blocks, iters),
+                      run<TEST, 10>(d_bad, blocks, iters), run<TEST, 12>(d_bad, blocks, iters), run<TEST, 16>(d_bad, blocks, iters),
                       run<TEST, 18>(d_bad, blocks, iters)};
     for (int i = 0; i < 13; ++i) printf("%u ", r[i]);
     printf("\n");
@@ -245,6 +284,8 @@ int main() {
     sweep<6>("valu_c", "2", d_bad, blocks, iters);
     sweep<7>("vcc_valu", "2", d_bad, blocks, iters);
     sweep<8>("mfma_ab", "12", d_bad, blocks, iters);
+    sweep<9>("waw_v", "12", d_bad, blocks, iters);
+    sweep<10>("raw_f16_lds", "12", d_bad, blocks, iters);
     hipFree(d_bad);
     return 0;
 }
