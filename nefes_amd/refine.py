@@ -390,7 +390,7 @@ class PoseRefiner:
         self.loss.copy_(loss.detach())
         return self.loss
 
-    def _verification(self):
+    def _verification(self, as_tensors=False):
         """PSNR and mean SSIM of the up-sampled, cropped render against the cropped query image (:117-128, :146-150)."""
         if self._x_rgb is not None:                        # de-normalise FusionNet's colour channels
             fnet = self.coarse.fusion_net
@@ -400,6 +400,8 @@ class PoseRefiner:
             img = self._rgb.reshape(1, self.h, self.w, 3).permute(0, 3, 1, 2)
         img = nn.functional.interpolate(img, size=(self.H, self.W), mode="bicubic")[:, :, 10:-10, 10:-10]
         gt = self.photo[:, :, 10:-10, 10:-10]
+        if as_tensors:                                     # (no host read: refine_apr_concurrently converts after its last replay)
+            return mse2psnr(img2mse(img, gt)).reshape(()), ssim_map(img, gt).mean().reshape(())
         return float(mse2psnr(img2mse(img, gt))), float(ssim_map(img, gt).mean())
 
     def predicted_pose(self, net=None):
@@ -474,6 +476,7 @@ class PoseRefiner:
         with torch.cuda.graph(g):
             self._apr_iteration()
         self.apr_graph = g
+        self._captured_apr_opt = self.apr_opt               # (the graph updates THIS optimizer's state tensors)
 
     def refine_apr(self, photo, feature_target, hist, iters=50, verification=True):
         """One query image, `pose_only=2`: `photo` [1,3,H,W], `feature_target` [C,H,W] (the query image's features at full
@@ -510,7 +513,132 @@ class PoseRefiner:
         return pose.detach().clone(), losses, info
 
 
-def _check_concurrent(refiners):
+def _apr_kernels_bit_stable(r, photo, feature_target, hist, trials=6):
+    """EMPIRICAL guard for refine_apr_concurrently.  The regression network, its backward, torch's Adam and the verification step are the
+    CALLER'S / torch's kernels; next to another stream's field kernels such code is exposed to the packed-fp32 finding of DESIGN.md 4.7
+    (hipcc vectorises torch's kernels the way it vectorised ours) -- whether a given network's kernels contain the affected forms cannot be
+    read off its Python.  So it is tried: two eager iterations + the verification step from the image's initial state, alone on the
+    device and `trials` times with this library's fine-field forward running on a second stream, every result compared bit for bit
+    (loss, every parameter of the working network, PSNR, SSIM).  The affected instructions go wrong in 0.05-0.35 % of their executions on
+    a quarter of the lanes: a kernel that carries one does not survive six trials of this.  Cached on the network object."""
+    key = "_nefes_bit_stable_next_to_field_kernels"
+    if getattr(r.apr_base, key, None) is not None:
+        return getattr(r.apr_base, key)
+    from . import lib as L
+    dev = r.dev
+    fine = r.kw["network_fine"]
+    pk = fine.packed()
+    g = torch.Generator().manual_seed(5)
+    N, S = 4800, 128
+    ro = (torch.randn(N, 3, generator=g) * 0.1).to(dev)
+    rd = nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).to(dev)
+    z = (torch.rand(N, S, generator=g).sort(-1).values * 3 + 0.2).to(dev)
+    side = torch.cuda.Stream(device=dev)
+
+    def run(storm):
+        r._apr_image_state(photo, feature_target, hist)
+        r._apr_fresh_adam()
+        torch.cuda.synchronize(dev)
+        keep = []
+        if storm:
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(8):                         # ~5 ms of field kernels: longer than the sequence under test
+                    keep.append(ops.FieldFromRays.apply(ro, rd, rd, z, pk, L.FIELD_FULL))
+        r._apr_iteration()
+        r._apr_iteration()
+        ps, ss = r._verification(as_tensors=True)
+        out = [r.loss.detach().clone(), ps.detach().clone(), ss.detach().clone()] + [p.detach().clone() for p in r.apr.parameters()]
+        torch.cuda.synchronize(dev)
+        return out
+
+    was_graph = r.apr_graph
+    views = (r._rgb, r._x_rgb)                             # (a captured iteration's views of ITS static buffers: eager calls re-point them)
+    r.apr_graph = None                                     # (eager iterations; _apr_fresh_adam then builds a fresh optimizer per run)
+    try:
+        solo = run(False)
+        ok = all(all(torch.equal(a, b) for a, b in zip(solo, run(True))) for _ in range(trials))
+    finally:
+        r.apr_graph = was_graph
+        if was_graph is not None:                          # the captured optimizer object and buffer views must be the live ones again
+            r.apr_opt = r._captured_apr_opt
+            r._rgb, r._x_rgb = views
+    setattr(r.apr_base, key, bool(ok))
+    return bool(ok)
+
+
+def refine_apr_concurrently(refiners, jobs, iters=50, verification=True, verify_kernels=True):
+    """refine_apr for K query images at the same time (the shipped default mode, `pose_only = 2`): one PoseRefiner(pose_model=...) and
+    one HIP stream per image, iterations replayed round-robin like refine_concurrently.  jobs = [(photo, feature_target, hist), ...] ->
+    [(pose [3,4], losses [iters], info), ...] in job order, each identical to what refine_apr returns for that image alone.
+    The regression network's kernels are the caller's: `verify_kernels` first TRIES them next to this library's field kernels
+    (_apr_kernels_bit_stable) and raises if a result moves -- run such a network's images one after the other (refine_apr)."""
+    if not refiners or not jobs:
+        raise ValueError("nefes_amd: refine_apr_concurrently needs at least one PoseRefiner and one job")
+    if len({id(r) for r in refiners}) != len(refiners):
+        raise ValueError("nefes_amd: refine_apr_concurrently needs DISTINCT PoseRefiner objects")
+    if any(r.apr is None for r in refiners):
+        raise RuntimeError("nefes_amd: refine_apr_concurrently needs refiners built with pose_model=")
+    if len(jobs) > len(refiners):
+        out = []
+        for k in range(0, len(jobs), len(refiners)):
+            part = jobs[k:k + len(refiners)]
+            out += refine_apr_concurrently(refiners[:len(part)], part, iters, verification, verify_kernels)
+        return out
+    refiners = refiners[:len(jobs)]
+    dev = refiners[0].dev
+    _check_concurrent(refiners, apr=True)
+    if verify_kernels:
+        for r, job in zip(refiners, jobs):
+            if not _apr_kernels_bit_stable(r, *job):
+                raise RuntimeError("nefes_amd: this regression network's kernels (or torch's Adam / the verification step) do not give "
+                                   "bit-identical results next to another stream's field kernels (DESIGN.md 4.7): refine its images "
+                                   "one after the other with PoseRefiner.refine_apr")
+    for r, job in zip(refiners, jobs):                      # per-image state, capture (one refiner at a time, on the caller's stream)
+        r._apr_image_state(*job)
+        r._apr_fresh_adam()
+        if r.use_graph and r.apr_graph is None:
+            r._capture_apr()
+    cur = torch.cuda.current_stream(dev)
+    for r in refiners:
+        if getattr(r, "_own_stream", None) is None:
+            r._own_stream = torch.cuda.Stream(device=dev)
+        r._own_stream.wait_stream(cur)
+    firsts, losses, checks = [], [torch.empty(iters, device=dev) for _ in refiners], [[] for _ in refiners]
+    for r, job in zip(refiners, jobs):
+        with torch.cuda.stream(r._own_stream):
+            r._apr_image_state(*job)
+            r._apr_fresh_adam()
+            firsts.append(r.predicted_pose())
+    for i in range(iters):
+        for k, r in enumerate(refiners):
+            with torch.cuda.stream(r._own_stream):
+                if r.apr_graph is not None:
+                    r.replay(apr=True)
+                else:
+                    r._apr_iteration()
+                losses[k][i] = r.loss
+                if verification and (i == 0 or i == iters - 1):
+                    checks[k].append(r._verification(as_tensors=True))
+    poses = []
+    for r in refiners:
+        with torch.cuda.stream(r._own_stream):
+            poses.append(r.predicted_pose().detach().clone())
+    for r in refiners:
+        cur.wait_stream(r._own_stream)
+    torch.cuda.synchronize(dev)
+    outs = []
+    for k in range(len(refiners)):
+        info, pose = {"retreat": False}, poses[k]
+        if verification and len(checks[k]) == 2:
+            (p0, s0), (p1, s1) = [(float(a), float(b)) for a, b in checks[k]]
+            info = {"psnr": (p0, p1), "ssim": (s0, s1), "retreat": bool(p1 < p0) or bool(s1 < s0)}
+            if info["retreat"]:
+                pose = firsts[k]
+        outs.append((pose.detach().clone(), losses[k], info))
+    return outs
+
+
+def _check_concurrent(refiners, apr=False):
     """What refine_concurrently's guarantees rest on, checked instead of assumed.
     (1) No shared mutable state between streams: refiners that share a FusionNet must not update its BatchNorm's running statistics
         (a read-modify-write of the module's buffers from several streams: lost counter increments, non-deterministic statistics).
@@ -525,7 +653,8 @@ def _check_concurrent(refiners):
         if other is not r and bn_tracks and (r.bn_running_stats or other.bn_running_stats):
             raise ValueError("nefes_amd: refine_concurrently: these refiners share one FusionNet whose BatchNorm would update its running "
                              "statistics from several streams at once; construct them with PoseRefiner(..., bn_running_stats=False)")
-        in_house = (r.fused_glue and isinstance(r.opt, ops.FusedAdam) and fnet.HIP_CONVS and (fnet.no_BN or fnet.HIP_BATCHNORM)
+        # (apr: the regression network and its optimizer are torch's by construction; refine_apr_concurrently tries them instead)
+        in_house = (r.fused_glue and (apr or isinstance(r.opt, ops.FusedAdam)) and fnet.HIP_CONVS and (fnet.no_BN or fnet.HIP_BATCHNORM)
                     and fnet._use_hip(r.hist))
         if not in_house:
             raise ValueError("nefes_amd: refine_concurrently needs every refiner on the library's own kernels (fused_glue=True, "

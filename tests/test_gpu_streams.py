@@ -117,6 +117,31 @@ def test_refiners_that_share_a_fusion_net_do_not_touch_its_running_statistics(go
         refine_concurrently([quiet[0], refiner(g, graph=False, networks=shared, bn_running_stats=False, fused_glue=False)], jobs, iters=1)
 
 
+def test_two_images_of_the_default_mode_on_two_streams_equal_their_solo_runs(golden):
+    """refine_apr_concurrently (`pose_only = 2`: the pose is a regression network's output, the loop trains a per-image copy of it): two
+    PoseRefiner(pose_model=...) on two streams, 12 iterations, different regression networks (starts 0 and 3) -- pose, loss curve, PSNR /
+    SSIM and the roll-back decision identical to refine_apr of each image alone; before that the regression network's own kernels are
+    TRIED next to the library's field kernels (the empirical guard: they are torch's, exposed to DESIGN.md 4.7) and found bit-stable."""
+    from nefes_amd.refine import _apr_kernels_bit_stable, refine_apr_concurrently
+    from tests.test_gpu_refine50 import TinyAPR, photo_of, target_full
+    g = golden("refine50")
+    shared = nets(g)
+    photo, tgt, hist = photo_of(g), target_full(g), T(g["hist"])
+    n = 12
+    refs = [refiner(g, graph=True, apr=TinyAPR(g["m2_weight"][k], g["m2_bias"][k]), networks=shared, bn_running_stats=False) for k in (0, 3)]
+    jobs = [(photo, tgt, hist)] * 2
+    solo = [r.refine_apr(*job, iters=n) for r, job in zip(refs, jobs)]
+    solo = [(p.clone(), l.clone(), dict(i)) for p, l, i in solo]
+    assert all(_apr_kernels_bit_stable(r, *job) for r, job in zip(refs, jobs))
+    for rep in range(2):
+        outs = refine_apr_concurrently(refs, jobs, iters=n)
+        for (p, l, info), (ps, ls, infos) in zip(outs, solo):
+            assert torch.equal(p, ps) and torch.equal(l, ls) and info == infos, rep
+    assert not torch.equal(solo[0][0], solo[1][0])
+    with pytest.raises(RuntimeError, match="pose_model"):
+        refine_apr_concurrently([refiner(g, graph=True, networks=shared, bn_running_stats=False)], jobs[:1], iters=1)
+
+
 @pytest.mark.parametrize("case", ["headline", "hashgrid", "train"])
 def test_other_paths_are_bit_stable_next_to_another_streams_field_kernels(case):
     """The same question for the paths the refinement loop does not run: the headline network's chain (8 x 256, C = 16, 64 + 128 samples),

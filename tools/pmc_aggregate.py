@@ -16,15 +16,42 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _strip_comments(text):
+    """C / C++ source without comments and with runs of blanks collapsed (string and character literals kept verbatim)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return re.sub(r"[ \t]+", " ", re.sub(r"[ \t]*\n\s*", "\n", "".join(out))).strip()
+
+
 def kernel_source_digest(root=ROOT):
-    """sha256 over the kernel sources (nefes_amd/csrc: *.hip, *.h, *.cpp, Makefile), 16 hex digits.  Stored with every counter
-    digest; bench.py quotes `roofline.traffic` from a committed digest only while this still matches the tree it runs from."""
+    """sha256 over the kernel sources (nefes_amd/csrc: *.hip, *.h, *.cpp, Makefile) WITHOUT their comments, 16 hex digits.  Stored with
+    every counter digest; bench.py quotes `roofline.traffic` from a committed digest only while this still matches the tree it runs
+    from.  (Comments are stripped since round 6: a reworded comment is not a different kernel, and every such edit used to cost a
+    re-collection; the Makefile's flags and every token of code still count.)"""
     d = os.path.join(root, "nefes_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile":
             h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+            text = open(os.path.join(d, f), "r", errors="replace").read()
+            h.update((text if f == "Makefile" else _strip_comments(text)).encode())
     return h.hexdigest()[:16]
 
 
