@@ -457,6 +457,13 @@ int nefes_probe_store_hazard(float* out, int64_t n_float4, int nops, void* strea
 /* Diagnostic: every lane runs `iters` v_pk_mul_f32 with op_sel:[0,1] / op_sel_hi:[1,0] on fresh operands; out dev [n] = how many of its
  * results were not the two products. */
 int nefes_probe_pk_mul(unsigned* out, int64_t n, int iters, void* stream);
+/* What the hardware itself does with the producer -> consumer pairs tools/hazard_lint.py checks (csrc/hazard_probe.hip):
+ * every SIMD runs `iters` repetitions of one pair with K wait states in between; *count (device, zeroed by the caller) += the lanes x
+ * repetitions whose result differs from the result with the full distance.  test: 0 fp32 MFMA result -> vector read, 1 / 2 16-bit MFMA
+ * result -> v_mov / v_accvgpr_read, 3 / 4 MFMA read of SrcB / SrcC -> vector overwrite, 5 / 6 vector write of SrcB / SrcC -> MFMA,
+ * 7 v_cmp VCC -> v_cndmask, 8 MFMA result -> next MFMA's SrcB, 9 MFMA result -> vector overwrite, 10 MFMA result -> ds_write;
+ * K in {0 .. 8, 10, 12, 16, 18}. */
+int nefes_probe_hazard(int test, int k, int blocks, int iters, unsigned* count, void* stream);
 /* Diagnostic neighbour for nefes_probe_pk_mul: `blocks` workgroups of 256 run `iters` rounds of one instruction kind (0: v_fma_mixlo/hi_f16,
  * 1: v_mfma_f32_32x32x16_f16, 2: both, 3: v_pk_fma_f32 with op_sel_hi, 4: v_fma_f32); sink dev [blocks * 256] floats. */
 int nefes_probe_aggressor(int kind, int iters, int blocks, float* sink, void* stream);

@@ -173,7 +173,7 @@ __device__ __forceinline__ void pin(T (&v)[N]) {
 // -amdgpu-mfma-vgpr-form (the Wd = 128 fp16 instances), or through field_h3.h acc_read's asm v_accvgpr_read_b32 (the Wd = 256
 // inference objects) -- nothing stood between the run's last MFMA and that read but whatever the scheduler had put there:
 // tools/hazard_lint.py found the transient heads' fp32 product read 2-6 wait states after its last k-step in every such backward
-// instance of round 5's library, the headline one included.  Measured on MI355X (tools/probe/hazard_probe.hip): the
+// instance of round 5's library, the headline one included.  Measured on MI355X (csrc/hazard_probe.hip): the
 // fp32 MFMA's result is interlocked (right at zero wait states), so no wrong number ever came of THAT read; a 16-bit (XDL) MFMA's
 // result is not -- a vector read within four wait states returns the old register contents, a vector write within seven is lost --
 // and the bf16x6 forward did have such a read (four wait states, on the short side of a branch hipcc's recognizer does not follow).

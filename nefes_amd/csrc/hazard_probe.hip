@@ -16,28 +16,11 @@
 //   waw_v       v_mfma_f32_32x32x16_f16 result register overwritten by v_mov                 LLVM: 12
 //   raw_f16_lds v_mfma_f32_32x32x16_f16 result read by ds_write_b32                          LLVM: 12
 //
-//     hipcc --offload-arch=gfx950 -O3 -o tools/probe/hazard_probe tools/probe/hazard_probe.hip && tools/probe/hazard_probe
+// Part of the library so that the driver's own GPU run records the table (tests/test_gpu_hazards.py); tools/hazard_probe.py prints it.
+// tools/hazard_lint.py and tests/test_hazard_lint.py exempt these kernels by name: they exist to violate the rules.
 #include <hip/hip_runtime.h>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-
-#define STR2(x) #x
-#define STR(x) STR2(x)
-// K wait states: nothing, or s_nop K-1 (K <= 16), or two of them
-#define NOPS(K) ((K) == 0 ? "" : "")
-
-template <int K>
-struct Nop {
-    static __device__ __forceinline__ void emit() {
-        if constexpr (K == 0) {
-        } else if constexpr (K <= 16) {
-            asm volatile("s_nop %0" ::"n"(K - 1));
-        } else {
-            asm volatile("s_nop 15\n\ts_nop %0" ::"n"(K - 17));
-        }
-    }
-};
+#include <stdint.h>
+#include "../../include/nefes_hip.h"
 
 // Every test: out[2 * i] = value obtained with K wait states, out[2 * i + 1] = value with the full distance.  All registers are named
 // explicitly (clobbered), so that nothing the compiler does can sit between producer and consumer: one asm statement per measurement.
@@ -223,7 +206,7 @@ __device__ __forceinline__ void raw_f16_lds(unsigned a, unsigned b, unsigned lds
 }
 
 template <int TEST, int K>
-__global__ __launch_bounds__(256) void probe_kernel(unsigned* __restrict__ bad, int iters) {
+__global__ __launch_bounds__(256) void hazard_probe_kernel(unsigned* __restrict__ bad, int iters) {
     const int lane = threadIdx.x & 63;
     unsigned n = 0;
     for (int it = 0; it < iters; ++it) {
@@ -243,49 +226,42 @@ __global__ __launch_bounds__(256) void probe_kernel(unsigned* __restrict__ bad, 
         if constexpr (TEST == 9) waw_v<K>(ha, hb, 7.f + (float)lane, e, l);
         if constexpr (TEST == 10) {
             __shared__ float buf[256];
-            raw_f16_lds<K>(ha, hb, (unsigned)(size_t)(&buf[threadIdx.x]) , e, l);
+            raw_f16_lds<K>(ha, hb, (unsigned)(size_t)(&buf[threadIdx.x]), e, l);
         }
         n += (__float_as_uint(e) != __float_as_uint(l)) ? 1u : 0u;
     }
     atomicAdd(&bad[0], n);
 }
 
-template <int TEST, int K>
-static unsigned run(unsigned* d_bad, int blocks, int iters) {
-    hipMemset(d_bad, 0, 4);
-    hipLaunchKernelGGL((probe_kernel<TEST, K>), dim3(blocks), dim3(256), 0, 0, d_bad, iters);
-    unsigned h = 0;
-    hipMemcpy(&h, d_bad, 4, hipMemcpyDeviceToHost);
-    return h;
-}
-
 template <int TEST>
-static void sweep(const char* name, const char* llvm, unsigned* d_bad, int blocks, int iters) {
-    printf("%-10s LLVM pads %-4s wrong lanes of %lld at K = 0 1 2 3 4 5 6 7 8 10 12 16 18: ", name, llvm, (long long)blocks * 256 * iters);
-    unsigned r[13] = {run<TEST, 0>(d_bad, blocks, iters), run<TEST, 1>(d_bad, blocks, iters), run<TEST, 2>(d_bad, blocks, iters),
-                      run<TEST, 3>(d_bad, blocks, iters), run<TEST, 4>(d_bad, blocks, iters), run<TEST, 5>(d_bad, blocks, iters),
-                      run<TEST, 6>(d_bad, blocks, iters), run<TEST, 7>(d_bad, blocks, iters), run<TEST, 8>(d_bad, blocks, iters),
-                      run<TEST, 10>(d_bad, blocks, iters), run<TEST, 12>(d_bad, blocks, iters), run<TEST, 16>(d_bad, blocks, iters),
-                      run<TEST, 18>(d_bad, blocks, iters)};
-    for (int i = 0; i < 13; ++i) printf("%u ", r[i]);
-    printf("\n");
+static int launch_k(int k, unsigned* bad, int blocks, int iters, hipStream_t st) {
+#define HZ_CASE(K) case K: hipLaunchKernelGGL((hazard_probe_kernel<TEST, K>), dim3(blocks), dim3(256), 0, st, bad, iters); break;
+    switch (k) {
+        HZ_CASE(0) HZ_CASE(1) HZ_CASE(2) HZ_CASE(3) HZ_CASE(4) HZ_CASE(5) HZ_CASE(6) HZ_CASE(7) HZ_CASE(8) HZ_CASE(10) HZ_CASE(12) HZ_CASE(16) HZ_CASE(18)
+        default: return NEFES_E_UNSUPPORTED;
+    }
+#undef HZ_CASE
+    return (int)hipGetLastError();
 }
 
-int main() {
-    unsigned* d_bad = nullptr;
-    if (hipMalloc(&d_bad, 4) != hipSuccess) { printf("no device\n"); return 1; }
-    const int blocks = 1024, iters = 200;
-    sweep<0>("raw_f32_v", "18", d_bad, blocks, iters);
-    sweep<1>("raw_f16_v", "12", d_bad, blocks, iters);
-    sweep<2>("raw_f16_a", "12", d_bad, blocks, iters);
-    sweep<3>("war_b", "-", d_bad, blocks, iters);
-    sweep<4>("war_c", "7", d_bad, blocks, iters);
-    sweep<5>("valu_b", "2", d_bad, blocks, iters);
-    sweep<6>("valu_c", "2", d_bad, blocks, iters);
-    sweep<7>("vcc_valu", "2", d_bad, blocks, iters);
-    sweep<8>("mfma_ab", "12", d_bad, blocks, iters);
-    sweep<9>("waw_v", "12", d_bad, blocks, iters);
-    sweep<10>("raw_f16_lds", "12", d_bad, blocks, iters);
-    hipFree(d_bad);
-    return 0;
+// `count` (device, one unsigned, zeroed by the caller) += lanes x repetitions whose result with K wait states between producer and consumer
+// differs from the result with the full distance.  test: 0 raw_f32_v, 1 raw_f16_v, 2 raw_f16_a, 3 war_b, 4 war_c, 5 valu_b, 6 valu_c,
+// 7 vcc_valu, 8 mfma_ab, 9 waw_v, 10 raw_f16_lds (the header comment above); K in {0..8, 10, 12, 16, 18}.
+extern "C" int nefes_probe_hazard(int test, int k, int blocks, int iters, unsigned* count, void* stream) {
+    if (!count || blocks <= 0 || iters <= 0) return NEFES_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (test) {
+        case 0: return launch_k<0>(k, count, blocks, iters, st);
+        case 1: return launch_k<1>(k, count, blocks, iters, st);
+        case 2: return launch_k<2>(k, count, blocks, iters, st);
+        case 3: return launch_k<3>(k, count, blocks, iters, st);
+        case 4: return launch_k<4>(k, count, blocks, iters, st);
+        case 5: return launch_k<5>(k, count, blocks, iters, st);
+        case 6: return launch_k<6>(k, count, blocks, iters, st);
+        case 7: return launch_k<7>(k, count, blocks, iters, st);
+        case 8: return launch_k<8>(k, count, blocks, iters, st);
+        case 9: return launch_k<9>(k, count, blocks, iters, st);
+        case 10: return launch_k<10>(k, count, blocks, iters, st);
+        default: return NEFES_E_UNSUPPORTED;
+    }
 }

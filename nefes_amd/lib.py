@@ -104,6 +104,7 @@ SIGNATURES = {
     "nefes_probe_mfma_clock": (_i, [_i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), _p]),
     "nefes_probe_store_hazard": (_i, [_p, C.c_int64, _i, _p]),
     "nefes_probe_pk_mul": (_i, [_p, C.c_int64, _i, _p]),
+    "nefes_probe_hazard": (_i, [_i, _i, _i, _i, _p, _p]),
     "nefes_probe_aggressor": (_i, [_i, _i, _i, _p, _p]),
     "nefes_train_rows": (_sz, [_desc]),
     "nefes_train_row_offset": (_i, [_desc, _i]),

@@ -203,3 +203,32 @@ def test_packed_fp32_op_sel_counts_next_to_field_kernels_are_recorded():
     assert counts["nothing"][0] == [0, 0, 0, 0], counts["nothing"]                       # never alone on the device
     for k, (t, _) in counts.items():
         assert t[1] == 0 and t[3] == 0, (k, t)                                           # never the [1,0] forms
+
+
+def test_wait_state_truth_table_of_this_gpu_is_recorded():
+    """csrc/hazard_probe.hip through nefes_probe_hazard: every producer -> consumer pair of tools/hazard_lint.py's table with K = 0 ... 18
+    wait states on every SIMD, counting wrong results.  RECORDED for whatever box runs it (parity log + a warning in the
+    test summary).  Asserted, because the library's padding and the notes rest on them: at LLVM's own distances nothing is ever wrong;
+    the fp32 MFMA's result, VCC and the operand overwrites are resolved by the hardware (right at K = 0); a 16-bit MFMA's result read
+    back to back is NOT (the obligation is real), and neither is a vector write of SrcB directly in front of its MFMA."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hazard_probe as HP
+    tab = HP.table(blocks=512, iters=100)
+    ks = HP.KS
+    text = "wait-state truth table (wrong lanes at K = " + ",".join(str(k) for k in ks) + "): " + "; ".join(
+        f"{name} [{' '.join(str(v) for v in row)}]" for name, row in tab.items())
+    print("[hazards] " + text)
+    for name, row in tab.items():
+        first_clean = next((k for k, v in zip(ks, row) if all(x == 0 for x in row[ks.index(k):])), None)
+        P.record("wait_state_truth_table", f"{name}: smallest probed K from which no result is wrong", direct=float(-1 if first_clean is None else first_clean),
+                 bound=float("inf"))
+    warnings.warn(UserWarning(text))
+    llvm = {"raw_f32_v": 18, "raw_f16_v": 12, "raw_f16_a": 12, "war_c": 8, "valu_b": 2, "valu_c": 2, "vcc_valu": 2, "mfma_ab": 12, "waw_v": 12,
+            "raw_f16_lds": 12}
+    for name, need in llvm.items():                                   # at the toolchain's own distance (and beyond) nothing is wrong
+        assert all(v == 0 for k, v in zip(ks, tab[name]) if k >= need), (name, tab[name])
+    for name in ("raw_f32_v", "war_b", "war_c", "valu_c", "vcc_valu", "mfma_ab"):           # resolved by the hardware
+        assert all(v == 0 for v in tab[name]), (name, tab[name])
+    assert tab["raw_f16_v"][0] > 0 and tab["raw_f16_a"][0] > 0 and tab["valu_b"][0] > 0 and tab["waw_v"][0] > 0      # real obligations

@@ -135,6 +135,7 @@ def test_operand_parsing():
 # kernels allowed to carry a finding, and why
 ALLOWED = {
     ("store_hazard_kernel<0>", "C6"): "csrc/probe.hip: the probe whose purpose is to overwrite a 16-byte store's data registers at once",
+    ("hazard_probe_kernel<", None): "csrc/hazard_probe.hip: every pair of the table with 0 ... 18 wait states, on purpose (DESIGN.md 4.10)",
 }
 
 
@@ -143,7 +144,7 @@ def test_shipped_library_has_no_unpadded_hazard():
     from nefes_amd import lib as L
     viol, kernels, insts = H.lint(L.LIB_PATH)
     assert kernels > 150 and insts > 1_000_000, (kernels, insts)                       # (the whole library was read)
-    bad = [v for v in viol if not any(k in v[0] and v[2] == r for (k, r) in ALLOWED)]
+    bad = [v for v in viol if not any(k in v[0] and (r is None or v[2] == r) for (k, r) in ALLOWED)]
     assert not bad, [(v[0][:80], hex(v[1]), v[2], f"need {v[3]} have {v[4]}", v[5], v[6]) for v in bad[:8]]
     # the probe's intended violation is still seen: the rule is alive on real disassembly
     assert any("store_hazard_kernel<0>" in v[0] and v[2] == "C6" for v in viol)

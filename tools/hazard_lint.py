@@ -33,7 +33,7 @@ Rules (R = wait states required between producer and consumer; N = passes of the
     C10 VALU write of an SGPR / VCC -> VALU reads it as a scalar operand (gfx940 "VALU / decoder co-execution")          R = 2
     C11 VALU write of a VGPR -> v_readlane / v_readfirstlane reads it  R = 1;  VALU write of EXEC -> v_read*lane / v_writelane  R = 4
 
-What MI355X itself requires, measured (tools/probe/hazard_probe.hip): B1 = 5 after an XDL MFMA (4 for an LDS store)
+What MI355X itself requires, measured (csrc/hazard_probe.hip): B1 = 5 after an XDL MFMA (4 for an LDS store)
 and nothing after the fp32 MFMA (interlocked), B2 = 8, A1 = 1 for SrcA / SrcB and nothing for SrcC, A3 / B3 / C10 interlocked.  The rules
 below stay at LLVM's numbers: a superset, and what compiler-placed code is padded to.
 
