@@ -8,7 +8,7 @@
    the net under the next schedule change.
 2. The packed-fp32 finding of round 5 (`v_pk_mul_f32 / v_pk_add_f32 op_sel:[0,1]` wrong on lanes 48-63 next to another
    queue's 16-bit K = 16 MFMA kernel) RECORDED on whatever box runs this: the counts go to the parity log and into a warning, so
-   that the driver's own run carries them.  Asserted: nothing wrong alone on the device, nothing wrong in the op_sel:[1,0] forms."""
+   that the driver's own run carries them.  Nothing about the hardware is asserted (a box that differs from rounds 5-6 is reported)."""
 import ctypes as C
 import warnings
 
@@ -200,17 +200,22 @@ def test_packed_fp32_op_sel_counts_next_to_field_kernels_are_recorded():
         P.record("packed_fp32_op_sel_probe", f"next to {k}: wrong low results of v_pk_mul_f32 / v_pk_add_f32 op_sel:[0,1] (of {each})",
                  direct=float(t[0] + t[2]), bound=float("inf"))
     warnings.warn(UserWarning(text))
-    assert counts["nothing"][0] == [0, 0, 0, 0], counts["nothing"]                       # never alone on the device
-    for k, (t, _) in counts.items():
-        assert t[1] == 0 and t[3] == 0, (k, t)                                           # never the [1,0] forms
+    # What every box so far has shown -- nothing wrong alone on the device, never the [1,0] forms -- is a statement about the hardware,
+    # not about this library: a box that differs is REPORTED, loudly, and does not stop the suite (the library's own bit-stability
+    # next to other streams is what tests/test_gpu_streams.py asserts).
+    odd = []
+    if counts["nothing"][0] != [0, 0, 0, 0]:
+        odd.append(f"wrong results ALONE on the device: {counts['nothing'][0]}")
+    odd += [f"[1,0] forms wrong next to {k}: {t}" for k, (t, _) in counts.items() if t[1] or t[3]]
+    if odd:
+        warnings.warn(UserWarning("packed-fp32 probe: THIS BOX DIFFERS FROM EVERY BOX OF ROUNDS 5-6 -- " + "; ".join(odd)))
 
 
 def test_wait_state_truth_table_of_this_gpu_is_recorded():
     """csrc/hazard_probe.hip through nefes_probe_hazard: every producer -> consumer pair of tools/hazard_lint.py's table with K = 0 ... 18
     wait states on every SIMD, counting wrong results.  RECORDED for whatever box runs it (parity log + a warning in the
-    test summary).  Asserted, because the library's padding and the notes rest on them: at LLVM's own distances nothing is ever wrong;
-    the fp32 MFMA's result, VCC and the operand overwrites are resolved by the hardware (right at K = 0); a 16-bit MFMA's result read
-    back to back is NOT (the obligation is real), and neither is a vector write of SrcB directly in front of its MFMA."""
+    test summary).  Asserted: at LLVM's own distances nothing is ever wrong (what the library's padding rests on).  Round 6's own
+    observations about the hardware are checked and a box that differs is reported, not failed."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -225,10 +230,14 @@ def test_wait_state_truth_table_of_this_gpu_is_recorded():
         P.record("wait_state_truth_table", f"{name}: smallest probed K from which no result is wrong", direct=float(-1 if first_clean is None else first_clean),
                  bound=float("inf"))
     warnings.warn(UserWarning(text))
-    llvm = {"raw_f32_v": 18, "raw_f16_v": 12, "raw_f16_a": 12, "war_c": 8, "valu_b": 2, "valu_c": 2, "vcc_valu": 2, "mfma_ab": 12, "waw_v": 12,
+    llvm = {"raw_f32_v": 18, "raw_f16_v": 12, "raw_f16_a": 12, "war_c": 7, "valu_b": 2, "valu_c": 2, "vcc_valu": 2, "mfma_ab": 12, "waw_v": 12,
             "raw_f16_lds": 12}
-    for name, need in llvm.items():                                   # at the toolchain's own distance (and beyond) nothing is wrong
-        assert all(v == 0 for k, v in zip(ks, tab[name]) if k >= need), (name, tab[name])
-    for name in ("raw_f32_v", "war_b", "war_c", "valu_c", "vcc_valu", "mfma_ab"):           # resolved by the hardware
-        assert all(v == 0 for v in tab[name]), (name, tab[name])
-    assert tab["raw_f16_v"][0] > 0 and tab["raw_f16_a"][0] > 0 and tab["valu_b"][0] > 0 and tab["waw_v"][0] > 0      # real obligations
+    for name, need in llvm.items():                                   # at the toolchain's own distance (and beyond) nothing is wrong:
+        assert all(v == 0 for k, v in zip(ks, tab[name]) if k >= need), (name, tab[name])     # what the library's padding rests on
+    # Round 6's table, as expectations about the HARDWARE: the fp32 MFMA's result, VCC and the operand overwrites resolved by the part
+    # itself (right at K = 0); a 16-bit MFMA's result read or overwritten back to back, and SrcB written directly in front of its MFMA,
+    # NOT.  A box that differs is reported, not failed: DESIGN.md 4.10's table is a measurement of the boxes it names.
+    odd = [f"{n} not clean at every K: {tab[n]}" for n in ("raw_f32_v", "war_b", "war_c", "valu_c", "vcc_valu", "mfma_ab") if any(tab[n])]
+    odd += [f"{n} right at K = 0" for n in ("raw_f16_v", "raw_f16_a", "valu_b", "waw_v", "raw_f16_lds") if tab[n][0] == 0]
+    if odd:
+        warnings.warn(UserWarning("wait-state truth table: THIS BOX DIFFERS FROM ROUND 6'S -- " + "; ".join(odd)))
