@@ -461,7 +461,9 @@ int nefes_probe_pk_mul(unsigned* out, int64_t n, int iters, void* stream);
  * every SIMD runs `iters` repetitions of one pair with K wait states in between; *count (device, zeroed by the caller) += the lanes x
  * repetitions whose result differs from the result with the full distance.  test: 0 fp32 MFMA result -> vector read, 1 / 2 16-bit MFMA
  * result -> v_mov / v_accvgpr_read, 3 / 4 MFMA read of SrcB / SrcC -> vector overwrite, 5 / 6 vector write of SrcB / SrcC -> MFMA,
- * 7 v_cmp VCC -> v_cndmask, 8 MFMA result -> next MFMA's SrcB, 9 MFMA result -> vector overwrite, 10 MFMA result -> ds_write;
+ * 7 v_cmp VCC -> v_cndmask, 8 MFMA result -> next MFMA's SrcB, 9 MFMA result -> vector overwrite, 10 MFMA result -> ds_write,
+ * 11 vector write -> v_permlane32_swap, 12 v_exp -> vector read, 13 vector write -> DPP read, 14 vector write -> v_readfirstlane,
+ * 15 v_accvgpr_write of SrcC -> MFMA;
  * K in {0 .. 8, 10, 12, 16, 18}. */
 int nefes_probe_hazard(int test, int k, int blocks, int iters, unsigned* count, void* stream);
 /* Diagnostic neighbour for nefes_probe_pk_mul: `blocks` workgroups of 256 run `iters` rounds of one instruction kind (0: v_fma_mixlo/hi_f16,

@@ -205,6 +205,74 @@ __device__ __forceinline__ void raw_f16_lds(unsigned a, unsigned b, unsigned lds
           "v50", "v51", "v52", "v53", "v54", "v55");
 }
 
+
+// ---- the vector-ALU-only rules of the linter (C4, C7, C9, C11, A1 through an AGPR) ------------------------------------------------
+// v_mov writes a register K wait states in front of v_permlane32_swap of it (old value = junk): LLVM 2
+template <int K>
+__device__ __forceinline__ void valu_swap(float x, float junk, float& early, float& late) {
+    asm volatile(
+        "v_mov_b32 v32, %3\n\tv_mov_b32 v33, %3\n\t" SETTLE
+        "v_mov_b32 v32, %2\n\t"
+        ".if %4 > 0\n\ts_nop %4-1\n\t.endif\n\t"
+        "v_permlane32_swap_b32 v32, v33\n\t" SETTLE
+        "v_add_f32 %0, v32, v33\n\t"
+        "v_mov_b32 v32, %2\n\tv_mov_b32 v33, %3\n\t" SETTLE
+        "v_permlane32_swap_b32 v32, v33\n\t" SETTLE
+        "v_add_f32 %1, v32, v33\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(x), "v"(junk), "n"(K) : "v32", "v33");
+}
+// transcendental result read by an ordinary vector instruction K wait states later: LLVM 1
+template <int K>
+__device__ __forceinline__ void trans_valu(float x, float junk, float& early, float& late) {
+    asm volatile(
+        "v_mov_b32 v32, %3\n\t" SETTLE
+        "v_exp_f32 v32, %2\n\t"
+        ".if %4 > 0\n\ts_nop %4-1\n\t.endif\n\t"
+        "v_add_f32 %0, v32, v32\n\t" SETTLE
+        "v_add_f32 %1, v32, v32\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(x), "v"(junk), "n"(K) : "v32");
+}
+// v_mov writes a register K wait states in front of a DPP instruction that reads it: LLVM 2
+template <int K>
+__device__ __forceinline__ void valu_dpp(float x, float junk, float& early, float& late) {
+    asm volatile(
+        "v_mov_b32 v32, %3\n\tv_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\t" SETTLE
+        "v_mov_b32 v32, %2\n\t"
+        ".if %4 > 0\n\ts_nop %4-1\n\t.endif\n\t"
+        "v_mov_b32_dpp %0, v32 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" SETTLE
+        "v_mov_b32_dpp %1, v32 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(x), "v"(junk), "n"(K) : "v32");
+}
+// v_mov writes a register K wait states in front of v_readfirstlane of it: LLVM 1
+template <int K>
+__device__ __forceinline__ void valu_readlane(float x, float junk, float& early, float& late) {
+    asm volatile(
+        "v_mov_b32 v32, %3\n\t" SETTLE
+        "v_mov_b32 v32, %2\n\t"
+        ".if %4 > 0\n\ts_nop %4-1\n\t.endif\n\t"
+        "v_readfirstlane_b32 s40, v32\n\t" SETTLE
+        "v_readfirstlane_b32 s41, v32\n\t"
+        "s_nop 3\n\tv_mov_b32 %0, s40\n\tv_mov_b32 %1, s41\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(x), "v"(junk), "n"(K) : "v32", "s40", "s41");
+}
+// v_accvgpr_write of the MFMA's SrcC (an AGPR tile) K wait states in front of it (old value = junk): LLVM 2
+template <int K>
+__device__ __forceinline__ void accw_c(unsigned a, unsigned b, float c, float junk, float& early, float& late) {
+    asm volatile(
+        ".irp r,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n\tv_accvgpr_write_b32 a\\r, %5\n\t.endr\n\t"
+        ".irp r,48,49,50,51\n\tv_mov_b32 v\\r, %2\n\t.endr\n\t.irp r,52,53,54,55\n\tv_mov_b32 v\\r, %3\n\t.endr\n\t" SETTLE
+        ".irp r,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n\tv_accvgpr_write_b32 a\\r, %4\n\t.endr\n\t"
+        ".if %6 > 16\n\ts_nop 15\n\ts_nop %6-17\n\t.elseif %6 > 0\n\ts_nop %6-1\n\t.endif\n\t"
+        "v_mfma_f32_32x32x16_f16 a[0:15], v[48:51], v[52:55], a[0:15]\n\t" SETTLE
+        "v_accvgpr_read_b32 %0, a15\n\t"
+        ".irp r,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n\tv_accvgpr_write_b32 a\\r, %4\n\t.endr\n\t" SETTLE
+        "v_mfma_f32_32x32x16_f16 a[0:15], v[48:51], v[52:55], a[0:15]\n\t" SETTLE
+        "v_accvgpr_read_b32 %1, a15\n\t"
+        : "=&v"(early), "=&v"(late) : "v"(a), "v"(b), "v"(c), "v"(junk), "n"(K)
+        : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "v48", "v49", "v50", "v51", "v52",
+          "v53", "v54", "v55");
+}
+
 template <int TEST, int K>
 __global__ __launch_bounds__(256) void hazard_probe_kernel(unsigned* __restrict__ bad, int iters) {
     const int lane = threadIdx.x & 63;
@@ -228,6 +296,11 @@ __global__ __launch_bounds__(256) void hazard_probe_kernel(unsigned* __restrict_
             __shared__ float buf[256];
             raw_f16_lds<K>(ha, hb, (unsigned)(size_t)(&buf[threadIdx.x]), e, l);
         }
+        if constexpr (TEST == 11) valu_swap<K>(fa + (float)lane, -77.f, e, l);
+        if constexpr (TEST == 12) trans_valu<K>(0.01f * (float)((lane + it) & 63), 5.f, e, l);
+        if constexpr (TEST == 13) valu_dpp<K>(fa + (float)lane, -77.f, e, l);
+        if constexpr (TEST == 14) valu_readlane<K>(fa + (float)it, -77.f, e, l);
+        if constexpr (TEST == 15) accw_c<K>(ha, hb, fa, 12345.f, e, l);
         n += (__float_as_uint(e) != __float_as_uint(l)) ? 1u : 0u;
     }
     atomicAdd(&bad[0], n);
@@ -246,7 +319,8 @@ static int launch_k(int k, unsigned* bad, int blocks, int iters, hipStream_t st)
 
 // `count` (device, one unsigned, zeroed by the caller) += lanes x repetitions whose result with K wait states between producer and consumer
 // differs from the result with the full distance.  test: 0 raw_f32_v, 1 raw_f16_v, 2 raw_f16_a, 3 war_b, 4 war_c, 5 valu_b, 6 valu_c,
-// 7 vcc_valu, 8 mfma_ab, 9 waw_v, 10 raw_f16_lds (the header comment above); K in {0..8, 10, 12, 16, 18}.
+// 7 vcc_valu, 8 mfma_ab, 9 waw_v, 10 raw_f16_lds (the header comment above), 11 valu_swap, 12 trans_valu, 13 valu_dpp, 14 valu_readlane,
+// 15 accw_c (vector-ALU-only rules, next to their definitions); K in {0..8, 10, 12, 16, 18}.
 extern "C" int nefes_probe_hazard(int test, int k, int blocks, int iters, unsigned* count, void* stream) {
     if (!count || blocks <= 0 || iters <= 0) return NEFES_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -262,6 +336,11 @@ extern "C" int nefes_probe_hazard(int test, int k, int blocks, int iters, unsign
         case 8: return launch_k<8>(k, count, blocks, iters, st);
         case 9: return launch_k<9>(k, count, blocks, iters, st);
         case 10: return launch_k<10>(k, count, blocks, iters, st);
+        case 11: return launch_k<11>(k, count, blocks, iters, st);
+        case 12: return launch_k<12>(k, count, blocks, iters, st);
+        case 13: return launch_k<13>(k, count, blocks, iters, st);
+        case 14: return launch_k<14>(k, count, blocks, iters, st);
+        case 15: return launch_k<15>(k, count, blocks, iters, st);
         default: return NEFES_E_UNSUPPORTED;
     }
 }

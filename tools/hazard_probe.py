@@ -13,7 +13,8 @@ TESTS = [("raw_f32_v   fp32 MFMA result -> vector read", 18), ("raw_f16_v   16-b
          ("war_b       MFMA read of SrcB -> vector overwrite", None), ("war_c       MFMA read of SrcC -> vector overwrite", 7),
          ("valu_b      vector write of SrcB -> MFMA", 2), ("valu_c      vector write of SrcC -> MFMA", 2), ("vcc_valu    v_cmp VCC -> v_cndmask", 2),
          ("mfma_ab     MFMA result -> next MFMA SrcB", 12), ("waw_v       MFMA result -> vector overwrite", 12),
-         ("raw_f16_lds MFMA result -> ds_write_b32", 12)]
+         ("raw_f16_lds MFMA result -> ds_write_b32", 12), ("valu_swap   vector write -> v_permlane32_swap", 2), ("trans_valu  v_exp -> vector read", 1),
+         ("valu_dpp    vector write -> DPP read", 2), ("valu_readlane vector write -> v_readfirstlane", 1), ("accw_c      v_accvgpr_write SrcC -> MFMA", 2)]
 KS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 18)
 
 
