@@ -409,7 +409,7 @@ def hbm_kernel_lines(kern, rays, Nc, Ni, Wd, C):
     for k, b in per_ray.items():
         if k in kern and kern[k] > 0:
             gbs = b * rays / (kern[k] * 1e-3) / 1e9
-            out[k] = {"ms": round(kern[k], 4), "algorithmic_bytes_per_ray": b, "GB/s": round(gbs, 1), "frac_of_8TB/s": round(gbs / 8000.0, 4)}
+            out[k] = {"ms": round(kern[k], 4), "algorithmic_bytes_per_ray": b, "GB/s": round(gbs, 3), "frac_of_8TB/s": round(gbs / 8000.0, 6)}
     return out
 
 

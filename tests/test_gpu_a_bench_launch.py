@@ -70,7 +70,7 @@ def test_ranks_through_the_self_launcher_match_one_rank(ranks, size):
     for key in ("all_reduce_ms_device_mean_by_rank", "all_reduce_ms_device_max_by_rank", "all_reduce_ms_host_call_mean_by_rank",
                 "sustained_clock_ghz_by_rank", "sustained_16bit_mfma_tflops_by_rank"):
         assert len(m[key]) == ranks, (key, m[key])
-    assert m["all_reduces_per_rank"] == 1 and all(t > 0 for t in m["all_reduce_ms_device_mean_by_rank"])
+    assert m["all_reduces_per_rank"] == 1 and all(t >= 0 for t in m["all_reduce_ms_device_mean_by_rank"])
     # (N ranks SHARE this box's one GPU: each rank's probe sees a fraction of the clock -- 0.4 ... 1.7 GHz -- ; one rank per GPU reads 1.6-1.7)
     assert all(0.0 < c < 3.0 for c in m["sustained_clock_ghz_by_rank"]), m["sustained_clock_ghz_by_rank"]
     assert m["collective_library"]["backend"] == "gloo" and "topology" in m
@@ -78,7 +78,10 @@ def test_ranks_through_the_self_launcher_match_one_rank(ranks, size):
     # every line: the HBM-bound kernels against 8 TB/s and the whole step against the dominant kernel's bound
     for j in (j1, jn):
         hb = j["roofline"]["hbm_kernels"]
-        assert {"composite_fwd", "composite_bwd", "coarse_sample"} <= set(hb) and all(0 < v["frac_of_8TB/s"] < 1.2 for v in hb.values()), hb
+        # (N ranks sharing ONE GPU are time-sliced: a rank's kernel "duration" then includes other ranks' kernels and its GB/s can be
+        # anything small -- only the fields and their upper bound are checked here)
+        assert {"composite_fwd", "composite_bwd", "coarse_sample"} <= set(hb), hb
+        assert all(v["ms"] > 0 and v["algorithmic_bytes_per_ray"] > 0 and 0 <= v["frac_of_8TB/s"] < 1.2 for v in hb.values()), hb
         assert 0 < j["roofline"]["end_to_end_frac"] < 1.0 and j["roofline"]["end_to_end_vs_fp32_mfma_peak"] > 0
 
 

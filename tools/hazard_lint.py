@@ -566,11 +566,14 @@ def main():
     path = args[0] if args and os.path.exists(args[0]) else os.path.join(root, "nefes_amd", "libnefes_hip.so")
     flt = args[-1] if args and not os.path.exists(args[-1]) else ""
     viol, nk, ni = lint(path, flt)
+    # the probes that exist to violate a rule (csrc/probe.hip store_hazard_kernel<0>, csrc/hazard_probe.hip): counted, not listed
+    probes = [v for v in viol if "hazard_probe_kernel<" in v[0] or ("store_hazard_kernel<0>" in v[0] and v[2] == "C6")]
+    viol = [v for v in viol if v not in probes]
     by = collections.Counter((v[0][:100], v[2]) for v in viol)
     for (k, rule), n in sorted(by.items()):
         ex = next(v for v in viol if v[0][:100] == k and v[2] == rule)
         print(f"{rule:4s} x{n:<5d} {k}\n       e.g. {ex[1]:#x}: need {ex[3]}, have {ex[4]}:  {ex[5]}   ->   {ex[6]}")
-    print(f"{nk} kernels, {ni} instructions, {len(viol)} violations")
+    print(f"{nk} kernels, {ni} instructions, {len(viol)} violations (+ {len(probes)} in the probe kernels that exist to violate a rule)")
     return 1 if viol else 0
 
 
