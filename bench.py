@@ -383,8 +383,13 @@ def multi_gpu_diagnostics(dist, dev, world, rank, ar_times, a):
         out["collective_library"] = {"error": str(e)}
     try:                                                            # link types / hops between the node's GPUs (a child process; never an exec)
         import subprocess
-        r = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showtopotype", "--showtopohops", "--csv"], capture_output=True, text=True, timeout=30)
-        out["topology"] = [ln for ln in r.stdout.splitlines() if ln.strip()][:40]
+        topo = []
+        for cmd in (["/opt/rocm/bin/rocm-smi", "--showtopo"], ["/opt/rocm/bin/amd-smi", "topology"]):      # (the --csv form prints nothing on this image)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=60)
+            topo = [ln.rstrip() for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("WARNING")]
+            if len(topo) > 3:
+                break
+        out["topology"] = topo[:80]
     except Exception as e:
         out["topology"] = f"unavailable: {e}"
     if (a.workload, a.height, a.width) == ("metric", 0, 0) and world in SHARD_MS_ONE_GPU:
@@ -441,8 +446,19 @@ def main():
     one_gpu = os.environ.get("NEFES_BENCH_ONE_GPU", "0") == "1"
     dev_index = 0 if (world == 1 or one_gpu) else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    # NEFES_BENCH_FORCE_GROUP=1: a ONE-rank run still builds the process group and goes through every collective of the N-rank code
+    # path (barrier, the pose-gradient all-reduce with its events, the gathers of the diagnostics) -- the RCCL calls of an 8-GPU run
+    # exercised on a single-GPU box (tests/test_gpu_a_bench_launch.py); a functional check, never a measurement.
+    grouped = world > 1 or os.environ.get("NEFES_BENCH_FORCE_GROUP", "0") == "1"
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("NEFES_BENCH_BACKEND", "nccl")          # "nccl" = RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -452,6 +468,7 @@ def main():
 
     from nefes_amd import dist as D
     from nefes_amd import lib as L, ops
+    D.ONE_RANK_COLLECTIVES = grouped and world == 1
     from nefes_amd.field import NeRFH_NFF
     from nefes_amd.render import render
 
@@ -524,7 +541,7 @@ def main():
         return c2w.grad
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -532,7 +549,7 @@ def main():
         step()
     barrier()
     ops.TIMERS = {}
-    D.ALLREDUCE_TIMES = [] if world > 1 else None
+    D.ALLREDUCE_TIMES = [] if grouped else None
     t0 = time.perf_counter()
     trace = os.environ.get("NEFES_BENCH_TRACE", "0") == "1"           # debugging: host time of every step (adds a sync per step)
     for _ in range(a.steps):
@@ -551,7 +568,7 @@ def main():
     ar_times, D.ALLREDUCE_TIMES = D.ALLREDUCE_TIMES, None
     rank_ms = [dt / a.steps * 1e3]
     multi = None
-    if world > 1:
+    if grouped:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(tmax) for _ in range(world)]
         dist.all_gather(every, tmax)                                  # per-rank step time (min / max over ranks in the line)
@@ -598,8 +615,8 @@ def main():
         out = {
             "metric": "rays/s (fwd+bwd) at 640x480x(64+128) samples, 8x256 MLP" if a.workload == "metric"
                       else f"rays/s (fwd+bwd), secondary workload '{a.workload}'", "value": value, "unit": "rays/s",
-            "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1,
-            "collective_backend": (dist.get_backend() if world > 1 else None), "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "n_gpus": world, "world_size": dist.get_world_size() if grouped else 1,
+            "collective_backend": (dist.get_backend() if grouped else None), "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "matrix_core_arithmetic": "fp16 two-part split (3 products)" if h3 else ("bf16x6" if x6 else "fp32 MFMA"),
             "data": "synthetic",
@@ -656,7 +673,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(Wd, C, Nc, Ni, a.cpu_rows, W, focal)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -21,6 +21,9 @@ def row_shard(H: int, rank: int, world: int):
 # Diagnostics of the one collective (bench.py sets this to a list for its timed region): per all-reduce a pair of events recorded on
 # the current stream around the call (device time the stream spends in / waiting for the collective) and the host time of the call.
 ALLREDUCE_TIMES = None
+# True: a group of ONE rank still issues the all-reduce (an identity) -- how bench.py's NEFES_BENCH_FORCE_GROUP=1 takes the multi-rank
+# code path through RCCL on a single-GPU box (tests/test_gpu_a_bench_launch.py)
+ONE_RANK_COLLECTIVES = False
 
 
 class _PoseGradAllReduce(torch.autograd.Function):
@@ -32,7 +35,7 @@ class _PoseGradAllReduce(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous().clone()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(ctx.group) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(ctx.group) > 1 or ONE_RANK_COLLECTIVES):
             rec = ALLREDUCE_TIMES
             if rec is not None and g.is_cuda:
                 import time

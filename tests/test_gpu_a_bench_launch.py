@@ -110,3 +110,36 @@ def test_launcher_started_ranks_must_match_gpus():
 def test_more_gpus_than_the_node_has_is_refused_with_exit_code_2():
     r, j = bench(["--gpus", "64"] + SMALL, {"NEFES_BENCH_ONE_GPU": "0"})
     assert r.returncode == 2 and j is None and "refusing" in r.stderr
+
+
+def test_the_n_rank_code_path_of_bench_through_rccl_under_the_drivers_launcher():
+    """The driver's own N > 1 command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with N = 1 and NEFES_BENCH_FORCE_GROUP=1: the process group is RCCL (`nccl`, bound to the
+    device at init), and the run goes through every collective an 8-GPU run makes (barriers, the pose-gradient all-reduce inside
+    backward with its events, the gathers of the per-rank times and diagnostics, the MAX of the step time).  The gradient of a group of
+    one equals the plain run's bit for bit.  What stays unshown here: more than one rank over xGMI."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, NEFES_BENCH_FORCE_GROUP="1", OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "NEFES_BENCH_BACKEND", "NEFES_BENCH_ONE_GPU"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--height", "48", "--width", "64", "--cpu-rows", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900, close_fds=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and lines, (r.stdout[-1000:], r.stderr[-3000:])
+    j = json.loads(lines[-1])
+    assert j["n_gpus"] == 1 and j["world_size"] == 1 and j["collective_backend"] == "nccl" and j["steps"] == 2
+    m = j["multi_gpu"]
+    assert m["all_reduces_per_rank"] == 2 and m["collective_library"]["backend"] == "nccl"
+    assert len(m["collective_library"]["nccl_version"].split(".")) >= 2, m["collective_library"]
+    assert any("GPU0" in ln or "SELF" in ln for ln in m["topology"]), m["topology"]          # the node's link table made it into the line
+    assert len(m["all_reduce_ms_device_mean_by_rank"]) == 1 and 0 <= m["all_reduce_ms_device_mean_by_rank"][0] < 50.0, m
+    assert 1.0 < m["sustained_clock_ghz_by_rank"][0] < 3.0, m               # one rank on its own GPU: the real sustained clock
+    assert len(j["ms_per_step_by_rank"]["all"]) == 1
+    r1, j1 = bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--height", "48", "--width", "64", "--cpu-rows", "0"], {})
+    assert r1.returncode == 0 and j1 is not None, r1.stderr[-2000:]
+    assert j1["pose_grad"] == j["pose_grad"]                                # all-reduce over one rank: the identity
