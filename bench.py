@@ -378,7 +378,8 @@ def multi_gpu_diagnostics(dist, dev, world, rank, ar_times, a):
            "note": "all_reduce device time = events on the compute stream around the call: it includes waiting for the slowest rank to arrive"}
     try:
         out["collective_library"] = {"backend": dist.get_backend(), "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()),
-                                     "env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))}}
+                                     "env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
+                                     "loaded_from": sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "rccl" in ln or "nccl" in ln})[:4]}
     except Exception as e:
         out["collective_library"] = {"error": str(e)}
     try:                                                            # link types / hops between the node's GPUs (a child process; never an exec)
