@@ -385,7 +385,9 @@ class PoseRefiner:
         params = [p for p in self.apr.parameters() if p.requires_grad]
         # loss.backward() in the reference (train_on_batch, DFM_pose_refine.py:318) tolerates parameters the loss never touches --
         # DFNet's adaptation_layers with return_feature=False (feature/dfnet.py:142): their .grad stays None and Adam skips them
-        for p, g in zip(params, torch.autograd.grad(loss, params, allow_unused=True)):
+        if getattr(self, "_one", None) is None or self._one.shape != loss.shape:
+            self._one = torch.ones_like(loss)              # the root gradient, once (as loss_and_grad does)
+        for p, g in zip(params, torch.autograd.grad(loss, params, grad_outputs=self._one, allow_unused=True)):
             p.grad = g
         self.loss.copy_(loss.detach())
         return self.loss
