@@ -154,15 +154,13 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
         with torch.no_grad():
             raw_c = _field(pk_c, L.FIELD_SIGMA, rays_o.detach(), rays_d.detach(), viewdirs.detach(), z, cfg.xyz_encoder)
             if cfg.raw_noise_std > 0.:
-                raw_c = raw_c + torch.randn_like(raw_c) * cfg.raw_noise_std
+                raw_c = raw_c + _noise(raw_c.shape, dev) * cfg.raw_noise_std
             _, _, _, acc0, _, w0, _ = ops.composite_fwd(raw_c, z, C, L.COMP_SIGMA_ONLY)
         rgb0 = feat0 = disp0 = None
     else:
         raw_c = field(network_fn, pk_c, L.FIELD_STATIC, z)
         if cfg.raw_noise_std > 0.:
-            noise = torch.zeros_like(raw_c)
-            noise[:, 3 + C] = torch.randn(N, Nc, device=dev) * cfg.raw_noise_std
-            raw_c = raw_c + noise
+            raw_c = _with_density_noise(raw_c, C, cfg.raw_noise_std)
         rgb0, feat0, disp0, acc0, _, w0, _ = ops.Composite.apply(raw_c, z, C, 0, 0.1)
     if Ni == 0:
         if cfg.test_time:
@@ -176,6 +174,19 @@ def _render_core(rays_o, rays_d, viewdirs, near, far, network_fn, network_fine, 
     u = None if cfg.perturb == 0. else torch.rand(N, Ni, device=dev)
     z_fine, z_samples = ops.sample_pdf_merge(z, w0.detach(), Ni, u=u)
     return _fine_pass(rays_o, rays_d, viewdirs, z_fine, z_samples, network_fine, cfg, C, field, (rgb0, feat0, disp0, acc0))
+
+
+def _noise(shape, device):
+    """torch.randn_like(static_sigmas) of raw2outputs_NeRFH_NFF (nerfh_nff.py:67); a function of its own so that a test can put a
+    known tensor in its place (the device's generator and the reference's CPU generator share no stream)."""
+    return torch.randn(tuple(shape), device=device)
+
+
+def _with_density_noise(raw, C, std):
+    """raw [N, R, S] channel-major with the static density at channel 3 + C: density + randn * std (nerfh_nff.py:67-68)."""
+    noise = torch.zeros_like(raw)
+    noise[:, 3 + C] = _noise((raw.shape[0], raw.shape[2]), raw.device) * std
+    return raw + noise
 
 
 def _fine_pass(rays_o, rays_d, viewdirs, z_fine, z_samples, network_fine, cfg, C, field, coarse_maps):
@@ -206,6 +217,10 @@ def _fine_pass(rays_o, rays_d, viewdirs, z_fine, z_samples, network_fine, cfg, C
     pk_f = network_fine.packed()
     mode = L.FIELD_FULL if cfg.NeRFW else L.FIELD_STATIC
     raw_f = field(network_fine, pk_f, mode, z_f)
+    if cfg.raw_noise_std > 0. and not cfg.NeRFW:
+        # the reference draws the noise in every composite WITHOUT the transient head (nerfh_nff.py:66-68) -- the coarse pass above and a
+        # fine network with NeRFW off; with the transient head the line is not reached (:61-64)
+        raw_f = _with_density_noise(raw_f, C, cfg.raw_noise_std)
     if cfg.NeRFW:
         flags |= L.COMP_TRANSIENT
         if cfg.test_time and not cfg.transient_at_test:

@@ -384,3 +384,56 @@ def test_bicubic_upsample_matches_torch(shape, size):
     y.backward(go.cuda())
     assert torch.allclose(y.detach().cpu().double(), yr.detach(), rtol=0, atol=2e-6 * float(yr.detach().abs().max()))
     assert torch.allclose(xg.grad.cpu().double(), xr.grad, rtol=0, atol=2e-6 * float(xr.grad.abs().max()))
+
+
+def _known_noise(shape, device="cpu", dtype=torch.float32):
+    """A fixed 'draw': a function of the element index only, so the coarse [N, Nc] and the fine [N, Nc + Ni] draws of both
+    implementations agree whatever their shapes' rank."""
+    n = int(np.prod(tuple(shape)))
+    return torch.sin(0.37 * torch.arange(n, dtype=torch.float64) + 1.0).reshape(tuple(shape)).to(dtype).to(device)
+
+
+@pytest.mark.parametrize("case", ["train_mode_nerfw", "train_mode_nerfw_off", "test_time"])
+def test_raw_noise_std_reaches_the_static_density_where_the_reference_draws_it(case, monkeypatch):
+    """raw2outputs_NeRFH_NFF adds `randn_like(static_sigmas) * raw_noise_std` to the static density of every composite WITHOUT the
+    transient head (nerfh_nff.py:66-68): the coarse pass in both modes and a fine network with NeRFW off; with the transient head the
+    line is not reached (:61-64).  The draw itself is the generator's (device vs CPU streams share nothing), so both sides get the same
+    known tensor in its place; maps, extras and the branch-pinned pose gradient then follow the usual rules."""
+    from nefes_amd import render as RR
+    R, M, RU = dropin()
+    coarse, fine = nets(128, 16)
+    pc, pf = oracle_params(128, 16)
+    H, W, f, std = 3, 4, 3.0, 0.1
+    test_time, nerfw = case == "test_time", case != "train_mode_nerfw_off"
+    kw = kwargs(coarse, fine, Ni=64, test_time=test_time, tat=True)
+    kw["raw_noise_std"] = std
+    kw["args"].NeRFW = nerfw
+    monkeypatch.setattr(RR, "_noise", lambda shape, device: _known_noise(shape, device))
+    monkeypatch.setattr(torch, "randn_like", lambda t, **k: _known_noise(t.shape, t.device, t.dtype))
+    c2w = O.bench_pose().to(DEV).requires_grad_()
+    with B.tapped() as tap:
+        rgb, disp, acc, ex = R.render(H, W, f, c2w=c2w, near=0., far=4., **kw)
+    cfg = O.RenderCfg(N_samples=64, N_importance=64, test_time=test_time, transient_at_test=True, NeRFW=nerfw, raw_noise_std=std)
+    r_rgb, r_disp, r_acc, r_ex = O.render(H, W, f, pc, pf, cfg, c2w=O.bench_pose(), near=0., far=4.)
+    assert rel(rgb, r_rgb) < 1e-4 and rel(disp, r_disp) < 1e-4 and rel(acc, r_acc) < 1e-4
+    assert set(ex) == set(r_ex)
+    for k in r_ex:
+        assert rel(ex[k], r_ex[k]) < 1e-4, k
+    # ... and the noise is really in there: the same call without it gives other maps
+    kw0 = dict(kw, raw_noise_std=0.)
+    with torch.no_grad():
+        rgb_0, _, acc_0, _ = R.render(H, W, f, c2w=O.bench_pose().to(DEV), near=0., far=4., **kw0)
+    assert rel(rgb, rgb_0) > 1e-5            # (through the fine samples' positions only where the fine pass has its transient head: 7e-4 here)
+    O.bench_loss(rgb, ex["feat_map"]).backward()
+
+    def oracle_run(dt, act, zf):
+        c = O.bench_pose(dt).requires_grad_()
+        r, _, _, e = O.render(H, W, f, O.make_field_params("coarse", 128, 16, dtype=dt), O.make_field_params("fine", 128, 16, dtype=dt),
+                              cfg, c2w=c, near=0., far=4., fine_act=act, z_fine=zf)
+        return {"d c2w": torch.autograd.grad(O.bench_loss(r, e["feat_map"]), c)[0]}
+
+    if test_time:          # (train mode differentiates through the coarse pass too; its branch pattern is not tapped here)
+        B.pinned_gradients(f"raw_noise[{case}]", {"d c2w": c2w.grad}, tap, 128, oracle_run)
+    else:
+        e = rel(c2w.grad, oracle_run(torch.float64, None, None)["d c2w"])
+        assert e < 2e-2, e
