@@ -495,6 +495,8 @@ def main():
         sec2e, _, _ = refinement_loop(dev, graph=False, mode="2")
         sec2, _, err2 = refinement_loop(dev, graph=True, mode="2")
         sec2s, _, err2s = refinement_loop(dev, graph=True, mode="2", streams=2)
+        sec2s4, _, err2s4 = refinement_loop(dev, graph=True, mode="2", streams=4)
+        sec_s4, _, _ = refinement_loop(dev, graph=True, streams=4)
         print(json.dumps({"metric": "rays/s (fwd+bwd), secondary workload 'loop50'", "value": rays / sec, "unit": "rays/s",
                           "n_gpus": 1, "higher_is_better": True,
                           "dtype": "f32",
@@ -506,7 +508,9 @@ def main():
                           "ms_per_image_50_iterations_mode3": sec3 * 1e3, "ms_per_image_50_iterations_mode2": sec2 * 1e3,
                           "ms_per_image_50_iterations_mode2_eager": sec2e * 1e3,
                           "ms_per_image_50_iterations_mode2_2_images_on_2_streams": sec2s * 1e3,
-                          "pose_error_m_deg_after_50_iterations": {"mode3": err3, "mode2": err2, "mode2_2_streams": err2s, "upsampled_loss_learnpose": err_up,
+                          "ms_per_image_50_iterations_mode2_4_images_on_4_streams": sec2s4 * 1e3,
+                          "ms_per_image_50_iterations_4_images_on_4_streams": sec_s4 * 1e3,
+                          "pose_error_m_deg_after_50_iterations": {"mode3": err3, "mode2": err2, "mode2_2_streams": err2s, "mode2_4_streams": err2s4, "upsampled_loss_learnpose": err_up,
                                                                    "reference_from": "tests/golden/refine50_60x80.npz: the reference's own DFM_optimization_NFF / "
                                                                                      "train_on_batch on the CPU from the same start"},
                           "config": {"workload": "BASELINE configs[4] minus the DFNet CNN, on the scene of tests/golden/refine50_60x80.npz: 50 x "
