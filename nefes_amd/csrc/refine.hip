@@ -737,7 +737,83 @@ __global__ __launch_bounds__(256) void upcos_gram_bwd_kernel(int C, long P, doub
     g_x[idx] = (float)(k1 * tt[idx] - k2 * pmat[idx]);
 }
 
+// ---- verification step of train_on_batch (DFM_APR_refine.py:117-128, :146-150): PSNR and mean SSIM of two [C,H,W] images --------------
+// SSIM = utils/utils.py:15-49: 7x7 mean filters (nn.AvgPool2d(7, 1)) over the ReflectionPad2d(3) images, clamp(n / d, 0, 1).  In torch
+// that is two pads, five pools and ~15 element-wise launches per call; here one thread per pixel sums its 49-pixel windows of x, y,
+// x^2, y^2, xy (fp32, row-major, then / 49 as avg_pool2d does), float64 block partials, one fixed-order final.  x, y: [C] planes of
+// H x W with a row and a plane stride in elements, so the loop's 10-pixel crop is a view, not a copy.
+constexpr int kSsimBlock = 256;
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__global__ __launch_bounds__(kSsimBlock) void psnr_ssim_partial_kernel(int C, int H, int W, const float* __restrict__ x, long xr, long xc,
+                                                                       const float* __restrict__ y, long yr, long yc,
+                                                                       double* __restrict__ part) {        // part [blocks][2]
+    const long P = (long)H * W, n = (long)C * P;
+    double s_ssim = 0, s_se = 0;
+    for (long i = (long)blockIdx.x * kSsimBlock + threadIdx.x; i < n; i += (long)gridDim.x * kSsimBlock) {
+        const int c = (int)(i / P), r = (int)((i % P) / W), q = (int)(i % W);
+        const float* px = x + c * xc;
+        const float* py = y + c * yc;
+        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+        for (int dr = -3; dr <= 3; ++dr) {
+            const int rr = reflect_idx(r + dr, H);
+#pragma unroll
+            for (int dq = -3; dq <= 3; ++dq) {
+                const int qq = reflect_idx(q + dq, W);
+                const float a = px[rr * xr + qq], b = py[rr * yr + qq];
+                sx += a; sy += b;
+                sxx = __fadd_rn(sxx, __fmul_rn(a, a)); syy = __fadd_rn(syy, __fmul_rn(b, b)); sxy = __fadd_rn(sxy, __fmul_rn(a, b));
+            }
+        }
+        const float k = 49.f;
+        const float mx = sx / k, my = sy / k;
+        const float vx = __fsub_rn(sxx / k, __fmul_rn(mx, mx)), vy = __fsub_rn(syy / k, __fmul_rn(my, my)),
+                    vxy = __fsub_rn(sxy / k, __fmul_rn(mx, my));
+        const float c1 = (float)(0.01 * 0.01), c2 = (float)(0.03 * 0.03);      // (Python's 0.01 ** 2 as the fp32 scalar torch makes of it)
+        const float nn = __fmul_rn(__fadd_rn(__fmul_rn(__fmul_rn(2.f, mx), my), c1), __fadd_rn(__fmul_rn(2.f, vxy), c2));
+        const float dd = __fmul_rn(__fadd_rn(__fadd_rn(__fmul_rn(mx, mx), __fmul_rn(my, my)), c1), __fadd_rn(__fadd_rn(vx, vy), c2));
+        float v = nn / dd;
+        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);          // (NaN stays NaN, as torch.clamp leaves it)
+        s_ssim += (double)v;
+        const float e = __fsub_rn(px[r * xr + q], py[r * yr + q]);
+        s_se += (double)__fmul_rn(e, e);
+    }
+    __shared__ double sh[2][kSsimBlock];
+    sh[0][threadIdx.x] = s_ssim; sh[1][threadIdx.x] = s_se;
+    __syncthreads();
+    for (int s2 = kSsimBlock / 2; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) { sh[0][threadIdx.x] += sh[0][threadIdx.x + s2]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s2]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[blockIdx.x * 2] = sh[0][0]; part[blockIdx.x * 2 + 1] = sh[1][0]; }
+}
+// out[0] = psnr = -10 log10(mean squared error) (models/nerfh.py mse2psnr(img2mse(.))), out[1] = mean SSIM
+__global__ void psnr_ssim_final_kernel(int blocks, double n, const double* __restrict__ part, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    double a = 0, b = 0;
+    for (int i = 0; i < blocks; ++i) { a += part[i * 2]; b += part[i * 2 + 1]; }
+    out[0] = (float)(-10.0 * log(b / n) / log(10.0));
+    out[1] = (float)(a / n);
+}
+int psnr_ssim_blocks(int C, int H, int W) {
+    const long n = (long)C * H * W, b = (n + kSsimBlock - 1) / kSsimBlock;
+    return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
 }  // namespace
+
+extern "C" size_t nefes_psnr_ssim_workspace(int C, int H, int W) {
+    return C > 0 && H > 0 && W > 0 ? (size_t)psnr_ssim_blocks(C, H, W) * 2 * sizeof(double) : 0;
+}
+extern "C" int nefes_psnr_ssim(int C, int H, int W, const float* x, int64_t x_row_stride, int64_t x_plane_stride, const float* y,
+                               int64_t y_row_stride, int64_t y_plane_stride, void* workspace, float* out, void* stream) {
+    if (C <= 0 || H < 4 || W < 4 || !x || !y || !workspace || !out || x_row_stride < W || y_row_stride < W) return NEFES_E_BADARG;   // (reflection by 3 needs 4 pixels)
+    const int nb = psnr_ssim_blocks(C, H, W);
+    hipLaunchKernelGGL(psnr_ssim_partial_kernel, dim3(nb), dim3(kSsimBlock), 0, (hipStream_t)stream, C, H, W, x, (long)x_row_stride,
+                       (long)x_plane_stride, y, (long)y_row_stride, (long)y_plane_stride, (double*)workspace);
+    hipLaunchKernelGGL(psnr_ssim_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, nb, (double)C * H * W, (const double*)workspace, out);
+    return (int)hipGetLastError();
+}
 
 extern "C" int nefes_upcos_loss_fwd(int C, int h, int w, int OH, int OW, int crop, const float* x, const float* target, double* scratch,
                                     float* loss, void* stream) {

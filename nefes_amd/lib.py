@@ -120,6 +120,8 @@ SIGNATURES = {
     "nefes_bicubic_up_bwd": (_i, [C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "nefes_pose_compose_fwd": (_i, [_i, _p, _p, _p, C.c_float, C.POINTER(C.c_float), C.c_float, _p, _p]),
     "nefes_pose_compose_bwd": (_i, [_i, _p, _p, _p, C.c_float, C.POINTER(C.c_float), C.c_float, _p, _p, _p, _p]),
+    "nefes_psnr_ssim_workspace": (_sz, [_i, _i, _i]),
+    "nefes_psnr_ssim": (_i, [_i, _i, _i, _p, C.c_int64, C.c_int64, _p, C.c_int64, C.c_int64, _p, _p, _p]),
     "nefes_cosine_loss_scratch_doubles": (_sz, [_i]),
     "nefes_cosine_loss_fwd": (_i, [_i, C.c_int64, _p, _p, _p, _p, _p]),
     "nefes_cosine_loss_bwd": (_i, [_i, C.c_int64, _p, _p, _p, _p, _p, _p]),

@@ -1249,6 +1249,26 @@ def cosine_feature_loss(a, b, return_cos=False):
     return (loss, cos) if return_cos else loss
 
 
+def psnr_ssim(x, y):
+    """The verification step's two numbers (DFM_APR_refine.py:117-128, :146-150) of two [C,H,W] fp32 images on the GPU:
+    (mse2psnr(img2mse(x, y)), SSIM()(x, y).mean()) as 0-d tensors -- two launches (csrc/refine.hip psnr_ssim_*) where the torch
+    expressions take ~25.  Rows must be dense (stride 1 along W); row and plane strides are free, so a cropped view is not copied."""
+    for name, t in (("x", x), ("y", y)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.stride(2) == 1):
+            raise RuntimeError(f"nefes_amd: psnr_ssim: `{name}` must be a [C,H,W] float32 GPU tensor with dense rows (got {tuple(t.shape)}, "
+                               f"strides {t.stride()}, {t.dtype}, {t.device})")
+    if x.shape != y.shape:
+        raise RuntimeError(f"nefes_amd: psnr_ssim: shapes differ ({tuple(x.shape)} vs {tuple(y.shape)})")
+    lib = L.load()
+    Cc, H, W = (int(v) for v in x.shape)
+    ws = torch.empty(lib.nefes_psnr_ssim_workspace(Cc, H, W), dtype=torch.uint8, device=x.device)
+    out = torch.empty(2, device=x.device)
+    x, y = x.detach(), y.detach()
+    L.check(lib.nefes_psnr_ssim(Cc, H, W, C.c_void_p(x.data_ptr()), x.stride(1), x.stride(0), C.c_void_p(y.data_ptr()), y.stride(1),
+                                y.stride(0), _chk(ws, "workspace", torch.uint8), _chk(out, "out"), _stream()), "nefes_psnr_ssim")
+    return out[0], out[1]
+
+
 _GATHER_TABLES = {}
 
 

@@ -115,6 +115,7 @@ class PoseRefiner:
     # Mode 2: svd_reg + fix_coord_supp behind the regression network as one launch each way (ops.regressed_pose).  False: ops.svd_reg
     # followed by fix_coord_supp's torch expression (the tests compare the two and tap the pose in between).
     FUSED_REGRESSED_POSE = True
+    FUSED_VERIFICATION = True       # PSNR + SSIM of the verification step as ops.psnr_ssim (False: the torch expressions)
 
     def __init__(self, render_kwargs, args, hwf, near, far, tinyscale=4, lr_r=0.01, lr_t=0.1, lietorch=False,
                  upsample=False, per_pixel=False, world_setup=None, graph=True, device="cuda", adam_capturable=None,
@@ -402,9 +403,13 @@ class PoseRefiner:
             img = self._rgb.reshape(1, self.h, self.w, 3).permute(0, 3, 1, 2)
         img = nn.functional.interpolate(img, size=(self.H, self.W), mode="bicubic")[:, :, 10:-10, 10:-10]
         gt = self.photo[:, :, 10:-10, 10:-10]
-        if as_tensors:                                     # (no host read: refine_apr_concurrently converts after its last replay)
-            return mse2psnr(img2mse(img, gt)).reshape(()), ssim_map(img, gt).mean().reshape(())
-        return float(mse2psnr(img2mse(img, gt))), float(ssim_map(img, gt).mean())
+        if self.fused_glue and self.FUSED_VERIFICATION and img.is_cuda and img.dtype == torch.float32 and img.shape[0] == 1:
+            ps, ss = ops.psnr_ssim(img[0], gt[0])          # two launches for PSNR + SSIM (torch: ~25); the crops stay views
+        else:
+            ps, ss = mse2psnr(img2mse(img, gt)).reshape(()), ssim_map(img, gt).mean().reshape(())
+        if as_tensors:                                     # (no host read: the callers convert after their last replay)
+            return ps, ss
+        return float(ps), float(ss)
 
     def predicted_pose(self, net=None):
         """inference_pose_regression (DFM_pose_refine.py:131-160) of the working (or given) network on the query image: [3,4]."""
@@ -504,11 +509,11 @@ class PoseRefiner:
                 self._apr_iteration()
             losses[i] = self.loss
             if verification and (i == 0 or i == iters - 1):
-                checks.append(self._verification())
+                checks.append(self._verification(as_tensors=True))        # (read after the loop: no host sync behind iteration 0)
         pose = self.predicted_pose()
         info = {"retreat": False}
         if verification and len(checks) == 2:
-            (p0, s0), (p1, s1) = checks
+            (p0, s0), (p1, s1) = [(float(a), float(b)) for a, b in checks]
             info = {"psnr": (p0, p1), "ssim": (s0, s1), "retreat": bool(p1 < p0) or bool(s1 < s0)}       # :242-250
             if info["retreat"]:
                 pose = first

@@ -482,3 +482,52 @@ def test_batch_norm_train_kernels_match_torch_in_float64(B, C, H, W, per_image):
     else:
         assert int(bn.num_batches_tracked) == 2
         assert rel(bn.running_mean.cpu().numpy(), bn64.running_mean.numpy()) < 1e-6 and rel(bn.running_var.cpu().numpy(), bn64.running_var.numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("C,H,W,crop", [(3, 240, 320, 10), (3, 60, 80, 0), (1, 4, 5, 0), (2, 9, 33, 1)])
+def test_psnr_ssim_kernels_equal_the_verification_steps_torch_expressions(C, H, W, crop):
+    """ops.psnr_ssim (csrc/refine.hip psnr_ssim_*: the verification step of train_on_batch, DFM_APR_refine.py:117-128, :146-150) against
+    mse2psnr(img2mse(x, y)) and SSIM()(x, y).mean() (utils/utils.py:15-49) -- the float64 value of the same expressions and torch's own
+    fp32 on the device -- on cropped VIEWS, which the kernel reads through their strides."""
+    from nefes_amd import ops
+    from nefes_amd.refine import ssim_map, mse2psnr, img2mse
+    g = torch.Generator().manual_seed(11)
+    base = torch.rand(1, C, H, W, generator=g)
+    other = (base + 0.1 * torch.randn(1, C, H, W, generator=g)).clamp(0, 1)
+    sl = (slice(None), slice(None), slice(crop, H - crop), slice(crop, W - crop)) if crop else (slice(None),) * 4
+    x, y = base.to(DEV)[sl], other.to(DEV)[sl]
+    ps, ss = ops.psnr_ssim(x[0], y[0])
+    x64, y64 = base.double()[sl], other.double()[sl]
+    ps64, ss64 = float(mse2psnr(img2mse(x64, y64))), float(ssim_map(x64, y64).mean())
+    ps32, ss32 = float(mse2psnr(img2mse(x, y))), float(ssim_map(x, y).mean())
+    assert abs(float(ps) - ps64) <= 2e-6 * abs(ps64) and abs(float(ss) - ss64) <= 2e-6, (float(ps), ps64, float(ss), ss64)
+    assert abs(float(ps) - ps32) <= 5e-6 * abs(ps32) and abs(float(ss) - ss32) <= 5e-6, (float(ps), ps32, float(ss), ss32)
+    if crop:                                           # the view was read in place: a contiguous copy gives the same bits
+        ps_c, ss_c = ops.psnr_ssim(x[0].contiguous(), y[0].contiguous())
+        assert torch.equal(ps, ps_c) and torch.equal(ss, ss_c)
+    same_p, same_s = ops.psnr_ssim(x[0], x[0])         # identical images: mse 0 -> psnr +inf (torch: -10 log(0) / log(10)), ssim 1
+    assert torch.isinf(same_p) and float(same_p) > 0 and abs(float(same_s) - 1.0) < 1e-6
+    with pytest.raises(RuntimeError, match="dense rows"):
+        ops.psnr_ssim(x[0][:, :, ::2], y[0][:, :, ::2])
+    with pytest.raises(RuntimeError, match="bad argument"):
+        ops.psnr_ssim(x[0][:, :3], y[0][:, :3])        # three rows: ReflectionPad2d(3) needs four
+
+
+def test_verification_step_through_the_kernels_equals_the_torch_expressions(golden):
+    """PoseRefiner._verification with FUSED_VERIFICATION on / off behind the same iterations of mode 2 (the refine50 fixture's scene):
+    PSNR and SSIM agree to fp32 rounding -- and with the reference's own numbers for that iteration (tests/test_gpu_refine50.py holds
+    every checked iteration to those)."""
+    from nefes_amd.refine import PoseRefiner
+    from tests.test_gpu_refine50 import TinyAPR, refiner, target_full
+    from tests.test_refine50_oracle import photo_of
+    g = golden("refine50")
+    ref = refiner(g, apr=TinyAPR(g["m2_weight"][0], g["m2_bias"][0]))
+    ref.refine_apr(photo_of(g), target_full(g), T(g["hist"]), iters=2, verification=False)
+    on = ref._verification()
+    try:
+        PoseRefiner.FUSED_VERIFICATION = False
+        off = ref._verification()
+    finally:
+        PoseRefiner.FUSED_VERIFICATION = True
+    assert abs(on[0] - off[0]) <= 5e-6 * abs(off[0]) and abs(on[1] - off[1]) <= 5e-6, (on, off)
+    assert abs(on[0] - g["m2_psnr"][0, 1]) < 2e-2 and abs(on[1] - g["m2_ssim"][0, 1]) < 2e-4, (on, g["m2_psnr"][0, 1], g["m2_ssim"][0, 1])
