@@ -1207,6 +1207,18 @@ def regressed_pose(pose, do_svd, world_setup=None):
     return RegressedPose.apply(pose, bool(do_svd), sc, mv)
 
 
+# Where the next feature-loss Function writes its value: PoseRefiner points this at its static loss buffer around its loss call, so that an
+# iteration needs no separate 4-byte copy kernel to leave the value there (None: a fresh tensor, as any other caller gets).
+LOSS_OUT = None
+
+
+def _loss_out(device):
+    t = LOSS_OUT
+    if t is not None and t.dim() == 0 and t.dtype == torch.float32 and t.device == torch.device(device) and not t.requires_grad:
+        return t.detach()          # (a new tensor object on the same storage: autograd attaches this call's history to it, not to the buffer)
+    return torch.empty((), device=device)
+
+
 class CosineFeatureLoss(torch.autograd.Function):
     """feature_loss (dm/DFM_pose_refine.py:211-233, per_pixel=False) on [C, ...] maps: 1 - mean over channels of the cosine
     similarity over pixels; two launches forward, one backward (to `a` only: the target carries no gradient)."""
@@ -1219,7 +1231,7 @@ class CosineFeatureLoss(torch.autograd.Function):
             raise ValueError(f"nefes_amd: feature maps of different shapes: {tuple(a.shape)} vs {tuple(b.shape)}")
         lib = L.load()
         scratch = torch.empty(lib.nefes_cosine_loss_scratch_doubles(Cc), dtype=torch.float64, device=af.device)
-        loss = torch.empty((), device=af.device)
+        loss = _loss_out(af.device)
         L.check(lib.nefes_cosine_loss_fwd(Cc, af.shape[1], _chk(af, "a"), _chk(bf, "b"), _chk(scratch, "scratch", torch.float64),
                                           _chk(loss, "loss"), _stream()), "nefes_cosine_loss_fwd")
         ctx.save_for_backward(af, bf, scratch)
@@ -1311,7 +1323,7 @@ class UpsampledCosineLoss(torch.autograd.Function):
         tf = _f32(target).reshape(Cc, OH - 2 * crop, OW - 2 * crop)
         lib = L.load()
         scratch = torch.empty(lib.nefes_cosine_loss_scratch_doubles(Cc), dtype=torch.float64, device=xf.device)
-        loss = torch.empty((), device=xf.device)
+        loss = _loss_out(xf.device)
         with _timed("upcos_loss_fwd"):
             L.check(lib.nefes_upcos_loss_fwd(Cc, h, w, OH, OW, crop, _chk(xf, "x"), _chk(tf, "target"), _chk(scratch, "scratch", torch.float64),
                                              _chk(loss, "loss"), _stream()), "nefes_upcos_loss_fwd")
@@ -1408,7 +1420,7 @@ class UpsampledCosineLossPrepared(torch.autograd.Function):
         lib = L.load()
         scratch = torch.empty(lib.nefes_cosine_loss_scratch_doubles(prep.C), dtype=torch.float64, device=xf.device)
         pmat = torch.empty(prep.C, prep.h, prep.w, dtype=torch.float64, device=xf.device)
-        loss = torch.empty((), device=xf.device)
+        loss = _loss_out(xf.device)
         with _timed("upcos_gram_fwd"):
             L.check(lib.nefes_upcos_gram_fwd(prep.C, prep.h, prep.w, _chk(xf, "x"), _chk(prep.tt, "tt", torch.float64),
                                              _chk(prep.dbb, "dbb", torch.float64), _chk(prep.gx, "gram_x", torch.float64),

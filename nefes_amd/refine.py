@@ -290,7 +290,7 @@ class PoseRefiner:
     def loss_and_grad(self):
         """Loss at the current (r, t) and its gradient, written into the parameters' static .grad buffers (no optimizer step).
         The gradients are copied over the previous ones: nothing has to be zeroed between iterations."""
-        loss, per_image = self._loss()
+        loss, per_image = self._loss_into_buffer()
         if getattr(self, "_one", None) is None or self._one.shape != loss.shape:
             self._one = torch.ones_like(loss)              # the root gradient, once: autograd otherwise fills a new one per iteration
         gr, gt = torch.autograd.grad(loss, [self.model.r, self.model.t], grad_outputs=self._one)
@@ -299,8 +299,18 @@ class PoseRefiner:
                 p.grad = torch.empty_like(p)
             if g.data_ptr() != p.grad.data_ptr():          # (the fused pose kernel writes the parameters' .grad itself)
                 p.grad.copy_(g)
-        self.loss.copy_(per_image)
+        if per_image.data_ptr() != self.loss.data_ptr():   # (the fused loss kernels wrote it there themselves: _loss_into_buffer)
+            self.loss.copy_(per_image)
         return self.loss
+
+    def _loss_into_buffer(self):
+        """self._loss() with the library's loss kernel writing its value straight into the static buffer self.loss (one image, fused glue):
+        no 4-byte copy launch per iteration.  Everything else (images=B, the torch expressions) returns its own tensor and is copied."""
+        ops.LOSS_OUT = self.loss if (self.B == 1 and self.fused_glue) else None
+        try:
+            return self._loss()
+        finally:
+            ops.LOSS_OUT = None
 
     def _iteration(self):
         self.loss_and_grad()
@@ -382,7 +392,7 @@ class PoseRefiner:
     # ---- train_on_batch / DFM_post_processing (pose_only=2) ------------------------------------------------------------
     def apr_loss_and_grad(self):
         """Loss at the working network's current parameters; gradients into their .grad (no optimizer step)."""
-        loss, _ = self._loss()
+        loss, _ = self._loss_into_buffer()
         params = [p for p in self.apr.parameters() if p.requires_grad]
         # loss.backward() in the reference (train_on_batch, DFM_pose_refine.py:318) tolerates parameters the loss never touches --
         # DFNet's adaptation_layers with return_feature=False (feature/dfnet.py:142): their .grad stays None and Adam skips them
@@ -390,7 +400,8 @@ class PoseRefiner:
             self._one = torch.ones_like(loss)              # the root gradient, once (as loss_and_grad does)
         for p, g in zip(params, torch.autograd.grad(loss, params, grad_outputs=self._one, allow_unused=True)):
             p.grad = g
-        self.loss.copy_(loss.detach())
+        if loss.data_ptr() != self.loss.data_ptr():
+            self.loss.copy_(loss.detach())
         return self.loss
 
     def _verification(self, as_tensors=False):
